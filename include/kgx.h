@@ -1,0 +1,138 @@
+/*
+ * kgx.h — C ABI of the MI355X-native population allele-count / inbreeding sweep.
+ *
+ * This is the drop-in boundary for the one hot path of kellerberrin/KGL_Gene that this
+ * repository accelerates.  The reference has no FFI of its own: analyses are
+ * C++ classes compiled into the executable behind `VirtualAnalysis`
+ * (kgl_app/kgl_package_analysis_virtual.h:20-55).  The C++ analysis classes shipped in
+ * kgl_gene_amd/csrc/host/ (GpuAlleleAnalysis, GpuInbreedAnalysis) implement that interface and
+ * call ONLY the functions declared here; tests and bench.py bind the same symbols via ctypes.
+ *
+ * Conventions
+ *   - plain pointers and sizes; no C++/torch types; caller owns every host buffer
+ *   - every function returning int returns 0 on success, a negative KGX_E* code on failure;
+ *     kgx_last_error() then holds a message (thread-local).  The C++ layer maps failure to
+ *     `return false` + log().error, the reference's error convention
+ *     (kgl_app/kgl_package_analysis.cpp:72-76).
+ *   - an opaque kgx_pop owns device memory for ONE genome shard on ONE device; functions are not
+ *     re-entrant per handle (the reference calls its analysis virtuals from a single thread,
+ *     kgl_app/kgl_package.cpp:41-75).
+ *   - "variant row" v: one distinct HGVS variant (locus × alt); biallelic ⇒ one row per locus.
+ *     Row order is the caller's; the reference's lexicographic-HGVS order
+ *     (kgl_variant_db_variant.cpp:17-30) is applied host-side by the C++ layer.
+ *   - dosage code per (genome, variant), 2 bits: 0 = (A,A) reference homozygous, 1 = (a,A)
+ *     heterozygous, 2 = (a,a) minor homozygous, 3 = non-diploid (>2 copies; the reference warns
+ *     and does not count it, kgl_variant_db_variant.cpp:158-161).
+ *   - there is NO CPU fallback: every compute entry point fails with KGX_ENODEVICE when no
+ *     gfx950 device is usable.
+ */
+#ifndef KGX_H
+#define KGX_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define KGX_OK          0
+#define KGX_EINVAL     -1   /* bad argument (null pointer, range, shape)            */
+#define KGX_ENODEVICE  -2   /* no usable HIP device / wrong architecture            */
+#define KGX_EHIP       -3   /* a HIP runtime call failed; see kgx_last_error()      */
+#define KGX_ENOMEM     -4   /* device or host allocation failed                     */
+#define KGX_ESTATE     -5   /* call order violated (e.g. genotypes not loaded)      */
+
+typedef struct kgx_pop kgx_pop;           /* 2-bit dosage population shard (K2/K3/K4/K8)      */
+typedef struct kgx_locus_set kgx_locus_set; /* sampled loci + per-locus allele tables (K5-K7)   */
+
+/* ---- library / device ------------------------------------------------------------------- */
+
+const char* kgx_version(void);
+const char* kgx_last_error(void);
+/* Number of visible HIP devices (0 if none / runtime unavailable). Never fails. */
+int kgx_device_count(void);
+/* Bind this process to `device` and create the library stream.  Must precede all other calls. */
+int kgx_init(int device);
+/* Device properties a caller needs for roofline reporting. */
+int kgx_device_info(char* name, size_t name_len, char* arch, size_t arch_len,
+                    int* compute_units, uint64_t* hbm_bytes);
+int kgx_synchronize(void);
+
+/* ---- population shard: replaces PopulationDB→VariantDBVariant (kgl_variant_db_variant.h:53-76)
+ *      D[g][v] uint8 rows become variant-major 2-bit rows in HBM.                                */
+
+/* n_genomes in THIS shard, n_variants rows.  Rows are zero (all reference-homozygous) after create. */
+kgx_pop* kgx_population_create(uint64_t n_genomes, uint64_t n_variants);
+void     kgx_population_destroy(kgx_pop* pop);
+uint64_t kgx_population_genomes(const kgx_pop* pop);
+uint64_t kgx_population_variants(const kgx_pop* pop);
+/* Device row pitch in bytes (multiple of 16; ceil(n_genomes/4) rounded up). */
+uint64_t kgx_population_row_pitch(const kgx_pop* pop);
+/* Algorithmic HBM bytes of one allele-count sweep: n_variants*ceil(n_genomes/4) + 16*n_variants. */
+uint64_t kgx_population_sweep_bytes(const kgx_pop* pop);
+
+/* Host → device, packed 2-bit rows [v0,v1): src row r at src + r*src_pitch, ceil(G/4) bytes used,
+ * genome g of the shard in bits (2*(g%4)) of byte g/4. */
+int kgx_population_load_dosage2(kgx_pop* pop, const uint8_t* src, uint64_t src_pitch,
+                                uint64_t v0, uint64_t v1);
+/* Host → device from the reference's own layout: VariantDBGenomeData rows, one uint8 dosage vector
+ * of n_variants per genome (kgl_variant_db_variant.h:49-51).  Genomes [g0,g1) of this shard;
+ * src row (g-g0) at src + (g-g0)*n_variants.  Dosage >2 is stored as code 3. Packed on device. */
+int kgx_population_load_dosage_u8(kgx_pop* pop, const uint8_t* src, uint64_t g0, uint64_t g1);
+/* Device → host copy of packed rows [v0,v1) with dst_pitch >= ceil(G/4) (tests). */
+int kgx_population_read_dosage2(const kgx_pop* pop, uint8_t* dst, uint64_t dst_pitch,
+                                uint64_t v0, uint64_t v1);
+/* Per-variant allele frequency as parsed from VCF INFO (float32, the reference's storage type,
+ * kgl_parser/kgl_variant_factory_vcf_parse_info.h:27-37); NaN = missing. */
+int kgx_population_set_af(kgx_pop* pop, const float* af /* [n_variants] */);
+int kgx_population_get_af(const kgx_pop* pop, float* af /* [n_variants] */);
+
+/* Fill the shard with the synthetic biallelic population of SURVEY.md §8(d) directly in HBM:
+ * Philox4x32-10 keyed by `seed`, AF[v] = float32(U[0.01,0.5]), genome (genome_base+g) has
+ * inbreeding F = -0.5 + 0.01*((genome_base+g) % 101), genotype drawn from the reference's
+ * Hardy-Weinberg-with-inbreeding class probabilities (kga_analysis_inbreed_freq.cpp:127-205,221-261).
+ * The host twin kgx_synth_biallelic_host() produces identical bits. */
+int kgx_population_synth_biallelic(kgx_pop* pop, uint64_t seed, uint64_t genome_base,
+                                   uint64_t variant_base);
+/* Host twin of the device generator (no device needed): packed rows [v0,v1) for genomes
+ * [genome_base, genome_base+n_genomes), dst_pitch bytes per row; af_out may be NULL. */
+int kgx_synth_biallelic_host(uint64_t seed, uint64_t genome_base, uint64_t n_genomes,
+                             uint64_t v0, uint64_t v1, uint8_t* dst, uint64_t dst_pitch,
+                             float* af_out);
+
+/* ---- K2: per-variant allele summary = VariantDBVariant::summaryByVariant for every variant
+ *      (kgl_variant_db_variant.cpp:126-178, caller kga_analysis_PfEMP_FWS.cpp:41-70).
+ *      out[v] = { referenceHomozygous, minorHeterozygous, minorHomozygous, nonDiploid } (uint32 each). */
+int kgx_allele_count_by_locus(kgx_pop* pop, uint32_t* out /* host [n_variants][4] */);
+/* Same, result left in device memory (caller's buffer, e.g. a torch tensor to all-reduce);
+ * launched on `stream` (a hipStream_t; NULL = the library stream), asynchronous. */
+int kgx_allele_count_by_locus_dev(kgx_pop* pop, void* d_out /* device [n_variants][4] u32 */,
+                                  void* stream);
+/* Epilogue on (all-reduced) device counts: af[v] = (het + 2*hom) / (2*total_genomes) in fp64. */
+int kgx_allele_frequency_dev(const void* d_counts /* device [n][4] u32 */, uint64_t n_variants,
+                             uint64_t total_genomes, void* d_af /* device [n] f64 */, void* stream);
+/* Timed repetition of the K2 launch with HIP events on the launch stream: per-iteration kernel
+ * durations (ms) into ms_each[iters].  d_out as above. */
+int kgx_allele_count_timed(kgx_pop* pop, void* d_out, void* stream, int warmup, int iters,
+                           float* ms_each);
+
+/* ---- K3: per-genome allele summary = VariantDBVariant::summaryByGenome for every genome
+ *      (kgl_variant_db_variant.cpp:180-231), restricted to variants with mask[v] != 0
+ *      (mask NULL = all): the FWS allele-frequency bins of kga_analysis_PfEMP_FWS.cpp:15-38,72-101.
+ *      out[g] = { referenceHomozygous, minorHeterozygous, minorHomozygous, nonDiploid } (uint64 each). */
+int kgx_count_by_genome(kgx_pop* pop, const uint8_t* variant_mask /* host [n_variants] or NULL */,
+                        uint64_t* out /* host [n_genomes][4] */);
+/* All bins in one call: bin_of_variant[v] in [0,n_bins) or 0xFF = in no bin.
+ * out[g][b] = 4 x uint64 as above. */
+int kgx_count_by_genome_binned(kgx_pop* pop, const uint8_t* bin_of_variant /* host [n_variants] */,
+                               uint32_t n_bins, uint64_t* out /* host [n_genomes][n_bins][4] */);
+
+/* ---- K4: VariantDBVariant::populationSummary (kgl_variant_db_variant.cpp:234-279). */
+int kgx_population_summary(kgx_pop* pop, uint64_t out[4]);
+
+#ifdef __cplusplus
+}
+#endif
+
+#endif /* KGX_H */

@@ -1,0 +1,267 @@
+"""ctypes binding of include/kgx.h — the same symbols the C++ analysis packages call.
+
+Loading fails loudly when libkgx.so is absent, and every compute call fails loudly (KgxError)
+when no gfx950 device is bound: there is no CPU fallback anywhere in this package.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import re
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parent.parent
+LIB_PATH = ROOT / "kgl_gene_amd" / "lib" / "libkgx.so"
+HEADER = ROOT / "include" / "kgx.h"
+
+KGX_OK, KGX_EINVAL, KGX_ENODEVICE, KGX_EHIP, KGX_ENOMEM, KGX_ESTATE = 0, -1, -2, -3, -4, -5
+
+
+class KgxError(RuntimeError):
+    def __init__(self, code: int, message: str):
+        super().__init__(f"kgx error {code}: {message}")
+        self.code = code
+
+
+_lib = None
+
+_u8p = C.POINTER(C.c_uint8)
+_u32p = C.POINTER(C.c_uint32)
+_u64p = C.POINTER(C.c_uint64)
+_f32p = C.POINTER(C.c_float)
+_f64p = C.POINTER(C.c_double)
+
+_SIGNATURES = {
+    "kgx_version": (C.c_char_p, []),
+    "kgx_last_error": (C.c_char_p, []),
+    "kgx_device_count": (C.c_int, []),
+    "kgx_init": (C.c_int, [C.c_int]),
+    "kgx_device_info": (C.c_int, [C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t, C.POINTER(C.c_int), _u64p]),
+    "kgx_synchronize": (C.c_int, []),
+    "kgx_population_create": (C.c_void_p, [C.c_uint64, C.c_uint64]),
+    "kgx_population_destroy": (None, [C.c_void_p]),
+    "kgx_population_genomes": (C.c_uint64, [C.c_void_p]),
+    "kgx_population_variants": (C.c_uint64, [C.c_void_p]),
+    "kgx_population_row_pitch": (C.c_uint64, [C.c_void_p]),
+    "kgx_population_sweep_bytes": (C.c_uint64, [C.c_void_p]),
+    "kgx_population_load_dosage2": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64]),
+    "kgx_population_load_dosage_u8": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64]),
+    "kgx_population_read_dosage2": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64]),
+    "kgx_population_set_af": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "kgx_population_get_af": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "kgx_population_synth_biallelic": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64]),
+    "kgx_synth_biallelic_host": (C.c_int, [C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64,
+                                           C.c_void_p, C.c_uint64, C.c_void_p]),
+    "kgx_allele_count_by_locus": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "kgx_allele_count_by_locus_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "kgx_allele_frequency_dev": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p, C.c_void_p]),
+    "kgx_allele_count_timed": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+    "kgx_count_by_genome": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "kgx_count_by_genome_binned": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]),
+    "kgx_population_summary": (C.c_int, [C.c_void_p, C.c_void_p]),
+}
+
+
+def declared_symbols() -> list[str]:
+    """Every function name include/kgx.h declares (parsed from the header itself)."""
+    text = HEADER.read_text()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(kgx_[a-z0-9_]+)\s*\(", text)))
+
+
+def lib() -> C.CDLL:
+    """Load libkgx.so (once).  Raises if the HIP extension has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not LIB_PATH.exists():
+        raise ImportError(
+            f"{LIB_PATH} is missing: build the HIP extension first "
+            f"(python -m kgl_gene_amd.build, or __graft_entry__.build()). There is no CPU fallback."
+        )
+    handle = C.CDLL(str(LIB_PATH))
+    for name, (restype, argtypes) in _SIGNATURES.items():
+        fn = getattr(handle, name)  # AttributeError here = header/library mismatch: fail loudly
+        fn.restype = restype
+        fn.argtypes = argtypes
+    _lib = handle
+    return _lib
+
+
+def check(rc: int) -> None:
+    if rc != KGX_OK:
+        raise KgxError(rc, lib().kgx_last_error().decode(errors="replace"))
+
+
+def ptr(a: np.ndarray) -> C.c_void_p:
+    return C.c_void_p(a.ctypes.data)
+
+
+def device_count() -> int:
+    return int(lib().kgx_device_count())
+
+
+def init(device: int = 0) -> None:
+    check(lib().kgx_init(int(device)))
+
+
+def device_info() -> dict:
+    name = C.create_string_buffer(128)
+    arch = C.create_string_buffer(64)
+    cus = C.c_int(0)
+    hbm = C.c_uint64(0)
+    check(lib().kgx_device_info(name, 128, arch, 64, C.byref(cus), C.byref(hbm)))
+    return {"name": name.value.decode(), "arch": arch.value.decode(), "compute_units": cus.value,
+            "hbm_bytes": hbm.value}
+
+
+def synchronize() -> None:
+    check(lib().kgx_synchronize())
+
+
+def synth_biallelic_host(seed: int, genome_base: int, n_genomes: int, v0: int, v1: int):
+    """Host twin of the device generator: (packed rows [v1-v0][ceil(G/4)] uint8, af float32)."""
+    row_bytes = (n_genomes + 3) // 4
+    rows = np.zeros((v1 - v0, row_bytes), dtype=np.uint8)
+    af = np.zeros(v1 - v0, dtype=np.float32)
+    check(lib().kgx_synth_biallelic_host(seed, genome_base, n_genomes, v0, v1, ptr(rows), row_bytes, ptr(af)))
+    return rows, af
+
+
+def unpack_dosage2(rows: np.ndarray, n_genomes: int) -> np.ndarray:
+    """[V][ceil(G/4)] packed bytes -> [V][G] uint8 codes (host helper for tests and flattening)."""
+    r = np.ascontiguousarray(rows, dtype=np.uint8)
+    out = np.empty((r.shape[0], r.shape[1] * 4), dtype=np.uint8)
+    for j in range(4):
+        out[:, j::4] = (r >> (2 * j)) & 3
+    return out[:, :n_genomes]
+
+
+def pack_dosage2(codes: np.ndarray) -> np.ndarray:
+    """[V][G] uint8 codes (0..3) -> [V][ceil(G/4)] packed bytes."""
+    c = np.ascontiguousarray(codes, dtype=np.uint8)
+    v, g = c.shape
+    pad = (-g) % 4
+    if pad:
+        c = np.concatenate([c, np.zeros((v, pad), dtype=np.uint8)], axis=1)
+    c = c.reshape(v, -1, 4)
+    return (c[:, :, 0] | (c[:, :, 1] << 2) | (c[:, :, 2] << 4) | (c[:, :, 3] << 6)).astype(np.uint8)
+
+
+class Population:
+    """One genome shard of a flattened PopulationDB resident in HBM (opaque kgx_pop)."""
+
+    def __init__(self, n_genomes: int, n_variants: int):
+        self._h = lib().kgx_population_create(int(n_genomes), int(n_variants))
+        if not self._h:
+            raise KgxError(KGX_EHIP, lib().kgx_last_error().decode(errors="replace"))
+        self.n_genomes = int(n_genomes)
+        self.n_variants = int(n_variants)
+
+    # -- lifetime ---------------------------------------------------------------------------
+    def close(self) -> None:
+        if getattr(self, "_h", None):
+            lib().kgx_population_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    @property
+    def handle(self):
+        return self._h
+
+    @property
+    def row_pitch(self) -> int:
+        return int(lib().kgx_population_row_pitch(self._h))
+
+    @property
+    def sweep_bytes(self) -> int:
+        return int(lib().kgx_population_sweep_bytes(self._h))
+
+    # -- loading ----------------------------------------------------------------------------
+    def load_dosage2(self, rows: np.ndarray, v0: int = 0) -> None:
+        rows = np.ascontiguousarray(rows, dtype=np.uint8)
+        check(lib().kgx_population_load_dosage2(self._h, ptr(rows), rows.shape[1], v0, v0 + rows.shape[0]))
+
+    def load_dosage_u8(self, dosage: np.ndarray, g0: int = 0) -> None:
+        """dosage: [n][n_variants] uint8, the reference's VariantDBGenomeData rows."""
+        d = np.ascontiguousarray(dosage, dtype=np.uint8)
+        if d.ndim != 2 or d.shape[1] != self.n_variants:
+            raise ValueError("dosage must be [genomes][n_variants]")
+        check(lib().kgx_population_load_dosage_u8(self._h, ptr(d), g0, g0 + d.shape[0]))
+
+    def read_dosage2(self, v0: int = 0, v1: int | None = None) -> np.ndarray:
+        v1 = self.n_variants if v1 is None else v1
+        out = np.zeros((v1 - v0, (self.n_genomes + 3) // 4), dtype=np.uint8)
+        check(lib().kgx_population_read_dosage2(self._h, ptr(out), out.shape[1], v0, v1))
+        return out
+
+    def set_af(self, af: np.ndarray) -> None:
+        a = np.ascontiguousarray(af, dtype=np.float32)
+        if a.shape != (self.n_variants,):
+            raise ValueError("af must be [n_variants]")
+        check(lib().kgx_population_set_af(self._h, ptr(a)))
+
+    def get_af(self) -> np.ndarray:
+        a = np.zeros(self.n_variants, dtype=np.float32)
+        check(lib().kgx_population_get_af(self._h, ptr(a)))
+        return a
+
+    def synth_biallelic(self, seed: int = 1111, genome_base: int = 0, variant_base: int = 0) -> None:
+        check(lib().kgx_population_synth_biallelic(self._h, seed, genome_base, variant_base))
+
+    # -- the sweeps -------------------------------------------------------------------------
+    def allele_count_by_locus(self) -> np.ndarray:
+        """[n_variants][4] uint32: refHom, het, minorHom, nonDiploid (summaryByVariant)."""
+        out = np.zeros((self.n_variants, 4), dtype=np.uint32)
+        check(lib().kgx_allele_count_by_locus(self._h, ptr(out)))
+        return out
+
+    def allele_count_by_locus_dev(self, d_out: int, stream: int = 0) -> None:
+        check(lib().kgx_allele_count_by_locus_dev(self._h, C.c_void_p(d_out), C.c_void_p(stream)))
+
+    def allele_count_timed(self, d_out: int, stream: int, warmup: int, iters: int) -> np.ndarray:
+        ms = np.zeros(iters, dtype=np.float32)
+        check(lib().kgx_allele_count_timed(self._h, C.c_void_p(d_out), C.c_void_p(stream), warmup, iters, ptr(ms)))
+        return ms
+
+    def count_by_genome(self, variant_mask: np.ndarray | None = None) -> np.ndarray:
+        """[n_genomes][4] uint64 (summaryByGenome), optionally over variants with mask != 0."""
+        out = np.zeros((self.n_genomes, 4), dtype=np.uint64)
+        if variant_mask is None:
+            check(lib().kgx_count_by_genome(self._h, None, ptr(out)))
+        else:
+            m = np.ascontiguousarray(variant_mask, dtype=np.uint8)
+            if m.shape != (self.n_variants,):
+                raise ValueError("variant_mask must be [n_variants]")
+            check(lib().kgx_count_by_genome(self._h, ptr(m), ptr(out)))
+        return out
+
+    def count_by_genome_binned(self, bin_of_variant: np.ndarray, n_bins: int) -> np.ndarray:
+        b = np.ascontiguousarray(bin_of_variant, dtype=np.uint8)
+        if b.shape != (self.n_variants,):
+            raise ValueError("bin_of_variant must be [n_variants]")
+        out = np.zeros((self.n_genomes, n_bins, 4), dtype=np.uint64)
+        check(lib().kgx_count_by_genome_binned(self._h, ptr(b), n_bins, ptr(out)))
+        return out
+
+    def population_summary(self) -> np.ndarray:
+        out = np.zeros(4, dtype=np.uint64)
+        check(lib().kgx_population_summary(self._h, ptr(out)))
+        return out
+
+
+def allele_frequency_dev(d_counts: int, n_variants: int, total_genomes: int, d_af: int, stream: int = 0) -> None:
+    check(lib().kgx_allele_frequency_dev(C.c_void_p(d_counts), n_variants, total_genomes, C.c_void_p(d_af),
+                                         C.c_void_p(stream)))

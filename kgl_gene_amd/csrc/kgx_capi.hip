@@ -1,0 +1,530 @@
+// C ABI (include/kgx.h) over the gfx950 kernels.  Owns device memory and the launch logic;
+// no CPU fallback exists: without a usable device every compute entry point fails.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/kgx.h"
+#include "kgx_kernels.h"
+#include "kgx_internal.h"
+
+namespace {
+
+thread_local std::string g_error;
+
+}  // namespace
+
+namespace kgx {
+
+State g_state;
+
+int fail(int code, const char* fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  g_error = buf;
+  return code;
+}
+
+int require_device() {
+  if (!g_state.ready) return fail(KGX_ENODEVICE, "kgx_init() has not succeeded: no gfx950 device bound (there is no CPU fallback)");
+  return KGX_OK;
+}
+
+uint32_t stream_grid(uint64_t work_items, uint32_t items_per_block) {
+  const uint64_t want = (work_items + items_per_block - 1) / items_per_block;
+  const uint64_t cap = static_cast<uint64_t>(g_state.compute_units) * 8u;
+  const uint64_t g = want < cap ? want : cap;
+  return static_cast<uint32_t>(g ? g : 1);
+}
+
+// Lanes cooperating on one row: smallest power of two covering the row's 16-byte chunks, <= 64.
+static int lanes_per_row(uint32_t chunks_per_row) {
+  int w = 1;
+  while (w < 64 && static_cast<uint32_t>(w) < chunks_per_row) w <<= 1;
+  return w;
+}
+
+template <int W, int U>
+static void launch_count(const kgx_pop* pop, kgx_v4u* d_out, hipStream_t stream) {
+  const uint64_t rows_per_iter = static_cast<uint64_t>(kWave / W) * U;
+  const uint64_t waves = (pop->n_variants + rows_per_iter - 1) / rows_per_iter;
+  const uint32_t grid = stream_grid(waves, kBlock / kWave);
+  hipLaunchKernelGGL((k_allele_count<W, U>), dim3(grid), dim3(kBlock), 0, stream,
+                     reinterpret_cast<const kgx_v4u*>(pop->d_rows), pop->chunks_per_row,
+                     pop->n_variants, static_cast<uint32_t>(pop->n_genomes), d_out);
+}
+
+int launch_allele_count(const kgx_pop* pop, void* d_out, hipStream_t stream) {
+  if (pop->n_variants == 0) return KGX_OK;
+  kgx_v4u* out = static_cast<kgx_v4u*>(d_out);
+  switch (lanes_per_row(pop->chunks_per_row)) {
+    case 1:  launch_count<1, 4>(pop, out, stream); break;
+    case 2:  launch_count<2, 4>(pop, out, stream); break;
+    case 4:  launch_count<4, 4>(pop, out, stream); break;
+    case 8:  launch_count<8, 4>(pop, out, stream); break;
+    case 16: launch_count<16, 4>(pop, out, stream); break;
+    case 32: launch_count<32, 4>(pop, out, stream); break;
+    default: launch_count<64, 4>(pop, out, stream); break;
+  }
+  KGX_HIP(hipGetLastError());
+  return KGX_OK;
+}
+
+int ensure_counts(kgx_pop* pop) {
+  if (!pop->d_counts && pop->n_variants) {
+    KGX_HIP_MEM(hipMalloc(&pop->d_counts, pop->n_variants * 16u));
+  }
+  return KGX_OK;
+}
+
+
+// ---- K3 host glue -----------------------------------------------------------------------------
+
+template <int W>
+static void launch_by_genome(const kgx_pop* pop, const uint32_t* d_index, const GenomeWork* d_work,
+                             uint32_t n_work, uint32_t n_bins, unsigned long long* d_acc) {
+  hipLaunchKernelGGL((k_count_by_genome<W>), dim3(n_work), dim3(kBlock), 0, g_state.stream,
+                     reinterpret_cast<const kgx_v4u*>(pop->d_rows), pop->chunks_per_row, pop->n_genomes,
+                     d_index, d_work, n_bins, d_acc);
+}
+
+static int count_by_genome_impl(kgx_pop* pop, const uint8_t* bin_of_variant, uint32_t n_bins, uint64_t* out) {
+  const uint64_t V = pop->n_variants, G = pop->n_genomes;
+  if (V > 0xFFFFFFFFull) return fail(KGX_EINVAL, "n_variants exceeds the 32-bit row index of the by-genome sweep");
+  // Selected rows grouped by bin (stable counting sort), so a workgroup only ever touches one bin.
+  std::vector<unsigned long long> rows_in_bin(n_bins, 0);
+  std::vector<uint64_t> offset(n_bins + 1, 0);
+  std::vector<uint32_t> index;
+  bool identity = false;
+  if (!bin_of_variant) {
+    rows_in_bin[0] = V;
+    offset[1] = V;
+    identity = true;
+  } else {
+    for (uint64_t v = 0; v < V; ++v)
+      if (bin_of_variant[v] < n_bins) ++rows_in_bin[bin_of_variant[v]];
+    for (uint32_t b = 0; b < n_bins; ++b) offset[b + 1] = offset[b] + rows_in_bin[b];
+    index.resize(offset[n_bins]);
+    std::vector<uint64_t> cursor(offset.begin(), offset.end() - 1);
+    for (uint64_t v = 0; v < V; ++v)
+      if (bin_of_variant[v] < n_bins) index[cursor[bin_of_variant[v]]++] = static_cast<uint32_t>(v);
+  }
+  const uint64_t selected = offset[n_bins];
+
+  const int W = lanes_per_row(pop->chunks_per_row);
+  const uint32_t n_cg = (pop->chunks_per_row + 63) / 64;
+  const uint64_t gran = static_cast<uint64_t>(64 / W) * (kBlock / kWave) * 8;
+  const uint64_t target = static_cast<uint64_t>(g_state.compute_units) * 10u;
+  uint64_t per_wg = (selected * n_cg + target - 1) / target;
+  per_wg = (per_wg + gran - 1) / gran * gran;
+  if (per_wg < gran * 4) per_wg = gran * 4;
+  std::vector<GenomeWork> work;
+  for (uint32_t b = 0; b < n_bins; ++b)
+    for (uint64_t p = offset[b]; p < offset[b + 1]; p += per_wg)
+      for (uint32_t cg = 0; cg < n_cg; ++cg) {
+        GenomeWork w;
+        w.begin = p;
+        w.end = (p + per_wg < offset[b + 1]) ? p + per_wg : offset[b + 1];
+        w.col_group = cg;
+        w.bin = b;
+        work.push_back(w);
+      }
+
+  const uint64_t cells = G * n_bins;
+  unsigned long long *d_acc = nullptr, *d_out = nullptr, *d_nbin = nullptr;
+  uint32_t* d_index = nullptr;
+  GenomeWork* d_work = nullptr;
+  int rc = KGX_OK;
+  auto cleanup = [&]() {
+    if (d_acc) (void)hipFree(d_acc);
+    if (d_out) (void)hipFree(d_out);
+    if (d_nbin) (void)hipFree(d_nbin);
+    if (d_index) (void)hipFree(d_index);
+    if (d_work) (void)hipFree(d_work);
+  };
+#define KGX_TRY(call, code, what)                                          \
+  if (rc == KGX_OK && (call) != hipSuccess) {                             \
+    (void)hipGetLastError();                                               \
+    rc = fail(code, "count_by_genome: %s failed", what);                   \
+  }
+  KGX_TRY(hipMalloc(&d_acc, cells * 3 * sizeof(unsigned long long)), KGX_ENOMEM, "hipMalloc(acc)");
+  KGX_TRY(hipMalloc(&d_out, cells * 4 * sizeof(unsigned long long)), KGX_ENOMEM, "hipMalloc(out)");
+  KGX_TRY(hipMalloc(&d_nbin, n_bins * sizeof(unsigned long long)), KGX_ENOMEM, "hipMalloc(rows_in_bin)");
+  KGX_TRY(hipMemsetAsync(d_acc, 0, cells * 3 * sizeof(unsigned long long), g_state.stream), KGX_EHIP, "memset(acc)");
+  KGX_TRY(hipMemcpyAsync(d_nbin, rows_in_bin.data(), n_bins * sizeof(unsigned long long), hipMemcpyHostToDevice,
+                         g_state.stream), KGX_EHIP, "H2D(rows_in_bin)");
+  if (rc == KGX_OK && !work.empty()) {
+    if (!identity) {
+      KGX_TRY(hipMalloc(&d_index, index.size() * sizeof(uint32_t)), KGX_ENOMEM, "hipMalloc(index)");
+      KGX_TRY(hipMemcpyAsync(d_index, index.data(), index.size() * sizeof(uint32_t), hipMemcpyHostToDevice,
+                             g_state.stream), KGX_EHIP, "H2D(index)");
+    }
+    KGX_TRY(hipMalloc(&d_work, work.size() * sizeof(GenomeWork)), KGX_ENOMEM, "hipMalloc(work)");
+    KGX_TRY(hipMemcpyAsync(d_work, work.data(), work.size() * sizeof(GenomeWork), hipMemcpyHostToDevice,
+                           g_state.stream), KGX_EHIP, "H2D(work)");
+    if (rc == KGX_OK) {
+      const uint32_t n_work = static_cast<uint32_t>(work.size());
+      switch (W) {
+        case 1:  launch_by_genome<1>(pop, d_index, d_work, n_work, n_bins, d_acc); break;
+        case 2:  launch_by_genome<2>(pop, d_index, d_work, n_work, n_bins, d_acc); break;
+        case 4:  launch_by_genome<4>(pop, d_index, d_work, n_work, n_bins, d_acc); break;
+        case 8:  launch_by_genome<8>(pop, d_index, d_work, n_work, n_bins, d_acc); break;
+        case 16: launch_by_genome<16>(pop, d_index, d_work, n_work, n_bins, d_acc); break;
+        case 32: launch_by_genome<32>(pop, d_index, d_work, n_work, n_bins, d_acc); break;
+        default: launch_by_genome<64>(pop, d_index, d_work, n_work, n_bins, d_acc); break;
+      }
+      KGX_TRY(hipGetLastError(), KGX_EHIP, "k_count_by_genome launch");
+    }
+  }
+  if (rc == KGX_OK) {
+    hipLaunchKernelGGL(k_finish_by_genome, dim3(stream_grid(cells, kBlock)), dim3(kBlock), 0, g_state.stream,
+                       d_acc, d_nbin, G, n_bins, d_out);
+    KGX_TRY(hipGetLastError(), KGX_EHIP, "k_finish_by_genome launch");
+    KGX_TRY(hipMemcpyAsync(out, d_out, cells * 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost, g_state.stream),
+            KGX_EHIP, "D2H(out)");
+    KGX_TRY(hipStreamSynchronize(g_state.stream), KGX_EHIP, "stream synchronize");
+  }
+#undef KGX_TRY
+  cleanup();
+  return rc;
+}
+
+}  // namespace kgx
+
+using namespace kgx;
+
+extern "C" {
+
+const char* kgx_version(void) { return "kgx 0.1.0 (gfx950)"; }
+
+const char* kgx_last_error(void) { return g_error.c_str(); }
+
+int kgx_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) {
+    (void)hipGetLastError();
+    return 0;
+  }
+  return n;
+}
+
+int kgx_init(int device) {
+  int n = kgx_device_count();
+  if (n <= 0) return fail(KGX_ENODEVICE, "no HIP device visible (there is no CPU fallback)");
+  if (device < 0 || device >= n) return fail(KGX_EINVAL, "device %d out of range [0,%d)", device, n);
+  KGX_HIP(hipSetDevice(device));
+  hipDeviceProp_t prop;
+  KGX_HIP(hipGetDeviceProperties(&prop, device));
+  if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+    return fail(KGX_ENODEVICE, "device %d is %s; this library is built for gfx950 only", device, prop.gcnArchName);
+  if (g_state.ready && g_state.device == device) return KGX_OK;
+  if (g_state.ready && g_state.stream) {
+    (void)hipStreamDestroy(g_state.stream);
+    g_state.stream = nullptr;
+  }
+  KGX_HIP(hipStreamCreateWithFlags(&g_state.stream, hipStreamNonBlocking));
+  g_state.device = device;
+  g_state.compute_units = prop.multiProcessorCount;
+  g_state.hbm_bytes = prop.totalGlobalMem;
+  std::snprintf(g_state.name, sizeof(g_state.name), "%s", prop.name);
+  std::snprintf(g_state.arch, sizeof(g_state.arch), "%s", prop.gcnArchName);
+  g_state.ready = true;
+  return KGX_OK;
+}
+
+int kgx_device_info(char* name, size_t name_len, char* arch, size_t arch_len, int* compute_units,
+                    uint64_t* hbm_bytes) {
+  if (int rc = require_device()) return rc;
+  if (name && name_len) std::snprintf(name, name_len, "%s", g_state.name);
+  if (arch && arch_len) std::snprintf(arch, arch_len, "%s", g_state.arch);
+  if (compute_units) *compute_units = g_state.compute_units;
+  if (hbm_bytes) *hbm_bytes = g_state.hbm_bytes;
+  return KGX_OK;
+}
+
+int kgx_synchronize(void) {
+  if (int rc = require_device()) return rc;
+  KGX_HIP(hipStreamSynchronize(g_state.stream));
+  KGX_HIP(hipDeviceSynchronize());
+  return KGX_OK;
+}
+
+kgx_pop* kgx_population_create(uint64_t n_genomes, uint64_t n_variants) {
+  if (require_device()) return nullptr;
+  if (n_genomes == 0 || n_genomes > (1ull << 31)) {
+    fail(KGX_EINVAL, "n_genomes %llu outside (0, 2^31] (uint32 per-variant counts)", (unsigned long long)n_genomes);
+    return nullptr;
+  }
+  kgx_pop* pop = new (std::nothrow) kgx_pop();
+  if (!pop) { fail(KGX_ENOMEM, "host allocation failed"); return nullptr; }
+  pop->n_genomes = n_genomes;
+  pop->n_variants = n_variants;
+  pop->row_bytes = (n_genomes + 3) / 4;
+  pop->pitch = (pop->row_bytes + 15) / 16 * 16;
+  pop->chunks_per_row = static_cast<uint32_t>(pop->pitch / 16);
+  const uint64_t bytes = pop->pitch * n_variants;
+  if (bytes) {
+    if (hipMalloc(&pop->d_rows, bytes) != hipSuccess) {
+      (void)hipGetLastError();
+      fail(KGX_ENOMEM, "hipMalloc of %llu bytes for %llu x %llu dosage rows failed",
+           (unsigned long long)bytes, (unsigned long long)n_variants, (unsigned long long)n_genomes);
+      delete pop;
+      return nullptr;
+    }
+    if (hipMemsetAsync(pop->d_rows, 0, bytes, g_state.stream) != hipSuccess ||
+        hipStreamSynchronize(g_state.stream) != hipSuccess) {
+      fail(KGX_EHIP, "hipMemset of dosage rows failed");
+      (void)hipFree(pop->d_rows);
+      delete pop;
+      return nullptr;
+    }
+  }
+  return pop;
+}
+
+void kgx_population_destroy(kgx_pop* pop) {
+  if (!pop) return;
+  if (pop->d_rows) (void)hipFree(pop->d_rows);
+  if (pop->d_af) (void)hipFree(pop->d_af);
+  if (pop->d_counts) (void)hipFree(pop->d_counts);
+  delete pop;
+}
+
+uint64_t kgx_population_genomes(const kgx_pop* pop) { return pop ? pop->n_genomes : 0; }
+uint64_t kgx_population_variants(const kgx_pop* pop) { return pop ? pop->n_variants : 0; }
+uint64_t kgx_population_row_pitch(const kgx_pop* pop) { return pop ? pop->pitch : 0; }
+uint64_t kgx_population_sweep_bytes(const kgx_pop* pop) {
+  return pop ? pop->n_variants * pop->row_bytes + 16u * pop->n_variants : 0;
+}
+
+int kgx_population_load_dosage2(kgx_pop* pop, const uint8_t* src, uint64_t src_pitch, uint64_t v0,
+                                uint64_t v1) {
+  if (int rc = require_device()) return rc;
+  if (!pop || !src) return fail(KGX_EINVAL, "null population or source");
+  if (v0 > v1 || v1 > pop->n_variants) return fail(KGX_EINVAL, "variant range [%llu,%llu) outside [0,%llu)",
+      (unsigned long long)v0, (unsigned long long)v1, (unsigned long long)pop->n_variants);
+  if (src_pitch < pop->row_bytes) return fail(KGX_EINVAL, "src_pitch %llu < row bytes %llu",
+      (unsigned long long)src_pitch, (unsigned long long)pop->row_bytes);
+  if (v0 == v1) return KGX_OK;
+  KGX_HIP(hipMemcpy2DAsync(pop->d_rows + v0 * pop->pitch, pop->pitch, src, src_pitch, pop->row_bytes,
+                           v1 - v0, hipMemcpyHostToDevice, g_state.stream));
+  const uint64_t touched = (v1 - v0) * (pop->pitch - pop->row_bytes + 1);
+  hipLaunchKernelGGL(k_mask_row_tail, dim3(stream_grid(touched, kBlock)), dim3(kBlock), 0, g_state.stream,
+                     pop->d_rows, pop->pitch, pop->n_genomes, v0, v1);
+  KGX_HIP(hipGetLastError());
+  KGX_HIP(hipStreamSynchronize(g_state.stream));
+  return KGX_OK;
+}
+
+int kgx_population_load_dosage_u8(kgx_pop* pop, const uint8_t* src, uint64_t g0, uint64_t g1) {
+  if (int rc = require_device()) return rc;
+  if (!pop || !src) return fail(KGX_EINVAL, "null population or source");
+  if (g0 > g1 || g1 > pop->n_genomes) return fail(KGX_EINVAL, "genome range [%llu,%llu) outside [0,%llu)",
+      (unsigned long long)g0, (unsigned long long)g1, (unsigned long long)pop->n_genomes);
+  if (g0 & 3u) return fail(KGX_EINVAL, "g0 must be a multiple of 4 (whole packed bytes)");
+  if ((g1 & 3u) && g1 != pop->n_genomes) return fail(KGX_EINVAL, "g1 must be a multiple of 4 or n_genomes");
+  if (g0 == g1 || pop->n_variants == 0) return KGX_OK;
+  // Stage in slabs of genomes so the staging buffer stays bounded (<= 1 GiB).
+  const uint64_t V = pop->n_variants;
+  uint64_t slab = (1ull << 30) / V;
+  slab = slab / 4 * 4;
+  if (slab < 4) slab = 4;
+  uint8_t* d_stage = nullptr;
+  const uint64_t max_rows = (g1 - g0) < slab ? (g1 - g0) : slab;
+  KGX_HIP_MEM(hipMalloc(&d_stage, max_rows * V));
+  int rc = KGX_OK;
+  for (uint64_t g = g0; g < g1 && rc == KGX_OK; g += slab) {
+    const uint64_t n = (g1 - g) < slab ? (g1 - g) : slab;
+    if (hipMemcpyAsync(d_stage, src + (g - g0) * V, n * V, hipMemcpyHostToDevice, g_state.stream) != hipSuccess) {
+      rc = fail(KGX_EHIP, "H2D copy of dosage rows failed");
+      break;
+    }
+    const uint64_t work = (n + 3) / 4 * V;
+    hipLaunchKernelGGL(k_pack_dosage_u8, dim3(stream_grid(work, kBlock)), dim3(kBlock), 0, g_state.stream,
+                       d_stage, n, V, g, pop->d_rows, pop->pitch);
+    if (hipGetLastError() != hipSuccess || hipStreamSynchronize(g_state.stream) != hipSuccess)
+      rc = fail(KGX_EHIP, "dosage pack kernel failed");
+  }
+  (void)hipFree(d_stage);
+  return rc;
+}
+
+int kgx_population_read_dosage2(const kgx_pop* pop, uint8_t* dst, uint64_t dst_pitch, uint64_t v0,
+                                uint64_t v1) {
+  if (int rc = require_device()) return rc;
+  if (!pop || !dst) return fail(KGX_EINVAL, "null population or destination");
+  if (v0 > v1 || v1 > pop->n_variants) return fail(KGX_EINVAL, "variant range out of bounds");
+  if (dst_pitch < pop->row_bytes) return fail(KGX_EINVAL, "dst_pitch too small");
+  if (v0 == v1) return KGX_OK;
+  KGX_HIP(hipMemcpy2DAsync(dst, dst_pitch, pop->d_rows + v0 * pop->pitch, pop->pitch, pop->row_bytes,
+                           v1 - v0, hipMemcpyDeviceToHost, g_state.stream));
+  KGX_HIP(hipStreamSynchronize(g_state.stream));
+  return KGX_OK;
+}
+
+static int ensure_af(kgx_pop* pop) {
+  if (!pop->d_af && pop->n_variants) KGX_HIP_MEM(hipMalloc(&pop->d_af, pop->n_variants * sizeof(float)));
+  return KGX_OK;
+}
+
+int kgx_population_set_af(kgx_pop* pop, const float* af) {
+  if (int rc = require_device()) return rc;
+  if (!pop || !af) return fail(KGX_EINVAL, "null population or af");
+  if (int rc = ensure_af(pop)) return rc;
+  if (pop->n_variants) {
+    KGX_HIP(hipMemcpyAsync(pop->d_af, af, pop->n_variants * sizeof(float), hipMemcpyHostToDevice, g_state.stream));
+    KGX_HIP(hipStreamSynchronize(g_state.stream));
+  }
+  pop->has_af = true;
+  return KGX_OK;
+}
+
+int kgx_population_get_af(const kgx_pop* pop, float* af) {
+  if (int rc = require_device()) return rc;
+  if (!pop || !af) return fail(KGX_EINVAL, "null population or af");
+  if (!pop->has_af) return fail(KGX_ESTATE, "allele frequencies were never set");
+  if (pop->n_variants) {
+    KGX_HIP(hipMemcpyAsync(af, pop->d_af, pop->n_variants * sizeof(float), hipMemcpyDeviceToHost, g_state.stream));
+    KGX_HIP(hipStreamSynchronize(g_state.stream));
+  }
+  return KGX_OK;
+}
+
+int kgx_population_synth_biallelic(kgx_pop* pop, uint64_t seed, uint64_t genome_base, uint64_t variant_base) {
+  if (int rc = require_device()) return rc;
+  if (!pop) return fail(KGX_EINVAL, "null population");
+  if (int rc = ensure_af(pop)) return rc;
+  if (pop->n_variants == 0) return KGX_OK;
+  const uint64_t chunks = pop->n_variants * pop->chunks_per_row;
+  hipLaunchKernelGGL(k_synth_biallelic, dim3(stream_grid(chunks, kBlock)), dim3(kBlock), 0, g_state.stream,
+                     reinterpret_cast<kgx_v4u*>(pop->d_rows), pop->chunks_per_row, pop->n_variants,
+                     pop->n_genomes, seed, genome_base, variant_base, pop->d_af);
+  KGX_HIP(hipGetLastError());
+  KGX_HIP(hipStreamSynchronize(g_state.stream));
+  pop->has_af = true;
+  return KGX_OK;
+}
+
+int kgx_synth_biallelic_host(uint64_t seed, uint64_t genome_base, uint64_t n_genomes, uint64_t v0,
+                             uint64_t v1, uint8_t* dst, uint64_t dst_pitch, float* af_out) {
+  if (!dst) return fail(KGX_EINVAL, "null destination");
+  const uint64_t row_bytes = (n_genomes + 3) / 4;
+  if (v0 > v1 || dst_pitch < row_bytes) return fail(KGX_EINVAL, "bad range or pitch");
+  for (uint64_t v = v0; v < v1; ++v) {
+    const float af = kgx_synth_af(seed, v);
+    if (af_out) af_out[v - v0] = af;
+    const double p = static_cast<double>(af);
+    uint8_t* row = dst + (v - v0) * dst_pitch;
+    std::memset(row, 0, dst_pitch);
+    for (uint64_t g = 0; g < n_genomes; ++g)
+      row[g >> 2] |= static_cast<uint8_t>(kgx_synth_dosage(seed, v, genome_base + g, p) << (2 * (g & 3u)));
+  }
+  return KGX_OK;
+}
+
+int kgx_allele_count_by_locus_dev(kgx_pop* pop, void* d_out, void* stream) {
+  if (int rc = require_device()) return rc;
+  if (!pop || !d_out) return fail(KGX_EINVAL, "null population or output");
+  hipStream_t s = stream ? static_cast<hipStream_t>(stream) : g_state.stream;
+  return launch_allele_count(pop, d_out, s);
+}
+
+int kgx_allele_count_by_locus(kgx_pop* pop, uint32_t* out) {
+  if (int rc = require_device()) return rc;
+  if (!pop || !out) return fail(KGX_EINVAL, "null population or output");
+  if (pop->n_variants == 0) return KGX_OK;
+  if (int rc = ensure_counts(pop)) return rc;
+  if (int rc = launch_allele_count(pop, pop->d_counts, g_state.stream)) return rc;
+  KGX_HIP(hipMemcpyAsync(out, pop->d_counts, pop->n_variants * 16u, hipMemcpyDeviceToHost, g_state.stream));
+  KGX_HIP(hipStreamSynchronize(g_state.stream));
+  return KGX_OK;
+}
+
+int kgx_allele_frequency_dev(const void* d_counts, uint64_t n_variants, uint64_t total_genomes, void* d_af,
+                             void* stream) {
+  if (int rc = require_device()) return rc;
+  if (!d_counts || !d_af) return fail(KGX_EINVAL, "null device pointer");
+  if (total_genomes == 0) return fail(KGX_EINVAL, "total_genomes must be > 0");
+  if (n_variants == 0) return KGX_OK;
+  hipStream_t s = stream ? static_cast<hipStream_t>(stream) : g_state.stream;
+  hipLaunchKernelGGL(k_allele_frequency, dim3(stream_grid(n_variants, kBlock)), dim3(kBlock), 0, s,
+                     static_cast<const kgx_v4u*>(d_counts), n_variants, total_genomes, static_cast<double*>(d_af));
+  KGX_HIP(hipGetLastError());
+  return KGX_OK;
+}
+
+int kgx_allele_count_timed(kgx_pop* pop, void* d_out, void* stream, int warmup, int iters, float* ms_each) {
+  if (int rc = require_device()) return rc;
+  if (!pop || !d_out || !ms_each || iters <= 0 || warmup < 0) return fail(KGX_EINVAL, "bad arguments");
+  hipStream_t s = stream ? static_cast<hipStream_t>(stream) : g_state.stream;
+  for (int i = 0; i < warmup; ++i)
+    if (int rc = launch_allele_count(pop, d_out, s)) return rc;
+  std::vector<hipEvent_t> ev(2 * static_cast<size_t>(iters));
+  for (auto& e : ev) KGX_HIP(hipEventCreate(&e));
+  int rc = KGX_OK;
+  for (int i = 0; i < iters && rc == KGX_OK; ++i) {
+    if (hipEventRecord(ev[2 * i], s) != hipSuccess) { rc = fail(KGX_EHIP, "hipEventRecord failed"); break; }
+    rc = launch_allele_count(pop, d_out, s);
+    if (rc == KGX_OK && hipEventRecord(ev[2 * i + 1], s) != hipSuccess) rc = fail(KGX_EHIP, "hipEventRecord failed");
+  }
+  if (rc == KGX_OK && hipStreamSynchronize(s) != hipSuccess) rc = fail(KGX_EHIP, "stream synchronize failed");
+  for (int i = 0; i < iters && rc == KGX_OK; ++i)
+    if (hipEventElapsedTime(&ms_each[i], ev[2 * i], ev[2 * i + 1]) != hipSuccess)
+      rc = fail(KGX_EHIP, "hipEventElapsedTime failed");
+  for (auto& e : ev) (void)hipEventDestroy(e);
+  return rc;
+}
+
+int kgx_population_summary(kgx_pop* pop, uint64_t out[4]) {
+  if (int rc = require_device()) return rc;
+  if (!pop || !out) return fail(KGX_EINVAL, "null population or output");
+  out[0] = out[1] = out[2] = out[3] = 0;
+  if (pop->n_variants == 0) return KGX_OK;
+  if (int rc = ensure_counts(pop)) return rc;
+  if (int rc = launch_allele_count(pop, pop->d_counts, g_state.stream)) return rc;
+  unsigned long long* d_total = nullptr;
+  KGX_HIP_MEM(hipMalloc(&d_total, 4 * sizeof(unsigned long long)));
+  int rc = KGX_OK;
+  if (hipMemsetAsync(d_total, 0, 4 * sizeof(unsigned long long), g_state.stream) != hipSuccess) rc = fail(KGX_EHIP, "memset failed");
+  if (rc == KGX_OK) {
+    hipLaunchKernelGGL(k_sum_counts, dim3(stream_grid(pop->n_variants, kBlock)), dim3(kBlock), 0, g_state.stream,
+                       static_cast<const kgx_v4u*>(pop->d_counts), pop->n_variants, d_total);
+    unsigned long long h[4];
+    if (hipGetLastError() != hipSuccess ||
+        hipMemcpyAsync(h, d_total, sizeof(h), hipMemcpyDeviceToHost, g_state.stream) != hipSuccess ||
+        hipStreamSynchronize(g_state.stream) != hipSuccess) {
+      rc = fail(KGX_EHIP, "population summary reduction failed");
+    } else {
+      for (int j = 0; j < 4; ++j) out[j] = h[j];
+    }
+  }
+  (void)hipFree(d_total);
+  return rc;
+}
+
+int kgx_count_by_genome(kgx_pop* pop, const uint8_t* variant_mask, uint64_t* out) {
+  if (int rc = require_device()) return rc;
+  if (!pop || !out) return fail(KGX_EINVAL, "null population or output");
+  if (!variant_mask) return count_by_genome_impl(pop, nullptr, 1, out);
+  std::vector<uint8_t> bins(pop->n_variants);
+  for (uint64_t v = 0; v < pop->n_variants; ++v) bins[v] = variant_mask[v] ? 0 : 0xFF;
+  return count_by_genome_impl(pop, bins.data(), 1, out);
+}
+
+int kgx_count_by_genome_binned(kgx_pop* pop, const uint8_t* bin_of_variant, uint32_t n_bins, uint64_t* out) {
+  if (int rc = require_device()) return rc;
+  if (!pop || !out || !bin_of_variant) return fail(KGX_EINVAL, "null population, bins or output");
+  if (n_bins == 0 || n_bins > 254) return fail(KGX_EINVAL, "n_bins %u outside [1,254]", n_bins);
+  return count_by_genome_impl(pop, bin_of_variant, n_bins, out);
+}
+
+}  // extern "C"

@@ -1,0 +1,62 @@
+// Internal declarations shared by the C-ABI translation units.
+#ifndef KGX_INTERNAL_H
+#define KGX_INTERNAL_H
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+struct kgx_pop {
+  uint64_t n_genomes = 0;        // genomes in this shard
+  uint64_t n_variants = 0;       // variant rows
+  uint64_t row_bytes = 0;        // ceil(n_genomes / 4): algorithmic bytes per row
+  uint64_t pitch = 0;            // device row pitch, multiple of 16
+  uint32_t chunks_per_row = 0;   // pitch / 16
+  uint8_t* d_rows = nullptr;     // [n_variants][pitch] dosage2
+  float* d_af = nullptr;         // [n_variants] INFO allele frequency (float32, NaN = missing)
+  void* d_counts = nullptr;      // [n_variants][4] u32 scratch for the host-returning entry points
+  bool has_af = false;
+};
+
+namespace kgx {
+
+struct State {
+  bool ready = false;
+  int device = -1;
+  int compute_units = 0;
+  uint64_t hbm_bytes = 0;
+  hipStream_t stream = nullptr;
+  char name[128] = {0};
+  char arch[64] = {0};
+};
+
+extern State g_state;
+
+int fail(int code, const char* fmt, ...) __attribute__((format(printf, 2, 3)));
+int require_device();
+uint32_t stream_grid(uint64_t work_items, uint32_t items_per_block);
+int launch_allele_count(const kgx_pop* pop, void* d_out, hipStream_t stream);
+int ensure_counts(kgx_pop* pop);
+
+}  // namespace kgx
+
+#define KGX_HIP(call)                                                                             \
+  do {                                                                                            \
+    hipError_t kgx_err_ = (call);                                                                 \
+    if (kgx_err_ != hipSuccess) {                                                                 \
+      (void)hipGetLastError();                                                                    \
+      return ::kgx::fail(KGX_EHIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(kgx_err_),  \
+                         __FILE__, __LINE__);                                                     \
+    }                                                                                             \
+  } while (0)
+
+#define KGX_HIP_MEM(call)                                                                         \
+  do {                                                                                            \
+    hipError_t kgx_err_ = (call);                                                                 \
+    if (kgx_err_ != hipSuccess) {                                                                 \
+      (void)hipGetLastError();                                                                    \
+      return ::kgx::fail(KGX_ENOMEM, "%s failed: %s (%s:%d)", #call, hipGetErrorString(kgx_err_), \
+                         __FILE__, __LINE__);                                                     \
+    }                                                                                             \
+  } while (0)
+
+#endif  // KGX_INTERNAL_H
