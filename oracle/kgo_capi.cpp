@@ -1,0 +1,543 @@
+// ORACLE — TEST INFRASTRUCTURE ONLY.  PARITY UNPINNED (see kgo_core.h).
+// extern "C" surface so tests/ (ctypes) can drive the restatement.  Nothing in the product links this.
+#include <chrono>
+#include <cstring>
+#include <sstream>
+
+#include "kgo_analysis.h"
+#include "kgo_inbreed.h"
+
+using namespace kgo;
+
+struct kgo_pop {
+  std::shared_ptr<PopulationDB> pop;
+  std::vector<std::string> input_ids;   // genome ids in the caller's order
+  uint64_t next_record = 0;
+};
+
+struct kgo_vdb {
+  std::shared_ptr<const PopulationDB> pop;
+  std::unique_ptr<VariantDBVariant> vdb;
+};
+
+struct kgo_columns {
+  std::vector<std::pair<std::string, ResultsMap>> columns;
+  std::vector<std::string> genome_order;
+};
+
+static void copyString(const std::string& s, char* buf, size_t len) {
+  if (!buf || !len) return;
+  const size_t n = std::min(len - 1, s.size());
+  std::memcpy(buf, s.data(), n);
+  buf[n] = 0;
+}
+
+static void fillResults(const LocusResults& r, uint64_t* counts, double* freqs) {
+  counts[0] = r.major_hetero_count;
+  counts[1] = r.minor_hetero_count;
+  counts[2] = r.minor_homo_count;
+  counts[3] = r.major_homo_count;
+  counts[4] = r.total_allele_count;
+  freqs[0] = r.major_hetero_freq;
+  freqs[1] = r.minor_hetero_freq;
+  freqs[2] = r.minor_homo_freq;
+  freqs[3] = r.major_homo_freq;
+  freqs[4] = r.inbred_allele_sum;
+}
+
+extern "C" {
+
+const char* kgo_banner(void) { return "kgo oracle: CPU restatement of the KGL_Gene hot path; TEST INFRASTRUCTURE; parity unpinned"; }
+
+void kgo_set_threads(int n) { setThreadOverride(n > 0 ? static_cast<size_t>(n) : 0); }
+int kgo_default_threads(void) { return static_cast<int>(WorkflowThreads::defaultThreads()); }
+int kgo_pool_threads(uint64_t jobs) { return static_cast<int>(poolThreads(jobs)); }
+
+kgo_pop* kgo_population_create(const char* id) {
+  auto* p = new kgo_pop();
+  p->pop = std::make_shared<PopulationDB>(id ? id : "population");
+  return p;
+}
+
+void kgo_population_destroy(kgo_pop* p) { delete p; }
+
+// PfVCFImpl::setupPopulationStructure (kgl_variant_factory_pf_impl.cpp:399-425): genomes exist even if
+// they carry no variant.  Also fixes the caller's genome order for index-mapped outputs.
+int kgo_population_add_genomes(kgo_pop* p, uint64_t n, const char* const* ids, int precreate) {
+  if (!p || !ids) return -1;
+  for (uint64_t i = 0; i < n; ++i) {
+    p->input_ids.emplace_back(ids[i]);
+    if (precreate) p->pop->getCreateGenome(ids[i]);
+  }
+  return 0;
+}
+
+// Expand VCF-like records into Variant objects the way the reference's parsers do.
+//  mode 0: Genome1000VCFImpl::ParseRecord (kgl_variant_factory_1000_impl.cpp:63-145,274-318): per record one
+//          shared Variant per (alt, phase); all phase-A variants are added before phase-B ones.
+//  mode 1: PfVCFImpl (kgl_variant_factory_pf_impl.cpp:287-384,427-455): per genome, per allele copy, a fresh
+//          UNPHASED Variant; A allele before B allele.
+//  mode 2: reference mono-genome (gnomAD-style, no genotypes): every alt added once, UNPHASED, to genome_ids[0].
+// gt: [n_records][n_genomes][2] allele indices (0 = reference); ignored for mode 2.
+// af_flat: [sum(n_alts)][6] float32 (NaN = missing) or NULL (no AF INFO at all).
+int kgo_population_add_records(kgo_pop* p, int mode, const char* contig, uint64_t n_records, const uint64_t* offsets,
+                               const char* const* refs, const uint8_t* n_alts, const char* const* alts_flat,
+                               const uint8_t* pass, const float* af_flat, uint64_t n_genomes,
+                               const char* const* genome_ids, const uint8_t* gt) {
+  if (!p || !contig || !offsets || !refs || !n_alts || !alts_flat) return -1;
+  uint64_t alt_cursor = 0;
+  const std::string contig_id(contig);
+  for (uint64_t r = 0; r < n_records; ++r) {
+    const uint32_t A = n_alts[r];
+    auto ev = std::make_shared<RecordEvidence>();
+    ev->record_index = p->next_record++;
+    ev->pass = pass ? pass[r] != 0 : true;
+    ev->alt_count = A;
+    if (af_flat) {
+      ev->af.resize(static_cast<size_t>(SUPER_POP_COUNT) * A);
+      for (uint32_t a = 0; a < A; ++a)
+        for (int sp = 0; sp < SUPER_POP_COUNT; ++sp)
+          ev->af[static_cast<size_t>(sp) * A + a] = af_flat[(alt_cursor + a) * SUPER_POP_COUNT + sp];
+    }
+    const std::string ref(refs[r]);
+    if (mode == 2) {
+      if (n_genomes < 1) return -1;
+      std::vector<std::string> gv{genome_ids[0]};
+      for (uint32_t a = 0; a < A; ++a)
+        p->pop->addVariant(std::make_shared<const Variant>(contig_id, offsets[r], VariantPhase::UNPHASED, ref,
+                                                          alts_flat[alt_cursor + a], ev, a), gv);
+    } else if (mode == 0) {
+      for (int phase = 0; phase < 2; ++phase) {
+        std::map<size_t, std::vector<std::string>> phase_map;
+        for (uint64_t g = 0; g < n_genomes; ++g) {
+          const uint32_t idx = gt[(r * n_genomes + g) * 2 + phase];
+          if (idx != 0 && idx <= A) phase_map[idx - 1].push_back(genome_ids[g]);
+        }
+        for (const auto& [alt_allele, genome_vector] : phase_map) {
+          auto v = std::make_shared<const Variant>(contig_id, offsets[r],
+                                                   phase == 0 ? VariantPhase::DIPLOID_PHASE_A : VariantPhase::DIPLOID_PHASE_B,
+                                                   ref, alts_flat[alt_cursor + alt_allele], ev, static_cast<uint32_t>(alt_allele));
+          p->pop->addVariant(v, genome_vector);
+        }
+      }
+    } else if (mode == 1) {
+      for (uint64_t g = 0; g < n_genomes; ++g) {
+        std::vector<std::string> gv{genome_ids[g]};
+        for (int copy = 0; copy < 2; ++copy) {
+          const uint32_t idx = gt[(r * n_genomes + g) * 2 + copy];
+          if (idx != 0 && idx <= A)
+            p->pop->addVariant(std::make_shared<const Variant>(contig_id, offsets[r], VariantPhase::UNPHASED, ref,
+                                                              alts_flat[alt_cursor + idx - 1], ev, idx - 1), gv);
+        }
+      }
+    } else {
+      return -1;
+    }
+    alt_cursor += A;
+  }
+  return 0;
+}
+
+uint64_t kgo_population_variant_count(kgo_pop* p) { return p ? p->pop->variantCount() : 0; }
+uint64_t kgo_population_genome_count(kgo_pop* p) { return p ? p->pop->getMap().size() : 0; }
+
+// Sorted (std::map) genome order -> index into the caller's id list; -1 if the id was never declared.
+int kgo_population_genome_order(kgo_pop* p, int64_t* input_index) {
+  if (!p || !input_index) return -1;
+  std::map<std::string, int64_t> pos;
+  for (size_t i = 0; i < p->input_ids.size(); ++i) pos.emplace(p->input_ids[i], static_cast<int64_t>(i));
+  size_t k = 0;
+  for (const auto& [id, g] : p->pop->getMap()) {
+    auto it = pos.find(id);
+    input_index[k++] = it == pos.end() ? -1 : it->second;
+  }
+  return 0;
+}
+
+// PopulationDB::viewFilter(AndFilter(SNPFilter(), PassFilter())) (kga_analysis_inbreed.cpp:79).
+kgo_pop* kgo_population_filter_snp_pass(kgo_pop* p) {
+  if (!p) return nullptr;
+  auto* out = new kgo_pop();
+  out->pop = std::shared_ptr<PopulationDB>(p->pop->viewFilter([](const Variant& v) { return v.isSNP() && v.passFilter(); }));
+  out->input_ids = p->input_ids;
+  return out;
+}
+
+// ---- VariantDBVariant --------------------------------------------------------------------------
+
+kgo_vdb* kgo_vdb_create(kgo_pop* p, double* seconds) {
+  if (!p) return nullptr;
+  auto* h = new kgo_vdb();
+  h->pop = p->pop;
+  const auto t0 = std::chrono::steady_clock::now();
+  h->vdb = std::make_unique<VariantDBVariant>(h->pop);
+  if (seconds) *seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  return h;
+}
+
+void kgo_vdb_destroy(kgo_vdb* h) { delete h; }
+uint64_t kgo_vdb_variants(kgo_vdb* h) { return h ? h->vdb->variantMap().size() : 0; }
+uint64_t kgo_vdb_genomes(kgo_vdb* h) { return h ? h->vdb->genomeData().size() : 0; }
+uint64_t kgo_vdb_warnings(kgo_vdb* h) { return h ? h->vdb->warnings() : 0; }
+
+// For variant rank i (lexicographic HGVS): the record and alt it was cut from.
+int kgo_vdb_variant_keys(kgo_vdb* h, uint64_t* record_index, uint32_t* alt_index) {
+  if (!h) return -1;
+  for (const auto& [hgvs, rec] : h->vdb->variantMap()) {
+    record_index[rec.second] = rec.first->evidence().record_index;
+    alt_index[rec.second] = rec.first->altVariantIndex();
+  }
+  return 0;
+}
+
+int kgo_vdb_hgvs(kgo_vdb* h, uint64_t i, char* buf, size_t len) {
+  if (!h) return -1;
+  for (const auto& [hgvs, rec] : h->vdb->variantMap())
+    if (rec.second == i) { copyString(hgvs, buf, len); return 0; }
+  return -1;
+}
+
+int kgo_vdb_genome_id(kgo_vdb* h, uint64_t i, char* buf, size_t len) {
+  if (!h || i >= h->vdb->genomeData().size()) return -1;
+  copyString(h->vdb->genomeData()[i].first, buf, len);
+  return 0;
+}
+
+// summaryByVariant for every variant in index order, the loop of CalcFWS::updateVariantFWSMap
+// (kga_analysis_PfEMP_FWS.cpp:41-70).  out[i] = { referenceHomozygous, minorHeterozygous, minorHomozygous }.
+int kgo_vdb_summary_by_variant(kgo_vdb* h, uint64_t* out, double* seconds) {
+  if (!h || !out) return -1;
+  const auto t0 = std::chrono::steady_clock::now();
+  for (const auto& [hgvs, rec] : h->vdb->variantMap()) {
+    const AlleleSummmary s = h->vdb->summaryByVariant(rec.first);
+    out[rec.second * 3 + 0] = s.referenceHomozygous_;
+    out[rec.second * 3 + 1] = s.minorHeterozygous_;
+    out[rec.second * 3 + 2] = s.minorHomozygous_;
+  }
+  if (seconds) *seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  return 0;
+}
+
+int kgo_vdb_summary_by_genome(kgo_vdb* h, uint64_t* out, double* seconds) {
+  if (!h || !out) return -1;
+  const auto t0 = std::chrono::steady_clock::now();
+  size_t i = 0;
+  for (const auto& [genome_id, idx] : h->vdb->genomeMap()) {
+    const AlleleSummmary s = h->vdb->summaryByGenome(genome_id);
+    out[idx * 3 + 0] = s.referenceHomozygous_;
+    out[idx * 3 + 1] = s.minorHeterozygous_;
+    out[idx * 3 + 2] = s.minorHomozygous_;
+    ++i;
+  }
+  if (seconds) *seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  return 0;
+}
+
+int kgo_vdb_population_summary(kgo_vdb* h, uint64_t out[3]) {
+  if (!h || !out) return -1;
+  const AlleleSummmary s = h->vdb->populationSummary();
+  out[0] = s.referenceHomozygous_;
+  out[1] = s.minorHeterozygous_;
+  out[2] = s.minorHomozygous_;
+  return 0;
+}
+
+// The dense matrix itself: out[g][v], genome rank g, variant rank v.
+int kgo_vdb_dosage(kgo_vdb* h, uint8_t* out) {
+  if (!h || !out) return -1;
+  const size_t V = h->vdb->variantMap().size();
+  size_t g = 0;
+  for (const auto& [id, row] : h->vdb->genomeData()) {
+    std::memcpy(out + g * V, row.data(), V);
+    ++g;
+  }
+  return 0;
+}
+
+// ---- dense tier: the same summary loops over a caller-supplied dosage matrix ---------------------
+// VariantDBGenomeData is G separately allocated uint8 vectors (kgl_variant_db_variant.h:49-51); the
+// by-variant loop walks one column across all of them (kgl_variant_db_variant.cpp:143-165).  This tier
+// skips the pointer-chasing PopulationDB so that C2-scale inputs (1e9 cells) can be checked and timed.
+
+struct kgo_dense {
+  VariantDBGenomeData genome_data;
+  size_t n_variants = 0;
+};
+
+kgo_dense* kgo_dense_create(const uint8_t* dosage /* [G][V] */, uint64_t G, uint64_t V) {
+  auto* d = new kgo_dense();
+  d->n_variants = V;
+  d->genome_data.reserve(G);
+  for (uint64_t g = 0; g < G; ++g)
+    d->genome_data.emplace_back("G" + std::to_string(g), std::vector<uint8_t>(dosage + g * V, dosage + (g + 1) * V));
+  return d;
+}
+
+void kgo_dense_destroy(kgo_dense* d) { delete d; }
+
+int kgo_dense_summary_by_variant(kgo_dense* d, uint64_t v0, uint64_t v1, uint64_t* out /* [v1-v0][3] */, double* seconds) {
+  if (!d || !out || v1 > d->n_variants || v0 > v1) return -1;
+  const auto t0 = std::chrono::steady_clock::now();
+  for (uint64_t variant_index = v0; variant_index < v1; ++variant_index) {
+    AlleleSummmary s;
+    for (const auto& [genome, variant_vector] : d->genome_data) {
+      switch (variant_vector[variant_index]) {
+        case 0: ++s.referenceHomozygous_; break;
+        case 1: ++s.minorHeterozygous_; break;
+        case 2: ++s.minorHomozygous_; break;
+        default: break;
+      }
+    }
+    uint64_t* o = out + (variant_index - v0) * 3;
+    o[0] = s.referenceHomozygous_;
+    o[1] = s.minorHeterozygous_;
+    o[2] = s.minorHomozygous_;
+  }
+  if (seconds) *seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  return 0;
+}
+
+int kgo_dense_summary_by_genome(kgo_dense* d, const uint8_t* variant_mask, uint64_t* out /* [G][3] */, double* seconds) {
+  if (!d || !out) return -1;
+  const auto t0 = std::chrono::steady_clock::now();
+  size_t g = 0;
+  for (const auto& [genome, allele_vector] : d->genome_data) {
+    AlleleSummmary s;
+    for (size_t v = 0; v < allele_vector.size(); ++v) {
+      if (variant_mask && !variant_mask[v]) continue;   // variant absent from the filtered population
+      switch (allele_vector[v]) {
+        case 0: ++s.referenceHomozygous_; break;
+        case 1: ++s.minorHeterozygous_; break;
+        case 2: ++s.minorHomozygous_; break;
+        default: break;
+      }
+    }
+    out[g * 3 + 0] = s.referenceHomozygous_;
+    out[g * 3 + 1] = s.minorHeterozygous_;
+    out[g * 3 + 2] = s.minorHomozygous_;
+    ++g;
+  }
+  if (seconds) *seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  return 0;
+}
+
+// ---- CalcFWS / HeteroHomoZygous ----------------------------------------------------------------
+
+// variant_out [V][3] in HGVS order of the UNFILTERED population; genome_out [G][11][3] in genome-id order.
+int kgo_fws(kgo_pop* p, uint64_t* variant_out, uint64_t* genome_out) {
+  if (!p) return -1;
+  CalcFWS fws;
+  fws.calcFwsStatistics(p->pop);
+  if (variant_out) {
+    size_t i = 0;
+    for (const auto& [hgvs, s] : fws.getVariantMap()) {
+      variant_out[i * 3 + 0] = s.referenceHomozygous_;
+      variant_out[i * 3 + 1] = s.minorHeterozygous_;
+      variant_out[i * 3 + 2] = s.minorHomozygous_;
+      ++i;
+    }
+  }
+  if (genome_out) {
+    size_t g = 0;
+    for (const auto& [id, arr] : fws.getGenomeMap()) {
+      for (size_t b = 0; b < FWS_FREQUENCY_ARRAY_SIZE; ++b) {
+        genome_out[(g * FWS_FREQUENCY_ARRAY_SIZE + b) * 3 + 0] = arr[b].referenceHomozygous_;
+        genome_out[(g * FWS_FREQUENCY_ARRAY_SIZE + b) * 3 + 1] = arr[b].minorHeterozygous_;
+        genome_out[(g * FWS_FREQUENCY_ARRAY_SIZE + b) * 3 + 2] = arr[b].minorHomozygous_;
+      }
+      ++g;
+    }
+  }
+  return 0;
+}
+
+// out[g][7] for one contig, genome-id order: total, snp, indel, hom_minor, het_minor, het_ref_minor, hom_ref.
+int kgo_hethom(kgo_pop* p, const char* contig, uint64_t* out) {
+  if (!p || !contig || !out) return -1;
+  auto result = analyzeVariantPopulation(*p->pop);
+  size_t g = 0;
+  for (const auto& [genome_id, contig_map] : result) {
+    VariantAnalysisType r;
+    auto it = contig_map.find(contig);
+    if (it != contig_map.end()) r = it->second;
+    uint64_t* o = out + g * 7;
+    o[0] = r.total_variants_;
+    o[1] = r.snp_count_;
+    o[2] = r.indel_count_;
+    o[3] = r.homozygous_minor_alleles_;
+    o[4] = r.heterozygous_minor_alleles_;
+    o[5] = r.heterozygous_reference_minor_alleles_;
+    o[6] = r.homozygous_reference_alleles_;
+    ++g;
+  }
+  return 0;
+}
+
+double kgo_wrights_fis(const uint64_t location[7], const uint64_t genome[7]) {
+  VariantAnalysisType l, g;
+  l.total_variants_ = location[0]; l.heterozygous_minor_alleles_ = location[4]; l.heterozygous_reference_minor_alleles_ = location[5];
+  g.total_variants_ = genome[0]; g.heterozygous_minor_alleles_ = genome[4]; g.heterozygous_reference_minor_alleles_ = genome[5];
+  return wrightsFIS(l, g);
+}
+
+// ---- inbreeding --------------------------------------------------------------------------------
+
+// AlleleFreqVector::alleleClassFrequencies for raw minor allele frequencies (no Variant objects needed):
+// out = { majorHom, majorHet, minorHom, minorHet }.
+int kgo_class_frequencies(const double* minor_af, uint32_t n, double inbreeding, int normalize, double out[4]) {
+  // The arithmetic of unadjustedAlleleClassFrequencies (_freq.cpp:127-205) on caller-supplied doubles
+  // (AlleleFreqVector itself reads float32 INFO values through Variant objects).
+  std::vector<double> freqs(minor_af, minor_af + n);
+  double sum_minor_freq = 0.0;
+  for (double f : freqs) sum_minor_freq += f;
+  const double major_frequency = std::max(0.0, (1.0 - sum_minor_freq));
+  std::vector<double> m;
+  for (double f : freqs) m.push_back(sum_minor_freq > 1.0 ? f / sum_minor_freq : f);
+  double minor_homozygous = 0.0;
+  for (double f : m) minor_homozygous += (inbreeding * f) + ((1.0 - inbreeding) * f * f);
+  double minor_heterozygous = 0.0;
+  for (size_t i = 0; i < m.size(); ++i)
+    for (size_t j = i + 1; j < m.size(); ++j) minor_heterozygous += (1.0 - inbreeding) * 2.0 * m[i] * m[j];
+  const double major_homozygous = (inbreeding * major_frequency) + ((1.0 - inbreeding) * major_frequency * major_frequency);
+  double major_heterozygous = 0.0;
+  for (double f : m) major_heterozygous += (1.0 - inbreeding) * 2.0 * major_frequency * f;
+  AlleleClassFrequencies cf(major_homozygous, major_heterozygous, minor_homozygous, minor_heterozygous, inbreeding);
+  if (normalize) cf.normalize();
+  out[0] = cf.majorHomozygous();
+  out[1] = cf.majorHeterozygous();
+  out[2] = cf.minorHomozygous();
+  out[3] = cf.minorHeterozygous();
+  return 0;
+}
+
+// RetrieveLociiVector::getLociiCount / getLociiFromTo on the (single-genome, single-contig) reference population.
+int64_t kgo_sample_locii(kgo_pop* reference, int super_pop, int by_count, uint64_t lower, uint64_t upper, uint64_t spacing,
+                         uint64_t count, double min_af, double max_af, uint64_t* out, uint64_t out_cap) {
+  if (!reference || reference->pop->getMap().size() != 1) return -1;
+  const auto& genome = reference->pop->getMap().begin()->second;
+  if (genome->getMap().size() != 1) return -1;
+  const ContigDB& contig = *genome->getMap().begin()->second;
+  LociiVectorArguments a;
+  a.lower_offset = lower; a.upper_offset = upper; a.spacing = spacing; a.locii_count = count;
+  a.allele_frequency_min = std::clamp(min_af, 0.0, 1.0);
+  a.allele_frequency_max = std::clamp(max_af, 0.0, 1.0);
+  const auto v = by_count ? getLociiCount(contig, super_pop, a) : getLociiFromTo(contig, super_pop, a);
+  for (size_t i = 0; i < v.size() && i < out_cap; ++i) out[i] = v[i];
+  return static_cast<int64_t>(v.size());
+}
+
+// One window = InbreedingAnalysis::populationInbreedingSample (_diploid.cpp:83-94): locus lists per super
+// population from [lower, upper] (getLociiFromTo), then one task per genome.
+// super_pop_of_genome: [G] in genome-id (std::map) order; -1 = no PED record (genome skipped).
+// counts_out [G][5] = major_het, minor_het, minor_hom, major_hom, total; freqs_out [G][5] = the four class
+// frequency sums in the same order + inbred_allele_sum.  Skipped genomes are left untouched.
+int kgo_inbreed_window(kgo_pop* reference, kgo_pop* diploid, const int32_t* super_pop_of_genome, const char* algorithm,
+                       uint64_t lower, uint64_t upper, uint64_t spacing, uint64_t count, double min_af, double max_af,
+                       uint64_t start_seed, uint64_t* counts_out, double* freqs_out, uint8_t* present_out,
+                       double* seconds) {
+  if (!reference || !diploid || !algorithm) return -1;
+  if (reference->pop->getMap().size() != 1) return -1;
+  const auto& ref_genome = reference->pop->getMap().begin()->second;
+  if (ref_genome->getMap().size() != 1) return -1;
+  const auto& [contig_id, contig_ptr] = *ref_genome->getMap().begin();
+  InbreedingParameters params;
+  params.locii.lower_offset = lower; params.locii.upper_offset = upper; params.locii.spacing = spacing;
+  params.locii.locii_count = count;
+  params.locii.allele_frequency_min = std::clamp(min_af, 0.0, 1.0);
+  params.locii.allele_frequency_max = std::clamp(max_af, 0.0, 1.0);
+  params.algorithm = algorithm;
+  params.start_seed = start_seed;
+  std::map<std::string, int> sp_map;
+  size_t g = 0;
+  for (const auto& [id, genome] : diploid->pop->getMap()) {
+    if (super_pop_of_genome[g] >= 0) sp_map[id] = super_pop_of_genome[g];
+    ++g;
+  }
+  const auto t0 = std::chrono::steady_clock::now();
+  std::map<int, std::shared_ptr<const ContigDB>> locus_map;
+  for (int sp = 0; sp < SUPER_POP_COUNT; ++sp) locus_map[sp] = getLocusList(*contig_ptr, sp, params.locii);
+  ResultsMap results = processResults(*diploid->pop, contig_id, locus_map, sp_map, params);
+  if (seconds) *seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  g = 0;
+  for (const auto& [id, genome] : diploid->pop->getMap()) {
+    auto it = results.find(id);
+    if (present_out) present_out[g] = it != results.end();
+    if (it != results.end()) fillResults(it->second, counts_out + g * 5, freqs_out + g * 5);
+    ++g;
+  }
+  return 0;
+}
+
+// The whole window loop (populationInbreeding, _diploid.cpp:18-79).
+kgo_columns* kgo_population_inbreeding(kgo_pop* reference, kgo_pop* diploid, const int32_t* super_pop_of_genome,
+                                       const char* algorithm, uint64_t lower, uint64_t upper, uint64_t spacing,
+                                       uint64_t count, double min_af, double max_af, uint64_t start_seed) {
+  if (!reference || !diploid || !algorithm) return nullptr;
+  InbreedingParameters params;
+  params.locii.lower_offset = lower; params.locii.upper_offset = upper; params.locii.spacing = spacing;
+  params.locii.locii_count = count;
+  params.locii.allele_frequency_min = std::clamp(min_af, 0.0, 1.0);
+  params.locii.allele_frequency_max = std::clamp(max_af, 0.0, 1.0);
+  params.algorithm = algorithm;
+  params.start_seed = start_seed;
+  std::map<std::string, int> sp_map;
+  auto* out = new kgo_columns();
+  size_t g = 0;
+  for (const auto& [id, genome] : diploid->pop->getMap()) {
+    if (super_pop_of_genome[g] >= 0) sp_map[id] = super_pop_of_genome[g];
+    out->genome_order.push_back(id);
+    ++g;
+  }
+  out->columns = populationInbreeding(*reference->pop, *diploid->pop, sp_map, params);
+  return out;
+}
+
+void kgo_columns_destroy(kgo_columns* c) { delete c; }
+uint64_t kgo_columns_count(kgo_columns* c) { return c ? c->columns.size() : 0; }
+int kgo_columns_ident(kgo_columns* c, uint64_t i, char* buf, size_t len) {
+  if (!c || i >= c->columns.size()) return -1;
+  copyString(c->columns[i].first, buf, len);
+  return 0;
+}
+int kgo_columns_results(kgo_columns* c, uint64_t i, uint64_t* counts_out, double* freqs_out, uint8_t* present_out) {
+  if (!c || i >= c->columns.size()) return -1;
+  for (size_t g = 0; g < c->genome_order.size(); ++g) {
+    auto it = c->columns[i].second.find(c->genome_order[g]);
+    if (present_out) present_out[g] = it != c->columns[i].second.end();
+    if (it != c->columns[i].second.end()) fillResults(it->second, counts_out + g * 5, freqs_out + g * 5);
+  }
+  return 0;
+}
+
+// Synthetic-inbreeding self-check (SyntheticAnalysis::processSynResults, _synthetic.cpp:74-138) for one super
+// population and one window: generate 101 genomes with F = -0.5 .. 0.5, estimate F back.
+// syn_out / calc_out: [101]; returns the number of genomes.
+int64_t kgo_synthetic_check(kgo_pop* reference, int super_pop, const char* algorithm, uint64_t lower, uint64_t upper,
+                            uint64_t spacing, double min_af, double max_af, uint64_t seed, double* syn_out,
+                            double* calc_out, uint64_t cap) {
+  if (!reference || reference->pop->getMap().size() != 1) return -1;
+  const auto& ref_genome = reference->pop->getMap().begin()->second;
+  if (ref_genome->getMap().size() != 1) return -1;
+  const auto& [contig_id, contig_ptr] = *ref_genome->getMap().begin();
+  InbreedingParameters params;
+  params.locii.lower_offset = lower; params.locii.upper_offset = upper; params.locii.spacing = spacing;
+  params.locii.allele_frequency_min = min_af; params.locii.allele_frequency_max = max_af;
+  params.algorithm = algorithm;
+  params.start_seed = seed;
+  auto locus_list = getLocusList(*contig_ptr, super_pop, params.locii);
+  auto population = generateSyntheticPopulation(-0.5, 0.5, 0.01, super_pop, *locus_list, seed);
+  std::map<int, std::shared_ptr<const ContigDB>> locus_map{{super_pop, locus_list}};
+  std::map<std::string, int> sp_map;
+  for (const auto& [id, g] : population->getMap()) sp_map[id] = super_pop;
+  ResultsMap results = processResults(*population, contig_id, locus_map, sp_map, params);
+  uint64_t i = 0;
+  for (const auto& [id, r] : results) {
+    if (i >= cap) break;
+    syn_out[i] = generateInbreeding(id).second;
+    calc_out[i] = r.inbred_allele_sum;
+    ++i;
+  }
+  return static_cast<int64_t>(results.size());
+}
+
+}  // extern "C"

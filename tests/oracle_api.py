@@ -1,0 +1,341 @@
+"""ctypes driver of oracle/_build/libkgo.so — the CPU restatement used as the checker.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may use this module.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import subprocess
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parent.parent
+LIB_PATH = ROOT / "oracle" / "_build" / "libkgo.so"
+
+SUPER_POPS = ["AFR", "AMR", "EAS", "EUR", "SAS", "ALL"]
+ALL = 5
+
+_lib = None
+
+
+def lib() -> C.CDLL:
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not LIB_PATH.exists():
+        subprocess.run(["make", "-s", "-C", str(ROOT / "oracle")], check=True)
+    L = C.CDLL(str(LIB_PATH))
+    vp, u64, i64, dbl = C.c_void_p, C.c_uint64, C.c_int64, C.c_double
+    sig = {
+        "kgo_banner": (C.c_char_p, []),
+        "kgo_set_threads": (None, [C.c_int]),
+        "kgo_default_threads": (C.c_int, []),
+        "kgo_pool_threads": (C.c_int, [u64]),
+        "kgo_population_create": (vp, [C.c_char_p]),
+        "kgo_population_destroy": (None, [vp]),
+        "kgo_population_add_genomes": (C.c_int, [vp, u64, vp, C.c_int]),
+        "kgo_population_add_records": (C.c_int, [vp, C.c_int, C.c_char_p, u64, vp, vp, vp, vp, vp, vp, u64, vp, vp]),
+        "kgo_population_variant_count": (u64, [vp]),
+        "kgo_population_genome_count": (u64, [vp]),
+        "kgo_population_genome_order": (C.c_int, [vp, vp]),
+        "kgo_population_filter_snp_pass": (vp, [vp]),
+        "kgo_vdb_create": (vp, [vp, vp]),
+        "kgo_vdb_destroy": (None, [vp]),
+        "kgo_vdb_variants": (u64, [vp]),
+        "kgo_vdb_genomes": (u64, [vp]),
+        "kgo_vdb_warnings": (u64, [vp]),
+        "kgo_vdb_variant_keys": (C.c_int, [vp, vp, vp]),
+        "kgo_vdb_hgvs": (C.c_int, [vp, u64, C.c_char_p, C.c_size_t]),
+        "kgo_vdb_genome_id": (C.c_int, [vp, u64, C.c_char_p, C.c_size_t]),
+        "kgo_vdb_summary_by_variant": (C.c_int, [vp, vp, vp]),
+        "kgo_vdb_summary_by_genome": (C.c_int, [vp, vp, vp]),
+        "kgo_vdb_population_summary": (C.c_int, [vp, vp]),
+        "kgo_vdb_dosage": (C.c_int, [vp, vp]),
+        "kgo_dense_create": (vp, [vp, u64, u64]),
+        "kgo_dense_destroy": (None, [vp]),
+        "kgo_dense_summary_by_variant": (C.c_int, [vp, u64, u64, vp, vp]),
+        "kgo_dense_summary_by_genome": (C.c_int, [vp, vp, vp, vp]),
+        "kgo_fws": (C.c_int, [vp, vp, vp]),
+        "kgo_hethom": (C.c_int, [vp, C.c_char_p, vp]),
+        "kgo_wrights_fis": (dbl, [vp, vp]),
+        "kgo_class_frequencies": (C.c_int, [vp, C.c_uint32, dbl, C.c_int, vp]),
+        "kgo_sample_locii": (i64, [vp, C.c_int, C.c_int, u64, u64, u64, u64, dbl, dbl, vp, u64]),
+        "kgo_inbreed_window": (C.c_int, [vp, vp, vp, C.c_char_p, u64, u64, u64, u64, dbl, dbl, u64, vp, vp, vp, vp]),
+        "kgo_population_inbreeding": (vp, [vp, vp, vp, C.c_char_p, u64, u64, u64, u64, dbl, dbl, u64]),
+        "kgo_columns_destroy": (None, [vp]),
+        "kgo_columns_count": (u64, [vp]),
+        "kgo_columns_ident": (C.c_int, [vp, u64, C.c_char_p, C.c_size_t]),
+        "kgo_columns_results": (C.c_int, [vp, u64, vp, vp, vp]),
+        "kgo_synthetic_check": (i64, [vp, C.c_int, C.c_char_p, u64, u64, u64, dbl, dbl, u64, vp, vp, u64]),
+    }
+    for name, (res, args) in sig.items():
+        fn = getattr(L, name)
+        fn.restype = res
+        fn.argtypes = args
+    _lib = L
+    return L
+
+
+def _p(a):
+    return None if a is None else C.c_void_p(a.ctypes.data)
+
+
+def _strs(items):
+    arr = (C.c_char_p * len(items))()
+    arr[:] = [s.encode() if isinstance(s, str) else s for s in items]
+    return arr
+
+
+class Records:
+    """A VCF-like block: what a parser would hand to PopulationDB."""
+
+    def __init__(self, contig, offsets, refs, alts, af=None, passed=None):
+        self.contig = contig
+        self.offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        self.refs = list(refs)
+        self.alts = [list(a) for a in alts]            # per record: list of alt strings
+        self.n_alts = np.array([len(a) for a in self.alts], dtype=np.uint8)
+        self.n_records = len(self.refs)
+        # af: list per record of [n_alt][6] float32 (NaN = missing) or None
+        self.af = af
+        self.passed = None if passed is None else np.ascontiguousarray(passed, dtype=np.uint8)
+
+    def af_flat(self):
+        if self.af is None:
+            return None
+        return np.ascontiguousarray(np.concatenate([np.asarray(a, dtype=np.float32).reshape(-1, 6) for a in self.af]),
+                                    dtype=np.float32)
+
+    def alts_flat(self):
+        return [x for a in self.alts for x in a]
+
+
+class Population:
+    PHASED, UNPHASED, REFERENCE = 0, 1, 2
+
+    def __init__(self, name="population", handle=None):
+        self._h = handle if handle is not None else lib().kgo_population_create(name.encode())
+        self.genome_ids: list[str] = []
+
+    def close(self):
+        if self._h:
+            lib().kgo_population_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def add_genomes(self, ids, precreate=True):
+        self.genome_ids = list(ids)
+        arr = _strs(self.genome_ids)
+        assert lib().kgo_population_add_genomes(self._h, len(ids), C.cast(arr, C.c_void_p), int(precreate)) == 0
+
+    def add_records(self, rec: Records, gt: np.ndarray | None, mode: int):
+        """gt: [n_records][n_genomes][2] uint8 allele indices (0 = ref)."""
+        ids = _strs(self.genome_ids)
+        refs = _strs(rec.refs)
+        alts = _strs(rec.alts_flat())
+        af = rec.af_flat()
+        if gt is not None:
+            gt = np.ascontiguousarray(gt, dtype=np.uint8)
+            assert gt.shape == (rec.n_records, len(self.genome_ids), 2)
+        rc = lib().kgo_population_add_records(self._h, mode, rec.contig.encode(), rec.n_records, _p(rec.offsets),
+                                              C.cast(refs, C.c_void_p), _p(rec.n_alts), C.cast(alts, C.c_void_p),
+                                              _p(rec.passed), _p(af), len(self.genome_ids), C.cast(ids, C.c_void_p), _p(gt))
+        assert rc == 0
+
+    @property
+    def handle(self):
+        return self._h
+
+    def variant_count(self):
+        return int(lib().kgo_population_variant_count(self._h))
+
+    def genome_count(self):
+        return int(lib().kgo_population_genome_count(self._h))
+
+    def genome_order(self):
+        """Sorted-by-id position -> index in the caller's genome id list."""
+        out = np.zeros(self.genome_count(), dtype=np.int64)
+        assert lib().kgo_population_genome_order(self._h, _p(out)) == 0
+        return out
+
+    def filter_snp_pass(self):
+        p = Population(handle=lib().kgo_population_filter_snp_pass(self._h))
+        p.genome_ids = list(self.genome_ids)
+        return p
+
+    # -- allele-count analyses ----------------------------------------------------------------
+    def fws(self):
+        G = self.genome_count()
+        vdb = VariantDB(self)
+        V = vdb.n_variants
+        variant_out = np.zeros((V, 3), dtype=np.uint64)
+        genome_out = np.zeros((G, 11, 3), dtype=np.uint64)
+        assert lib().kgo_fws(self._h, _p(variant_out), _p(genome_out)) == 0
+        return variant_out, genome_out, vdb
+
+    def hethom(self, contig):
+        out = np.zeros((self.genome_count(), 7), dtype=np.uint64)
+        assert lib().kgo_hethom(self._h, contig.encode(), _p(out)) == 0
+        return out
+
+
+class VariantDB:
+    """VariantDBVariant (kgl_variant_db_variant.h:53-76)."""
+
+    def __init__(self, pop: Population):
+        sec = C.c_double(0)
+        self._h = lib().kgo_vdb_create(pop.handle, C.byref(sec))
+        self.build_seconds = sec.value
+        self.n_variants = int(lib().kgo_vdb_variants(self._h))
+        self.n_genomes = int(lib().kgo_vdb_genomes(self._h))
+
+    def __del__(self):
+        try:
+            if self._h:
+                lib().kgo_vdb_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+    def variant_keys(self):
+        rec = np.zeros(self.n_variants, dtype=np.uint64)
+        alt = np.zeros(self.n_variants, dtype=np.uint32)
+        assert lib().kgo_vdb_variant_keys(self._h, _p(rec), _p(alt)) == 0
+        return rec, alt
+
+    def hgvs(self, i):
+        buf = C.create_string_buffer(512)
+        assert lib().kgo_vdb_hgvs(self._h, i, buf, 512) == 0
+        return buf.value.decode()
+
+    def genome_id(self, i):
+        buf = C.create_string_buffer(256)
+        assert lib().kgo_vdb_genome_id(self._h, i, buf, 256) == 0
+        return buf.value.decode()
+
+    def summary_by_variant(self):
+        out = np.zeros((self.n_variants, 3), dtype=np.uint64)
+        sec = C.c_double(0)
+        assert lib().kgo_vdb_summary_by_variant(self._h, _p(out), C.byref(sec)) == 0
+        self.by_variant_seconds = sec.value
+        return out
+
+    def summary_by_genome(self):
+        out = np.zeros((self.n_genomes, 3), dtype=np.uint64)
+        sec = C.c_double(0)
+        assert lib().kgo_vdb_summary_by_genome(self._h, _p(out), C.byref(sec)) == 0
+        self.by_genome_seconds = sec.value
+        return out
+
+    def population_summary(self):
+        out = np.zeros(3, dtype=np.uint64)
+        assert lib().kgo_vdb_population_summary(self._h, _p(out)) == 0
+        return out
+
+    def dosage(self):
+        out = np.zeros((self.n_genomes, self.n_variants), dtype=np.uint8)
+        assert lib().kgo_vdb_dosage(self._h, _p(out)) == 0
+        return out
+
+    def warnings(self):
+        return int(lib().kgo_vdb_warnings(self._h))
+
+
+class Dense:
+    """The reference's summary loops over a caller-supplied VariantDBGenomeData matrix [G][V]."""
+
+    def __init__(self, dosage: np.ndarray):
+        d = np.ascontiguousarray(dosage, dtype=np.uint8)
+        self.G, self.V = d.shape
+        self._h = lib().kgo_dense_create(_p(d), self.G, self.V)
+
+    def __del__(self):
+        try:
+            if self._h:
+                lib().kgo_dense_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+    def summary_by_variant(self, v0=0, v1=None):
+        v1 = self.V if v1 is None else v1
+        out = np.zeros((v1 - v0, 3), dtype=np.uint64)
+        sec = C.c_double(0)
+        assert lib().kgo_dense_summary_by_variant(self._h, v0, v1, _p(out), C.byref(sec)) == 0
+        self.seconds = sec.value
+        return out
+
+    def summary_by_genome(self, mask=None):
+        out = np.zeros((self.G, 3), dtype=np.uint64)
+        sec = C.c_double(0)
+        m = None if mask is None else np.ascontiguousarray(mask, dtype=np.uint8)
+        assert lib().kgo_dense_summary_by_genome(self._h, _p(m), _p(out), C.byref(sec)) == 0
+        self.seconds = sec.value
+        return out
+
+
+def class_frequencies(minor_af, inbreeding, normalize=True):
+    a = np.ascontiguousarray(minor_af, dtype=np.float64)
+    out = np.zeros(4, dtype=np.float64)
+    assert lib().kgo_class_frequencies(_p(a), len(a), float(inbreeding), int(normalize), _p(out)) == 0
+    return out  # majorHom, majorHet, minorHom, minorHet
+
+
+def sample_locii(reference: Population, super_pop, by_count, lower, upper, spacing, count, min_af, max_af):
+    cap = 1 << 22
+    out = np.zeros(cap, dtype=np.uint64)
+    n = lib().kgo_sample_locii(reference.handle, super_pop, int(by_count), lower, upper, spacing, count, min_af, max_af,
+                               _p(out), cap)
+    assert n >= 0
+    return out[:n].copy()
+
+
+def inbreed_window(reference: Population, diploid: Population, super_pop_of_genome, algorithm, lower, upper, spacing,
+                   count, min_af, max_af, seed=0):
+    G = diploid.genome_count()
+    sp = np.ascontiguousarray(super_pop_of_genome, dtype=np.int32)
+    counts = np.zeros((G, 5), dtype=np.uint64)
+    freqs = np.zeros((G, 5), dtype=np.float64)
+    present = np.zeros(G, dtype=np.uint8)
+    sec = C.c_double(0)
+    rc = lib().kgo_inbreed_window(reference.handle, diploid.handle, _p(sp), algorithm.encode(), lower, upper, spacing,
+                                  count, min_af, max_af, seed, _p(counts), _p(freqs), _p(present), C.byref(sec))
+    assert rc == 0
+    return counts, freqs, present.astype(bool), sec.value
+
+
+def population_inbreeding(reference: Population, diploid: Population, super_pop_of_genome, algorithm, lower, upper,
+                          spacing, count, min_af, max_af, seed=0):
+    G = diploid.genome_count()
+    sp = np.ascontiguousarray(super_pop_of_genome, dtype=np.int32)
+    h = lib().kgo_population_inbreeding(reference.handle, diploid.handle, _p(sp), algorithm.encode(), lower, upper,
+                                        spacing, count, min_af, max_af, seed)
+    assert h
+    cols = []
+    try:
+        for i in range(int(lib().kgo_columns_count(h))):
+            buf = C.create_string_buffer(256)
+            lib().kgo_columns_ident(h, i, buf, 256)
+            counts = np.zeros((G, 5), dtype=np.uint64)
+            freqs = np.zeros((G, 5), dtype=np.float64)
+            present = np.zeros(G, dtype=np.uint8)
+            lib().kgo_columns_results(h, i, _p(counts), _p(freqs), _p(present))
+            cols.append((buf.value.decode(), counts, freqs, present.astype(bool)))
+    finally:
+        lib().kgo_columns_destroy(h)
+    return cols
+
+
+def synthetic_check(reference: Population, super_pop, algorithm, lower, upper, spacing, min_af, max_af, seed):
+    syn = np.zeros(128, dtype=np.float64)
+    calc = np.zeros(128, dtype=np.float64)
+    n = lib().kgo_synthetic_check(reference.handle, super_pop, algorithm.encode(), lower, upper, spacing, min_af, max_af,
+                                  seed, _p(syn), _p(calc), 128)
+    assert n >= 0
+    return syn[:n].copy(), calc[:n].copy()
