@@ -1,0 +1,225 @@
+#!/usr/bin/env python3
+"""Headline benchmark: the allele-frequency sweep (K2 = summaryByVariant for every variant, + the
+all-reduce of per-variant counts across genome shards, + the AF epilogue) over a synthetic population
+resident in HBM.
+
+  python bench.py --gpus N --steps K --warmup W        (N>1: launched by torch.distributed.run)
+
+A step = one pass of the hot path over this rank's genome shard.  Workload (config.workload):
+  c3  (default) 10,000 genomes x 10,000,000 biallelic SNPs PER GPU  (BASELINE.json configs[2]; weak scaling)
+  c4            100,000 genomes x 10M SNPs split over the N ranks    (configs[3]; needs N >= 2)
+  c2            1,000 genomes x 1M SNPs per GPU                      (configs[1]; fits the 256 MiB L3)
+One JSON line is printed by rank 0.  PyTorch is plumbing only (device tensors, RCCL all-reduce).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E peak (MI355X_MICROARCH.md); ~6.3 TB/s is the measured copy ceiling
+
+WORKLOADS = {
+    "c2": dict(genomes_per_gpu=1_000, variants=1_000_000, label="C2: 1k genomes x 1M biallelic SNPs per GPU"),
+    "c3": dict(genomes_per_gpu=10_000, variants=10_000_000, label="C3: 10k genomes x 10M biallelic SNPs per GPU"),
+    "c4": dict(total_genomes=100_000, variants=10_000_000, label="C4: 100k genomes x 10M biallelic SNPs sharded over the ranks"),
+}
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", choices=sorted(WORKLOADS), default="c3")
+    ap.add_argument("--genomes", type=int, default=0, help="override genomes per GPU")
+    ap.add_argument("--variants", type=int, default=0, help="override variant rows")
+    ap.add_argument("--seed", type=int, default=1111)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample-variants", type=int, default=100_000)
+    return ap.parse_args()
+
+
+def cpu_baseline(capi, pop, G, V, k2_host_sample_rows, sample_variants):
+    """The oracle's dense tier (the reference's summaryByVariant column walk over VariantDBGenomeData,
+    single-threaded as in CalcFWS::updateVariantFWSMap) timed on this box's host cores, on the first
+    `sample_variants` rows x all genomes of the same population.  Also a parity check of that block."""
+    from tests import oracle_api as oa
+
+    nv = min(sample_variants, V)
+    packed = pop.read_dosage2(0, nv)
+    codes = capi.unpack_dosage2(packed, G)             # [nv][G]
+    dosage = np.ascontiguousarray(codes.T)             # VariantDBGenomeData layout [G][nv]
+    del codes, packed
+    dense = oa.Dense(dosage)
+    want = dense.summary_by_variant()
+    seconds = dense.seconds
+    ok = bool(np.array_equal(k2_host_sample_rows[:, :3].astype(np.uint64), want))
+    return {
+        "value": G * nv / seconds,
+        "unit": "variants·genomes/s",
+        "cores": 1,
+        "kind": "port",
+        "sample": f"first {nv} variants x all {G} genomes of the same population ({G * nv:.3g} cells, {seconds:.1f} s); "
+                  f"oracle dense tier = reference summaryByVariant loop (single-threaded in the reference); "
+                  f"host has {os.cpu_count()} cpus; block parity vs GPU: {'bit-exact' if ok else 'MISMATCH'}",
+        "parity_ok": ok,
+    }
+
+
+def main():
+    args = parse_args()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    n_gpus = args.gpus
+    if world != n_gpus:
+        if world == 1 and n_gpus > 1:
+            sys.exit("bench.py --gpus N>1 must be launched with python -m torch.distributed.run --nproc-per-node N")
+        n_gpus = world
+
+    import torch
+    import torch.distributed as dist
+
+    from kgl_gene_amd import capi
+
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs a GPU (there is no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if n_gpus > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=dev)
+    capi.init(local_rank)
+
+    wl = WORKLOADS[args.workload]
+    V = args.variants or wl["variants"]
+    if args.workload == "c4":
+        if n_gpus < 2 and not args.genomes:
+            sys.exit("workload c4 (100k x 10M = 250 GB) is sharded: run it with --gpus >= 2")
+        total_genomes = wl["total_genomes"]
+        per = [total_genomes // n_gpus + (1 if r < total_genomes % n_gpus else 0) for r in range(n_gpus)]
+        scaling = "strong"
+    else:
+        g = args.genomes or wl["genomes_per_gpu"]
+        per = [g] * n_gpus
+        scaling = "weak"
+    if args.genomes and args.workload == "c4":
+        per = [args.genomes] * n_gpus
+    total_genomes = sum(per)
+    G = per[rank]
+    genome_base = sum(per[:rank])
+
+    pop = capi.Population(G, V)
+    t0 = time.perf_counter()
+    pop.synth_biallelic(args.seed, genome_base, 0)
+    capi.synchronize()
+    t_synth = time.perf_counter() - t0
+
+    counts = torch.empty((V, 4), dtype=torch.int32, device=dev)      # uint32 bit patterns; sums < 2^31
+    af = torch.empty((V,), dtype=torch.float64, device=dev)
+    stream = torch.cuda.current_stream(dev).cuda_stream
+
+    def step():
+        pop.allele_count_by_locus_dev(counts.data_ptr(), stream)
+        if n_gpus > 1:
+            dist.all_reduce(counts, op=dist.ReduceOp.SUM)              # RCCL over xGMI: the one exchange step
+        capi.allele_frequency_dev(counts.data_ptr(), V, total_genomes, af.data_ptr(), stream)
+
+    def fence():
+        if n_gpus > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    if n_gpus > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # Dominant kernel (K2) timed alone with HIP events on the launch stream.
+    scratch = torch.empty((V, 4), dtype=torch.int32, device=dev)
+    ms = pop.allele_count_timed(scratch.data_ptr(), stream, 2, max(args.steps, 10))
+    k2_ms = float(np.mean(ms))
+    sweep_bytes = pop.sweep_bytes                                     # V*ceil(G/4) + 16*V
+    achieved = sweep_bytes / (k2_ms * 1e-3) / 1e9
+
+    result = None
+    if rank == 0:
+        value = total_genomes * V * args.steps / elapsed
+        traffic = None
+        tf = ROOT / "profiles" / "k2_traffic.json"
+        if tf.exists():
+            try:
+                rec = json.loads(tf.read_text()).get(f"{G}x{V}")
+                if rec:
+                    traffic = rec["hbm_bytes_per_launch"]
+            except Exception:
+                traffic = None
+        result = {
+            "metric": "variants·genomes/sec (allele-freq sweep)",
+            "value": value,
+            "unit": "variants·genomes/s",
+            "n_gpus": n_gpus,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": scaling,
+            "vs_baseline": None,
+            "dtype": "u32",
+            "data": "synthetic",
+            "config": {
+                "workload": wl["label"],
+                "genomes_per_gpu": G,
+                "total_genomes": total_genomes,
+                "variants": V,
+                "layout": "2-bit dosage rows, variant-major",
+                "exchange": "RCCL all-reduce(sum,u32) of [V][4] counts" if n_gpus > 1 else "none (1 GPU)",
+                "seed": args.seed,
+                "synth_seconds": round(t_synth, 3),
+            },
+            "roofline": {
+                "bound": "hbm",
+                "kernel": "k_allele_count",
+                "achieved": achieved,
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS,
+                "traffic": traffic,
+                "algorithmic_bytes_per_launch": sweep_bytes,
+                "kernel_ms": k2_ms,
+            },
+        }
+        if n_gpus == 1 and not args.no_cpu_baseline:
+            nv = min(args.cpu_sample_variants, V)
+            k2_rows = counts[:nv].cpu().numpy().view(np.uint32)
+            result["cpu_baseline"] = cpu_baseline(capi, pop, G, V, k2_rows, nv)
+        else:
+            result["cpu_baseline"] = None
+
+    pop.close()
+    if n_gpus > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(result, ensure_ascii=False))
+
+
+if __name__ == "__main__":
+    main()
