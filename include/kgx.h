@@ -57,6 +57,8 @@ int kgx_init(int device);
 /* Device properties a caller needs for roofline reporting. */
 int kgx_device_info(char* name, size_t name_len, char* arch, size_t arch_len,
                     int* compute_units, uint64_t* hbm_bytes);
+/* The library's own (non-blocking) hipStream_t, used by every host-returning entry point. */
+void* kgx_stream(void);
 int kgx_synchronize(void);
 
 /* ---- population shard: replaces PopulationDB→VariantDBVariant (kgl_variant_db_variant.h:53-76)
@@ -67,7 +69,8 @@ kgx_pop* kgx_population_create(uint64_t n_genomes, uint64_t n_variants);
 void     kgx_population_destroy(kgx_pop* pop);
 uint64_t kgx_population_genomes(const kgx_pop* pop);
 uint64_t kgx_population_variants(const kgx_pop* pop);
-/* Device row pitch in bytes (multiple of 16; ceil(n_genomes/4) rounded up). */
+/* Device row pitch in bytes: ceil(n_genomes/4) rounded up to 16, or to 128 when a row exceeds 512 B
+ * (line-aligned rows: every 1 KiB wave load then covers whole 128-B lines). */
 uint64_t kgx_population_row_pitch(const kgx_pop* pop);
 /* Algorithmic HBM bytes of one allele-count sweep: n_variants*ceil(n_genomes/4) + 16*n_variants. */
 uint64_t kgx_population_sweep_bytes(const kgx_pop* pop);
@@ -106,7 +109,8 @@ int kgx_synth_biallelic_host(uint64_t seed, uint64_t genome_base, uint64_t n_gen
  *      out[v] = { referenceHomozygous, minorHeterozygous, minorHomozygous, nonDiploid } (uint32 each). */
 int kgx_allele_count_by_locus(kgx_pop* pop, uint32_t* out /* host [n_variants][4] */);
 /* Same, result left in device memory (caller's buffer, e.g. a torch tensor to all-reduce);
- * launched on `stream` (a hipStream_t; NULL = the library stream), asynchronous. */
+ * launched asynchronously on `stream`, taken literally as a hipStream_t (NULL = the legacy default
+ * stream, which is what torch.cuda.current_stream().cuda_stream is unless a side stream is current). */
 int kgx_allele_count_by_locus_dev(kgx_pop* pop, void* d_out /* device [n_variants][4] u32 */,
                                   void* stream);
 /* Epilogue on (all-reduced) device counts: af[v] = (het + 2*hom) / (2*total_genomes) in fp64. */

@@ -38,6 +38,7 @@ _SIGNATURES = {
     "kgx_device_count": (C.c_int, []),
     "kgx_init": (C.c_int, [C.c_int]),
     "kgx_device_info": (C.c_int, [C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t, C.POINTER(C.c_int), _u64p]),
+    "kgx_stream": (C.c_void_p, []),
     "kgx_synchronize": (C.c_int, []),
     "kgx_population_create": (C.c_void_p, [C.c_uint64, C.c_uint64]),
     "kgx_population_destroy": (None, [C.c_void_p]),
@@ -114,6 +115,11 @@ def device_info() -> dict:
     check(lib().kgx_device_info(name, 128, arch, 64, C.byref(cus), C.byref(hbm)))
     return {"name": name.value.decode(), "arch": arch.value.decode(), "compute_units": cus.value,
             "hbm_bytes": hbm.value}
+
+
+def stream() -> int:
+    """The library's own hipStream_t (as an integer handle)."""
+    return int(lib().kgx_stream() or 0)
 
 
 def synchronize() -> None:

@@ -11,6 +11,7 @@ struct kgx_pop {
   uint64_t row_bytes = 0;        // ceil(n_genomes / 4): algorithmic bytes per row
   uint64_t pitch = 0;            // device row pitch, multiple of 16
   uint32_t chunks_per_row = 0;   // pitch / 16
+  uint8_t* d_alloc = nullptr;    // the hipMalloc'd block holding d_rows
   uint8_t* d_rows = nullptr;     // [n_variants][pitch] dosage2
   float* d_af = nullptr;         // [n_variants] INFO allele frequency (float32, NaN = missing)
   void* d_counts = nullptr;      // [n_variants][4] u32 scratch for the host-returning entry points

@@ -59,7 +59,7 @@ __device__ __forceinline__ void count_chunk(const kgx_v4u x, uint32_t& a, uint32
 // row sets in flight per wave (U independent 16-B loads per lane per step).
 // out[v] = { refHom, het, minorHom, nonDiploid }.
 // ---------------------------------------------------------------------------------------------
-template <int W, int U>
+template <int W, int U, bool NT = true>
 __global__ void __launch_bounds__(kBlock)
 k_allele_count(const kgx_v4u* __restrict__ rows, uint32_t chunks_per_row, uint64_t n_rows,
                uint32_t n_genomes, kgx_v4u* __restrict__ out) {
@@ -86,7 +86,7 @@ k_allele_count(const kgx_v4u* __restrict__ rows, uint32_t chunks_per_row, uint64
     for (uint32_t k = sub; k < chunks_per_row; k += W) {
       kgx_v4u x[U];
 #pragma unroll
-      for (int u = 0; u < U; ++u) x[u] = __builtin_nontemporal_load(rp[u] + k);
+      for (int u = 0; u < U; ++u) x[u] = NT ? __builtin_nontemporal_load(rp[u] + k) : rp[u][k];
 #pragma unroll
       for (int u = 0; u < U; ++u) count_chunk(x[u], a[u], b[u], c[u]);
     }
