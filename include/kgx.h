@@ -132,6 +132,17 @@ int kgx_count_by_genome(kgx_pop* pop, const uint8_t* variant_mask /* host [n_var
 int kgx_count_by_genome_binned(kgx_pop* pop, const uint8_t* bin_of_variant /* host [n_variants] */,
                                uint32_t n_bins, uint64_t* out /* host [n_genomes][n_bins][4] */);
 
+/* ---- K8: compound offsets of HeteroHomoZygous::updateVariantAnalysisType
+ *      (kga_analytic/kga_PfEMP/kga_analysis_PfEMP_heterozygous.cpp:61-105).  A group is a contig offset at
+ *      which the population holds n_rows[i] >= 2 distinct variants, stored as adjacent rows starting at
+ *      first_row[i]; bin[i] in [0,n_bins) selects the output slot (the contig).  Per genome and bin:
+ *      out[g][bin] = { heterozygous_reference_minor (exactly one copy there),
+ *                      homozygous_minor (distinct variants carried when >= 2 copies; the reference's quirk),
+ *                      heterozygous_minor (variants carried exactly once when >= 2 copies) }.
+ *      Offsets with one row follow from kgx_count_by_genome_binned and are not passed here. */
+int kgx_compound_offsets(kgx_pop* pop, const uint32_t* first_row, const uint32_t* n_rows, const uint32_t* bin,
+                         uint64_t n_groups, uint32_t n_bins, uint64_t* out /* host [n_genomes][n_bins][3] */);
+
 /* ---- K4: VariantDBVariant::populationSummary (kgl_variant_db_variant.cpp:234-279). */
 int kgx_population_summary(kgx_pop* pop, uint64_t out[4]);
 

@@ -61,6 +61,7 @@ _SIGNATURES = {
     "kgx_count_by_genome": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "kgx_count_by_genome_binned": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]),
     "kgx_population_summary": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "kgx_compound_offsets": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_void_p]),
 }
 
 
@@ -260,6 +261,15 @@ class Population:
             raise ValueError("bin_of_variant must be [n_variants]")
         out = np.zeros((self.n_genomes, n_bins, 4), dtype=np.uint64)
         check(lib().kgx_count_by_genome_binned(self._h, ptr(b), n_bins, ptr(out)))
+        return out
+
+    def compound_offsets(self, first_row, n_rows, bins, n_bins: int) -> np.ndarray:
+        """[n_genomes][n_bins][3] uint64: het_ref_minor, hom_minor, het_minor at offsets with >= 2 distinct variants."""
+        fr = np.ascontiguousarray(first_row, dtype=np.uint32)
+        nr = np.ascontiguousarray(n_rows, dtype=np.uint32)
+        bn = np.ascontiguousarray(bins, dtype=np.uint32)
+        out = np.zeros((self.n_genomes, n_bins, 3), dtype=np.uint64)
+        check(lib().kgx_compound_offsets(self._h, ptr(fr), ptr(nr), ptr(bn), len(fr), n_bins, ptr(out)))
         return out
 
     def population_summary(self) -> np.ndarray:

@@ -1,0 +1,309 @@
+#include "kga_analysis_gpu_allele.h"
+
+#include <fstream>
+
+#include "../../../include/kgx.h"
+
+namespace kga = kellerberrin::genome::analysis;
+namespace kgl = kellerberrin::genome;
+using kellerberrin::ExecEnv;
+
+namespace {
+
+// Owns a kgx_pop for the duration of one file's sweeps.
+struct DevicePopulation {
+  kgx_pop* handle{nullptr};
+  ~DevicePopulation() { if (handle) kgx_population_destroy(handle); }
+};
+
+std::string joinPath(const std::string& dir, const std::string& stem) {
+  if (dir.empty()) return stem + ".csv";
+  return dir + (dir.back() == '/' ? "" : "/") + stem + ".csv";
+}
+
+}  // namespace
+
+bool kga::GpuAlleleAnalysis::initializeAnalysis(const std::string& work_directory, const ActiveParameterList& named_parameters,
+                                                const std::shared_ptr<const AnalysisResources>&) {
+  ExecEnv::log().info("Analysis Id: {} initialized with work directory: {}", ident(), work_directory);
+  work_directory_ = work_directory;
+  for (const auto& [block_name, named_vector] : named_parameters.getMap()) {
+    for (const auto& parameter_map : named_vector.second) {
+      if (auto v = parameter_map.getSize("Device")) device_ = static_cast<int>(v.value().front());
+      if (auto v = parameter_map.getString("VariantFile")) variant_file_ = v.value().front();
+      if (auto v = parameter_map.getString("GenomeFile")) genome_file_ = v.value().front();
+      if (auto v = parameter_map.getString("HetHomFile")) hethom_file_ = v.value().front();
+    }
+  }
+  if (kgx_init(device_) != KGX_OK) {
+    // No CPU fallback: the analysis is disabled, other packages continue (kgl_package_analysis.cpp:41-42).
+    ExecEnv::log().error("GpuAlleleAnalysis::initializeAnalysis; cannot bind MI355X device {}: {}", device_, kgx_last_error());
+    return false;
+  }
+  device_ready_ = true;
+  return true;
+}
+
+bool kga::GpuAlleleAnalysis::fileReadAnalysis(std::shared_ptr<const DataDB> data_object_ptr) {
+  ExecEnv::log().info("Analysis: {}, begin processing data file: {}", ident(), data_object_ptr->fileId());
+  if (!device_ready_) {
+    ExecEnv::log().error("GpuAlleleAnalysis::fileReadAnalysis; no device bound");
+    return false;
+  }
+  const auto file_characteristic = data_object_ptr->dataCharacteristic();
+  if (file_characteristic.data_structure != DataStructureEnum::DiploidPhased &&
+      file_characteristic.data_structure != DataStructureEnum::DiploidUnphased) {
+    ExecEnv::log().info("Analysis: {}, file: {} is not a diploid population; ignored", ident(), data_object_ptr->fileId());
+    return true;
+  }
+  auto population = std::dynamic_pointer_cast<const PopulationDB>(data_object_ptr);
+  if (!population) {
+    ExecEnv::log().error("GpuAlleleAnalysis::fileReadAnalysis; Analysis: {}, file: {} is not a PopulationDB", ident(), data_object_ptr->fileId());
+    return false;
+  }
+  return sweepPopulation(*population);
+}
+
+bool kga::GpuAlleleAnalysis::sweepPopulation(const PopulationDB& population) {
+  const gpu::FlatPopulation flat = gpu::flattenPopulation(population);
+  const uint64_t G = flat.genomes(), V = flat.variants();
+  ExecEnv::log().info("GpuAlleleAnalysis; population: {}, genomes: {}, distinct variants: {}, Variant objects: {}",
+                      population.populationId(), G, V, flat.variant_objects);
+  if (G == 0) return true;
+  for (const auto& genome_id : flat.genome_ids) {
+    genome_fws_map_.try_emplace(genome_id, GpuFwsFrequencyArray());
+    auto& contig_map = variant_analysis_map_[genome_id];
+    for (const auto& [contig_id, contig_ptr] : population.getMap().at(genome_id)->getMap()) contig_map.try_emplace(contig_id);
+  }
+  if (V == 0) return true;
+
+  DevicePopulation dev;
+  dev.handle = kgx_population_create(G, V);
+  if (!dev.handle) {
+    ExecEnv::log().error("GpuAlleleAnalysis; kgx_population_create failed: {}", kgx_last_error());
+    return false;
+  }
+  if (kgx_population_load_dosage2(dev.handle, flat.packed.data(), flat.row_bytes, 0, V) != KGX_OK) {
+    ExecEnv::log().error("GpuAlleleAnalysis; upload failed: {}", kgx_last_error());
+    return false;
+  }
+
+  // ---- K2: CalcFWS::updateVariantFWSMap -- summaryByVariant for every variant ------------------
+  std::vector<uint32_t> by_variant(V * 4);
+  if (kgx_allele_count_by_locus(dev.handle, by_variant.data()) != KGX_OK) {
+    ExecEnv::log().error("GpuAlleleAnalysis; allele count sweep failed: {}", kgx_last_error());
+    return false;
+  }
+  for (uint64_t v = 0; v < V; ++v) {
+    AlleleSummmary summary;
+    summary.referenceHomozygous_ = by_variant[v * 4 + 0];
+    summary.minorHeterozygous_ = by_variant[v * 4 + 1];
+    summary.minorHomozygous_ = by_variant[v * 4 + 2];
+    if (by_variant[v * 4 + 3] != 0)   // the reference's warning (kgl_variant_db_variant.cpp:158-161,168-174)
+      ExecEnv::log().warn("GpuAlleleAnalysis; Variant: {} has {} genomes with a non diploid allele count", flat.rows[v].hgvs, by_variant[v * 4 + 3]);
+    variant_fws_map_[flat.rows[v].hgvs] += summary;
+  }
+
+  // ---- K3: CalcFWS::updateGenomeFWSMap over the 11 allele-frequency bins -----------------------
+  {
+    std::vector<uint8_t> bin_of_variant(V);
+    for (uint64_t v = 0; v < V; ++v) bin_of_variant[v] = gpu::fwsBinOfFrequency(flat.rows[v].info_af);
+    std::vector<uint64_t> by_genome(G * gpu::FWS_FREQUENCY_ARRAY_SIZE * 4);
+    if (kgx_count_by_genome_binned(dev.handle, bin_of_variant.data(), gpu::FWS_FREQUENCY_ARRAY_SIZE, by_genome.data()) != KGX_OK) {
+      ExecEnv::log().error("GpuAlleleAnalysis; by-genome sweep failed: {}", kgx_last_error());
+      return false;
+    }
+    for (uint64_t g = 0; g < G; ++g) {
+      auto& freq_array = genome_fws_map_[flat.genome_ids[g]];
+      for (size_t b = 0; b < gpu::FWS_FREQUENCY_ARRAY_SIZE; ++b) {
+        const uint64_t* c = &by_genome[(g * gpu::FWS_FREQUENCY_ARRAY_SIZE + b) * 4];
+        AlleleSummmary summary;
+        summary.referenceHomozygous_ = c[0];
+        summary.minorHeterozygous_ = c[1];
+        summary.minorHomozygous_ = c[2];
+        freq_array[b] += summary;
+      }
+    }
+  }
+
+  // ---- K3 + K8: HeteroHomoZygous::updateVariantAnalysisType per genome x contig ---------------
+  {
+    std::map<ContigId_t, uint32_t> contig_index;
+    for (const auto& row : flat.rows) contig_index.try_emplace(row.contig, 0);
+    uint32_t n_contigs = 0;
+    std::vector<ContigId_t> contig_ids;
+    for (auto& [contig_id, index] : contig_index) { index = n_contigs++; contig_ids.push_back(contig_id); }
+    if (n_contigs * 4 > 254) {
+      ExecEnv::log().error("GpuAlleleAnalysis; {} contigs exceed the 63 supported by the binned by-genome sweep", n_contigs);
+      return false;
+    }
+    // Offsets holding >= 2 distinct variants are adjacent rows (same "contig:g.offset" prefix in HGVS order).
+    std::vector<uint32_t> first_row, n_rows, group_bin;
+    std::vector<uint8_t> compound(V, 0);
+    for (uint64_t v = 0; v < V;) {
+      uint64_t e = v + 1;
+      while (e < V && flat.rows[e].offset == flat.rows[v].offset && flat.rows[e].contig == flat.rows[v].contig) ++e;
+      if (e - v >= 2) {
+        first_row.push_back(static_cast<uint32_t>(v));
+        n_rows.push_back(static_cast<uint32_t>(e - v));
+        group_bin.push_back(contig_index.at(flat.rows[v].contig));
+        for (uint64_t r = v; r < e; ++r) compound[r] = 1;
+      }
+      v = e;
+    }
+    // bin = contig*4 + is_snp*2 + compound: dosage-weighted totals per class of row
+    std::vector<uint8_t> bin_of_variant(V);
+    for (uint64_t v = 0; v < V; ++v)
+      bin_of_variant[v] = static_cast<uint8_t>(contig_index.at(flat.rows[v].contig) * 4 + (flat.rows[v].is_snp ? 2 : 0) + compound[v]);
+    const uint32_t n_bins = n_contigs * 4;
+    std::vector<uint64_t> by_genome(G * n_bins * 4);
+    if (kgx_count_by_genome_binned(dev.handle, bin_of_variant.data(), n_bins, by_genome.data()) != KGX_OK) {
+      ExecEnv::log().error("GpuAlleleAnalysis; by-genome (contig) sweep failed: {}", kgx_last_error());
+      return false;
+    }
+    std::vector<uint64_t> compound_counts(G * n_contigs * 3);
+    if (kgx_compound_offsets(dev.handle, first_row.data(), n_rows.data(), group_bin.data(), first_row.size(), n_contigs,
+                             compound_counts.data()) != KGX_OK) {
+      ExecEnv::log().error("GpuAlleleAnalysis; compound offset sweep failed: {}", kgx_last_error());
+      return false;
+    }
+    // exact copy numbers of the (rare) non-diploid cells: code 3 counted them as nothing in het/hom
+    std::vector<uint64_t> extra_total(G * n_contigs, 0), extra_snp(G * n_contigs, 0);
+    for (const auto& cell : flat.non_diploid) {
+      const uint32_t c = contig_index.at(flat.rows[cell.row].contig);
+      extra_total[cell.genome * n_contigs + c] += cell.dosage;
+      if (flat.rows[cell.row].is_snp) extra_snp[cell.genome * n_contigs + c] += cell.dosage;
+    }
+    for (uint64_t g = 0; g < G; ++g) {
+      auto& contig_map = variant_analysis_map_[flat.genome_ids[g]];
+      for (uint32_t c = 0; c < n_contigs; ++c) {
+        VariantAnalysisType& record = contig_map[contig_ids[c]];
+        uint64_t copies_snp = 0, copies_indel = 0;
+        for (uint32_t cls = 0; cls < 4; ++cls) {
+          const uint64_t* k = &by_genome[(g * n_bins + c * 4 + cls) * 4];   // refHom, het, hom, nonDiploid
+          const uint64_t copies = k[1] + 2 * k[2];
+          if (cls & 2) copies_snp += copies; else copies_indel += copies;
+          if ((cls & 1) == 0) {   // offsets with a single distinct variant: 1 copy -> (A;a), >= 2 copies -> one unique "homozygous" alt
+            record.heterozygous_reference_minor_alleles_ += k[1];
+            record.homozygous_minor_alleles_ += k[2] + k[3];
+          }
+        }
+        const uint64_t x_total = extra_total[g * n_contigs + c], x_snp = extra_snp[g * n_contigs + c];
+        record.snp_count_ += copies_snp + x_snp;
+        record.indel_count_ += copies_indel + (x_total - x_snp);
+        record.total_variants_ += copies_snp + copies_indel + x_total;
+        const uint64_t* k8 = &compound_counts[(g * n_contigs + c) * 3];
+        record.heterozygous_reference_minor_alleles_ += k8[0];
+        record.homozygous_minor_alleles_ += k8[1];
+        record.heterozygous_minor_alleles_ += k8[2];
+        // homozygous_reference_alleles_ is never incremented by the reference.
+      }
+    }
+  }
+  return true;
+}
+
+bool kga::GpuAlleleAnalysis::iterationAnalysis() {
+  ExecEnv::log().info("Iteration Analysis called for Analysis Id: {}", ident());
+  return true;
+}
+
+bool kga::GpuAlleleAnalysis::finalizeAnalysis() {
+  ExecEnv::log().info("Finalize Analysis called for Analysis Id: {}", ident());
+  bool ok = writeVariantResults(joinPath(work_directory_, variant_file_));
+  ok = writeGenomeResults(joinPath(work_directory_, genome_file_)) && ok;
+  ok = writeHetHomResults(joinPath(work_directory_, hethom_file_)) && ok;
+  return ok;
+}
+
+double kga::GpuAlleleAnalysis::wrightsInbreeding(const VariantAnalysisType& location, const VariantAnalysisType& genome) {
+  double wrights_inbreeding{0.0};
+  if (location.total_variants_ > 0 and genome.total_variants_ > 0) {
+    const double expected = static_cast<double>(location.heterozygous_minor_alleles_ + location.heterozygous_reference_minor_alleles_) /
+                            static_cast<double>(location.total_variants_);
+    const double observed = static_cast<double>(genome.heterozygous_minor_alleles_ + genome.heterozygous_reference_minor_alleles_) /
+                            static_cast<double>(genome.total_variants_);
+    wrights_inbreeding = (expected - observed) / expected;
+  }
+  return wrights_inbreeding;
+}
+
+// Column layout of CalcFWS::writeVariantResults (kga_analysis_PfEMP_FWS.cpp:235-309).
+bool kga::GpuAlleleAnalysis::writeVariantResults(const std::string& file_name) const {
+  std::ofstream out(file_name);
+  if (!out.good()) {
+    ExecEnv::log().error("GpuAlleleAnalysis::writeVariantResults; Unable to open results file: {}", file_name);
+    return false;
+  }
+  out << "Variant" << CSV_DELIMITER_ << "Hom/Het" << CSV_DELIMITER_ << "Minor Hom/Het" << CSV_DELIMITER_ << "Genome Count"
+      << CSV_DELIMITER_ << "Hom Ref (A;A)" << CSV_DELIMITER_ << "Het Ref Minor (A;a)" << CSV_DELIMITER_ << "Hom Minor (a;a)" << '\n';
+  for (const auto& [hgvs, s] : variant_fws_map_) {
+    const size_t het = s.minorHeterozygous_;
+    const double hom_het = het > 0 ? static_cast<double>(s.minorHomozygous_ + s.referenceHomozygous_) / static_cast<double>(het) : 0.0;
+    const double minor_hom_het = het > 0 ? static_cast<double>(s.minorHomozygous_) / static_cast<double>(het) : 0.0;
+    out << hgvs << CSV_DELIMITER_ << hom_het << CSV_DELIMITER_ << minor_hom_het << CSV_DELIMITER_ << (s.minorHeterozygous_ + s.minorHomozygous_)
+        << CSV_DELIMITER_ << s.referenceHomozygous_ << CSV_DELIMITER_ << s.minorHeterozygous_ << CSV_DELIMITER_ << s.minorHomozygous_ << '\n';
+  }
+  return out.good();
+}
+
+// Column layout of CalcFWS::writeGenomeResults (kga_analysis_PfEMP_FWS.cpp:147-232) without the Pf7 FWS join.
+bool kga::GpuAlleleAnalysis::writeGenomeResults(const std::string& file_name) const {
+  std::ofstream out(file_name);
+  if (!out.good()) {
+    ExecEnv::log().error("GpuAlleleAnalysis::writeGenomeResults; Unable to open results file: {}", file_name);
+    return false;
+  }
+  out << "Genome";
+  for (size_t i = 0; i < gpu::FWS_FREQUENCY_ARRAY_SIZE; ++i)
+    out << CSV_DELIMITER_ << "LowerFreq" << CSV_DELIMITER_ << "UpperFreq" << CSV_DELIMITER_ << "Hom/Het" << CSV_DELIMITER_ << "Minor Hom/Het"
+        << CSV_DELIMITER_ << "Variant Count" << CSV_DELIMITER_ << "Hom Ref (A;A)" << CSV_DELIMITER_ << "Het Ref Minor (A;a)"
+        << CSV_DELIMITER_ << "Hom Minor (a;a)";
+  out << '\n';
+  for (const auto& [genome_id, freq_array] : genome_fws_map_) {
+    out << genome_id;
+    for (size_t i = 0; i < gpu::FWS_FREQUENCY_ARRAY_SIZE; ++i) {
+      const AlleleSummmary& s = freq_array[i];
+      const size_t het = s.minorHeterozygous_;
+      const double hom_het = het > 0 ? static_cast<double>(s.minorHomozygous_ + s.referenceHomozygous_) / static_cast<double>(het) : 0.0;
+      const double minor_hom_het = het > 0 ? static_cast<double>(s.minorHomozygous_) / static_cast<double>(het) : 0.0;
+      const auto [lower_range, upper_range] = gpu::fwsBinRange(i);
+      out << CSV_DELIMITER_ << lower_range << CSV_DELIMITER_ << upper_range << CSV_DELIMITER_ << hom_het << CSV_DELIMITER_ << minor_hom_het
+          << CSV_DELIMITER_ << (s.minorHeterozygous_ + s.minorHomozygous_) << CSV_DELIMITER_ << s.referenceHomozygous_
+          << CSV_DELIMITER_ << s.minorHeterozygous_ << CSV_DELIMITER_ << s.minorHomozygous_;
+    }
+    out << '\n';
+  }
+  return out.good();
+}
+
+// One line per genome x contig with the VariantAnalysisType counters and Wright's F_IS against the
+// whole-population aggregate of the contig.
+bool kga::GpuAlleleAnalysis::writeHetHomResults(const std::string& file_name) const {
+  std::ofstream out(file_name);
+  if (!out.good()) {
+    ExecEnv::log().error("GpuAlleleAnalysis::writeHetHomResults; Unable to open results file: {}", file_name);
+    return false;
+  }
+  std::map<std::string, VariantAnalysisType> aggregate;
+  for (const auto& [genome_id, contig_map] : variant_analysis_map_)
+    for (const auto& [contig_id, r] : contig_map) {
+      VariantAnalysisType& a = aggregate[contig_id];
+      a.total_variants_ += r.total_variants_;
+      a.heterozygous_reference_minor_alleles_ += r.heterozygous_reference_minor_alleles_;
+      a.homozygous_minor_alleles_ += r.homozygous_minor_alleles_;
+      a.heterozygous_minor_alleles_ += r.heterozygous_minor_alleles_;
+      a.snp_count_ += r.snp_count_;
+      a.indel_count_ += r.indel_count_;
+    }
+  out << "Genome" << CSV_DELIMITER_ << "Contig" << CSV_DELIMITER_ << "Variant Count" << CSV_DELIMITER_ << "SNP" << CSV_DELIMITER_ << "Indel"
+      << CSV_DELIMITER_ << "Hom Ref (A;A)" << CSV_DELIMITER_ << "Het Ref Minor (A;a)" << CSV_DELIMITER_ << "Hom Minor (a;a)"
+      << CSV_DELIMITER_ << "Het Diff Minor (a;b)" << CSV_DELIMITER_ << "FIS" << '\n';
+  for (const auto& [genome_id, contig_map] : variant_analysis_map_)
+    for (const auto& [contig_id, r] : contig_map)
+      out << genome_id << CSV_DELIMITER_ << contig_id << CSV_DELIMITER_ << r.total_variants_ << CSV_DELIMITER_ << r.snp_count_
+          << CSV_DELIMITER_ << r.indel_count_ << CSV_DELIMITER_ << r.homozygous_reference_alleles_ << CSV_DELIMITER_
+          << r.heterozygous_reference_minor_alleles_ << CSV_DELIMITER_ << r.homozygous_minor_alleles_ << CSV_DELIMITER_
+          << r.heterozygous_minor_alleles_ << CSV_DELIMITER_ << wrightsInbreeding(aggregate.at(contig_id), r) << '\n';
+  return out.good();
+}

@@ -1,0 +1,126 @@
+#include "kgx_flatten.h"
+
+#include <algorithm>
+#include <cmath>
+#include <limits>
+#include <map>
+#include <thread>
+#include <unordered_map>
+
+namespace kellerberrin::genome::analysis::gpu {
+
+std::pair<double, double> fwsBinRange(size_t bin) {
+  static const double edges[FWS_FREQUENCY_ARRAY_SIZE + 1] = {0.0, 0.05, 0.10, 0.15, 0.20, 0.25, 0.30, 0.35, 0.40, 0.45, 0.5, 1.0};
+  if (bin >= FWS_FREQUENCY_ARRAY_SIZE) return {0.0, 0.0};
+  return {edges[bin], edges[bin + 1]};
+}
+
+uint8_t fwsBinOfFrequency(float info_af) {
+  if (std::isnan(info_af)) return FWS_NO_BIN;   // missing: passes lower AND upper filter -> NOT(upper) rejects it
+  const double af = static_cast<double>(info_af);
+  for (size_t b = 0; b < FWS_FREQUENCY_ARRAY_SIZE; ++b) {
+    const auto [lo, hi] = fwsBinRange(b);
+    if (af >= lo && !(af >= hi)) return static_cast<uint8_t>(b);
+  }
+  return FWS_NO_BIN;
+}
+
+static float infoAF(const Variant& variant) {
+  // What P7FrequencyFilter reads (kgl_variant_filter_Pf7.cpp:28-44): the "AF" vector, one value per alt.
+  auto info_opt = InfoEvidenceAnalysis::getTypedInfoData<std::vector<double>>(variant, "AF");
+  if (!info_opt) return std::numeric_limits<float>::quiet_NaN();
+  const std::vector<double>& v = info_opt.value();
+  const size_t alt_count = variant.evidence().altVariantCount();
+  const size_t alt_index = variant.evidence().altVariantIndex();
+  if (v.size() != alt_count || v.size() <= alt_index) return std::numeric_limits<float>::infinity();   // filter errors out: in no bin
+  return static_cast<float>(v[alt_index]);
+}
+
+FlatPopulation flattenPopulation(const PopulationDB& population, size_t threads) {
+  FlatPopulation flat;
+  if (threads == 0) threads = std::max<size_t>(std::thread::hardware_concurrency(), 2) - 1;
+
+  // Row index: distinct HGVS in std::map order, first Variant seen kept (PopulationDB::uniqueVariants,
+  // kgl_variant_db_population.cpp:133-161).  Shared Variant objects (one per record/alt/phase in the
+  // 1000-Genomes parser) are recognised by address so that HGVS is formatted once per object, not per visit.
+  std::map<std::string, std::shared_ptr<const Variant>> unique;
+  std::unordered_map<const Variant*, const std::string*> seen;
+  for (const auto& [genome_id, genome_ptr] : population.getMap()) {
+    flat.genome_ids.push_back(genome_id);
+    for (const auto& [contig_id, contig_ptr] : genome_ptr->getMap())
+      for (const auto& [offset, offset_ptr] : contig_ptr->getMap())
+        for (const auto& variant_ptr : offset_ptr->getVariantArray()) {
+          ++flat.variant_objects;
+          if (seen.count(variant_ptr.get())) continue;
+          auto it = unique.try_emplace(variant_ptr->HGVS(), variant_ptr).first;
+          seen.emplace(variant_ptr.get(), &it->first);
+        }
+  }
+  std::unordered_map<const Variant*, uint32_t> row_of;
+  row_of.reserve(seen.size());
+  {
+    std::unordered_map<const std::string*, uint32_t> index_of_key;
+    index_of_key.reserve(unique.size());
+    flat.rows.reserve(unique.size());
+    uint32_t index = 0;
+    for (const auto& [hgvs, variant_ptr] : unique) {
+      VariantRow row;
+      row.hgvs = hgvs;
+      row.contig = variant_ptr->contigId();
+      row.offset = variant_ptr->offset();
+      row.is_snp = variant_ptr->isSNP();
+      row.info_af = infoAF(*variant_ptr);
+      row.variant = variant_ptr;
+      flat.rows.push_back(std::move(row));
+      index_of_key.emplace(&hgvs, index++);
+    }
+    for (const auto& [ptr, key] : seen) row_of.emplace(ptr, index_of_key.at(key));
+  }
+
+  const size_t G = flat.genome_ids.size();
+  const size_t V = flat.rows.size();
+  flat.row_bytes = (G + 3) / 4;
+  flat.packed.assign(V * flat.row_bytes, 0);
+
+  // Dosage = number of Variant objects with that HGVS in the genome (kgl_variant_db_variant.cpp:103).
+  // Workers own whole bytes (4 consecutive genomes), so no two threads touch the same byte.
+  std::vector<std::shared_ptr<const GenomeDB>> genomes;
+  genomes.reserve(G);
+  for (const auto& [genome_id, genome_ptr] : population.getMap()) genomes.push_back(genome_ptr);
+  const size_t quads = (G + 3) / 4;
+  threads = std::max<size_t>(1, std::min(threads, quads));
+  std::vector<std::vector<NonDiploidCell>> overflow(threads);
+  auto worker = [&](size_t t) {
+    std::vector<uint32_t> touched;
+    std::vector<uint16_t> count(V, 0);
+    for (size_t q = t; q < quads; q += threads) {
+      for (size_t j = 0; j < 4 && q * 4 + j < G; ++j) {
+        const size_t g = q * 4 + j;
+        touched.clear();
+        for (const auto& [contig_id, contig_ptr] : genomes[g]->getMap())
+          for (const auto& [offset, offset_ptr] : contig_ptr->getMap())
+            for (const auto& variant_ptr : offset_ptr->getVariantArray()) {
+              const uint32_t r = row_of.at(variant_ptr.get());
+              if (count[r]++ == 0) touched.push_back(r);
+            }
+        for (uint32_t r : touched) {
+          const uint32_t d = count[r];
+          count[r] = 0;
+          flat.packed[static_cast<size_t>(r) * flat.row_bytes + q] |= static_cast<uint8_t>((d > 2 ? 3u : d) << (2 * j));
+          if (d > 2) overflow[t].push_back({r, static_cast<uint32_t>(g), d});
+        }
+      }
+    }
+  };
+  std::vector<std::thread> pool;
+  for (size_t t = 1; t < threads; ++t) pool.emplace_back(worker, t);
+  worker(0);
+  for (auto& th : pool) th.join();
+  for (auto& o : overflow) flat.non_diploid.insert(flat.non_diploid.end(), o.begin(), o.end());
+  std::sort(flat.non_diploid.begin(), flat.non_diploid.end(), [](const NonDiploidCell& a, const NonDiploidCell& b) {
+    return a.row != b.row ? a.row < b.row : a.genome < b.genome;
+  });
+  return flat;
+}
+
+}  // namespace kellerberrin::genome::analysis::gpu

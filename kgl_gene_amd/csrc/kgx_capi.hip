@@ -562,4 +562,54 @@ int kgx_count_by_genome_binned(kgx_pop* pop, const uint8_t* bin_of_variant, uint
   return count_by_genome_impl(pop, bin_of_variant, n_bins, out);
 }
 
+int kgx_compound_offsets(kgx_pop* pop, const uint32_t* first_row, const uint32_t* n_rows, const uint32_t* bin,
+                         uint64_t n_groups, uint32_t n_bins, uint64_t* out) {
+  if (int rc = require_device()) return rc;
+  if (!pop || !out || (n_groups && (!first_row || !n_rows || !bin))) return fail(KGX_EINVAL, "null argument");
+  if (n_bins == 0) return fail(KGX_EINVAL, "n_bins must be > 0");
+  const uint64_t G = pop->n_genomes;
+  const uint64_t cells = G * n_bins * 3;
+  std::memset(out, 0, cells * sizeof(uint64_t));
+  if (n_groups == 0) return KGX_OK;
+  std::vector<OffsetGroup> groups(n_groups);
+  for (uint64_t i = 0; i < n_groups; ++i) {
+    if (n_rows[i] > 15) return fail(KGX_EINVAL, "group %llu has %u rows; at most 15 distinct variants per offset are supported",
+                                    (unsigned long long)i, n_rows[i]);
+    if (static_cast<uint64_t>(first_row[i]) + n_rows[i] > pop->n_variants || bin[i] >= n_bins)
+      return fail(KGX_EINVAL, "group %llu out of range", (unsigned long long)i);
+    groups[i] = OffsetGroup{first_row[i], n_rows[i], bin[i], 0};
+  }
+  OffsetGroup* d_groups = nullptr;
+  unsigned long long* d_acc = nullptr;
+  int rc = KGX_OK;
+  if (hipMalloc(&d_groups, n_groups * sizeof(OffsetGroup)) != hipSuccess || hipMalloc(&d_acc, cells * sizeof(unsigned long long)) != hipSuccess) {
+    (void)hipGetLastError();
+    rc = fail(KGX_ENOMEM, "compound_offsets: hipMalloc failed");
+  }
+  if (rc == KGX_OK) {
+    const uint64_t cols = (G + 15) / 16;
+    const uint32_t gx = static_cast<uint32_t>((cols + kBlock - 1) / kBlock);
+    uint64_t slices = (static_cast<uint64_t>(g_state.compute_units) * 8 + gx - 1) / gx;
+    if (slices > n_groups) slices = n_groups;
+    if (slices > 65535) slices = 65535;
+    const uint64_t per_slice = (n_groups + slices - 1) / slices;
+    const uint32_t gy = static_cast<uint32_t>((n_groups + per_slice - 1) / per_slice);
+    if (hipMemsetAsync(d_acc, 0, cells * sizeof(unsigned long long), g_state.stream) != hipSuccess ||
+        hipMemcpyAsync(d_groups, groups.data(), n_groups * sizeof(OffsetGroup), hipMemcpyHostToDevice, g_state.stream) != hipSuccess) {
+      rc = fail(KGX_EHIP, "compound_offsets: upload failed");
+    } else {
+      hipLaunchKernelGGL(k_compound_offsets, dim3(gx, gy), dim3(kBlock), 0, g_state.stream,
+                         reinterpret_cast<const uint32_t*>(pop->d_rows), pop->pitch / 4, G, d_groups, n_groups, per_slice,
+                         n_bins, d_acc);
+      if (hipGetLastError() != hipSuccess ||
+          hipMemcpyAsync(out, d_acc, cells * sizeof(unsigned long long), hipMemcpyDeviceToHost, g_state.stream) != hipSuccess ||
+          hipStreamSynchronize(g_state.stream) != hipSuccess)
+        rc = fail(KGX_EHIP, "compound_offsets: kernel or readback failed");
+    }
+  }
+  if (d_groups) (void)hipFree(d_groups);
+  if (d_acc) (void)hipFree(d_acc);
+  return rc;
+}
+
 }  // extern "C"

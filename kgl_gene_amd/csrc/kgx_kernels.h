@@ -341,6 +341,87 @@ k_finish_by_genome(const unsigned long long* __restrict__ acc, const unsigned lo
 }
 
 // ---------------------------------------------------------------------------------------------
+// K8  compound offsets of HeteroHomoZygous::updateVariantAnalysisType
+// (kga_analytic/kga_PfEMP/kga_analysis_PfEMP_heterozygous.cpp:61-105).  At a contig offset where the
+// population holds k >= 2 distinct variants (adjacent rows), a genome with n variant copies there counts
+//   n == 1 : heterozygous_reference_minor_alleles_ += 1
+//   n >= 2 : homozygous_minor_alleles_ += #distinct variants carried   (UniqueUnphasedFilter; the
+//            reference's quirk: every distinct alt counts, not only homozygous ones)
+//            heterozygous_minor_alleles_ += #variants carried exactly once (HeterozygousFilter)
+// Offsets with a single row need no kernel: they follow from the by-genome sweep (K3).
+// A lane owns 16 genomes (one dword per row) and keeps their counters in registers; a workgroup walks a
+// slice of the groups; results are added to acc[g][bin][3] = {het_ref_minor, hom_minor, het_minor} with
+// integer atomics.  Reads only the rows of compound offsets.
+// ---------------------------------------------------------------------------------------------
+struct OffsetGroup {
+  uint32_t first_row;
+  uint32_t n_rows;
+  uint32_t bin;        // output bin (contig index)
+  uint32_t pad;
+};
+
+__global__ void __launch_bounds__(kBlock)
+k_compound_offsets(const uint32_t* __restrict__ rows, uint64_t dwords_per_row, uint64_t n_genomes,
+                   const OffsetGroup* __restrict__ groups, uint64_t n_groups, uint64_t groups_per_slice,
+                   uint32_t n_bins, unsigned long long* __restrict__ acc) {
+  const uint64_t col = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x;   // dword column = 16 genomes
+  if (col * 16 >= n_genomes) return;
+  const uint64_t g_begin = static_cast<uint64_t>(blockIdx.y) * groups_per_slice;
+  const uint64_t g_end = g_begin + groups_per_slice < n_groups ? g_begin + groups_per_slice : n_groups;
+  uint32_t het_ref[16], hom_minor[16], het_minor[16];
+#pragma unroll
+  for (int j = 0; j < 16; ++j) het_ref[j] = hom_minor[j] = het_minor[j] = 0;
+  uint32_t current_bin = g_begin < g_end ? groups[g_begin].bin : 0;
+
+  auto flush = [&](uint32_t bin) {
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      const uint64_t g = col * 16 + j;
+      if (g < n_genomes) {
+        unsigned long long* a = acc + (g * n_bins + bin) * 3;
+        if (het_ref[j]) atomicAdd(a + 0, static_cast<unsigned long long>(het_ref[j]));
+        if (hom_minor[j]) atomicAdd(a + 1, static_cast<unsigned long long>(hom_minor[j]));
+        if (het_minor[j]) atomicAdd(a + 2, static_cast<unsigned long long>(het_minor[j]));
+      }
+      het_ref[j] = hom_minor[j] = het_minor[j] = 0;
+    }
+  };
+
+  for (uint64_t gi = g_begin; gi < g_end; ++gi) {
+    const OffsetGroup grp = groups[gi];
+    if (grp.bin != current_bin) {
+      flush(current_bin);
+      current_bin = grp.bin;
+    }
+    // Field-wise sums in 2-bit fields would overflow for k > 3, so split even/odd genomes into 4-bit fields.
+    uint32_t present_e = 0, present_o = 0, single_e = 0, single_o = 0, ge2 = 0;
+    for (uint32_t r = 0; r < grp.n_rows; ++r) {
+      const uint32_t w = rows[(static_cast<uint64_t>(grp.first_row) + r) * dwords_per_row + col];
+      const uint32_t lo = w & 0x55555555u, hi = (w >> 1) & 0x55555555u;
+      const uint32_t present = lo | hi, single = lo & ~hi;
+      present_e += present & 0x11111111u;
+      present_o += (present >> 2) & 0x11111111u;
+      single_e += single & 0x11111111u;
+      single_o += (single >> 2) & 0x11111111u;
+      ge2 |= hi;
+    }
+    if ((present_e | present_o) == 0) continue;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      // genome j of the dword sits in bits 2j..2j+1: even j -> nibble j/2 of *_e, odd j -> nibble j/2 of *_o
+      const uint32_t np = ((j & 1) ? present_o : present_e) >> (4 * (j >> 1)) & 0xFu;
+      const uint32_t ns = ((j & 1) ? single_o : single_e) >> (4 * (j >> 1)) & 0xFu;
+      const uint32_t two = (ge2 >> (2 * j)) & 1u;
+      const bool n_ge2 = two || np >= 2;
+      het_ref[j] += (!n_ge2 && np == 1) ? 1u : 0u;
+      hom_minor[j] += n_ge2 ? np : 0u;
+      het_minor[j] += n_ge2 ? ns : 0u;
+    }
+  }
+  flush(current_bin);
+}
+
+// ---------------------------------------------------------------------------------------------
 // Flattening helpers.
 // ---------------------------------------------------------------------------------------------
 

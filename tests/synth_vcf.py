@@ -49,3 +49,57 @@ def variant_rows_in_reference_order(vdb: oa.VariantDB, rec: oa.Records):
     rec_idx, alt_idx = vdb.variant_keys()
     first_row = np.concatenate([[0], np.cumsum(rec.n_alts.astype(np.int64))[:-1]])
     return first_row[rec_idx.astype(np.int64)] + alt_idx.astype(np.int64)
+
+
+def multiallelic_block(G, L, rng_seed=11, contig="chr1", indel_frac=0.15, missing_af_frac=0.02, dup_records=2):
+    """Random mixed SNP/indel multiallelic loci (the shape of BASELINE config 4) as (records, gt[L][G][2]).
+
+    ~70/20/10 % of loci have 1/2/3 alts; some alts are indels; a few AF values are missing; `dup_records`
+    loci are repeated as a second record at the same offset (the only way a genome reaches > 2 copies)."""
+    rng = np.random.default_rng(rng_seed)
+    offsets, refs, alts, afs = [], [], [], []
+    pos = 0
+    bases = "ACGT"
+    for _ in range(L):
+        pos += int(rng.integers(1, 51))
+        n_alt = int(rng.choice([1, 2, 3], p=[0.7, 0.2, 0.1]))
+        ref = bases[rng.integers(0, 4)]
+        cand = [b for b in bases if b != ref]
+        rng.shuffle(cand)
+        al = []
+        for a in range(n_alt):
+            if rng.random() < indel_frac:
+                if rng.random() < 0.5:
+                    al.append(ref + "".join(bases[i] for i in rng.integers(0, 4, int(rng.integers(1, 5)))))   # insertion
+                else:
+                    al.append("")   # placeholder: deletion needs a longer REF, patched below
+            else:
+                al.append(cand[a])
+        if "" in al:
+            ref_long = ref + "".join(bases[i] for i in rng.integers(0, 4, int(rng.integers(1, 5))))
+            al = [ref if x == "" else (x + ref_long[1:] if len(x) == 1 else x + ref_long[1:]) for x in al]
+            ref = ref_long
+        # de-duplicate alts within the record
+        seen, al2 = set(), []
+        for x in al:
+            while x in seen or x == ref:
+                x = x + bases[rng.integers(0, 4)]
+            seen.add(x)
+            al2.append(x)
+        p = rng.uniform(0.01, 0.5, n_alt)
+        p *= min(1.0, 0.6 / p.sum())
+        af = np.tile(p.astype(np.float32).reshape(-1, 1), (1, 6))
+        af[rng.random(af.shape) < missing_af_frac] = np.nan
+        offsets.append(pos); refs.append(ref); alts.append(al2); afs.append(af)
+    for d in range(dup_records):
+        i = int(rng.integers(0, L))
+        offsets.append(offsets[i]); refs.append(refs[i]); alts.append(list(alts[i])); afs.append(afs[i].copy())
+    R = len(offsets)
+    rec = oa.Records(contig, np.array(offsets, dtype=np.uint64), refs, alts, af=afs)
+    gt = np.zeros((R, G, 2), dtype=np.uint8)
+    for r in range(R):
+        p = np.nan_to_num(afs[r][:, 5].astype(np.float64), nan=0.05)
+        probs = np.concatenate([[max(0.0, 1.0 - p.sum())], p])
+        probs /= probs.sum()
+        gt[r] = rng.choice(len(probs), size=(G, 2), p=probs).astype(np.uint8)
+    return rec, gt

@@ -1,0 +1,62 @@
+"""The C++ analysis package GpuAlleleAnalysis driven through the VirtualAnalysis surface
+(initializeAnalysis -> fileReadAnalysis -> iterationAnalysis -> finalizeAnalysis) by kgx_host_driver,
+its CSV output compared with the oracle's CalcFWS / HeteroHomoZygous restatement.  Needs a GPU."""
+import numpy as np
+import pytest
+
+from . import oracle_api as oa
+from . import records_io as rio
+from . import synth_vcf as sv
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("mode,source", [(oa.Population.UNPHASED, "Falciparum"), (oa.Population.PHASED, "Genome1000")])
+def test_gpu_allele_package_matches_oracle(tmp_path, mode, source, kgx):
+    G, L = 53, 1500
+    rec, gt = sv.multiallelic_block(G, L, rng_seed=21 + mode)
+    ids = sv.genome_ids(G, prefix="PF")
+    path = tmp_path / "pop.bin"
+    rio.write_records(path, rec, gt, ids, mode, source, population_id="Pf7")
+    res = rio.run_driver("GPU_ALLELE", tmp_path, [path])
+    assert res.returncode == 0, res.stderr
+
+    opop = sv.oracle_population(rec, gt, ids, mode)
+    variant_out, genome_out, vdb = opop.fws()
+    hgvs = [vdb.hgvs(i) for i in range(vdb.n_variants)]
+
+    # VariantFWS.csv: one line per distinct variant in lexicographic HGVS order, counts bit-exact
+    header, rows = rio.read_csv(tmp_path / "VariantFWS.csv")
+    assert header[0] == "Variant" and header[-3:] == ["Hom Ref (A;A)", "Het Ref Minor (A;a)", "Hom Minor (a;a)"]
+    assert [r[0] for r in rows] == hgvs
+    got = np.array([[int(x) for x in r[-3:]] for r in rows], dtype=np.uint64)
+    assert np.array_equal(got, variant_out)
+
+    # GenomeFWS.csv: genome-id order, 11 bins x (ref, het, hom)
+    header, rows = rio.read_csv(tmp_path / "GenomeFWS.csv")
+    assert [r[0] for r in rows] == sorted(ids)
+    got = np.array([[int(r[1 + 8 * b + 5 + k]) for b in range(11) for k in range(3)] for r in rows], dtype=np.uint64)
+    assert np.array_equal(got.reshape(len(rows), 11, 3), genome_out)
+    lows = [float(rows[0][1 + 8 * b]) for b in range(11)]
+    assert lows == [0.0, 0.05, 0.1, 0.15, 0.2, 0.25, 0.3, 0.35, 0.4, 0.45, 0.5]
+
+    # VariantStatistics.csv: HeteroHomoZygous counters per genome x contig (incl. compound offsets and > 2 copies)
+    header, rows = rio.read_csv(tmp_path / "VariantStatistics.csv")
+    want = opop.hethom(rec.contig)     # total,snp,indel,hom_minor,het_minor,het_ref_minor,hom_ref
+    got = np.array([[int(r[2]), int(r[3]), int(r[4]), int(r[7]), int(r[8]), int(r[6]), int(r[5])] for r in rows], dtype=np.uint64)
+    assert [r[0] for r in rows] == sorted(ids) and all(r[1] == rec.contig for r in rows)
+    assert np.array_equal(got, want)
+    assert want[:, 4].sum() > 0 and want[:, 2].sum() > 0      # compound offsets and indels were exercised
+    # Wright's F_IS column against the population aggregate
+    agg = want.sum(0)
+    for r, w in zip(rows, want):
+        fis = oa.lib().kgo_wrights_fis(oa._p(np.ascontiguousarray(agg)), oa._p(np.ascontiguousarray(w)))
+        assert float(r[9]) == pytest.approx(fis, rel=1e-5, abs=1e-9)      # CSV prints 6 significant digits
+
+
+def test_gpu_allele_package_disables_itself_on_bad_device(tmp_path, kgx):
+    rec, gt = sv.multiallelic_block(4, 10)
+    path = tmp_path / "pop.bin"
+    rio.write_records(path, rec, gt, sv.genome_ids(4), oa.Population.UNPHASED, "Falciparum")
+    res = rio.run_driver("GPU_ALLELE", tmp_path, [path], Device=99)
+    assert res.returncode == 1 and "initializeAnalysis failed" in res.stderr
