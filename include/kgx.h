@@ -44,7 +44,6 @@ extern "C" {
 #define KGX_ESTATE     -5   /* call order violated (e.g. genotypes not loaded)      */
 
 typedef struct kgx_pop kgx_pop;           /* 2-bit dosage population shard (K2/K3/K4/K8)      */
-typedef struct kgx_locus_set kgx_locus_set; /* sampled loci + per-locus allele tables (K5-K7)   */
 
 /* ---- library / device ------------------------------------------------------------------- */
 
@@ -145,6 +144,58 @@ int kgx_compound_offsets(kgx_pop* pop, const uint32_t* first_row, const uint32_t
 
 /* ---- K4: VariantDBVariant::populationSummary (kgl_variant_db_variant.cpp:234-279). */
 int kgx_population_summary(kgx_pop* pop, uint64_t out[4]);
+
+/* ---- inbreeding: kga_analytic/kga_inbreed on a locus-major allele-index matrix -------------------------
+ *
+ * kgx_gt8: one byte per (locus, genome).  Low nibble = the first SNP variant the genome carries at the
+ * locus, as 1 + its index in the locus's reference alt list (0 = none, 15 = a SNP alt the reference list does
+ * not hold); high nibble = the second SNP variant (0 = none); 0xFF = three or more.  Indels never enter:
+ * INBREED filters the reference population to SNP & PASS (kga_analysis_inbreed.cpp:79) and each genome's
+ * contig to SNPs (kga_analysis_inbreed_freq.cpp:436).  The order of the two nibbles is the order of the
+ * genome's OffsetDB array (front()/back() at _freq.cpp:462,476,493). */
+typedef struct kgx_gt8 kgx_gt8;
+kgx_gt8* kgx_gt8_create(uint64_t n_genomes, uint64_t n_loci);
+void     kgx_gt8_destroy(kgx_gt8* gt);
+uint64_t kgx_gt8_genomes(const kgx_gt8* gt);
+uint64_t kgx_gt8_loci(const kgx_gt8* gt);
+/* Algorithmic bytes of one frequency sweep: G*n_selected + 8*amax*n_selected + 80*G. */
+uint64_t kgx_gt8_sweep_bytes(uint64_t n_genomes, uint64_t n_selected, uint32_t amax);
+/* Host -> device.  kgx_gt8_load: genome-major source, genomes [g0,g1), row (g-g0) = n_loci bytes (transposed
+ * on the device).  kgx_gt8_load_rows: locus-major source rows [l0,l1) of n_genomes bytes at src_pitch. */
+int kgx_gt8_load(kgx_gt8* gt, const uint8_t* src, uint64_t g0, uint64_t g1);
+int kgx_gt8_load_rows(kgx_gt8* gt, const uint8_t* src, uint64_t src_pitch, uint64_t l0, uint64_t l1);
+int kgx_gt8_read_rows(const kgx_gt8* gt, uint8_t* dst, uint64_t dst_pitch, uint64_t l0, uint64_t l1);
+
+/* LocusResults (kga_analysis_inbreed_output.h:21-35) without the genome id, same field order. */
+typedef struct kgx_locus_results {
+  uint64_t major_hetero_count;  double major_hetero_freq;
+  uint64_t minor_hetero_count;  double minor_hetero_freq;
+  uint64_t minor_homo_count;    double minor_homo_freq;
+  uint64_t major_homo_count;    double major_homo_freq;
+  uint64_t total_allele_count;  double inbred_allele_sum;
+} kgx_locus_results;
+
+/* InbreedingCalculation::algoMap() (kga_analysis_inbreed_calc.h:93-117). */
+#define KGX_ALGO_RITLAND_LOCUS  0
+#define KGX_ALGO_SIMPLE         1
+#define KGX_ALGO_HALL_ME        2
+#define KGX_ALGO_LOGLIKELIHOOD  3
+
+/* K6 alone: per locus { majorAlleleFrequency, majorHom, majorHet, minorHom, minorHet } =
+ * AlleleFreqVector::alleleClassFrequencies(inbreeding) (kga_analysis_inbreed_freq.cpp:119-217) from the locus's
+ * minor allele frequencies minor_af[l][amax] (NaN = alt absent from the AlleleFreqVector); valid[l] =
+ * checkValidAlleleVector() (:61-75).  valid may be NULL. */
+int kgx_locus_class_frequencies(const double* minor_af, uint64_t n_loci, uint32_t amax, double inbreeding,
+                                double* out /* [n_loci][5] */, uint8_t* valid /* [n_loci] */);
+
+/* K5+K7: InbreedingAnalysis::processResults for genomes [g0,g1) (g0 a multiple of 4) over one locus list
+ * (kga_analysis_inbreed_diploid.cpp:98-166 -> InbreedingCalculation::process*, _calc.cpp).
+ * locus_index[n_selected]: rows of the matrix, ascending (NULL = rows 0..n_selected-1);
+ * minor_af[n_selected][amax]: super-population allele frequency of each reference alt (double(float32)), NaN = the
+ * alt is not in the locus's AlleleFreqVector; phased != 0 when the two copies of a homozygous alt carry different
+ * phases (1000-Genomes style); algorithm = KGX_ALGO_*.  out[g1-g0]. */
+int kgx_inbreed(kgx_gt8* gt, uint64_t g0, uint64_t g1, const uint32_t* locus_index, uint64_t n_selected,
+                const double* minor_af, uint32_t amax, int phased, int algorithm, kgx_locus_results* out);
 
 #ifdef __cplusplus
 }

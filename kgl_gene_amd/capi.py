@@ -61,6 +61,17 @@ _SIGNATURES = {
     "kgx_count_by_genome": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "kgx_count_by_genome_binned": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]),
     "kgx_population_summary": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "kgx_gt8_create": (C.c_void_p, [C.c_uint64, C.c_uint64]),
+    "kgx_gt8_destroy": (None, [C.c_void_p]),
+    "kgx_gt8_genomes": (C.c_uint64, [C.c_void_p]),
+    "kgx_gt8_loci": (C.c_uint64, [C.c_void_p]),
+    "kgx_gt8_sweep_bytes": (C.c_uint64, [C.c_uint64, C.c_uint64, C.c_uint32]),
+    "kgx_gt8_load": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64]),
+    "kgx_gt8_load_rows": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64]),
+    "kgx_gt8_read_rows": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64]),
+    "kgx_locus_class_frequencies": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint32, C.c_double, C.c_void_p, C.c_void_p]),
+    "kgx_inbreed": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint32, C.c_int,
+                              C.c_int, C.c_void_p]),
     "kgx_compound_offsets": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_void_p]),
 }
 
@@ -281,3 +292,69 @@ class Population:
 def allele_frequency_dev(d_counts: int, n_variants: int, total_genomes: int, d_af: int, stream: int = 0) -> None:
     check(lib().kgx_allele_frequency_dev(C.c_void_p(d_counts), n_variants, total_genomes, C.c_void_p(d_af),
                                          C.c_void_p(stream)))
+
+
+ALGORITHMS = {"RitlandLocus": 0, "Simple": 1, "HallME": 2, "Loglikelihood": 3}
+
+# numpy view of kgx_locus_results (field order of LocusResults, kga_analysis_inbreed_output.h:21-35)
+LOCUS_RESULTS_DTYPE = np.dtype([
+    ("major_hetero_count", np.uint64), ("major_hetero_freq", np.float64),
+    ("minor_hetero_count", np.uint64), ("minor_hetero_freq", np.float64),
+    ("minor_homo_count", np.uint64), ("minor_homo_freq", np.float64),
+    ("major_homo_count", np.uint64), ("major_homo_freq", np.float64),
+    ("total_allele_count", np.uint64), ("inbred_allele_sum", np.float64)])
+
+
+def locus_class_frequencies(minor_af: np.ndarray, inbreeding: float = 0.0):
+    """K6 alone: ([n][5] = p_major, majorHom, majorHet, minorHom, minorHet; valid[n])."""
+    a = np.ascontiguousarray(minor_af, dtype=np.float64)
+    n, amax = a.shape
+    out = np.zeros((n, 5), dtype=np.float64)
+    valid = np.zeros(n, dtype=np.uint8)
+    check(lib().kgx_locus_class_frequencies(ptr(a), n, amax, float(inbreeding), ptr(out), ptr(valid)))
+    return out, valid.astype(bool)
+
+
+class GenotypeMatrix:
+    """Locus-major allele-index bytes resident in HBM (opaque kgx_gt8)."""
+
+    def __init__(self, n_genomes: int, n_loci: int):
+        self._h = lib().kgx_gt8_create(int(n_genomes), int(n_loci))
+        if not self._h:
+            raise KgxError(KGX_EHIP, lib().kgx_last_error().decode(errors="replace"))
+        self.n_genomes, self.n_loci = int(n_genomes), int(n_loci)
+
+    def close(self) -> None:
+        if getattr(self, "_h", None):
+            lib().kgx_gt8_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def load_rows(self, rows: np.ndarray, l0: int = 0) -> None:
+        r = np.ascontiguousarray(rows, dtype=np.uint8)
+        check(lib().kgx_gt8_load_rows(self._h, ptr(r), r.shape[1], l0, l0 + r.shape[0]))
+
+    def load_genomes(self, by_genome: np.ndarray, g0: int = 0) -> None:
+        r = np.ascontiguousarray(by_genome, dtype=np.uint8)
+        check(lib().kgx_gt8_load(self._h, ptr(r), g0, g0 + r.shape[0]))
+
+    def read_rows(self, l0: int = 0, l1: int | None = None) -> np.ndarray:
+        l1 = self.n_loci if l1 is None else l1
+        out = np.zeros((l1 - l0, self.n_genomes), dtype=np.uint8)
+        check(lib().kgx_gt8_read_rows(self._h, ptr(out), self.n_genomes, l0, l1))
+        return out
+
+    def inbreed(self, minor_af: np.ndarray, algorithm: str, phased: bool, locus_index=None, g0: int = 0, g1: int | None = None):
+        g1 = self.n_genomes if g1 is None else g1
+        a = np.ascontiguousarray(minor_af, dtype=np.float64)
+        n_sel, amax = a.shape if a.ndim == 2 else (0, 1)
+        idx = None if locus_index is None else np.ascontiguousarray(locus_index, dtype=np.uint32)
+        out = np.zeros(g1 - g0, dtype=LOCUS_RESULTS_DTYPE)
+        check(lib().kgx_inbreed(self._h, g0, g1, None if idx is None else ptr(idx), n_sel, ptr(a), amax, int(bool(phased)),
+                                ALGORITHMS[algorithm], ptr(out)))
+        return out

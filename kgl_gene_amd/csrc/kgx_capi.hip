@@ -612,4 +612,262 @@ int kgx_compound_offsets(kgx_pop* pop, const uint32_t* first_row, const uint32_t
   return rc;
 }
 
+// ---- gt8 + inbreeding -------------------------------------------------------------------------------
+
+kgx_gt8* kgx_gt8_create(uint64_t n_genomes, uint64_t n_loci) {
+  if (require_device()) return nullptr;
+  if (n_genomes == 0) { fail(KGX_EINVAL, "n_genomes must be > 0"); return nullptr; }
+  if (n_loci > 0xFFFFFFFFull) { fail(KGX_EINVAL, "n_loci exceeds the 32-bit locus index"); return nullptr; }
+  kgx_gt8* h = new (std::nothrow) kgx_gt8();
+  if (!h) { fail(KGX_ENOMEM, "host allocation failed"); return nullptr; }
+  h->n_genomes = n_genomes;
+  h->n_loci = n_loci;
+  h->pitch = (n_genomes + 127) / 128 * 128;
+  const uint64_t bytes = h->pitch * n_loci;
+  if (bytes) {
+    if (hipMalloc(&h->d_gt, bytes) != hipSuccess) {
+      (void)hipGetLastError();
+      fail(KGX_ENOMEM, "hipMalloc of %llu bytes for the %llu x %llu genotype matrix failed", (unsigned long long)bytes,
+           (unsigned long long)n_loci, (unsigned long long)n_genomes);
+      delete h;
+      return nullptr;
+    }
+    if (hipMemsetAsync(h->d_gt, 0, bytes, g_state.stream) != hipSuccess || hipStreamSynchronize(g_state.stream) != hipSuccess) {
+      fail(KGX_EHIP, "memset of the genotype matrix failed");
+      (void)hipFree(h->d_gt);
+      delete h;
+      return nullptr;
+    }
+  }
+  return h;
+}
+
+void kgx_gt8_destroy(kgx_gt8* h) {
+  if (!h) return;
+  if (h->d_gt) (void)hipFree(h->d_gt);
+  delete h;
+}
+
+uint64_t kgx_gt8_genomes(const kgx_gt8* h) { return h ? h->n_genomes : 0; }
+uint64_t kgx_gt8_loci(const kgx_gt8* h) { return h ? h->n_loci : 0; }
+uint64_t kgx_gt8_sweep_bytes(uint64_t n_genomes, uint64_t n_selected, uint32_t amax) {
+  return n_genomes * n_selected + 8ull * amax * n_selected + 80ull * n_genomes;
+}
+
+int kgx_gt8_load(kgx_gt8* h, const uint8_t* src, uint64_t g0, uint64_t g1) {
+  if (int rc = require_device()) return rc;
+  if (!h || !src) return fail(KGX_EINVAL, "null handle or source");
+  if (g0 > g1 || g1 > h->n_genomes) return fail(KGX_EINVAL, "genome range out of bounds");
+  if (g0 == g1 || h->n_loci == 0) return KGX_OK;
+  const uint64_t L = h->n_loci;
+  uint64_t slab = (1ull << 30) / L;
+  if (slab < 1) slab = 1;
+  const uint64_t max_rows = (g1 - g0) < slab ? (g1 - g0) : slab;
+  uint8_t* d_stage = nullptr;
+  KGX_HIP_MEM(hipMalloc(&d_stage, max_rows * L));
+  int rc = KGX_OK;
+  for (uint64_t g = g0; g < g1 && rc == KGX_OK; g += slab) {
+    const uint64_t n = (g1 - g) < slab ? (g1 - g) : slab;
+    if (hipMemcpyAsync(d_stage, src + (g - g0) * L, n * L, hipMemcpyHostToDevice, g_state.stream) != hipSuccess) {
+      rc = fail(KGX_EHIP, "H2D copy of genotype bytes failed");
+      break;
+    }
+    hipLaunchKernelGGL(k_gt8_transpose, dim3(stream_grid(n * L, kBlock)), dim3(kBlock), 0, g_state.stream, d_stage, n, L, g,
+                       h->d_gt, h->pitch);
+    if (hipGetLastError() != hipSuccess || hipStreamSynchronize(g_state.stream) != hipSuccess)
+      rc = fail(KGX_EHIP, "genotype transpose kernel failed");
+  }
+  (void)hipFree(d_stage);
+  return rc;
+}
+
+int kgx_gt8_load_rows(kgx_gt8* h, const uint8_t* src, uint64_t src_pitch, uint64_t l0, uint64_t l1) {
+  if (int rc = require_device()) return rc;
+  if (!h || !src) return fail(KGX_EINVAL, "null handle or source");
+  if (l0 > l1 || l1 > h->n_loci || src_pitch < h->n_genomes) return fail(KGX_EINVAL, "bad locus range or pitch");
+  if (l0 == l1) return KGX_OK;
+  KGX_HIP(hipMemcpy2DAsync(h->d_gt + l0 * h->pitch, h->pitch, src, src_pitch, h->n_genomes, l1 - l0, hipMemcpyHostToDevice, g_state.stream));
+  KGX_HIP(hipStreamSynchronize(g_state.stream));
+  return KGX_OK;
+}
+
+int kgx_gt8_read_rows(const kgx_gt8* h, uint8_t* dst, uint64_t dst_pitch, uint64_t l0, uint64_t l1) {
+  if (int rc = require_device()) return rc;
+  if (!h || !dst) return fail(KGX_EINVAL, "null handle or destination");
+  if (l0 > l1 || l1 > h->n_loci || dst_pitch < h->n_genomes) return fail(KGX_EINVAL, "bad locus range or pitch");
+  if (l0 == l1) return KGX_OK;
+  KGX_HIP(hipMemcpy2DAsync(dst, dst_pitch, h->d_gt + l0 * h->pitch, h->pitch, h->n_genomes, l1 - l0, hipMemcpyDeviceToHost, g_state.stream));
+  KGX_HIP(hipStreamSynchronize(g_state.stream));
+  return KGX_OK;
+}
+
+int kgx_locus_class_frequencies(const double* minor_af, uint64_t n_loci, uint32_t amax, double inbreeding, double* out, uint8_t* valid) {
+  if (int rc = require_device()) return rc;
+  if (!minor_af || !out || amax == 0 || amax > 14) return fail(KGX_EINVAL, "bad arguments (amax must be 1..14)");
+  if (n_loci == 0) return KGX_OK;
+  const uint32_t stride = amax + kTableExtra;
+  double *d_in = nullptr, *d_table = nullptr;
+  uint8_t* d_valid = nullptr;
+  int rc = KGX_OK;
+  if (hipMalloc(&d_in, n_loci * amax * sizeof(double)) != hipSuccess || hipMalloc(&d_table, n_loci * stride * sizeof(double)) != hipSuccess ||
+      hipMalloc(&d_valid, n_loci) != hipSuccess) {
+    (void)hipGetLastError();
+    rc = fail(KGX_ENOMEM, "locus_class_frequencies: hipMalloc failed");
+  }
+  if (rc == KGX_OK) {
+    std::vector<double> table(n_loci * stride);
+    std::vector<uint8_t> v(n_loci);
+    if (hipMemcpyAsync(d_in, minor_af, n_loci * amax * sizeof(double), hipMemcpyHostToDevice, g_state.stream) != hipSuccess) rc = fail(KGX_EHIP, "H2D failed");
+    if (rc == KGX_OK) {
+      hipLaunchKernelGGL(k_locus_tables, dim3(stream_grid(n_loci, kBlock)), dim3(kBlock), 0, g_state.stream, d_in, n_loci, amax, inbreeding, d_table, d_valid);
+      if (hipGetLastError() != hipSuccess ||
+          hipMemcpyAsync(table.data(), d_table, table.size() * sizeof(double), hipMemcpyDeviceToHost, g_state.stream) != hipSuccess ||
+          hipMemcpyAsync(v.data(), d_valid, n_loci, hipMemcpyDeviceToHost, g_state.stream) != hipSuccess ||
+          hipStreamSynchronize(g_state.stream) != hipSuccess)
+        rc = fail(KGX_EHIP, "locus table kernel failed");
+    }
+    if (rc == KGX_OK) {
+      for (uint64_t l = 0; l < n_loci; ++l) {
+        for (int k = 0; k < 5; ++k) out[l * 5 + k] = table[l * stride + amax + k];
+        if (valid) valid[l] = v[l];
+      }
+    }
+  }
+  if (d_in) (void)hipFree(d_in);
+  if (d_table) (void)hipFree(d_table);
+  if (d_valid) (void)hipFree(d_valid);
+  return rc;
+}
+
+int kgx_inbreed(kgx_gt8* h, uint64_t g0, uint64_t g1, const uint32_t* locus_index, uint64_t n_sel, const double* minor_af,
+                uint32_t amax, int phased, int algorithm, kgx_locus_results* out) {
+  if (int rc = require_device()) return rc;
+  if (!h || !out || (n_sel && !minor_af)) return fail(KGX_EINVAL, "null argument");
+  if (g0 > g1 || g1 > h->n_genomes || (g0 & 3u)) return fail(KGX_EINVAL, "genome range must lie in the matrix and start on a multiple of 4");
+  if (amax == 0 || amax > 14) return fail(KGX_EINVAL, "amax %u outside [1,14] (4-bit allele indices)", amax);
+  if (algorithm < 0 || algorithm > 3) return fail(KGX_EINVAL, "unknown algorithm %d", algorithm);
+  if (!locus_index && n_sel > h->n_loci) return fail(KGX_EINVAL, "n_sel exceeds the locus count");
+  if (locus_index)
+    for (uint64_t i = 0; i < n_sel; ++i)
+      if (locus_index[i] >= h->n_loci) return fail(KGX_EINVAL, "locus_index[%llu] out of range", (unsigned long long)i);
+  const uint64_t n = g1 - g0;
+  if (n == 0) return KGX_OK;
+  static_assert(sizeof(kgx_locus_results) == sizeof(LocusResultsDev), "LocusResults layout");
+
+  const uint32_t stride = amax + kTableExtra;
+  const uint32_t gx = static_cast<uint32_t>(((n + 3) / 4 + kBlock - 1) / kBlock);
+  uint64_t n_seg = (static_cast<uint64_t>(g_state.compute_units) * 8 + gx - 1) / gx;
+  if (n_seg > (n_sel + 63) / 64) n_seg = (n_sel + 63) / 64;
+  if (n_seg < 1) n_seg = 1;
+  if (n_seg > 65535) n_seg = 65535;
+  const uint64_t per_seg = n_sel ? (n_sel + n_seg - 1) / n_seg : 1;
+  n_seg = n_sel ? (n_sel + per_seg - 1) / per_seg : 1;
+
+  double *d_af = nullptr, *d_table = nullptr, *d_part = nullptr, *d_sums = nullptr, *d_f = nullptr, *d_eval = nullptr;
+  uint8_t* d_valid = nullptr;
+  uint32_t* d_index = nullptr;
+  unsigned long long* d_counts = nullptr;
+  LocusResultsDev* d_out = nullptr;
+  GoldenState* d_golden = nullptr;
+  int rc = KGX_OK;
+  auto try_hip = [&](hipError_t e, int code, const char* what) {
+    if (rc == KGX_OK && e != hipSuccess) {
+      (void)hipGetLastError();
+      rc = fail(code, "kgx_inbreed: %s failed: %s", what, hipGetErrorString(e));
+    }
+  };
+  const uint64_t n_tab = n_sel ? n_sel : 1;
+  try_hip(hipMalloc(&d_af, n_tab * amax * sizeof(double)), KGX_ENOMEM, "hipMalloc(af)");
+  try_hip(hipMalloc(&d_table, n_tab * stride * sizeof(double)), KGX_ENOMEM, "hipMalloc(table)");
+  try_hip(hipMalloc(&d_valid, n_tab), KGX_ENOMEM, "hipMalloc(valid)");
+  try_hip(hipMalloc(&d_part, n_seg * n * kParts0 * sizeof(double)), KGX_ENOMEM, "hipMalloc(partials)");
+  try_hip(hipMalloc(&d_sums, n * kParts0 * sizeof(double)), KGX_ENOMEM, "hipMalloc(sums)");
+  try_hip(hipMalloc(&d_counts, n * 6 * sizeof(unsigned long long)), KGX_ENOMEM, "hipMalloc(counts)");
+  try_hip(hipMalloc(&d_f, n * sizeof(double)), KGX_ENOMEM, "hipMalloc(f)");
+  try_hip(hipMalloc(&d_eval, n * sizeof(double)), KGX_ENOMEM, "hipMalloc(eval)");
+  try_hip(hipMalloc(&d_out, n * sizeof(LocusResultsDev)), KGX_ENOMEM, "hipMalloc(out)");
+  if (locus_index && n_sel) try_hip(hipMalloc(&d_index, n_sel * sizeof(uint32_t)), KGX_ENOMEM, "hipMalloc(index)");
+  hipStream_t st = g_state.stream;
+  if (rc == KGX_OK && n_sel) {
+    try_hip(hipMemcpyAsync(d_af, minor_af, n_sel * amax * sizeof(double), hipMemcpyHostToDevice, st), KGX_EHIP, "H2D(af)");
+    if (d_index) try_hip(hipMemcpyAsync(d_index, locus_index, n_sel * sizeof(uint32_t), hipMemcpyHostToDevice, st), KGX_EHIP, "H2D(index)");
+  }
+  try_hip(hipMemsetAsync(d_counts, 0, n * 6 * sizeof(unsigned long long), st), KGX_EHIP, "memset(counts)");
+  try_hip(hipMemsetAsync(d_part, 0, n_seg * n * kParts0 * sizeof(double), st), KGX_EHIP, "memset(partials)");
+  try_hip(hipMemsetAsync(d_f, 0, n * sizeof(double), st), KGX_EHIP, "memset(f)");
+
+  const dim3 grid(gx, static_cast<uint32_t>(n_seg));
+  const uint32_t* gt32 = reinterpret_cast<const uint32_t*>(h->d_gt);
+  const uint64_t dwords_per_row = h->pitch / 4;
+  auto sweep = [&](int mode) {
+    if (n_sel == 0) return;
+    if (mode == 0)
+      hipLaunchKernelGGL((k_inbreed_sweep<0>), grid, dim3(kBlock), 0, st, gt32, dwords_per_row, g0, n, d_index, n_sel, per_seg, d_table,
+                         d_valid, amax, phased, d_f, d_counts, d_part);
+    else if (mode == 1)
+      hipLaunchKernelGGL((k_inbreed_sweep<1>), grid, dim3(kBlock), 0, st, gt32, dwords_per_row, g0, n, d_index, n_sel, per_seg, d_table,
+                         d_valid, amax, phased, d_f, d_counts, d_part);
+    else
+      hipLaunchKernelGGL((k_inbreed_sweep<2>), grid, dim3(kBlock), 0, st, gt32, dwords_per_row, g0, n, d_index, n_sel, per_seg, d_table,
+                         d_valid, amax, phased, d_f, d_counts, d_part);
+  };
+  const uint32_t lin_grid = stream_grid(n, kBlock);
+  if (rc == KGX_OK) {
+    if (n_sel) hipLaunchKernelGGL(k_locus_tables, dim3(stream_grid(n_sel, kBlock)), dim3(kBlock), 0, st, d_af, n_sel, amax, 0.0, d_table, d_valid);
+    sweep(0);
+    hipLaunchKernelGGL(k_reduce_parts, dim3(stream_grid(n * kParts0, kBlock)), dim3(kBlock), 0, st, d_part, n_seg, n * kParts0, d_sums);
+    if (algorithm == 2) {
+      // processHallME (_calc.cpp:225-307).  The reference restarts from U(0,0.5] and, through RetryCalcResult's
+      // self-comparison, always stops after 5 restarts of exactly 50 expectation steps, keeping the last; the
+      // fixed start 0.25 (the mean of its start distribution) replaces the random draw.
+      std::vector<double> f0(n, 0.25);
+      try_hip(hipMemcpyAsync(d_f, f0.data(), n * sizeof(double), hipMemcpyHostToDevice, st), KGX_EHIP, "H2D(f0)");
+      try_hip(hipStreamSynchronize(st), KGX_EHIP, "sync");
+      for (int it = 0; it < 50 && rc == KGX_OK; ++it) {
+        sweep(1);
+        hipLaunchKernelGGL(k_reduce_parts, dim3(lin_grid), dim3(kBlock), 0, st, d_part, n_seg, n, d_eval);
+        hipLaunchKernelGGL(k_hall_update, dim3(lin_grid), dim3(kBlock), 0, st, d_eval, d_counts, n, d_f);
+      }
+    } else if (algorithm == 3) {
+      // processLogLikelihood (_calc.cpp:153-216): maximise over [-1,1].  The objective is a sum of logs of
+      // clamped linear functions of F; a golden-section search on that same clamped objective replaces nlopt's
+      // Nelder-Mead (un-vendored, unpinned), to 1e-8 in F where the reference asks for 1e-6.
+      try_hip(hipMalloc(&d_golden, n * sizeof(GoldenState)), KGX_ENOMEM, "hipMalloc(golden)");
+      const double inv_phi = 0.6180339887498949;
+      GoldenState init;
+      init.a = -1.0; init.b = 1.0;
+      init.c = init.b - inv_phi * (init.b - init.a);
+      init.d = init.a + inv_phi * (init.b - init.a);
+      init.fc = init.fd = 0.0; init.last_was_c = 0; init.pad = 0;
+      std::vector<GoldenState> gs(n, init);
+      std::vector<double> f0(n, init.c);
+      try_hip(hipMemcpyAsync(d_golden, gs.data(), n * sizeof(GoldenState), hipMemcpyHostToDevice, st), KGX_EHIP, "H2D(golden)");
+      try_hip(hipMemcpyAsync(d_f, f0.data(), n * sizeof(double), hipMemcpyHostToDevice, st), KGX_EHIP, "H2D(f0)");
+      try_hip(hipStreamSynchronize(st), KGX_EHIP, "sync");
+      for (int it = 0; it < 42 && rc == KGX_OK; ++it) {
+        sweep(2);
+        hipLaunchKernelGGL(k_reduce_parts, dim3(lin_grid), dim3(kBlock), 0, st, d_part, n_seg, n, d_eval);
+        hipLaunchKernelGGL(k_golden_step, dim3(lin_grid), dim3(kBlock), 0, st, d_golden, d_eval, n, it < 2 ? it : 2, d_f);
+      }
+      // coefficient = the better interior point of the final bracket
+      if (rc == KGX_OK) {
+        try_hip(hipMemcpyAsync(gs.data(), d_golden, n * sizeof(GoldenState), hipMemcpyDeviceToHost, st), KGX_EHIP, "D2H(golden)");
+        try_hip(hipStreamSynchronize(st), KGX_EHIP, "sync");
+        for (uint64_t g = 0; g < n; ++g) f0[g] = 0.5 * (gs[g].a + gs[g].b);
+        try_hip(hipMemcpyAsync(d_f, f0.data(), n * sizeof(double), hipMemcpyHostToDevice, st), KGX_EHIP, "H2D(f)");
+        try_hip(hipStreamSynchronize(st), KGX_EHIP, "sync");
+      }
+    }
+    hipLaunchKernelGGL(k_finish_inbreed, dim3(lin_grid), dim3(kBlock), 0, st, d_counts, d_sums, n, algorithm, d_f, d_out);
+    try_hip(hipGetLastError(), KGX_EHIP, "kernel launch");
+    try_hip(hipMemcpyAsync(out, d_out, n * sizeof(LocusResultsDev), hipMemcpyDeviceToHost, st), KGX_EHIP, "D2H(out)");
+    try_hip(hipStreamSynchronize(st), KGX_EHIP, "stream synchronize");
+  }
+  for (void* p : {static_cast<void*>(d_af), static_cast<void*>(d_table), static_cast<void*>(d_valid), static_cast<void*>(d_part),
+                  static_cast<void*>(d_sums), static_cast<void*>(d_counts), static_cast<void*>(d_f), static_cast<void*>(d_eval),
+                  static_cast<void*>(d_out), static_cast<void*>(d_index), static_cast<void*>(d_golden)})
+    if (p) (void)hipFree(p);
+  return rc;
+}
+
 }  // extern "C"

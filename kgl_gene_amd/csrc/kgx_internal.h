@@ -18,6 +18,13 @@ struct kgx_pop {
   bool has_af = false;
 };
 
+struct kgx_gt8 {
+  uint64_t n_genomes = 0;
+  uint64_t n_loci = 0;
+  uint64_t pitch = 0;            // bytes per locus row, multiple of 128
+  uint8_t* d_gt = nullptr;       // [n_loci][pitch]
+};
+
 namespace kgx {
 
 struct State {

@@ -422,6 +422,301 @@ k_compound_offsets(const uint32_t* __restrict__ rows, uint64_t dwords_per_row, u
 }
 
 // ---------------------------------------------------------------------------------------------
+// K5/K6/K7  inbreeding sweep (kga_analytic/kga_inbreed).
+//
+// HBM layout ("gt8"): locus-major byte rows, row l at gt + l*pitch, one byte per genome:
+//   low nibble  = first SNP variant the genome carries at the locus, as 1 + index into the locus's
+//                 reference alt list (0 = none, 15 = a SNP alt the reference list does not hold)
+//   high nibble = second SNP variant (0 = none);  0xFF = three or more SNP variants.
+// Indel alleles never appear: INBREED filters both sides to SNPs (kga_analysis_inbreed.cpp:79,
+// kga_analysis_inbreed_freq.cpp:436).  A lane owns 4 consecutive genomes (one dword per locus row), a wave
+// 256 genomes; everything indexed by locus (allele frequencies, class frequencies) is wave-uniform.
+//
+// Per-locus table row (K6, computed once per locus instead of once per genome per locus as the
+// reference does at _freq.cpp:444,552):  af[amax] (NaN = alt not in the AlleleFreqVector), p_major =
+// majorAlleleFrequency(), cf[4] = alleleClassFrequencies(0.0) {majorHom, majorHet, minorHom, minorHet}.
+// ---------------------------------------------------------------------------------------------
+constexpr int kTableExtra = 5;   // p_major + 4 class frequencies after the af[amax] slots
+
+__device__ __forceinline__ double clamp01(double x) { return x < 0.0 ? 0.0 : (x > 1.0 ? 1.0 : x); }
+
+// K6: AlleleFreqVector (ctor clamp, _freq.cpp:47), checkValidAlleleVector (:61-75), majorAlleleFrequency
+// (:119-123), unadjustedAlleleClassFrequencies(0.0) + normalize (:127-217), in the reference's operation order.
+// valid[l] = 0 marks a locus generateFrequencies skips (:445-449).
+__global__ void __launch_bounds__(kBlock)
+k_locus_tables(const double* __restrict__ af_in, uint64_t n_loci, uint32_t amax, double inbreeding,
+               double* __restrict__ table, uint8_t* __restrict__ valid) {
+  const uint32_t stride = amax + kTableExtra;
+  for (uint64_t l = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x; l < n_loci;
+       l += static_cast<uint64_t>(gridDim.x) * blockDim.x) {
+    const double* in = af_in + l * amax;
+    double* out = table + l * stride;
+    double sum_minor = 0.0;
+    uint32_t n = 0;
+    for (uint32_t a = 0; a < amax; ++a) {
+      double f = in[a];
+      if (f == f) { f = clamp01(f); sum_minor += f; ++n; }
+      out[a] = f;
+    }
+    valid[l] = (n > 0 && !((sum_minor - 1.0) > 1.0e-5)) ? 1 : 0;
+    out[amax] = clamp01(1.0 - clamp01(sum_minor));                        // majorAlleleFrequency()
+    const double major_frequency = (1.0 - sum_minor) > 0.0 ? (1.0 - sum_minor) : 0.0;
+    const bool rescale = sum_minor > 1.0;
+    double minor_hom = 0.0, major_het = 0.0, minor_het = 0.0;
+    for (uint32_t a = 0; a < amax; ++a) {
+      const double f0 = out[a];
+      if (!(f0 == f0)) continue;
+      const double f = rescale ? f0 / sum_minor : f0;
+      minor_hom += (inbreeding * f) + ((1.0 - inbreeding) * f * f);
+    }
+    for (uint32_t a = 0; a < amax; ++a) {
+      const double fa0 = out[a];
+      if (!(fa0 == fa0)) continue;
+      const double fa = rescale ? fa0 / sum_minor : fa0;
+      for (uint32_t b = a + 1; b < amax; ++b) {
+        const double fb0 = out[b];
+        if (!(fb0 == fb0)) continue;
+        const double fb = rescale ? fb0 / sum_minor : fb0;
+        minor_het += (1.0 - inbreeding) * 2.0 * fa * fb;
+      }
+    }
+    double major_hom = (inbreeding * major_frequency) + ((1.0 - inbreeding) * major_frequency * major_frequency);
+    for (uint32_t a = 0; a < amax; ++a) {
+      const double f0 = out[a];
+      if (!(f0 == f0)) continue;
+      const double f = rescale ? f0 / sum_minor : f0;
+      major_het += (1.0 - inbreeding) * 2.0 * major_frequency * f;
+    }
+    major_hom = major_hom > 0.0 ? major_hom : 0.0;
+    major_het = major_het > 0.0 ? major_het : 0.0;
+    minor_hom = minor_hom > 0.0 ? minor_hom : 0.0;
+    minor_het = minor_het > 0.0 ? minor_het : 0.0;
+    const double sum_freqs = major_hom + major_het + minor_hom + minor_het;
+    out[amax + 1] = major_hom / sum_freqs;
+    out[amax + 2] = major_het / sum_freqs;
+    out[amax + 3] = minor_hom / sum_freqs;
+    out[amax + 4] = minor_het / sum_freqs;
+  }
+}
+
+enum : int { kClassNone = 0, kMajorHom = 1, kMajorHet = 2, kMinorHom = 3, kMinorHet = 4 };
+
+// generateFrequencies' per-locus decision (_freq.cpp:452-543) for one genotype byte.
+__device__ __forceinline__ int classify_cell(uint32_t b, const double* __restrict__ row, uint32_t amax, bool phased,
+                                             double& f1, double& f2) {
+  const double p_major = row[amax];
+  if (b == 0) {
+    if (p_major > 0.01) { f1 = p_major; f2 = p_major; return kMajorHom; }   // minimum_major_frequency (:531-539)
+    return kClassNone;
+  }
+  const uint32_t a1 = b & 15u, a2 = b >> 4;
+  if (a1 == 15u || a2 == 15u || a1 > amax || a2 > amax) return kClassNone;    // unknown alt, or >= 3 variants (0xFF)
+  f1 = row[a1 - 1];
+  if (!(f1 == f1)) return kClassNone;                                         // front() not in the AF list
+  if (a2 == 0) { f2 = p_major; return kMajorHet; }
+  if (a1 == a2 && phased) { f2 = f1; return kMinorHom; }                      // homozygous(): same HGVS, different phase
+  f2 = row[a2 - 1];
+  if (!(f2 == f2)) return kClassNone;                                         // second minor allele not found (:503-506)
+  return kMinorHet;
+}
+
+// MODE 0: class counts + class-frequency sums at F=0 + Ritland terms   (generateFrequencies, processRitlandLocus)
+// MODE 1: one Hall expectation step:  sum over hom loci of F/(F+(1-F)p)  (processHallME :255-285)
+// MODE 2: log-likelihood at F                                            (logLikelihood :94-129)
+// Grid: x = genome quads of 256 threads (1024 genomes), y = locus segment.  Per (segment, genome) partials
+// go to part[(seg*n_genomes + g)*kParts + k]; integer class counts are added atomically to counts[g][6].
+constexpr int kParts0 = 5;   // majorHom, majorHet, minorHom, minorHet frequency sums, Ritland sum
+template <int MODE>
+__global__ void __launch_bounds__(kBlock)
+k_inbreed_sweep(const uint32_t* __restrict__ gt, uint64_t dwords_per_row, uint64_t g0, uint64_t n_genomes,
+                const uint32_t* __restrict__ locus_index, uint64_t n_sel, uint64_t loci_per_seg,
+                const double* __restrict__ table, const uint8_t* __restrict__ valid, uint32_t amax, int phased,
+                const double* __restrict__ f_in, unsigned long long* __restrict__ counts, double* __restrict__ part) {
+  const uint64_t quad = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x;   // 4 genomes g0 + 4*quad ..
+  if (quad * 4 >= n_genomes) return;
+  const uint64_t seg = blockIdx.y;
+  const uint64_t s_begin = seg * loci_per_seg;
+  const uint64_t s_end = s_begin + loci_per_seg < n_sel ? s_begin + loci_per_seg : n_sel;
+  const uint32_t stride = amax + kTableExtra;
+  const uint64_t col = (g0 >> 2) + quad;                  // g0 is a multiple of 4
+
+  uint32_t cnt[4][6];        // majorHom, majorHet, minorHom, minorHet, total, ritland count
+  double acc[4][MODE == 0 ? kParts0 : 1];
+  double F[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+#pragma unroll
+    for (int k = 0; k < 6; ++k) cnt[j][k] = 0;
+#pragma unroll
+    for (int k = 0; k < (MODE == 0 ? kParts0 : 1); ++k) acc[j][k] = 0.0;
+    const uint64_t g = quad * 4 + j;
+    F[j] = (MODE != 0 && g < n_genomes) ? f_in[g] : 0.0;
+  }
+
+  for (uint64_t s = s_begin; s < s_end; ++s) {
+    if (!valid[s]) continue;
+    const uint64_t l = locus_index ? static_cast<uint64_t>(locus_index[s]) : s;
+    const uint32_t w = gt[l * dwords_per_row + col];
+    const double* row = table + s * stride;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      double f1 = 0.0, f2 = 0.0;
+      const int cls = classify_cell((w >> (8 * j)) & 0xFFu, row, amax, phased != 0, f1, f2);
+      if (cls == kClassNone) continue;
+      if constexpr (MODE == 0) {
+        ++cnt[j][cls - 1];
+        ++cnt[j][4];
+        acc[j][0] += row[amax + 1];
+        acc[j][1] += row[amax + 2];
+        acc[j][2] += row[amax + 3];
+        acc[j][3] += row[amax + 4];
+        if (cls == kMajorHom || cls == kMinorHom) {
+          if (f1 > 0.001) {                     // minimum_frequency (_calc.cpp:380,396)
+            acc[j][4] += 1.0 / f1;
+            acc[j][4] -= 1.0;
+            ++cnt[j][5];
+          }
+        } else {
+          acc[j][4] -= 1.0;
+          ++cnt[j][5];
+        }
+      } else if constexpr (MODE == 1) {
+        if (cls == kMajorHom || cls == kMinorHom) {
+          const double denominator = F[j] + ((1.0 - F[j]) * f1);
+          if (denominator != 0) acc[j][0] += F[j] / denominator;
+        }
+      } else {
+        double prob;
+        if (cls == kMajorHom || cls == kMinorHom) prob = (F[j] * f1) + ((1.0 - F[j]) * (f1 * f1));
+        else prob = 2 * (1.0 - F[j]) * f1 * f2;
+        prob = prob < 1e-10 ? 1e-10 : (prob > 1.0 ? 1.0 : prob);
+        acc[j][0] += log(prob);
+      }
+    }
+  }
+
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const uint64_t g = quad * 4 + j;
+    if (g >= n_genomes) continue;
+    if constexpr (MODE == 0) {
+#pragma unroll
+      for (int k = 0; k < 6; ++k)
+        if (cnt[j][k]) atomicAdd(&counts[g * 6 + k], static_cast<unsigned long long>(cnt[j][k]));
+#pragma unroll
+      for (int k = 0; k < kParts0; ++k) part[(seg * n_genomes + g) * kParts0 + k] = acc[j][k];
+    } else {
+      part[seg * n_genomes + g] = acc[j][0];
+    }
+  }
+}
+
+// Sum the per-segment partials in segment order (deterministic; segments are ascending locus ranges).
+__global__ void __launch_bounds__(kBlock)
+k_reduce_parts(const double* __restrict__ part, uint64_t n_seg, uint64_t n_items, double* __restrict__ out) {
+  for (uint64_t i = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n_items;
+       i += static_cast<uint64_t>(gridDim.x) * blockDim.x) {
+    double s = 0.0;
+    for (uint64_t k = 0; k < n_seg; ++k) s += part[k * n_items + i];
+    out[i] = s;
+  }
+}
+
+// processHallME's update: F <- expectation_sum / N (N = all classified loci, _calc.cpp:283).
+__global__ void __launch_bounds__(kBlock)
+k_hall_update(const double* __restrict__ expectation_sum, const unsigned long long* __restrict__ counts, uint64_t n,
+              double* __restrict__ f) {
+  for (uint64_t g = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x; g < n;
+       g += static_cast<uint64_t>(gridDim.x) * blockDim.x)
+    f[g] = expectation_sum[g] / static_cast<double>(counts[g * 6 + 4]);
+}
+
+// Golden-section maximiser state per genome: bracket [a,b], interior points c<d with values fc, fd.
+// phase 0: f_eval holds value at c -> store, next eval at d; phase 1: value at d -> store, start shrinking;
+// phase 2: f_eval is the value at the newly placed point.
+struct GoldenState { double a, b, c, d, fc, fd; int last_was_c; int pad; };
+
+__global__ void __launch_bounds__(kBlock)
+k_golden_step(GoldenState* __restrict__ st, const double* __restrict__ f_eval, uint64_t n, int phase, double* __restrict__ f_next) {
+  const double inv_phi = 0.6180339887498949;
+  for (uint64_t g = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x; g < n;
+       g += static_cast<uint64_t>(gridDim.x) * blockDim.x) {
+    GoldenState s = st[g];
+    if (phase == 0) {
+      s.fc = f_eval[g];
+      f_next[g] = s.d;
+    } else {
+      if (phase == 1) s.fd = f_eval[g];
+      else if (s.last_was_c) s.fc = f_eval[g];
+      else s.fd = f_eval[g];
+      if (s.fc > s.fd) {          // maximum in [a, d]
+        s.b = s.d; s.d = s.c; s.fd = s.fc;
+        s.c = s.b - inv_phi * (s.b - s.a);
+        s.last_was_c = 1;
+        f_next[g] = s.c;
+      } else {                    // maximum in [c, b]
+        s.a = s.c; s.c = s.d; s.fc = s.fd;
+        s.d = s.a + inv_phi * (s.b - s.a);
+        s.last_was_c = 0;
+        f_next[g] = s.d;
+      }
+    }
+    st[g] = s;
+  }
+}
+
+// LocusResults per genome (kga_analysis_inbreed_output.h:21-35) incl. the estimator's coefficient:
+//   Simple  (processSimple, _calc.cpp:318-365): (obsHom - expHom) / (N - expHom)
+//   Ritland (processRitlandLocus :374-431):     sum / count
+//   HallME / Loglikelihood: the iterated value handed in through f.
+struct LocusResultsDev {
+  unsigned long long major_hetero_count; double major_hetero_freq;
+  unsigned long long minor_hetero_count; double minor_hetero_freq;
+  unsigned long long minor_homo_count;   double minor_homo_freq;
+  unsigned long long major_homo_count;   double major_homo_freq;
+  unsigned long long total_allele_count; double inbred_allele_sum;
+};
+
+__global__ void __launch_bounds__(kBlock)
+k_finish_inbreed(const unsigned long long* __restrict__ counts, const double* __restrict__ sums, uint64_t n, int algorithm,
+                 const double* __restrict__ f, LocusResultsDev* __restrict__ out) {
+  for (uint64_t g = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x; g < n;
+       g += static_cast<uint64_t>(gridDim.x) * blockDim.x) {
+    const unsigned long long* c = counts + g * 6;     // majorHom, majorHet, minorHom, minorHet, total, ritland count
+    const double* s = sums + g * kParts0;              // majorHom, majorHet, minorHom, minorHet, ritland sum
+    LocusResultsDev r;
+    r.major_homo_count = c[0]; r.major_hetero_count = c[1]; r.minor_homo_count = c[2]; r.minor_hetero_count = c[3];
+    r.total_allele_count = c[4];
+    r.major_homo_freq = s[0]; r.major_hetero_freq = s[1]; r.minor_homo_freq = s[2]; r.minor_hetero_freq = s[3];
+    double coefficient = 0.0;
+    if (algorithm == 1) {
+      if (r.total_allele_count > 0) {
+        const double observed_homozygous = static_cast<double>(r.minor_homo_count + r.major_homo_count);
+        const double expected_homozygous = r.minor_homo_freq + r.major_homo_freq;
+        coefficient = (observed_homozygous - expected_homozygous) / (static_cast<double>(r.total_allele_count) - expected_homozygous);
+      }
+    } else if (algorithm == 0) {
+      coefficient = c[5] > 0 ? s[4] / static_cast<double>(c[5]) : 0.0;
+    } else {
+      coefficient = f[g];
+    }
+    r.inbred_allele_sum = coefficient;
+    out[g] = r;
+  }
+}
+
+// Pack caller genome-major bytes [n][n_loci] into locus-major gt8 rows (one thread per output dword).
+__global__ void __launch_bounds__(kBlock)
+k_gt8_transpose(const uint8_t* __restrict__ src, uint64_t n_src, uint64_t n_loci, uint64_t g0, uint8_t* __restrict__ gt, uint64_t pitch) {
+  const uint64_t total = n_src * n_loci;
+  for (uint64_t i = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < total;
+       i += static_cast<uint64_t>(gridDim.x) * blockDim.x) {
+    const uint64_t l = i % n_loci, g = i / n_loci;      // consecutive threads read consecutive loci of one genome
+    gt[l * pitch + g0 + g] = src[g * n_loci + l];
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // Flattening helpers.
 // ---------------------------------------------------------------------------------------------
 

@@ -323,6 +323,11 @@ static constexpr size_t MAXIMUM_ITERATIONS_ = 1000;
 static constexpr size_t MAX_RETRIES_ = 50;
 static constexpr size_t MIN_RETRIES_ = 5;
 
+// Test hook: start_seed == kFixedStarts replaces the random restart points by the midpoint of the
+// reference's start interval (HallME: 0.25 of (0,0.5]; Loglikelihood: 0.0 of (-0.5,0.5]), so that a
+// deterministic implementation can be compared value for value.  Any other seed draws as the reference does.
+static constexpr uint64_t kFixedStarts = ~0ull;
+
 static std::mt19937_64 makeEntropy(uint64_t seed) {
   if (seed == 0) {
     std::random_device rd;
@@ -402,7 +407,7 @@ LocusResults processLogLikelihood(const std::string& genome_id, const ContigDB& 
   double updated_coefficient = 0.0;
   RetryCalcResult retry_results(FINAL_ACCURACY_, MIN_RETRIES_, MAX_RETRIES_);
   do {
-    const double initial_f = initialize_distribution(entropy_mt);
+    const double initial_f = start_seed == kFixedStarts ? 0.0 : initialize_distribution(entropy_mt);
     const auto& data = frequency_vector;
     updated_coefficient = neldermead1D([&data](double f) { return logLikelihood(f, data); }, initial_f, -1.0, 1.0, 1e-06, 500, nullptr);
   } while (!retry_results.checkRetry(updated_coefficient));
@@ -423,7 +428,7 @@ LocusResults processHallME(const std::string& genome_id, const ContigDB& contig,
   double inbreed_coefficient;
   RetryCalcResult retry_results(FINAL_ACCURACY_, MIN_RETRIES_, MAX_RETRIES_);
   do {
-    updated_coefficient = initialize_distribution(entropy_mt);
+    updated_coefficient = start_seed == kFixedStarts ? 0.25 : initialize_distribution(entropy_mt);
     RetryCalcResult converge_retry(FINAL_ACCURACY_, MINIMUM_ITERATIONS_, MAXIMUM_ITERATIONS_);
     do {
       inbreed_coefficient = updated_coefficient;
@@ -516,7 +521,7 @@ ResultsMap processResults(const PopulationDB& diploid_population, const std::str
     std::shared_ptr<const ContigDB> contig = contig_opt.value();
     std::shared_ptr<const ContigDB> locus_list = locus_result->second;
     const std::string gid = genome_id;
-    const uint64_t seed = params.start_seed ? params.start_seed + future_vector.size() : 0;
+    const uint64_t seed = params.start_seed == ~0ull ? ~0ull : (params.start_seed ? params.start_seed + future_vector.size() : 0);
     future_vector.push_back(thread_pool.enqueueFuture([=]() -> LocusResults {
       switch (algo) {
         case InbreedAlgorithm::RitlandLocus: return processRitlandLocus(gid, *contig, super_pop, *locus_list);

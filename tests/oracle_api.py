@@ -14,6 +14,7 @@ ROOT = Path(__file__).resolve().parent.parent
 LIB_PATH = ROOT / "oracle" / "_build" / "libkgo.so"
 
 SUPER_POPS = ["AFR", "AMR", "EAS", "EUR", "SAS", "ALL"]
+FIXED_STARTS = 0xFFFFFFFFFFFFFFFF   # oracle test hook: deterministic restart points (see kgo_inbreed.cpp)
 ALL = 5
 
 _lib = None
