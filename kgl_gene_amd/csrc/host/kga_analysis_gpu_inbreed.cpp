@@ -1,0 +1,419 @@
+#include "kga_analysis_gpu_inbreed.h"
+
+#include <algorithm>
+#include <cmath>
+#include <fstream>
+#include <limits>
+#include <sstream>
+#include <unordered_map>
+
+#include "../../../include/kgx.h"
+
+namespace kga = kellerberrin::genome::analysis;
+namespace kgl = kellerberrin::genome;
+using kellerberrin::ExecEnv;
+
+namespace {
+
+constexpr double kNaN = std::numeric_limits<double>::quiet_NaN();
+
+struct DeviceMatrix {
+  kgx_gt8* handle{nullptr};
+  ~DeviceMatrix() { if (handle) kgx_gt8_destroy(handle); }
+};
+
+int algorithmCode(const std::string& name) {   // InbreedingCalculation::algoMap keys (kga_analysis_inbreed_calc.h:93-101)
+  if (name == "RitlandLocus") return KGX_ALGO_RITLAND_LOCUS;
+  if (name == "Simple") return KGX_ALGO_SIMPLE;
+  if (name == "HallME") return KGX_ALGO_HALL_ME;
+  if (name == "Loglikelihood") return KGX_ALGO_LOGLIKELIHOOD;
+  return -1;
+}
+
+}  // namespace
+
+// ---- parameters ----------------------------------------------------------------------------------------
+
+std::vector<kga::GpuInbreedingParameters> kga::GpuInbreedAnalysis::extractParameters(const ActiveParameterList& named_parameters) {
+  std::vector<GpuInbreedingParameters> param_vector;
+  for (const auto& [block_name, named_vector] : named_parameters.getMap()) {
+    for (const auto& xml_vector : named_vector.second) {
+      GpuInbreedingParameters p;
+      p.parameter_ident = block_name;
+      auto analysis_opt = xml_vector.getBool("AnalysisType");
+      auto output_opt = xml_vector.getString("OutputFile");
+      auto algo_opt = xml_vector.getString("Algorithm");
+      auto min_opt = xml_vector.getFloat("MinAlleleFreq");
+      auto max_opt = xml_vector.getFloat("MaxAlleleFreq");
+      auto low_opt = xml_vector.getSize("LowerWindow");
+      auto high_opt = xml_vector.getSize("UpperWindow");
+      auto count_opt = xml_vector.getSize("LociiCount");
+      auto spacing_opt = xml_vector.getSize("SamplingDistance");
+      if (!analysis_opt || !output_opt || !algo_opt || !min_opt || !max_opt || !low_opt || !high_opt || !count_opt || !spacing_opt) {
+        ExecEnv::log().error("GpuInbreedAnalysis::extractParameters; bad or missing value in parameter block: {}", block_name);
+        continue;
+      }
+      p.analyze_synthetic = analysis_opt.value();
+      p.output_file = output_opt.value().front();
+      p.inbreeding_algorithm = algo_opt.value().front();
+      p.locii.allele_frequency_min = std::clamp(min_opt.value().front(), 0.0, 1.0);
+      p.locii.allele_frequency_max = std::clamp(max_opt.value().front(), 0.0, 1.0);
+      p.locii.lower_offset = low_opt.value().front();
+      p.locii.upper_offset = high_opt.value().front();
+      p.locii.locii_count = count_opt.value().front();
+      p.locii.spacing = spacing_opt.value().front();
+      param_vector.push_back(p);
+    }
+    ExecEnv::log().info("Inbreeding Analysis, parsed named argument vector: {}, size: {}", block_name, param_vector.size());
+  }
+  return param_vector;
+}
+
+// ---- reference contig ----------------------------------------------------------------------------------
+
+kga::GpuReferenceContig kga::GpuInbreedAnalysis::buildReference(const PopulationDB& unphased_population, bool& ok) {
+  GpuReferenceContig ref;
+  ok = false;
+  if (unphased_population.getMap().size() != 1) {
+    ExecEnv::log().error("GpuInbreedAnalysis; Unphased Population: {} has unexpected Genome count: {}", unphased_population.populationId(),
+                         unphased_population.getMap().size());
+    return ref;
+  }
+  const auto& genome_ptr = unphased_population.getMap().begin()->second;
+  if (genome_ptr->getMap().size() != 1) {
+    ExecEnv::log().error("GpuInbreedAnalysis; Unphased Population: {} has more than 1 contig: {}", unphased_population.populationId(),
+                         genome_ptr->getMap().size());
+    return ref;
+  }
+  const auto& [contig_id, contig_ptr] = *genome_ptr->getMap().begin();
+  ref.contig_id = contig_id;
+  const auto& super_pops = FrequencyDatabaseRead::superPopulations();
+  for (const auto& [offset, offset_ptr] : contig_ptr->getMap()) {
+    GpuReferenceLocus locus;
+    locus.offset = offset;
+    for (const auto& variant_ptr : offset_ptr->getVariantArray()) {
+      if (!variant_ptr->isSNP() || !variant_ptr->evidence().passFilter()) continue;   // AndFilter(SNPFilter(), PassFilter())
+      GpuReferenceAlt alt;
+      alt.hgvs = variant_ptr->HGVS();
+      for (size_t sp = 0; sp < 6 && sp < super_pops.size(); ++sp) {
+        auto f = FrequencyDatabaseRead::superPopFrequency(*variant_ptr, super_pops[sp]);
+        alt.af[sp] = f ? f.value() : kNaN;
+      }
+      locus.alts.push_back(std::move(alt));
+    }
+    if (locus.alts.empty()) continue;    // trimEmpty (kgl_variant_db_contig.cpp:135-148)
+    ref.max_alts = std::max<uint32_t>(ref.max_alts, static_cast<uint32_t>(locus.alts.size()));
+    ref.loci.push_back(std::move(locus));
+  }
+  ok = true;
+  return ref;
+}
+
+void kga::GpuReferenceContig::alleleFreqRow(size_t l, int sp, double* row, uint32_t amax) const {
+  const auto& alts = loci[l].alts;
+  for (uint32_t j = 0; j < amax; ++j) row[j] = kNaN;
+  for (size_t j = 0; j < alts.size() && j < amax; ++j) {
+    const double f = alts[j].af[sp];
+    if (std::isnan(f)) continue;
+    bool duplicate = false;
+    for (size_t k = 0; k < j; ++k)
+      if (!std::isnan(row[k]) && alts[k].hgvs == alts[j].hgvs) { duplicate = true; break; }
+    if (!duplicate) row[j] = std::clamp(f, 0.0, 1.0);
+  }
+}
+
+bool kga::GpuReferenceContig::validForSampling(size_t l, int sp, double& minor_sum) const {
+  double row[16];
+  const uint32_t amax = std::min<uint32_t>(16, std::max<uint32_t>(1, static_cast<uint32_t>(loci[l].alts.size())));
+  alleleFreqRow(l, sp, row, amax);
+  double sum = 0.0;
+  size_t n = 0;
+  for (uint32_t j = 0; j < amax; ++j)
+    if (!std::isnan(row[j])) { sum += row[j]; ++n; }
+  if ((sum - 1.0) > 1.0e-5 || n == 0) return false;     // checkValidAlleleVector
+  minor_sum = std::clamp(sum, 0.0, 1.0);                // minorAlleleFrequencies
+  return true;
+}
+
+std::vector<uint32_t> kga::GpuReferenceContig::sampleLocii(int sp, const GpuLociiArguments& args, bool by_count) const {
+  std::vector<uint32_t> out;
+  auto it = std::lower_bound(loci.begin(), loci.end(), args.lower_offset,
+                             [](const GpuReferenceLocus& locus, ContigOffset_t v) { return locus.offset < v; });
+  ContigOffset_t previous_offset{0};
+  for (; it != loci.end(); ++it) {
+    const ContigOffset_t offset = it->offset;
+    if (by_count ? out.size() >= args.locii_count : offset > args.upper_offset) break;
+    if (offset >= previous_offset + args.spacing || previous_offset == 0) {
+      double sum_frequencies = 0.0;
+      const size_t l = static_cast<size_t>(it - loci.begin());
+      if (!validForSampling(l, sp, sum_frequencies)) continue;
+      if (sum_frequencies == 0.0 || sum_frequencies < args.allele_frequency_min || sum_frequencies > args.allele_frequency_max) continue;
+      previous_offset = offset;
+      out.push_back(static_cast<uint32_t>(l));
+    }
+  }
+  return out;
+}
+
+// ---- VirtualAnalysis -----------------------------------------------------------------------------------
+
+bool kga::GpuInbreedAnalysis::initializeAnalysis(const std::string& work_directory, const ActiveParameterList& named_parameters,
+                                                 const std::shared_ptr<const AnalysisResources>& resource_ptr) {
+  ExecEnv::log().info("Analysis Id: {} initialized with work directory: {}", ident(), work_directory);
+  genealogy_data_ = resource_ptr->getSingleResource<HsGenomeGenealogyData>(ResourceProperties::GENEALOGY_RESOURCE_ID_);
+  work_directory_ = work_directory;
+  for (const auto& [block_name, named_vector] : named_parameters.getMap())
+    for (const auto& parameter_map : named_vector.second)
+      if (auto v = parameter_map.getSize("Device")) device_ = static_cast<int>(v.value().front());
+  for (const auto& parameter : extractParameters(named_parameters)) {
+    GpuParamOutput out;
+    out.parameters = parameter;
+    parameter_output_vector_.push_back(std::move(out));
+  }
+  if (kgx_init(device_) != KGX_OK) {
+    ExecEnv::log().error("GpuInbreedAnalysis::initializeAnalysis; cannot bind MI355X device {}: {}", device_, kgx_last_error());
+    return false;
+  }
+  device_ready_ = true;
+  return true;
+}
+
+bool kga::GpuInbreedAnalysis::fileReadAnalysis(std::shared_ptr<const DataDB> data_object_ptr) {
+  ExecEnv::log().info("Analysis: {}, begin processing data file: {}", ident(), data_object_ptr->fileId());
+  const auto file_characteristic = data_object_ptr->dataCharacteristic();
+  if (file_characteristic.data_structure == DataStructureEnum::DiploidPhased ||
+      file_characteristic.data_structure == DataStructureEnum::DiploidUnphased) {
+    diploid_population_ = std::dynamic_pointer_cast<const PopulationDB>(data_object_ptr);
+    if (!diploid_population_) {
+      ExecEnv::log().error("GpuInbreedAnalysis::fileReadAnalysis, Analysis: {}, file: {} is not a Diploid Population", ident(), data_object_ptr->fileId());
+      return false;
+    }
+  }
+  if (file_characteristic.data_structure == DataStructureEnum::UnphasedMonoGenome) {
+    unphased_population_ = std::dynamic_pointer_cast<const PopulationDB>(data_object_ptr);
+    if (!unphased_population_) {
+      ExecEnv::log().error("GpuInbreedAnalysis::fileReadAnalysis, Analysis: {}, file: {} is not an Unphased Population", ident(), data_object_ptr->fileId());
+      return false;
+    }
+  }
+  return true;
+}
+
+bool kga::GpuInbreedAnalysis::iterationAnalysis() {
+  ExecEnv::log().info("Iteration Analysis called for Analysis Id: {}", ident());
+  if (!device_ready_) return false;
+  if (!diploid_population_ || !unphased_population_ || !genealogy_data_) {
+    ExecEnv::log().critical("GpuInbreedAnalysis::iterationAnalysis; necessary variant databases not supplied - program terminates.");
+    return false;
+  }
+  bool ok = true;
+  for (auto& param_output : parameter_output_vector_) {
+    if (param_output.parameters.analyze_synthetic) {
+      ExecEnv::log().error("GpuInbreedAnalysis; parameter block: {} asks for the synthetic self-check, which this package does not run; use AnalysisType=false",
+                           param_output.parameters.parameter_ident);
+      ok = false;
+      continue;
+    }
+    ok = populationInbreeding(param_output) && ok;
+  }
+  diploid_population_ = nullptr;
+  unphased_population_ = nullptr;
+  return ok;
+}
+
+bool kga::GpuInbreedAnalysis::populationInbreeding(GpuParamOutput& param_output) {
+  const GpuInbreedingParameters& params = param_output.parameters;
+  const int algorithm = algorithmCode(params.inbreeding_algorithm);
+  if (algorithm < 0) {
+    ExecEnv::log().error("InbreedingAnalysis::populationInbreeding, Inbreeding algorithm not found: {}", params.inbreeding_algorithm);
+    return true;   // the reference logs and returns an empty results map (_diploid.cpp:107-112)
+  }
+  bool ok = false;
+  const GpuReferenceContig reference = buildReference(*unphased_population_, ok);
+  if (!ok) return false;
+  if (reference.max_alts > 14) {
+    ExecEnv::log().error("GpuInbreedAnalysis; a reference offset holds {} SNP alts; at most 14 fit the 4-bit allele index", reference.max_alts);
+    return false;
+  }
+  const uint32_t amax = std::max<uint32_t>(1, reference.max_alts);
+  const uint64_t n_loci = reference.loci.size();
+  const auto& super_pops = FrequencyDatabaseRead::superPopulations();
+  const bool phased = diploid_population_->dataCharacteristic().data_structure == DataStructureEnum::DiploidPhased;
+
+  // Genomes with the contig and a PED record, grouped by super population; each group starts on a multiple of 4.
+  struct DeviceGenome { std::shared_ptr<const ContigDB> contig; GenomeId_t id; };
+  std::vector<std::vector<DeviceGenome>> by_super_pop(super_pops.size());
+  for (const auto& [genome_id, genome_ptr] : diploid_population_->getMap()) {
+    auto contig_opt = genome_ptr->getContig(reference.contig_id);
+    if (!contig_opt) continue;
+    auto record_opt = genealogy_data_->getGenomeGenealogyRecord(genome_id);
+    if (!record_opt) {
+      ExecEnv::log().error("InbreedingAnalysis::populationInbreeding, Genome sample: {} does not have a PED record", genome_id);
+      continue;
+    }
+    const auto sp_it = std::find(super_pops.begin(), super_pops.end(), record_opt.value().superPopulation());
+    if (sp_it == super_pops.end()) {
+      ExecEnv::log().error("InbreedingAnalysis::populationInbreeding, Locus set not found for super population: {}", record_opt.value().superPopulation());
+      continue;
+    }
+    by_super_pop[static_cast<size_t>(sp_it - super_pops.begin())].push_back({contig_opt.value(), genome_id});
+  }
+  std::vector<uint64_t> range_begin(super_pops.size(), 0), range_end(super_pops.size(), 0);
+  uint64_t device_genomes = 0;
+  for (size_t sp = 0; sp < super_pops.size(); ++sp) {
+    device_genomes = (device_genomes + 3) / 4 * 4;
+    range_begin[sp] = device_genomes;
+    device_genomes += by_super_pop[sp].size();
+    range_end[sp] = device_genomes;
+  }
+  if (device_genomes == 0 || n_loci == 0) return true;
+
+  // Allele-index bytes [locus][genome]: each genome's SNP variants at each reference offset, in OffsetDB order.
+  std::unordered_map<ContigOffset_t, uint32_t> locus_of_offset;
+  locus_of_offset.reserve(n_loci * 2);
+  for (uint32_t l = 0; l < n_loci; ++l) locus_of_offset.emplace(reference.loci[l].offset, l);
+  std::vector<uint8_t> bytes(n_loci * device_genomes, 0);
+  for (size_t sp = 0; sp < super_pops.size(); ++sp) {
+    for (size_t k = 0; k < by_super_pop[sp].size(); ++k) {
+      const uint64_t g = range_begin[sp] + k;
+      for (const auto& [offset, offset_ptr] : by_super_pop[sp][k].contig->getMap()) {
+        auto lit = locus_of_offset.find(offset);
+        if (lit == locus_of_offset.end()) continue;
+        const auto& alts = reference.loci[lit->second].alts;
+        uint32_t n = 0, code[2] = {0, 0};
+        VariantPhase phase[2] = {VariantPhase::UNPHASED, VariantPhase::UNPHASED};
+        for (const auto& variant_ptr : offset_ptr->getVariantArray()) {
+          if (!variant_ptr->isSNP()) continue;                         // contig_ptr->viewFilter(SNPFilter()) (_freq.cpp:436)
+          if (n < 2) {
+            const std::string hgvs = variant_ptr->HGVS();
+            uint32_t c = 15;
+            for (size_t j = 0; j < alts.size(); ++j)
+              if (alts[j].hgvs == hgvs) { c = static_cast<uint32_t>(j + 1); break; }
+            code[n] = c;
+            phase[n] = variant_ptr->phaseId();
+          }
+          ++n;
+        }
+        if (n == 0) continue;
+        uint8_t b;
+        if (n >= 3) b = 0xFF;
+        else {
+          if (n == 2 && code[0] == code[1] && code[0] != 15 && phased && phase[0] == phase[1]) {
+            ExecEnv::log().error("GpuInbreedAnalysis; Genome: {} holds two copies of one variant with the SAME phase at offset {}; not representable",
+                                 by_super_pop[sp][k].id, offset);
+            return false;
+          }
+          b = static_cast<uint8_t>(code[0] | (code[1] << 4));
+        }
+        bytes[static_cast<uint64_t>(lit->second) * device_genomes + g] = b;
+      }
+    }
+  }
+  DeviceMatrix dev;
+  dev.handle = kgx_gt8_create(device_genomes, n_loci);
+  if (!dev.handle || kgx_gt8_load_rows(dev.handle, bytes.data(), device_genomes, 0, n_loci) != KGX_OK) {
+    ExecEnv::log().error("GpuInbreedAnalysis; genotype upload failed: {}", kgx_last_error());
+    return false;
+  }
+  bytes.clear();
+  bytes.shrink_to_fit();
+
+  // The window loop of InbreedingAnalysis::populationInbreeding (_diploid.cpp:43-75).
+  const int all_slot = static_cast<int>(std::find(super_pops.begin(), super_pops.end(), std::string(FrequencyDatabaseRead::SUPER_POP_ALL_)) - super_pops.begin());
+  GpuLociiArguments local = params.locii;
+  std::vector<uint32_t> locii_vector = reference.sampleLocii(all_slot, local, true);
+  if (locii_vector.empty()) return true;
+  local.upper_offset = reference.loci[locii_vector.back()].offset;
+  std::vector<double> af_table;
+  std::vector<kgx_locus_results> device_results;
+  while (local.upper_offset < params.locii.upper_offset && locii_vector.size() >= 100) {
+    GpuResultColumn column;
+    {
+      std::stringstream ss;
+      ss << reference.contig_id << "_" << local.lower_offset << "_" << local.upper_offset;
+      column.column_ident = ss.str();
+    }
+    for (size_t sp = 0; sp < super_pops.size(); ++sp) {
+      const uint64_t n = range_end[sp] - range_begin[sp];
+      if (n == 0) continue;
+      const std::vector<uint32_t> selected = reference.sampleLocii(static_cast<int>(sp), local, false);   // getLocusList (_locus.cpp:263-326)
+      af_table.assign(selected.size() * amax, kNaN);
+      for (size_t s = 0; s < selected.size(); ++s) reference.alleleFreqRow(selected[s], static_cast<int>(sp), &af_table[s * amax], amax);
+      device_results.assign(n, kgx_locus_results{});
+      if (kgx_inbreed(dev.handle, range_begin[sp], range_end[sp], selected.data(), selected.size(), af_table.data(), amax, phased ? 1 : 0,
+                      algorithm, device_results.data()) != KGX_OK) {
+        ExecEnv::log().error("GpuInbreedAnalysis; inbreeding sweep failed: {}", kgx_last_error());
+        return false;
+      }
+      for (uint64_t k = 0; k < n; ++k) {
+        const kgx_locus_results& d = device_results[k];
+        GpuLocusResults r;
+        r.genome = by_super_pop[sp][k].id;
+        r.major_hetero_count = d.major_hetero_count;  r.major_hetero_freq = d.major_hetero_freq;
+        r.minor_hetero_count = d.minor_hetero_count;  r.minor_hetero_freq = d.minor_hetero_freq;
+        r.minor_homo_count = d.minor_homo_count;      r.minor_homo_freq = d.minor_homo_freq;
+        r.major_homo_count = d.major_homo_count;      r.major_homo_freq = d.major_homo_freq;
+        r.total_allele_count = d.total_allele_count;  r.inbred_allele_sum = d.inbred_allele_sum;
+        column.results[r.genome] = r;
+      }
+    }
+    param_output.columns.push_back(std::move(column));
+    local.lower_offset = local.upper_offset;
+    locii_vector = reference.sampleLocii(all_slot, local, true);
+    if (locii_vector.empty()) break;
+    local.upper_offset = reference.loci[locii_vector.back()].offset;
+  }
+  return true;
+}
+
+bool kga::GpuInbreedAnalysis::finalizeAnalysis() {
+  ExecEnv::log().info("Finalize called for Analysis Id: {}", ident());
+  return writeResults();
+}
+
+// Layout of InbreedingOutput::writePedResults (kga_analysis_inbreed_output.cpp:188-305) with the PED columns this
+// shim knows (super population); plus "<OutputFile>_detail.csv" carrying every LocusResults field at full precision.
+bool kga::GpuInbreedAnalysis::writeResults() const {
+  for (const auto& param_output : parameter_output_vector_) {
+    if (param_output.columns.empty()) {
+      ExecEnv::log().error("InbreedingOutput::writePedResults; No results to output for parameter ident: {}", param_output.parameters.parameter_ident);
+      continue;
+    }
+    const auto& p = param_output.parameters;
+    const std::string stem = work_directory_ + (work_directory_.empty() || work_directory_.back() == '/' ? "" : "/") + p.output_file;
+    std::ofstream outfile(stem + ".csv", std::ofstream::out | std::ofstream::trunc);
+    std::ofstream detail(stem + "_detail.csv", std::ofstream::out | std::ofstream::trunc);
+    if (!outfile.good() || !detail.good()) {
+      ExecEnv::log().error("InbreedingAnalysis::writeColumnResults; could not open output file: {}", stem);
+      return false;
+    }
+    outfile << p.parameter_ident << DELIMITER_ << "Algorithm:" << p.inbreeding_algorithm << DELIMITER_ << "Min_AF:" << p.locii.allele_frequency_min
+            << DELIMITER_ << "Max_AF:" << p.locii.allele_frequency_max << DELIMITER_ << "Spacing:" << p.locii.spacing << DELIMITER_
+            << "Count:" << p.locii.locii_count << '\n';
+    outfile << "Sample" << DELIMITER_ << "SuperPopulation";
+    for (const auto& column : param_output.columns) outfile << DELIMITER_ << column.column_ident;
+    outfile << '\n';
+    detail.precision(17);
+    detail << "Column,Sample,MajorHetCount,MajorHetFreq,MinorHetCount,MinorHetFreq,MinorHomCount,MinorHomFreq,MajorHomCount,MajorHomFreq,Total,Inbreeding\n";
+    for (const auto& [genome_id, first] : param_output.columns.front().results) {
+      auto record_opt = genealogy_data_ ? genealogy_data_->getGenomeGenealogyRecord(genome_id) : std::nullopt;
+      outfile << genome_id << DELIMITER_ << (record_opt ? record_opt.value().superPopulation() : std::string()) << DELIMITER_;
+      for (const auto& column : param_output.columns) {
+        auto found = column.results.find(genome_id);
+        if (found == column.results.end()) {
+          ExecEnv::log().error("InbreedingAnalysis::writeColumnResults, Column: {}, Genome sample: {} not found", column.column_ident, genome_id);
+          return false;
+        }
+        outfile << found->second.inbred_allele_sum << DELIMITER_;
+      }
+      outfile << '\n';
+    }
+    for (const auto& column : param_output.columns)
+      for (const auto& [genome_id, r] : column.results)
+        detail << column.column_ident << DELIMITER_ << genome_id << DELIMITER_ << r.major_hetero_count << DELIMITER_ << r.major_hetero_freq << DELIMITER_
+               << r.minor_hetero_count << DELIMITER_ << r.minor_hetero_freq << DELIMITER_ << r.minor_homo_count << DELIMITER_ << r.minor_homo_freq
+               << DELIMITER_ << r.major_homo_count << DELIMITER_ << r.major_homo_freq << DELIMITER_ << r.total_allele_count << DELIMITER_
+               << r.inbred_allele_sum << '\n';
+  }
+  return true;
+}

@@ -1,0 +1,128 @@
+// GpuInbreedAnalysis — the INBREED package (kga_analytic/kga_inbreed/kga_analysis_inbreed.{h,cpp}) with
+// the per-genome x per-locus sweep on the MI355X.  Same sequencing, same XML parameters
+// (kga_analysis_inbreed_args.h:24-55,164-172), same window loop (kga_analysis_inbreed_diploid.cpp:18-79),
+// same locus sampling (kga_analysis_inbreed_locus.cpp), same estimators (kga_analysis_inbreed_calc.cpp);
+// what the reference fans out as one thread-pool task per genome (_diploid.cpp:98-166) is one kgx_inbreed()
+// call per super population.  Register next to InbreedAnalysis in kga_analytic/kga_analysis_factory.cpp:31-43.
+#ifndef KGA_ANALYSIS_GPU_INBREED_H
+#define KGA_ANALYSIS_GPU_INBREED_H
+
+#include <array>
+
+#ifdef KGX_WITH_REFERENCE_HEADERS
+#include "kgl_package_analysis_virtual.h"
+#include "kgl_hsgenealogy_parser.h"
+#include "kgl_variant_db_freq.h"
+#else
+#include "kgx_refshim.h"
+#endif
+
+namespace kellerberrin::genome::analysis {
+
+// LociiVectorArguments + InbreedingParameters (kga_analysis_inbreed_args.h:69-160), defaults included.
+struct GpuLociiArguments {
+  ContigOffset_t lower_offset{0};
+  ContigOffset_t upper_offset{1000000000};
+  size_t spacing{1000};
+  size_t locii_count{1000};
+  double allele_frequency_min{0.0};
+  double allele_frequency_max{1.0};
+};
+
+struct GpuInbreedingParameters {
+  std::string parameter_ident{"ParamIdent"};
+  GpuLociiArguments locii;
+  std::string inbreeding_algorithm{"Loglikelihood"};
+  std::string output_file{"output"};
+  bool analyze_synthetic{true};
+};
+
+// LocusResults (kga_analysis_inbreed_output.h:21-35)
+struct GpuLocusResults {
+  GenomeId_t genome;
+  size_t major_hetero_count{0};
+  double major_hetero_freq{0.0};
+  size_t minor_hetero_count{0};
+  double minor_hetero_freq{0.0};
+  size_t minor_homo_count{0};
+  double minor_homo_freq{0.0};
+  size_t major_homo_count{0};
+  double major_homo_freq{0.0};
+  size_t total_allele_count{0};
+  double inbred_allele_sum{0.0};
+};
+using GpuResultsMap = std::map<GenomeId_t, GpuLocusResults>;
+
+struct GpuResultColumn {
+  std::string column_ident;          // InbreedingResultColumn::generateIdent: contig_lower_upper
+  GpuResultsMap results;
+};
+
+struct GpuParamOutput {
+  GpuInbreedingParameters parameters;
+  std::vector<GpuResultColumn> columns;
+};
+
+// The SNP & PASS view of the reference (unphased, mono-genome) contig that locus sampling and the AF tables
+// are cut from (InbreedAnalysis::fileReadAnalysis, kga_analysis_inbreed.cpp:79).
+struct GpuReferenceAlt {
+  std::string hgvs;
+  std::array<double, 6> af{};        // per FrequencyDatabaseRead::superPopulations() slot, NaN = no value
+};
+struct GpuReferenceLocus {
+  ContigOffset_t offset{0};
+  std::vector<GpuReferenceAlt> alts; // OffsetDB array order
+};
+class GpuReferenceContig {
+ public:
+  ContigId_t contig_id;
+  std::vector<GpuReferenceLocus> loci;     // ascending offset
+  uint32_t max_alts{0};
+  // AlleleFreqVector for locus l and super population slot sp as a fixed-width row: af of alt j, NaN when the
+  // alt is not in the vector (no value, or analogous to an earlier alt) (kga_analysis_inbreed_freq.cpp:18-57).
+  void alleleFreqRow(size_t l, int sp, double* row, uint32_t amax) const;
+  // checkValidAlleleVector + the sampling predicate (kga_analysis_inbreed_locus.cpp:46-62): returns false when the
+  // locus cannot be sampled; minor_sum = minorAlleleFrequencies().
+  [[nodiscard]] bool validForSampling(size_t l, int sp, double& minor_sum) const;
+  // RetrieveLociiVector::getLociiCount / getLociiFromTo: indices into loci.
+  [[nodiscard]] std::vector<uint32_t> sampleLocii(int sp, const GpuLociiArguments& args, bool by_count) const;
+};
+
+class GpuInbreedAnalysis : public VirtualAnalysis {
+ public:
+  GpuInbreedAnalysis() = default;
+  ~GpuInbreedAnalysis() override = default;
+
+  inline static const std::string IDENT{"GPU_INBREED"};
+  [[nodiscard]] std::string ident() const override { return IDENT; }
+  [[nodiscard]] static std::unique_ptr<VirtualAnalysis> factory() { return std::make_unique<GpuInbreedAnalysis>(); }
+
+  [[nodiscard]] bool initializeAnalysis(const std::string& work_directory, const ActiveParameterList& named_parameters,
+                                        const std::shared_ptr<const AnalysisResources>& resource_ptr) override;
+  [[nodiscard]] bool fileReadAnalysis(std::shared_ptr<const DataDB> data_object_ptr) override;
+  [[nodiscard]] bool iterationAnalysis() override;
+  [[nodiscard]] bool finalizeAnalysis() override;
+
+  [[nodiscard]] const std::vector<GpuParamOutput>& parameterOutput() const { return parameter_output_vector_; }
+
+  // InbreedArguments::extractParameters (kga_analysis_inbreed_args.cpp:8-152)
+  [[nodiscard]] static std::vector<GpuInbreedingParameters> extractParameters(const ActiveParameterList& named_parameters);
+  [[nodiscard]] static GpuReferenceContig buildReference(const PopulationDB& unphased_population, bool& ok);
+
+ private:
+  bool populationInbreeding(GpuParamOutput& param_output);
+  bool writeResults() const;
+
+  std::vector<GpuParamOutput> parameter_output_vector_;
+  std::string work_directory_;
+  int device_{0};
+  bool device_ready_{false};
+  std::shared_ptr<const PopulationDB> diploid_population_;
+  std::shared_ptr<const PopulationDB> unphased_population_;
+  std::shared_ptr<const HsGenomeGenealogyData> genealogy_data_;
+  constexpr static const char DELIMITER_ = ',';
+};
+
+}  // namespace kellerberrin::genome::analysis
+
+#endif  // KGA_ANALYSIS_GPU_INBREED_H

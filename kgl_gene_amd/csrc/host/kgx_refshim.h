@@ -370,8 +370,8 @@ class ParameterMap {
     if (v.size() != 1) return std::nullopt;
     std::string s;
     for (char c : v.front()) s += static_cast<char>(std::toupper(static_cast<unsigned char>(c)));
-    if (s == "TRUE" || s == "1" || s == "SYNTHETIC") return true;
-    if (s == "FALSE" || s == "0" || s == "INBREED") return false;
+    if (s == "TRUE") return true;      // kgl_app/kgl_runtime.cpp:295-324
+    if (s == "FALSE") return false;
     return std::nullopt;
   }
   constexpr static const size_t ANY_SIZE{99999999999};

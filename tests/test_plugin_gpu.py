@@ -60,3 +60,58 @@ def test_gpu_allele_package_disables_itself_on_bad_device(tmp_path, kgx):
     rio.write_records(path, rec, gt, sv.genome_ids(4), oa.Population.UNPHASED, "Falciparum")
     res = rio.run_driver("GPU_ALLELE", tmp_path, [path], Device=99)
     assert res.returncode == 1 and "initializeAnalysis failed" in res.stderr
+
+
+@pytest.mark.parametrize("algorithm,mode,source", [("Simple", oa.Population.PHASED, "Genome1000"),
+                                                   ("RitlandLocus", oa.Population.UNPHASED, "Falciparum"),
+                                                   ("HallME", oa.Population.PHASED, "Genome1000"),
+                                                   ("Loglikelihood", oa.Population.PHASED, "Genome1000")])
+def test_gpu_inbreed_package_matches_oracle_window_loop(tmp_path, kgx, algorithm, mode, source):
+    """GPU_INBREED through the VirtualAnalysis surface vs the oracle's populationInbreeding window loop."""
+    G, L = 67, 2000
+    rec, gt = sv.multiallelic_block(G, L, rng_seed=31, missing_af_frac=0.03, dup_records=0)
+    for a in rec.af:                       # Gnomad 2.1 reads SAS from the same "AF" field as ALL (kgl_variant_db_freq.h:92)
+        a[:, 4] = a[:, 5]
+    ids = sv.genome_ids(G, prefix="NA")
+    pops = ["AFR", "AMR", "EAS", "EUR", "SAS"]
+    ped = [(g, pops[i % 5]) for i, g in enumerate(ids) if i % 13 != 7]      # a few genomes have no PED record
+    ref_path, dip_path = tmp_path / "gnomad.bin", tmp_path / "diploid.bin"
+    rio.write_records(ref_path, rec, None, ["Reference"], oa.Population.REFERENCE, "Gnomad2_1", population_id="Gnomad")
+    rio.write_records(dip_path, rec, gt, ids, mode, source, population_id="Diploid", ped=ped)
+    params = dict(AnalysisType="false", OutputFile="inbreed", Algorithm=algorithm, MinAlleleFreq=0.02, MaxAlleleFreq=0.9,
+                  LowerWindow=0, UpperWindow=60000, LociiCount=150, SamplingDistance=40)
+    res = rio.run_driver("GPU_INBREED", tmp_path, [ref_path, dip_path], **params)
+    assert res.returncode == 0, res.stderr
+
+    ref = oa.Population("gnomad")
+    ref.add_genomes(["Reference"])
+    ref.add_records(rec, None, oa.Population.REFERENCE)
+    dip = sv.oracle_population(rec, gt, ids, mode)
+    ped_map = dict(ped)
+    sorted_ids = sorted(ids)
+    sp_of = np.array([oa.SUPER_POPS.index(ped_map[g]) if g in ped_map else -1 for g in sorted_ids], dtype=np.int32)
+    cols = oa.population_inbreeding(ref.filter_snp_pass(), dip, sp_of, algorithm, 0, 60000, 40, 150, 0.02, 0.9, seed=oa.FIXED_STARTS)
+    assert len(cols) >= 3
+
+    header, rows = rio.read_csv(tmp_path / "inbreed_detail.csv")
+    got = {}
+    for r in rows:
+        got[(r[0], r[1])] = ([int(r[2]), int(r[4]), int(r[6]), int(r[8]), int(r[10])], [float(r[3]), float(r[5]), float(r[7]), float(r[9]), float(r[11])])
+    n_checked = 0
+    for ident, counts, freqs, present in cols:
+        for k, g in enumerate(sorted_ids):
+            if not present[k]:
+                assert (ident, g) not in got
+                continue
+            c, f = got[(ident, g)]
+            assert c == counts[k].tolist(), (ident, g)                       # major_het, minor_het, minor_hom, major_hom, total
+            assert np.allclose(f[:4], freqs[k, :4], rtol=1e-12, atol=1e-12)
+            tol = {"Simple": 1e-10, "RitlandLocus": 1e-10, "HallME": 1e-9, "Loglikelihood": 1e-5}[algorithm]
+            assert abs(f[4] - freqs[k, 4]) <= tol, (ident, g, f[4], freqs[k, 4])
+            n_checked += 1
+    assert n_checked == len(got) and n_checked >= 3 * (G - 6)
+    # the summary CSV: header line, one column per window with the reference's ident contig_lower_upper
+    lines = (tmp_path / "inbreed.csv").read_text().strip().split("\n")
+    assert lines[0].startswith("DriverParameters,Algorithm:" + algorithm)
+    assert lines[1].split(",")[2:] == [c[0] for c in cols]
+    assert len(lines) == 2 + int(np.sum(sp_of >= 0))
