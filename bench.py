@@ -90,6 +90,7 @@ def main():
     import torch.distributed as dist
 
     from kgl_gene_amd import capi
+    from kgl_gene_amd.sharding import allreduce_counts, replicate_genomes, shard_genomes
 
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a GPU (there is no CPU fallback)")
@@ -102,21 +103,17 @@ def main():
 
     wl = WORKLOADS[args.workload]
     V = args.variants or wl["variants"]
-    if args.workload == "c4":
-        if n_gpus < 2 and not args.genomes:
+    if args.workload == "c4" and not args.genomes:
+        if n_gpus < 2:
             sys.exit("workload c4 (100k x 10M = 250 GB) is sharded: run it with --gpus >= 2")
-        total_genomes = wl["total_genomes"]
-        per = [total_genomes // n_gpus + (1 if r < total_genomes % n_gpus else 0) for r in range(n_gpus)]
+        shards = shard_genomes(wl["total_genomes"], n_gpus)
         scaling = "strong"
     else:
-        g = args.genomes or wl["genomes_per_gpu"]
-        per = [g] * n_gpus
+        shards = replicate_genomes(args.genomes or wl.get("genomes_per_gpu", 10_000), n_gpus)
         scaling = "weak"
-    if args.genomes and args.workload == "c4":
-        per = [args.genomes] * n_gpus
-    total_genomes = sum(per)
-    G = per[rank]
-    genome_base = sum(per[:rank])
+    total_genomes = sum(s.n_genomes for s in shards)
+    G = shards[rank].n_genomes
+    genome_base = shards[rank].genome_base
 
     pop = capi.Population(G, V)
     t0 = time.perf_counter()
@@ -130,8 +127,7 @@ def main():
 
     def step():
         pop.allele_count_by_locus_dev(counts.data_ptr(), stream)
-        if n_gpus > 1:
-            dist.all_reduce(counts, op=dist.ReduceOp.SUM)              # RCCL over xGMI: the one exchange step
+        allreduce_counts(counts, n_gpus)                               # RCCL over xGMI: the one exchange step
         capi.allele_frequency_dev(counts.data_ptr(), V, total_genomes, af.data_ptr(), stream)
 
     def fence():

@@ -197,6 +197,17 @@ int kgx_locus_class_frequencies(const double* minor_af, uint64_t n_loci, uint32_
 int kgx_inbreed(kgx_gt8* gt, uint64_t g0, uint64_t g1, const uint32_t* locus_index, uint64_t n_selected,
                 const double* minor_af, uint32_t amax, int phased, int algorithm, kgx_locus_results* out);
 
+/* Synthetic multi-allelic SNP+indel population (BASELINE.json configs[4]) written straight into
+ * the matrix: 1/2/3 alts (70/20/10 %), 15 % of alts are indels, AFs rescaled to sum <= 0.6, genotypes drawn from
+ * the reference's class probabilities at F = -0.5 + 0.01*((genome_base+g) % 101).  af_table (host, may be NULL)
+ * receives the SNP alt frequencies [n_loci][3], NaN padded.  kgx_synth_multiallelic_host is the bit-identical
+ * host twin for loci [l0,l1): gt8 bytes [l1-l0][pitch] and/or the raw allele pairs [l1-l0][n_genomes][2]
+ * (1-based over ALL alts, 0 = reference); kgx_synth_locus_host describes one locus. */
+int kgx_gt8_synth_multiallelic(kgx_gt8* gt, uint64_t seed, uint64_t genome_base, uint64_t locus_base, double* af_table);
+int kgx_synth_multiallelic_host(uint64_t seed, uint64_t genome_base, uint64_t n_genomes, uint64_t l0, uint64_t l1,
+                                uint8_t* gt8, uint64_t pitch, double* af_table, uint8_t* alleles);
+int kgx_synth_locus_host(uint64_t seed, uint64_t l, int* n_alt, float af[3], int is_indel[3]);
+
 #ifdef __cplusplus
 }
 #endif

@@ -72,6 +72,10 @@ _SIGNATURES = {
     "kgx_locus_class_frequencies": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint32, C.c_double, C.c_void_p, C.c_void_p]),
     "kgx_inbreed": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint32, C.c_int,
                               C.c_int, C.c_void_p]),
+    "kgx_gt8_synth_multiallelic": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64, C.c_void_p]),
+    "kgx_synth_multiallelic_host": (C.c_int, [C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64, C.c_void_p, C.c_uint64,
+                                              C.c_void_p, C.c_void_p]),
+    "kgx_synth_locus_host": (C.c_int, [C.c_uint64, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p]),
     "kgx_compound_offsets": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_void_p]),
 }
 
@@ -349,6 +353,12 @@ class GenotypeMatrix:
         check(lib().kgx_gt8_read_rows(self._h, ptr(out), self.n_genomes, l0, l1))
         return out
 
+    def synth_multiallelic(self, seed: int = 1111, genome_base: int = 0, locus_base: int = 0) -> np.ndarray:
+        """Fill with the synthetic multi-allelic population; returns the SNP AF table [n_loci][3] (NaN padded)."""
+        table = np.zeros((self.n_loci, 3), dtype=np.float64)
+        check(lib().kgx_gt8_synth_multiallelic(self._h, seed, genome_base, locus_base, ptr(table)))
+        return table
+
     def inbreed(self, minor_af: np.ndarray, algorithm: str, phased: bool, locus_index=None, g0: int = 0, g1: int | None = None):
         g1 = self.n_genomes if g1 is None else g1
         a = np.ascontiguousarray(minor_af, dtype=np.float64)
@@ -358,3 +368,12 @@ class GenotypeMatrix:
         check(lib().kgx_inbreed(self._h, g0, g1, None if idx is None else ptr(idx), n_sel, ptr(a), amax, int(bool(phased)),
                                 ALGORITHMS[algorithm], ptr(out)))
         return out
+
+
+def synth_multiallelic_host(seed: int, genome_base: int, n_genomes: int, l0: int, l1: int):
+    """Host twin: (gt8 bytes [l1-l0][G], SNP AF table [l1-l0][3], raw allele pairs [l1-l0][G][2])."""
+    gt8 = np.zeros((l1 - l0, n_genomes), dtype=np.uint8)
+    table = np.zeros((l1 - l0, 3), dtype=np.float64)
+    alleles = np.zeros((l1 - l0, n_genomes, 2), dtype=np.uint8)
+    check(lib().kgx_synth_multiallelic_host(seed, genome_base, n_genomes, l0, l1, ptr(gt8), n_genomes, ptr(table), ptr(alleles)))
+    return gt8, table, alleles

@@ -719,7 +719,7 @@ int kgx_locus_class_frequencies(const double* minor_af, uint64_t n_loci, uint32_
     std::vector<uint8_t> v(n_loci);
     if (hipMemcpyAsync(d_in, minor_af, n_loci * amax * sizeof(double), hipMemcpyHostToDevice, g_state.stream) != hipSuccess) rc = fail(KGX_EHIP, "H2D failed");
     if (rc == KGX_OK) {
-      hipLaunchKernelGGL(k_locus_tables, dim3(stream_grid(n_loci, kBlock)), dim3(kBlock), 0, g_state.stream, d_in, n_loci, amax, inbreeding, d_table, d_valid);
+      hipLaunchKernelGGL((k_locus_tables<false>), dim3(stream_grid(n_loci, kBlock)), dim3(kBlock), 0, g_state.stream, d_in, n_loci, amax, inbreeding, d_table, d_valid);
       if (hipGetLastError() != hipSuccess ||
           hipMemcpyAsync(table.data(), d_table, table.size() * sizeof(double), hipMemcpyDeviceToHost, g_state.stream) != hipSuccess ||
           hipMemcpyAsync(v.data(), d_valid, n_loci, hipMemcpyDeviceToHost, g_state.stream) != hipSuccess ||
@@ -729,7 +729,7 @@ int kgx_locus_class_frequencies(const double* minor_af, uint64_t n_loci, uint32_
     if (rc == KGX_OK) {
       for (uint64_t l = 0; l < n_loci; ++l) {
         for (int k = 0; k < 5; ++k) out[l * 5 + k] = table[l * stride + amax + k];
-        if (valid) valid[l] = v[l];
+        if (valid) valid[l] = v[l] ? 1 : 0;
       }
     }
   }
@@ -754,7 +754,7 @@ int kgx_inbreed(kgx_gt8* h, uint64_t g0, uint64_t g1, const uint32_t* locus_inde
   if (n == 0) return KGX_OK;
   static_assert(sizeof(kgx_locus_results) == sizeof(LocusResultsDev), "LocusResults layout");
 
-  const uint32_t stride = amax + kTableExtra;
+  const uint32_t stride = sweep_stride(amax);
   const uint32_t gx = static_cast<uint32_t>(((n + 3) / 4 + kBlock - 1) / kBlock);
   uint64_t n_seg = (static_cast<uint64_t>(g_state.compute_units) * 8 + gx - 1) / gx;
   if (n_seg > (n_sel + 63) / 64) n_seg = (n_sel + 63) / 64;
@@ -763,7 +763,7 @@ int kgx_inbreed(kgx_gt8* h, uint64_t g0, uint64_t g1, const uint32_t* locus_inde
   const uint64_t per_seg = n_sel ? (n_sel + n_seg - 1) / n_seg : 1;
   n_seg = n_sel ? (n_sel + per_seg - 1) / per_seg : 1;
 
-  double *d_af = nullptr, *d_table = nullptr, *d_part = nullptr, *d_sums = nullptr, *d_f = nullptr, *d_eval = nullptr;
+  double *d_af = nullptr, *d_table = nullptr, *d_part = nullptr, *d_sums = nullptr, *d_f = nullptr, *d_eval = nullptr, *d_segdef = nullptr;
   uint8_t* d_valid = nullptr;
   uint32_t* d_index = nullptr;
   unsigned long long* d_counts = nullptr;
@@ -781,6 +781,7 @@ int kgx_inbreed(kgx_gt8* h, uint64_t g0, uint64_t g1, const uint32_t* locus_inde
   try_hip(hipMalloc(&d_table, n_tab * stride * sizeof(double)), KGX_ENOMEM, "hipMalloc(table)");
   try_hip(hipMalloc(&d_valid, n_tab), KGX_ENOMEM, "hipMalloc(valid)");
   try_hip(hipMalloc(&d_part, n_seg * n * kParts0 * sizeof(double)), KGX_ENOMEM, "hipMalloc(partials)");
+  try_hip(hipMalloc(&d_segdef, n_seg * kSegDefaults * sizeof(double)), KGX_ENOMEM, "hipMalloc(segment defaults)");
   try_hip(hipMalloc(&d_sums, n * kParts0 * sizeof(double)), KGX_ENOMEM, "hipMalloc(sums)");
   try_hip(hipMalloc(&d_counts, n * 6 * sizeof(unsigned long long)), KGX_ENOMEM, "hipMalloc(counts)");
   try_hip(hipMalloc(&d_f, n * sizeof(double)), KGX_ENOMEM, "hipMalloc(f)");
@@ -801,10 +802,16 @@ int kgx_inbreed(kgx_gt8* h, uint64_t g0, uint64_t g1, const uint32_t* locus_inde
   const uint64_t dwords_per_row = h->pitch / 4;
   auto sweep = [&](int mode) {
     if (n_sel == 0) return;
-    if (mode == 0)
-      hipLaunchKernelGGL((k_inbreed_sweep<0>), grid, dim3(kBlock), 0, st, gt32, dwords_per_row, g0, n, d_index, n_sel, per_seg, d_table,
-                         d_valid, amax, phased, d_f, d_counts, d_part);
-    else if (mode == 1)
+    if (mode == 0) {
+      if (env_int("KGX_K5_GENERIC", 0)) {
+        hipLaunchKernelGGL((k_inbreed_sweep<0>), grid, dim3(kBlock), 0, st, gt32, dwords_per_row, g0, n, d_index, n_sel, per_seg, d_table,
+                           d_valid, amax, phased, d_f, d_counts, d_part);
+      } else {
+        hipLaunchKernelGGL(k_segment_defaults, dim3(static_cast<uint32_t>(n_seg)), dim3(kWave), 0, st, d_table, d_valid, n_sel, per_seg, amax, d_segdef);
+        hipLaunchKernelGGL(k_inbreed_sweep_fast, grid, dim3(kBlock), 0, st, gt32, dwords_per_row, g0, n, d_index, n_sel, per_seg, d_table,
+                           d_valid, amax, phased, d_segdef, d_counts, d_part);
+      }
+    } else if (mode == 1)
       hipLaunchKernelGGL((k_inbreed_sweep<1>), grid, dim3(kBlock), 0, st, gt32, dwords_per_row, g0, n, d_index, n_sel, per_seg, d_table,
                          d_valid, amax, phased, d_f, d_counts, d_part);
     else
@@ -813,7 +820,7 @@ int kgx_inbreed(kgx_gt8* h, uint64_t g0, uint64_t g1, const uint32_t* locus_inde
   };
   const uint32_t lin_grid = stream_grid(n, kBlock);
   if (rc == KGX_OK) {
-    if (n_sel) hipLaunchKernelGGL(k_locus_tables, dim3(stream_grid(n_sel, kBlock)), dim3(kBlock), 0, st, d_af, n_sel, amax, 0.0, d_table, d_valid);
+    if (n_sel) hipLaunchKernelGGL((k_locus_tables<true>), dim3(stream_grid(n_sel, kBlock)), dim3(kBlock), 0, st, d_af, n_sel, amax, 0.0, d_table, d_valid);
     sweep(0);
     hipLaunchKernelGGL(k_reduce_parts, dim3(stream_grid(n * kParts0, kBlock)), dim3(kBlock), 0, st, d_part, n_seg, n * kParts0, d_sums);
     if (algorithm == 2) {
@@ -865,9 +872,60 @@ int kgx_inbreed(kgx_gt8* h, uint64_t g0, uint64_t g1, const uint32_t* locus_inde
   }
   for (void* p : {static_cast<void*>(d_af), static_cast<void*>(d_table), static_cast<void*>(d_valid), static_cast<void*>(d_part),
                   static_cast<void*>(d_sums), static_cast<void*>(d_counts), static_cast<void*>(d_f), static_cast<void*>(d_eval),
-                  static_cast<void*>(d_out), static_cast<void*>(d_index), static_cast<void*>(d_golden)})
+                  static_cast<void*>(d_out), static_cast<void*>(d_index), static_cast<void*>(d_golden), static_cast<void*>(d_segdef)})
     if (p) (void)hipFree(p);
   return rc;
+}
+
+int kgx_gt8_synth_multiallelic(kgx_gt8* h, uint64_t seed, uint64_t genome_base, uint64_t locus_base, double* af_table) {
+  if (int rc = require_device()) return rc;
+  if (!h) return fail(KGX_EINVAL, "null handle");
+  if (h->n_loci == 0) return KGX_OK;
+  double* d_table = nullptr;
+  if (af_table) KGX_HIP_MEM(hipMalloc(&d_table, h->n_loci * KGX_SYNTH_MAX_ALTS * sizeof(double)));
+  const uint64_t work = h->n_loci * ((h->n_genomes + 3) / 4);
+  hipLaunchKernelGGL(k_synth_gt8, dim3(stream_grid(work, kBlock)), dim3(kBlock), 0, g_state.stream,
+                     reinterpret_cast<uint32_t*>(h->d_gt), h->pitch / 4, h->n_loci, h->n_genomes, seed, genome_base, locus_base, d_table);
+  int rc = KGX_OK;
+  if (hipGetLastError() != hipSuccess) rc = fail(KGX_EHIP, "synthetic genotype kernel launch failed");
+  if (rc == KGX_OK && af_table &&
+      hipMemcpyAsync(af_table, d_table, h->n_loci * KGX_SYNTH_MAX_ALTS * sizeof(double), hipMemcpyDeviceToHost, g_state.stream) != hipSuccess)
+    rc = fail(KGX_EHIP, "D2H of the allele-frequency table failed");
+  if (rc == KGX_OK && hipStreamSynchronize(g_state.stream) != hipSuccess) rc = fail(KGX_EHIP, "synthetic genotype kernel failed");
+  if (d_table) (void)hipFree(d_table);
+  return rc;
+}
+
+int kgx_synth_multiallelic_host(uint64_t seed, uint64_t genome_base, uint64_t n_genomes, uint64_t l0, uint64_t l1, uint8_t* gt8,
+                                uint64_t pitch, double* af_table, uint8_t* alleles) {
+  if (l0 > l1 || (gt8 && pitch < n_genomes)) return fail(KGX_EINVAL, "bad range or pitch");
+  for (uint64_t l = l0; l < l1; ++l) {
+    const kgx_synth_locus loc = kgx_synth_make_locus(seed, l);
+    if (af_table) {
+      double* row = af_table + (l - l0) * KGX_SYNTH_MAX_ALTS;
+      for (int a = 0; a < KGX_SYNTH_MAX_ALTS; ++a) row[a] = std::nan("");
+      for (int a = 0; a < loc.n_alt; ++a)
+        if (!loc.is_indel[a]) row[loc.snp_index[a] - 1] = static_cast<double>(loc.af[a]);
+    }
+    for (uint64_t g = 0; g < n_genomes; ++g) {
+      int a1, a2;
+      kgx_synth_multi_genotype(seed, l, genome_base + g, loc, a1, a2);
+      if (gt8) gt8[(l - l0) * pitch + g] = static_cast<uint8_t>(kgx_synth_gt8_byte(loc, a1, a2));
+      if (alleles) {
+        alleles[((l - l0) * n_genomes + g) * 2 + 0] = static_cast<uint8_t>(a1);
+        alleles[((l - l0) * n_genomes + g) * 2 + 1] = static_cast<uint8_t>(a2);
+      }
+    }
+  }
+  return KGX_OK;
+}
+
+int kgx_synth_locus_host(uint64_t seed, uint64_t l, int* n_alt, float af[3], int is_indel[3]) {
+  if (!n_alt || !af || !is_indel) return fail(KGX_EINVAL, "null argument");
+  const kgx_synth_locus loc = kgx_synth_make_locus(seed, l);
+  *n_alt = loc.n_alt;
+  for (int a = 0; a < KGX_SYNTH_MAX_ALTS; ++a) { af[a] = loc.af[a]; is_indel[a] = loc.is_indel[a]; }
+  return KGX_OK;
 }
 
 }  // extern "C"

@@ -12,6 +12,7 @@
 #include <stdint.h>
 
 #include "kgx_synth.h"
+#include "kgx_synth_multi.h"
 
 typedef uint32_t kgx_v4u __attribute__((ext_vector_type(4)));
 
@@ -437,16 +438,21 @@ k_compound_offsets(const uint32_t* __restrict__ rows, uint64_t dwords_per_row, u
 // majorAlleleFrequency(), cf[4] = alleleClassFrequencies(0.0) {majorHom, majorHet, minorHom, minorHet}.
 // ---------------------------------------------------------------------------------------------
 constexpr int kTableExtra = 5;   // p_major + 4 class frequencies after the af[amax] slots
+// The sweep's table row is wider: [af[amax] | p_major | cf[4] | 1/af[amax] | 1/p_major]  (reciprocals once per locus
+// instead of one fp64 divide per genome per locus in processRitlandLocus, _calc.cpp:398).
+__host__ __device__ constexpr uint32_t sweep_stride(uint32_t amax) { return 2 * amax + kTableExtra + 1; }
+enum : uint8_t { kLocusValid = 1, kLocusDefault = 2, kLocusRitlandDefault = 4 };   // valid[] flag bits
 
 __device__ __forceinline__ double clamp01(double x) { return x < 0.0 ? 0.0 : (x > 1.0 ? 1.0 : x); }
 
 // K6: AlleleFreqVector (ctor clamp, _freq.cpp:47), checkValidAlleleVector (:61-75), majorAlleleFrequency
 // (:119-123), unadjustedAlleleClassFrequencies(0.0) + normalize (:127-217), in the reference's operation order.
 // valid[l] = 0 marks a locus generateFrequencies skips (:445-449).
+template <bool WIDE>
 __global__ void __launch_bounds__(kBlock)
 k_locus_tables(const double* __restrict__ af_in, uint64_t n_loci, uint32_t amax, double inbreeding,
                double* __restrict__ table, uint8_t* __restrict__ valid) {
-  const uint32_t stride = amax + kTableExtra;
+  const uint32_t stride = WIDE ? sweep_stride(amax) : amax + kTableExtra;
   for (uint64_t l = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x; l < n_loci;
        l += static_cast<uint64_t>(gridDim.x) * blockDim.x) {
     const double* in = af_in + l * amax;
@@ -458,8 +464,17 @@ k_locus_tables(const double* __restrict__ af_in, uint64_t n_loci, uint32_t amax,
       if (f == f) { f = clamp01(f); sum_minor += f; ++n; }
       out[a] = f;
     }
-    valid[l] = (n > 0 && !((sum_minor - 1.0) > 1.0e-5)) ? 1 : 0;
-    out[amax] = clamp01(1.0 - clamp01(sum_minor));                        // majorAlleleFrequency()
+    const bool is_valid = n > 0 && !((sum_minor - 1.0) > 1.0e-5);
+    const double p_major = clamp01(1.0 - clamp01(sum_minor));             // majorAlleleFrequency()
+    out[amax] = p_major;
+    // flag bits: a reference-homozygous genome is MAJOR_HOMOZYGOUS here iff p_major > 0.01 (_freq.cpp:531-539) and
+    // enters the Ritland sum iff p_major > 0.001 (_calc.cpp:380,396)
+    valid[l] = !is_valid ? 0 : static_cast<uint8_t>(kLocusValid | (p_major > 0.01 ? kLocusDefault : 0) |
+                                                    ((p_major > 0.01 && p_major > 0.001) ? kLocusRitlandDefault : 0));
+    if constexpr (WIDE) {
+      for (uint32_t a = 0; a < amax; ++a) out[amax + kTableExtra + a] = 1.0 / out[a];
+      out[2 * amax + kTableExtra] = 1.0 / p_major;
+    }
     const double major_frequency = (1.0 - sum_minor) > 0.0 ? (1.0 - sum_minor) : 0.0;
     const bool rescale = sum_minor > 1.0;
     double minor_hom = 0.0, major_het = 0.0, minor_het = 0.0;
@@ -537,7 +552,7 @@ k_inbreed_sweep(const uint32_t* __restrict__ gt, uint64_t dwords_per_row, uint64
   const uint64_t seg = blockIdx.y;
   const uint64_t s_begin = seg * loci_per_seg;
   const uint64_t s_end = s_begin + loci_per_seg < n_sel ? s_begin + loci_per_seg : n_sel;
-  const uint32_t stride = amax + kTableExtra;
+  const uint32_t stride = sweep_stride(amax);
   const uint64_t col = (g0 >> 2) + quad;                  // g0 is a multiple of 4
 
   uint32_t cnt[4][6];        // majorHom, majorHet, minorHom, minorHet, total, ritland count
@@ -554,7 +569,7 @@ k_inbreed_sweep(const uint32_t* __restrict__ gt, uint64_t dwords_per_row, uint64
   }
 
   for (uint64_t s = s_begin; s < s_end; ++s) {
-    if (!valid[s]) continue;
+    if (!(valid[s] & kLocusValid)) continue;
     const uint64_t l = locus_index ? static_cast<uint64_t>(locus_index[s]) : s;
     const uint32_t w = gt[l * dwords_per_row + col];
     const double* row = table + s * stride;
@@ -608,6 +623,145 @@ k_inbreed_sweep(const uint32_t* __restrict__ gt, uint64_t dwords_per_row, uint64
     } else {
       part[seg * n_genomes + g] = acc[j][0];
     }
+  }
+}
+
+// Per-segment totals of what a genome that is reference-homozygous at EVERY locus of the segment would collect:
+// def[seg] = { sum majorHom cf, sum majorHet cf, sum minorHom cf, sum minorHet cf, Ritland sum, #default loci,
+// #Ritland-default loci, 0 }.  One wave per segment; lanes stride the loci, then a wave reduction.
+constexpr int kSegDefaults = 8;
+__global__ void __launch_bounds__(kWave)
+k_segment_defaults(const double* __restrict__ table, const uint8_t* __restrict__ flags, uint64_t n_sel, uint64_t loci_per_seg,
+                   uint32_t amax, double* __restrict__ seg_def) {
+  const uint64_t seg = blockIdx.x;
+  const uint64_t s_begin = seg * loci_per_seg;
+  const uint64_t s_end = s_begin + loci_per_seg < n_sel ? s_begin + loci_per_seg : n_sel;
+  const uint32_t stride = sweep_stride(amax);
+  double acc[7] = {0, 0, 0, 0, 0, 0, 0};
+  for (uint64_t s = s_begin + threadIdx.x; s < s_end; s += kWave) {
+    const uint8_t f = flags[s];
+    if (!(f & kLocusDefault)) continue;
+    const double* row = table + s * stride;
+    acc[0] += row[amax + 1]; acc[1] += row[amax + 2]; acc[2] += row[amax + 3]; acc[3] += row[amax + 4];
+    acc[5] += 1.0;
+    if (f & kLocusRitlandDefault) { acc[4] += row[2 * amax + kTableExtra]; acc[4] -= 1.0; acc[6] += 1.0; }
+  }
+#pragma unroll
+  for (int k = 0; k < 7; ++k) {
+    double v = acc[k];
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+    if (threadIdx.x == 0) seg_def[seg * kSegDefaults + k] = v;
+  }
+  if (threadIdx.x == 0) seg_def[seg * kSegDefaults + 7] = 0.0;
+}
+
+// K5 fast path (MODE 0 of k_inbreed_sweep, same results up to fp64 summation order).  Every class-frequency sum
+// of generateFrequencies is class independent (_freq.cpp:549-556) and a reference-homozygous genome behaves the
+// same at a locus for every genome, so a genome's results are the segment defaults (k_segment_defaults) corrected
+// at the loci where it carries a variant.  Reference-homozygous dwords (4 genomes) cost one load and one compare:
+// the sweep is HBM-bound instead of fp64-bound.  8 locus rows are in flight per lane.
+__global__ void __launch_bounds__(kBlock)
+k_inbreed_sweep_fast(const uint32_t* __restrict__ gt, uint64_t dwords_per_row, uint64_t g0, uint64_t n_genomes,
+                     const uint32_t* __restrict__ locus_index, uint64_t n_sel, uint64_t loci_per_seg,
+                     const double* __restrict__ table, const uint8_t* __restrict__ flags, uint32_t amax, int phased,
+                     const double* __restrict__ seg_def, unsigned long long* __restrict__ counts, double* __restrict__ part) {
+  const uint64_t quad = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (quad * 4 >= n_genomes) return;
+  const uint64_t seg = blockIdx.y;
+  const uint64_t s_begin = seg * loci_per_seg;
+  const uint64_t s_end = s_begin + loci_per_seg < n_sel ? s_begin + loci_per_seg : n_sel;
+  const uint32_t stride = sweep_stride(amax);
+  const uint64_t col = (g0 >> 2) + quad;
+
+  uint32_t miss_def[4], miss_rit[4], cnt[4][3], rit_cnt[4];   // cnt: majorHet, minorHom, minorHet
+  double cf_corr[4][4], rit_corr[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    miss_def[j] = miss_rit[j] = rit_cnt[j] = 0;
+    cnt[j][0] = cnt[j][1] = cnt[j][2] = 0;
+    cf_corr[j][0] = cf_corr[j][1] = cf_corr[j][2] = cf_corr[j][3] = 0.0;
+    rit_corr[j] = 0.0;
+  }
+
+  constexpr int kBatch = 8;
+  for (uint64_t s0 = s_begin; s0 < s_end; s0 += kBatch) {
+    uint32_t w[kBatch];
+#pragma unroll
+    for (int i = 0; i < kBatch; ++i) {
+      const uint64_t s = s0 + i;
+      uint32_t v = 0;
+      if (s < s_end) {
+        const uint64_t l = locus_index ? static_cast<uint64_t>(locus_index[s]) : s;
+        v = __builtin_nontemporal_load(gt + l * dwords_per_row + col);
+      }
+      w[i] = v;
+    }
+#pragma unroll
+    for (int i = 0; i < kBatch; ++i) {
+      if (w[i] == 0) continue;
+      const uint64_t s = s0 + i;
+      const uint8_t f = flags[s];
+      if (!(f & kLocusValid)) continue;
+      const double* row = table + s * stride;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const uint32_t b = (w[i] >> (8 * j)) & 0xFFu;
+        if (b == 0) continue;
+        if (f & kLocusDefault) ++miss_def[j];
+        if (f & kLocusRitlandDefault) {
+          ++miss_rit[j];
+          rit_corr[j] -= row[2 * amax + kTableExtra];
+          rit_corr[j] += 1.0;
+        }
+        double f1 = 0.0, f2 = 0.0;
+        const int cls = classify_cell(b, row, amax, phased != 0, f1, f2);
+        if (cls == kClassNone) {
+          if (f & kLocusDefault) {
+            cf_corr[j][0] -= row[amax + 1]; cf_corr[j][1] -= row[amax + 2]; cf_corr[j][2] -= row[amax + 3]; cf_corr[j][3] -= row[amax + 4];
+          }
+          continue;
+        }
+        if (!(f & kLocusDefault)) {
+          cf_corr[j][0] += row[amax + 1]; cf_corr[j][1] += row[amax + 2]; cf_corr[j][2] += row[amax + 3]; cf_corr[j][3] += row[amax + 4];
+        }
+        ++cnt[j][cls - kMajorHet];
+        if (cls == kMinorHom) {
+          if (f1 > 0.001) {
+            rit_corr[j] += row[amax + kTableExtra + (b & 15u) - 1];     // 1 / af[a1]
+            rit_corr[j] -= 1.0;
+            ++rit_cnt[j];
+          }
+        } else {
+          rit_corr[j] -= 1.0;
+          ++rit_cnt[j];
+        }
+      }
+    }
+  }
+
+  const double* def = seg_def + seg * kSegDefaults;
+  const unsigned long long n_def = static_cast<unsigned long long>(def[5]);
+  const unsigned long long n_rit = static_cast<unsigned long long>(def[6]);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const uint64_t g = quad * 4 + j;
+    if (g >= n_genomes) continue;
+    const unsigned long long major_hom = n_def - miss_def[j];
+    const unsigned long long classified = cnt[j][0] + cnt[j][1] + cnt[j][2];
+    unsigned long long* c = counts + g * 6;
+    if (major_hom) atomicAdd(c + 0, major_hom);
+    if (cnt[j][0]) atomicAdd(c + 1, static_cast<unsigned long long>(cnt[j][0]));
+    if (cnt[j][1]) atomicAdd(c + 2, static_cast<unsigned long long>(cnt[j][1]));
+    if (cnt[j][2]) atomicAdd(c + 3, static_cast<unsigned long long>(cnt[j][2]));
+    if (major_hom + classified) atomicAdd(c + 4, major_hom + classified);
+    const unsigned long long rit = n_rit - miss_rit[j] + rit_cnt[j];
+    if (rit) atomicAdd(c + 5, rit);
+    double* p = part + (seg * n_genomes + g) * kParts0;
+    p[0] = def[0] + cf_corr[j][0];
+    p[1] = def[1] + cf_corr[j][1];
+    p[2] = def[2] + cf_corr[j][2];
+    p[3] = def[3] + cf_corr[j][3];
+    p[4] = def[4] + rit_corr[j];
   }
 }
 
@@ -702,6 +856,36 @@ k_finish_inbreed(const unsigned long long* __restrict__ counts, const double* __
     }
     r.inbred_allele_sum = coefficient;
     out[g] = r;
+  }
+}
+
+// Synthetic multi-allelic genotype bytes straight into HBM (one thread per dword = 4 genomes of one locus),
+// plus the per-locus SNP allele-frequency table [n_loci][3] (NaN padded) the inbreeding sweep needs.
+__global__ void __launch_bounds__(kBlock)
+k_synth_gt8(uint32_t* __restrict__ gt, uint64_t dwords_per_row, uint64_t n_loci, uint64_t n_genomes, uint64_t seed,
+            uint64_t genome_base, uint64_t locus_base, double* __restrict__ af_table) {
+  const uint64_t quads = (n_genomes + 3) / 4;
+  const uint64_t total = n_loci * quads;
+  for (uint64_t i = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < total;
+       i += static_cast<uint64_t>(gridDim.x) * blockDim.x) {
+    const uint64_t l = i / quads, q = i % quads;
+    const kgx_synth_locus loc = kgx_synth_make_locus(seed, locus_base + l);
+    if (q == 0 && af_table) {
+      double row[KGX_SYNTH_MAX_ALTS] = {__builtin_nan(""), __builtin_nan(""), __builtin_nan("")};
+      for (int a = 0; a < loc.n_alt; ++a)
+        if (!loc.is_indel[a]) row[loc.snp_index[a] - 1] = static_cast<double>(loc.af[a]);
+      for (int a = 0; a < KGX_SYNTH_MAX_ALTS; ++a) af_table[l * KGX_SYNTH_MAX_ALTS + a] = row[a];
+    }
+    uint32_t word = 0;
+    for (int j = 0; j < 4; ++j) {
+      const uint64_t g = q * 4 + j;
+      if (g < n_genomes) {
+        int a1, a2;
+        kgx_synth_multi_genotype(seed, locus_base + l, genome_base + g, loc, a1, a2);
+        word |= kgx_synth_gt8_byte(loc, a1, a2) << (8 * j);
+      }
+    }
+    gt[l * dwords_per_row + q] = word;
   }
 }
 

@@ -103,3 +103,29 @@ def multiallelic_block(G, L, rng_seed=11, contig="chr1", indel_frac=0.15, missin
         probs /= probs.sum()
         gt[r] = rng.choice(len(probs), size=(G, 2), p=probs).astype(np.uint8)
     return rec, gt
+
+
+def synth_multiallelic_block(G, L, seed=1111, contig="chr1"):
+    """The product's synthetic multi-allelic population (host twin of the device generator) as records + gt."""
+    import ctypes as C
+
+    gt8, table, alleles = capi.synth_multiallelic_host(seed, 0, G, 0, L)
+    rng = np.random.default_rng(seed)
+    offsets = np.cumsum(rng.integers(1, 51, L)).astype(np.uint64)
+    refs, alts, afs = [], [], []
+    bases = "ACGT"
+    for l in range(L):
+        n_alt = C.c_int(0)
+        af = (C.c_float * 3)()
+        indel = (C.c_int * 3)()
+        capi.check(capi.lib().kgx_synth_locus_host(seed, l, C.byref(n_alt), af, indel))
+        ref = bases[l % 4]
+        cand = [b for b in bases if b != ref]
+        al = []
+        for a in range(n_alt.value):
+            al.append(ref + "GA"[a % 2] * (a + 1) if indel[a] else cand[a])
+        refs.append(ref)
+        alts.append(al)
+        afs.append(np.tile(np.array([af[a] for a in range(n_alt.value)], dtype=np.float32).reshape(-1, 1), (1, 6)))
+    rec = oa.Records(contig, offsets, refs, alts, af=afs)
+    return rec, alleles, gt8, table

@@ -107,3 +107,58 @@ def test_genome_major_loader_and_subranges(kgx):
     part = m.inbreed(af, "Simple", phased=True, g0=32, g1=64)
     assert np.array_equal(whole[32:64], part)
     m.close()
+
+
+def test_device_multiallelic_generator_and_oracle_parity(kgx):
+    """The C5-shaped synthetic population: device generator == host twin, and the sweep on it == oracle."""
+    G, L = 160, 900
+    rec, alleles, gt8_host, table_host = sv.synth_multiallelic_block(G, L)
+    m = kgx.GenotypeMatrix(G, L)
+    table = m.synth_multiallelic(1111, 0, 0)
+    assert np.array_equal(m.read_rows(), gt8_host)
+    assert np.array_equal(np.isnan(table), np.isnan(table_host)) and np.array_equal(np.nan_to_num(table), np.nan_to_num(table_host))
+    ids = sv.genome_ids(G)
+    ref = oa.Population("gnomad")
+    ref.add_genomes(["Reference"])
+    ref.add_records(rec, None, oa.Population.REFERENCE)
+    dip = sv.oracle_population(rec, alleles, ids, oa.Population.PHASED)
+    # every locus with a SNP alt, no spacing: the whole matrix is one window
+    lower, upper = 0, int(rec.offsets[-1]) + 1
+    counts, freqs, present, _ = oa.inbreed_window(ref.filter_snp_pass(), dip, np.full(G, oa.ALL, dtype=np.int32), "Simple",
+                                                  lower, upper, 1, 10**6, 0.0, 1.0)
+    got = m.inbreed(table, "Simple", phased=True)[dip.genome_order()]
+    for k, name in enumerate(["major_hetero_count", "minor_hetero_count", "minor_homo_count", "major_homo_count", "total_allele_count"]):
+        assert np.array_equal(got[name], counts[:, k]), name
+    assert np.allclose(got["inbred_allele_sum"], freqs[:, 4], rtol=1e-10, atol=1e-12)
+    # the estimator recovers the generating inbreeding coefficients on average
+    F_true = (np.arange(G) % 101 - 50) / 100.0
+    assert np.corrcoef(F_true, got["inbred_allele_sum"][np.argsort(dip.genome_order())])[0, 1] > 0.8
+    m.close()
+
+
+def test_c5_full_size_properties(kgx):
+    """BASELINE config 4 on one GPU: 10k genomes x 5M mixed SNP+indel multi-allelic loci (50 GB)."""
+    G, L = 10_000, 5_000_000
+    m = kgx.GenotypeMatrix(G, L)
+    table = m.synth_multiallelic(1111, 0, 0)
+    res = m.inbreed(table, "Simple", phased=True)
+    n_valid = int((~np.isnan(table)).any(1).sum())
+    assert np.all(res["total_allele_count"] <= n_valid) and np.all(res["total_allele_count"] > 0.98 * n_valid)
+    tot = res["major_hetero_count"] + res["minor_hetero_count"] + res["minor_homo_count"] + res["major_homo_count"]
+    assert np.array_equal(tot, res["total_allele_count"])
+    fsum = res["major_hetero_freq"] + res["minor_hetero_freq"] + res["minor_homo_freq"] + res["major_homo_freq"]
+    assert np.allclose(fsum, res["total_allele_count"], rtol=1e-9)          # class frequencies sum to 1 per classified locus
+    F_true = (np.arange(G) % 101 - 50) / 100.0
+    assert np.abs(res["inbred_allele_sum"] - F_true).max() < 0.05           # 5M loci pin F tightly
+    # sub-block regenerated by the host twin
+    l0 = 1_234_567
+    host_gt8, host_table, _ = kgx.synth_multiallelic_host(1111, 0, G, l0, l0 + 4)
+    assert np.array_equal(m.read_rows(l0, l0 + 4), host_gt8)
+    # a genome sub-range gives the same rows as the whole
+    part = m.inbreed(table, "Simple", phased=True, g0=4000, g1=4100)
+    for name in part.dtype.names:       # integer fields bit-exact; fp64 sums differ only by the segment grouping
+        if name.endswith("_count"):
+            assert np.array_equal(part[name], res[name][4000:4100])
+        else:
+            assert np.allclose(part[name], res[name][4000:4100], rtol=1e-11, atol=0)
+    m.close()

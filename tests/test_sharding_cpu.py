@@ -1,0 +1,77 @@
+"""The N > 1 path on CPU: two gloo ranks shard the genomes of one synthetic population, count their shards,
+all-reduce the per-variant counts and gather the per-genome rows.  The counting itself is done here with numpy
+on the host twin of the device generator (the HIP kernels cannot run without a GPU); what is under test is the
+product's sharding plan and exchange step (kgl_gene_amd/sharding.py), which bench.py runs unchanged over RCCL."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from kgl_gene_amd import capi
+from kgl_gene_amd.sharding import allreduce_counts, gather_by_genome, replicate_genomes, shard_genomes
+
+TOTAL_G, V, SEED = 1003, 400, 1111
+
+
+def counts_of(codes):
+    het, hom, oth = (codes == 1).sum(1), (codes == 2).sum(1), (codes == 3).sum(1)
+    return np.stack([codes.shape[1] - het - hom - oth, het, hom, oth], 1).astype(np.uint32)
+
+
+def _worker(rank, world, port, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    shards = shard_genomes(TOTAL_G, world)
+    me = shards[rank]
+    rows, _ = capi.synth_biallelic_host(SEED, me.genome_base, me.n_genomes, 0, V)
+    codes = capi.unpack_dosage2(rows, me.n_genomes)
+    counts = torch.from_numpy(counts_of(codes).view(np.int32).copy())
+    allreduce_counts(counts, world)
+    by_genome = torch.from_numpy(np.stack([(codes == k).sum(0) for k in range(4)], 1).astype(np.int64))
+    gathered = gather_by_genome(by_genome, shards, world)
+    if rank == 0:
+        np.save(os.path.join(out_dir, "counts.npy"), counts.numpy().view(np.uint32))
+        np.save(os.path.join(out_dir, "by_genome.npy"), gathered.numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+@pytest.mark.timeout(120)
+def test_two_rank_gloo_allreduce_matches_unsharded(tmp_path):
+    mp.spawn(_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    rows, _ = capi.synth_biallelic_host(SEED, 0, TOTAL_G, 0, V)
+    codes = capi.unpack_dosage2(rows, TOTAL_G)
+    want = counts_of(codes)
+    want[:, 0] = TOTAL_G - want[:, 1] - want[:, 2] - want[:, 3]
+    assert np.array_equal(np.load(tmp_path / "counts.npy"), want)
+    assert np.array_equal(np.load(tmp_path / "by_genome.npy"), np.stack([(codes == k).sum(0) for k in range(4)], 1))
+
+
+def test_shard_plans():
+    for total, world in [(100_000, 8), (1003, 2), (7, 4), (0, 3), (10, 1), (12_500, 8)]:
+        shards = shard_genomes(total, world)
+        assert [s.rank for s in shards] == list(range(world))
+        assert sum(s.n_genomes for s in shards) == total
+        base = 0
+        for s in shards:
+            assert s.genome_base == base and s.genome_base % 4 == 0 or s.n_genomes == 0
+            base += s.n_genomes
+        sizes = [s.n_genomes for s in shards if s.n_genomes]
+        if sizes:
+            assert max(sizes) - min(sizes) <= 4 + 3
+    assert [s.n_genomes for s in shard_genomes(100_000, 8)] == [12_500] * 8          # BASELINE config 3
+    weak = replicate_genomes(10_000, 4)
+    assert [s.genome_base for s in weak] == [0, 10_000, 20_000, 30_000]
+    with pytest.raises(ValueError):
+        shard_genomes(10, 0)
