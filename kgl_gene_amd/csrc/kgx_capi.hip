@@ -758,9 +758,11 @@ int kgx_inbreed(kgx_gt8* h, uint64_t g0, uint64_t g1, const uint32_t* locus_inde
   const uint32_t gx = static_cast<uint32_t>(((n + 3) / 4 + kBlock - 1) / kBlock);
   uint64_t n_seg = (static_cast<uint64_t>(g_state.compute_units) * 8 + gx - 1) / gx;
   if (n_seg > (n_sel + 63) / 64) n_seg = (n_sel + 63) / 64;
+  if (n_seg < (n_sel + 65534) / 65535) n_seg = (n_sel + 65534) / 65535;   // 16-bit class counters per segment
   if (n_seg < 1) n_seg = 1;
   if (n_seg > 65535) n_seg = 65535;
-  const uint64_t per_seg = n_sel ? (n_sel + n_seg - 1) / n_seg : 1;
+  uint64_t per_seg = n_sel ? (n_sel + n_seg - 1) / n_seg : 8;
+  per_seg = (per_seg + 7) / 8 * 8;                                          // whole 8-locus batches per segment
   n_seg = n_sel ? (n_sel + per_seg - 1) / per_seg : 1;
 
   double *d_af = nullptr, *d_table = nullptr, *d_part = nullptr, *d_sums = nullptr, *d_f = nullptr, *d_eval = nullptr, *d_segdef = nullptr;
@@ -768,6 +770,8 @@ int kgx_inbreed(kgx_gt8* h, uint64_t g0, uint64_t g1, const uint32_t* locus_inde
   uint32_t* d_index = nullptr;
   unsigned long long* d_counts = nullptr;
   LocusResultsDev* d_out = nullptr;
+  LocusBits* d_bits = nullptr;
+  uint32_t* d_meta = nullptr;
   GoldenState* d_golden = nullptr;
   int rc = KGX_OK;
   auto try_hip = [&](hipError_t e, int code, const char* what) {
@@ -780,6 +784,9 @@ int kgx_inbreed(kgx_gt8* h, uint64_t g0, uint64_t g1, const uint32_t* locus_inde
   try_hip(hipMalloc(&d_af, n_tab * amax * sizeof(double)), KGX_ENOMEM, "hipMalloc(af)");
   try_hip(hipMalloc(&d_table, n_tab * stride * sizeof(double)), KGX_ENOMEM, "hipMalloc(table)");
   try_hip(hipMalloc(&d_valid, n_tab), KGX_ENOMEM, "hipMalloc(valid)");
+  try_hip(hipMalloc(&d_bits, n_tab * sizeof(LocusBits)), KGX_ENOMEM, "hipMalloc(bits)");
+  try_hip(hipMalloc(&d_meta, (n_tab + 8) * sizeof(uint32_t)), KGX_ENOMEM, "hipMalloc(meta)");
+  try_hip(hipMemsetAsync(d_meta, 0, (n_tab + 8) * sizeof(uint32_t), g_state.stream), KGX_EHIP, "memset(meta)");
   try_hip(hipMalloc(&d_part, n_seg * n * kParts0 * sizeof(double)), KGX_ENOMEM, "hipMalloc(partials)");
   try_hip(hipMalloc(&d_segdef, n_seg * kSegDefaults * sizeof(double)), KGX_ENOMEM, "hipMalloc(segment defaults)");
   try_hip(hipMalloc(&d_sums, n * kParts0 * sizeof(double)), KGX_ENOMEM, "hipMalloc(sums)");
@@ -787,7 +794,10 @@ int kgx_inbreed(kgx_gt8* h, uint64_t g0, uint64_t g1, const uint32_t* locus_inde
   try_hip(hipMalloc(&d_f, n * sizeof(double)), KGX_ENOMEM, "hipMalloc(f)");
   try_hip(hipMalloc(&d_eval, n * sizeof(double)), KGX_ENOMEM, "hipMalloc(eval)");
   try_hip(hipMalloc(&d_out, n * sizeof(LocusResultsDev)), KGX_ENOMEM, "hipMalloc(out)");
-  if (locus_index && n_sel) try_hip(hipMalloc(&d_index, n_sel * sizeof(uint32_t)), KGX_ENOMEM, "hipMalloc(index)");
+  if (locus_index && n_sel) {
+    try_hip(hipMalloc(&d_index, (n_sel + 8) * sizeof(uint32_t)), KGX_ENOMEM, "hipMalloc(index)");
+    try_hip(hipMemsetAsync(d_index, 0, (n_sel + 8) * sizeof(uint32_t), g_state.stream), KGX_EHIP, "memset(index)");
+  }
   hipStream_t st = g_state.stream;
   if (rc == KGX_OK && n_sel) {
     try_hip(hipMemcpyAsync(d_af, minor_af, n_sel * amax * sizeof(double), hipMemcpyHostToDevice, st), KGX_EHIP, "H2D(af)");
@@ -803,13 +813,24 @@ int kgx_inbreed(kgx_gt8* h, uint64_t g0, uint64_t g1, const uint32_t* locus_inde
   auto sweep = [&](int mode) {
     if (n_sel == 0) return;
     if (mode == 0) {
-      if (env_int("KGX_K5_GENERIC", 0)) {
+      if (env_int("KGX_K5_GENERIC", 0) || amax > 4) {
         hipLaunchKernelGGL((k_inbreed_sweep<0>), grid, dim3(kBlock), 0, st, gt32, dwords_per_row, g0, n, d_index, n_sel, per_seg, d_table,
                            d_valid, amax, phased, d_f, d_counts, d_part);
       } else {
+        hipLaunchKernelGGL(k_locus_bits, dim3(stream_grid(n_sel, kBlock)), dim3(kBlock), 0, st, d_table, d_valid, n_sel, amax, d_bits, d_meta);
         hipLaunchKernelGGL(k_segment_defaults, dim3(static_cast<uint32_t>(n_seg)), dim3(kWave), 0, st, d_table, d_valid, n_sel, per_seg, amax, d_segdef);
-        hipLaunchKernelGGL(k_inbreed_sweep_fast, grid, dim3(kBlock), 0, st, gt32, dwords_per_row, g0, n, d_index, n_sel, per_seg, d_table,
-                           d_valid, amax, phased, d_segdef, d_counts, d_part);
+        if (algorithm == KGX_ALGO_RITLAND_LOCUS)
+          hipLaunchKernelGGL((k_inbreed_sweep_fast<true>), grid, dim3(kBlock), 0, st, gt32, dwords_per_row, g0, n, d_index, n_sel, per_seg,
+                             d_table, d_valid, d_bits, amax, phased, d_segdef, d_counts, d_part);
+        else if (env_int("KGX_K5_NO_SWAR", 0))
+          hipLaunchKernelGGL((k_inbreed_sweep_fast<false>), grid, dim3(kBlock), 0, st, gt32, dwords_per_row, g0, n, d_index, n_sel, per_seg,
+                             d_table, d_valid, d_bits, amax, phased, d_segdef, d_counts, d_part);
+        else if (d_index)
+          hipLaunchKernelGGL((k_inbreed_sweep_swar<true>), grid, dim3(kBlock), 0, st, gt32, dwords_per_row, g0, n, d_index, n_sel, per_seg,
+                             d_table, d_meta, amax, phased, d_segdef, d_counts, d_part);
+        else
+          hipLaunchKernelGGL((k_inbreed_sweep_swar<false>), grid, dim3(kBlock), 0, st, gt32, dwords_per_row, g0, n, d_index, n_sel, per_seg,
+                             d_table, d_meta, amax, phased, d_segdef, d_counts, d_part);
       }
     } else if (mode == 1)
       hipLaunchKernelGGL((k_inbreed_sweep<1>), grid, dim3(kBlock), 0, st, gt32, dwords_per_row, g0, n, d_index, n_sel, per_seg, d_table,
@@ -872,7 +893,7 @@ int kgx_inbreed(kgx_gt8* h, uint64_t g0, uint64_t g1, const uint32_t* locus_inde
   }
   for (void* p : {static_cast<void*>(d_af), static_cast<void*>(d_table), static_cast<void*>(d_valid), static_cast<void*>(d_part),
                   static_cast<void*>(d_sums), static_cast<void*>(d_counts), static_cast<void*>(d_f), static_cast<void*>(d_eval),
-                  static_cast<void*>(d_out), static_cast<void*>(d_index), static_cast<void*>(d_golden), static_cast<void*>(d_segdef)})
+                  static_cast<void*>(d_out), static_cast<void*>(d_index), static_cast<void*>(d_golden), static_cast<void*>(d_segdef), static_cast<void*>(d_bits), static_cast<void*>(d_meta)})
     if (p) (void)hipFree(p);
   return rc;
 }

@@ -658,13 +658,41 @@ k_segment_defaults(const double* __restrict__ table, const uint8_t* __restrict__
 // K5 fast path (MODE 0 of k_inbreed_sweep, same results up to fp64 summation order).  Every class-frequency sum
 // of generateFrequencies is class independent (_freq.cpp:549-556) and a reference-homozygous genome behaves the
 // same at a locus for every genome, so a genome's results are the segment defaults (k_segment_defaults) corrected
-// at the loci where it carries a variant.  Reference-homozygous dwords (4 genomes) cost one load and one compare:
-// the sweep is HBM-bound instead of fp64-bound.  8 locus rows are in flight per lane.
+// at the loci where it carries a variant.  The per-cell decision (_freq.cpp:452-543) is branch-free integer logic on
+// per-locus bit masks held in scalar registers (which alts are in the AlleleFreqVector, which have AF > 0.001), so
+// a wave never diverges on genotype; class counts accumulate in packed 16-bit fields (a segment holds <= 65535
+// loci); only the rare cells whose classification disagrees with the locus default touch fp64 class sums.
+// RITLAND adds the two fp64 sums processRitlandLocus needs.  amax <= 4 (wider loci take the generic kernel).
+struct LocusBits {          // per selected locus, built by k_locus_bits from the table
+  uint16_t in_list;         // bit a (1..amax): alt a is in the AlleleFreqVector
+  uint16_t rit_ok;          // bit a: af[a] > 0.001 (minimum_frequency, _calc.cpp:380)
+};
+
+// meta[s] (for amax <= 7): flag bits (kLocus*) | in_list bits 0..7 << 8 | rit_ok bits << 16 — one scalar dword per locus.
+__global__ void __launch_bounds__(kBlock)
+k_locus_bits(const double* __restrict__ table, const uint8_t* __restrict__ flags, uint64_t n_sel, uint32_t amax,
+             LocusBits* __restrict__ bits, uint32_t* __restrict__ meta) {
+  const uint32_t stride = sweep_stride(amax);
+  for (uint64_t s = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x; s < n_sel;
+       s += static_cast<uint64_t>(gridDim.x) * blockDim.x) {
+    const double* row = table + s * stride;
+    uint32_t in_list = 0, rit_ok = 0;
+    for (uint32_t a = 0; a < amax; ++a) {
+      const double f = row[a];
+      if (f == f) { in_list |= 1u << (a + 1); if (f > 0.001) rit_ok |= 1u << (a + 1); }
+    }
+    bits[s] = LocusBits{static_cast<uint16_t>(in_list), static_cast<uint16_t>(rit_ok)};
+    meta[s] = static_cast<uint32_t>(flags[s]) | ((in_list & 0xFFu) << 8) | ((rit_ok & 0xFFFFu) << 16);
+  }
+}
+
+template <bool RITLAND>
 __global__ void __launch_bounds__(kBlock)
 k_inbreed_sweep_fast(const uint32_t* __restrict__ gt, uint64_t dwords_per_row, uint64_t g0, uint64_t n_genomes,
                      const uint32_t* __restrict__ locus_index, uint64_t n_sel, uint64_t loci_per_seg,
-                     const double* __restrict__ table, const uint8_t* __restrict__ flags, uint32_t amax, int phased,
-                     const double* __restrict__ seg_def, unsigned long long* __restrict__ counts, double* __restrict__ part) {
+                     const double* __restrict__ table, const uint8_t* __restrict__ flags, const LocusBits* __restrict__ bits,
+                     uint32_t amax, int phased, const double* __restrict__ seg_def, unsigned long long* __restrict__ counts,
+                     double* __restrict__ part) {
   const uint64_t quad = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
   if (quad * 4 >= n_genomes) return;
   const uint64_t seg = blockIdx.y;
@@ -672,15 +700,15 @@ k_inbreed_sweep_fast(const uint32_t* __restrict__ gt, uint64_t dwords_per_row, u
   const uint64_t s_end = s_begin + loci_per_seg < n_sel ? s_begin + loci_per_seg : n_sel;
   const uint32_t stride = sweep_stride(amax);
   const uint64_t col = (g0 >> 2) + quad;
+  const uint32_t ph = phased ? 1u : 0u;
 
-  uint32_t miss_def[4], miss_rit[4], cnt[4][3], rit_cnt[4];   // cnt: majorHet, minorHom, minorHet
-  double cf_corr[4][4], rit_corr[4];
+  uint32_t acc0[4], acc1[4], acc2[4];   // majorHet | minorHom<<16 ; minorHet | missDefault<<16 ; ritCount | missRit<<16
+  double cf_corr[4][4], s_inv[4], s_miss[4];
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
-    miss_def[j] = miss_rit[j] = rit_cnt[j] = 0;
-    cnt[j][0] = cnt[j][1] = cnt[j][2] = 0;
+    acc0[j] = acc1[j] = acc2[j] = 0;
     cf_corr[j][0] = cf_corr[j][1] = cf_corr[j][2] = cf_corr[j][3] = 0.0;
-    rit_corr[j] = 0.0;
+    s_inv[j] = s_miss[j] = 0.0;
   }
 
   constexpr int kBatch = 8;
@@ -698,70 +726,217 @@ k_inbreed_sweep_fast(const uint32_t* __restrict__ gt, uint64_t dwords_per_row, u
     }
 #pragma unroll
     for (int i = 0; i < kBatch; ++i) {
-      if (w[i] == 0) continue;
       const uint64_t s = s0 + i;
-      const uint8_t f = flags[s];
+      if (s >= s_end) break;
+      const uint32_t f = flags[s];                       // wave-uniform
       if (!(f & kLocusValid)) continue;
+      const LocusBits lb = bits[s];
+      const uint32_t in_list = lb.in_list, rit_ok = lb.rit_ok;
+      const uint32_t def = (f & kLocusDefault) ? 1u : 0u, ritdef = (f & kLocusRitlandDefault) ? 1u : 0u;
       const double* row = table + s * stride;
+      uint32_t rare_any = 0;
+      uint32_t rare[4];
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const uint32_t b = (w[i] >> (8 * j)) & 0xFFu;
-        if (b == 0) continue;
-        if (f & kLocusDefault) ++miss_def[j];
-        if (f & kLocusRitlandDefault) {
-          ++miss_rit[j];
-          rit_corr[j] -= row[2 * amax + kTableExtra];
-          rit_corr[j] += 1.0;
+        const uint32_t a1 = b & 15u, a2 = b >> 4;
+        const uint32_t nz = b != 0 ? 1u : 0u;
+        const uint32_t ok1 = (in_list >> a1) & 1u, ok2 = (in_list >> a2) & 1u;     // bit 0 and bit 15 are never set
+        const uint32_t single = a2 == 0 ? 1u : 0u;
+        const uint32_t hom = (a1 == a2 ? 1u : 0u) & ph;
+        const uint32_t major_het = ok1 & single;
+        const uint32_t minor_hom = ok1 & hom & (single ^ 1u);
+        const uint32_t minor_het = ok1 & ok2 & (single ^ 1u) & (hom ^ 1u);
+        const uint32_t classified = major_het | minor_hom | minor_het;
+        acc0[j] += major_het | (minor_hom << 16);
+        acc1[j] += minor_het | ((nz & def) << 16);
+        rare[j] = nz & (def ^ classified);
+        rare_any |= rare[j];
+        if constexpr (RITLAND) {
+          const uint32_t hom_counts = minor_hom & ((rit_ok >> a1) & 1u);
+          acc2[j] += (hom_counts | major_het | minor_het) | ((nz & ritdef) << 16);
+          double inv = 0.0;
+#pragma unroll
+          for (uint32_t a = 1; a <= 4; ++a)
+            if (a <= amax) inv = (hom_counts && a1 == a) ? row[amax + kTableExtra + a - 1] : inv;
+          s_inv[j] += inv;
+          s_miss[j] += (nz & ritdef) ? row[2 * amax + kTableExtra] : 0.0;
         }
-        double f1 = 0.0, f2 = 0.0;
-        const int cls = classify_cell(b, row, amax, phased != 0, f1, f2);
-        if (cls == kClassNone) {
-          if (f & kLocusDefault) {
-            cf_corr[j][0] -= row[amax + 1]; cf_corr[j][1] -= row[amax + 2]; cf_corr[j][2] -= row[amax + 3]; cf_corr[j][3] -= row[amax + 4];
-          }
-          continue;
-        }
-        if (!(f & kLocusDefault)) {
-          cf_corr[j][0] += row[amax + 1]; cf_corr[j][1] += row[amax + 2]; cf_corr[j][2] += row[amax + 3]; cf_corr[j][3] += row[amax + 4];
-        }
-        ++cnt[j][cls - kMajorHet];
-        if (cls == kMinorHom) {
-          if (f1 > 0.001) {
-            rit_corr[j] += row[amax + kTableExtra + (b & 15u) - 1];     // 1 / af[a1]
-            rit_corr[j] -= 1.0;
-            ++rit_cnt[j];
-          }
-        } else {
-          rit_corr[j] -= 1.0;
-          ++rit_cnt[j];
+      }
+      if (rare_any) {     // the cell's classification disagrees with the locus default: adjust the class-frequency sums
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          if (!rare[j]) continue;
+          const double sign = def ? -1.0 : 1.0;
+          cf_corr[j][0] += sign * row[amax + 1]; cf_corr[j][1] += sign * row[amax + 2];
+          cf_corr[j][2] += sign * row[amax + 3]; cf_corr[j][3] += sign * row[amax + 4];
         }
       }
     }
   }
 
-  const double* def = seg_def + seg * kSegDefaults;
-  const unsigned long long n_def = static_cast<unsigned long long>(def[5]);
-  const unsigned long long n_rit = static_cast<unsigned long long>(def[6]);
+  const double* def_row = seg_def + seg * kSegDefaults;
+  const unsigned long long n_def = static_cast<unsigned long long>(def_row[5]);
+  const unsigned long long n_rit = static_cast<unsigned long long>(def_row[6]);
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     const uint64_t g = quad * 4 + j;
     if (g >= n_genomes) continue;
-    const unsigned long long major_hom = n_def - miss_def[j];
-    const unsigned long long classified = cnt[j][0] + cnt[j][1] + cnt[j][2];
+    const unsigned long long major_het = acc0[j] & 0xFFFFu, minor_hom = acc0[j] >> 16;
+    const unsigned long long minor_het = acc1[j] & 0xFFFFu, miss_def = acc1[j] >> 16;
+    const unsigned long long major_hom = n_def - miss_def;
+    const unsigned long long total = major_hom + major_het + minor_hom + minor_het;
     unsigned long long* c = counts + g * 6;
     if (major_hom) atomicAdd(c + 0, major_hom);
-    if (cnt[j][0]) atomicAdd(c + 1, static_cast<unsigned long long>(cnt[j][0]));
-    if (cnt[j][1]) atomicAdd(c + 2, static_cast<unsigned long long>(cnt[j][1]));
-    if (cnt[j][2]) atomicAdd(c + 3, static_cast<unsigned long long>(cnt[j][2]));
-    if (major_hom + classified) atomicAdd(c + 4, major_hom + classified);
-    const unsigned long long rit = n_rit - miss_rit[j] + rit_cnt[j];
-    if (rit) atomicAdd(c + 5, rit);
+    if (major_het) atomicAdd(c + 1, major_het);
+    if (minor_hom) atomicAdd(c + 2, minor_hom);
+    if (minor_het) atomicAdd(c + 3, minor_het);
+    if (total) atomicAdd(c + 4, total);
     double* p = part + (seg * n_genomes + g) * kParts0;
-    p[0] = def[0] + cf_corr[j][0];
-    p[1] = def[1] + cf_corr[j][1];
-    p[2] = def[2] + cf_corr[j][2];
-    p[3] = def[3] + cf_corr[j][3];
-    p[4] = def[4] + rit_corr[j];
+    p[0] = def_row[0] + cf_corr[j][0];
+    p[1] = def_row[1] + cf_corr[j][1];
+    p[2] = def_row[2] + cf_corr[j][2];
+    p[3] = def_row[3] + cf_corr[j][3];
+    if constexpr (RITLAND) {
+      const unsigned long long rit_cnt = acc2[j] & 0xFFFFu, miss_rit = acc2[j] >> 16;
+      const unsigned long long rit = n_rit - miss_rit + rit_cnt;
+      if (rit) atomicAdd(c + 5, rit);
+      // default sum, minus the defaults this genome does not take ((1/p_major - 1) each), plus its own terms
+      double r = def_row[4];
+      r -= s_miss[j];
+      r += static_cast<double>(miss_rit);
+      r += s_inv[j];
+      r -= static_cast<double>(rit_cnt);
+      p[4] = r;
+    } else {
+      p[4] = 0.0;
+    }
+  }
+}
+
+// K5 SWAR path (Simple / HallME / Loglikelihood frequency pass; amax <= 6): the four genotype bytes of a dword
+// are classified together.  v_perm_b32 is a 4-lane byte LUT: the per-locus "alt is in the AlleleFreqVector" table
+// (8 bytes, wave-uniform, in a scalar register pair) is indexed by the low / high nibbles of all four bytes in one
+// instruction; the rest is byte-parallel boolean algebra, and the class counters are byte lanes of a dword flushed
+// to wide counters every 255 loci.  ~40 VALU operations per dword instead of ~25 per byte.
+__device__ __forceinline__ uint32_t bytes_nonzero(uint32_t x) {   // x: bytes <= 0x0F -> 0x01 where byte != 0
+  return ((x + 0x0F0F0F0Fu) >> 4) & 0x01010101u;
+}
+
+// locus_index and meta are padded by 8 entries past n_sel (whole batches are fetched with one scalar load each);
+// loci_per_seg is a multiple of 8.
+template <bool INDEXED>
+__global__ void __launch_bounds__(kBlock)
+k_inbreed_sweep_swar(const uint32_t* __restrict__ gt, uint64_t dwords_per_row, uint64_t g0, uint64_t n_genomes,
+                     const uint32_t* __restrict__ locus_index, uint64_t n_sel, uint64_t loci_per_seg,
+                     const double* __restrict__ table, const uint32_t* __restrict__ meta,
+                     uint32_t amax, int phased, const double* __restrict__ seg_def, unsigned long long* __restrict__ counts,
+                     double* __restrict__ part) {
+  const uint64_t quad = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (quad * 4 >= n_genomes) return;
+  const uint64_t seg = blockIdx.y;
+  const uint64_t s_begin = seg * loci_per_seg;
+  const uint64_t s_end = s_begin + loci_per_seg < n_sel ? s_begin + loci_per_seg : n_sel;
+  const uint32_t stride = sweep_stride(amax);
+  const uint64_t col = (g0 >> 2) + quad;
+  const uint32_t ph_mask = phased ? 0x01010101u : 0u;
+
+  uint32_t b_major_het = 0, b_minor_hom = 0, b_minor_het = 0, b_miss = 0;     // 4 x 8-bit lanes
+  uint32_t n_major_het[4] = {0, 0, 0, 0}, n_minor_hom[4] = {0, 0, 0, 0}, n_minor_het[4] = {0, 0, 0, 0}, n_miss[4] = {0, 0, 0, 0};
+  double cf_corr[4][4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) cf_corr[j][0] = cf_corr[j][1] = cf_corr[j][2] = cf_corr[j][3] = 0.0;
+  uint32_t since_flush = 0;
+
+  auto flush = [&]() {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      n_major_het[j] += (b_major_het >> (8 * j)) & 0xFFu;
+      n_minor_hom[j] += (b_minor_hom >> (8 * j)) & 0xFFu;
+      n_minor_het[j] += (b_minor_het >> (8 * j)) & 0xFFu;
+      n_miss[j] += (b_miss >> (8 * j)) & 0xFFu;
+    }
+    b_major_het = b_minor_hom = b_minor_het = b_miss = 0;
+    since_flush = 0;
+  };
+
+  constexpr int kBatch = 8;
+  for (uint64_t s0 = s_begin; s0 < s_end; s0 += kBatch) {
+    uint32_t w[kBatch], m[kBatch], idx[kBatch];
+#pragma unroll
+    for (int i = 0; i < kBatch; ++i) {          // wave-uniform: two scalar loads of 8 dwords
+      m[i] = meta[s0 + i];
+      idx[i] = INDEXED ? locus_index[s0 + i] : 0u;
+    }
+#pragma unroll
+    for (int i = 0; i < kBatch; ++i) {
+      const uint64_t s = s0 + i;
+      const uint64_t l = INDEXED ? static_cast<uint64_t>(idx[i]) : s;
+      w[i] = (s < s_end) ? __builtin_nontemporal_load(gt + l * dwords_per_row + col) : 0u;
+    }
+    if (since_flush + kBatch > 255) flush();
+    since_flush += kBatch;
+#pragma unroll
+    for (int i = 0; i < kBatch; ++i) {
+      const uint64_t s = s0 + i;
+      if (s >= s_end) break;
+      const uint32_t f = m[i] & 0xFFu;                   // wave-uniform
+      if (!(f & kLocusValid)) continue;
+      // byte LUT: entry a = 1 if alt a is in the list (entries 0 and 7 are 0: "no allele" and "unknown alt")
+      const uint32_t in_list = (m[i] >> 8) & 0xFFu;
+      const uint32_t lut_lo = ((in_list >> 0) & 1u) | (((in_list >> 1) & 1u) << 8) | (((in_list >> 2) & 1u) << 16) | (((in_list >> 3) & 1u) << 24);
+      const uint32_t lut_hi = ((in_list >> 4) & 1u) | (((in_list >> 5) & 1u) << 8) | (((in_list >> 6) & 1u) << 16);
+      const uint32_t def_mask = (f & kLocusDefault) ? 0x01010101u : 0u;
+      const uint32_t x = w[i];
+      const uint32_t lo = x & 0x0F0F0F0Fu, hi = (x >> 4) & 0x0F0F0F0Fu;
+      const uint32_t ok1 = __builtin_amdgcn_perm(lut_hi, lut_lo, lo & 0x07070707u);   // nibble 15 -> entry 7 -> 0
+      const uint32_t ok2 = __builtin_amdgcn_perm(lut_hi, lut_lo, hi & 0x07070707u);
+      const uint32_t nz1 = bytes_nonzero(lo), nz2 = bytes_nonzero(hi);
+      const uint32_t same = bytes_nonzero(lo ^ hi) ^ 0x01010101u;
+      const uint32_t hom = same & ph_mask & nz2;
+      const uint32_t major_het = ok1 & (nz2 ^ 0x01010101u);
+      const uint32_t minor_hom = ok1 & hom;
+      const uint32_t minor_het = ok1 & ok2 & nz2 & (hom ^ 0x01010101u);
+      const uint32_t miss = (nz1 | nz2) & def_mask;
+      b_major_het += major_het;
+      b_minor_hom += minor_hom;
+      b_minor_het += minor_het;
+      b_miss += miss;
+      const uint32_t rare = (nz1 | nz2) & (def_mask ^ (major_het | minor_hom | minor_het));
+      if (rare) {     // classification disagrees with the locus default: adjust the class-frequency sums
+        const double* row = table + s * stride;
+        const double sign = def_mask ? -1.0 : 1.0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          if (!((rare >> (8 * j)) & 1u)) continue;
+          cf_corr[j][0] += sign * row[amax + 1]; cf_corr[j][1] += sign * row[amax + 2];
+          cf_corr[j][2] += sign * row[amax + 3]; cf_corr[j][3] += sign * row[amax + 4];
+        }
+      }
+    }
+  }
+  flush();
+
+  const double* def_row = seg_def + seg * kSegDefaults;
+  const unsigned long long n_def = static_cast<unsigned long long>(def_row[5]);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const uint64_t g = quad * 4 + j;
+    if (g >= n_genomes) continue;
+    const unsigned long long major_hom = n_def - n_miss[j];
+    const unsigned long long total = major_hom + n_major_het[j] + n_minor_hom[j] + n_minor_het[j];
+    unsigned long long* c = counts + g * 6;
+    if (major_hom) atomicAdd(c + 0, major_hom);
+    if (n_major_het[j]) atomicAdd(c + 1, static_cast<unsigned long long>(n_major_het[j]));
+    if (n_minor_hom[j]) atomicAdd(c + 2, static_cast<unsigned long long>(n_minor_hom[j]));
+    if (n_minor_het[j]) atomicAdd(c + 3, static_cast<unsigned long long>(n_minor_het[j]));
+    if (total) atomicAdd(c + 4, total);
+    double* p = part + (seg * n_genomes + g) * kParts0;
+    p[0] = def_row[0] + cf_corr[j][0];
+    p[1] = def_row[1] + cf_corr[j][1];
+    p[2] = def_row[2] + cf_corr[j][2];
+    p[3] = def_row[3] + cf_corr[j][3];
+    p[4] = 0.0;
   }
 }
 
