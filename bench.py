@@ -94,12 +94,19 @@ def main():
 
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a GPU (there is no CPU fallback)")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # Rehearsal on a 1-GPU box only: KGX_BENCH_REHEARSAL=1 puts every rank on device 0 and exchanges through gloo
+    # (RCCL refuses two ranks on one device).  The driver's runs use one GPU per rank and RCCL.
+    rehearsal = os.environ.get("KGX_BENCH_REHEARSAL") == "1"
+    device_index = 0 if rehearsal else local_rank
+    torch.cuda.set_device(device_index)
+    dev = torch.device("cuda", device_index)
     if n_gpus > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=dev)
-    capi.init(local_rank)
+        if rehearsal:
+            dist.init_process_group(backend="gloo")
+        else:
+            dist.init_process_group(backend="nccl", device_id=dev)
+    capi.init(device_index)
 
     wl = WORKLOADS[args.workload]
     V = args.variants or wl["variants"]
@@ -186,7 +193,7 @@ def main():
                 "total_genomes": total_genomes,
                 "variants": V,
                 "layout": "2-bit dosage rows, variant-major",
-                "exchange": "RCCL all-reduce(sum,u32) of [V][4] counts" if n_gpus > 1 else "none (1 GPU)",
+                "exchange": ("gloo rehearsal on one device" if rehearsal else "RCCL all-reduce(sum,u32) of [V][4] counts") if n_gpus > 1 else "none (1 GPU)",
                 "seed": args.seed,
                 "synth_seconds": round(t_synth, 3),
             },
