@@ -94,6 +94,8 @@ def main():
 
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a GPU (there is no CPU fallback)")
+    if local_rank == 0:
+        capi.ensure_built()
     # Rehearsal on a 1-GPU box only: KGX_BENCH_REHEARSAL=1 puts every rank on device 0 and exchanges through gloo
     # (RCCL refuses two ranks on one device).  The driver's runs use one GPU per rank and RCCL.
     rehearsal = os.environ.get("KGX_BENCH_REHEARSAL") == "1"

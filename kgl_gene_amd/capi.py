@@ -87,6 +87,16 @@ def declared_symbols() -> list[str]:
     return sorted(set(re.findall(r"\b(kgx_[a-z0-9_]+)\s*\(", text)))
 
 
+def ensure_built() -> None:
+    """Compile the HIP extension in-tree if it is not there yet (hipcc must be on the box).  This only builds
+    the extension; it never substitutes anything for it."""
+    if not LIB_PATH.exists():
+        from . import build as _build
+
+        _build.build_kgx(verbose=True)
+        _build.build_host()
+
+
 def lib() -> C.CDLL:
     """Load libkgx.so (once).  Raises if the HIP extension has not been built."""
     global _lib

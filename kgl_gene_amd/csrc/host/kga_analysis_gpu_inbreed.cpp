@@ -240,7 +240,7 @@ bool kga::GpuInbreedAnalysis::populationInbreeding(GpuParamOutput& param_output)
   const auto& super_pops = FrequencyDatabaseRead::superPopulations();
   const bool phased = diploid_population_->dataCharacteristic().data_structure == DataStructureEnum::DiploidPhased;
 
-  // Genomes with the contig and a PED record, grouped by super population; each group starts on a multiple of 4.
+  // Genomes with the contig and a PED record, grouped by super population; each group starts on a multiple of 16.
   struct DeviceGenome { std::shared_ptr<const ContigDB> contig; GenomeId_t id; };
   std::vector<std::vector<DeviceGenome>> by_super_pop(super_pops.size());
   for (const auto& [genome_id, genome_ptr] : diploid_population_->getMap()) {
@@ -261,7 +261,7 @@ bool kga::GpuInbreedAnalysis::populationInbreeding(GpuParamOutput& param_output)
   std::vector<uint64_t> range_begin(super_pops.size(), 0), range_end(super_pops.size(), 0);
   uint64_t device_genomes = 0;
   for (size_t sp = 0; sp < super_pops.size(); ++sp) {
-    device_genomes = (device_genomes + 3) / 4 * 4;
+    device_genomes = (device_genomes + 15) / 16 * 16;   // 16-genome boundary: the widest sweep kernel applies
     range_begin[sp] = device_genomes;
     device_genomes += by_super_pop[sp].size();
     range_end[sp] = device_genomes;

@@ -755,8 +755,13 @@ int kgx_inbreed(kgx_gt8* h, uint64_t g0, uint64_t g1, const uint32_t* locus_inde
   static_assert(sizeof(kgx_locus_results) == sizeof(LocusResultsDev), "LocusResults layout");
 
   const uint32_t stride = sweep_stride(amax);
+  // Frequency pass flavour: 16 genomes per lane (SWAR, 16-byte loads) when the group starts on a 16-genome boundary and
+  // the estimator needs no Ritland terms; otherwise 4 genomes per lane.
+  const bool swar16 = !env_int("KGX_K5_GENERIC", 0) && !env_int("KGX_K5_NO_SWAR16", 0) && amax <= 4 && (g0 & 15u) == 0 &&
+                      algorithm != KGX_ALGO_RITLAND_LOCUS;
   const uint32_t gx = static_cast<uint32_t>(((n + 3) / 4 + kBlock - 1) / kBlock);
-  uint64_t n_seg = (static_cast<uint64_t>(g_state.compute_units) * 8 + gx - 1) / gx;
+  const uint32_t gx16 = static_cast<uint32_t>(((n + 15) / 16 + kBlock - 1) / kBlock);
+  uint64_t n_seg = (static_cast<uint64_t>(g_state.compute_units) * 8 + (swar16 ? gx16 : gx) - 1) / (swar16 ? gx16 : gx);
   if (n_seg > (n_sel + 63) / 64) n_seg = (n_sel + 63) / 64;
   if (n_seg < (n_sel + 65534) / 65535) n_seg = (n_sel + 65534) / 65535;   // 16-bit class counters per segment
   if (n_seg < 1) n_seg = 1;
@@ -813,7 +818,19 @@ int kgx_inbreed(kgx_gt8* h, uint64_t g0, uint64_t g1, const uint32_t* locus_inde
   auto sweep = [&](int mode) {
     if (n_sel == 0) return;
     if (mode == 0) {
-      if (env_int("KGX_K5_GENERIC", 0) || amax > 4) {
+      if (swar16) {
+        hipLaunchKernelGGL(k_locus_bits, dim3(stream_grid(n_sel, kBlock)), dim3(kBlock), 0, st, d_table, d_valid, n_sel, amax, d_bits, d_meta);
+        hipLaunchKernelGGL(k_segment_defaults, dim3(static_cast<uint32_t>(n_seg)), dim3(kWave), 0, st, d_table, d_valid, n_sel, per_seg, amax, d_segdef);
+        hipLaunchKernelGGL(k_fill_defaults, dim3(stream_grid(n_seg * n, kBlock)), dim3(kBlock), 0, st, d_segdef, n_seg, n, d_part);
+        const dim3 grid16(gx16, static_cast<uint32_t>(n_seg));
+        const kgx_v4u* gt128 = reinterpret_cast<const kgx_v4u*>(h->d_gt);
+        if (d_index)
+          hipLaunchKernelGGL((k_inbreed_sweep_swar16<true>), grid16, dim3(kBlock), 0, st, gt128, h->pitch / 16, g0, n, d_index, n_sel, per_seg,
+                             d_table, d_meta, amax, phased, d_segdef, d_counts, d_part);
+        else
+          hipLaunchKernelGGL((k_inbreed_sweep_swar16<false>), grid16, dim3(kBlock), 0, st, gt128, h->pitch / 16, g0, n, d_index, n_sel, per_seg,
+                             d_table, d_meta, amax, phased, d_segdef, d_counts, d_part);
+      } else if (env_int("KGX_K5_GENERIC", 0) || amax > 4) {
         hipLaunchKernelGGL((k_inbreed_sweep<0>), grid, dim3(kBlock), 0, st, gt32, dwords_per_row, g0, n, d_index, n_sel, per_seg, d_table,
                            d_valid, amax, phased, d_f, d_counts, d_part);
       } else {

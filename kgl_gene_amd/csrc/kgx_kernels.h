@@ -940,6 +940,153 @@ k_inbreed_sweep_swar(const uint32_t* __restrict__ gt, uint64_t dwords_per_row, u
   }
 }
 
+// K5 SWAR path, 16 genomes per lane: one 16-byte load per locus row (a wave moves a full 1 KiB line-aligned
+// segment), four dwords classified as in k_inbreed_sweep_swar.  Class counters: byte lanes flushed into 16-bit
+// halves of registers (a segment holds < 65536 loci).  The rare cells whose classification disagrees with the locus
+// default adjust the lane's own (segment, genome) partial slot in memory directly — the slot has exactly one writer,
+// so the result is deterministic — which keeps fp64 out of the register file.  part[] must be pre-filled with the
+// segment defaults (k_fill_defaults).
+template <bool INDEXED>
+__global__ void __launch_bounds__(kBlock)
+k_inbreed_sweep_swar16(const kgx_v4u* __restrict__ gt, uint64_t chunks_per_row, uint64_t g0, uint64_t n_genomes,
+                       const uint32_t* __restrict__ locus_index, uint64_t n_sel, uint64_t loci_per_seg,
+                       const double* __restrict__ table, const uint32_t* __restrict__ meta, uint32_t amax, int phased,
+                       const double* __restrict__ seg_def, unsigned long long* __restrict__ counts, double* __restrict__ part) {
+  const uint64_t lane16 = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x;     // 16 genomes g0 + 16*lane16 ..
+  if (lane16 * 16 >= n_genomes) return;
+  const uint64_t seg = blockIdx.y;
+  const uint64_t s_begin = seg * loci_per_seg;
+  const uint64_t s_end = s_begin + loci_per_seg < n_sel ? s_begin + loci_per_seg : n_sel;
+  const uint32_t stride = sweep_stride(amax);
+  const uint64_t col = (g0 >> 4) + lane16;                 // g0 is a multiple of 16
+  const uint32_t ph_mask = phased ? 0x01010101u : 0u;
+
+  uint32_t b_mhet[4] = {0, 0, 0, 0}, b_mhom[4] = {0, 0, 0, 0}, b_nhet[4] = {0, 0, 0, 0}, b_miss[4] = {0, 0, 0, 0};   // byte lanes
+  // wide counters: [dword d][pair p] holds genomes 4d+p (low 16 bits) and 4d+p+2 (high 16 bits)
+  uint32_t n_mhet[4][2], n_mhom[4][2], n_nhet[4][2], n_miss[4][2];
+#pragma unroll
+  for (int d = 0; d < 4; ++d)
+#pragma unroll
+    for (int p = 0; p < 2; ++p) n_mhet[d][p] = n_mhom[d][p] = n_nhet[d][p] = n_miss[d][p] = 0;
+  uint32_t since_flush = 0;
+
+  auto flush = [&]() {
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+      // bytes 0,2 -> pair 0 (low/high halves), bytes 1,3 -> pair 1
+      n_mhet[d][0] += b_mhet[d] & 0x00FF00FFu;  n_mhet[d][1] += (b_mhet[d] >> 8) & 0x00FF00FFu;
+      n_mhom[d][0] += b_mhom[d] & 0x00FF00FFu;  n_mhom[d][1] += (b_mhom[d] >> 8) & 0x00FF00FFu;
+      n_nhet[d][0] += b_nhet[d] & 0x00FF00FFu;  n_nhet[d][1] += (b_nhet[d] >> 8) & 0x00FF00FFu;
+      n_miss[d][0] += b_miss[d] & 0x00FF00FFu;  n_miss[d][1] += (b_miss[d] >> 8) & 0x00FF00FFu;
+      b_mhet[d] = b_mhom[d] = b_nhet[d] = b_miss[d] = 0;
+    }
+    since_flush = 0;
+  };
+
+  constexpr int kBatch = 4;
+  for (uint64_t s0 = s_begin; s0 < s_end; s0 += kBatch) {
+    kgx_v4u w[kBatch];
+    uint32_t m[kBatch], idx[kBatch];
+#pragma unroll
+    for (int i = 0; i < kBatch; ++i) {
+      m[i] = meta[s0 + i];
+      idx[i] = INDEXED ? locus_index[s0 + i] : 0u;
+    }
+#pragma unroll
+    for (int i = 0; i < kBatch; ++i) {
+      const uint64_t s = s0 + i;
+      const uint64_t l = INDEXED ? static_cast<uint64_t>(idx[i]) : s;
+      kgx_v4u v = {0u, 0u, 0u, 0u};
+      if (s < s_end) v = __builtin_nontemporal_load(gt + l * chunks_per_row + col);
+      w[i] = v;
+    }
+    if (since_flush + kBatch > 255) flush();
+    since_flush += kBatch;
+#pragma unroll
+    for (int i = 0; i < kBatch; ++i) {
+      const uint64_t s = s0 + i;
+      if (s >= s_end) break;
+      const uint32_t f = m[i] & 0xFFu;
+      if (!(f & kLocusValid)) continue;
+      const uint32_t in_list = (m[i] >> 8) & 0xFFu;
+      const uint32_t lut_lo = ((in_list >> 0) & 1u) | (((in_list >> 1) & 1u) << 8) | (((in_list >> 2) & 1u) << 16) | (((in_list >> 3) & 1u) << 24);
+      const uint32_t lut_hi = ((in_list >> 4) & 1u) | (((in_list >> 5) & 1u) << 8) | (((in_list >> 6) & 1u) << 16);
+      const uint32_t def_mask = (f & kLocusDefault) ? 0x01010101u : 0u;
+      uint32_t rare[4];
+      uint32_t rare_any = 0;
+#pragma unroll
+      for (int d = 0; d < 4; ++d) {
+        const uint32_t x = w[i][d];
+        const uint32_t lo = x & 0x0F0F0F0Fu, hi = (x >> 4) & 0x0F0F0F0Fu;
+        const uint32_t ok1 = __builtin_amdgcn_perm(lut_hi, lut_lo, lo & 0x07070707u);
+        const uint32_t ok2 = __builtin_amdgcn_perm(lut_hi, lut_lo, hi & 0x07070707u);
+        const uint32_t nz1 = bytes_nonzero(lo), nz2 = bytes_nonzero(hi);
+        const uint32_t same = bytes_nonzero(lo ^ hi) ^ 0x01010101u;
+        const uint32_t hom = same & ph_mask & nz2;
+        const uint32_t major_het = ok1 & (nz2 ^ 0x01010101u);
+        const uint32_t minor_hom = ok1 & hom;
+        const uint32_t minor_het = ok1 & ok2 & nz2 & (hom ^ 0x01010101u);
+        b_mhet[d] += major_het;
+        b_mhom[d] += minor_hom;
+        b_nhet[d] += minor_het;
+        b_miss[d] += (nz1 | nz2) & def_mask;
+        rare[d] = (nz1 | nz2) & (def_mask ^ (major_het | minor_hom | minor_het));
+        rare_any |= rare[d];
+      }
+      if (rare_any) {
+        const double* row = table + s * stride;
+        const double sign = def_mask ? -1.0 : 1.0;
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+          if (!rare[d]) continue;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            if (!((rare[d] >> (8 * j)) & 1u)) continue;
+            const uint64_t g = lane16 * 16 + d * 4 + j;
+            if (g >= n_genomes) continue;
+            double* p = part + (seg * n_genomes + g) * kParts0;     // single writer: this lane
+            p[0] += sign * row[amax + 1]; p[1] += sign * row[amax + 2]; p[2] += sign * row[amax + 3]; p[3] += sign * row[amax + 4];
+          }
+        }
+      }
+    }
+  }
+  flush();
+
+  const unsigned long long n_def = static_cast<unsigned long long>(seg_def[seg * kSegDefaults + 5]);
+#pragma unroll
+  for (int d = 0; d < 4; ++d) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const uint64_t g = lane16 * 16 + d * 4 + j;
+      if (g >= n_genomes) continue;
+      const int pair = j & 1, shift = (j & 2) ? 16 : 0;
+      const unsigned long long mhet = (n_mhet[d][pair] >> shift) & 0xFFFFu, mhom = (n_mhom[d][pair] >> shift) & 0xFFFFu;
+      const unsigned long long nhet = (n_nhet[d][pair] >> shift) & 0xFFFFu, miss = (n_miss[d][pair] >> shift) & 0xFFFFu;
+      const unsigned long long major_hom = n_def - miss;
+      const unsigned long long total = major_hom + mhet + mhom + nhet;
+      unsigned long long* c = counts + g * 6;
+      if (major_hom) atomicAdd(c + 0, major_hom);
+      if (mhet) atomicAdd(c + 1, mhet);
+      if (mhom) atomicAdd(c + 2, mhom);
+      if (nhet) atomicAdd(c + 3, nhet);
+      if (total) atomicAdd(c + 4, total);
+    }
+  }
+}
+
+// part[(seg, g)][0..4] = segment defaults (class-frequency sums of a genome that is reference-homozygous throughout).
+__global__ void __launch_bounds__(kBlock)
+k_fill_defaults(const double* __restrict__ seg_def, uint64_t n_seg, uint64_t n_genomes, double* __restrict__ part) {
+  const uint64_t total = n_seg * n_genomes;
+  for (uint64_t i = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < total;
+       i += static_cast<uint64_t>(gridDim.x) * blockDim.x) {
+    const double* d = seg_def + (i / n_genomes) * kSegDefaults;
+    double* p = part + i * kParts0;
+    p[0] = d[0]; p[1] = d[1]; p[2] = d[2]; p[3] = d[3]; p[4] = 0.0;
+  }
+}
+
 // Sum the per-segment partials in segment order (deterministic; segments are ascending locus ranges).
 __global__ void __launch_bounds__(kBlock)
 k_reduce_parts(const double* __restrict__ part, uint64_t n_seg, uint64_t n_items, double* __restrict__ out) {

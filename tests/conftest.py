@@ -18,6 +18,7 @@ def kgx():
     """The ctypes binding with device 0 bound.  Fails (not skips) if the HIP library is missing."""
     from kgl_gene_amd import capi
 
+    capi.ensure_built()
     capi.lib()
     if capi.device_count() <= 0:
         pytest.fail("no HIP device visible: -m gpu tests must run on the GPU box")

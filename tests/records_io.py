@@ -64,6 +64,10 @@ def write_records(path, rec: oa.Records, gt, genome_ids, mode, data_source, popu
 
 
 def run_driver(ident, work_dir, files, **params):
+    if not DRIVER.exists():
+        from kgl_gene_amd import build as kbuild
+
+        kbuild.build_host()
     args = [str(DRIVER), ident, str(work_dir)] + [f"{k}={v}" for k, v in params.items()] + ["quiet=1", "--"] + [str(f) for f in files]
     return subprocess.run(args, capture_output=True, text=True)
 
