@@ -119,77 +119,75 @@ static void launch_by_genome(const kgx_pop* pop, const uint32_t* d_index, const 
 static int count_by_genome_impl(kgx_pop* pop, const uint8_t* bin_of_variant, uint32_t n_bins, uint64_t* out) {
   const uint64_t V = pop->n_variants, G = pop->n_genomes;
   if (V > 0xFFFFFFFFull) return fail(KGX_EINVAL, "n_variants exceeds the 32-bit row index of the by-genome sweep");
-  // Selected rows grouped by bin (stable counting sort), so a workgroup only ever touches one bin.
-  std::vector<unsigned long long> rows_in_bin(n_bins, 0);
-  std::vector<uint64_t> offset(n_bins + 1, 0);
-  std::vector<uint32_t> index;
-  bool identity = false;
-  if (!bin_of_variant) {
-    rows_in_bin[0] = V;
-    offset[1] = V;
-    identity = true;
-  } else {
-    for (uint64_t v = 0; v < V; ++v)
-      if (bin_of_variant[v] < n_bins) ++rows_in_bin[bin_of_variant[v]];
-    for (uint32_t b = 0; b < n_bins; ++b) offset[b + 1] = offset[b] + rows_in_bin[b];
-    index.resize(offset[n_bins]);
-    std::vector<uint64_t> cursor(offset.begin(), offset.end() - 1);
-    for (uint64_t v = 0; v < V; ++v)
-      if (bin_of_variant[v] < n_bins) index[cursor[bin_of_variant[v]]++] = static_cast<uint32_t>(v);
-  }
-  const uint64_t selected = offset[n_bins];
-
-  const int W = lanes_per_row(pop->chunks_per_row);
-  const uint32_t n_cg = (pop->chunks_per_row + 63) / 64;
-  const uint64_t gran = static_cast<uint64_t>(64 / W) * (kBlock / kWave) * 8;
-  const uint64_t target = static_cast<uint64_t>(g_state.compute_units) * 10u;
-  uint64_t per_wg = (selected * n_cg + target - 1) / target;
-  per_wg = (per_wg + gran - 1) / gran * gran;
-  if (per_wg < gran * 4) per_wg = gran * 4;
-  std::vector<GenomeWork> work;
-  for (uint32_t b = 0; b < n_bins; ++b)
-    for (uint64_t p = offset[b]; p < offset[b + 1]; p += per_wg)
-      for (uint32_t cg = 0; cg < n_cg; ++cg) {
-        GenomeWork w;
-        w.begin = p;
-        w.end = (p + per_wg < offset[b + 1]) ? p + per_wg : offset[b + 1];
-        w.col_group = cg;
-        w.bin = b;
-        work.push_back(w);
-      }
-
   const uint64_t cells = G * n_bins;
-  unsigned long long *d_acc = nullptr, *d_out = nullptr, *d_nbin = nullptr;
-  uint32_t* d_index = nullptr;
+  const bool identity = bin_of_variant == nullptr;
+  hipStream_t st = g_state.stream;
+
+  unsigned long long *d_acc = nullptr, *d_out = nullptr, *d_nbin = nullptr, *d_binoff = nullptr;
+  uint32_t *d_index = nullptr, *d_chunks = nullptr;
+  uint8_t* d_bins = nullptr;
   GenomeWork* d_work = nullptr;
   int rc = KGX_OK;
-  auto cleanup = [&]() {
-    if (d_acc) (void)hipFree(d_acc);
-    if (d_out) (void)hipFree(d_out);
-    if (d_nbin) (void)hipFree(d_nbin);
-    if (d_index) (void)hipFree(d_index);
-    if (d_work) (void)hipFree(d_work);
-  };
-#define KGX_TRY(call, code, what)                                          \
-  if (rc == KGX_OK && (call) != hipSuccess) {                             \
-    (void)hipGetLastError();                                               \
-    rc = fail(code, "count_by_genome: %s failed", what);                   \
-  }
-  KGX_TRY(hipMalloc(&d_acc, cells * 3 * sizeof(unsigned long long)), KGX_ENOMEM, "hipMalloc(acc)");
-  KGX_TRY(hipMalloc(&d_out, cells * 4 * sizeof(unsigned long long)), KGX_ENOMEM, "hipMalloc(out)");
-  KGX_TRY(hipMalloc(&d_nbin, n_bins * sizeof(unsigned long long)), KGX_ENOMEM, "hipMalloc(rows_in_bin)");
-  KGX_TRY(hipMemsetAsync(d_acc, 0, cells * 3 * sizeof(unsigned long long), g_state.stream), KGX_EHIP, "memset(acc)");
-  KGX_TRY(hipMemcpyAsync(d_nbin, rows_in_bin.data(), n_bins * sizeof(unsigned long long), hipMemcpyHostToDevice,
-                         g_state.stream), KGX_EHIP, "H2D(rows_in_bin)");
-  if (rc == KGX_OK && !work.empty()) {
-    if (!identity) {
-      KGX_TRY(hipMalloc(&d_index, index.size() * sizeof(uint32_t)), KGX_ENOMEM, "hipMalloc(index)");
-      KGX_TRY(hipMemcpyAsync(d_index, index.data(), index.size() * sizeof(uint32_t), hipMemcpyHostToDevice,
-                             g_state.stream), KGX_EHIP, "H2D(index)");
+  auto try_hip = [&](hipError_t e, int code, const char* what) {
+    if (rc == KGX_OK && e != hipSuccess) {
+      (void)hipGetLastError();
+      rc = fail(code, "count_by_genome: %s failed: %s", what, hipGetErrorString(e));
     }
-    KGX_TRY(hipMalloc(&d_work, work.size() * sizeof(GenomeWork)), KGX_ENOMEM, "hipMalloc(work)");
-    KGX_TRY(hipMemcpyAsync(d_work, work.data(), work.size() * sizeof(GenomeWork), hipMemcpyHostToDevice,
-                           g_state.stream), KGX_EHIP, "H2D(work)");
+  };
+  try_hip(hipMalloc(&d_acc, (cells ? cells : 1) * 3 * sizeof(unsigned long long)), KGX_ENOMEM, "hipMalloc(acc)");
+  try_hip(hipMalloc(&d_out, (cells ? cells : 1) * 4 * sizeof(unsigned long long)), KGX_ENOMEM, "hipMalloc(out)");
+  try_hip(hipMalloc(&d_nbin, n_bins * sizeof(unsigned long long)), KGX_ENOMEM, "hipMalloc(rows_in_bin)");
+  try_hip(hipMalloc(&d_binoff, (n_bins + 1) * sizeof(unsigned long long)), KGX_ENOMEM, "hipMalloc(bin_offset)");
+  try_hip(hipMemsetAsync(d_acc, 0, (cells ? cells : 1) * 3 * sizeof(unsigned long long), st), KGX_EHIP, "memset(acc)");
+
+  // Rows grouped by bin, so that a workgroup only ever touches one bin: on the device (k_bin_count / _scan / _scatter).
+  std::vector<unsigned long long> bin_offset(n_bins + 1, 0);
+  if (identity) {
+    bin_offset[1] = V;
+    const unsigned long long v = V;
+    try_hip(hipMemcpyAsync(d_nbin, &v, sizeof(v), hipMemcpyHostToDevice, st), KGX_EHIP, "H2D(rows_in_bin)");
+    try_hip(hipStreamSynchronize(st), KGX_EHIP, "sync");
+  } else if (V > 0) {
+    const uint32_t n_chunks = static_cast<uint32_t>((V + kBinChunk - 1) / kBinChunk);
+    try_hip(hipMalloc(&d_bins, V), KGX_ENOMEM, "hipMalloc(bins)");
+    try_hip(hipMalloc(&d_index, V * sizeof(uint32_t)), KGX_ENOMEM, "hipMalloc(index)");
+    try_hip(hipMalloc(&d_chunks, static_cast<uint64_t>(n_chunks) * n_bins * sizeof(uint32_t)), KGX_ENOMEM, "hipMalloc(chunk counts)");
+    try_hip(hipMemcpyAsync(d_bins, bin_of_variant, V, hipMemcpyHostToDevice, st), KGX_EHIP, "H2D(bins)");
+    if (rc == KGX_OK) {
+      hipLaunchKernelGGL(k_bin_count, dim3(n_chunks), dim3(kBlock), 0, st, d_bins, V, n_bins, d_chunks);
+      hipLaunchKernelGGL(k_bin_scan, dim3(1), dim3(kMaxBins), 0, st, d_chunks, n_chunks, n_bins, d_nbin, d_binoff);
+      hipLaunchKernelGGL(k_bin_scatter, dim3(n_chunks), dim3(kBlock), 0, st, d_bins, V, n_bins, d_chunks, d_index);
+      try_hip(hipGetLastError(), KGX_EHIP, "bin grouping kernels");
+      try_hip(hipMemcpyAsync(bin_offset.data(), d_binoff, (n_bins + 1) * sizeof(unsigned long long), hipMemcpyDeviceToHost, st), KGX_EHIP, "D2H(bin offsets)");
+      try_hip(hipStreamSynchronize(st), KGX_EHIP, "sync");
+    }
+  } else {
+    try_hip(hipMemsetAsync(d_nbin, 0, n_bins * sizeof(unsigned long long), st), KGX_EHIP, "memset(rows_in_bin)");
+  }
+  const uint64_t selected = bin_offset[n_bins];
+
+  if (rc == KGX_OK && selected > 0) {
+    const int W = lanes_per_row(pop->chunks_per_row);
+    const uint32_t n_cg = (pop->chunks_per_row + 63) / 64;
+    const uint64_t gran = static_cast<uint64_t>(64 / W) * (kBlock / kWave) * 8;
+    const uint64_t target = static_cast<uint64_t>(g_state.compute_units) * 10u;
+    uint64_t per_wg = (selected * n_cg + target - 1) / target;
+    per_wg = (per_wg + gran - 1) / gran * gran;
+    if (per_wg < gran * 4) per_wg = gran * 4;
+    std::vector<GenomeWork> work;
+    for (uint32_t b = 0; b < n_bins; ++b)
+      for (uint64_t p = bin_offset[b]; p < bin_offset[b + 1]; p += per_wg)
+        for (uint32_t cg = 0; cg < n_cg; ++cg) {
+          GenomeWork w;
+          w.begin = p;
+          w.end = (p + per_wg < bin_offset[b + 1]) ? p + per_wg : bin_offset[b + 1];
+          w.col_group = cg;
+          w.bin = b;
+          work.push_back(w);
+        }
+    try_hip(hipMalloc(&d_work, work.size() * sizeof(GenomeWork)), KGX_ENOMEM, "hipMalloc(work)");
+    try_hip(hipMemcpyAsync(d_work, work.data(), work.size() * sizeof(GenomeWork), hipMemcpyHostToDevice, st), KGX_EHIP, "H2D(work)");
+    try_hip(hipStreamSynchronize(st), KGX_EHIP, "sync");     // `work` is pageable host memory
     if (rc == KGX_OK) {
       const uint32_t n_work = static_cast<uint32_t>(work.size());
       switch (W) {
@@ -201,19 +199,18 @@ static int count_by_genome_impl(kgx_pop* pop, const uint8_t* bin_of_variant, uin
         case 32: launch_by_genome<32>(pop, d_index, d_work, n_work, n_bins, d_acc); break;
         default: launch_by_genome<64>(pop, d_index, d_work, n_work, n_bins, d_acc); break;
       }
-      KGX_TRY(hipGetLastError(), KGX_EHIP, "k_count_by_genome launch");
+      try_hip(hipGetLastError(), KGX_EHIP, "k_count_by_genome launch");
     }
   }
-  if (rc == KGX_OK) {
-    hipLaunchKernelGGL(k_finish_by_genome, dim3(stream_grid(cells, kBlock)), dim3(kBlock), 0, g_state.stream,
-                       d_acc, d_nbin, G, n_bins, d_out);
-    KGX_TRY(hipGetLastError(), KGX_EHIP, "k_finish_by_genome launch");
-    KGX_TRY(hipMemcpyAsync(out, d_out, cells * 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost, g_state.stream),
-            KGX_EHIP, "D2H(out)");
-    KGX_TRY(hipStreamSynchronize(g_state.stream), KGX_EHIP, "stream synchronize");
+  if (rc == KGX_OK && cells > 0) {
+    hipLaunchKernelGGL(k_finish_by_genome, dim3(stream_grid(cells, kBlock)), dim3(kBlock), 0, st, d_acc, d_nbin, G, n_bins, d_out);
+    try_hip(hipGetLastError(), KGX_EHIP, "k_finish_by_genome launch");
+    try_hip(hipMemcpyAsync(out, d_out, cells * 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost, st), KGX_EHIP, "D2H(out)");
+    try_hip(hipStreamSynchronize(st), KGX_EHIP, "stream synchronize");
   }
-#undef KGX_TRY
-  cleanup();
+  for (void* p : {static_cast<void*>(d_acc), static_cast<void*>(d_out), static_cast<void*>(d_nbin), static_cast<void*>(d_binoff),
+                  static_cast<void*>(d_index), static_cast<void*>(d_chunks), static_cast<void*>(d_bins), static_cast<void*>(d_work)})
+    if (p) (void)hipFree(p);
   return rc;
 }
 
@@ -836,18 +833,29 @@ int kgx_inbreed(kgx_gt8* h, uint64_t g0, uint64_t g1, const uint32_t* locus_inde
       } else {
         hipLaunchKernelGGL(k_locus_bits, dim3(stream_grid(n_sel, kBlock)), dim3(kBlock), 0, st, d_table, d_valid, n_sel, amax, d_bits, d_meta);
         hipLaunchKernelGGL(k_segment_defaults, dim3(static_cast<uint32_t>(n_seg)), dim3(kWave), 0, st, d_table, d_valid, n_sel, per_seg, amax, d_segdef);
-        if (algorithm == KGX_ALGO_RITLAND_LOCUS)
-          hipLaunchKernelGGL((k_inbreed_sweep_fast<true>), grid, dim3(kBlock), 0, st, gt32, dwords_per_row, g0, n, d_index, n_sel, per_seg,
-                             d_table, d_valid, d_bits, amax, phased, d_segdef, d_counts, d_part);
-        else if (env_int("KGX_K5_NO_SWAR", 0))
-          hipLaunchKernelGGL((k_inbreed_sweep_fast<false>), grid, dim3(kBlock), 0, st, gt32, dwords_per_row, g0, n, d_index, n_sel, per_seg,
-                             d_table, d_valid, d_bits, amax, phased, d_segdef, d_counts, d_part);
-        else if (d_index)
-          hipLaunchKernelGGL((k_inbreed_sweep_swar<true>), grid, dim3(kBlock), 0, st, gt32, dwords_per_row, g0, n, d_index, n_sel, per_seg,
-                             d_table, d_meta, amax, phased, d_segdef, d_counts, d_part);
-        else
-          hipLaunchKernelGGL((k_inbreed_sweep_swar<false>), grid, dim3(kBlock), 0, st, gt32, dwords_per_row, g0, n, d_index, n_sel, per_seg,
-                             d_table, d_meta, amax, phased, d_segdef, d_counts, d_part);
+        const bool ritland = algorithm == KGX_ALGO_RITLAND_LOCUS;
+        if (env_int("KGX_K5_NO_SWAR", 0)) {
+          if (ritland)
+            hipLaunchKernelGGL((k_inbreed_sweep_fast<true>), grid, dim3(kBlock), 0, st, gt32, dwords_per_row, g0, n, d_index, n_sel, per_seg,
+                               d_table, d_valid, d_bits, amax, phased, d_segdef, d_counts, d_part);
+          else
+            hipLaunchKernelGGL((k_inbreed_sweep_fast<false>), grid, dim3(kBlock), 0, st, gt32, dwords_per_row, g0, n, d_index, n_sel, per_seg,
+                               d_table, d_valid, d_bits, amax, phased, d_segdef, d_counts, d_part);
+        } else if (d_index) {
+          if (ritland)
+            hipLaunchKernelGGL((k_inbreed_sweep_swar<true, true>), grid, dim3(kBlock), 0, st, gt32, dwords_per_row, g0, n, d_index, n_sel, per_seg,
+                               d_table, d_meta, amax, phased, d_segdef, d_counts, d_part);
+          else
+            hipLaunchKernelGGL((k_inbreed_sweep_swar<true, false>), grid, dim3(kBlock), 0, st, gt32, dwords_per_row, g0, n, d_index, n_sel, per_seg,
+                               d_table, d_meta, amax, phased, d_segdef, d_counts, d_part);
+        } else {
+          if (ritland)
+            hipLaunchKernelGGL((k_inbreed_sweep_swar<false, true>), grid, dim3(kBlock), 0, st, gt32, dwords_per_row, g0, n, d_index, n_sel, per_seg,
+                               d_table, d_meta, amax, phased, d_segdef, d_counts, d_part);
+          else
+            hipLaunchKernelGGL((k_inbreed_sweep_swar<false, false>), grid, dim3(kBlock), 0, st, gt32, dwords_per_row, g0, n, d_index, n_sel, per_seg,
+                               d_table, d_meta, amax, phased, d_segdef, d_counts, d_part);
+        }
       }
     } else if (mode == 1)
       hipLaunchKernelGGL((k_inbreed_sweep<1>), grid, dim3(kBlock), 0, st, gt32, dwords_per_row, g0, n, d_index, n_sel, per_seg, d_table,

@@ -341,6 +341,75 @@ k_finish_by_genome(const unsigned long long* __restrict__ acc, const unsigned lo
   }
 }
 
+// Group the selected rows by bin on the device (counting sort in two passes).  A chunk of kBinChunk consecutive rows
+// goes to one workgroup: pass 1 counts rows per bin per chunk; after an exclusive scan over (bin, chunk) on one
+// small kernel, pass 2 scatters row numbers into their bin's range.  Within a chunk the order is arbitrary (LDS
+// atomics) — integer sums do not care — while chunks keep their order, so gathered rows stay nearly sequential.
+constexpr int kBinChunk = 4096;
+constexpr int kMaxBins = 256;
+
+__global__ void __launch_bounds__(kBlock)
+k_bin_count(const uint8_t* __restrict__ bin_of_row, uint64_t n_rows, uint32_t n_bins, uint32_t* __restrict__ chunk_counts) {
+  __shared__ uint32_t cnt[kMaxBins];
+  for (uint32_t b = threadIdx.x; b < n_bins; b += kBlock) cnt[b] = 0;
+  __syncthreads();
+  const uint64_t base = static_cast<uint64_t>(blockIdx.x) * kBinChunk;
+  for (uint32_t i = threadIdx.x; i < kBinChunk; i += kBlock) {
+    const uint64_t r = base + i;
+    if (r < n_rows) {
+      const uint32_t b = bin_of_row[r];
+      if (b < n_bins) atomicAdd(&cnt[b], 1u);
+    }
+  }
+  __syncthreads();
+  for (uint32_t b = threadIdx.x; b < n_bins; b += kBlock) chunk_counts[static_cast<uint64_t>(b) * gridDim.x + blockIdx.x] = cnt[b];
+}
+
+// Exclusive scan of chunk_counts in (bin-major, chunk) order; rows_in_bin[b] and bin_offset[b] as by-products.
+// One thread per bin walks its chunks (n_chunks is a few thousand); bins are then chained by thread 0.
+__global__ void __launch_bounds__(kMaxBins)
+k_bin_scan(uint32_t* __restrict__ chunk_counts, uint32_t n_chunks, uint32_t n_bins, unsigned long long* __restrict__ rows_in_bin,
+           unsigned long long* __restrict__ bin_offset) {
+  __shared__ unsigned long long total[kMaxBins];
+  const uint32_t b = threadIdx.x;
+  if (b < n_bins) {
+    unsigned long long t = 0;
+    for (uint32_t c = 0; c < n_chunks; ++c) t += chunk_counts[static_cast<uint64_t>(b) * n_chunks + c];
+    total[b] = t;
+  }
+  __syncthreads();
+  if (b == 0) {
+    unsigned long long off = 0;
+    for (uint32_t k = 0; k < n_bins; ++k) { bin_offset[k] = off; rows_in_bin[k] = total[k]; off += total[k]; }
+    bin_offset[n_bins] = off;
+  }
+  __syncthreads();
+  if (b < n_bins) {
+    unsigned long long run = bin_offset[b];
+    for (uint32_t c = 0; c < n_chunks; ++c) {
+      const uint32_t v = chunk_counts[static_cast<uint64_t>(b) * n_chunks + c];
+      chunk_counts[static_cast<uint64_t>(b) * n_chunks + c] = static_cast<uint32_t>(run);   // < 2^32 rows in total
+      run += v;
+    }
+  }
+}
+
+__global__ void __launch_bounds__(kBlock)
+k_bin_scatter(const uint8_t* __restrict__ bin_of_row, uint64_t n_rows, uint32_t n_bins, const uint32_t* __restrict__ chunk_offsets,
+              uint32_t* __restrict__ index) {
+  __shared__ uint32_t cursor[kMaxBins];
+  for (uint32_t b = threadIdx.x; b < n_bins; b += kBlock) cursor[b] = chunk_offsets[static_cast<uint64_t>(b) * gridDim.x + blockIdx.x];
+  __syncthreads();
+  const uint64_t base = static_cast<uint64_t>(blockIdx.x) * kBinChunk;
+  for (uint32_t i = threadIdx.x; i < kBinChunk; i += kBlock) {
+    const uint64_t r = base + i;
+    if (r < n_rows) {
+      const uint32_t b = bin_of_row[r];
+      if (b < n_bins) index[atomicAdd(&cursor[b], 1u)] = static_cast<uint32_t>(r);
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------------------------
 // K8  compound offsets of HeteroHomoZygous::updateVariantAnalysisType
 // (kga_analytic/kga_PfEMP/kga_analysis_PfEMP_heterozygous.cpp:61-105).  At a contig offset where the
@@ -825,7 +894,7 @@ __device__ __forceinline__ uint32_t bytes_nonzero(uint32_t x) {   // x: bytes <=
 
 // locus_index and meta are padded by 8 entries past n_sel (whole batches are fetched with one scalar load each);
 // loci_per_seg is a multiple of 8.
-template <bool INDEXED>
+template <bool INDEXED, bool RITLAND>
 __global__ void __launch_bounds__(kBlock)
 k_inbreed_sweep_swar(const uint32_t* __restrict__ gt, uint64_t dwords_per_row, uint64_t g0, uint64_t n_genomes,
                      const uint32_t* __restrict__ locus_index, uint64_t n_sel, uint64_t loci_per_seg,
@@ -843,9 +912,13 @@ k_inbreed_sweep_swar(const uint32_t* __restrict__ gt, uint64_t dwords_per_row, u
 
   uint32_t b_major_het = 0, b_minor_hom = 0, b_minor_het = 0, b_miss = 0;     // 4 x 8-bit lanes
   uint32_t n_major_het[4] = {0, 0, 0, 0}, n_minor_hom[4] = {0, 0, 0, 0}, n_minor_het[4] = {0, 0, 0, 0}, n_miss[4] = {0, 0, 0, 0};
-  double cf_corr[4][4];
+  uint32_t b_rit = 0, b_miss_rit = 0, n_rit[4] = {0, 0, 0, 0}, n_miss_rit[4] = {0, 0, 0, 0};   // RITLAND only
+  double cf_corr[4][4], s_inv[4], s_miss[4];
 #pragma unroll
-  for (int j = 0; j < 4; ++j) cf_corr[j][0] = cf_corr[j][1] = cf_corr[j][2] = cf_corr[j][3] = 0.0;
+  for (int j = 0; j < 4; ++j) {
+    cf_corr[j][0] = cf_corr[j][1] = cf_corr[j][2] = cf_corr[j][3] = 0.0;
+    s_inv[j] = s_miss[j] = 0.0;
+  }
   uint32_t since_flush = 0;
 
   auto flush = [&]() {
@@ -855,8 +928,12 @@ k_inbreed_sweep_swar(const uint32_t* __restrict__ gt, uint64_t dwords_per_row, u
       n_minor_hom[j] += (b_minor_hom >> (8 * j)) & 0xFFu;
       n_minor_het[j] += (b_minor_het >> (8 * j)) & 0xFFu;
       n_miss[j] += (b_miss >> (8 * j)) & 0xFFu;
+      if constexpr (RITLAND) {
+        n_rit[j] += (b_rit >> (8 * j)) & 0xFFu;
+        n_miss_rit[j] += (b_miss_rit >> (8 * j)) & 0xFFu;
+      }
     }
-    b_major_het = b_minor_hom = b_minor_het = b_miss = 0;
+    b_major_het = b_minor_hom = b_minor_het = b_miss = b_rit = b_miss_rit = 0;
     since_flush = 0;
   };
 
@@ -902,6 +979,28 @@ k_inbreed_sweep_swar(const uint32_t* __restrict__ gt, uint64_t dwords_per_row, u
       b_minor_hom += minor_hom;
       b_minor_het += minor_het;
       b_miss += miss;
+      if constexpr (RITLAND) {
+        // processRitlandLocus (_calc.cpp:390-423): a homozygous cell enters only if its allele frequency > 0.001
+        const uint32_t rit_bits = (m[i] >> 16) & 0xFFu;
+        const uint32_t rit_lo = ((rit_bits >> 0) & 1u) | (((rit_bits >> 1) & 1u) << 8) | (((rit_bits >> 2) & 1u) << 16) | (((rit_bits >> 3) & 1u) << 24);
+        const uint32_t rit_hi = ((rit_bits >> 4) & 1u) | (((rit_bits >> 5) & 1u) << 8) | (((rit_bits >> 6) & 1u) << 16);
+        const uint32_t hom_counts = minor_hom & __builtin_amdgcn_perm(rit_hi, rit_lo, lo & 0x07070707u);
+        const uint32_t miss_rit = (nz1 | nz2) & ((f & kLocusRitlandDefault) ? 0x01010101u : 0u);
+        b_rit += hom_counts | major_het | minor_het;
+        b_miss_rit += miss_rit;
+        const double* row = table + s * stride;
+        const double inv_major = row[2 * amax + kTableExtra];
+        double inv_alt[4];
+#pragma unroll
+        for (uint32_t a = 0; a < 4; ++a) inv_alt[a] = a < amax ? row[amax + kTableExtra + a] : 0.0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          s_miss[j] += ((miss_rit >> (8 * j)) & 1u) ? inv_major : 0.0;
+          const uint32_t a1 = (lo >> (8 * j)) & 0xFu;
+          double inv = a1 == 1 ? inv_alt[0] : (a1 == 2 ? inv_alt[1] : (a1 == 3 ? inv_alt[2] : inv_alt[3]));
+          s_inv[j] += ((hom_counts >> (8 * j)) & 1u) ? inv : 0.0;
+        }
+      }
       const uint32_t rare = (nz1 | nz2) & (def_mask ^ (major_het | minor_hom | minor_het));
       if (rare) {     // classification disagrees with the locus default: adjust the class-frequency sums
         const double* row = table + s * stride;
@@ -936,7 +1035,19 @@ k_inbreed_sweep_swar(const uint32_t* __restrict__ gt, uint64_t dwords_per_row, u
     p[1] = def_row[1] + cf_corr[j][1];
     p[2] = def_row[2] + cf_corr[j][2];
     p[3] = def_row[3] + cf_corr[j][3];
-    p[4] = 0.0;
+    if constexpr (RITLAND) {
+      const unsigned long long rit = static_cast<unsigned long long>(def_row[6]) - n_miss_rit[j] + n_rit[j];
+      if (rit) atomicAdd(c + 5, rit);
+      // default Ritland sum, minus the (1/p_major - 1) defaults this genome does not take, plus its own terms
+      double r = def_row[4];
+      r -= s_miss[j];
+      r += static_cast<double>(n_miss_rit[j]);
+      r += s_inv[j];
+      r -= static_cast<double>(n_rit[j]);
+      p[4] = r;
+    } else {
+      p[4] = 0.0;
+    }
   }
 }
 
