@@ -1,6 +1,7 @@
 #include "kga_analysis_gpu_allele.h"
 
 #include <fstream>
+#include <iterator>
 
 #include "../../../include/kgx.h"
 
@@ -51,6 +52,7 @@ bool kga::GpuAlleleAnalysis::fileReadAnalysis(std::shared_ptr<const DataDB> data
     return false;
   }
   const auto file_characteristic = data_object_ptr->dataCharacteristic();
+  if (file_characteristic.data_structure == DataStructureEnum::NoStructure) return sweepVcfFile(data_object_ptr->fileId());
   if (file_characteristic.data_structure != DataStructureEnum::DiploidPhased &&
       file_characteristic.data_structure != DataStructureEnum::DiploidUnphased) {
     ExecEnv::log().info("Analysis: {}, file: {} is not a diploid population; ignored", ident(), data_object_ptr->fileId());
@@ -66,14 +68,33 @@ bool kga::GpuAlleleAnalysis::fileReadAnalysis(std::shared_ptr<const DataDB> data
 
 bool kga::GpuAlleleAnalysis::sweepPopulation(const PopulationDB& population) {
   const gpu::FlatPopulation flat = gpu::flattenPopulation(population);
+  // contigs a genome holds without any variant still get a (zero) record (heterozygous.cpp:38-41)
+  for (const auto& [genome_id, genome_ptr] : population.getMap()) {
+    auto& contig_map = variant_analysis_map_[genome_id];
+    for (const auto& [contig_id, contig_ptr] : genome_ptr->getMap()) contig_map.try_emplace(contig_id);
+  }
+  return sweepFlat(flat, population.populationId());
+}
+
+bool kga::GpuAlleleAnalysis::sweepVcfFile(const std::string& file_name) {
+  std::ifstream in(file_name, std::ios::binary);
+  if (!in.good()) {
+    ExecEnv::log().error("GpuAlleleAnalysis; cannot open VCF file: {}", file_name);
+    return false;
+  }
+  std::string text((std::istreambuf_iterator<char>(in)), std::istreambuf_iterator<char>());
+  const gpu::FlatPopulation flat = gpu::flattenVcf1000(text);
+  return sweepFlat(flat, file_name);
+}
+
+bool kga::GpuAlleleAnalysis::sweepFlat(const gpu::FlatPopulation& flat, const std::string& label) {
   const uint64_t G = flat.genomes(), V = flat.variants();
   ExecEnv::log().info("GpuAlleleAnalysis; population: {}, genomes: {}, distinct variants: {}, Variant objects: {}",
-                      population.populationId(), G, V, flat.variant_objects);
+                      label, G, V, flat.variant_objects);
   if (G == 0) return true;
   for (const auto& genome_id : flat.genome_ids) {
     genome_fws_map_.try_emplace(genome_id, GpuFwsFrequencyArray());
-    auto& contig_map = variant_analysis_map_[genome_id];
-    for (const auto& [contig_id, contig_ptr] : population.getMap().at(genome_id)->getMap()) contig_map.try_emplace(contig_id);
+    variant_analysis_map_.try_emplace(genome_id);
   }
   if (V == 0) return true;
 

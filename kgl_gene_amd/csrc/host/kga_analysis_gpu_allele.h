@@ -66,6 +66,8 @@ class GpuAlleleAnalysis : public VirtualAnalysis {
   [[nodiscard]] bool initializeAnalysis(const std::string& work_directory, const ActiveParameterList& named_parameters,
                                         const std::shared_ptr<const AnalysisResources>& resource_ptr) override;
   // A diploid PopulationDB (DiploidPhased / DiploidUnphased): flattened, swept on the GPU, accumulated.
+  // A "FileNameOnly" data file (NoStructure, kgl_parser/kgl_data_file_type.h:133) is read as a phased-diploid VCF
+  // and flattened directly, bypassing Variant/PopulationDB construction.
   [[nodiscard]] bool fileReadAnalysis(std::shared_ptr<const DataDB> data_object_ptr) override;
   [[nodiscard]] bool iterationAnalysis() override;
   // Writes the three CSV files into the work directory.
@@ -79,6 +81,8 @@ class GpuAlleleAnalysis : public VirtualAnalysis {
 
  private:
   bool sweepPopulation(const PopulationDB& population);
+  bool sweepVcfFile(const std::string& file_name);
+  bool sweepFlat(const gpu::FlatPopulation& flat, const std::string& label);
   bool writeVariantResults(const std::string& file_name) const;
   bool writeGenomeResults(const std::string& file_name) const;
   bool writeHetHomResults(const std::string& file_name) const;

@@ -13,6 +13,7 @@
 #endif
 
 #include <string>
+#include <string_view>
 #include <vector>
 
 namespace kellerberrin::genome::analysis::gpu {
@@ -49,6 +50,11 @@ struct FlatPopulation {
 
 // threads == 0: the reference's default, hardware_concurrency() - 1 (kel_thread/kel_workflow_threads.h:40).
 [[nodiscard]] FlatPopulation flattenPopulation(const PopulationDB& population, size_t threads = 0);
+
+// VCF text (phased diploid, 1000-Genomes flavour) straight to the same FlatPopulation a PopulationDB filled by the
+// reference's Genome1000VCFImpl parser would flatten to — without creating Variant objects.
+// VariantRow::variant is left null.  Implemented in kgx_vcf_flatten.cpp.
+[[nodiscard]] FlatPopulation flattenVcf1000(std::string_view text, size_t threads = 0);
 
 // P7FrequencyFilter / CalcFWS bins on the "AF" INFO value of a row (kgl_variant_filter_Pf7.cpp:20-66,
 // kga_analysis_PfEMP_FWS.cpp:15-38,104-145): bin index 0..10, or 0xFF when the row is in no bin

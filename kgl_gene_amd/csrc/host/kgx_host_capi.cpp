@@ -1,0 +1,55 @@
+// Small extern "C" window onto the host-side flatteners so that they can be tested without a GPU (ctypes).
+// Not part of the device ABI (include/kgx.h): pure host code, no HIP calls.
+#include <cstring>
+
+#include "kgx_flatten.h"
+
+using kellerberrin::genome::analysis::gpu::FlatPopulation;
+
+extern "C" {
+
+void* kgxh_flatten_vcf1000(const char* text, uint64_t len, int threads) {
+  if (!text) return nullptr;
+  auto* flat = new FlatPopulation(kellerberrin::genome::analysis::gpu::flattenVcf1000(std::string_view(text, len), threads > 0 ? threads : 0));
+  return flat;
+}
+
+void kgxh_flat_destroy(void* h) { delete static_cast<FlatPopulation*>(h); }
+uint64_t kgxh_flat_genomes(void* h) { return h ? static_cast<FlatPopulation*>(h)->genomes() : 0; }
+uint64_t kgxh_flat_variants(void* h) { return h ? static_cast<FlatPopulation*>(h)->variants() : 0; }
+uint64_t kgxh_flat_row_bytes(void* h) { return h ? static_cast<FlatPopulation*>(h)->row_bytes : 0; }
+uint64_t kgxh_flat_variant_objects(void* h) { return h ? static_cast<FlatPopulation*>(h)->variant_objects : 0; }
+uint64_t kgxh_flat_non_diploid(void* h) { return h ? static_cast<FlatPopulation*>(h)->non_diploid.size() : 0; }
+
+int kgxh_flat_copy(void* h, uint8_t* packed, float* info_af, uint8_t* is_snp, uint64_t* offsets) {
+  if (!h) return -1;
+  const FlatPopulation& f = *static_cast<FlatPopulation*>(h);
+  if (packed && !f.packed.empty()) std::memcpy(packed, f.packed.data(), f.packed.size());
+  for (size_t v = 0; v < f.rows.size(); ++v) {
+    if (info_af) info_af[v] = f.rows[v].info_af;
+    if (is_snp) is_snp[v] = f.rows[v].is_snp ? 1 : 0;
+    if (offsets) offsets[v] = f.rows[v].offset;
+  }
+  return 0;
+}
+
+static void copyOut(const std::string& s, char* buf, size_t n) {
+  if (!buf || !n) return;
+  const size_t k = s.size() < n - 1 ? s.size() : n - 1;
+  std::memcpy(buf, s.data(), k);
+  buf[k] = 0;
+}
+
+int kgxh_flat_hgvs(void* h, uint64_t i, char* buf, size_t n) {
+  if (!h || i >= static_cast<FlatPopulation*>(h)->rows.size()) return -1;
+  copyOut(static_cast<FlatPopulation*>(h)->rows[i].hgvs, buf, n);
+  return 0;
+}
+
+int kgxh_flat_genome_id(void* h, uint64_t i, char* buf, size_t n) {
+  if (!h || i >= static_cast<FlatPopulation*>(h)->genome_ids.size()) return -1;
+  copyOut(static_cast<FlatPopulation*>(h)->genome_ids[i], buf, n);
+  return 0;
+}
+
+}  // extern "C"

@@ -4,7 +4,10 @@
 // -> finalizeAnalysis on the VirtualAnalysis interface.  Used by the parity tests; in the reference tree the
 // packages are registered in the factory map instead.
 //
-//   kgx_host_driver <IDENT> <work_dir> [key=value ...] -- <records.bin> [<records.bin> ...]
+//   kgx_host_driver <IDENT> <work_dir> [key=value ...] -- <records.bin | vcf:<file.vcf>> ...
+//
+// "vcf:<path>" hands the package a FilenameDataDB (the reference's "FileNameOnly" data file,
+// kgl_parser/kgl_variant_factory_parsers.cpp:65-66): the package reads the VCF itself.
 //
 // Record file (little endian): "KGXR" u32 version=1, u32 mode (0 = phased 1000-Genomes style, 1 = unphased
 // Pf style, 2 = reference mono-genome), u32 data_source (DataSourceEnum), str population_id, str contig,
@@ -35,7 +38,7 @@ struct Reader {
 };
 
 struct LoadedFile {
-  std::shared_ptr<kgl::PopulationDB> population;
+  std::shared_ptr<kgl::DataDB> population;
   std::vector<std::pair<std::string, std::string>> ped;
 };
 
@@ -151,6 +154,12 @@ int main(int argc, char** argv) {
   std::vector<LoadedFile> files;
   auto genealogy = std::make_shared<kgl::HsGenomeGenealogyData>("PED");
   for (; i < argc; ++i) {
+    if (std::strncmp(argv[i], "vcf:", 4) == 0) {
+      LoadedFile f;
+      f.population = std::make_shared<kgl::FilenameDataDB>(kgl::DataSourceEnum::NotImplemented, std::string(argv[i] + 4));
+      files.push_back(std::move(f));
+      continue;
+    }
     files.push_back(loadRecords(argv[i]));
     for (const auto& [genome, sp] : files.back().ped) genealogy->addGenealogyRecord(kgl::HsGenealogyRecord(genome, sp));
   }

@@ -112,6 +112,15 @@ class DataDB {
   DataSourceEnum data_source_;
 };
 
+// kgl_parser/kgl_variant_factory_parsers.cpp:65-66: a "FileNameOnly" data file reaches the package as its name only.
+class FilenameDataDB : public DataDB {
+ public:
+  FilenameDataDB(DataSourceEnum data_source, std::string file_name) : DataDB(data_source), file_name_(std::move(file_name)) {}
+  [[nodiscard]] const std::string& fileId() const override { return file_name_; }
+ private:
+  std::string file_name_;
+};
+
 // kgl_variant_db/kgl_variant_db.h:25-28
 enum class VariantPhase : std::uint8_t { HAPLOID_PHASED = 0, DIPLOID_PHASE_A = 1, DIPLOID_PHASE_B = 2, UNPHASED = 255 };
 

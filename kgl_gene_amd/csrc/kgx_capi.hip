@@ -297,21 +297,14 @@ kgx_pop* kgx_population_create(uint64_t n_genomes, uint64_t n_variants) {
   pop->chunks_per_row = static_cast<uint32_t>(pop->pitch / 16);
   const uint64_t bytes = pop->pitch * n_variants;
   if (bytes) {
-    const uint64_t slack = static_cast<uint64_t>(env_int("KGX_BASE_SLACK_MB", 0)) << 20;
-    const uint64_t base_off = static_cast<uint64_t>(env_int("KGX_BASE_OFFSET_KB", 0)) << 10;
-    if (hipMalloc(&pop->d_alloc, bytes + slack) != hipSuccess) {
+    if (hipMalloc(&pop->d_alloc, bytes) != hipSuccess) {
       (void)hipGetLastError();
       fail(KGX_ENOMEM, "hipMalloc of %llu bytes for %llu x %llu dosage rows failed",
            (unsigned long long)bytes, (unsigned long long)n_variants, (unsigned long long)n_genomes);
       delete pop;
       return nullptr;
     }
-    {
-      uintptr_t a = reinterpret_cast<uintptr_t>(pop->d_alloc);
-      if (slack) a = (a + slack - 1) / slack * slack;     // align the rows to the slack size (tuning only)
-      pop->d_rows = reinterpret_cast<uint8_t*>(a + base_off);
-      if (env_int("KGX_DEBUG", 0)) std::fprintf(stderr, "kgx: rows at %p (alloc %p), %llu bytes\n", (void*)pop->d_rows, (void*)pop->d_alloc, (unsigned long long)bytes);
-    }
+    pop->d_rows = pop->d_alloc;
     if (hipMemsetAsync(pop->d_rows, 0, bytes, g_state.stream) != hipSuccess ||
         hipStreamSynchronize(g_state.stream) != hipSuccess) {
       fail(KGX_EHIP, "hipMemset of dosage rows failed");

@@ -96,7 +96,8 @@ bool p7FrequencyFilter(const Variant& v, double freq_cutoff) {
   // getTypedInfoData<vector<double>>("AF"): the float32 values widened to double; a missing field or a
   // missing value for this alt lets the variant through (:61-64).  Size mismatch -> false (:31-44).
   const RecordEvidence& ev = v.evidence();
-  if (ev.af.size() != static_cast<size_t>(SUPER_POP_COUNT) * ev.alt_count) return true;   // field absent
+  if (ev.af.size() != static_cast<size_t>(SUPER_POP_COUNT) * ev.alt_count || ev.info_af_size == -1) return true;   // field absent
+  if (ev.info_af_size >= 0 && static_cast<uint32_t>(ev.info_af_size) != ev.alt_count) return false;               // vector size != alt count (:31-37)
   if (v.altVariantIndex() >= ev.alt_count) return false;
   const float f = ev.af[static_cast<size_t>(ALL) * ev.alt_count + v.altVariantIndex()];
   if (std::isnan(f)) return true;

@@ -45,6 +45,11 @@ static void fillResults(const LocusResults& r, uint64_t* counts, double* freqs) 
   freqs[4] = r.inbred_allele_sum;
 }
 
+namespace kgo {
+std::pair<size_t, size_t> alternateIndex1000(const std::string& contig, const std::string& genotype, size_t n_alt);
+long addVcf1000(PopulationDB& population, std::string_view text, std::vector<std::string>* genome_names_out);
+}
+
 extern "C" {
 
 const char* kgo_banner(void) { return "kgo oracle: CPU restatement of the KGL_Gene hot path; TEST INFRASTRUCTURE; parity unpinned"; }
@@ -135,6 +140,22 @@ int kgo_population_add_records(kgo_pop* p, int mode, const char* contig, uint64_
     }
     alt_cursor += A;
   }
+  return 0;
+}
+
+// VCF text (1000 Genomes flavour) -> Variants in the population; returns the record count (or -1).
+long kgo_population_add_vcf_1000(kgo_pop* p, const char* text, uint64_t len) {
+  if (!p || !text) return -1;
+  std::vector<std::string> names;
+  const long n = addVcf1000(*p->pop, std::string_view(text, len), &names);
+  if (p->input_ids.empty()) p->input_ids = names;
+  return n;
+}
+
+int kgo_gt_alternate_index(const char* contig, const char* genotype, uint64_t n_alt, uint64_t out[2]) {
+  const auto ab = alternateIndex1000(contig, genotype, n_alt);
+  out[0] = ab.first;
+  out[1] = ab.second;
   return 0;
 }
 

@@ -52,6 +52,7 @@ struct RecordEvidence {
   bool pass = true;
   uint32_t alt_count = 0;
   std::vector<float> af;   // [SUPER_POP_COUNT][alt_count]
+  int info_af_size = -2;   // number of values in the raw "AF" INFO vector; -1 = field absent; -2 = same as alt_count
 };
 
 class Variant {

@@ -1,0 +1,176 @@
+// ORACLE — TEST INFRASTRUCTURE ONLY.  PARITY UNPINNED (see kgo_core.h).
+// VCF text -> PopulationDB for the phased-diploid (1000 Genomes) flavour, restated from
+//   ParseVCF::moveToVcfRecord                 kgl_genomics/kgl_parser/kgl_variant_vcf_impl.cpp:96-170
+//   Genome1000VCFImpl::ParseRecord            kgl_parser/kgl_variant_factory_1000_impl.cpp:63-145
+//   Genome1000VCFImpl::alternateIndex         :148-272   (constants kgl_variant_factory_1000_impl.h:55-63)
+//   Genome1000VCFImpl::addVariants            :274-318
+//   VCFInfoParser float conversion (std::stof) kgl_parser/kgl_variant_factory_vcf_parse_info.cpp:205-260
+//   Utility::viewTokenizer / trimEndWhiteSpace kel_utility/kel_utility.cpp:190-295
+#include <cctype>
+#include <cstring>
+#include <limits>
+#include <string_view>
+
+#include "kgo_core.h"
+
+namespace kgo {
+
+static std::vector<std::string_view> viewTokenizer(std::string_view str_view, char delim) {
+  std::vector<std::string_view> token_vector;
+  size_t token_index = 0, index = 0;
+  for (; index < str_view.size(); ++index) {
+    if (str_view[index] == delim) {
+      token_vector.emplace_back(str_view.data() + token_index, index - token_index);
+      token_index = index + 1;
+    }
+  }
+  if (token_index > index) token_vector.emplace_back();
+  else token_vector.emplace_back(str_view.data() + token_index, index - token_index);
+  return token_vector;
+}
+
+static std::string trimWhiteSpace(const std::string& s) {
+  size_t b = 0, e = s.size();
+  while (b < e && std::isspace(static_cast<unsigned char>(s[b]))) ++b;
+  while (e > b && std::isspace(static_cast<unsigned char>(s[e - 1]))) --e;
+  return s.substr(b, e - b);
+}
+
+enum class ChromosomeType { AUTOSOME, ALLOSOME_X, ALLOSOME_Y };
+
+static ChromosomeType lookupType(const std::string& contig) {
+  if (contig == "X" || contig == "chrX") return ChromosomeType::ALLOSOME_X;
+  if (contig == "Y" || contig == "chrY") return ChromosomeType::ALLOSOME_Y;
+  return ChromosomeType::AUTOSOME;
+}
+
+// Genome1000VCFImpl::alternateIndex: { phase A alt, phase B alt }, 0 = reference.
+std::pair<size_t, size_t> alternateIndex1000(const std::string& contig, const std::string& genotype, size_t n_alt) {
+  constexpr size_t REFERENCE_VARIANT_INDEX_ = 0;
+  const std::string trim_genotype = trimWhiteSpace(genotype);
+  if (trim_genotype.empty()) return {REFERENCE_VARIANT_INDEX_, REFERENCE_VARIANT_INDEX_};
+  size_t GT_size = trim_genotype.find(':');
+  if (GT_size == std::string::npos) GT_size = trim_genotype.size();
+  std::string_view unphased_view(trim_genotype.c_str(), GT_size);
+  std::vector<std::string_view> phase_vector = viewTokenizer(unphased_view, '|');
+  size_t phase_A_alt = REFERENCE_VARIANT_INDEX_, phase_B_alt = REFERENCE_VARIANT_INDEX_;
+  try {
+    if (phase_vector.size() == 1) {
+      if (unphased_view != "." && unphased_view != "-") {
+        switch (lookupType(contig)) {
+          case ChromosomeType::ALLOSOME_X: phase_A_alt = std::stoul(std::string(unphased_view)); break;
+          case ChromosomeType::ALLOSOME_Y: phase_B_alt = std::stoul(std::string(unphased_view)); break;
+          default: break;   // autosome with a single phase: warned, stays reference
+        }
+      }
+      if (phase_A_alt > n_alt || phase_B_alt > n_alt) return {REFERENCE_VARIANT_INDEX_, REFERENCE_VARIANT_INDEX_};
+      return {phase_A_alt, phase_B_alt};
+    }
+    if (phase_vector[0].find('<') == std::string_view::npos) {
+      if (phase_vector[0] != "." && phase_vector[0] != "-") phase_A_alt = std::stoul(std::string(phase_vector[0]));
+    }
+    if (phase_vector[1].find('<') == std::string_view::npos) {
+      // as written in the reference: the second test looks at phase_vector[0]
+      if (phase_vector[1] != "." && phase_vector[0] != "-") phase_B_alt = std::stoul(std::string(phase_vector[1]));
+    }
+  } catch (...) {
+    return {REFERENCE_VARIANT_INDEX_, REFERENCE_VARIANT_INDEX_};
+  }
+  if (phase_A_alt > n_alt || phase_B_alt > n_alt) return {REFERENCE_VARIANT_INDEX_, REFERENCE_VARIANT_INDEX_};
+  return {phase_A_alt, phase_B_alt};
+}
+
+static float convertToFloat(const std::string& value) {
+  if (value == ".") return std::numeric_limits<float>::quiet_NaN();
+  std::string uc;
+  for (char c : value) uc += static_cast<char>(std::toupper(static_cast<unsigned char>(c)));
+  if (uc == "NAN") return std::numeric_limits<float>::quiet_NaN();
+  try {
+    return std::stof(value);
+  } catch (std::out_of_range&) {
+    if (uc.find("E-") != std::string::npos) return std::numeric_limits<float>::min();
+    if (uc.find("E") != std::string::npos) return std::numeric_limits<float>::max();
+    return std::numeric_limits<float>::quiet_NaN();
+  } catch (...) {
+    return std::numeric_limits<float>::quiet_NaN();
+  }
+}
+
+// INFO "k=v;k2=a,b" -> per super-population AF vectors using the 1000-Genomes field names (kgl_variant_db_freq.h:84-96).
+static void parseInfoAF(std::string_view info, uint32_t n_alt, std::vector<float>& af, int& info_af_size) {
+  info_af_size = -1;
+  static const char* fields[SUPER_POP_COUNT] = {"AFR_AF", "AMR_AF", "EAS_AF", "EUR_AF", "SAS_AF", "AF"};
+  af.assign(static_cast<size_t>(SUPER_POP_COUNT) * n_alt, std::numeric_limits<float>::quiet_NaN());
+  for (auto item : viewTokenizer(info, ';')) {
+    const size_t eq = item.find('=');
+    if (eq == std::string_view::npos) continue;
+    const std::string_view key = item.substr(0, eq), value = item.substr(eq + 1);
+    for (int sp = 0; sp < SUPER_POP_COUNT; ++sp) {
+      if (key != fields[sp]) continue;
+      auto values = viewTokenizer(value, ',');
+      if (sp == ALL) info_af_size = static_cast<int>(values.size());
+      if (values.size() == n_alt) {
+        for (uint32_t a = 0; a < n_alt; ++a) af[static_cast<size_t>(sp) * n_alt + a] = convertToFloat(std::string(values[a]));
+      } else if (values.size() == 1) {       // scalar field: the same value for every alt (infoFloatField, kgl_variant_db_freq.cpp:78-81)
+        for (uint32_t a = 0; a < n_alt; ++a) af[static_cast<size_t>(sp) * n_alt + a] = convertToFloat(std::string(values[0]));
+      }
+    }
+  }
+}
+
+// The whole path: text -> records -> Variants added to genomes.  Returns the number of records parsed, -1 on a
+// malformed file.  sample names come from the #CHROM line.
+long addVcf1000(PopulationDB& population, std::string_view text, std::vector<std::string>* genome_names_out) {
+  std::vector<std::string> genome_names;
+  long n_records = 0;
+  size_t line_number = 0;
+  for (auto line : viewTokenizer(text, '\n')) {
+    ++line_number;
+    if (!line.empty() && line.back() == '\r') line.remove_suffix(1);
+    if (line.empty()) continue;
+    if (line[0] == '#') {
+      if (line.rfind("#CHROM", 0) == 0) {
+        auto f = viewTokenizer(line, '\t');
+        for (size_t i = 9; i < f.size(); ++i) genome_names.emplace_back(f[i]);
+      }
+      continue;
+    }
+    auto field_views = viewTokenizer(line, '\t');
+    if (field_views.size() < 8) continue;                                   // error + record dropped
+    const std::string contig(field_views[0]);
+    const uint64_t offset = std::stoull(std::string(field_views[1])) - 1;   // VCF is 1-based
+    const std::string ref(field_views[3]);
+    const std::string alt = field_views[4] == "." ? std::string() : std::string(field_views[4]);
+    std::string filter_uc;
+    for (char c : field_views[6]) filter_uc += static_cast<char>(std::toupper(static_cast<unsigned char>(c)));
+    const bool passed_filter = filter_uc == "PASS";
+    std::vector<std::string> alt_vector;
+    for (auto a : viewTokenizer(alt, ',')) alt_vector.emplace_back(a);
+    auto ev = std::make_shared<RecordEvidence>();
+    ev->record_index = static_cast<uint64_t>(n_records);
+    ev->pass = passed_filter;
+    ev->alt_count = static_cast<uint32_t>(alt_vector.size());
+    parseInfoAF(field_views[7], ev->alt_count, ev->af, ev->info_af_size);
+
+    std::map<size_t, std::vector<std::string>> phase_A_map, phase_B_map;
+    for (size_t idx = 9; idx < field_views.size(); ++idx) {
+      const size_t genotype_count = idx - 9;
+      if (genotype_count >= genome_names.size()) break;
+      const auto [A_index, B_index] = alternateIndex1000(contig, std::string(field_views[idx]), alt_vector.size());
+      if (A_index != 0) phase_A_map[A_index - 1].push_back(genome_names[genotype_count]);
+      if (B_index != 0) phase_B_map[B_index - 1].push_back(genome_names[genotype_count]);
+    }
+    for (int phase = 0; phase < 2; ++phase) {
+      for (const auto& [alt_allele, genome_vector] : (phase == 0 ? phase_A_map : phase_B_map)) {
+        auto v = std::make_shared<const Variant>(contig, offset, phase == 0 ? VariantPhase::DIPLOID_PHASE_A : VariantPhase::DIPLOID_PHASE_B,
+                                                 ref, alt_vector[alt_allele], ev, static_cast<uint32_t>(alt_allele));
+        population.addVariant(v, genome_vector);
+      }
+    }
+    ++n_records;
+  }
+  if (genome_names_out) *genome_names_out = genome_names;
+  return n_records;
+}
+
+}  // namespace kgo

@@ -1,0 +1,61 @@
+"""ctypes window onto the host-side flatteners in kgl_gene_amd/lib/libkgx_analysis.so (pure host code)."""
+from __future__ import annotations
+
+import ctypes as C
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parent.parent
+LIB = ROOT / "kgl_gene_amd" / "lib" / "libkgx_analysis.so"
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not LIB.exists():
+            from kgl_gene_amd import build as kbuild
+
+            kbuild.build_kgx()
+            kbuild.build_host()
+        L = C.CDLL(str(LIB))
+        L.kgxh_flatten_vcf1000.restype = C.c_void_p
+        L.kgxh_flatten_vcf1000.argtypes = [C.c_char_p, C.c_uint64, C.c_int]
+        L.kgxh_flat_destroy.argtypes = [C.c_void_p]
+        for name in ("kgxh_flat_genomes", "kgxh_flat_variants", "kgxh_flat_row_bytes", "kgxh_flat_variant_objects", "kgxh_flat_non_diploid"):
+            getattr(L, name).restype = C.c_uint64
+            getattr(L, name).argtypes = [C.c_void_p]
+        L.kgxh_flat_copy.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.kgxh_flat_hgvs.argtypes = [C.c_void_p, C.c_uint64, C.c_char_p, C.c_size_t]
+        L.kgxh_flat_genome_id.argtypes = [C.c_void_p, C.c_uint64, C.c_char_p, C.c_size_t]
+        _lib = L
+    return _lib
+
+
+class FlatVcf:
+    def __init__(self, text: str, threads: int = 0):
+        b = text.encode()
+        h = lib().kgxh_flatten_vcf1000(b, len(b), threads)
+        assert h
+        try:
+            self.G, self.V = int(lib().kgxh_flat_genomes(h)), int(lib().kgxh_flat_variants(h))
+            self.row_bytes = int(lib().kgxh_flat_row_bytes(h))
+            self.variant_objects = int(lib().kgxh_flat_variant_objects(h))
+            self.non_diploid = int(lib().kgxh_flat_non_diploid(h))
+            self.packed = np.zeros((self.V, self.row_bytes), dtype=np.uint8)
+            self.info_af = np.zeros(self.V, dtype=np.float32)
+            self.is_snp = np.zeros(self.V, dtype=np.uint8)
+            self.offsets = np.zeros(self.V, dtype=np.uint64)
+            p = lambda a: C.c_void_p(a.ctypes.data)
+            lib().kgxh_flat_copy(h, p(self.packed), p(self.info_af), p(self.is_snp), p(self.offsets))
+            buf = C.create_string_buffer(1024)
+            self.hgvs, self.genome_ids = [], []
+            for i in range(self.V):
+                lib().kgxh_flat_hgvs(h, i, buf, 1024)
+                self.hgvs.append(buf.value.decode())
+            for i in range(self.G):
+                lib().kgxh_flat_genome_id(h, i, buf, 1024)
+                self.genome_ids.append(buf.value.decode())
+        finally:
+            lib().kgxh_flat_destroy(h)

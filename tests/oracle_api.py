@@ -37,6 +37,8 @@ def lib() -> C.CDLL:
         "kgo_population_destroy": (None, [vp]),
         "kgo_population_add_genomes": (C.c_int, [vp, u64, vp, C.c_int]),
         "kgo_population_add_records": (C.c_int, [vp, C.c_int, C.c_char_p, u64, vp, vp, vp, vp, vp, vp, u64, vp, vp]),
+        "kgo_population_add_vcf_1000": (C.c_long, [vp, C.c_char_p, u64]),
+        "kgo_gt_alternate_index": (C.c_int, [C.c_char_p, C.c_char_p, u64, vp]),
         "kgo_population_variant_count": (u64, [vp]),
         "kgo_population_genome_count": (u64, [vp]),
         "kgo_population_genome_order": (C.c_int, [vp, vp]),
@@ -148,6 +150,13 @@ class Population:
                                               C.cast(refs, C.c_void_p), _p(rec.n_alts), C.cast(alts, C.c_void_p),
                                               _p(rec.passed), _p(af), len(self.genome_ids), C.cast(ids, C.c_void_p), _p(gt))
         assert rc == 0
+
+    def add_vcf_1000(self, text: str) -> int:
+        """Parse VCF text the way Genome1000VCFImpl does; genome ids come from the #CHROM line."""
+        b = text.encode()
+        n = lib().kgo_population_add_vcf_1000(self._h, b, len(b))
+        assert n >= 0
+        return int(n)
 
     @property
     def handle(self):
@@ -340,3 +349,9 @@ def synthetic_check(reference: Population, super_pop, algorithm, lower, upper, s
                                   seed, _p(syn), _p(calc), 128)
     assert n >= 0
     return syn[:n].copy(), calc[:n].copy()
+
+
+def gt_alternate_index(contig: str, genotype: str, n_alt: int):
+    out = np.zeros(2, dtype=np.uint64)
+    lib().kgo_gt_alternate_index(contig.encode(), genotype.encode(), n_alt, _p(out))
+    return int(out[0]), int(out[1])

@@ -115,3 +115,33 @@ def test_gpu_inbreed_package_matches_oracle_window_loop(tmp_path, kgx, algorithm
     assert lines[0].startswith("DriverParameters,Algorithm:" + algorithm)
     assert lines[1].split(",")[2:] == [c[0] for c in cols]
     assert len(lines) == 2 + int(np.sum(sp_of >= 0))
+
+
+def test_gpu_allele_package_reads_vcf_directly(tmp_path, kgx):
+    """A FileNameOnly data file: the package parses the VCF itself (no Variant / PopulationDB objects) and must
+    produce what the oracle gets by parsing the same text the reference's way and running CalcFWS / HeteroHomoZygous."""
+    from . import vcf_text as vt
+
+    G, L = 37, 1200
+    rec, gt = sv.multiallelic_block(G, L, rng_seed=9, dup_records=2)
+    ids = [f"HG{i:05d}" for i in range(G)]
+    text = vt.write_vcf_1000(rec, gt, ids, rng_seed=4)
+    vcf = tmp_path / "pop.vcf"
+    vcf.write_text(text)
+    res = rio.run_driver("GPU_ALLELE", tmp_path, [f"vcf:{vcf}"])
+    assert res.returncode == 0, res.stderr
+
+    opop = oa.Population("vcf")
+    opop.add_vcf_1000(text)
+    variant_out, genome_out, vdb = opop.fws()
+    header, rows = rio.read_csv(tmp_path / "VariantFWS.csv")
+    assert [r[0] for r in rows] == [vdb.hgvs(i) for i in range(vdb.n_variants)]
+    assert np.array_equal(np.array([[int(x) for x in r[-3:]] for r in rows], dtype=np.uint64), variant_out)
+    header, rows = rio.read_csv(tmp_path / "GenomeFWS.csv")
+    assert [r[0] for r in rows] == [vdb.genome_id(i) for i in range(vdb.n_genomes)]
+    got = np.array([[int(r[1 + 8 * b + 5 + k]) for b in range(11) for k in range(3)] for r in rows], dtype=np.uint64)
+    assert np.array_equal(got.reshape(len(rows), 11, 3), genome_out)
+    header, rows = rio.read_csv(tmp_path / "VariantStatistics.csv")
+    want = opop.hethom(rec.contig)
+    got = np.array([[int(r[2]), int(r[3]), int(r[4]), int(r[7]), int(r[8]), int(r[6]), int(r[5])] for r in rows], dtype=np.uint64)
+    assert np.array_equal(got, want)
