@@ -18,9 +18,10 @@ def write_vcf_1000(rec, gt, ids, rng_seed=0, quirks=True, contig=None):
         for sp, name in enumerate(fields):
             vals = ",".join("." if np.isnan(v) else repr(float(v)) for v in af[:, sp])
             info.append(f"{name}={vals}")
-        if quirks and r % 37 == 5:
+        q = int(rec.offsets[r])      # keyed by offset so that repeated records of one locus carry the same INFO
+        if quirks and q % 37 == 5:
             info = [x for x in info if not x.startswith("AF=")]          # AF missing entirely
-        if quirks and r % 41 == 7 and len(alts) > 1:
+        if quirks and q % 41 == 7 and len(alts) > 1:
             info = [x if not x.startswith("AF=") else "AF=0.25" for x in info]   # scalar AF on a multi-alt record
         flt = "PASS" if r % 11 else ("pass" if r % 2 else "q10")
         cols = []
