@@ -208,6 +208,14 @@ int kgx_synth_multiallelic_host(uint64_t seed, uint64_t genome_base, uint64_t n_
                                 uint8_t* gt8, uint64_t pitch, double* af_table, uint8_t* alleles);
 int kgx_synth_locus_host(uint64_t seed, uint64_t l, int* n_alt, float af[3], int is_indel[3]);
 
+/* The reference's synthetic-inbreeding self-check population (InbreedSynthetic::generateSyntheticPopulation,
+ * kga_analysis_inbreed_syngen.cpp:20-196) written into the matrix: locus l has the minor allele frequencies
+ * minor_af[l][amax] (NaN = alt not in the list), genome g the inbreeding coefficient inbreeding[g]; allele classes
+ * and alleles are drawn as the reference does, from Philox4x32-10 keyed by `seed` (the reference uses std::random_device).
+ * Homozygous pairs carry two phases: analyse with phased = 1. */
+int kgx_gt8_synth_inbred(kgx_gt8* gt, const double* minor_af, uint32_t amax, const double* inbreeding /* [n_genomes] */,
+                         uint64_t seed);
+
 #ifdef __cplusplus
 }
 #endif

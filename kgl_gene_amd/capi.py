@@ -76,6 +76,7 @@ _SIGNATURES = {
     "kgx_synth_multiallelic_host": (C.c_int, [C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64, C.c_void_p, C.c_uint64,
                                               C.c_void_p, C.c_void_p]),
     "kgx_synth_locus_host": (C.c_int, [C.c_uint64, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "kgx_gt8_synth_inbred": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint64]),
     "kgx_compound_offsets": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_void_p]),
 }
 
@@ -368,6 +369,14 @@ class GenotypeMatrix:
         table = np.zeros((self.n_loci, 3), dtype=np.float64)
         check(lib().kgx_gt8_synth_multiallelic(self._h, seed, genome_base, locus_base, ptr(table)))
         return table
+
+    def synth_inbred(self, minor_af: np.ndarray, inbreeding: np.ndarray, seed: int = 1111) -> None:
+        """Fill with the reference's synthetic-inbreeding self-check genomes (genome g has F = inbreeding[g])."""
+        a = np.ascontiguousarray(minor_af, dtype=np.float64)
+        f = np.ascontiguousarray(inbreeding, dtype=np.float64)
+        if a.shape[0] != self.n_loci or f.shape != (self.n_genomes,):
+            raise ValueError("minor_af must have one row per locus and inbreeding one value per genome")
+        check(lib().kgx_gt8_synth_inbred(self._h, ptr(a), a.shape[1], ptr(f), int(seed)))
 
     def inbreed(self, minor_af: np.ndarray, algorithm: str, phased: bool, locus_index=None, g0: int = 0, g1: int | None = None):
         g1 = self.n_genomes if g1 is None else g1

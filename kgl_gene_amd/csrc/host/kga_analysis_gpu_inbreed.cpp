@@ -3,6 +3,7 @@
 #include <algorithm>
 #include <cmath>
 #include <fstream>
+#include <iomanip>
 #include <limits>
 #include <sstream>
 #include <unordered_map>
@@ -164,7 +165,10 @@ bool kga::GpuInbreedAnalysis::initializeAnalysis(const std::string& work_directo
   work_directory_ = work_directory;
   for (const auto& [block_name, named_vector] : named_parameters.getMap())
     for (const auto& parameter_map : named_vector.second)
+    {
       if (auto v = parameter_map.getSize("Device")) device_ = static_cast<int>(v.value().front());
+      if (auto v = parameter_map.getSize("SyntheticSeed")) synthetic_seed_ = v.value().front();
+    }
   for (const auto& parameter : extractParameters(named_parameters)) {
     GpuParamOutput out;
     out.parameters = parameter;
@@ -202,19 +206,24 @@ bool kga::GpuInbreedAnalysis::fileReadAnalysis(std::shared_ptr<const DataDB> dat
 bool kga::GpuInbreedAnalysis::iterationAnalysis() {
   ExecEnv::log().info("Iteration Analysis called for Analysis Id: {}", ident());
   if (!device_ready_) return false;
-  if (!diploid_population_ || !unphased_population_ || !genealogy_data_) {
-    ExecEnv::log().critical("GpuInbreedAnalysis::iterationAnalysis; necessary variant databases not supplied - program terminates.");
-    return false;
-  }
   bool ok = true;
   for (auto& param_output : parameter_output_vector_) {
+    // ExecuteInbreedingAnalysis::executeAnalysis (kga_analysis_inbreed_execute.cpp:16-45)
     if (param_output.parameters.analyze_synthetic) {
-      ExecEnv::log().error("GpuInbreedAnalysis; parameter block: {} asks for the synthetic self-check, which this package does not run; use AnalysisType=false",
-                           param_output.parameters.parameter_ident);
-      ok = false;
-      continue;
+      if (!unphased_population_) {
+        ExecEnv::log().error("InbreedAnalysis::iterationAnalysis; Insufficient data, cannot process synthetic diploid inbreeding");
+        ok = false;
+        continue;
+      }
+      ok = syntheticInbreeding(param_output) && ok;
+    } else {
+      if (!diploid_population_ || !unphased_population_ || !genealogy_data_) {
+        ExecEnv::log().error("ExecuteInbreedingAnalysis::processDiploid; Insufficient data, cannot process diploid inbreeding");
+        ok = false;
+        continue;
+      }
+      ok = populationInbreeding(param_output) && ok;
     }
-    ok = populationInbreeding(param_output) && ok;
   }
   diploid_population_ = nullptr;
   unphased_population_ = nullptr;
@@ -366,6 +375,112 @@ bool kga::GpuInbreedAnalysis::populationInbreeding(GpuParamOutput& param_output)
   return true;
 }
 
+// ---- synthetic self-check ------------------------------------------------------------------------------
+
+kgl::GenomeId_t kga::GpuInbreedAnalysis::generateSyntheticGenomeId(double inbreeding, const std::string& super_population, size_t counter) {
+  std::stringstream genome_id_stream;
+  genome_id_stream << std::fixed << std::setprecision(0);
+  if (inbreeding >= 0) genome_id_stream << super_population << "_" << (inbreeding * 1000000.0) << "_" << counter;
+  else genome_id_stream << super_population << "_N" << (-inbreeding * 1000000.0) << "_" << counter;
+  return genome_id_stream.str();
+}
+
+std::pair<bool, double> kga::GpuInbreedAnalysis::generateInbreeding(const GenomeId_t& genome_id) {
+  bool valid_value = false, negative = false;
+  double inbreed_coefficient = -1000.0;
+  auto first_pos = genome_id.find_first_of("N");
+  if (first_pos == std::string::npos) first_pos = genome_id.find_first_of("_");
+  else negative = true;
+  if (first_pos != std::string::npos) {
+    ++first_pos;
+    const auto second_pos = genome_id.find_first_of("_", first_pos);
+    if (second_pos != std::string::npos) {
+      try {
+        const size_t coefficient = static_cast<size_t>(std::stod(genome_id.substr(first_pos, second_pos - first_pos)));
+        inbreed_coefficient = static_cast<double>(coefficient) / 1000000.0;
+        valid_value = true;
+        if (negative) inbreed_coefficient = -1.0 * inbreed_coefficient;
+      } catch (std::exception&) {
+      }
+    }
+  }
+  return {valid_value, inbreed_coefficient};
+}
+
+bool kga::GpuInbreedAnalysis::syntheticInbreeding(GpuParamOutput& param_output) {
+  const GpuInbreedingParameters& params = param_output.parameters;
+  const int algorithm = algorithmCode(params.inbreeding_algorithm);
+  if (algorithm < 0) {
+    ExecEnv::log().error("InbreedingAnalysis::populationInbreeding, Inbreeding algorithm not found: {}", params.inbreeding_algorithm);
+    return true;
+  }
+  bool ok = false;
+  const GpuReferenceContig reference = buildReference(*unphased_population_, ok);
+  if (!ok) return false;
+  if (reference.max_alts > 14) {
+    ExecEnv::log().error("GpuInbreedAnalysis; a reference offset holds {} SNP alts; at most 14 fit the 4-bit allele index", reference.max_alts);
+    return false;
+  }
+  const uint32_t amax = std::max<uint32_t>(1, reference.max_alts);
+  const auto& super_pops = FrequencyDatabaseRead::superPopulations();
+  const int all_slot = static_cast<int>(std::find(super_pops.begin(), super_pops.end(), std::string(FrequencyDatabaseRead::SUPER_POP_ALL_)) - super_pops.begin());
+
+  // The inbreeding grid of generateSyntheticPopulation (_syngen.cpp:44-56): repeated addition, as the reference does.
+  std::vector<double> grid;
+  for (double inbreeding = -0.5; inbreeding <= (0.5 + 0.000001); inbreeding += 0.01) grid.push_back(inbreeding);
+
+  // One column's worth of work: SyntheticAnalysis::processSynResults uses the ORIGINAL window of the parameter block
+  // (_synthetic.cpp:53), so every column of a block analyses the same locus lists; only the draws differ in the
+  // reference.  Here the draws are keyed by (seed, column).
+  auto process = [&](uint64_t column, GpuResultsMap& results_map) -> bool {
+    for (size_t sp = 0; sp < super_pops.size(); ++sp) {
+      const std::vector<uint32_t> selected = reference.sampleLocii(static_cast<int>(sp), params.locii, false);
+      std::vector<double> af_table(selected.size() * amax, kNaN);
+      for (size_t s = 0; s < selected.size(); ++s) reference.alleleFreqRow(selected[s], static_cast<int>(sp), &af_table[s * amax], amax);
+      DeviceMatrix dev;
+      dev.handle = kgx_gt8_create(grid.size(), selected.size());
+      std::vector<kgx_locus_results> device_results(grid.size());
+      if (!dev.handle ||
+          kgx_gt8_synth_inbred(dev.handle, af_table.data(), amax, grid.data(), synthetic_seed_ + 1000003ull * column + sp) != KGX_OK ||
+          kgx_inbreed(dev.handle, 0, grid.size(), nullptr, selected.size(), af_table.data(), amax, 1, algorithm, device_results.data()) != KGX_OK) {
+        ExecEnv::log().error("GpuInbreedAnalysis; synthetic sweep failed: {}", kgx_last_error());
+        return false;
+      }
+      for (size_t g = 0; g < grid.size(); ++g) {
+        const kgx_locus_results& d = device_results[g];
+        GpuLocusResults r;
+        r.genome = generateSyntheticGenomeId(grid[g], super_pops[sp], g);
+        r.major_hetero_count = d.major_hetero_count;  r.major_hetero_freq = d.major_hetero_freq;
+        r.minor_hetero_count = d.minor_hetero_count;  r.minor_hetero_freq = d.minor_hetero_freq;
+        r.minor_homo_count = d.minor_homo_count;      r.minor_homo_freq = d.minor_homo_freq;
+        r.major_homo_count = d.major_homo_count;      r.major_homo_freq = d.major_homo_freq;
+        r.total_allele_count = d.total_allele_count;  r.inbred_allele_sum = d.inbred_allele_sum;
+        results_map[r.genome] = r;
+      }
+    }
+    return true;
+  };
+
+  GpuLociiArguments local = params.locii;
+  std::vector<uint32_t> locii_vector = reference.sampleLocii(all_slot, local, true);
+  if (locii_vector.empty()) return true;
+  local.upper_offset = reference.loci[locii_vector.back()].offset;
+  uint64_t column_index = 0;
+  while (local.upper_offset < params.locii.upper_offset && locii_vector.size() >= 100) {
+    GpuResultColumn column;
+    std::stringstream ss;
+    ss << reference.contig_id << "_" << local.lower_offset << "_" << local.upper_offset;
+    column.column_ident = ss.str();
+    if (!process(column_index++, column.results)) return false;
+    param_output.columns.push_back(std::move(column));
+    local.lower_offset = local.upper_offset;
+    locii_vector = reference.sampleLocii(all_slot, local, true);
+    if (locii_vector.empty()) break;
+    local.upper_offset = reference.loci[locii_vector.back()].offset;
+  }
+  return true;
+}
+
 bool kga::GpuInbreedAnalysis::finalizeAnalysis() {
   ExecEnv::log().info("Finalize called for Analysis Id: {}", ident());
   return writeResults();
@@ -390,14 +505,21 @@ bool kga::GpuInbreedAnalysis::writeResults() const {
     outfile << p.parameter_ident << DELIMITER_ << "Algorithm:" << p.inbreeding_algorithm << DELIMITER_ << "Min_AF:" << p.locii.allele_frequency_min
             << DELIMITER_ << "Max_AF:" << p.locii.allele_frequency_max << DELIMITER_ << "Spacing:" << p.locii.spacing << DELIMITER_
             << "Count:" << p.locii.locii_count << '\n';
-    outfile << "Sample" << DELIMITER_ << "SuperPopulation";
-    for (const auto& column : param_output.columns) outfile << DELIMITER_ << column.column_ident;
-    outfile << '\n';
+    if (p.analyze_synthetic) outfile << "Sample" << DELIMITER_ << "SynInbreed" << DELIMITER_ << "CalcInbreed" << '\n';   // writeSynthetic (_output.cpp:353)
+    else {
+      outfile << "Sample" << DELIMITER_ << "SuperPopulation";
+      for (const auto& column : param_output.columns) outfile << DELIMITER_ << column.column_ident;
+      outfile << '\n';
+    }
     detail.precision(17);
     detail << "Column,Sample,MajorHetCount,MajorHetFreq,MinorHetCount,MinorHetFreq,MinorHomCount,MinorHomFreq,MajorHomCount,MajorHomFreq,Total,Inbreeding\n";
     for (const auto& [genome_id, first] : param_output.columns.front().results) {
-      auto record_opt = genealogy_data_ ? genealogy_data_->getGenomeGenealogyRecord(genome_id) : std::nullopt;
-      outfile << genome_id << DELIMITER_ << (record_opt ? record_opt.value().superPopulation() : std::string()) << DELIMITER_;
+      if (p.analyze_synthetic) {
+        outfile << genome_id << DELIMITER_ << generateInbreeding(genome_id).second << DELIMITER_;
+      } else {
+        auto record_opt = genealogy_data_ ? genealogy_data_->getGenomeGenealogyRecord(genome_id) : std::nullopt;
+        outfile << genome_id << DELIMITER_ << (record_opt ? record_opt.value().superPopulation() : std::string()) << DELIMITER_;
+      }
       for (const auto& column : param_output.columns) {
         auto found = column.results.find(genome_id);
         if (found == column.results.end()) {

@@ -111,6 +111,18 @@ class GpuInbreedAnalysis : public VirtualAnalysis {
 
  private:
   bool populationInbreeding(GpuParamOutput& param_output);
+  // SyntheticAnalysis::syntheticInbreeding (kga_analysis_inbreed_synthetic.cpp:17-138)
+  bool syntheticInbreeding(GpuParamOutput& param_output);
+
+ public:
+  // InbreedSynthetic::generateSyntheticGenomeId / generateInbreeding (kga_analysis_inbreed_syngen.cpp:202-275)
+  [[nodiscard]] static GenomeId_t generateSyntheticGenomeId(double inbreeding, const std::string& super_population, size_t counter);
+  [[nodiscard]] static std::pair<bool, double> generateInbreeding(const GenomeId_t& genome_id);
+  // Seed of the synthetic draws (parameter "SyntheticSeed", default 1111 = DeterministicEntropySource, kel_distribution.h:60;
+  // the reference itself seeds from std::random_device).
+  uint64_t synthetic_seed_{1111};
+
+ private:
   bool writeResults() const;
 
   std::vector<GpuParamOutput> parameter_output_vector_;

@@ -967,4 +967,26 @@ int kgx_synth_locus_host(uint64_t seed, uint64_t l, int* n_alt, float af[3], int
   return KGX_OK;
 }
 
+int kgx_gt8_synth_inbred(kgx_gt8* h, const double* minor_af, uint32_t amax, const double* inbreeding, uint64_t seed) {
+  if (int rc = require_device()) return rc;
+  if (!h || !minor_af || !inbreeding) return fail(KGX_EINVAL, "null argument");
+  if (amax == 0 || amax > 14) return fail(KGX_EINVAL, "amax %u outside [1,14]", amax);
+  if (h->n_loci == 0) return KGX_OK;
+  double *d_table = nullptr, *d_f = nullptr;
+  KGX_HIP_MEM(hipMalloc(&d_table, h->n_loci * amax * sizeof(double)));
+  if (hipMalloc(&d_f, h->n_genomes * sizeof(double)) != hipSuccess) { (void)hipGetLastError(); (void)hipFree(d_table); return fail(KGX_ENOMEM, "hipMalloc failed"); }
+  int rc = KGX_OK;
+  if (hipMemcpyAsync(d_table, minor_af, h->n_loci * amax * sizeof(double), hipMemcpyHostToDevice, g_state.stream) != hipSuccess ||
+      hipMemcpyAsync(d_f, inbreeding, h->n_genomes * sizeof(double), hipMemcpyHostToDevice, g_state.stream) != hipSuccess)
+    rc = fail(KGX_EHIP, "H2D of the allele-frequency table failed");
+  if (rc == KGX_OK) {
+    hipLaunchKernelGGL(k_synth_inbred, dim3(stream_grid(h->n_loci * h->n_genomes, kBlock)), dim3(kBlock), 0, g_state.stream, h->d_gt,
+                       h->pitch, h->n_loci, h->n_genomes, d_table, amax, d_f, seed);
+    if (hipGetLastError() != hipSuccess || hipStreamSynchronize(g_state.stream) != hipSuccess) rc = fail(KGX_EHIP, "synthetic inbred genome kernel failed");
+  }
+  (void)hipFree(d_table);
+  (void)hipFree(d_f);
+  return rc;
+}
+
 }  // extern "C"

@@ -594,7 +594,8 @@ __device__ __forceinline__ int classify_cell(uint32_t b, const double* __restric
     return kClassNone;
   }
   const uint32_t a1 = b & 15u, a2 = b >> 4;
-  if (a1 == 15u || a2 == 15u || a1 > amax || a2 > amax) return kClassNone;    // unknown alt, or >= 3 variants (0xFF)
+  // unknown alt, >= 3 variants (0xFF), or a byte no flattener writes (second variant without a first)
+  if (a1 == 0u || a1 == 15u || a2 == 15u || a1 > amax || a2 > amax) return kClassNone;
   f1 = row[a1 - 1];
   if (!(f1 == f1)) return kClassNone;                                         // front() not in the AF list
   if (a2 == 0) { f2 = p_major; return kMajorHet; }
@@ -891,6 +892,15 @@ k_inbreed_sweep_fast(const uint32_t* __restrict__ gt, uint64_t dwords_per_row, u
 __device__ __forceinline__ uint32_t bytes_nonzero(uint32_t x) {   // x: bytes <= 0x0F -> 0x01 where byte != 0
   return ((x + 0x0F0F0F0Fu) >> 4) & 0x01010101u;
 }
+// Bit 0 of every byte that holds a nibble >= 8 (other bits: don't care).  This path's table has 8 entries (amax <= 6),
+// so allele indices 8..14 are past it, 15 is "unknown alt" and 0xFF ">= 3 variants": generateFrequencies skips the
+// cell in every one of those cases, whatever the other nibble holds.  The v_perm selectors are left unmasked: a
+// selector of 8..12 returns 0x00 (the LUT bytes have no sign bit) and 13..15 returns 0xFF, and every use of the
+// looked-up bytes is ANDed with a 0x01-per-byte mask that this kill bit has already cleared.
+__device__ __forceinline__ uint32_t bytes_wide_nibble(uint32_t x) {
+  const uint32_t t = x | (x >> 4);
+  return t >> 3;
+}
 
 // locus_index and meta are padded by 8 entries past n_sel (whole batches are fetched with one scalar load each);
 // loci_per_seg is a multiple of 8.
@@ -966,8 +976,8 @@ k_inbreed_sweep_swar(const uint32_t* __restrict__ gt, uint64_t dwords_per_row, u
       const uint32_t def_mask = (f & kLocusDefault) ? 0x01010101u : 0u;
       const uint32_t x = w[i];
       const uint32_t lo = x & 0x0F0F0F0Fu, hi = (x >> 4) & 0x0F0F0F0Fu;
-      const uint32_t ok1 = __builtin_amdgcn_perm(lut_hi, lut_lo, lo & 0x07070707u);   // nibble 15 -> entry 7 -> 0
-      const uint32_t ok2 = __builtin_amdgcn_perm(lut_hi, lut_lo, hi & 0x07070707u);
+      const uint32_t ok1 = __builtin_amdgcn_perm(lut_hi, lut_lo, lo) & ~bytes_wide_nibble(x);
+      const uint32_t ok2 = __builtin_amdgcn_perm(lut_hi, lut_lo, hi);
       const uint32_t nz1 = bytes_nonzero(lo), nz2 = bytes_nonzero(hi);
       const uint32_t same = bytes_nonzero(lo ^ hi) ^ 0x01010101u;
       const uint32_t hom = same & ph_mask & nz2;
@@ -984,7 +994,7 @@ k_inbreed_sweep_swar(const uint32_t* __restrict__ gt, uint64_t dwords_per_row, u
         const uint32_t rit_bits = (m[i] >> 16) & 0xFFu;
         const uint32_t rit_lo = ((rit_bits >> 0) & 1u) | (((rit_bits >> 1) & 1u) << 8) | (((rit_bits >> 2) & 1u) << 16) | (((rit_bits >> 3) & 1u) << 24);
         const uint32_t rit_hi = ((rit_bits >> 4) & 1u) | (((rit_bits >> 5) & 1u) << 8) | (((rit_bits >> 6) & 1u) << 16);
-        const uint32_t hom_counts = minor_hom & __builtin_amdgcn_perm(rit_hi, rit_lo, lo & 0x07070707u);
+        const uint32_t hom_counts = minor_hom & __builtin_amdgcn_perm(rit_hi, rit_lo, lo);
         const uint32_t miss_rit = (nz1 | nz2) & ((f & kLocusRitlandDefault) ? 0x01010101u : 0u);
         b_rit += hom_counts | major_het | minor_het;
         b_miss_rit += miss_rit;
@@ -1129,8 +1139,8 @@ k_inbreed_sweep_swar16(const kgx_v4u* __restrict__ gt, uint64_t chunks_per_row, 
       for (int d = 0; d < 4; ++d) {
         const uint32_t x = w[i][d];
         const uint32_t lo = x & 0x0F0F0F0Fu, hi = (x >> 4) & 0x0F0F0F0Fu;
-        const uint32_t ok1 = __builtin_amdgcn_perm(lut_hi, lut_lo, lo & 0x07070707u);
-        const uint32_t ok2 = __builtin_amdgcn_perm(lut_hi, lut_lo, hi & 0x07070707u);
+        const uint32_t ok1 = __builtin_amdgcn_perm(lut_hi, lut_lo, lo) & ~bytes_wide_nibble(x);
+        const uint32_t ok2 = __builtin_amdgcn_perm(lut_hi, lut_lo, hi);
         const uint32_t nz1 = bytes_nonzero(lo), nz2 = bytes_nonzero(hi);
         const uint32_t same = bytes_nonzero(lo ^ hi) ^ 0x01010101u;
         const uint32_t hom = same & ph_mask & nz2;
@@ -1319,6 +1329,94 @@ k_synth_gt8(uint32_t* __restrict__ gt, uint64_t dwords_per_row, uint64_t n_loci,
       }
     }
     gt[l * dwords_per_row + q] = word;
+  }
+}
+
+// Synthetic inbred genomes for the reference's self-check (InbreedSynthetic::generateSyntheticPopulation,
+// kga_analytic/kga_inbreed/kga_analysis_inbreed_syngen.cpp:20-196): genome g has F = inbreeding[g]; at every locus
+// of the list an allele class is drawn from alleleClassFrequencies(F) and alleles from the select* functions
+// (kga_analysis_inbreed_freq.cpp:221-420).  The reference draws from std::random_device; here Philox4x32-10 keyed by
+// `seed`, counter (locus, genome, KGX_STREAM_SELFCHECK).  One thread per (locus, genome) byte.
+__global__ void __launch_bounds__(kBlock)
+k_synth_inbred(uint8_t* __restrict__ gt, uint64_t pitch, uint64_t n_loci, uint64_t n_genomes, const double* __restrict__ af_table,
+               uint32_t amax, const double* __restrict__ inbreeding, uint64_t seed) {
+  const uint64_t total = n_loci * n_genomes;
+  for (uint64_t i = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < total;
+       i += static_cast<uint64_t>(gridDim.x) * blockDim.x) {
+    const uint64_t l = i / n_genomes, g = i % n_genomes;
+    const double F = inbreeding[g];
+    const double* row = af_table + l * amax;
+    double f[14];
+    uint32_t alt_of[14];
+    uint32_t n = 0;
+    double sum_minor = 0.0;
+    for (uint32_t a = 0; a < amax && a < 14; ++a) {
+      const double x = row[a];
+      if (x == x) { f[n] = clamp01(x); alt_of[n] = a + 1; sum_minor += f[n]; ++n; }
+    }
+    uint32_t a1 = 0, a2 = 0;
+    if (n > 0) {
+      const double major = (1.0 - sum_minor) > 0.0 ? (1.0 - sum_minor) : 0.0;
+      const bool rescale = sum_minor > 1.0;
+      double minor_hom = 0.0, minor_het = 0.0, major_het = 0.0;
+      for (uint32_t a = 0; a < n; ++a) { const double p = rescale ? f[a] / sum_minor : f[a]; minor_hom += (F * p) + ((1.0 - F) * p * p); }
+      for (uint32_t a = 0; a < n; ++a)
+        for (uint32_t b = a + 1; b < n; ++b) {
+          const double pa = rescale ? f[a] / sum_minor : f[a], pb = rescale ? f[b] / sum_minor : f[b];
+          minor_het += (1.0 - F) * 2.0 * pa * pb;
+        }
+      double major_hom = (F * major) + ((1.0 - F) * major * major);
+      for (uint32_t a = 0; a < n; ++a) { const double p = rescale ? f[a] / sum_minor : f[a]; major_het += (1.0 - F) * 2.0 * major * p; }
+      minor_hom = minor_hom > 0.0 ? minor_hom : 0.0; minor_het = minor_het > 0.0 ? minor_het : 0.0;
+      major_hom = major_hom > 0.0 ? major_hom : 0.0; major_het = major_het > 0.0 ? major_het : 0.0;
+      const double total_freq = major_hom + major_het + minor_hom + minor_het;
+      minor_hom /= total_freq; minor_het /= total_freq; major_hom /= total_freq; major_het /= total_freq;
+      const kgx_u32x4 r = kgx_philox4x32_10(static_cast<uint32_t>(l), static_cast<uint32_t>(l >> 32), static_cast<uint32_t>(g), 5u,
+                                            static_cast<uint32_t>(seed), static_cast<uint32_t>(seed >> 32));
+      const double u_class = kgx_u01(r.v[0]), u_allele = kgx_u01(r.v[1]);
+      double cum = minor_hom;
+      if (u_class <= cum) {                                   // MINOR_HOMOZYGOUS
+        if (minor_hom != 0.0) {
+          if (n == 1) a1 = a2 = alt_of[0];
+          else {
+            double s2 = 0.0;
+            for (uint32_t a = 0; a < n; ++a) {                // selectMinorHomozygous uses the un-rescaled frequencies
+              s2 += ((f[a] * F) + (1.0 - F) * f[a] * f[a]) / minor_hom;
+              if (u_allele <= s2) { a1 = a2 = alt_of[a]; break; }
+            }
+          }
+        }
+      } else if (u_class <= (cum += minor_het)) {             // MINOR_HETEROZYGOUS
+        if (n >= 2 && minor_het != 0.0) {
+          if (n == 2) { a1 = alt_of[0]; a2 = alt_of[1]; }
+          else {
+            double s2 = 0.0;
+            bool done = false;
+            for (uint32_t a = 0; a < n && !done; ++a)
+              for (uint32_t b = a + 1; b < n; ++b) {
+                s2 += ((1.0 - F) * 2.0 * f[a] * f[b]) / minor_het;
+                if (u_allele <= s2) { a1 = alt_of[a]; a2 = alt_of[b]; done = true; break; }
+              }
+          }
+        }
+      } else if (u_class <= (cum += major_hom)) {             // MAJOR_HOMOZYGOUS
+      } else if (u_class <= (cum += major_het)) {             // MAJOR_HETEROZYGOUS
+        if (major_het != 0.0) {
+          if (n == 1) a1 = alt_of[0];
+          else {
+            const double major_freq = clamp01(1.0 - clamp01(sum_minor));
+            double s2 = 0.0;
+            for (uint32_t a = 0; a < n; ++a) {
+              s2 += ((1.0 - F) * 2.0 * major_freq * f[a]) / major_het;
+              if (u_allele <= s2) { a1 = alt_of[a]; break; }
+            }
+          }
+          // the reference's RandomBoolean phase of the single carrier (_syngen.cpp:107-115) has no slot in gt8: the low
+          // nibble is the first variant of the OffsetDB array whatever its phase, and no estimator reads it
+        }
+      }
+    }
+    gt[l * pitch + g] = static_cast<uint8_t>(a1 | (a2 << 4));
   }
 }
 

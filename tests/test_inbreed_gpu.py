@@ -162,3 +162,106 @@ def test_c5_full_size_properties(kgx):
         else:
             assert np.allclose(part[name], res[name][4000:4100], rtol=1e-11, atol=0)
     m.close()
+
+
+def _f_grid():
+    # the reference's grid, built the way it builds it (kga_analysis_inbreed_syngen.cpp:44-56)
+    grid, f = [], -0.5
+    while f <= 0.5 + 0.000001:
+        grid.append(f)
+        f += 0.01
+    return np.array(grid, dtype=np.float64)
+
+
+def test_synth_inbred_draws_follow_class_frequencies(kgx):
+    """kgx_gt8_synth_inbred (InbreedSynthetic::generateSyntheticPopulation on the device): every genome's class
+    counts sit within sampling error of the sum of the oracle's class frequencies at that genome's F, the allele
+    picks follow the minor frequencies, and the estimators recover F (the reference's self-check)."""
+    rng = np.random.default_rng(23)
+    L, amax = 30000, 3
+    table = np.full((L, amax), np.nan)
+    table[:, 0] = rng.uniform(0.05, 0.4, L)
+    two = rng.random(L) < 0.4
+    table[two, 1] = rng.uniform(0.02, 0.2, int(two.sum()))
+    three = two & (rng.random(L) < 0.3)
+    table[three, 2] = rng.uniform(0.01, 0.1, int(three.sum()))
+    grid = _f_grid()
+    assert len(grid) == 101
+    gm = kgx.GenotypeMatrix(len(grid), L)
+    gm.synth_inbred(table, grid, seed=77)
+    rows = gm.read_rows()[:, :len(grid)]
+    a1, a2 = (rows & 0xF).astype(np.int64), (rows >> 4).astype(np.int64)
+    assert a1.max() <= amax and a2.max() <= amax
+    # no pick of an allele the locus does not have
+    n_alt = np.sum(~np.isnan(table), axis=1)
+    assert np.all(a1 <= n_alt[:, None]) and np.all(a2 <= n_alt[:, None])
+    cls = {
+        "major_hom": (a1 == 0) & (a2 == 0),
+        "major_het": (a1 == 0) != (a2 == 0),
+        "minor_hom": (a1 != 0) & (a1 == a2),
+        "minor_het": (a1 != 0) & (a2 != 0) & (a1 != a2),
+    }
+    order = ["major_hom", "major_het", "minor_hom", "minor_het"]
+    for g in range(0, len(grid), 10):
+        freqs = np.array([oa.class_frequencies(table[l][~np.isnan(table[l])], grid[g]) for l in range(0, L, 15)])
+        sub = slice(0, L, 15)
+        n = freqs.shape[0]
+        expect = freqs.sum(axis=0)
+        sigma = np.sqrt((freqs * (1 - freqs)).sum(axis=0)) + 1.0
+        got = np.array([cls[k][sub, g].sum() for k in order], dtype=np.float64)
+        assert got.sum() == n
+        assert np.all(np.abs(got - expect) < 5 * sigma), (g, grid[g], got, expect)
+    # a single carrier sits in the low nibble (gt8 has no phase slot for it)
+    assert not np.any((a1 == 0) & (a2 != 0))
+    # the reference's self-check through the device estimators
+    for algorithm, tol in (("Simple", 0.05), ("Loglikelihood", 0.05)):
+        res = gm.inbreed(table, algorithm, phased=True)
+        calc = res["inbred_allele_sum"]
+        slope, intercept = np.polyfit(grid, calc, 1)
+        assert slope > 0.9 and abs(intercept) < 0.02, (algorithm, slope, intercept)
+        mild = grid > -0.2          # strongly negative F clamps the minor-homozygous class at rare loci, which biases every estimator
+        assert np.abs(calc - grid)[mild].max() < tol, (algorithm, np.abs(calc - grid)[mild].max())
+        assert np.abs(calc - grid).max() < 0.15
+    # determinism and seed sensitivity
+    gm2 = kgx.GenotypeMatrix(len(grid), L)
+    gm2.synth_inbred(table, grid, seed=77)
+    assert np.array_equal(gm2.read_rows(), gm.read_rows())
+    gm2.synth_inbred(table, grid, seed=78)
+    assert not np.array_equal(gm2.read_rows(), gm.read_rows())
+
+
+@pytest.mark.parametrize("algorithm", ["Simple", "RitlandLocus", "HallME", "Loglikelihood"])
+@pytest.mark.parametrize("amax", [3, 6])
+def test_inbreed_survives_bytes_no_flattener_writes(kgx, algorithm, amax):
+    """Every one of the 256 byte values, valid or not, in every genome column: bytes the layout does not define
+    (second variant without a first, indices past the table) must be skipped by every sweep flavour, never read
+    through.  Checked against a numpy restatement of generateFrequencies' class decision."""
+    L, G = 512, 64
+    rng = np.random.default_rng(amax)
+    table = np.full((L, amax), np.nan)
+    table[:, 0] = rng.uniform(0.05, 0.3, L)
+    table[::2, 1] = rng.uniform(0.02, 0.2, L // 2)
+    rows = np.zeros((L, G), dtype=np.uint8)
+    for l in range(L):
+        rows[l] = (np.arange(G) * 4 + l * 7 + (np.arange(G) % 4)) & 0xFF     # all 256 values appear in every column
+    gm = kgx.GenotypeMatrix(G, L)
+    gm.load_rows(rows)
+    res = gm.inbreed(table, algorithm, phased=True)
+    a1, a2 = (rows & 0xF).astype(np.int64), (rows >> 4).astype(np.int64)
+    n_alt = amax
+    in1 = np.zeros_like(rows, dtype=bool)
+    in2 = np.zeros_like(rows, dtype=bool)
+    for a in range(1, n_alt + 1):
+        has = ~np.isnan(table[:, a - 1])[:, None]
+        in1 |= (a1 == a) & has
+        in2 |= (a2 == a) & has
+    bad = (a1 == 15) | (a2 == 15) | (a1 > n_alt) | (a2 > n_alt)
+    major_hom = rows == 0
+    major_het = ~bad & in1 & (a2 == 0)
+    minor_hom = ~bad & in1 & (a2 != 0) & (a1 == a2)
+    minor_het = ~bad & in1 & (a2 != 0) & (a1 != a2) & in2
+    assert np.array_equal(res["major_homo_count"], major_hom.sum(axis=0).astype(np.uint64))
+    assert np.array_equal(res["major_hetero_count"], major_het.sum(axis=0).astype(np.uint64))
+    assert np.array_equal(res["minor_homo_count"], minor_hom.sum(axis=0).astype(np.uint64))
+    assert np.array_equal(res["minor_hetero_count"], minor_het.sum(axis=0).astype(np.uint64))
+    assert np.all(np.isfinite(res["inbred_allele_sum"]))

@@ -145,3 +145,45 @@ def test_gpu_allele_package_reads_vcf_directly(tmp_path, kgx):
     want = opop.hethom(rec.contig)
     got = np.array([[int(r[2]), int(r[3]), int(r[4]), int(r[7]), int(r[8]), int(r[6]), int(r[5])] for r in rows], dtype=np.uint64)
     assert np.array_equal(got, want)
+
+
+@pytest.mark.parametrize("algorithm", ["Simple", "Loglikelihood"])
+def test_gpu_inbreed_package_synthetic_self_check(tmp_path, kgx, algorithm):
+    """AnalysisType=true: SyntheticAnalysis::syntheticInbreeding (kga_analysis_inbreed_synthetic.cpp:17-138) with the
+    synthetic genomes drawn on the device.  Only the reference (Gnomad) file is needed; the CSV has the layout of
+    InbreedingOutput::writeSynthetic and the estimates track the F each genome id encodes."""
+    L = 6000
+    rng = np.random.default_rng(3)
+    offsets = np.arange(1, L + 1, dtype=np.uint64) * 50
+    af = rng.uniform(0.05, 0.5, L).astype(np.float32)
+    rec = oa.Records("chr7", offsets, ["A"] * L, [["T"]] * L, af=[np.tile(np.float32(a), (1, 6)) for a in af])
+    ref_path = tmp_path / "gnomad.bin"
+    rio.write_records(ref_path, rec, None, ["Reference"], oa.Population.REFERENCE, "Gnomad2_1", population_id="Gnomad")
+    params = dict(AnalysisType="true", OutputFile="syn", Algorithm=algorithm, MinAlleleFreq=0.0, MaxAlleleFreq=1.0,
+                  LowerWindow=0, UpperWindow=L * 50 + 10, LociiCount=2000, SamplingDistance=50, SyntheticSeed=99)
+    res = rio.run_driver("GPU_INBREED", tmp_path, [ref_path], **params)
+    assert res.returncode == 0, res.stderr
+    lines = (tmp_path / "syn.csv").read_text().strip().split("\n")
+    assert lines[0].startswith("DriverParameters,Algorithm:" + algorithm)
+    assert lines[1] == "Sample,SynInbreed,CalcInbreed"
+    rows = [ln.split(",") for ln in lines[2:]]
+    # 101 genomes per super population (kgl_variant_db_freq.h:64-69 lists six, ALL included), ids as
+    # generateSyntheticGenomeId writes them (_syngen.cpp:202-222)
+    assert len(rows) == 101 * 6
+    by_sp = {}
+    for r in rows:
+        sp, code, counter = r[0].split("_")
+        f = -int(code[1:]) / 1e6 if code.startswith("N") else int(code) / 1e6
+        assert abs(float(r[1]) - f) < 1e-9                      # generateInbreeding decodes what the id encodes
+        assert abs(f - (-0.5 + 0.01 * int(counter))) < 2e-6
+        by_sp.setdefault(sp, []).append((f, [float(x) for x in r[2:] if x != ""]))
+    assert sorted(by_sp) == ["AFR", "ALL", "AMR", "EAS", "EUR", "SAS"]
+    for sp, vals in by_sp.items():
+        syn = np.array([v[0] for v in vals])
+        calc = np.array([v[1] for v in vals])
+        assert calc.shape[1] == 3        # one CalcInbreed per 2000-locus window of the 6000 loci
+        for c in range(calc.shape[1]):
+            slope, intercept = np.polyfit(syn, calc[:, c], 1)
+            assert slope > 0.8 and abs(intercept) < 0.05, (sp, c, slope, intercept)
+    # the two windows use different draws
+    assert not np.array_equal(calc[:, 0], calc[:, 1])
