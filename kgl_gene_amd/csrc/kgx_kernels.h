@@ -892,14 +892,31 @@ k_inbreed_sweep_fast(const uint32_t* __restrict__ gt, uint64_t dwords_per_row, u
 __device__ __forceinline__ uint32_t bytes_nonzero(uint32_t x) {   // x: bytes <= 0x0F -> 0x01 where byte != 0
   return ((x + 0x0F0F0F0Fu) >> 4) & 0x01010101u;
 }
-// Bit 0 of every byte that holds a nibble >= 8 (other bits: don't care).  This path's table has 8 entries (amax <= 6),
-// so allele indices 8..14 are past it, 15 is "unknown alt" and 0xFF ">= 3 variants": generateFrequencies skips the
-// cell in every one of those cases, whatever the other nibble holds.  The v_perm selectors are left unmasked: a
-// selector of 8..12 returns 0x00 (the LUT bytes have no sign bit) and 13..15 returns 0xFF, and every use of the
-// looked-up bytes is ANDed with a 0x01-per-byte mask that this kill bit has already cleared.
-__device__ __forceinline__ uint32_t bytes_wide_nibble(uint32_t x) {
-  const uint32_t t = x | (x >> 4);
-  return t >> 3;
+// The class decision of generateFrequencies (_freq.cpp:452-543) for the four genotype bytes of a dword at one locus.
+// All outputs are 0x01-per-byte masks.  LUT lookups are v_perm_b32 with the 3-bit nibbles as selectors:
+//   in-list LUT (lut_hi:lut_lo)  entry a = 1 if alt a is in the AlleleFreqVector (entries 0 and 7 are 0);
+//   "is zero" LUT {entry 0 = 1}  applied to the high nibble       -> no second variant;
+//   "same"    LUT {entry 0 = ph} applied to lo ^ hi               -> same variant on both phases (phased input only).
+// A nibble >= 8 is past this path's 8-entry table (amax <= 6), "unknown alt" (15) or ">= 3 variants" (0xFF): the
+// cell is skipped whatever the other nibble holds.  Bit 3 of either nibble clears ok1, and every class needs ok1, so
+// the aliasing of 8..15 onto 0..7 in the selectors never shows.
+struct SwarClasses {
+  uint32_t major_het, minor_hom, minor_het, nonzero;
+};
+__device__ __forceinline__ SwarClasses swar_classify(uint32_t x, uint32_t lut_lo, uint32_t lut_hi, uint32_t same_lut) {
+  const uint32_t xs = x >> 4;
+  const uint32_t lo = x & 0x07070707u, hi = xs & 0x07070707u;
+  const uint32_t t = x | xs;                                                     // low nibble of each byte: lo | hi
+  const uint32_t ok1 = __builtin_amdgcn_perm(lut_hi, lut_lo, lo) & ~(t >> 3);
+  const uint32_t ok2 = __builtin_amdgcn_perm(lut_hi, lut_lo, hi);
+  const uint32_t hom = __builtin_amdgcn_perm(0u, same_lut, lo ^ hi);             // homozygous(): same HGVS, different phase
+  const uint32_t single = __builtin_amdgcn_perm(0u, 1u, hi);
+  SwarClasses c;
+  c.major_het = ok1 & single;
+  c.minor_hom = ok1 & hom;
+  c.minor_het = (ok1 & ok2) ^ c.minor_hom;       // hom => ok2 == ok1; ok2 => a second variant (LUT entry 0 is 0)
+  c.nonzero = bytes_nonzero(t & 0x0F0F0F0Fu);
+  return c;
 }
 
 // locus_index and meta are padded by 8 entries past n_sel (whole batches are fetched with one scalar load each);
@@ -918,7 +935,7 @@ k_inbreed_sweep_swar(const uint32_t* __restrict__ gt, uint64_t dwords_per_row, u
   const uint64_t s_end = s_begin + loci_per_seg < n_sel ? s_begin + loci_per_seg : n_sel;
   const uint32_t stride = sweep_stride(amax);
   const uint64_t col = (g0 >> 2) + quad;
-  const uint32_t ph_mask = phased ? 0x01010101u : 0u;
+  const uint32_t same_lut = phased ? 1u : 0u;
 
   uint32_t b_major_het = 0, b_minor_hom = 0, b_minor_het = 0, b_miss = 0;     // 4 x 8-bit lanes
   uint32_t n_major_het[4] = {0, 0, 0, 0}, n_minor_hom[4] = {0, 0, 0, 0}, n_minor_het[4] = {0, 0, 0, 0}, n_miss[4] = {0, 0, 0, 0};
@@ -973,29 +990,21 @@ k_inbreed_sweep_swar(const uint32_t* __restrict__ gt, uint64_t dwords_per_row, u
       const uint32_t in_list = (m[i] >> 8) & 0xFFu;
       const uint32_t lut_lo = ((in_list >> 0) & 1u) | (((in_list >> 1) & 1u) << 8) | (((in_list >> 2) & 1u) << 16) | (((in_list >> 3) & 1u) << 24);
       const uint32_t lut_hi = ((in_list >> 4) & 1u) | (((in_list >> 5) & 1u) << 8) | (((in_list >> 6) & 1u) << 16);
-      const uint32_t def_mask = (f & kLocusDefault) ? 0x01010101u : 0u;
-      const uint32_t x = w[i];
-      const uint32_t lo = x & 0x0F0F0F0Fu, hi = (x >> 4) & 0x0F0F0F0Fu;
-      const uint32_t ok1 = __builtin_amdgcn_perm(lut_hi, lut_lo, lo) & ~bytes_wide_nibble(x);
-      const uint32_t ok2 = __builtin_amdgcn_perm(lut_hi, lut_lo, hi);
-      const uint32_t nz1 = bytes_nonzero(lo), nz2 = bytes_nonzero(hi);
-      const uint32_t same = bytes_nonzero(lo ^ hi) ^ 0x01010101u;
-      const uint32_t hom = same & ph_mask & nz2;
-      const uint32_t major_het = ok1 & (nz2 ^ 0x01010101u);
-      const uint32_t minor_hom = ok1 & hom;
-      const uint32_t minor_het = ok1 & ok2 & nz2 & (hom ^ 0x01010101u);
-      const uint32_t miss = (nz1 | nz2) & def_mask;
+      const bool is_default = (f & kLocusDefault) != 0;       // wave-uniform
+      const SwarClasses c = swar_classify(w[i], lut_lo, lut_hi, same_lut);
+      const uint32_t lo = w[i] & 0x07070707u;
+      const uint32_t major_het = c.major_het, minor_hom = c.minor_hom, minor_het = c.minor_het;
       b_major_het += major_het;
       b_minor_hom += minor_hom;
       b_minor_het += minor_het;
-      b_miss += miss;
+      if (is_default) b_miss += c.nonzero;
       if constexpr (RITLAND) {
         // processRitlandLocus (_calc.cpp:390-423): a homozygous cell enters only if its allele frequency > 0.001
         const uint32_t rit_bits = (m[i] >> 16) & 0xFFu;
         const uint32_t rit_lo = ((rit_bits >> 0) & 1u) | (((rit_bits >> 1) & 1u) << 8) | (((rit_bits >> 2) & 1u) << 16) | (((rit_bits >> 3) & 1u) << 24);
         const uint32_t rit_hi = ((rit_bits >> 4) & 1u) | (((rit_bits >> 5) & 1u) << 8) | (((rit_bits >> 6) & 1u) << 16);
         const uint32_t hom_counts = minor_hom & __builtin_amdgcn_perm(rit_hi, rit_lo, lo);
-        const uint32_t miss_rit = (nz1 | nz2) & ((f & kLocusRitlandDefault) ? 0x01010101u : 0u);
+        const uint32_t miss_rit = (f & kLocusRitlandDefault) ? c.nonzero : 0u;
         b_rit += hom_counts | major_het | minor_het;
         b_miss_rit += miss_rit;
         const double* row = table + s * stride;
@@ -1011,10 +1020,11 @@ k_inbreed_sweep_swar(const uint32_t* __restrict__ gt, uint64_t dwords_per_row, u
           s_inv[j] += ((hom_counts >> (8 * j)) & 1u) ? inv : 0.0;
         }
       }
-      const uint32_t rare = (nz1 | nz2) & (def_mask ^ (major_het | minor_hom | minor_het));
+      const uint32_t classed = major_het | minor_hom | minor_het;          // a subset of nonzero
+      const uint32_t rare = is_default ? (c.nonzero ^ classed) : classed;
       if (rare) {     // classification disagrees with the locus default: adjust the class-frequency sums
         const double* row = table + s * stride;
-        const double sign = def_mask ? -1.0 : 1.0;
+        const double sign = is_default ? -1.0 : 1.0;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           if (!((rare >> (8 * j)) & 1u)) continue;
@@ -1080,7 +1090,7 @@ k_inbreed_sweep_swar16(const kgx_v4u* __restrict__ gt, uint64_t chunks_per_row, 
   const uint64_t s_end = s_begin + loci_per_seg < n_sel ? s_begin + loci_per_seg : n_sel;
   const uint32_t stride = sweep_stride(amax);
   const uint64_t col = (g0 >> 4) + lane16;                 // g0 is a multiple of 16
-  const uint32_t ph_mask = phased ? 0x01010101u : 0u;
+  const uint32_t same_lut = phased ? 1u : 0u;
 
   uint32_t b_mhet[4] = {0, 0, 0, 0}, b_mhom[4] = {0, 0, 0, 0}, b_nhet[4] = {0, 0, 0, 0}, b_miss[4] = {0, 0, 0, 0};   // byte lanes
   // wide counters: [dword d][pair p] holds genomes 4d+p (low 16 bits) and 4d+p+2 (high 16 bits)
@@ -1132,31 +1142,27 @@ k_inbreed_sweep_swar16(const kgx_v4u* __restrict__ gt, uint64_t chunks_per_row, 
       const uint32_t in_list = (m[i] >> 8) & 0xFFu;
       const uint32_t lut_lo = ((in_list >> 0) & 1u) | (((in_list >> 1) & 1u) << 8) | (((in_list >> 2) & 1u) << 16) | (((in_list >> 3) & 1u) << 24);
       const uint32_t lut_hi = ((in_list >> 4) & 1u) | (((in_list >> 5) & 1u) << 8) | (((in_list >> 6) & 1u) << 16);
-      const uint32_t def_mask = (f & kLocusDefault) ? 0x01010101u : 0u;
+      const bool is_default = (f & kLocusDefault) != 0;       // wave-uniform
       uint32_t rare[4];
       uint32_t rare_any = 0;
 #pragma unroll
       for (int d = 0; d < 4; ++d) {
-        const uint32_t x = w[i][d];
-        const uint32_t lo = x & 0x0F0F0F0Fu, hi = (x >> 4) & 0x0F0F0F0Fu;
-        const uint32_t ok1 = __builtin_amdgcn_perm(lut_hi, lut_lo, lo) & ~bytes_wide_nibble(x);
-        const uint32_t ok2 = __builtin_amdgcn_perm(lut_hi, lut_lo, hi);
-        const uint32_t nz1 = bytes_nonzero(lo), nz2 = bytes_nonzero(hi);
-        const uint32_t same = bytes_nonzero(lo ^ hi) ^ 0x01010101u;
-        const uint32_t hom = same & ph_mask & nz2;
-        const uint32_t major_het = ok1 & (nz2 ^ 0x01010101u);
-        const uint32_t minor_hom = ok1 & hom;
-        const uint32_t minor_het = ok1 & ok2 & nz2 & (hom ^ 0x01010101u);
-        b_mhet[d] += major_het;
-        b_mhom[d] += minor_hom;
-        b_nhet[d] += minor_het;
-        b_miss[d] += (nz1 | nz2) & def_mask;
-        rare[d] = (nz1 | nz2) & (def_mask ^ (major_het | minor_hom | minor_het));
+        const SwarClasses c = swar_classify(w[i][d], lut_lo, lut_hi, same_lut);
+        b_mhet[d] += c.major_het;
+        b_mhom[d] += c.minor_hom;
+        b_nhet[d] += c.minor_het;
+        const uint32_t classed = c.major_het | c.minor_hom | c.minor_het;        // a subset of nonzero
+        if (is_default) {
+          b_miss[d] += c.nonzero;
+          rare[d] = c.nonzero ^ classed;
+        } else {
+          rare[d] = classed;
+        }
         rare_any |= rare[d];
       }
       if (rare_any) {
         const double* row = table + s * stride;
-        const double sign = def_mask ? -1.0 : 1.0;
+        const double sign = is_default ? -1.0 : 1.0;
 #pragma unroll
         for (int d = 0; d < 4; ++d) {
           if (!rare[d]) continue;

@@ -1,0 +1,56 @@
+"""Condense gpurun_out/prof_<tag>_aux/ (rocprofv3 output of scripts/profile_aux.sh) into profiles/<tag>_k3_kernel_stats.csv,
+profiles/<tag>_k5_kernel_stats.csv and profiles/<tag>_aux_summary.md.  Algorithmic bytes: K3 reads V*ceil(G/4) bytes of
+dosage2 per pass; K5 reads L*G bytes of gt8 plus the per-locus table (kgx_gt8_sweep_bytes)."""
+import csv, glob, re, sys
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent.parent
+tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+src = ROOT / "gpurun_out" / f"prof_{tag}_aux"
+dst = ROOT / "profiles"
+
+def stats(sub):
+    files = glob.glob(str(src / sub / "*" / "*kernel_stats.csv"))
+    if not files:
+        sys.exit(f"missing kernel_stats.csv under {src / sub}")
+    text = Path(files[0]).read_text()
+    (dst / f"{tag}_{sub}_kernel_stats.csv").write_text(text)
+    return list(csv.DictReader(text.splitlines()))
+
+def short(name):
+    name = re.sub(r"^void ", "", name)
+    return name.split("(")[0]
+
+def table(rows, alg_bytes, main):
+    out = ["| kernel | calls | avg ms | algorithmic GB/s |", "|---|---|---|---|"]
+    for r in rows:
+        ms = float(r["AverageNs"]) / 1e6
+        gbs = f"{alg_bytes / ms / 1e6:,.0f}" if any(m in r["Name"] for m in main) else ""
+        out.append(f"| `{short(r['Name'])}` | {r['Calls']} | {ms:.3f} | {gbs} |")
+    return "\n".join(out)
+
+G3, V3 = 10_000, 10_000_000
+k3_bytes = V3 * ((G3 + 3) // 4)
+k5_txt = (src / "k5.txt").read_text()
+m = re.search(r"algorithmic bytes per frequency sweep: ([0-9.]+) GB", k5_txt)
+k5_bytes = float(m.group(1)) * 1e9
+md = f"""# rocprofv3 kernel stats `{tag}` — secondary sweeps (scripts/profile_aux.sh, scripts/summarize_aux.py)
+
+## K3 by-genome sweep at C3 (10k x 10M; 3 x all rows + 2 x 11 FWS bins)
+
+{table(stats("k3"), k3_bytes, ["k_count_by_genome"])}
+
+```
+{(src / "k3.txt").read_text().strip()}
+```
+
+## K5 inbreeding sweep at C5 (10k x 5M multi-allelic; Simple then RitlandLocus)
+
+{table(stats("k5"), k5_bytes, ["k_inbreed_sweep"])}
+
+```
+{k5_txt.strip()}
+```
+"""
+(dst / f"{tag}_aux_summary.md").write_text(md)
+print(md)
