@@ -196,6 +196,10 @@ int kgx_locus_class_frequencies(const double* minor_af, uint64_t n_loci, uint32_
  * phases (1000-Genomes style); algorithm = KGX_ALGO_*.  out[g1-g0]. */
 int kgx_inbreed(kgx_gt8* gt, uint64_t g0, uint64_t g1, const uint32_t* locus_index, uint64_t n_selected,
                 const double* minor_af, uint32_t amax, int phased, int algorithm, kgx_locus_results* out);
+/* Device time (HIP events on the library stream) of the frequency sweep -- locus helpers + the K5 kernel, i.e. the one
+ * pass over the genotype bytes that every estimator makes -- of the most recent successful kgx_inbreed call on this
+ * process; 0 before the first.  For bench.py / profiles: algorithmic bytes = kgx_gt8_sweep_bytes(). */
+double kgx_inbreed_last_sweep_ms(void);
 
 /* Synthetic multi-allelic SNP+indel population (BASELINE.json configs[4]) written straight into
  * the matrix: 1/2/3 alts (70/20/10 %), 15 % of alts are indels, AFs rescaled to sum <= 0.6, genotypes drawn from

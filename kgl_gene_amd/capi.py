@@ -72,6 +72,7 @@ _SIGNATURES = {
     "kgx_locus_class_frequencies": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint32, C.c_double, C.c_void_p, C.c_void_p]),
     "kgx_inbreed": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint32, C.c_int,
                               C.c_int, C.c_void_p]),
+    "kgx_inbreed_last_sweep_ms": (C.c_double, []),
     "kgx_gt8_synth_multiallelic": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64, C.c_void_p]),
     "kgx_synth_multiallelic_host": (C.c_int, [C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64, C.c_void_p, C.c_uint64,
                                               C.c_void_p, C.c_void_p]),
@@ -387,6 +388,11 @@ class GenotypeMatrix:
         check(lib().kgx_inbreed(self._h, g0, g1, None if idx is None else ptr(idx), n_sel, ptr(a), amax, int(bool(phased)),
                                 ALGORITHMS[algorithm], ptr(out)))
         return out
+
+
+def inbreed_last_sweep_ms() -> float:
+    """Device time of the frequency sweep of the most recent GenotypeMatrix.inbreed call (HIP events)."""
+    return float(lib().kgx_inbreed_last_sweep_ms())
 
 
 def synth_multiallelic_host(seed: int, genome_base: int, n_genomes: int, l0: int, l1: int):

@@ -749,9 +749,11 @@ int kgx_inbreed(kgx_gt8* h, uint64_t g0, uint64_t g1, const uint32_t* locus_inde
   // the estimator needs no Ritland terms; otherwise 4 genomes per lane.
   const bool swar16 = !env_int("KGX_K5_GENERIC", 0) && !env_int("KGX_K5_NO_SWAR16", 0) && amax <= 4 && (g0 & 15u) == 0 &&
                       algorithm != KGX_ALGO_RITLAND_LOCUS;
+  // The evaluation passes of HallME / Loglikelihood go through the per-batch LDS tables when the allele indices fit them.
+  const bool eval_lut = !env_int("KGX_K5_GENERIC", 0) && !env_int("KGX_K5_NO_EVAL_LUT", 0) && amax <= 7;
   const uint32_t gx = static_cast<uint32_t>(((n + 3) / 4 + kBlock - 1) / kBlock);
   const uint32_t gx16 = static_cast<uint32_t>(((n + 15) / 16 + kBlock - 1) / kBlock);
-  uint64_t n_seg = (static_cast<uint64_t>(g_state.compute_units) * 8 + (swar16 ? gx16 : gx) - 1) / (swar16 ? gx16 : gx);
+  uint64_t n_seg = (static_cast<uint64_t>(g_state.compute_units) * env_int("KGX_K5_BLOCKS_PER_CU", 8) + (swar16 ? gx16 : gx) - 1) / (swar16 ? gx16 : gx);
   if (n_seg > (n_sel + 63) / 64) n_seg = (n_sel + 63) / 64;
   if (n_seg < (n_sel + 65534) / 65535) n_seg = (n_sel + 65534) / 65535;   // 16-bit class counters per segment
   if (n_seg < 1) n_seg = 1;
@@ -850,6 +852,13 @@ int kgx_inbreed(kgx_gt8* h, uint64_t g0, uint64_t g1, const uint32_t* locus_inde
                                d_table, d_meta, amax, phased, d_segdef, d_counts, d_part);
         }
       }
+    } else if (eval_lut) {
+      if (mode == 1)
+        hipLaunchKernelGGL((k_inbreed_eval_lut<1>), grid, dim3(kBlock), 0, st, gt32, dwords_per_row, g0, n, d_index, n_sel, per_seg, d_table,
+                           d_valid, amax, phased, d_f, d_part);
+      else
+        hipLaunchKernelGGL((k_inbreed_eval_lut<2>), grid, dim3(kBlock), 0, st, gt32, dwords_per_row, g0, n, d_index, n_sel, per_seg, d_table,
+                           d_valid, amax, phased, d_f, d_part);
     } else if (mode == 1)
       hipLaunchKernelGGL((k_inbreed_sweep<1>), grid, dim3(kBlock), 0, st, gt32, dwords_per_row, g0, n, d_index, n_sel, per_seg, d_table,
                          d_valid, amax, phased, d_f, d_counts, d_part);
@@ -860,7 +869,13 @@ int kgx_inbreed(kgx_gt8* h, uint64_t g0, uint64_t g1, const uint32_t* locus_inde
   const uint32_t lin_grid = stream_grid(n, kBlock);
   if (rc == KGX_OK) {
     if (n_sel) hipLaunchKernelGGL((k_locus_tables<true>), dim3(stream_grid(n_sel, kBlock)), dim3(kBlock), 0, st, d_af, n_sel, amax, 0.0, d_table, d_valid);
+    if (!g_state.sweep_begin) {
+      try_hip(hipEventCreate(&g_state.sweep_begin), KGX_EHIP, "hipEventCreate");
+      try_hip(hipEventCreate(&g_state.sweep_end), KGX_EHIP, "hipEventCreate");
+    }
+    if (rc == KGX_OK) try_hip(hipEventRecord(g_state.sweep_begin, st), KGX_EHIP, "hipEventRecord");
     sweep(0);
+    if (rc == KGX_OK) try_hip(hipEventRecord(g_state.sweep_end, st), KGX_EHIP, "hipEventRecord");
     hipLaunchKernelGGL(k_reduce_parts, dim3(stream_grid(n * kParts0, kBlock)), dim3(kBlock), 0, st, d_part, n_seg, n * kParts0, d_sums);
     if (algorithm == 2) {
       // processHallME (_calc.cpp:225-307).  The reference restarts from U(0,0.5] and, through RetryCalcResult's
@@ -908,6 +923,10 @@ int kgx_inbreed(kgx_gt8* h, uint64_t g0, uint64_t g1, const uint32_t* locus_inde
     try_hip(hipGetLastError(), KGX_EHIP, "kernel launch");
     try_hip(hipMemcpyAsync(out, d_out, n * sizeof(LocusResultsDev), hipMemcpyDeviceToHost, st), KGX_EHIP, "D2H(out)");
     try_hip(hipStreamSynchronize(st), KGX_EHIP, "stream synchronize");
+    if (rc == KGX_OK) {
+      float ms = 0.f;
+      if (hipEventElapsedTime(&ms, g_state.sweep_begin, g_state.sweep_end) == hipSuccess) g_state.last_sweep_ms = ms;
+    }
   }
   for (void* p : {static_cast<void*>(d_af), static_cast<void*>(d_table), static_cast<void*>(d_valid), static_cast<void*>(d_part),
                   static_cast<void*>(d_sums), static_cast<void*>(d_counts), static_cast<void*>(d_f), static_cast<void*>(d_eval),
@@ -915,6 +934,8 @@ int kgx_inbreed(kgx_gt8* h, uint64_t g0, uint64_t g1, const uint32_t* locus_inde
     if (p) (void)hipFree(p);
   return rc;
 }
+
+double kgx_inbreed_last_sweep_ms(void) { return g_state.last_sweep_ms; }
 
 int kgx_gt8_synth_multiallelic(kgx_gt8* h, uint64_t seed, uint64_t genome_base, uint64_t locus_base, double* af_table) {
   if (int rc = require_device()) return rc;

@@ -35,6 +35,8 @@ struct State {
   hipStream_t stream = nullptr;
   char name[128] = {0};
   char arch[64] = {0};
+  hipEvent_t sweep_begin = nullptr, sweep_end = nullptr;   // bracket the frequency sweep of the last kgx_inbreed call
+  double last_sweep_ms = 0.0;
 };
 
 extern State g_state;

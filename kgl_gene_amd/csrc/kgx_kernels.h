@@ -696,6 +696,134 @@ k_inbreed_sweep(const uint32_t* __restrict__ gt, uint64_t dwords_per_row, uint64
   }
 }
 
+// K5 evaluation passes (MODE 1: one Hall expectation step; MODE 2: the log-likelihood at F) for amax <= 7, the passes
+// HallME runs 50 times and Loglikelihood ~40 times per call.  What a cell contributes depends only on (locus, byte
+// value, F of the genome), so per batch of 8 loci the block first tabulates, in LDS, a pair (x, y) for each of the
+// 128 values of (byte & 0x7F) -- classify_cell decides every entry, so the class logic is the generic kernel's own --
+// and each cell is then one LDS read and a handful of fp64 operations:
+//   MODE 2  prob = F*x + (1-F)*y   hom: (f1, f1*f1)  het: (0, 2*f1*f2)  unclassified: (1, 1) -> prob 1
+//           (logLikelihood, _calc.cpp:94-129: F*f + (1-F)*f*f and 2*(1-F)*f1*f2, clamped to [1e-10, 1]).  The clamped
+//           probabilities of a batch are multiplied, the exponent of the running product is peeled off into an integer
+//           after every batch, and ONE log per (segment, genome) is taken at the end: sum(log p) = log(prod p).
+//   MODE 1  hom: (1, f1): den = F + (1-F)*f1, term F/den (processHallME, _calc.cpp:255-285); else (0, 1): no term.
+//           The batch's terms are summed as one fraction N/D (N <- N*den + D, D <- D*den), one division per batch.
+// Bit 7 of the byte (second allele index >= 8) is folded onto bit 3, and every entry with bit 3 set is "unclassified".
+// 4 genomes per lane as in k_inbreed_sweep; the whole block takes part in the table build, so no early return.
+struct alignas(16) EvalEntry { double x, y; };
+constexpr int kEvalBatch = 8;
+
+template <int MODE>
+__device__ __forceinline__ void build_eval_table(EvalEntry* __restrict__ lut, uint64_t s0, uint64_t s_end,
+                                                 const double* __restrict__ table, const uint8_t* __restrict__ valid,
+                                                 uint32_t stride, uint32_t amax, bool phased) {
+  for (uint32_t e = threadIdx.x; e < kEvalBatch * 128u; e += kBlock) {
+    const uint64_t s = s0 + (e >> 7);
+    const uint32_t idx = e & 127u;
+    double x = MODE == 2 ? 1.0 : 0.0, y = 1.0;
+    if (s < s_end && !(idx & 8u) && (valid[s] & kLocusValid)) {
+      double f1 = 0.0, f2 = 0.0;
+      const int cls = classify_cell(idx, table + s * stride, amax, phased, f1, f2);
+      if (cls == kMajorHom || cls == kMinorHom) {
+        if constexpr (MODE == 2) { x = f1; y = f1 * f1; }
+        else { x = 1.0; y = f1; }
+      } else if (cls != kClassNone) {
+        if constexpr (MODE == 2) { x = 0.0; y = 2.0 * f1 * f2; }
+      }
+    }
+    lut[e].x = x;
+    lut[e].y = y;
+  }
+}
+
+template <int MODE>
+__global__ void __launch_bounds__(kBlock)
+k_inbreed_eval_lut(const uint32_t* __restrict__ gt, uint64_t dwords_per_row, uint64_t g0, uint64_t n_genomes,
+                   const uint32_t* __restrict__ locus_index, uint64_t n_sel, uint64_t loci_per_seg,
+                   const double* __restrict__ table, const uint8_t* __restrict__ valid, uint32_t amax, int phased,
+                   const double* __restrict__ f_in, double* __restrict__ part) {
+  __shared__ EvalEntry lut[2][kEvalBatch * 128];
+  const uint64_t quad = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  const bool active = quad * 4 < n_genomes;
+  const uint64_t seg = blockIdx.y;
+  const uint64_t s_begin = seg * loci_per_seg;
+  const uint64_t s_end = s_begin + loci_per_seg < n_sel ? s_begin + loci_per_seg : n_sel;
+  const uint32_t stride = sweep_stride(amax);
+  const uint64_t col = (g0 >> 2) + quad;
+
+  double F[4], omF[4], acc[4], run_a[4], run_b[4];   // MODE 2: run_a = product, run_b unused; MODE 1: run_a = N, run_b = D
+  int expo[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const uint64_t g = quad * 4 + j;
+    F[j] = g < n_genomes ? f_in[g] : 0.0;
+    omF[j] = 1.0 - F[j];
+    acc[j] = 0.0;
+    run_a[j] = MODE == 2 ? 1.0 : 0.0;
+    run_b[j] = 1.0;
+    expo[j] = 0;
+  }
+
+  if (s_begin < s_end) build_eval_table<MODE>(lut[0], s_begin, s_end, table, valid, stride, amax, phased != 0);
+  __syncthreads();
+  int buf = 0;
+  for (uint64_t s0 = s_begin; s0 < s_end; s0 += kEvalBatch, buf ^= 1) {
+    uint32_t w[kEvalBatch];
+#pragma unroll
+    for (int i = 0; i < kEvalBatch; ++i) {
+      const uint64_t s = s0 + i;
+      uint32_t x = 0x08080808u;                            // past the segment: unclassified
+      if (active && s < s_end) {
+        const uint64_t l = locus_index ? static_cast<uint64_t>(locus_index[s]) : s;
+        x = __builtin_nontemporal_load(gt + l * dwords_per_row + col);
+      }
+      w[i] = x;
+    }
+    if (s0 + kEvalBatch < s_end) build_eval_table<MODE>(lut[buf ^ 1], s0 + kEvalBatch, s_end, table, valid, stride, amax, phased != 0);
+    if (active) {
+      const EvalEntry* __restrict__ cur = lut[buf];
+#pragma unroll
+      for (int i = 0; i < kEvalBatch; ++i) {
+        const uint32_t xf = w[i] | ((w[i] & 0x80808080u) >> 4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const EvalEntry e = cur[i * 128 + ((xf >> (8 * j)) & 0x7Fu)];
+          const double v = F[j] * e.x + omF[j] * e.y;      // MODE 2: the cell's probability; MODE 1: its denominator
+          if constexpr (MODE == 2) {
+            const double prob = v < 1e-10 ? 1e-10 : (v > 1.0 ? 1.0 : v);
+            run_a[j] *= prob;
+          } else {
+            const bool term = e.x != 0.0 && v != 0;         // a homozygous cell with a usable denominator (:272)
+            const double den = term ? v : 1.0;
+            run_a[j] = run_a[j] * den + (term ? run_b[j] : 0.0);
+            run_b[j] *= den;
+          }
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        if constexpr (MODE == 2) {                          // 8 factors >= 1e-10: no underflow before the exponent is peeled
+          expo[j] += __builtin_amdgcn_frexp_exp(run_a[j]);
+          run_a[j] = __builtin_amdgcn_frexp_mant(run_a[j]);
+        } else {
+          acc[j] += F[j] * (run_a[j] / run_b[j]);
+          run_a[j] = 0.0;
+          run_b[j] = 1.0;
+        }
+      }
+    }
+    __syncthreads();
+  }
+
+  if (!active) return;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const uint64_t g = quad * 4 + j;
+    if (g >= n_genomes) continue;
+    if constexpr (MODE == 2) part[seg * n_genomes + g] = log(run_a[j]) + static_cast<double>(expo[j]) * 0.6931471805599453;
+    else part[seg * n_genomes + g] = acc[j];
+  }
+}
+
 // Per-segment totals of what a genome that is reference-homozygous at EVERY locus of the segment would collect:
 // def[seg] = { sum majorHom cf, sum majorHet cf, sum minorHom cf, sum minorHet cf, Ritland sum, #default loci,
 // #Ritland-default loci, 0 }.  One wave per segment; lanes stride the loci, then a wave reduction.
