@@ -52,7 +52,8 @@ def build_kgx(force: bool = False, verbose: bool = False) -> Path:
     LIBDIR.mkdir(parents=True, exist_ok=True)
     if not force and not _stale(LIBKGX, _deps()):
         return LIBKGX
-    cmd = [HIPCC, *HIP_FLAGS, "-I", str(ROOT / "include"), "-o", str(LIBKGX), *map(str, _sources())]
+    extra = os.environ.get("KGX_HIPCC_FLAGS", "").split()   # experiments only (e.g. -DKGX_EXP_...); the default build has none
+    cmd = [HIPCC, *HIP_FLAGS, *extra, "-I", str(ROOT / "include"), "-o", str(LIBKGX), *map(str, _sources())]
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     subprocess.run(cmd, check=True, cwd=str(ROOT))

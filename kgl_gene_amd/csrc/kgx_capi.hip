@@ -751,6 +751,9 @@ int kgx_inbreed(kgx_gt8* h, uint64_t g0, uint64_t g1, const uint32_t* locus_inde
                       algorithm != KGX_ALGO_RITLAND_LOCUS;
   // The evaluation passes of HallME / Loglikelihood go through the per-batch LDS tables when the allele indices fit them.
   const bool eval_lut = !env_int("KGX_K5_GENERIC", 0) && !env_int("KGX_K5_NO_EVAL_LUT", 0) && amax <= 7;
+  int eval_gpl = env_int("KGX_K5_EVAL_GPL", 8);            // genomes per lane: the widest load the group's alignment allows
+  if (eval_gpl != 4 && eval_gpl != 8 && eval_gpl != 16) eval_gpl = 8;
+  while (eval_gpl > 4 && (g0 % static_cast<uint64_t>(eval_gpl)) != 0) eval_gpl /= 2;
   const uint32_t gx = static_cast<uint32_t>(((n + 3) / 4 + kBlock - 1) / kBlock);
   const uint32_t gx16 = static_cast<uint32_t>(((n + 15) / 16 + kBlock - 1) / kBlock);
   uint64_t n_seg = (static_cast<uint64_t>(g_state.compute_units) * env_int("KGX_K5_BLOCKS_PER_CU", 8) + (swar16 ? gx16 : gx) - 1) / (swar16 ? gx16 : gx);
@@ -853,12 +856,16 @@ int kgx_inbreed(kgx_gt8* h, uint64_t g0, uint64_t g1, const uint32_t* locus_inde
         }
       }
     } else if (eval_lut) {
-      if (mode == 1)
-        hipLaunchKernelGGL((k_inbreed_eval_lut<1>), grid, dim3(kBlock), 0, st, gt32, dwords_per_row, g0, n, d_index, n_sel, per_seg, d_table,
-                           d_valid, amax, phased, d_f, d_part);
-      else
-        hipLaunchKernelGGL((k_inbreed_eval_lut<2>), grid, dim3(kBlock), 0, st, gt32, dwords_per_row, g0, n, d_index, n_sel, per_seg, d_table,
-                           d_valid, amax, phased, d_f, d_part);
+      const dim3 grid_eval(static_cast<uint32_t>(((n + eval_gpl - 1) / eval_gpl + kBlock - 1) / kBlock), static_cast<uint32_t>(n_seg));
+#define KGX_EVAL(M, W)                                                                                                            \
+  hipLaunchKernelGGL((k_inbreed_eval_lut<M, W>), grid_eval, dim3(kBlock), 0, st, gt32, dwords_per_row, g0, n, d_index, n_sel, per_seg, \
+                     d_table, d_valid, amax, phased, d_f, d_part)
+      if (mode == 1) {
+        if (eval_gpl == 16) KGX_EVAL(1, 16); else if (eval_gpl == 8) KGX_EVAL(1, 8); else KGX_EVAL(1, 4);
+      } else {
+        if (eval_gpl == 16) KGX_EVAL(2, 16); else if (eval_gpl == 8) KGX_EVAL(2, 8); else KGX_EVAL(2, 4);
+      }
+#undef KGX_EVAL
     } else if (mode == 1)
       hipLaunchKernelGGL((k_inbreed_sweep<1>), grid, dim3(kBlock), 0, st, gt32, dwords_per_row, g0, n, d_index, n_sel, per_seg, d_table,
                          d_valid, amax, phased, d_f, d_counts, d_part);
@@ -882,19 +889,22 @@ int kgx_inbreed(kgx_gt8* h, uint64_t g0, uint64_t g1, const uint32_t* locus_inde
       // self-comparison, always stops after 5 restarts of exactly 50 expectation steps, keeping the last; the
       // fixed start 0.25 (the mean of its start distribution) replaces the random draw.
       std::vector<double> f0(n, 0.25);
+      // locus slots every lane of k_inbreed_eval_lut walks: whole batches of 8 in every segment
+      const unsigned long long walked = eval_lut && n_sel ? (n_seg - 1) * per_seg + (n_sel - (n_seg - 1) * per_seg + 7) / 8 * 8 : 0ull;
       try_hip(hipMemcpyAsync(d_f, f0.data(), n * sizeof(double), hipMemcpyHostToDevice, st), KGX_EHIP, "H2D(f0)");
       try_hip(hipStreamSynchronize(st), KGX_EHIP, "sync");
       for (int it = 0; it < 50 && rc == KGX_OK; ++it) {
         sweep(1);
         hipLaunchKernelGGL(k_reduce_parts, dim3(lin_grid), dim3(kBlock), 0, st, d_part, n_seg, n, d_eval);
-        hipLaunchKernelGGL(k_hall_update, dim3(lin_grid), dim3(kBlock), 0, st, d_eval, d_counts, n, d_f);
+        hipLaunchKernelGGL(k_hall_update, dim3(lin_grid), dim3(kBlock), 0, st, d_eval, d_counts, n, walked, d_f);
       }
     } else if (algorithm == 3) {
       // processLogLikelihood (_calc.cpp:153-216): maximise over [-1,1].  The objective is a sum of logs of
       // clamped linear functions of F; a golden-section search on that same clamped objective replaces nlopt's
-      // Nelder-Mead (un-vendored, unpinned), to 1e-8 in F where the reference asks for 1e-6.
+      // Nelder-Mead (un-vendored, unpinned), to a 6e-8 bracket in F where the reference asks for 1e-6.
       try_hip(hipMalloc(&d_golden, n * sizeof(GoldenState)), KGX_ENOMEM, "hipMalloc(golden)");
       const double inv_phi = 0.6180339887498949;
+      constexpr int kGoldenSteps = 38;     // bracket 2 * 0.618^36 = 6e-8 after the two start-up evaluations
       GoldenState init;
       init.a = -1.0; init.b = 1.0;
       init.c = init.b - inv_phi * (init.b - init.a);
@@ -905,7 +915,7 @@ int kgx_inbreed(kgx_gt8* h, uint64_t g0, uint64_t g1, const uint32_t* locus_inde
       try_hip(hipMemcpyAsync(d_golden, gs.data(), n * sizeof(GoldenState), hipMemcpyHostToDevice, st), KGX_EHIP, "H2D(golden)");
       try_hip(hipMemcpyAsync(d_f, f0.data(), n * sizeof(double), hipMemcpyHostToDevice, st), KGX_EHIP, "H2D(f0)");
       try_hip(hipStreamSynchronize(st), KGX_EHIP, "sync");
-      for (int it = 0; it < 42 && rc == KGX_OK; ++it) {
+      for (int it = 0; it < kGoldenSteps && rc == KGX_OK; ++it) {
         sweep(2);
         hipLaunchKernelGGL(k_reduce_parts, dim3(lin_grid), dim3(kBlock), 0, st, d_part, n_seg, n, d_eval);
         hipLaunchKernelGGL(k_golden_step, dim3(lin_grid), dim3(kBlock), 0, st, d_golden, d_eval, n, it < 2 ? it : 2, d_f);

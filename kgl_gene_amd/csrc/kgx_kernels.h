@@ -698,114 +698,145 @@ k_inbreed_sweep(const uint32_t* __restrict__ gt, uint64_t dwords_per_row, uint64
 
 // K5 evaluation passes (MODE 1: one Hall expectation step; MODE 2: the log-likelihood at F) for amax <= 7, the passes
 // HallME runs 50 times and Loglikelihood ~40 times per call.  What a cell contributes depends only on (locus, byte
-// value, F of the genome), so per batch of 8 loci the block first tabulates, in LDS, a pair (x, y) for each of the
+// value, F of the genome), so per batch of 8 loci the block first tabulates, in LDS, a pair (y, d) for each of the
 // 128 values of (byte & 0x7F) -- classify_cell decides every entry, so the class logic is the generic kernel's own --
-// and each cell is then one LDS read and a handful of fp64 operations:
-//   MODE 2  prob = F*x + (1-F)*y   hom: (f1, f1*f1)  het: (0, 2*f1*f2)  unclassified: (1, 1) -> prob 1
-//           (logLikelihood, _calc.cpp:94-129: F*f + (1-F)*f*f and 2*(1-F)*f1*f2, clamped to [1e-10, 1]).  The clamped
-//           probabilities of a batch are multiplied, the exponent of the running product is peeled off into an integer
-//           after every batch, and ONE log per (segment, genome) is taken at the end: sum(log p) = log(prod p).
-//   MODE 1  hom: (1, f1): den = F + (1-F)*f1, term F/den (processHallME, _calc.cpp:255-285); else (0, 1): no term.
-//           The batch's terms are summed as one fraction N/D (N <- N*den + D, D <- D*den), one division per batch.
+// and each cell is then one LDS read, one fma  v = y + F*d  and a few more fp64 operations:
+//   MODE 2  v = the cell's probability.  hom: y = f1*f1, d = f1 - f1*f1   (F*f + (1-F)*f*f,  _calc.cpp:94-129)
+//                                        het: y = 2*f1*f2, d = -y         (2*(1-F)*f1*f2)
+//                                        unclassified: (1, 0) -> probability 1, log 0.
+//           The probabilities, clamped to [1e-10, 1] as the reference clamps them, are multiplied across the batch, the
+//           exponent of the running product is peeled off into an integer after every batch, and ONE log per
+//           (segment, genome) is taken at the end: sum(log p) = log(prod p).
+//   MODE 1  v = the denominator F + (1-F)*f1 of a homozygous cell: y = f1, d = 1 - f1; every other cell (1, 0), i.e.
+//           v = 1 exactly.  The terms 1/v of ALL cells of a batch are summed as one fraction N/D (N <- N*v + D,
+//           D <- D*v; one division per batch), so part[] holds  sum_hom 1/v + #(other cells the lane walked);
+//           k_hall_update subtracts that count (it is known: loci walked - homozygous cells counted by the frequency
+//           sweep) and multiplies by F.  The reference's zero-denominator guard (_calc.cpp:272) can only fire at
+//           F = 0, where every term F/v is 0: such a genome is walked with F = 1 (v = 1 everywhere) and the
+//           multiplication by its F = 0 happens in k_hall_update.
 // Bit 7 of the byte (second allele index >= 8) is folded onto bit 3, and every entry with bit 3 set is "unclassified".
-// 4 genomes per lane as in k_inbreed_sweep; the whole block takes part in the table build, so no early return.
-struct alignas(16) EvalEntry { double x, y; };
+// GPL genomes per lane (4, 8 or 16: one dword / dwordx2 / dwordx4 load per locus); the whole block takes part in the
+// table build, so there is no early return.
+struct alignas(16) EvalEntry { double y, d; };
 constexpr int kEvalBatch = 8;
 
+// Only the (amax+1)^2 entries whose two allele indices are <= amax can ever be classified; the rest of the 128 are
+// written "unclassified" once, before the first batch, and never touched again.
 template <int MODE>
 __device__ __forceinline__ void build_eval_table(EvalEntry* __restrict__ lut, uint64_t s0, uint64_t s_end,
                                                  const double* __restrict__ table, const uint8_t* __restrict__ valid,
                                                  uint32_t stride, uint32_t amax, bool phased) {
-  for (uint32_t e = threadIdx.x; e < kEvalBatch * 128u; e += kBlock) {
-    const uint64_t s = s0 + (e >> 7);
-    const uint32_t idx = e & 127u;
-    double x = MODE == 2 ? 1.0 : 0.0, y = 1.0;
-    if (s < s_end && !(idx & 8u) && (valid[s] & kLocusValid)) {
+  for (uint32_t e = threadIdx.x; e < kEvalBatch * 64u; e += kBlock) {
+    const uint32_t a1 = e & 7u, a2 = (e >> 3) & 7u;
+    if (a1 > amax || a2 > amax) continue;
+    const uint64_t s = s0 + (e >> 6);
+    double y = 1.0, d = 0.0;
+    if (s < s_end && (valid[s] & kLocusValid)) {
       double f1 = 0.0, f2 = 0.0;
-      const int cls = classify_cell(idx, table + s * stride, amax, phased, f1, f2);
+      const int cls = classify_cell(a1 | (a2 << 4), table + s * stride, amax, phased, f1, f2);
       if (cls == kMajorHom || cls == kMinorHom) {
-        if constexpr (MODE == 2) { x = f1; y = f1 * f1; }
-        else { x = 1.0; y = f1; }
+        if constexpr (MODE == 2) { y = f1 * f1; d = f1 - y; }
+        else { y = f1; d = 1.0 - f1; }
       } else if (cls != kClassNone) {
-        if constexpr (MODE == 2) { x = 0.0; y = 2.0 * f1 * f2; }
+        if constexpr (MODE == 2) { y = 2.0 * f1 * f2; d = -y; }
       }
     }
-    lut[e].x = x;
-    lut[e].y = y;
+    EvalEntry* slot = lut + (e >> 6) * 128u + (a1 | (a2 << 4));
+    slot->y = y;
+    slot->d = d;
   }
 }
 
-template <int MODE>
+template <int MODE, int GPL>
 __global__ void __launch_bounds__(kBlock)
 k_inbreed_eval_lut(const uint32_t* __restrict__ gt, uint64_t dwords_per_row, uint64_t g0, uint64_t n_genomes,
                    const uint32_t* __restrict__ locus_index, uint64_t n_sel, uint64_t loci_per_seg,
                    const double* __restrict__ table, const uint8_t* __restrict__ valid, uint32_t amax, int phased,
                    const double* __restrict__ f_in, double* __restrict__ part) {
+  constexpr int DW = GPL / 4;
   __shared__ EvalEntry lut[2][kEvalBatch * 128];
-  const uint64_t quad = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
-  const bool active = quad * 4 < n_genomes;
+  const uint64_t lane = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x;   // genomes g0 + GPL*lane ..
+  const bool active = lane * GPL < n_genomes;
   const uint64_t seg = blockIdx.y;
   const uint64_t s_begin = seg * loci_per_seg;
   const uint64_t s_end = s_begin + loci_per_seg < n_sel ? s_begin + loci_per_seg : n_sel;
   const uint32_t stride = sweep_stride(amax);
-  const uint64_t col = (g0 >> 2) + quad;
+  const uint64_t col = (g0 >> 2) + lane * DW;              // g0 is a multiple of GPL
 
-  double F[4], omF[4], acc[4], run_a[4], run_b[4];   // MODE 2: run_a = product, run_b unused; MODE 1: run_a = N, run_b = D
-  int expo[4];
+  double F[GPL], acc[MODE == 1 ? GPL : 1], run_a[GPL], run_b[MODE == 1 ? GPL : 1];
+  int expo[MODE == 2 ? GPL : 1];          // MODE 2: run_a = product;  MODE 1: run_a / run_b = N / D
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const uint64_t g = quad * 4 + j;
+  for (int j = 0; j < GPL; ++j) {
+    const uint64_t g = lane * GPL + j;
     F[j] = g < n_genomes ? f_in[g] : 0.0;
-    omF[j] = 1.0 - F[j];
-    acc[j] = 0.0;
     run_a[j] = MODE == 2 ? 1.0 : 0.0;
-    run_b[j] = 1.0;
-    expo[j] = 0;
+    if constexpr (MODE == 1) {
+      acc[j] = 0.0; run_b[j] = 1.0;
+      if (!(F[j] > 0.0)) F[j] = 1.0;                        // see above: v = 1 everywhere, k_hall_update multiplies by the real F
+    } else {
+      expo[j] = 0;
+    }
   }
 
-  if (s_begin < s_end) build_eval_table<MODE>(lut[0], s_begin, s_end, table, valid, stride, amax, phased != 0);
+  for (uint32_t e = threadIdx.x; e < 2u * kEvalBatch * 128u; e += kBlock) {
+    (&lut[0][0] + e)->y = 1.0;
+    (&lut[0][0] + e)->d = 0.0;
+  }
+  __syncthreads();
+  build_eval_table<MODE>(lut[0], s_begin, s_end, table, valid, stride, amax, phased != 0);
   __syncthreads();
   int buf = 0;
   for (uint64_t s0 = s_begin; s0 < s_end; s0 += kEvalBatch, buf ^= 1) {
-    uint32_t w[kEvalBatch];
+    uint32_t w[kEvalBatch][DW];
 #pragma unroll
     for (int i = 0; i < kEvalBatch; ++i) {
       const uint64_t s = s0 + i;
-      uint32_t x = 0x08080808u;                            // past the segment: unclassified
+#pragma unroll
+      for (int k = 0; k < DW; ++k) w[i][k] = 0x08080808u;  // past the segment: unclassified
       if (active && s < s_end) {
         const uint64_t l = locus_index ? static_cast<uint64_t>(locus_index[s]) : s;
-        x = __builtin_nontemporal_load(gt + l * dwords_per_row + col);
+        const uint32_t* src = gt + l * dwords_per_row + col;
+        if constexpr (DW == 1) {
+          w[i][0] = __builtin_nontemporal_load(src);
+        } else if constexpr (DW == 2) {
+          typedef uint32_t v2u __attribute__((ext_vector_type(2)));
+          const v2u v = __builtin_nontemporal_load(reinterpret_cast<const v2u*>(src));
+          w[i][0] = v.x; w[i][1] = v.y;
+        } else {
+          const kgx_v4u v = __builtin_nontemporal_load(reinterpret_cast<const kgx_v4u*>(src));
+          w[i][0] = v.x; w[i][1] = v.y; w[i][2] = v.z; w[i][3] = v.w;
+        }
       }
-      w[i] = x;
     }
     if (s0 + kEvalBatch < s_end) build_eval_table<MODE>(lut[buf ^ 1], s0 + kEvalBatch, s_end, table, valid, stride, amax, phased != 0);
     if (active) {
       const EvalEntry* __restrict__ cur = lut[buf];
 #pragma unroll
       for (int i = 0; i < kEvalBatch; ++i) {
-        const uint32_t xf = w[i] | ((w[i] & 0x80808080u) >> 4);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const EvalEntry e = cur[i * 128 + ((xf >> (8 * j)) & 0x7Fu)];
-          const double v = F[j] * e.x + omF[j] * e.y;      // MODE 2: the cell's probability; MODE 1: its denominator
-          if constexpr (MODE == 2) {
-            const double prob = v < 1e-10 ? 1e-10 : (v > 1.0 ? 1.0 : v);
-            run_a[j] *= prob;
-          } else {
-            const bool term = e.x != 0.0 && v != 0;         // a homozygous cell with a usable denominator (:272)
-            const double den = term ? v : 1.0;
-            run_a[j] = run_a[j] * den + (term ? run_b[j] : 0.0);
-            run_b[j] *= den;
+        for (int k = 0; k < DW; ++k) {
+          const uint32_t xf = w[i][k] | ((w[i][k] & 0x80808080u) >> 4);
+#pragma unroll
+          for (int b = 0; b < 4; ++b) {
+            const int j = 4 * k + b;
+            const EvalEntry e = cur[i * 128 + ((xf >> (8 * b)) & 0x7Fu)];
+            const double v = __builtin_fma(F[j], e.d, e.y);
+            if constexpr (MODE == 2) {
+              run_a[j] *= __builtin_fmin(__builtin_fmax(v, 1e-10), 1.0);   // the clamp of logLikelihood (:117-121)
+            } else {
+              run_a[j] = __builtin_fma(run_a[j], v, run_b[j]);
+              run_b[j] *= v;
+            }
           }
         }
       }
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
+      for (int j = 0; j < GPL; ++j) {
         if constexpr (MODE == 2) {                          // 8 factors >= 1e-10: no underflow before the exponent is peeled
           expo[j] += __builtin_amdgcn_frexp_exp(run_a[j]);
           run_a[j] = __builtin_amdgcn_frexp_mant(run_a[j]);
         } else {
-          acc[j] += F[j] * (run_a[j] / run_b[j]);
+          acc[j] += run_a[j] / run_b[j];
           run_a[j] = 0.0;
           run_b[j] = 1.0;
         }
@@ -816,8 +847,8 @@ k_inbreed_eval_lut(const uint32_t* __restrict__ gt, uint64_t dwords_per_row, uin
 
   if (!active) return;
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const uint64_t g = quad * 4 + j;
+  for (int j = 0; j < GPL; ++j) {
+    const uint64_t g = lane * GPL + j;
     if (g >= n_genomes) continue;
     if constexpr (MODE == 2) part[seg * n_genomes + g] = log(run_a[j]) + static_cast<double>(expo[j]) * 0.6931471805599453;
     else part[seg * n_genomes + g] = acc[j];
@@ -1353,13 +1384,20 @@ k_reduce_parts(const double* __restrict__ part, uint64_t n_seg, uint64_t n_items
   }
 }
 
-// processHallME's update: F <- expectation_sum / N (N = all classified loci, _calc.cpp:283).
+// processHallME's update: F <- expectation_sum / N (N = all classified loci, _calc.cpp:283).  walked > 0: the sums
+// come from k_inbreed_eval_lut<1> (sum over homozygous cells of 1/den, plus 1 for every other locus slot walked).
 __global__ void __launch_bounds__(kBlock)
 k_hall_update(const double* __restrict__ expectation_sum, const unsigned long long* __restrict__ counts, uint64_t n,
-              double* __restrict__ f) {
+              unsigned long long walked, double* __restrict__ f) {
   for (uint64_t g = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x; g < n;
-       g += static_cast<uint64_t>(gridDim.x) * blockDim.x)
-    f[g] = expectation_sum[g] / static_cast<double>(counts[g * 6 + 4]);
+       g += static_cast<uint64_t>(gridDim.x) * blockDim.x) {
+    double sum = expectation_sum[g];
+    if (walked) {
+      const unsigned long long homozygous = counts[g * 6 + 0] + counts[g * 6 + 2];
+      sum = f[g] > 0.0 ? f[g] * (sum - static_cast<double>(walked - homozygous)) : 0.0;
+    }
+    f[g] = sum / static_cast<double>(counts[g * 6 + 4]);
+  }
 }
 
 // Golden-section maximiser state per genome: bracket [a,b], interior points c<d with values fc, fd.
