@@ -715,25 +715,29 @@ k_inbreed_sweep(const uint32_t* __restrict__ gt, uint64_t dwords_per_row, uint64
 //           F = 0, where every term F/v is 0: such a genome is walked with F = 1 (v = 1 everywhere) and the
 //           multiplication by its F = 0 happens in k_hall_update.
 // Bit 7 of the byte (second allele index >= 8) is folded onto bit 3, and every entry with bit 3 set is "unclassified".
+// Entry (a1, a2) sits at slot a1 + 20*a2 of the locus's 160-slot table (a1 < 16, a2 < 8: injective), so the 16-byte
+// slots of the cells a 16-lane ds_read_b128 group meets together -- a1, a2 in 0..3 -- fall on 16 different bank quads
+// ((a1 + 4*a2) mod 16); at slot a1 + 16*a2 every a2 shared a1's banks (SQ_LDS_BANK_CONFLICT: 2.7 extra cycles a read).
 // GPL genomes per lane (4, 8 or 16: one dword / dwordx2 / dwordx4 load per locus); the whole block takes part in the
 // table build, so there is no early return.
 struct alignas(16) EvalEntry { double y, d; };
 constexpr int kEvalBatch = 8;
+constexpr uint32_t kEvalSlots = 160;
 
-// Only the (amax+1)^2 entries whose two allele indices are <= amax can ever be classified; the rest of the 128 are
+// Only the (amax+1)^2 entries whose two allele indices are <= amax can ever be classified; the rest of the 160 are
 // written "unclassified" once, before the first batch, and never touched again.
+// rows / flags: the batch's 8 per-locus table rows and valid[] flags, staged in LDS two batches ahead (flag 0 past the
+// segment), so that no global-load latency sits between a batch's arithmetic and the next.
 template <int MODE>
-__device__ __forceinline__ void build_eval_table(EvalEntry* __restrict__ lut, uint64_t s0, uint64_t s_end,
-                                                 const double* __restrict__ table, const uint8_t* __restrict__ valid,
-                                                 uint32_t stride, uint32_t amax, bool phased) {
+__device__ __forceinline__ void build_eval_table(EvalEntry* __restrict__ lut, const double* __restrict__ rows,
+                                                 const uint8_t* __restrict__ flags, uint32_t stride, uint32_t amax, bool phased) {
   for (uint32_t e = threadIdx.x; e < kEvalBatch * 64u; e += kBlock) {
-    const uint32_t a1 = e & 7u, a2 = (e >> 3) & 7u;
+    const uint32_t a1 = e & 7u, a2 = (e >> 3) & 7u, i = e >> 6;
     if (a1 > amax || a2 > amax) continue;
-    const uint64_t s = s0 + (e >> 6);
     double y = 1.0, d = 0.0;
-    if (s < s_end && (valid[s] & kLocusValid)) {
+    if (flags[i] & kLocusValid) {
       double f1 = 0.0, f2 = 0.0;
-      const int cls = classify_cell(a1 | (a2 << 4), table + s * stride, amax, phased, f1, f2);
+      const int cls = classify_cell(a1 | (a2 << 4), rows + i * stride, amax, phased, f1, f2);
       if (cls == kMajorHom || cls == kMinorHom) {
         if constexpr (MODE == 2) { y = f1 * f1; d = f1 - y; }
         else { y = f1; d = 1.0 - f1; }
@@ -741,7 +745,7 @@ __device__ __forceinline__ void build_eval_table(EvalEntry* __restrict__ lut, ui
         if constexpr (MODE == 2) { y = 2.0 * f1 * f2; d = -y; }
       }
     }
-    EvalEntry* slot = lut + (e >> 6) * 128u + (a1 | (a2 << 4));
+    EvalEntry* slot = lut + i * kEvalSlots + (a1 + 20u * a2);
     slot->y = y;
     slot->d = d;
   }
@@ -754,7 +758,9 @@ k_inbreed_eval_lut(const uint32_t* __restrict__ gt, uint64_t dwords_per_row, uin
                    const double* __restrict__ table, const uint8_t* __restrict__ valid, uint32_t amax, int phased,
                    const double* __restrict__ f_in, double* __restrict__ part) {
   constexpr int DW = GPL / 4;
-  __shared__ EvalEntry lut[2][kEvalBatch * 128];
+  __shared__ EvalEntry lut[2][kEvalBatch * kEvalSlots];
+  __shared__ double rows[2][kEvalBatch * sweep_stride(7)];
+  __shared__ uint8_t flags[2][kEvalBatch];
   const uint64_t lane = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x;   // genomes g0 + GPL*lane ..
   const bool active = lane * GPL < n_genomes;
   const uint64_t seg = blockIdx.y;
@@ -778,12 +784,31 @@ k_inbreed_eval_lut(const uint32_t* __restrict__ gt, uint64_t dwords_per_row, uin
     }
   }
 
-  for (uint32_t e = threadIdx.x; e < 2u * kEvalBatch * 128u; e += kBlock) {
+  for (uint32_t e = threadIdx.x; e < 2u * kEvalBatch * kEvalSlots; e += kBlock) {
     (&lut[0][0] + e)->y = 1.0;
     (&lut[0][0] + e)->d = 0.0;
   }
+  // stage(batch): thread t < 8*stride carries one double of the batch's contiguous table rows, t < 8 one valid[] flag
+  double staged_row = 0.0;
+  uint8_t staged_flag = 0;
+  auto fetch = [&](uint64_t s0) {
+    staged_row = 0.0;
+    staged_flag = 0;
+    if (s0 >= s_end) return;
+    const uint64_t loci = s_end - s0 < kEvalBatch ? s_end - s0 : kEvalBatch;
+    if (threadIdx.x < loci * stride) staged_row = table[s0 * stride + threadIdx.x];
+    if (threadIdx.x < loci) staged_flag = valid[s0 + threadIdx.x];
+  };
+  auto stash = [&](int rb) {
+    if (threadIdx.x < kEvalBatch * stride) rows[rb][threadIdx.x] = staged_row;
+    if (threadIdx.x < kEvalBatch) flags[rb][threadIdx.x] = staged_flag;
+  };
+  fetch(s_begin);
+  stash(0);
+  fetch(s_begin + kEvalBatch);
+  stash(1);
   __syncthreads();
-  build_eval_table<MODE>(lut[0], s_begin, s_end, table, valid, stride, amax, phased != 0);
+  build_eval_table<MODE>(lut[0], rows[0], flags[0], stride, amax, phased != 0);
   __syncthreads();
   int buf = 0;
   for (uint64_t s0 = s_begin; s0 < s_end; s0 += kEvalBatch, buf ^= 1) {
@@ -808,18 +833,20 @@ k_inbreed_eval_lut(const uint32_t* __restrict__ gt, uint64_t dwords_per_row, uin
         }
       }
     }
-    if (s0 + kEvalBatch < s_end) build_eval_table<MODE>(lut[buf ^ 1], s0 + kEvalBatch, s_end, table, valid, stride, amax, phased != 0);
+    fetch(s0 + 2 * kEvalBatch);
+    if (s0 + kEvalBatch < s_end) build_eval_table<MODE>(lut[buf ^ 1], rows[buf ^ 1], flags[buf ^ 1], stride, amax, phased != 0);
     if (active) {
       const EvalEntry* __restrict__ cur = lut[buf];
 #pragma unroll
       for (int i = 0; i < kEvalBatch; ++i) {
 #pragma unroll
         for (int k = 0; k < DW; ++k) {
-          const uint32_t xf = w[i][k] | ((w[i][k] & 0x80808080u) >> 4);
+          const uint32_t xf = (w[i][k] & 0x7F7F7F7Fu) | ((w[i][k] >> 4) & 0x08080808u);
+          const uint32_t slots = xf + ((xf >> 2) & 0x1C1C1C1Cu);          // a1 + 16*a2 + 4*a2 per byte, < 156: no carry
 #pragma unroll
           for (int b = 0; b < 4; ++b) {
             const int j = 4 * k + b;
-            const EvalEntry e = cur[i * 128 + ((xf >> (8 * b)) & 0x7Fu)];
+            const EvalEntry e = cur[i * kEvalSlots + ((slots >> (8 * b)) & 0xFFu)];
             const double v = __builtin_fma(F[j], e.d, e.y);
             if constexpr (MODE == 2) {
               run_a[j] *= __builtin_fmin(__builtin_fmax(v, 1e-10), 1.0);   // the clamp of logLikelihood (:117-121)
@@ -842,6 +869,7 @@ k_inbreed_eval_lut(const uint32_t* __restrict__ gt, uint64_t dwords_per_row, uin
         }
       }
     }
+    stash(buf);          // rows[buf] fed this batch's table one iteration ago: free for the batch after next
     __syncthreads();
   }
 
