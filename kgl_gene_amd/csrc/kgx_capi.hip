@@ -752,7 +752,7 @@ int kgx_inbreed(kgx_gt8* h, uint64_t g0, uint64_t g1, const uint32_t* locus_inde
   // The evaluation passes of HallME / Loglikelihood go through the per-batch LDS tables when the allele indices fit them.
   const bool eval_lut = !env_int("KGX_K5_GENERIC", 0) && !env_int("KGX_K5_NO_EVAL_LUT", 0) && amax <= 7;
   int eval_gpl = env_int("KGX_K5_EVAL_GPL", 8);            // genomes per lane: the widest load the group's alignment allows
-  if (eval_gpl != 4 && eval_gpl != 8 && eval_gpl != 16) eval_gpl = 8;
+  if (eval_gpl != 4 && eval_gpl != 8) eval_gpl = 8;
   while (eval_gpl > 4 && (g0 % static_cast<uint64_t>(eval_gpl)) != 0) eval_gpl /= 2;
   const uint32_t gx = static_cast<uint32_t>(((n + 3) / 4 + kBlock - 1) / kBlock);
   const uint32_t gx16 = static_cast<uint32_t>(((n + 15) / 16 + kBlock - 1) / kBlock);
@@ -857,14 +857,19 @@ int kgx_inbreed(kgx_gt8* h, uint64_t g0, uint64_t g1, const uint32_t* locus_inde
       }
     } else if (eval_lut) {
       const dim3 grid_eval(static_cast<uint32_t>(((n + eval_gpl - 1) / eval_gpl + kBlock - 1) / kBlock), static_cast<uint32_t>(n_seg));
-#define KGX_EVAL(M, W)                                                                                                            \
-  hipLaunchKernelGGL((k_inbreed_eval_lut<M, W>), grid_eval, dim3(kBlock), 0, st, gt32, dwords_per_row, g0, n, d_index, n_sel, per_seg, \
-                     d_table, d_valid, amax, phased, d_f, d_part)
+#define KGX_EVAL(M, W, B)                                                                                                         \
+  hipLaunchKernelGGL((k_inbreed_eval_lut<M, W, B>), grid_eval, dim3(kBlock), 0, st, gt32, dwords_per_row, g0, n, d_index, n_sel,  \
+                     per_seg, d_table, d_valid, amax, phased, d_f, d_part)
+#define KGX_EVAL_BITS(M, W)                                                                \
+  do {                                                                                     \
+    if (amax <= 1) KGX_EVAL(M, W, 1); else if (amax <= 3) KGX_EVAL(M, W, 2); else KGX_EVAL(M, W, 3); \
+  } while (0)
       if (mode == 1) {
-        if (eval_gpl == 16) KGX_EVAL(1, 16); else if (eval_gpl == 8) KGX_EVAL(1, 8); else KGX_EVAL(1, 4);
+        if (eval_gpl == 8) KGX_EVAL_BITS(1, 8); else KGX_EVAL_BITS(1, 4);
       } else {
-        if (eval_gpl == 16) KGX_EVAL(2, 16); else if (eval_gpl == 8) KGX_EVAL(2, 8); else KGX_EVAL(2, 4);
+        if (eval_gpl == 8) KGX_EVAL_BITS(2, 8); else KGX_EVAL_BITS(2, 4);
       }
+#undef KGX_EVAL_BITS
 #undef KGX_EVAL
     } else if (mode == 1)
       hipLaunchKernelGGL((k_inbreed_sweep<1>), grid, dim3(kBlock), 0, st, gt32, dwords_per_row, g0, n, d_index, n_sel, per_seg, d_table,

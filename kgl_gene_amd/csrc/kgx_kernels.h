@@ -728,11 +728,14 @@ constexpr uint32_t kEvalSlots = 160;
 // written "unclassified" once, before the first batch, and never touched again.
 // rows / flags: the batch's 8 per-locus table rows and valid[] flags, staged in LDS two batches ahead (flag 0 past the
 // segment), so that no global-load latency sits between a batch's arithmetic and the next.
-template <int MODE>
+template <int MODE, int BITS>
 __device__ __forceinline__ void build_eval_table(EvalEntry* __restrict__ lut, const double* __restrict__ rows,
                                                  const uint8_t* __restrict__ flags, uint32_t stride, uint32_t amax, bool phased) {
-  for (uint32_t e = threadIdx.x; e < kEvalBatch * 64u; e += kBlock) {
-    const uint32_t a1 = e & 7u, a2 = (e >> 3) & 7u, i = e >> 6;
+  // e enumerates (locus, a2, a1) with just enough bits per allele index for amax, so that at amax <= 3 two waves
+  // build the whole batch in one step and the other two go straight on to the arithmetic
+  constexpr uint32_t bits = BITS, mask = (1u << bits) - 1u;       // BITS = 1, 2, 3 for amax <= 1, 3, 7
+  for (uint32_t e = threadIdx.x; e < (static_cast<uint32_t>(kEvalBatch) << (2u * bits)); e += kBlock) {
+    const uint32_t a1 = e & mask, a2 = (e >> bits) & mask, i = e >> (2u * bits);
     if (a1 > amax || a2 > amax) continue;
     double y = 1.0, d = 0.0;
     if (flags[i] & kLocusValid) {
@@ -751,7 +754,7 @@ __device__ __forceinline__ void build_eval_table(EvalEntry* __restrict__ lut, co
   }
 }
 
-template <int MODE, int GPL>
+template <int MODE, int GPL, int BITS>
 __global__ void __launch_bounds__(kBlock)
 k_inbreed_eval_lut(const uint32_t* __restrict__ gt, uint64_t dwords_per_row, uint64_t g0, uint64_t n_genomes,
                    const uint32_t* __restrict__ locus_index, uint64_t n_sel, uint64_t loci_per_seg,
@@ -808,7 +811,7 @@ k_inbreed_eval_lut(const uint32_t* __restrict__ gt, uint64_t dwords_per_row, uin
   fetch(s_begin + kEvalBatch);
   stash(1);
   __syncthreads();
-  build_eval_table<MODE>(lut[0], rows[0], flags[0], stride, amax, phased != 0);
+  build_eval_table<MODE, BITS>(lut[0], rows[0], flags[0], stride, amax, phased != 0);
   __syncthreads();
   int buf = 0;
   for (uint64_t s0 = s_begin; s0 < s_end; s0 += kEvalBatch, buf ^= 1) {
@@ -834,7 +837,7 @@ k_inbreed_eval_lut(const uint32_t* __restrict__ gt, uint64_t dwords_per_row, uin
       }
     }
     fetch(s0 + 2 * kEvalBatch);
-    if (s0 + kEvalBatch < s_end) build_eval_table<MODE>(lut[buf ^ 1], rows[buf ^ 1], flags[buf ^ 1], stride, amax, phased != 0);
+    if (s0 + kEvalBatch < s_end) build_eval_table<MODE, BITS>(lut[buf ^ 1], rows[buf ^ 1], flags[buf ^ 1], stride, amax, phased != 0);
     if (active) {
       const EvalEntry* __restrict__ cur = lut[buf];
 #pragma unroll
