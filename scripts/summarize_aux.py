@@ -17,6 +17,14 @@ def stats(sub):
     (dst / f"{tag}_{sub}_kernel_stats.csv").write_text(text)
     return list(csv.DictReader(text.splitlines()))
 
+def calls(sub, needle):
+    """Per-call durations (ms) of the kernels whose name contains needle, in launch order."""
+    files = glob.glob(str(src / sub / "*" / "*kernel_trace.csv"))
+    rows = [r for r in csv.DictReader(open(files[0])) if needle in r["Kernel_Name"]]
+    rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+    return [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6 for r in rows]
+
+
 def short(name):
     name = re.sub(r"^void ", "", name)
     return name.split("(")[0]
@@ -39,6 +47,8 @@ md = f"""# rocprofv3 kernel stats `{tag}` — secondary sweeps (scripts/profile_
 ## K3 by-genome sweep at C3 (10k x 10M; 3 x all rows + 2 x 11 FWS bins)
 
 {table(stats("k3"), k3_bytes, ["k_count_by_genome"])}
+
+Per call, in launch order (3 x all rows in one bin, then 2 x 11 FWS bins): {", ".join(f"{ms:.2f} ms = {k3_bytes / ms / 1e6:,.0f} GB/s" for ms in calls("k3", "k_count_by_genome"))}.
 
 ```
 {(src / "k3.txt").read_text().strip()}
