@@ -747,8 +747,11 @@ int kgx_inbreed(kgx_gt8* h, uint64_t g0, uint64_t g1, const uint32_t* locus_inde
   const uint32_t stride = sweep_stride(amax);
   // Frequency pass flavour: 16 genomes per lane (SWAR, 16-byte loads) when the group starts on a 16-genome boundary and
   // the estimator needs no Ritland terms; otherwise 4 genomes per lane.
+  // RitlandLocus with allele indices that fit the tables: the plain frequency sweep, then one table pass for its terms.
+  const bool ritland_lut = algorithm == KGX_ALGO_RITLAND_LOCUS && !env_int("KGX_K5_GENERIC", 0) && !env_int("KGX_K5_NO_EVAL_LUT", 0) &&
+                           !env_int("KGX_K5_NO_SWAR", 0) && amax <= 4;
   const bool swar16 = !env_int("KGX_K5_GENERIC", 0) && !env_int("KGX_K5_NO_SWAR16", 0) && amax <= 4 && (g0 & 15u) == 0 &&
-                      algorithm != KGX_ALGO_RITLAND_LOCUS;
+                      (algorithm != KGX_ALGO_RITLAND_LOCUS || ritland_lut);
   // The evaluation passes of HallME / Loglikelihood go through the per-batch LDS tables when the allele indices fit them.
   const bool eval_lut = !env_int("KGX_K5_GENERIC", 0) && !env_int("KGX_K5_NO_EVAL_LUT", 0) && amax <= 7;
   int eval_gpl = env_int("KGX_K5_EVAL_GPL", 8);            // genomes per lane: the widest load the group's alignment allows
@@ -831,7 +834,7 @@ int kgx_inbreed(kgx_gt8* h, uint64_t g0, uint64_t g1, const uint32_t* locus_inde
       } else {
         hipLaunchKernelGGL(k_locus_bits, dim3(stream_grid(n_sel, kBlock)), dim3(kBlock), 0, st, d_table, d_valid, n_sel, amax, d_bits, d_meta);
         hipLaunchKernelGGL(k_segment_defaults, dim3(static_cast<uint32_t>(n_seg)), dim3(kWave), 0, st, d_table, d_valid, n_sel, per_seg, amax, d_segdef);
-        const bool ritland = algorithm == KGX_ALGO_RITLAND_LOCUS;
+        const bool ritland = algorithm == KGX_ALGO_RITLAND_LOCUS && !ritland_lut;
         if (env_int("KGX_K5_NO_SWAR", 0)) {
           if (ritland)
             hipLaunchKernelGGL((k_inbreed_sweep_fast<true>), grid, dim3(kBlock), 0, st, gt32, dwords_per_row, g0, n, d_index, n_sel, per_seg,
@@ -855,19 +858,21 @@ int kgx_inbreed(kgx_gt8* h, uint64_t g0, uint64_t g1, const uint32_t* locus_inde
                                d_table, d_meta, amax, phased, d_segdef, d_counts, d_part);
         }
       }
-    } else if (eval_lut) {
+    } else if (eval_lut || mode == 3) {
       const dim3 grid_eval(static_cast<uint32_t>(((n + eval_gpl - 1) / eval_gpl + kBlock - 1) / kBlock), static_cast<uint32_t>(n_seg));
 #define KGX_EVAL(M, W, B)                                                                                                         \
   hipLaunchKernelGGL((k_inbreed_eval_lut<M, W, B>), grid_eval, dim3(kBlock), 0, st, gt32, dwords_per_row, g0, n, d_index, n_sel,  \
-                     per_seg, d_table, d_valid, amax, phased, d_f, d_part)
+                     per_seg, d_table, d_valid, amax, phased, d_f, d_part, d_counts)
 #define KGX_EVAL_BITS(M, W)                                                                \
   do {                                                                                     \
     if (amax <= 1) KGX_EVAL(M, W, 1); else if (amax <= 3) KGX_EVAL(M, W, 2); else KGX_EVAL(M, W, 3); \
   } while (0)
       if (mode == 1) {
         if (eval_gpl == 8) KGX_EVAL_BITS(1, 8); else KGX_EVAL_BITS(1, 4);
-      } else {
+      } else if (mode == 2) {
         if (eval_gpl == 8) KGX_EVAL_BITS(2, 8); else KGX_EVAL_BITS(2, 4);
+      } else {
+        if (eval_gpl == 8) KGX_EVAL_BITS(3, 8); else KGX_EVAL_BITS(3, 4);
       }
 #undef KGX_EVAL_BITS
 #undef KGX_EVAL
@@ -887,6 +892,7 @@ int kgx_inbreed(kgx_gt8* h, uint64_t g0, uint64_t g1, const uint32_t* locus_inde
     }
     if (rc == KGX_OK) try_hip(hipEventRecord(g_state.sweep_begin, st), KGX_EHIP, "hipEventRecord");
     sweep(0);
+    if (ritland_lut) sweep(3);
     if (rc == KGX_OK) try_hip(hipEventRecord(g_state.sweep_end, st), KGX_EHIP, "hipEventRecord");
     hipLaunchKernelGGL(k_reduce_parts, dim3(stream_grid(n * kParts0, kBlock)), dim3(kBlock), 0, st, d_part, n_seg, n * kParts0, d_sums);
     if (algorithm == 2) {

@@ -714,6 +714,10 @@ k_inbreed_sweep(const uint32_t* __restrict__ gt, uint64_t dwords_per_row, uint64
 //           sweep) and multiplies by F.  The reference's zero-denominator guard (_calc.cpp:272) can only fire at
 //           F = 0, where every term F/v is 0: such a genome is walked with F = 1 (v = 1 everywhere) and the
 //           multiplication by its F = 0 happens in k_hall_update.
+//   MODE 3  RitlandLocus (processRitlandLocus, _calc.cpp:367-431): y = the cell's term -- homozygous with f1 > 0.001:
+//           1/f1 - 1, heterozygous: -1, anything else 0 -- and d = 1 where the cell is counted; both are summed per
+//           genome in fp64 (the count is exact) and written to the Ritland slot of the frequency sweep's partials
+//           and to counts[g][5].  Runs after the (non-Ritland) SWAR frequency sweep.
 // Bit 7 of the byte (second allele index >= 8) is folded onto bit 3, and every entry with bit 3 set is "unclassified".
 // Entry (a1, a2) sits at slot a1 + 20*a2 of the locus's 160-slot table (a1 < 16, a2 < 8: injective), so the 16-byte
 // slots of the cells a 16-lane ds_read_b128 group meets together -- a1, a2 in 0..3 -- fall on 16 different bank quads
@@ -737,15 +741,17 @@ __device__ __forceinline__ void build_eval_table(EvalEntry* __restrict__ lut, co
   for (uint32_t e = threadIdx.x; e < (static_cast<uint32_t>(kEvalBatch) << (2u * bits)); e += kBlock) {
     const uint32_t a1 = e & mask, a2 = (e >> bits) & mask, i = e >> (2u * bits);
     if (a1 > amax || a2 > amax) continue;
-    double y = 1.0, d = 0.0;
+    double y = MODE == 3 ? 0.0 : 1.0, d = 0.0;
     if (flags[i] & kLocusValid) {
       double f1 = 0.0, f2 = 0.0;
       const int cls = classify_cell(a1 | (a2 << 4), rows + i * stride, amax, phased, f1, f2);
       if (cls == kMajorHom || cls == kMinorHom) {
         if constexpr (MODE == 2) { y = f1 * f1; d = f1 - y; }
-        else { y = f1; d = 1.0 - f1; }
+        else if constexpr (MODE == 1) { y = f1; d = 1.0 - f1; }
+        else if (f1 > 0.001) { y = 1.0 / f1; y -= 1.0; d = 1.0; }     // minimum_frequency (_calc.cpp:380,396)
       } else if (cls != kClassNone) {
         if constexpr (MODE == 2) { y = 2.0 * f1 * f2; d = -y; }
+        else if constexpr (MODE == 3) { y = -1.0; d = 1.0; }
       }
     }
     EvalEntry* slot = lut + i * kEvalSlots + (a1 + 20u * a2);
@@ -759,7 +765,7 @@ __global__ void __launch_bounds__(kBlock)
 k_inbreed_eval_lut(const uint32_t* __restrict__ gt, uint64_t dwords_per_row, uint64_t g0, uint64_t n_genomes,
                    const uint32_t* __restrict__ locus_index, uint64_t n_sel, uint64_t loci_per_seg,
                    const double* __restrict__ table, const uint8_t* __restrict__ valid, uint32_t amax, int phased,
-                   const double* __restrict__ f_in, double* __restrict__ part) {
+                   const double* __restrict__ f_in, double* __restrict__ part, unsigned long long* __restrict__ counts) {
   constexpr int DW = GPL / 4;
   __shared__ EvalEntry lut[2][kEvalBatch * kEvalSlots];
   __shared__ double rows[2][kEvalBatch * sweep_stride(7)];
@@ -772,23 +778,25 @@ k_inbreed_eval_lut(const uint32_t* __restrict__ gt, uint64_t dwords_per_row, uin
   const uint32_t stride = sweep_stride(amax);
   const uint64_t col = (g0 >> 2) + lane * DW;              // g0 is a multiple of GPL
 
-  double F[GPL], acc[MODE == 1 ? GPL : 1], run_a[GPL], run_b[MODE == 1 ? GPL : 1];
-  int expo[MODE == 2 ? GPL : 1];          // MODE 2: run_a = product;  MODE 1: run_a / run_b = N / D
+  double F[MODE == 3 ? 1 : GPL], acc[MODE == 1 ? GPL : 1], run_a[GPL], run_b[MODE == 2 ? 1 : GPL];
+  int expo[MODE == 2 ? GPL : 1];   // MODE 2: run_a = product;  MODE 1: run_a / run_b = N / D;  MODE 3: run_a = sum, run_b = count
 #pragma unroll
   for (int j = 0; j < GPL; ++j) {
     const uint64_t g = lane * GPL + j;
-    F[j] = g < n_genomes ? f_in[g] : 0.0;
+    if constexpr (MODE != 3) F[j] = g < n_genomes ? f_in[g] : 0.0;
     run_a[j] = MODE == 2 ? 1.0 : 0.0;
     if constexpr (MODE == 1) {
       acc[j] = 0.0; run_b[j] = 1.0;
       if (!(F[j] > 0.0)) F[j] = 1.0;                        // see above: v = 1 everywhere, k_hall_update multiplies by the real F
-    } else {
+    } else if constexpr (MODE == 2) {
       expo[j] = 0;
+    } else {
+      run_b[j] = 0.0;
     }
   }
 
   for (uint32_t e = threadIdx.x; e < 2u * kEvalBatch * kEvalSlots; e += kBlock) {
-    (&lut[0][0] + e)->y = 1.0;
+    (&lut[0][0] + e)->y = MODE == 3 ? 0.0 : 1.0;
     (&lut[0][0] + e)->d = 0.0;
   }
   // stage(batch): thread t < 8*stride carries one double of the batch's contiguous table rows, t < 8 one valid[] flag
@@ -850,7 +858,12 @@ k_inbreed_eval_lut(const uint32_t* __restrict__ gt, uint64_t dwords_per_row, uin
           for (int b = 0; b < 4; ++b) {
             const int j = 4 * k + b;
             const EvalEntry e = cur[i * kEvalSlots + ((slots >> (8 * b)) & 0xFFu)];
-            const double v = __builtin_fma(F[j], e.d, e.y);
+            if constexpr (MODE == 3) {
+              run_a[j] += e.y;
+              run_b[j] += e.d;
+              continue;
+            }
+            const double v = __builtin_fma(F[MODE == 3 ? 0 : j], e.d, e.y);
             if constexpr (MODE == 2) {
               run_a[j] *= __builtin_fmin(__builtin_fmax(v, 1e-10), 1.0);   // the clamp of logLikelihood (:117-121)
             } else {
@@ -865,7 +878,7 @@ k_inbreed_eval_lut(const uint32_t* __restrict__ gt, uint64_t dwords_per_row, uin
         if constexpr (MODE == 2) {                          // 8 factors >= 1e-10: no underflow before the exponent is peeled
           expo[j] += __builtin_amdgcn_frexp_exp(run_a[j]);
           run_a[j] = __builtin_amdgcn_frexp_mant(run_a[j]);
-        } else {
+        } else if constexpr (MODE == 1) {
           acc[j] += run_a[j] / run_b[j];
           run_a[j] = 0.0;
           run_b[j] = 1.0;
@@ -881,8 +894,15 @@ k_inbreed_eval_lut(const uint32_t* __restrict__ gt, uint64_t dwords_per_row, uin
   for (int j = 0; j < GPL; ++j) {
     const uint64_t g = lane * GPL + j;
     if (g >= n_genomes) continue;
-    if constexpr (MODE == 2) part[seg * n_genomes + g] = log(run_a[j]) + static_cast<double>(expo[j]) * 0.6931471805599453;
-    else part[seg * n_genomes + g] = acc[j];
+    if constexpr (MODE == 2) {
+      part[seg * n_genomes + g] = log(run_a[j]) + static_cast<double>(expo[j]) * 0.6931471805599453;
+    } else if constexpr (MODE == 1) {
+      part[seg * n_genomes + g] = acc[j];
+    } else {
+      part[(seg * n_genomes + g) * kParts0 + 4] = run_a[j];
+      const unsigned long long counted = static_cast<unsigned long long>(run_b[j]);
+      if (counted) atomicAdd(&counts[g * 6 + 5], counted);
+    }
   }
 }
 
