@@ -243,9 +243,15 @@ int kgx_init(int device) {
   if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
     return fail(KGX_ENODEVICE, "device %d is %s; this library is built for gfx950 only", device, prop.gcnArchName);
   if (g_state.ready && g_state.device == device) return KGX_OK;
-  if (g_state.ready && g_state.stream) {
+  if (g_state.ready && g_state.stream) {      // rebinding to another device: drop what lives on the old one
     (void)hipStreamDestroy(g_state.stream);
     g_state.stream = nullptr;
+    if (g_state.sweep_begin) (void)hipEventDestroy(g_state.sweep_begin);
+    if (g_state.sweep_end) (void)hipEventDestroy(g_state.sweep_end);
+    g_state.sweep_begin = g_state.sweep_end = nullptr;
+    if (g_state.scratch) (void)hipFree(g_state.scratch);
+    g_state.scratch = nullptr;
+    g_state.scratch_bytes = 0;
   }
   KGX_HIP(hipStreamCreateWithFlags(&g_state.stream, hipStreamNonBlocking));
   g_state.device = device;
@@ -729,6 +735,38 @@ int kgx_locus_class_frequencies(const double* minor_af, uint64_t n_loci, uint32_
   return rc;
 }
 
+namespace {
+struct ScratchPlan {
+  size_t total = 0;
+  size_t add(size_t bytes) {
+    const size_t at = total;
+    total += (bytes + 255u) & ~static_cast<size_t>(255u);
+    return at;
+  }
+};
+int scratch_reserve(size_t bytes, char** out) {
+  if (bytes > g_state.scratch_bytes) {
+    if (g_state.scratch) (void)hipFree(g_state.scratch);
+    g_state.scratch = nullptr;
+    g_state.scratch_bytes = 0;
+    const size_t want = bytes + bytes / 8;            // headroom: windows of a contig differ a little in locus count
+    if (hipMalloc(&g_state.scratch, want) != hipSuccess) {
+      (void)hipGetLastError();
+      if (hipMalloc(&g_state.scratch, bytes) != hipSuccess) {
+        (void)hipGetLastError();
+        g_state.scratch = nullptr;
+        return fail(KGX_ENOMEM, "hipMalloc of %llu scratch bytes failed", static_cast<unsigned long long>(bytes));
+      }
+      g_state.scratch_bytes = bytes;
+    } else {
+      g_state.scratch_bytes = want;
+    }
+  }
+  *out = g_state.scratch;
+  return KGX_OK;
+}
+}  // namespace
+
 int kgx_inbreed(kgx_gt8* h, uint64_t g0, uint64_t g1, const uint32_t* locus_index, uint64_t n_sel, const double* minor_af,
                 uint32_t amax, int phased, int algorithm, kgx_locus_results* out) {
   if (int rc = require_device()) return rc;
@@ -783,22 +821,34 @@ int kgx_inbreed(kgx_gt8* h, uint64_t g0, uint64_t g1, const uint32_t* locus_inde
       rc = fail(code, "kgx_inbreed: %s failed: %s", what, hipGetErrorString(e));
     }
   };
+  // Scratch comes out of one grow-only device arena kept by the library (a window loop calls this hundreds of times;
+  // fourteen hipMalloc/hipFree pairs per call cost more than the sweep).  The call is synchronous, so reuse is safe.
   const uint64_t n_tab = n_sel ? n_sel : 1;
-  try_hip(hipMalloc(&d_af, n_tab * amax * sizeof(double)), KGX_ENOMEM, "hipMalloc(af)");
-  try_hip(hipMalloc(&d_table, n_tab * stride * sizeof(double)), KGX_ENOMEM, "hipMalloc(table)");
-  try_hip(hipMalloc(&d_valid, n_tab), KGX_ENOMEM, "hipMalloc(valid)");
-  try_hip(hipMalloc(&d_bits, n_tab * sizeof(LocusBits)), KGX_ENOMEM, "hipMalloc(bits)");
-  try_hip(hipMalloc(&d_meta, (n_tab + 8) * sizeof(uint32_t)), KGX_ENOMEM, "hipMalloc(meta)");
+  ScratchPlan plan;
+  const size_t o_af = plan.add(n_tab * amax * sizeof(double)), o_table = plan.add(n_tab * stride * sizeof(double));
+  const size_t o_valid = plan.add(n_tab), o_bits = plan.add(n_tab * sizeof(LocusBits)), o_meta = plan.add((n_tab + 8) * sizeof(uint32_t));
+  const size_t o_part = plan.add(n_seg * n * kParts0 * sizeof(double)), o_segdef = plan.add(n_seg * kSegDefaults * sizeof(double));
+  const size_t o_sums = plan.add(n * kParts0 * sizeof(double)), o_counts = plan.add(n * 6 * sizeof(unsigned long long));
+  const size_t o_f = plan.add(n * sizeof(double)), o_eval = plan.add(n * sizeof(double)), o_out = plan.add(n * sizeof(LocusResultsDev));
+  const size_t o_index = plan.add((n_sel + 8) * sizeof(uint32_t)), o_golden = plan.add(n * sizeof(GoldenState));
+  char* arena = nullptr;
+  if (int arc = scratch_reserve(plan.total, &arena)) return arc;
+  d_af = reinterpret_cast<double*>(arena + o_af);
+  d_table = reinterpret_cast<double*>(arena + o_table);
+  d_valid = reinterpret_cast<uint8_t*>(arena + o_valid);
+  d_bits = reinterpret_cast<LocusBits*>(arena + o_bits);
+  d_meta = reinterpret_cast<uint32_t*>(arena + o_meta);
+  d_part = reinterpret_cast<double*>(arena + o_part);
+  d_segdef = reinterpret_cast<double*>(arena + o_segdef);
+  d_sums = reinterpret_cast<double*>(arena + o_sums);
+  d_counts = reinterpret_cast<unsigned long long*>(arena + o_counts);
+  d_f = reinterpret_cast<double*>(arena + o_f);
+  d_eval = reinterpret_cast<double*>(arena + o_eval);
+  d_out = reinterpret_cast<LocusResultsDev*>(arena + o_out);
+  d_golden = reinterpret_cast<GoldenState*>(arena + o_golden);
   try_hip(hipMemsetAsync(d_meta, 0, (n_tab + 8) * sizeof(uint32_t), g_state.stream), KGX_EHIP, "memset(meta)");
-  try_hip(hipMalloc(&d_part, n_seg * n * kParts0 * sizeof(double)), KGX_ENOMEM, "hipMalloc(partials)");
-  try_hip(hipMalloc(&d_segdef, n_seg * kSegDefaults * sizeof(double)), KGX_ENOMEM, "hipMalloc(segment defaults)");
-  try_hip(hipMalloc(&d_sums, n * kParts0 * sizeof(double)), KGX_ENOMEM, "hipMalloc(sums)");
-  try_hip(hipMalloc(&d_counts, n * 6 * sizeof(unsigned long long)), KGX_ENOMEM, "hipMalloc(counts)");
-  try_hip(hipMalloc(&d_f, n * sizeof(double)), KGX_ENOMEM, "hipMalloc(f)");
-  try_hip(hipMalloc(&d_eval, n * sizeof(double)), KGX_ENOMEM, "hipMalloc(eval)");
-  try_hip(hipMalloc(&d_out, n * sizeof(LocusResultsDev)), KGX_ENOMEM, "hipMalloc(out)");
   if (locus_index && n_sel) {
-    try_hip(hipMalloc(&d_index, (n_sel + 8) * sizeof(uint32_t)), KGX_ENOMEM, "hipMalloc(index)");
+    d_index = reinterpret_cast<uint32_t*>(arena + o_index);
     try_hip(hipMemsetAsync(d_index, 0, (n_sel + 8) * sizeof(uint32_t), g_state.stream), KGX_EHIP, "memset(index)");
   }
   hipStream_t st = g_state.stream;
@@ -913,7 +963,6 @@ int kgx_inbreed(kgx_gt8* h, uint64_t g0, uint64_t g1, const uint32_t* locus_inde
       // processLogLikelihood (_calc.cpp:153-216): maximise over [-1,1].  The objective is a sum of logs of
       // clamped linear functions of F; a golden-section search on that same clamped objective replaces nlopt's
       // Nelder-Mead (un-vendored, unpinned), to a 6e-8 bracket in F where the reference asks for 1e-6.
-      try_hip(hipMalloc(&d_golden, n * sizeof(GoldenState)), KGX_ENOMEM, "hipMalloc(golden)");
       const double inv_phi = 0.6180339887498949;
       constexpr int kGoldenSteps = 38;     // bracket 2 * 0.618^36 = 6e-8 after the two start-up evaluations
       GoldenState init;
@@ -949,10 +998,6 @@ int kgx_inbreed(kgx_gt8* h, uint64_t g0, uint64_t g1, const uint32_t* locus_inde
       if (hipEventElapsedTime(&ms, g_state.sweep_begin, g_state.sweep_end) == hipSuccess) g_state.last_sweep_ms = ms;
     }
   }
-  for (void* p : {static_cast<void*>(d_af), static_cast<void*>(d_table), static_cast<void*>(d_valid), static_cast<void*>(d_part),
-                  static_cast<void*>(d_sums), static_cast<void*>(d_counts), static_cast<void*>(d_f), static_cast<void*>(d_eval),
-                  static_cast<void*>(d_out), static_cast<void*>(d_index), static_cast<void*>(d_golden), static_cast<void*>(d_segdef), static_cast<void*>(d_bits), static_cast<void*>(d_meta)})
-    if (p) (void)hipFree(p);
   return rc;
 }
 
