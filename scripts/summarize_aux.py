@@ -54,9 +54,9 @@ Per call, in launch order (3 x all rows in one bin, then 2 x 11 FWS bins): {", "
 {(src / "k3.txt").read_text().strip()}
 ```
 
-## K5 inbreeding sweep at C5 (10k x 5M multi-allelic; Simple then RitlandLocus)
+## K5 inbreeding sweep at C5 (10k x 5M multi-allelic; Simple then RitlandLocus, each called twice)
 
-{table(stats("k5"), k5_bytes, ["k_inbreed_sweep"])}
+{table(stats("k5"), k5_bytes, ["k_inbreed_sweep", "k_inbreed_eval_lut"])}
 
 ```
 {k5_txt.strip()}
