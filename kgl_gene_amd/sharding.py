@@ -47,6 +47,17 @@ def allreduce_counts(counts, world_size: int):
     return counts
 
 
+def allreduce_counts_async(counts, world_size: int):
+    """allreduce_counts issued asynchronously: returns a work handle whose wait() makes the CURRENT stream (not the
+    host) wait for the sums, or None with one rank.  The caller launches the next batch's sweep before waiting, so
+    the exchange over xGMI runs beside it (two count buffers alternate)."""
+    if world_size > 1:
+        import torch.distributed as dist
+
+        return dist.all_reduce(counts, op=dist.ReduceOp.SUM, async_op=True)
+    return None
+
+
 def gather_by_genome(local_rows, shards: list[GenomeShard], world_size: int):
     """Per-genome results need no reduction, only concatenation in shard order (all_gather of ragged rows)."""
     if world_size == 1:

@@ -12,7 +12,7 @@ import torch.distributed as dist
 import torch.multiprocessing as mp
 
 from kgl_gene_amd import capi
-from kgl_gene_amd.sharding import allreduce_counts, gather_by_genome, replicate_genomes, shard_genomes
+from kgl_gene_amd.sharding import allreduce_counts, allreduce_counts_async, gather_by_genome, replicate_genomes, shard_genomes
 
 TOTAL_G, V, SEED = 1003, 400, 1111
 
@@ -34,6 +34,22 @@ def _worker(rank, world, port, out_dir):
     allreduce_counts(counts, world)
     by_genome = torch.from_numpy(np.stack([(codes == k).sum(0) for k in range(4)], 1).astype(np.int64))
     gathered = gather_by_genome(by_genome, shards, world)
+    # bench.py's pipelined form: two alternating buffers, the exchange of batch i in flight while batch i+1 is counted
+    bufs = [torch.zeros_like(counts), torch.zeros_like(counts)]
+    pending, done = None, []
+    for i in range(3):
+        buf = bufs[i % 2]
+        buf.copy_(torch.from_numpy(counts_of(codes).view(np.int32).copy()) * (i + 1))
+        work = allreduce_counts_async(buf, world)
+        if pending is not None:
+            pending[0].wait()
+            done.append(pending[1].clone())
+        pending = (work, buf)
+    pending[0].wait()
+    done.append(pending[1].clone())
+    for i, d in enumerate(done):
+        assert torch.equal(d, counts * (i + 1)), i
+    assert allreduce_counts_async(counts, 1) is None
     if rank == 0:
         np.save(os.path.join(out_dir, "counts.npy"), counts.numpy().view(np.uint32))
         np.save(os.path.join(out_dir, "by_genome.npy"), gathered.numpy())
