@@ -34,6 +34,10 @@ bool kga::GpuAlleleAnalysis::initializeAnalysis(const std::string& work_director
       if (auto v = parameter_map.getString("VariantFile")) variant_file_ = v.value().front();
       if (auto v = parameter_map.getString("GenomeFile")) genome_file_ = v.value().front();
       if (auto v = parameter_map.getString("HetHomFile")) hethom_file_ = v.value().front();
+      // "FileNameOnly" VCF data files: which of the reference's parsers the text is for, and whether the PfEMP package's
+      // per-record quality filter (P7VariantFilter) runs before the counting
+      if (auto v = parameter_map.getString("VcfFlavour")) vcf_flavour_ = v.value().front();
+      if (auto v = parameter_map.getBool("Pf7QualityFilter")) pf7_quality_filter_ = v.value();
     }
   }
   if (kgx_init(device_) != KGX_OK) {
@@ -83,7 +87,17 @@ bool kga::GpuAlleleAnalysis::sweepVcfFile(const std::string& file_name) {
     return false;
   }
   std::string text((std::istreambuf_iterator<char>(in)), std::istreambuf_iterator<char>());
-  const gpu::FlatPopulation flat = gpu::flattenVcf1000(text);
+  if (vcf_flavour_ == "Genome1000") return sweepFlat(gpu::flattenVcf1000(text), file_name);
+  if (vcf_flavour_ != "Falciparum") {
+    ExecEnv::log().error("GpuAlleleAnalysis; unknown VcfFlavour: {} (Genome1000 or Falciparum)", vcf_flavour_);
+    return false;
+  }
+  const gpu::FlatPopulation flat = gpu::flattenVcfPf(text, 0, pf7_quality_filter_);
+  // every genome holds every contig of the header, carrier or not (PfVCFImpl::setupPopulationStructure): zero records
+  for (const auto& genome_id : flat.genome_ids) {
+    auto& contig_map = variant_analysis_map_[genome_id];
+    for (const auto& contig_id : flat.contig_ids) contig_map.try_emplace(contig_id);
+  }
   return sweepFlat(flat, file_name);
 }
 
@@ -198,7 +212,7 @@ bool kga::GpuAlleleAnalysis::sweepFlat(const gpu::FlatPopulation& flat, const st
     for (uint64_t g = 0; g < G; ++g) {
       auto& contig_map = variant_analysis_map_[flat.genome_ids[g]];
       for (uint32_t c = 0; c < n_contigs; ++c) {
-        VariantAnalysisType& record = contig_map[contig_ids[c]];
+        VariantAnalysisType record;
         uint64_t copies_snp = 0, copies_indel = 0;
         for (uint32_t cls = 0; cls < 4; ++cls) {
           const uint64_t* k = &by_genome[(g * n_bins + c * 4 + cls) * 4];   // refHom, het, hom, nonDiploid
@@ -218,6 +232,20 @@ bool kga::GpuAlleleAnalysis::sweepFlat(const gpu::FlatPopulation& flat, const st
         record.homozygous_minor_alleles_ += k8[1];
         record.heterozygous_minor_alleles_ += k8[2];
         // homozygous_reference_alleles_ is never incremented by the reference.
+        // A genome holds a contig only if it carries a variant there (or the parser created it up front): no carrier,
+        // no pre-existing record -> no record, as when the reference walks the genome's own contig map.
+        auto found = contig_map.find(contig_ids[c]);
+        if (found == contig_map.end()) {
+          if (record.total_variants_ == 0) continue;
+          found = contig_map.try_emplace(contig_ids[c]).first;
+        }
+        VariantAnalysisType& sum = found->second;
+        sum.total_variants_ += record.total_variants_;
+        sum.snp_count_ += record.snp_count_;
+        sum.indel_count_ += record.indel_count_;
+        sum.heterozygous_reference_minor_alleles_ += record.heterozygous_reference_minor_alleles_;
+        sum.homozygous_minor_alleles_ += record.homozygous_minor_alleles_;
+        sum.heterozygous_minor_alleles_ += record.heterozygous_minor_alleles_;
       }
     }
   }

@@ -88,6 +88,8 @@ class GpuAlleleAnalysis : public VirtualAnalysis {
   bool writeHetHomResults(const std::string& file_name) const;
 
   std::string work_directory_;
+  std::string vcf_flavour_{"Genome1000"};
+  bool pf7_quality_filter_{false};
   std::string variant_file_{"VariantFWS"}, genome_file_{"GenomeFWS"}, hethom_file_{"VariantStatistics"};
   int device_{0};
   bool device_ready_{false};

@@ -43,6 +43,7 @@ struct FlatPopulation {
   std::vector<uint8_t> packed;             // [rows][row_bytes] 2-bit dosage codes, genome g in bits 2*(g%4) of byte g/4
   std::vector<NonDiploidCell> non_diploid;
   size_t variant_objects{0};               // Variant visits (= PopulationDB::variantCount())
+  std::vector<ContigId_t> contig_ids;      // contigs EVERY genome holds, carrier or not (Pf flavour: the ##contig header lines)
 
   [[nodiscard]] size_t genomes() const { return genome_ids.size(); }
   [[nodiscard]] size_t variants() const { return rows.size(); }
@@ -55,6 +56,13 @@ struct FlatPopulation {
 // reference's Genome1000VCFImpl parser would flatten to — without creating Variant objects.
 // VariantRow::variant is left null.  Implemented in kgx_vcf_flatten.cpp.
 [[nodiscard]] FlatPopulation flattenVcf1000(std::string_view text, size_t threads = 0);
+
+// The same for the unphased P. falciparum (Pf7) flavour, PfVCFImpl (kgl_parser/kgl_variant_factory_pf_impl.cpp): every
+// sample is a genome, every called alt copy a canonical UNPHASED Variant unless it is the '*' allele or a spanning call
+// (AD 0,0).  quality_filter: records failing P7VariantFilter (kgl_variant_filter_Pf7.cpp:131-318) contribute nothing, as
+// after FilterPf7::qualityFilter's viewFilter (kga_analysis_lib_PfFilter.cpp:63-67).  Not reproduced: the check of REF
+// against the reference genome's sequence (ParseVCFRecord) -- the VCF is taken at its word.
+[[nodiscard]] FlatPopulation flattenVcfPf(std::string_view text, size_t threads = 0, bool quality_filter = false);
 
 // P7FrequencyFilter / CalcFWS bins on the "AF" INFO value of a row (kgl_variant_filter_Pf7.cpp:20-66,
 // kga_analysis_PfEMP_FWS.cpp:15-38,104-145): bin index 0..10, or 0xFF when the row is in no bin

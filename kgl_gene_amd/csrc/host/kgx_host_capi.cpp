@@ -14,6 +14,11 @@ void* kgxh_flatten_vcf1000(const char* text, uint64_t len, int threads) {
   return flat;
 }
 
+void* kgxh_flatten_vcf_pf(const char* text, uint64_t len, int threads, int quality_filter) {
+  if (!text) return nullptr;
+  return new FlatPopulation(kellerberrin::genome::analysis::gpu::flattenVcfPf(std::string_view(text, len), threads > 0 ? threads : 0, quality_filter != 0));
+}
+
 void kgxh_flat_destroy(void* h) { delete static_cast<FlatPopulation*>(h); }
 uint64_t kgxh_flat_genomes(void* h) { return h ? static_cast<FlatPopulation*>(h)->genomes() : 0; }
 uint64_t kgxh_flat_variants(void* h) { return h ? static_cast<FlatPopulation*>(h)->variants() : 0; }

@@ -7,6 +7,13 @@
 // would flatten to through flattenPopulation(): genomes exist only if they carry a variant, variants only if some
 // genome carries them, rows in lexicographic HGVS order, dosage = copies of the HGVS in the genome.
 // Records are independent, so they are parsed by a pool of threads straight into 2-bit rows.
+//
+// flattenVcfPf is the same for the reference's unphased P. falciparum (Pf7) parser,
+//   PfVCFImpl::ParseRecord / setupPopulationStructure   (kgl_parser/kgl_variant_factory_pf_impl.cpp:73-422)
+//   Variant::canonicalSequences                         (kgl_variant_db/kgl_variant_db.cpp:165-220)
+// optionally followed by the per-record quality filter the PfEMP package applies before it counts,
+//   P7VariantFilter::applyFilter                        (kgl_variant_filter/kgl_variant_filter_Pf7.cpp:131-318,
+//                                                        called from kga_analysis_lib_PfFilter.cpp:63-67).
 #include <algorithm>
 #include <atomic>
 #include <cctype>
@@ -130,14 +137,14 @@ struct RecordRows {            // what one VCF record contributes
   std::vector<uint8_t> copies;           // [n_alt][n_samples] copies of the alt in the sample (0..2)
 };
 
-}  // namespace
+struct VcfLines {
+  std::vector<std::string> samples;            // #CHROM columns 10..
+  std::vector<std::string> contigs;            // ##contig=<ID=...> header lines, in file order
+  std::vector<std::string_view> records;       // every non-empty line not starting with '#'
+};
 
-FlatPopulation flattenVcf1000(std::string_view text, size_t threads) {
-  if (threads == 0) threads = std::max<size_t>(std::thread::hardware_concurrency(), 2) - 1;
-
-  // Lines: sample names from the #CHROM header, records = every non-empty line not starting with '#'.
-  std::vector<std::string> samples;
-  std::vector<std::string_view> records;
+VcfLines scanLines(std::string_view text) {
+  VcfLines out;
   for (size_t begin = 0; begin <= text.size();) {
     size_t end = text.find('\n', begin);
     if (end == std::string_view::npos) end = text.size();
@@ -147,88 +154,67 @@ FlatPopulation flattenVcf1000(std::string_view text, size_t threads) {
       if (line[0] == '#') {
         if (line.rfind("#CHROM", 0) == 0) {
           const auto f = split(line, '\t');
-          for (size_t i = 9; i < f.size(); ++i) samples.emplace_back(f[i]);
+          for (size_t i = 9; i < f.size(); ++i) out.samples.emplace_back(f[i]);
+        } else if (line.rfind("##contig=<", 0) == 0) {
+          const size_t id = line.find("ID=");
+          if (id != std::string_view::npos) {
+            size_t stop = line.find_first_of(",>", id);
+            if (stop == std::string_view::npos) stop = line.size();
+            out.contigs.emplace_back(line.substr(id + 3, stop - id - 3));
+          }
         }
       } else {
-        records.push_back(line);
+        out.records.push_back(line);
       }
     }
     begin = end + 1;
   }
-  const size_t S = samples.size();
+  return out;
+}
 
-  std::vector<RecordRows> parsed(records.size());
+template <typename ParseRecord>
+std::vector<RecordRows> parseRecords(const VcfLines& lines, size_t threads, ParseRecord parse) {
+  if (threads == 0) threads = std::max<size_t>(std::thread::hardware_concurrency(), 2) - 1;
+  std::vector<RecordRows> parsed(lines.records.size());
   std::atomic<size_t> next{0};
   auto worker = [&]() {
-    for (size_t r = next.fetch_add(1); r < records.size(); r = next.fetch_add(1)) {
-      const auto f = split(records[r], '\t', S + 10);
-      if (f.size() < 8) continue;                                    // fewer than the mandatory fields: record dropped
-      const std::string_view contig = f[0];
-      bool pos_ok = true;
-      const uint64_t pos = parseIndex(f[1], pos_ok);
-      if (!pos_ok) continue;
-      const uint64_t offset = pos - 1;                               // VCF positions are 1-based
-      const std::string_view ref = f[3];
-      const std::string_view alt_field = f[4] == "." ? std::string_view() : f[4];
-      const auto alts = split(alt_field, ',');
-      const size_t A = alts.size();
-      // INFO "AF": one value per alt, or a single value for all
-      std::vector<float> af(A, std::numeric_limits<float>::quiet_NaN());
-      bool af_bad_size = false;
-      for (const auto item : split(f[7], ';')) {
-        if (item.size() > 3 && item.substr(0, 3) == "AF=") {
-          const auto values = split(item.substr(3), ',');
-          if (values.size() == A) for (size_t a = 0; a < A; ++a) af[a] = infoFloat(values[a]);
-          else af_bad_size = true;                                   // P7FrequencyFilter errors out on a size mismatch: in no bin
-        }
-      }
-      RecordRows& out = parsed[r];
-      out.rows.resize(A);
-      out.copies.assign(A * S, 0);
-      for (size_t a = 0; a < A; ++a) {
-        VariantRow& row = out.rows[a];
-        row.contig = std::string(contig);
-        row.offset = offset;
-        row.hgvs = row.contig + ":g." + std::to_string(offset) + std::string(ref) + ">" + std::string(alts[a]);
-        row.is_snp = isSnp(ref, alts[a]);
-        row.info_af = af_bad_size ? std::numeric_limits<float>::infinity() : af[a];
-      }
-      const Chromosome chrom = chromosomeOf(contig);
-      uint8_t* copies = out.copies.data();
-      for (size_t idx = 9; idx < f.size() && idx - 9 < S; ++idx) {
-        uint32_t pa, pb;
-        phasedAlleles(f[idx], A, chrom, pa, pb);
-        if (pa) ++copies[(pa - 1) * S + (idx - 9)];
-        if (pb) ++copies[(pb - 1) * S + (idx - 9)];
-      }
-    }
+    for (size_t r = next.fetch_add(1); r < lines.records.size(); r = next.fetch_add(1)) parse(lines.records[r], parsed[r]);
   };
-  {
-    const size_t n = std::max<size_t>(1, std::min(threads, records.size()));
-    std::vector<std::thread> pool;
-    for (size_t t = 1; t < n; ++t) pool.emplace_back(worker);
-    worker();
-    for (auto& th : pool) th.join();
-  }
+  const size_t n = std::max<size_t>(1, std::min(threads, lines.records.size()));
+  std::vector<std::thread> pool;
+  for (size_t t = 1; t < n; ++t) pool.emplace_back(worker);
+  worker();
+  for (auto& th : pool) th.join();
+  return parsed;
+}
 
-  // Variants: rows in lexicographic HGVS order; records repeating an HGVS add their copies.
+// Variants: rows in lexicographic HGVS order; records repeating an HGVS add their copies.  every_sample: all samples are
+// genomes (the Pf parser creates them up front); otherwise only carriers exist (the 1000-Genomes parser creates a genome
+// when it first adds a variant to it).
+FlatPopulation mergeRecords(const std::vector<RecordRows>& parsed, const std::vector<std::string>& samples, bool every_sample) {
+  const size_t S = samples.size();
   struct Key { const std::string* hgvs; uint32_t record, alt; };
   std::vector<Key> keys;
   for (uint32_t r = 0; r < parsed.size(); ++r)
     for (uint32_t a = 0; a < parsed[r].rows.size(); ++a) keys.push_back({&parsed[r].rows[a].hgvs, r, a});
   std::stable_sort(keys.begin(), keys.end(), [](const Key& x, const Key& y) { return *x.hgvs < *y.hgvs; });
 
-  // Genomes exist only if they carry something (the parser creates them in addVariant); std::map order.
-  std::vector<uint8_t> carries(S, 0);
-  for (const auto& rec : parsed)
-    for (size_t i = 0; i < rec.copies.size(); ++i)
-      if (rec.copies[i]) carries[i % S] = 1;
+  std::vector<uint8_t> carries(S, every_sample ? 1 : 0);
+  if (!every_sample)
+    for (const auto& rec : parsed)
+      for (size_t i = 0; i < rec.copies.size(); ++i)
+        if (rec.copies[i]) carries[i % S] = 1;
   std::vector<uint32_t> sample_order;
   for (uint32_t s = 0; s < S; ++s) if (carries[s]) sample_order.push_back(s);
   std::sort(sample_order.begin(), sample_order.end(), [&](uint32_t x, uint32_t y) { return samples[x] < samples[y]; });
-
+  // a sample named twice is one genome (std::map): its columns add up
   FlatPopulation flat;
-  for (uint32_t s : sample_order) flat.genome_ids.push_back(samples[s]);
+  std::vector<std::vector<uint32_t>> columns_of;      // genome -> sample columns
+  for (uint32_t s : sample_order) {
+    if (!flat.genome_ids.empty() && flat.genome_ids.back() == samples[s]) { columns_of.back().push_back(s); continue; }
+    flat.genome_ids.push_back(samples[s]);
+    columns_of.push_back({s});
+  }
   const size_t G = flat.genome_ids.size();
   flat.row_bytes = (G + 3) / 4;
   std::vector<uint32_t> total(S);
@@ -243,11 +229,18 @@ FlatPopulation flattenVcf1000(std::string_view text, size_t threads) {
     }
     if (any) {                                      // a variant nobody carries never reaches the PopulationDB
       const uint32_t row_index = static_cast<uint32_t>(flat.rows.size());
-      flat.rows.push_back(parsed[keys[k].record].rows[keys[k].alt]);      // the first record's Variant is kept (uniqueVariants)
+      // the Variant kept for an HGVS is the first one added (uniqueVariants): the first record that has a carrier
+      size_t first = k;
+      for (size_t m = k; m < e; ++m) {
+        const uint8_t* c = &parsed[keys[m].record].copies[static_cast<size_t>(keys[m].alt) * S];
+        if (std::any_of(c, c + S, [](uint8_t x) { return x != 0; })) { first = m; break; }
+      }
+      flat.rows.push_back(parsed[keys[first].record].rows[keys[first].alt]);
       const size_t base = flat.packed.size();
       flat.packed.resize(base + flat.row_bytes, 0);
       for (size_t g = 0; g < G; ++g) {
-        const uint32_t d = total[sample_order[g]];
+        uint32_t d = 0;
+        for (uint32_t column : columns_of[g]) d += total[column];
         flat.variant_objects += d;
         flat.packed[base + g / 4] |= static_cast<uint8_t>((d > 2 ? 3u : d) << (2 * (g % 4)));
         if (d > 2) flat.non_diploid.push_back({row_index, static_cast<uint32_t>(g), d});
@@ -255,6 +248,228 @@ FlatPopulation flattenVcf1000(std::string_view text, size_t threads) {
     }
     k = e;
   }
+  return flat;
+}
+
+// "AF" of the INFO column: one value per alt; a size mismatch is flagged with +inf (P7FrequencyFilter errors out: in no bin).
+void readInfoAf(std::string_view info, size_t A, std::vector<float>& af, bool& af_bad_size) {
+  af.assign(A, std::numeric_limits<float>::quiet_NaN());
+  af_bad_size = false;
+  for (const auto item : split(info, ';')) {
+    if (item.size() > 3 && item.substr(0, 3) == "AF=") {
+      const auto values = split(item.substr(3), ',');
+      if (values.size() == A) for (size_t a = 0; a < A; ++a) af[a] = infoFloat(values[a]);
+      else af_bad_size = true;
+    }
+  }
+}
+
+}  // namespace
+
+FlatPopulation flattenVcf1000(std::string_view text, size_t threads) {
+  const VcfLines lines = scanLines(text);
+  const size_t S = lines.samples.size();
+  const auto parsed = parseRecords(lines, threads, [&](std::string_view record, RecordRows& out) {
+    const auto f = split(record, '\t', S + 10);
+    if (f.size() < 8) return;                                      // fewer than the mandatory fields: record dropped
+    const std::string_view contig = f[0];
+    bool pos_ok = true;
+    const uint64_t pos = parseIndex(f[1], pos_ok);
+    if (!pos_ok) return;
+    const uint64_t offset = pos - 1;                               // VCF positions are 1-based
+    const std::string_view ref = f[3];
+    const std::string_view alt_field = f[4] == "." ? std::string_view() : f[4];
+    const auto alts = split(alt_field, ',');
+    const size_t A = alts.size();
+    std::vector<float> af;
+    bool af_bad_size = false;
+    readInfoAf(f[7], A, af, af_bad_size);
+    out.rows.resize(A);
+    out.copies.assign(A * S, 0);
+    for (size_t a = 0; a < A; ++a) {
+      VariantRow& row = out.rows[a];
+      row.contig = std::string(contig);
+      row.offset = offset;
+      row.hgvs = row.contig + ":g." + std::to_string(offset) + std::string(ref) + ">" + std::string(alts[a]);
+      row.is_snp = isSnp(ref, alts[a]);
+      row.info_af = af_bad_size ? std::numeric_limits<float>::infinity() : af[a];
+    }
+    const Chromosome chrom = chromosomeOf(contig);
+    uint8_t* copies = out.copies.data();
+    for (size_t idx = 9; idx < f.size() && idx - 9 < S; ++idx) {
+      uint32_t pa, pb;
+      phasedAlleles(f[idx], A, chrom, pa, pb);
+      if (pa) ++copies[(pa - 1) * S + (idx - 9)];
+      if (pb) ++copies[(pb - 1) * S + (idx - 9)];
+    }
+  });
+  return mergeRecords(parsed, lines.samples, false);
+}
+
+namespace {
+
+// std::stoll as the reference uses it on a GT / AD token: white space, optional sign, digits; anything after is ignored.
+// throws = true where std::stoll throws (no digits: invalid_argument; past int64: out_of_range).
+int64_t parseLongLong(std::string_view s, bool& throws) {
+  size_t i = 0;
+  while (i < s.size() && std::isspace(static_cast<unsigned char>(s[i]))) ++i;
+  bool negative = false;
+  if (i < s.size() && (s[i] == '+' || s[i] == '-')) { negative = s[i] == '-'; ++i; }
+  if (i >= s.size() || !std::isdigit(static_cast<unsigned char>(s[i]))) { throws = true; return 0; }
+  uint64_t v = 0;
+  const uint64_t limit = negative ? (1ull << 63) : (1ull << 63) - 1;
+  for (; i < s.size() && std::isdigit(static_cast<unsigned char>(s[i])); ++i) {
+    const uint64_t d = static_cast<uint64_t>(s[i] - '0');
+    if (v > (limit - d) / 10) { throws = true; return 0; }
+    v = v * 10 + d;
+  }
+  return negative ? -static_cast<int64_t>(v) : static_cast<int64_t>(v);
+}
+
+bool allDigits(std::string_view s) { return s.find_first_not_of("0123456789") == std::string_view::npos; }
+
+// Variant::canonicalSequences, on text.
+void canonicalSequences(std::string_view ref, std::string_view alt, uint64_t offset, std::string& c_ref, std::string& c_alt, uint64_t& c_offset) {
+  const bool canonical = (ref.size() == 1 && alt.size() == 1) || (alt.size() == 1 && ref.size() > 1) || (ref.size() == 1 && alt.size() > 1);
+  if (canonical) { c_ref = std::string(ref); c_alt = std::string(alt); c_offset = offset; return; }
+  const size_t common = std::min(ref.size(), alt.size());
+  size_t prefix = 0;
+  while (prefix < common && ref[prefix] == alt[prefix]) ++prefix;
+  prefix = prefix > 0 ? prefix - 1 : 0;                              // keeps one base in front: '1MnD' / '1MnI'
+  size_t suffix = 0;
+  while (suffix < common && ref[ref.size() - 1 - suffix] == alt[alt.size() - 1 - suffix]) ++suffix;
+  int64_t adjusted = static_cast<int64_t>(std::min(common - prefix - 1, suffix));      // unsigned, as the reference computes it
+  if (adjusted < 0) adjusted = 0;
+  auto strip = [&](std::string_view s) {
+    const size_t from = std::min(prefix, s.size());
+    const size_t to = s.size() - std::min(static_cast<size_t>(adjusted), s.size());
+    return to > from ? std::string(s.substr(from, to - from)) : std::string();
+  };
+  c_ref = strip(ref);
+  c_alt = strip(alt);
+  c_offset = offset + prefix;
+}
+
+// A scalar Float INFO value as getTypedInfoData<double> delivers it: nothing for a missing value.
+bool infoScalar(std::string_view info, std::string_view key, double& value) {
+  for (const auto item : split(info, ';')) {
+    if (item.size() <= key.size() || item[key.size()] != '=' || item.substr(0, key.size()) != key) continue;
+    const std::string text(item.substr(key.size() + 1));
+    if (text.size() == 3) {
+      std::string upper = text;
+      for (auto& c : upper) c = static_cast<char>(std::toupper(static_cast<unsigned char>(c)));
+      if (upper == "NAN") return false;
+    }
+    try {
+      value = static_cast<double>(std::stof(text));
+      return true;
+    } catch (const std::out_of_range&) {
+      std::string upper = text;
+      for (auto& c : upper) c = static_cast<char>(std::toupper(static_cast<unsigned char>(c)));
+      if (upper.find("E-") != std::string::npos) { value = std::numeric_limits<float>::min(); return true; }
+      if (upper.find('E') != std::string::npos) { value = std::numeric_limits<float>::max(); return true; }
+      return false;
+    } catch (...) {
+      return false;
+    }
+  }
+  return false;
+}
+
+bool passesP7VariantFilter(std::string_view info, std::string_view contig) {
+  double x = 0.0;
+  if (infoScalar(info, "VQSLOD", x)) return x >= 0.0;                 // when present, the only test
+  if (infoScalar(info, "QD", x) && !(x >= 2.0)) return false;
+  if (infoScalar(info, "MQ", x) && !(x >= (contig == "Pf3D7_MIT_v3" ? 5.0 : 30.0))) return false;
+  if (infoScalar(info, "SOR", x) && !(x <= 3.0)) return false;
+  if (infoScalar(info, "MQRankSum", x) && !(x >= -12.5)) return false;
+  if (infoScalar(info, "ReadPosRankSum", x) && !(x >= -8.0)) return false;
+  return true;
+}
+
+}  // namespace
+
+FlatPopulation flattenVcfPf(std::string_view text, size_t threads, bool quality_filter) {
+  const VcfLines lines = scanLines(text);
+  const size_t S = lines.samples.size();
+  const auto parsed = parseRecords(lines, threads, [&](std::string_view record, RecordRows& out) {
+    const auto f = split(record, '\t', S + 10);
+    if (f.size() < 9) return;
+    const std::string_view contig = f[0];
+    bool pos_ok = true;
+    const uint64_t pos = parseIndex(f[1], pos_ok);
+    if (!pos_ok) return;
+    const uint64_t offset = pos - 1;
+    const std::string_view ref = f[3];
+    const auto alts = split(f[4], ',');
+    const size_t A = alts.size();
+    const auto format = split(f[8], ':');
+    size_t gt_index = format.size(), ad_index = format.size();
+    for (size_t i = format.size(); i-- > 0;) {                       // formatIndex: the first match
+      if (format[i] == "GT") gt_index = i;
+      if (format[i] == "AD") ad_index = i;
+    }
+    if (gt_index == format.size() || ad_index == format.size()) return;   // both are required
+    if (quality_filter && !passesP7VariantFilter(f[7], contig)) return;    // every Variant of the record is filtered out
+    std::vector<float> af;
+    bool af_bad_size = false;
+    readInfoAf(f[7], A, af, af_bad_size);
+    out.rows.resize(A);
+    out.copies.assign(A * S, 0);
+    for (size_t a = 0; a < A; ++a) {
+      VariantRow& row = out.rows[a];
+      std::string c_ref, c_alt;
+      uint64_t c_offset = 0;
+      canonicalSequences(ref, alts[a], offset, c_ref, c_alt, c_offset);
+      row.contig = std::string(contig);
+      row.offset = c_offset;
+      row.hgvs = row.contig + ":g." + std::to_string(c_offset) + c_ref + ">" + c_alt;
+      row.is_snp = isSnp(c_ref, c_alt);
+      row.info_af = af_bad_size ? std::numeric_limits<float>::infinity() : af[a];
+    }
+    uint8_t* copies = out.copies.data();
+    std::vector<uint64_t> depth;
+    for (size_t idx = 9; idx < f.size() && idx - 9 < S; ++idx) {
+      const auto fields = split(f[idx], ':');
+      if (fields.size() <= gt_index) continue;
+      const std::string_view gt = fields[gt_index];
+      auto parts = split(gt, '/');
+      if (parts.size() != 2) {
+        parts = split(gt, '|');
+        if (parts.size() != 2) continue;                              // missing, or not diploid
+      }
+      // the reference tests parts[0] for digits before converting EITHER part; a conversion that throws ends the record
+      bool throws = false;
+      int64_t a_allele = 0, b_allele = 0;
+      if (allDigits(parts[0])) {
+        a_allele = parseLongLong(parts[0], throws);
+        if (throws) break;
+        b_allele = parseLongLong(parts[1], throws);
+        if (throws) break;
+      }
+      if (a_allele == 0 && b_allele == 0) continue;
+      if (fields.size() <= ad_index) continue;
+      const auto ad = split(fields[ad_index], ',');
+      if (ad.size() != A + 1) continue;
+      depth.clear();
+      for (const auto token : ad) {
+        if (!allDigits(token)) continue;                              // logged, not stored
+        depth.push_back(static_cast<uint64_t>(parseLongLong(token, throws)));
+        if (throws) break;
+      }
+      if (throws) break;
+      for (const int64_t allele : {a_allele, b_allele}) {
+        if (allele == 0) continue;
+        // past the alt list or the stored depths the reference reads out of bounds (undefined): such a call is skipped
+        if (allele < 0 || static_cast<uint64_t>(allele) > A || static_cast<uint64_t>(allele) >= depth.size()) continue;
+        if (alts[allele - 1] == "*") continue;                        // upstream deletion
+        if (depth[0] == 0 && depth[allele] == 0) continue;            // the spanning ("downstream") call of one
+        ++copies[(allele - 1) * S + (idx - 9)];
+      }
+    }
+  });
+  FlatPopulation flat = mergeRecords(parsed, lines.samples, true);
+  flat.contig_ids = lines.contigs;
   return flat;
 }
 

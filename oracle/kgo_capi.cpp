@@ -48,6 +48,9 @@ static void fillResults(const LocusResults& r, uint64_t* counts, double* freqs) 
 namespace kgo {
 std::pair<size_t, size_t> alternateIndex1000(const std::string& contig, const std::string& genotype, size_t n_alt);
 long addVcf1000(PopulationDB& population, std::string_view text, std::vector<std::string>* genome_names_out);
+long addVcfPf(PopulationDB& population, std::string_view text, std::vector<std::string>* genome_names_out);
+bool p7VariantFilter(const Variant& v);
+void canonicalSequences(const std::string& ref, const std::string& alt, uint64_t offset, std::string& c_ref, std::string& c_alt, uint64_t& c_offset);
 }
 
 extern "C" {
@@ -150,6 +153,34 @@ long kgo_population_add_vcf_1000(kgo_pop* p, const char* text, uint64_t len) {
   const long n = addVcf1000(*p->pop, std::string_view(text, len), &names);
   if (p->input_ids.empty()) p->input_ids = names;
   return n;
+}
+
+// VCF text (unphased P. falciparum flavour) -> Variants in the population; returns the record count (or -1).
+long kgo_population_add_vcf_pf(kgo_pop* p, const char* text, uint64_t len) {
+  if (!p || !text) return -1;
+  std::vector<std::string> names;
+  const long n = addVcfPf(*p->pop, std::string_view(text, len), &names);
+  if (p->input_ids.empty()) p->input_ids = names;
+  return n;
+}
+
+// PopulationDB::viewFilter(P7VariantFilter()) (kga_analysis_lib_PfFilter.cpp:63-67).
+kgo_pop* kgo_population_filter_p7(kgo_pop* p) {
+  if (!p) return nullptr;
+  auto* out = new kgo_pop();
+  out->pop = std::shared_ptr<PopulationDB>(p->pop->viewFilter([](const Variant& v) { return p7VariantFilter(v); }));
+  out->input_ids = p->input_ids;
+  return out;
+}
+
+// Variant::canonicalSequences on text; ref_out / alt_out hold at least len(ref) + len(alt) + 1 bytes.
+uint64_t kgo_canonical(const char* ref, const char* alt, uint64_t offset, char* ref_out, char* alt_out) {
+  std::string r, a;
+  uint64_t o = 0;
+  canonicalSequences(ref, alt, offset, r, a, o);
+  std::strcpy(ref_out, r.c_str());
+  std::strcpy(alt_out, a.c_str());
+  return o;
 }
 
 int kgo_gt_alternate_index(const char* contig, const char* genotype, uint64_t n_alt, uint64_t out[2]) {
@@ -391,6 +422,16 @@ int kgo_hethom(kgo_pop* p, const char* contig, uint64_t* out) {
     o[6] = r.homozygous_reference_alleles_;
     ++g;
   }
+  return 0;
+}
+
+// 1 where the genome's record map holds the contig at all (a genome holds a contig once a variant was added to it, or
+// when the parser created it up front).
+int kgo_hethom_present(kgo_pop* p, const char* contig, uint8_t* out) {
+  if (!p || !contig || !out) return -1;
+  auto result = analyzeVariantPopulation(*p->pop);
+  size_t g = 0;
+  for (const auto& [genome_id, contig_map] : result) out[g++] = contig_map.count(contig) ? 1 : 0;
   return 0;
 }
 

@@ -53,6 +53,14 @@ struct RecordEvidence {
   uint32_t alt_count = 0;
   std::vector<float> af;   // [SUPER_POP_COUNT][alt_count]
   int info_af_size = -2;   // number of values in the raw "AF" INFO vector; -1 = field absent; -2 = same as alt_count
+  // Scalar Float INFO fields that hold a value (a missing value is not stored): what
+  // InfoEvidenceAnalysis::getTypedInfoData<double> returns (kgl_variant_factory_vcf_evidence_analysis.h:141-166).
+  std::vector<std::pair<std::string, float>> info_scalar;
+  std::optional<double> infoScalar(const std::string& field) const {
+    for (const auto& [name, value] : info_scalar)
+      if (name == field) return static_cast<double>(value);
+    return std::nullopt;
+  }
 };
 
 class Variant {

@@ -1,5 +1,10 @@
 // ORACLE — TEST INFRASTRUCTURE ONLY.  PARITY UNPINNED (see kgo_core.h).
-// VCF text -> PopulationDB for the phased-diploid (1000 Genomes) flavour, restated from
+// VCF text -> PopulationDB.  The unphased P. falciparum (Pf7) flavour, at the end of the file, restates
+//   PfVCFImpl::ParseRecord / setupPopulationStructure / createAddVariant   kgl_parser/kgl_variant_factory_pf_impl.cpp:73-467
+//   Variant::canonicalSequences / isCanonical                              kgl_variant_db/kgl_variant_db.cpp:165-220
+//   AlphabetString::commonPrefix / commonSuffix / removePrefixSuffix       kgl_sequence/kgl_alphabet_string.h:249-314
+//   P7VariantFilter::applyFilter                                           kgl_variant_filter/kgl_variant_filter_Pf7.cpp:131-318
+// The phased-diploid (1000 Genomes) flavour is restated from
 //   ParseVCF::moveToVcfRecord                 kgl_genomics/kgl_parser/kgl_variant_vcf_impl.cpp:96-170
 //   Genome1000VCFImpl::ParseRecord            kgl_parser/kgl_variant_factory_1000_impl.cpp:63-145
 //   Genome1000VCFImpl::alternateIndex         :148-272   (constants kgl_variant_factory_1000_impl.h:55-63)
@@ -169,6 +174,193 @@ long addVcf1000(PopulationDB& population, std::string_view text, std::vector<std
     }
     ++n_records;
   }
+  if (genome_names_out) *genome_names_out = genome_names;
+  return n_records;
+}
+
+// ---- the unphased P. falciparum flavour ---------------------------------------------------------------------------
+
+// Variant::canonicalSequences: SNPs as '1X', deletes as '1MnD', inserts as '1MnI'; everything else loses its common
+// prefix (all but one base) and suffix, with the reference's unsigned arithmetic.
+void canonicalSequences(const std::string& ref, const std::string& alt, uint64_t offset, std::string& c_ref, std::string& c_alt,
+                        uint64_t& c_offset) {
+  const bool canonical = (ref.size() == 1 && alt.size() == 1) || (alt.size() == 1 && ref.size() > alt.size()) ||
+                         (ref.size() == 1 && ref.size() < alt.size());
+  if (canonical) {
+    c_ref = ref; c_alt = alt; c_offset = offset;
+    return;
+  }
+  const size_t common_size = std::min(ref.size(), alt.size());
+  size_t prefix_size = 0;
+  while (prefix_size < common_size && ref[prefix_size] == alt[prefix_size]) ++prefix_size;
+  prefix_size = prefix_size > 0 ? (prefix_size - 1) : 0;
+  size_t suffix_size = 0;
+  while (suffix_size < common_size && ref[ref.size() - 1 - suffix_size] == alt[alt.size() - 1 - suffix_size]) ++suffix_size;
+  const size_t min_size = common_size;
+  int64_t adj_suffix_size = static_cast<int64_t>(std::min(min_size - prefix_size - 1, suffix_size));   // size_t arithmetic, as written
+  adj_suffix_size = adj_suffix_size < 0 ? 0 : adj_suffix_size;
+  auto remove = [&](const std::string& s) {
+    // std::ranges::next(begin, n, end) / prev(end, n, begin): bounded steps; empty if nothing is left
+    const size_t from = std::min(prefix_size, s.size());
+    const size_t drop = std::min(static_cast<size_t>(adj_suffix_size), s.size());
+    const size_t to = s.size() - drop;
+    return to > from ? s.substr(from, to - from) : std::string();
+  };
+  c_ref = remove(ref);
+  c_alt = remove(alt);
+  c_offset = offset + prefix_size;
+}
+
+static bool allDigits(const std::string& s) { return s.find_first_not_of("0123456789") == std::string::npos; }
+
+// VCFInfoParser::convertToFloat with "missing" kept apart from a value (kgl_variant_factory_vcf_parse_info.cpp:206-279).
+static std::optional<float> convertToFloatValue(const std::string& value) {
+  if (value.size() == 3) {
+    std::string uc;
+    for (char c : value) uc += static_cast<char>(std::toupper(static_cast<unsigned char>(c)));
+    if (uc == "NAN") return std::nullopt;
+  }
+  try {
+    return std::stof(value);
+  } catch (std::out_of_range&) {
+    std::string uc;
+    for (char c : value) uc += static_cast<char>(std::toupper(static_cast<unsigned char>(c)));
+    if (uc.find("E-") != std::string::npos) return std::numeric_limits<float>::min();
+    if (uc.find("E") != std::string::npos) return std::numeric_limits<float>::max();
+    return std::nullopt;
+  } catch (...) {
+    return std::nullopt;
+  }
+}
+
+// P7VariantFilter::applyFilter: VQSLOD alone when the record has it, else every other threshold the record has a value for.
+bool p7VariantFilter(const Variant& v) {
+  const RecordEvidence& ev = v.evidence();
+  if (auto x = ev.infoScalar("VQSLOD")) return x.value() >= 0.0;
+  if (auto x = ev.infoScalar("QD"); x && !(x.value() >= 2.0)) return false;
+  if (auto x = ev.infoScalar("MQ")) {
+    const double mq_level = v.contigId() == "Pf3D7_MIT_v3" ? 5.0 : 30.0;
+    if (!(x.value() >= mq_level)) return false;
+  }
+  if (auto x = ev.infoScalar("SOR"); x && !(x.value() <= 3.0)) return false;
+  if (auto x = ev.infoScalar("MQRankSum"); x && !(x.value() >= -12.5)) return false;
+  if (auto x = ev.infoScalar("ReadPosRankSum"); x && !(x.value() >= -8.0)) return false;
+  return true;
+}
+
+// text -> records -> UNPHASED canonical Variants, one per called alt copy.  Every sample of the #CHROM line becomes a
+// genome holding every contig of the ##contig header lines (setupPopulationStructure), carrier or not.
+long addVcfPf(PopulationDB& population, std::string_view text, std::vector<std::string>* genome_names_out) {
+  std::vector<std::string> genome_names, header_contigs;
+  bool structure_done = false;
+  auto setupPopulationStructure = [&]() {
+    if (structure_done) return;
+    structure_done = true;
+    for (const auto& genome_id : genome_names) {
+      auto genome = population.getCreateGenome(genome_id);
+      for (const auto& contig : header_contigs) genome->getCreateContig(contig);
+    }
+  };
+  long n_records = 0;
+  for (auto line : viewTokenizer(text, '\n')) {
+    if (!line.empty() && line.back() == '\r') line.remove_suffix(1);
+    if (line.empty()) continue;
+    if (line[0] == '#') {
+      if (line.rfind("##contig=<", 0) == 0) {
+        const size_t id = line.find("ID=");
+        if (id != std::string_view::npos) {
+          size_t end = line.find_first_of(",>", id);
+          if (end == std::string_view::npos) end = line.size();
+          header_contigs.emplace_back(line.substr(id + 3, end - id - 3));
+        }
+      } else if (line.rfind("#CHROM", 0) == 0) {
+        auto f = viewTokenizer(line, '\t');
+        for (size_t i = 9; i < f.size(); ++i) genome_names.emplace_back(f[i]);
+      }
+      continue;
+    }
+    setupPopulationStructure();
+    auto field_views = viewTokenizer(line, '\t');
+    if (field_views.size() < 9) continue;                                    // no FORMAT column: nothing to read
+    const std::string contig(field_views[0]);
+    const uint64_t offset = std::stoull(std::string(field_views[1])) - 1;
+    const std::string reference(field_views[3]);
+    std::vector<std::string> alleles;
+    for (auto a : viewTokenizer(field_views[4], ',')) alleles.emplace_back(a);
+    std::string filter_uc;
+    for (char c : field_views[6]) filter_uc += static_cast<char>(std::toupper(static_cast<unsigned char>(c)));
+    std::vector<std::string> format_fields;
+    for (auto a : viewTokenizer(field_views[8], ':')) format_fields.emplace_back(a);
+    auto formatIndex = [&](const char* code) -> std::optional<size_t> {
+      for (size_t i = 0; i < format_fields.size(); ++i)
+        if (format_fields[i] == code) return i;
+      return std::nullopt;
+    };
+    const auto GT_offset_opt = formatIndex("GT"), AD_offset_opt = formatIndex("AD");
+    ++n_records;
+    if (!GT_offset_opt || !AD_offset_opt) continue;                          // error: record contributes nothing
+
+    auto ev_base = std::make_shared<RecordEvidence>();
+    ev_base->record_index = static_cast<uint64_t>(n_records - 1);
+    ev_base->pass = filter_uc == "PASS";
+    ev_base->alt_count = static_cast<uint32_t>(alleles.size());
+    parseInfoAF(field_views[7], ev_base->alt_count, ev_base->af, ev_base->info_af_size);
+    for (auto item : viewTokenizer(field_views[7], ';')) {
+      const size_t eq = item.find('=');
+      if (eq == std::string_view::npos) continue;
+      const std::string key(item.substr(0, eq));
+      if (key != "VQSLOD" && key != "QD" && key != "MQ" && key != "SOR" && key != "MQRankSum" && key != "ReadPosRankSum") continue;
+      if (auto value = convertToFloatValue(std::string(item.substr(eq + 1)))) ev_base->info_scalar.emplace_back(key, value.value());
+    }
+
+    try {   // ProcessVCFRecord catches whatever ParseRecord throws: the rest of the record is lost, what was added stays
+      for (size_t genotype_count = 0; genotype_count + 9 < field_views.size() && genotype_count < genome_names.size(); ++genotype_count) {
+        const std::string genotype(field_views[9 + genotype_count]);
+        const std::vector<std::string> genome_vector{genome_names[genotype_count]};
+        auto genotype_formats = viewTokenizer(genotype, ':');
+        if (genotype_formats.size() <= GT_offset_opt.value()) continue;
+        const std::string GT_format(genotype_formats[GT_offset_opt.value()]);
+        std::vector<std::string> gt_vector;
+        for (auto a : viewTokenizer(GT_format, '/')) gt_vector.emplace_back(a);
+        if (gt_vector.size() != 2) {
+          gt_vector.clear();
+          for (auto a : viewTokenizer(GT_format, '|')) gt_vector.emplace_back(a);
+          if (gt_vector.size() != 2) continue;                               // missing ('.') or not diploid
+        }
+        size_t A_allele = 0, B_allele = 0;
+        if (allDigits(gt_vector[0])) A_allele = static_cast<size_t>(std::stoll(gt_vector[0]));
+        if (allDigits(gt_vector[0])) B_allele = static_cast<size_t>(std::stoll(gt_vector[1]));   // [0] tested, [1] converted: as written
+        if (A_allele == 0 && B_allele == 0) continue;
+        if (genotype_formats.size() <= AD_offset_opt.value()) continue;
+        const std::string AD_text(genotype_formats[AD_offset_opt.value()]);
+        auto ad_vector = viewTokenizer(AD_text, ',');
+        if (ad_vector.size() != alleles.size() + 1) continue;
+        std::vector<size_t> ad_count_vector;
+        for (auto depth_count_text : ad_vector) {
+          const std::string t(depth_count_text);
+          if (!allDigits(t)) continue;
+          ad_count_vector.push_back(static_cast<size_t>(std::stoll(t)));
+        }
+        for (const size_t allele_number : {A_allele, B_allele}) {
+          if (allele_number == 0) continue;
+          // the reference indexes alleles()[n-1] and ad_count_vector[n] unchecked (undefined past the end): skipped here
+          if (allele_number > alleles.size() || allele_number >= ad_count_vector.size()) continue;
+          const std::string& allele = alleles[allele_number - 1];
+          const size_t ref_count = ad_count_vector[0], alt_count = ad_count_vector[allele_number];
+          const bool downstream_variant = ref_count == 0 && alt_count == 0;   // spanning upstream deletion
+          if (allele == "*" || downstream_variant) continue;
+          std::string c_ref, c_alt;
+          uint64_t c_offset = 0;
+          canonicalSequences(reference, allele, offset, c_ref, c_alt, c_offset);
+          auto v = std::make_shared<const Variant>(contig, c_offset, VariantPhase::UNPHASED, c_ref, c_alt, ev_base,
+                                                   static_cast<uint32_t>(allele_number - 1));
+          population.addVariant(v, genome_vector);
+        }
+      }
+    } catch (const std::exception&) {
+    }
+  }
+  setupPopulationStructure();
   if (genome_names_out) *genome_names_out = genome_names;
   return n_records;
 }

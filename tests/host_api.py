@@ -22,6 +22,8 @@ def lib():
         L = C.CDLL(str(LIB))
         L.kgxh_flatten_vcf1000.restype = C.c_void_p
         L.kgxh_flatten_vcf1000.argtypes = [C.c_char_p, C.c_uint64, C.c_int]
+        L.kgxh_flatten_vcf_pf.restype = C.c_void_p
+        L.kgxh_flatten_vcf_pf.argtypes = [C.c_char_p, C.c_uint64, C.c_int, C.c_int]
         L.kgxh_flat_destroy.argtypes = [C.c_void_p]
         for name in ("kgxh_flat_genomes", "kgxh_flat_variants", "kgxh_flat_row_bytes", "kgxh_flat_variant_objects", "kgxh_flat_non_diploid"):
             getattr(L, name).restype = C.c_uint64
@@ -34,9 +36,13 @@ def lib():
 
 
 class FlatVcf:
-    def __init__(self, text: str, threads: int = 0):
+    def __init__(self, text: str, threads: int = 0, flavour: str = "Genome1000", quality_filter: bool = False):
         b = text.encode()
-        h = lib().kgxh_flatten_vcf1000(b, len(b), threads)
+        if flavour == "Genome1000":
+            h = lib().kgxh_flatten_vcf1000(b, len(b), threads)
+        else:
+            assert flavour == "Falciparum"
+            h = lib().kgxh_flatten_vcf_pf(b, len(b), threads, int(quality_filter))
         assert h
         try:
             self.G, self.V = int(lib().kgxh_flat_genomes(h)), int(lib().kgxh_flat_variants(h))

@@ -38,6 +38,10 @@ def lib() -> C.CDLL:
         "kgo_population_add_genomes": (C.c_int, [vp, u64, vp, C.c_int]),
         "kgo_population_add_records": (C.c_int, [vp, C.c_int, C.c_char_p, u64, vp, vp, vp, vp, vp, vp, u64, vp, vp]),
         "kgo_population_add_vcf_1000": (C.c_long, [vp, C.c_char_p, u64]),
+        "kgo_population_add_vcf_pf": (C.c_long, [vp, C.c_char_p, u64]),
+        "kgo_hethom_present": (C.c_int, [vp, C.c_char_p, vp]),
+        "kgo_population_filter_p7": (vp, [vp]),
+        "kgo_canonical": (u64, [C.c_char_p, C.c_char_p, u64, C.c_char_p, C.c_char_p]),
         "kgo_gt_alternate_index": (C.c_int, [C.c_char_p, C.c_char_p, u64, vp]),
         "kgo_population_variant_count": (u64, [vp]),
         "kgo_population_genome_count": (u64, [vp]),
@@ -158,6 +162,19 @@ class Population:
         assert n >= 0
         return int(n)
 
+    def add_vcf_pf(self, text: str) -> int:
+        """Parse VCF text the way PfVCFImpl does (unphased P. falciparum flavour): every sample becomes a genome."""
+        b = text.encode()
+        n = lib().kgo_population_add_vcf_pf(self._h, b, len(b))
+        assert n >= 0
+        return int(n)
+
+    def filter_p7(self):
+        """viewFilter(P7VariantFilter()), the per-record quality filter of FilterPf7::qualityFilter."""
+        p = Population(handle=lib().kgo_population_filter_p7(self._h))
+        p.genome_ids = list(self.genome_ids)
+        return p
+
     @property
     def handle(self):
         return self._h
@@ -193,6 +210,12 @@ class Population:
         out = np.zeros((self.genome_count(), 7), dtype=np.uint64)
         assert lib().kgo_hethom(self._h, contig.encode(), _p(out)) == 0
         return out
+
+
+    def hethom_present(self, contig):
+        out = np.zeros(self.genome_count(), dtype=np.uint8)
+        assert lib().kgo_hethom_present(self._h, contig.encode(), _p(out)) == 0
+        return out.astype(bool)
 
 
 class VariantDB:
@@ -349,6 +372,14 @@ def synthetic_check(reference: Population, super_pop, algorithm, lower, upper, s
                                   seed, _p(syn), _p(calc), 128)
     assert n >= 0
     return syn[:n].copy(), calc[:n].copy()
+
+
+def canonical(ref: str, alt: str, offset: int):
+    """Variant::canonicalSequences -> (ref, alt, offset)."""
+    r = C.create_string_buffer(len(ref) + len(alt) + 2)
+    a = C.create_string_buffer(len(ref) + len(alt) + 2)
+    o = lib().kgo_canonical(ref.encode(), alt.encode(), offset, r, a)
+    return r.value.decode(), a.value.decode(), int(o)
 
 
 def gt_alternate_index(contig: str, genotype: str, n_alt: int):

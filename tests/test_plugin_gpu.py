@@ -187,3 +187,47 @@ def test_gpu_inbreed_package_synthetic_self_check(tmp_path, kgx, algorithm):
             assert slope > 0.8 and abs(intercept) < 0.05, (sp, c, slope, intercept)
     # the two windows use different draws
     assert not np.array_equal(calc[:, 0], calc[:, 1])
+
+
+@pytest.mark.parametrize("quality_filter", [False, True])
+def test_gpu_allele_package_reads_pf_vcf(tmp_path, kgx, quality_filter):
+    """VcfFlavour=Falciparum: the package parses the unphased Pf7-style VCF itself (PfVCFImpl's rules, canonical
+    variants, every sample a genome holding every header contig), optionally drops the records P7VariantFilter rejects,
+    and must produce what the oracle gets from the same text through Variant objects, viewFilter and CalcFWS /
+    HeteroHomoZygous."""
+    from . import vcf_text as vt
+
+    G, L = 45, 2500
+    ids = [f"PF{i:04d}-C" for i in range(G)]
+    text = vt.write_vcf_pf(L, ids, rng_seed=21)
+    vcf = tmp_path / "pf.vcf"
+    vcf.write_text(text)
+    res = rio.run_driver("GPU_ALLELE", tmp_path, [f"vcf:{vcf}"], VcfFlavour="Falciparum",
+                         Pf7QualityFilter="TRUE" if quality_filter else "FALSE")
+    assert res.returncode == 0, res.stderr
+
+    opop = oa.Population("pf")
+    opop.add_vcf_pf(text)
+    if quality_filter:
+        opop = opop.filter_p7()
+    variant_out, genome_out, vdb = opop.fws()
+    header, rows = rio.read_csv(tmp_path / "VariantFWS.csv")
+    assert [r[0] for r in rows] == [vdb.hgvs(i) for i in range(vdb.n_variants)]
+    assert np.array_equal(np.array([[int(x) for x in r[-3:]] for r in rows], dtype=np.uint64), variant_out)
+    header, rows = rio.read_csv(tmp_path / "GenomeFWS.csv")
+    assert [r[0] for r in rows] == [vdb.genome_id(i) for i in range(vdb.n_genomes)] == sorted(ids)
+    got = np.array([[int(r[1 + 8 * b + 5 + k]) for b in range(11) for k in range(3)] for r in rows], dtype=np.uint64)
+    assert np.array_equal(got.reshape(len(rows), 11, 3), genome_out)
+    header, rows = rio.read_csv(tmp_path / "VariantStatistics.csv")
+    got = {(r[0], r[1]): [int(r[2]), int(r[3]), int(r[4]), int(r[7]), int(r[8]), int(r[6]), int(r[5])] for r in rows}
+    n_rows = 0
+    for contig in ["Pf3D7_01_v3", "Pf3D7_02_v3", "Pf3D7_MIT_v3", "Pf3D7_API_v3"]:     # the last one has no record at all
+        want, present = opop.hethom(contig), opop.hethom_present(contig)
+        for g, genome in enumerate(sorted(ids)):
+            assert ((genome, contig) in got) == bool(present[g]), (genome, contig)
+            if present[g]:
+                assert got[(genome, contig)] == want[g].tolist(), (genome, contig)
+                n_rows += 1
+    assert n_rows == len(got)
+    if not quality_filter:
+        assert n_rows == 4 * G                                     # every genome holds every header contig

@@ -74,3 +74,72 @@ def test_vcf_flatten_edge_cases():
     o.add_vcf_1000(text)
     vdb = oa.VariantDB(o)
     assert [vdb.hgvs(0)] == flat.hgvs and vdb.dosage().T.tolist() == [[1, 2]]
+
+
+def test_canonical_sequences_through_one_record_vcfs():
+    # Variant::canonicalSequences as restated in the oracle == what the product's Pf flattener writes into the HGVS
+    cases = [("A", "T"), ("AT", "A"), ("A", "ATT"), ("ACG", "ATG"), ("ACGT", "ACCT"), ("ACGT", "AGT"), ("ACG", "ACGG"),
+             ("AAAA", "AAA"), ("ACGTACGT", "ACGACGT"), ("TTTT", "TTTTTT"), ("ACG", "TGA"), ("AC", "AC"), ("ACGT", "AC"),
+             ("CAG", "CAGCAG"), ("GATTACA", "GATACA"), ("AT", "TA"), ("ATG", "ACG"), ("AGG", "AG")]
+    for ref, alt in cases:
+        c_ref, c_alt, c_off = oa.canonical(ref, alt, 999)
+        text = ("##contig=<ID=c1>\n#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\tS1\n"
+                f"c1\t1000\t.\t{ref}\t{alt}\t.\tPASS\t.\tGT:AD\t0/1:5,5\n")
+        flat = ha.FlatVcf(text, flavour="Falciparum")
+        assert flat.hgvs == [f"c1:g.{c_off}{c_ref}>{c_alt}"], (ref, alt, flat.hgvs)
+        assert flat.offsets.tolist() == [c_off]
+    # hand-checked: prefix keeps one base, suffix trimmed, offset moves with the prefix
+    assert oa.canonical("ACGT", "ACCT", 10) == ("CG", "CC", 11)
+    assert oa.canonical("ACGTACGT", "ACGACGT", 0) == ("GT", "G", 2)
+    assert oa.canonical("AT", "A", 5) == ("AT", "A", 5)
+
+
+@pytest.mark.parametrize("threads,quality_filter", [(1, False), (5, False), (3, True)])
+def test_vcf_pf_flatten_matches_oracle_parser(threads, quality_filter):
+    G, L = 29, 1500
+    ids = [f"PF{i:04d}-C" for i in reversed(range(G))]
+    text = vt.write_vcf_pf(L, ids, rng_seed=11)
+    opop = oa.Population("pf")
+    assert opop.add_vcf_pf(text) == L
+    if quality_filter:
+        full_count = opop.variant_count()
+        opop = opop.filter_p7()
+        assert 0 < opop.variant_count() < full_count              # the filter bites, and not everything
+    vdb = oa.VariantDB(opop)
+    flat = ha.FlatVcf(text, threads, flavour="Falciparum", quality_filter=quality_filter)
+    assert flat.genome_ids == sorted(ids) == [vdb.genome_id(i) for i in range(vdb.n_genomes)]   # every sample is a genome
+    assert flat.hgvs == [vdb.hgvs(i) for i in range(vdb.n_variants)]
+    D = vdb.dosage()
+    codes = capi.unpack_dosage2(flat.packed, flat.G)
+    assert np.array_equal(codes, np.minimum(D.T, 3))
+    assert flat.variant_objects == opop.variant_count() == int(D.sum())
+    assert flat.non_diploid == int((D > 2).sum())
+    assert 0 < flat.is_snp.sum() < flat.V
+    assert not any(h.endswith(">*") for h in flat.hgvs)             # the upstream-deletion allele never becomes a Variant
+    from kgl_gene_amd.fws import fws_bin_of_variant
+    _, genome_out, _ = opop.fws()
+    bins = fws_bin_of_variant(np.where(np.isinf(flat.info_af), np.nan, flat.info_af))
+    dose = np.minimum(D.T, 3)
+    for b in range(11):
+        sel = dose[bins == b]
+        want = np.stack([(sel == 0).sum(0), (sel == 1).sum(0), (sel == 2).sum(0)], 1)
+        assert np.array_equal(genome_out[:, b, :], want.astype(np.uint64)), b
+
+
+def test_vcf_pf_edge_cases():
+    hdr = "##contig=<ID=c1,length=5>\n##contig=<ID=c2>\n#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\tB\tA\n"
+    flat = ha.FlatVcf(hdr, flavour="Falciparum")
+    assert flat.genome_ids == ["A", "B"] and flat.V == 0                 # genomes exist without any record
+    body = ("c1\t10\t.\tA\tT,*\t.\tPASS\tVQSLOD=-1\tGT:AD\t1/2:3,4,5\t0/1:0,0,9\n"     # B: T once ('*' dropped); A: spanning call
+            "c1\t11\t.\tG\tC\t.\tPASS\tQD=1.0\tGT:AD\t1/1:1,8\t1/.:2,2\n"              # A: stoll('.') throws after B was added
+            "c1\t12\t.\tG\tC\t.\tPASS\t.\tGT\t1/1\t1/1\n")                            # no AD in FORMAT
+    flat = ha.FlatVcf(hdr + body, flavour="Falciparum")
+    assert flat.hgvs == ["c1:g.10G>C", "c1:g.9A>T"]
+    assert capi.unpack_dosage2(flat.packed, 2).tolist() == [[0, 2], [0, 1]]
+    o = oa.Population("x")
+    o.add_vcf_pf(hdr + body)
+    vdb = oa.VariantDB(o)
+    assert [vdb.hgvs(i) for i in range(vdb.n_variants)] == flat.hgvs and vdb.dosage().T.tolist() == [[0, 2], [0, 1]]
+    # both records fail P7VariantFilter (VQSLOD < 0; QD < 2)
+    assert ha.FlatVcf(hdr + body, flavour="Falciparum", quality_filter=True).V == 0
+    assert o.filter_p7().variant_count() == 0
