@@ -11,7 +11,10 @@ from pathlib import Path
 import numpy as np
 
 ROOT = Path(__file__).resolve().parent.parent
-LIB_PATH = ROOT / "oracle" / "_build" / "libkgo.so"
+import os as _os
+
+# scripts/sanitize_host.sh points these at ASan/UBSan-instrumented builds of the same sources
+LIB_PATH = Path(_os.environ.get("KGX_SANITIZED_ORACLE_LIB") or ROOT / "oracle" / "_build" / "libkgo.so")
 
 SUPER_POPS = ["AFR", "AMR", "EAS", "EUR", "SAS", "ALL"]
 FIXED_STARTS = 0xFFFFFFFFFFFFFFFF   # oracle test hook: deterministic restart points (see kgo_inbreed.cpp)
