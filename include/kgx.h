@@ -200,6 +200,8 @@ int kgx_inbreed(kgx_gt8* gt, uint64_t g0, uint64_t g1, const uint32_t* locus_ind
  * pass over the genotype bytes that every estimator makes -- of the most recent successful kgx_inbreed call on this
  * process; 0 before the first.  For bench.py / profiles: algorithmic bytes = kgx_gt8_sweep_bytes(). */
 double kgx_inbreed_last_sweep_ms(void);
+/* Objective evaluations (= passes over the genotype bytes) the most recent KGX_ALGO_LOGLIKELIHOOD call needed. */
+int kgx_inbreed_last_evaluations(void);
 
 /* Synthetic multi-allelic SNP+indel population (BASELINE.json configs[4]) written straight into
  * the matrix: 1/2/3 alts (70/20/10 %), 15 % of alts are indels, AFs rescaled to sum <= 0.6, genotypes drawn from

@@ -73,6 +73,7 @@ _SIGNATURES = {
     "kgx_inbreed": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint32, C.c_int,
                               C.c_int, C.c_void_p]),
     "kgx_inbreed_last_sweep_ms": (C.c_double, []),
+    "kgx_inbreed_last_evaluations": (C.c_int, []),
     "kgx_gt8_synth_multiallelic": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64, C.c_void_p]),
     "kgx_synth_multiallelic_host": (C.c_int, [C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64, C.c_void_p, C.c_uint64,
                                               C.c_void_p, C.c_void_p]),
@@ -393,6 +394,11 @@ class GenotypeMatrix:
 def inbreed_last_sweep_ms() -> float:
     """Device time of the frequency sweep of the most recent GenotypeMatrix.inbreed call (HIP events)."""
     return float(lib().kgx_inbreed_last_sweep_ms())
+
+
+def inbreed_last_evaluations() -> int:
+    """Objective evaluations the most recent Loglikelihood call needed."""
+    return int(lib().kgx_inbreed_last_evaluations())
 
 
 def synth_multiallelic_host(seed: int, genome_base: int, n_genomes: int, l0: int, l1: int):

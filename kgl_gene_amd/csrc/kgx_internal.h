@@ -37,6 +37,7 @@ struct State {
   char arch[64] = {0};
   hipEvent_t sweep_begin = nullptr, sweep_end = nullptr;   // bracket the frequency sweep of the last kgx_inbreed call
   double last_sweep_ms = 0.0;
+  int last_evaluations = 0;                                // objective evaluations of the last Loglikelihood call
   char* scratch = nullptr;                                 // grow-only arena for kgx_inbreed's per-call buffers
   size_t scratch_bytes = 0;
 };

@@ -1485,6 +1485,75 @@ k_golden_step(GoldenState* __restrict__ st, const double* __restrict__ f_eval, u
   }
 }
 
+// Brent's method (golden-section steps with a parabolic step whenever the fit through the three best points is
+// acceptable; "Algorithms for Minimization without Derivatives", ch. 5) on -loglikelihood over [-1, 1], one state per
+// genome, one objective evaluation (= one sweep over the genotype bytes) per step for every genome that has not
+// converged.  mode 0: f_eval is the value at the start point; 1: at the point proposed last; 2: no evaluation,
+// just publish the best point.  still_running counts the genomes that proposed a new point.
+struct BrentState { double a, b, x, w, v, fx, fw, fv, d, e, u; int done; int pad; };
+
+__global__ void __launch_bounds__(kBlock)
+k_brent_step(BrentState* __restrict__ st, const double* __restrict__ f_eval, uint64_t n, int mode, double* __restrict__ f_next,
+             unsigned int* __restrict__ still_running) {
+  // Absolute tolerance: the search stops with the best point within 2 * tol1 = 5e-7 of the maximiser; the reference
+  // stops its Nelder-Mead at an absolute parameter change of 1e-6 (_calc.cpp:139).  Asking for much less runs into the
+  // rounding noise of the objective (a sum of ~1e6 logs), where parabolic steps stop working.
+  constexpr double kGold = 0.3819660112501051, kTol = 0.0, kZeps = 2.5e-7;
+  for (uint64_t g = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x; g < n;
+       g += static_cast<uint64_t>(gridDim.x) * blockDim.x) {
+    BrentState s = st[g];
+    if (mode == 2) { f_next[g] = s.x; continue; }
+    if (!s.done) {
+      const double fu = -f_eval[g];
+      if (mode == 0) {
+        s.fx = s.fw = s.fv = fu;
+      } else {
+        const double u = s.u;
+        if (fu <= s.fx) {
+          if (u >= s.x) s.a = s.x; else s.b = s.x;
+          s.v = s.w; s.w = s.x; s.x = u;
+          s.fv = s.fw; s.fw = s.fx; s.fx = fu;
+        } else {
+          if (u < s.x) s.a = u; else s.b = u;
+          if (fu <= s.fw || s.w == s.x) { s.v = s.w; s.w = u; s.fv = s.fw; s.fw = fu; }
+          else if (fu <= s.fv || s.v == s.x || s.v == s.w) { s.v = u; s.fv = fu; }
+        }
+      }
+      const double xm = 0.5 * (s.a + s.b);
+      const double tol1 = kTol * fabs(s.x) + kZeps, tol2 = 2.0 * tol1;
+      if (fabs(s.x - xm) <= (tol2 - 0.5 * (s.b - s.a))) {
+        s.done = 1;
+      } else {
+        bool golden = true;
+        if (fabs(s.e) > tol1) {
+          const double r = (s.x - s.w) * (s.fx - s.fv);
+          double q = (s.x - s.v) * (s.fx - s.fw);
+          double p = (s.x - s.v) * q - (s.x - s.w) * r;
+          q = 2.0 * (q - r);
+          if (q > 0.0) p = -p;
+          q = fabs(q);
+          const double etemp = s.e;
+          s.e = s.d;
+          if (!(fabs(p) >= fabs(0.5 * q * etemp) || p <= q * (s.a - s.x) || p >= q * (s.b - s.x))) {
+            s.d = p / q;
+            const double u = s.x + s.d;
+            if (u - s.a < tol2 || s.b - u < tol2) s.d = copysign(tol1, xm - s.x);
+            golden = false;
+          }
+        }
+        if (golden) {
+          s.e = s.x >= xm ? s.a - s.x : s.b - s.x;
+          s.d = kGold * s.e;
+        }
+        s.u = fabs(s.d) >= tol1 ? s.x + s.d : s.x + copysign(tol1, s.d);
+        atomicAdd(still_running, 1u);
+      }
+      st[g] = s;
+    }
+    f_next[g] = s.done ? s.x : s.u;
+  }
+}
+
 // LocusResults per genome (kga_analysis_inbreed_output.h:21-35) incl. the estimator's coefficient:
 //   Simple  (processSimple, _calc.cpp:318-365): (obsHom - expHom) / (N - expHom)
 //   Ritland (processRitlandLocus :374-431):     sum / count

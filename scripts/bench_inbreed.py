@@ -19,4 +19,4 @@ for algo in ("Simple", "RitlandLocus", "HallME", "Loglikelihood"):
     t0 = time.perf_counter(); res = m.inbreed(table, algo, phased=True); dt = time.perf_counter() - t0
     ms = capi.inbreed_last_sweep_ms()
     print(f"{algo}: wall {dt*1e3:.1f} ms (first call {dt_first*1e3:.1f}; incl. H2D of the AF table, all passes); frequency sweep {ms:.2f} ms = {alg_bytes/ms/1e9:.2f} TB/s"
-          f"  mean F {res['inbred_allele_sum'].mean():+.4f}", flush=True)
+          f"  mean F {res['inbred_allele_sum'].mean():+.4f}" + (f"  evaluations {capi.inbreed_last_evaluations()}" if algo == "Loglikelihood" else ""), flush=True)
