@@ -9,6 +9,8 @@ A step = one pass of the hot path over this rank's genome shard.  Workload (conf
   c3  (default) 10,000 genomes x 10,000,000 biallelic SNPs PER GPU  (BASELINE.json configs[2]; weak scaling)
   c4            100,000 genomes x 10M SNPs split over the N ranks    (configs[3]; needs N >= 2)
   c2            1,000 genomes x 1M SNPs per GPU                      (configs[1]; fits the 256 MiB L3)
+  c5            10,000 genomes x 5,000,000 multi-allelic loci per GPU: the inbreeding sweep (K5 + the estimator named by
+                --algorithm; configs[4]); genomes are independent, so N ranks are N shards with no exchange at all
 One JSON line is printed by rank 0.  PyTorch is plumbing only (device tensors, RCCL all-reduce).
 """
 from __future__ import annotations
@@ -31,6 +33,7 @@ WORKLOADS = {
     "c2": dict(genomes_per_gpu=1_000, variants=1_000_000, label="C2: 1k genomes x 1M biallelic SNPs per GPU"),
     "c3": dict(genomes_per_gpu=10_000, variants=10_000_000, label="C3: 10k genomes x 10M biallelic SNPs per GPU"),
     "c4": dict(total_genomes=100_000, variants=10_000_000, label="C4: 100k genomes x 10M biallelic SNPs sharded over the ranks"),
+    "c5": dict(genomes_per_gpu=10_000, variants=5_000_000, label="C5: 10k genomes x 5M multi-allelic loci per GPU, inbreeding sweep"),
 }
 
 
@@ -45,6 +48,8 @@ def parse_args():
     ap.add_argument("--seed", type=int, default=1111)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-variants", type=int, default=100_000)
+    ap.add_argument("--algorithm", choices=["Simple", "RitlandLocus", "HallME", "Loglikelihood"], default="Simple",
+                    help="estimator of the c5 workload")
     return ap.parse_args()
 
 
@@ -72,6 +77,57 @@ def cpu_baseline(capi, pop, G, V, k2_host_sample_rows, sample_variants):
                   f"oracle dense tier = reference summaryByVariant loop (single-threaded in the reference); "
                   f"host has {os.cpu_count()} cpus; block parity vs GPU: {'bit-exact' if ok else 'MISMATCH'}",
         "parity_ok": ok,
+    }
+
+
+def inbreed_workload(args, capi, dist, torch, dev, wl, L, n_gpus, rank):
+    """C5: every rank sweeps its own genomes (no collective: per-genome results only need that genome's bytes and the
+    per-locus tables).  A step = one kgx_inbreed call = the frequency sweep + the estimator's passes.  The boundary
+    hands the per-locus AF table over from the host each call, so ms_per_step includes that upload; roofline.achieved
+    is the frequency-sweep kernel time alone (HIP events inside the library)."""
+    G = args.genomes or wl["genomes_per_gpu"]
+    m = capi.GenotypeMatrix(G, L)
+    table = m.synth_multiallelic(args.seed, rank * G, 0)
+    sweep_bytes = int(capi.lib().kgx_gt8_sweep_bytes(G, L, table.shape[1]))
+
+    def fence():
+        if n_gpus > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    res = None
+    for _ in range(args.warmup):
+        res = m.inbreed(table, args.algorithm, phased=True)
+    fence()
+    t0 = time.perf_counter()
+    sweep_ms = []
+    for _ in range(args.steps):
+        res = m.inbreed(table, args.algorithm, phased=True)
+        sweep_ms.append(capi.inbreed_last_sweep_ms())
+    fence()
+    elapsed = time.perf_counter() - t0
+    if n_gpus > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    k5_ms = float(np.mean(sweep_ms))
+    achieved = sweep_bytes / (k5_ms * 1e-3) / 1e9
+    if rank != 0:
+        return None
+    return {
+        "metric": "genomes·loci/sec (inbreeding sweep + " + args.algorithm + ")",
+        "value": n_gpus * G * L * args.steps / elapsed,
+        "unit": "genomes·loci/s",
+        "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": elapsed / args.steps * 1e3,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8 classes, f64 sums", "data": "synthetic",
+        "config": {"workload": wl["label"], "genomes_per_gpu": G, "loci": L, "algorithm": args.algorithm,
+                   "layout": "gt8 allele-index bytes, locus-major", "exchange": "none (genomes are independent)",
+                   "mean_F": float(res["inbred_allele_sum"].mean()), "seed": args.seed},
+        "roofline": {"bound": "hbm", "kernel": "k_inbreed_sweep_swar16 (+ locus helpers)", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                     "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None, "algorithmic_bytes_per_launch": sweep_bytes,
+                     "kernel_ms": k5_ms},
+        "cpu_baseline": None,
     }
 
 
@@ -112,6 +168,14 @@ def main():
 
     wl = WORKLOADS[args.workload]
     V = args.variants or wl["variants"]
+    if args.workload == "c5":
+        result = inbreed_workload(args, capi, dist, torch, dev, wl, V, n_gpus, rank)
+        if n_gpus > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        if rank == 0:
+            print(json.dumps(result, ensure_ascii=False))
+        return
     if args.workload == "c4" and not args.genomes:
         if n_gpus < 2:
             sys.exit("workload c4 (100k x 10M = 250 GB) is sharded: run it with --gpus >= 2")
