@@ -56,7 +56,8 @@ bool kga::GpuAlleleAnalysis::fileReadAnalysis(std::shared_ptr<const DataDB> data
     return false;
   }
   const auto file_characteristic = data_object_ptr->dataCharacteristic();
-  if (file_characteristic.data_structure == DataStructureEnum::NoStructure) return sweepVcfFile(data_object_ptr->fileId());
+  if (std::dynamic_pointer_cast<const FilenameDataDB>(data_object_ptr) || file_characteristic.data_structure == DataStructureEnum::NoStructure)
+    return sweepVcfFile(data_object_ptr->fileId());                   // a "FileNameOnly" data file: the package reads the VCF itself
   if (file_characteristic.data_structure != DataStructureEnum::DiploidPhased &&
       file_characteristic.data_structure != DataStructureEnum::DiploidUnphased) {
     ExecEnv::log().info("Analysis: {}, file: {} is not a diploid population; ignored", ident(), data_object_ptr->fileId());

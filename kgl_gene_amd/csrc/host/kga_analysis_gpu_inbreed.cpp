@@ -185,6 +185,18 @@ bool kga::GpuInbreedAnalysis::initializeAnalysis(const std::string& work_directo
 bool kga::GpuInbreedAnalysis::fileReadAnalysis(std::shared_ptr<const DataDB> data_object_ptr) {
   ExecEnv::log().info("Analysis: {}, begin processing data file: {}", ident(), data_object_ptr->fileId());
   const auto file_characteristic = data_object_ptr->dataCharacteristic();
+  if (std::dynamic_pointer_cast<const FilenameDataDB>(data_object_ptr)) {
+    // a VCF the package reads itself: the 1000-Genomes population, or a mono-genome frequency source
+    if (data_object_ptr->dataSource() == DataSourceEnum::Genome1000) diploid_vcf_ = data_object_ptr->fileId();
+    else if (file_characteristic.data_structure == DataStructureEnum::UnphasedMonoGenome) {
+      reference_vcf_ = data_object_ptr->fileId();
+      reference_vcf_source_ = data_object_ptr->dataSource();
+    } else {
+      ExecEnv::log().error("GpuInbreedAnalysis::fileReadAnalysis, Analysis: {}, VCF file: {} is neither a Genome1000 population nor a frequency source", ident(), data_object_ptr->fileId());
+      return false;
+    }
+    return true;
+  }
   if (file_characteristic.data_structure == DataStructureEnum::DiploidPhased ||
       file_characteristic.data_structure == DataStructureEnum::DiploidUnphased) {
     diploid_population_ = std::dynamic_pointer_cast<const PopulationDB>(data_object_ptr);
@@ -210,14 +222,14 @@ bool kga::GpuInbreedAnalysis::iterationAnalysis() {
   for (auto& param_output : parameter_output_vector_) {
     // ExecuteInbreedingAnalysis::executeAnalysis (kga_analysis_inbreed_execute.cpp:16-45)
     if (param_output.parameters.analyze_synthetic) {
-      if (!unphased_population_) {
+      if (!haveReference()) {
         ExecEnv::log().error("InbreedAnalysis::iterationAnalysis; Insufficient data, cannot process synthetic diploid inbreeding");
         ok = false;
         continue;
       }
       ok = syntheticInbreeding(param_output) && ok;
     } else {
-      if (!diploid_population_ || !unphased_population_ || !genealogy_data_) {
+      if (!haveDiploid() || !haveReference() || !genealogy_data_) {
         ExecEnv::log().error("ExecuteInbreedingAnalysis::processDiploid; Insufficient data, cannot process diploid inbreeding");
         ok = false;
         continue;
@@ -227,7 +239,117 @@ bool kga::GpuInbreedAnalysis::iterationAnalysis() {
   }
   diploid_population_ = nullptr;
   unphased_population_ = nullptr;
+  reference_vcf_.clear();
+  diploid_vcf_.clear();
   return ok;
+}
+
+namespace {
+bool readWholeFile(const std::string& file_name, std::string& text) {
+  std::ifstream in(file_name, std::ios::binary);
+  if (!in.good()) return false;
+  text.assign((std::istreambuf_iterator<char>(in)), std::istreambuf_iterator<char>());
+  return true;
+}
+}  // namespace
+
+bool kga::GpuInbreedAnalysis::referenceInput(GpuReferenceContig& reference) const {
+  if (unphased_population_) {
+    bool ok = false;
+    reference = buildReference(*unphased_population_, ok);
+    return ok;
+  }
+  std::string text;
+  if (!readWholeFile(reference_vcf_, text)) {
+    ExecEnv::log().error("GpuInbreedAnalysis; cannot open reference VCF file: {}", reference_vcf_);
+    return false;
+  }
+  gpu::FlatReference flat = gpu::flattenReferenceVcf(text, reference_vcf_source_);
+  if (flat.contigs != 1) {
+    ExecEnv::log().error("InbreedingAnalysis::populationInbreeding; Unphased Population: {} has unexpected contig count: {}", reference_vcf_, flat.contigs);
+    return false;
+  }
+  reference.contig_id = std::move(flat.contig_id);
+  reference.max_alts = flat.max_alts;
+  reference.loci = std::move(flat.loci);
+  return true;
+}
+
+// Allele-index bytes [locus][genome]: each genome's SNP variants at each reference offset, in OffsetDB order.
+kgl::analysis::gpu::FlatDiploid kga::GpuInbreedAnalysis::diploidBytes(const PopulationDB& diploid_population, const GpuReferenceContig& reference,
+                                                                        bool phased) {
+  gpu::FlatDiploid out;
+  const uint64_t n_loci = reference.loci.size();
+  out.n_loci = n_loci;
+  std::vector<std::shared_ptr<const ContigDB>> contigs;
+  for (const auto& [genome_id, genome_ptr] : diploid_population.getMap()) {
+    auto contig_opt = genome_ptr->getContig(reference.contig_id);
+    if (!contig_opt) continue;
+    out.genome_ids.push_back(genome_id);
+    contigs.push_back(contig_opt.value());
+  }
+  const uint64_t G = out.genome_ids.size();
+  std::unordered_map<ContigOffset_t, uint32_t> locus_of_offset;
+  locus_of_offset.reserve(n_loci * 2);
+  for (uint32_t l = 0; l < n_loci; ++l) locus_of_offset.emplace(reference.loci[l].offset, l);
+  out.bytes.assign(n_loci * G, 0);
+  for (uint64_t g = 0; g < G; ++g) {
+    for (const auto& [offset, offset_ptr] : contigs[g]->getMap()) {
+      auto lit = locus_of_offset.find(offset);
+      if (lit == locus_of_offset.end()) continue;
+      const auto& alts = reference.loci[lit->second].alts;
+      uint32_t n = 0, code[2] = {0, 0};
+      VariantPhase phase[2] = {VariantPhase::UNPHASED, VariantPhase::UNPHASED};
+      for (const auto& variant_ptr : offset_ptr->getVariantArray()) {
+        if (!variant_ptr->isSNP()) continue;                         // contig_ptr->viewFilter(SNPFilter()) (_freq.cpp:436)
+        if (n < 2) {
+          const std::string hgvs = variant_ptr->HGVS();
+          uint32_t c = 15;
+          for (size_t j = 0; j < alts.size(); ++j)
+            if (alts[j].hgvs == hgvs) { c = static_cast<uint32_t>(j + 1); break; }
+          code[n] = c;
+          phase[n] = variant_ptr->phaseId();
+        }
+        ++n;
+      }
+      if (n == 0) continue;
+      uint8_t b;
+      if (n >= 3) b = 0xFF;
+      else {
+        if (n == 2 && code[0] == code[1] && code[0] != 15 && phased && phase[0] == phase[1]) {
+          out.error = "Genome: " + out.genome_ids[g] + " holds two copies of one variant with the SAME phase at offset " + std::to_string(offset) +
+                      "; not representable";
+          return out;
+        }
+        b = static_cast<uint8_t>(code[0] | (code[1] << 4));
+      }
+      out.bytes[static_cast<uint64_t>(lit->second) * G + g] = b;
+    }
+  }
+  return out;
+}
+
+bool kga::GpuInbreedAnalysis::diploidInput(const GpuReferenceContig& reference, gpu::FlatDiploid& diploid, bool& phased) const {
+  if (diploid_population_) {
+    phased = diploid_population_->dataCharacteristic().data_structure == DataStructureEnum::DiploidPhased;
+    diploid = diploidBytes(*diploid_population_, reference, phased);
+  } else {
+    std::string text;
+    if (!readWholeFile(diploid_vcf_, text)) {
+      ExecEnv::log().error("GpuInbreedAnalysis; cannot open population VCF file: {}", diploid_vcf_);
+      return false;
+    }
+    phased = true;                                                   // Genome1000: DiploidPhased (kgl_data_file_type.h:118-134)
+    gpu::FlatReference flat;
+    flat.contig_id = reference.contig_id;
+    flat.loci = reference.loci;
+    diploid = gpu::flattenVcf1000Gt8(text, flat);
+  }
+  if (!diploid.error.empty()) {
+    ExecEnv::log().error("GpuInbreedAnalysis; {}", diploid.error);
+    return false;
+  }
+  return true;
 }
 
 bool kga::GpuInbreedAnalysis::populationInbreeding(GpuParamOutput& param_output) {
@@ -237,9 +359,8 @@ bool kga::GpuInbreedAnalysis::populationInbreeding(GpuParamOutput& param_output)
     ExecEnv::log().error("InbreedingAnalysis::populationInbreeding, Inbreeding algorithm not found: {}", params.inbreeding_algorithm);
     return true;   // the reference logs and returns an empty results map (_diploid.cpp:107-112)
   }
-  bool ok = false;
-  const GpuReferenceContig reference = buildReference(*unphased_population_, ok);
-  if (!ok) return false;
+  GpuReferenceContig reference;
+  if (!referenceInput(reference)) return false;
   if (reference.max_alts > 14) {
     ExecEnv::log().error("GpuInbreedAnalysis; a reference offset holds {} SNP alts; at most 14 fit the 4-bit allele index", reference.max_alts);
     return false;
@@ -247,14 +368,15 @@ bool kga::GpuInbreedAnalysis::populationInbreeding(GpuParamOutput& param_output)
   const uint32_t amax = std::max<uint32_t>(1, reference.max_alts);
   const uint64_t n_loci = reference.loci.size();
   const auto& super_pops = FrequencyDatabaseRead::superPopulations();
-  const bool phased = diploid_population_->dataCharacteristic().data_structure == DataStructureEnum::DiploidPhased;
+  gpu::FlatDiploid diploid;
+  bool phased = true;
+  if (!diploidInput(reference, diploid, phased)) return false;
 
   // Genomes with the contig and a PED record, grouped by super population; each group starts on a multiple of 16.
-  struct DeviceGenome { std::shared_ptr<const ContigDB> contig; GenomeId_t id; };
+  struct DeviceGenome { uint64_t column; GenomeId_t id; };
   std::vector<std::vector<DeviceGenome>> by_super_pop(super_pops.size());
-  for (const auto& [genome_id, genome_ptr] : diploid_population_->getMap()) {
-    auto contig_opt = genome_ptr->getContig(reference.contig_id);
-    if (!contig_opt) continue;
+  for (uint64_t column = 0; column < diploid.genome_ids.size(); ++column) {
+    const GenomeId_t& genome_id = diploid.genome_ids[column];
     auto record_opt = genealogy_data_->getGenomeGenealogyRecord(genome_id);
     if (!record_opt) {
       ExecEnv::log().error("InbreedingAnalysis::populationInbreeding, Genome sample: {} does not have a PED record", genome_id);
@@ -265,7 +387,7 @@ bool kga::GpuInbreedAnalysis::populationInbreeding(GpuParamOutput& param_output)
       ExecEnv::log().error("InbreedingAnalysis::populationInbreeding, Locus set not found for super population: {}", record_opt.value().superPopulation());
       continue;
     }
-    by_super_pop[static_cast<size_t>(sp_it - super_pops.begin())].push_back({contig_opt.value(), genome_id});
+    by_super_pop[static_cast<size_t>(sp_it - super_pops.begin())].push_back({column, genome_id});
   }
   std::vector<uint64_t> range_begin(super_pops.size(), 0), range_end(super_pops.size(), 0);
   uint64_t device_genomes = 0;
@@ -277,47 +399,16 @@ bool kga::GpuInbreedAnalysis::populationInbreeding(GpuParamOutput& param_output)
   }
   if (device_genomes == 0 || n_loci == 0) return true;
 
-  // Allele-index bytes [locus][genome]: each genome's SNP variants at each reference offset, in OffsetDB order.
-  std::unordered_map<ContigOffset_t, uint32_t> locus_of_offset;
-  locus_of_offset.reserve(n_loci * 2);
-  for (uint32_t l = 0; l < n_loci; ++l) locus_of_offset.emplace(reference.loci[l].offset, l);
+  // Device column order = super-population groups; the flattened input is in genome-id order.
+  const uint64_t input_genomes = diploid.genome_ids.size();
   std::vector<uint8_t> bytes(n_loci * device_genomes, 0);
-  for (size_t sp = 0; sp < super_pops.size(); ++sp) {
+  for (size_t sp = 0; sp < super_pops.size(); ++sp)
     for (size_t k = 0; k < by_super_pop[sp].size(); ++k) {
-      const uint64_t g = range_begin[sp] + k;
-      for (const auto& [offset, offset_ptr] : by_super_pop[sp][k].contig->getMap()) {
-        auto lit = locus_of_offset.find(offset);
-        if (lit == locus_of_offset.end()) continue;
-        const auto& alts = reference.loci[lit->second].alts;
-        uint32_t n = 0, code[2] = {0, 0};
-        VariantPhase phase[2] = {VariantPhase::UNPHASED, VariantPhase::UNPHASED};
-        for (const auto& variant_ptr : offset_ptr->getVariantArray()) {
-          if (!variant_ptr->isSNP()) continue;                         // contig_ptr->viewFilter(SNPFilter()) (_freq.cpp:436)
-          if (n < 2) {
-            const std::string hgvs = variant_ptr->HGVS();
-            uint32_t c = 15;
-            for (size_t j = 0; j < alts.size(); ++j)
-              if (alts[j].hgvs == hgvs) { c = static_cast<uint32_t>(j + 1); break; }
-            code[n] = c;
-            phase[n] = variant_ptr->phaseId();
-          }
-          ++n;
-        }
-        if (n == 0) continue;
-        uint8_t b;
-        if (n >= 3) b = 0xFF;
-        else {
-          if (n == 2 && code[0] == code[1] && code[0] != 15 && phased && phase[0] == phase[1]) {
-            ExecEnv::log().error("GpuInbreedAnalysis; Genome: {} holds two copies of one variant with the SAME phase at offset {}; not representable",
-                                 by_super_pop[sp][k].id, offset);
-            return false;
-          }
-          b = static_cast<uint8_t>(code[0] | (code[1] << 4));
-        }
-        bytes[static_cast<uint64_t>(lit->second) * device_genomes + g] = b;
-      }
+      const uint64_t g = range_begin[sp] + k, column = by_super_pop[sp][k].column;
+      for (uint64_t l = 0; l < n_loci; ++l) bytes[l * device_genomes + g] = diploid.bytes[l * input_genomes + column];
     }
-  }
+  diploid.bytes.clear();
+  diploid.bytes.shrink_to_fit();
   DeviceMatrix dev;
   dev.handle = kgx_gt8_create(device_genomes, n_loci);
   if (!dev.handle || kgx_gt8_load_rows(dev.handle, bytes.data(), device_genomes, 0, n_loci) != KGX_OK) {
@@ -414,9 +505,8 @@ bool kga::GpuInbreedAnalysis::syntheticInbreeding(GpuParamOutput& param_output) 
     ExecEnv::log().error("InbreedingAnalysis::populationInbreeding, Inbreeding algorithm not found: {}", params.inbreeding_algorithm);
     return true;
   }
-  bool ok = false;
-  const GpuReferenceContig reference = buildReference(*unphased_population_, ok);
-  if (!ok) return false;
+  GpuReferenceContig reference;
+  if (!referenceInput(reference)) return false;
   if (reference.max_alts > 14) {
     ExecEnv::log().error("GpuInbreedAnalysis; a reference offset holds {} SNP alts; at most 14 fit the 4-bit allele index", reference.max_alts);
     return false;

@@ -16,6 +16,7 @@
 #else
 #include "kgx_refshim.h"
 #endif
+#include "kgx_flatten.h"
 
 namespace kellerberrin::genome::analysis {
 
@@ -65,14 +66,8 @@ struct GpuParamOutput {
 
 // The SNP & PASS view of the reference (unphased, mono-genome) contig that locus sampling and the AF tables
 // are cut from (InbreedAnalysis::fileReadAnalysis, kga_analysis_inbreed.cpp:79).
-struct GpuReferenceAlt {
-  std::string hgvs;
-  std::array<double, 6> af{};        // per FrequencyDatabaseRead::superPopulations() slot, NaN = no value
-};
-struct GpuReferenceLocus {
-  ContigOffset_t offset{0};
-  std::vector<GpuReferenceAlt> alts; // OffsetDB array order
-};
+using GpuReferenceAlt = gpu::ReferenceAltRow;       // hgvs + af[6] (NaN = no value)
+using GpuReferenceLocus = gpu::ReferenceLocusRow;   // offset + alts in OffsetDB array order
 class GpuReferenceContig {
  public:
   ContigId_t contig_id;
@@ -108,9 +103,17 @@ class GpuInbreedAnalysis : public VirtualAnalysis {
   // InbreedArguments::extractParameters (kga_analysis_inbreed_args.cpp:8-152)
   [[nodiscard]] static std::vector<GpuInbreedingParameters> extractParameters(const ActiveParameterList& named_parameters);
   [[nodiscard]] static GpuReferenceContig buildReference(const PopulationDB& unphased_population, bool& ok);
+  // The diploid population as allele-index bytes against the reference: [n_loci][genomes holding the contig, id order].
+  [[nodiscard]] static gpu::FlatDiploid diploidBytes(const PopulationDB& diploid_population, const GpuReferenceContig& reference, bool phased);
 
  private:
   bool populationInbreeding(GpuParamOutput& param_output);
+  // Either source of the two inputs: the PopulationDB objects a parser delivered, or "FileNameOnly" VCF files the
+  // package flattens itself (no Variant objects).
+  bool referenceInput(GpuReferenceContig& reference) const;
+  bool diploidInput(const GpuReferenceContig& reference, gpu::FlatDiploid& diploid, bool& phased) const;
+  [[nodiscard]] bool haveReference() const { return unphased_population_ != nullptr || !reference_vcf_.empty(); }
+  [[nodiscard]] bool haveDiploid() const { return diploid_population_ != nullptr || !diploid_vcf_.empty(); }
   // SyntheticAnalysis::syntheticInbreeding (kga_analysis_inbreed_synthetic.cpp:17-138)
   bool syntheticInbreeding(GpuParamOutput& param_output);
 
@@ -132,6 +135,8 @@ class GpuInbreedAnalysis : public VirtualAnalysis {
   std::shared_ptr<const PopulationDB> diploid_population_;
   std::shared_ptr<const PopulationDB> unphased_population_;
   std::shared_ptr<const HsGenomeGenealogyData> genealogy_data_;
+  std::string reference_vcf_, diploid_vcf_;            // FileNameOnly data files (kgl_variant_factory_parsers.cpp:65-66)
+  DataSourceEnum reference_vcf_source_{DataSourceEnum::NotImplemented};
   constexpr static const char DELIMITER_ = ',';
 };
 

@@ -12,6 +12,7 @@
 #include "kgx_refshim.h"
 #endif
 
+#include <array>
 #include <string>
 #include <string_view>
 #include <vector>
@@ -63,6 +64,43 @@ struct FlatPopulation {
 // after FilterPf7::qualityFilter's viewFilter (kga_analysis_lib_PfFilter.cpp:63-67).  Not reproduced: the check of REF
 // against the reference genome's sequence (ParseVCFRecord) -- the VCF is taken at its word.
 [[nodiscard]] FlatPopulation flattenVcfPf(std::string_view text, size_t threads = 0, bool quality_filter = false);
+
+// ---- the INBREED package's two inputs straight from VCF text (SURVEY.md §8f #1 for the K5 path) ------------------
+//
+// The unphased mono-genome reference (Gnomad / 1000-Genomes site files; GrchVCFImpl::ProcessVCFRecord,
+// kgl_parser/kgl_variant_factory_grch_impl.cpp:53-156: one UNPHASED Variant per alt, as written, in one genome), cut
+// down to what InbreedAnalysis keeps of it -- AndFilter(SNPFilter(), PassFilter()) (kga_analysis_inbreed.cpp:79) -- with
+// the six super-population frequencies FrequencyDatabaseRead::superPopFrequency reads for the data source
+// (kgl_variant_db_freq.cpp:13-122; NaN = no value).  Alts of one offset are in file order (the reference's order is
+// the order its parser threads happen to add them in).
+struct ReferenceAltRow {
+  std::string hgvs;
+  std::array<double, 6> af{};              // per FrequencyDatabaseRead::superPopulations() slot, NaN = no value
+};
+struct ReferenceLocusRow {
+  ContigOffset_t offset{0};
+  std::vector<ReferenceAltRow> alts;       // OffsetDB array order
+};
+struct FlatReference {
+  ContigId_t contig_id;                    // of the first record
+  size_t contigs{0};                       // distinct contigs seen (the package insists on exactly 1)
+  uint32_t max_alts{0};
+  std::vector<ReferenceLocusRow> loci;     // ascending offset
+};
+[[nodiscard]] FlatReference flattenReferenceVcf(std::string_view text, DataSourceEnum data_source);
+
+// The phased diploid population (1000-Genomes flavour, as flattenVcf1000) as the allele-index bytes of the inbreeding
+// sweep: for every reference locus and genome, the genome's SNP variants at that offset in the order the parser adds
+// them (phase A alts, then phase B, record by record), each as 1 + its index in the locus's reference alt list (15 =
+// not in the list), two per byte, 0xFF for three or more.  Genomes = samples carrying any variant on the reference's
+// contig (the parser creates a genome's contig when it first adds a variant to it), in id order.
+struct FlatDiploid {
+  std::vector<GenomeId_t> genome_ids;
+  uint64_t n_loci{0};
+  std::vector<uint8_t> bytes;              // [n_loci][genome_ids.size()]
+  std::string error;                       // non-empty: not representable (two same-phase copies of one variant)
+};
+[[nodiscard]] FlatDiploid flattenVcf1000Gt8(std::string_view text, const FlatReference& reference, size_t threads = 0);
 
 // P7FrequencyFilter / CalcFWS bins on the "AF" INFO value of a row (kgl_variant_filter_Pf7.cpp:20-66,
 // kga_analysis_PfEMP_FWS.cpp:15-38,104-145): bin index 0..10, or 0xFF when the row is in no bin

@@ -1,5 +1,6 @@
 // Small extern "C" window onto the host-side flatteners so that they can be tested without a GPU (ctypes).
 // Not part of the device ABI (include/kgx.h): pure host code, no HIP calls.
+#include <cmath>
 #include <cstring>
 
 #include "kgx_flatten.h"
@@ -54,6 +55,52 @@ int kgxh_flat_hgvs(void* h, uint64_t i, char* buf, size_t n) {
 int kgxh_flat_genome_id(void* h, uint64_t i, char* buf, size_t n) {
   if (!h || i >= static_cast<FlatPopulation*>(h)->genome_ids.size()) return -1;
   copyOut(static_cast<FlatPopulation*>(h)->genome_ids[i], buf, n);
+  return 0;
+}
+
+// ---- INBREED inputs from VCF text: reference site file + 1000-Genomes population --------------------------------
+struct InbreedInputs {
+  kellerberrin::genome::analysis::gpu::FlatReference reference;
+  kellerberrin::genome::analysis::gpu::FlatDiploid diploid;
+};
+
+void* kgxh_inbreed_inputs(const char* reference_text, uint64_t reference_len, int data_source, const char* diploid_text, uint64_t diploid_len,
+                          int threads) {
+  if (!reference_text || !diploid_text) return nullptr;
+  namespace g = kellerberrin::genome::analysis::gpu;
+  auto* out = new InbreedInputs();
+  out->reference = g::flattenReferenceVcf(std::string_view(reference_text, reference_len), static_cast<kellerberrin::genome::DataSourceEnum>(data_source));
+  out->diploid = g::flattenVcf1000Gt8(std::string_view(diploid_text, diploid_len), out->reference, threads > 0 ? threads : 0);
+  return out;
+}
+void kgxh_inbreed_inputs_destroy(void* h) { delete static_cast<InbreedInputs*>(h); }
+uint64_t kgxh_inbreed_loci(void* h) { return h ? static_cast<InbreedInputs*>(h)->reference.loci.size() : 0; }
+uint64_t kgxh_inbreed_genomes(void* h) { return h ? static_cast<InbreedInputs*>(h)->diploid.genome_ids.size() : 0; }
+uint64_t kgxh_inbreed_max_alts(void* h) { return h ? static_cast<InbreedInputs*>(h)->reference.max_alts : 0; }
+uint64_t kgxh_inbreed_contigs(void* h) { return h ? static_cast<InbreedInputs*>(h)->reference.contigs : 0; }
+int kgxh_inbreed_error(void* h, char* buf, size_t n) {
+  if (!h) return -1;
+  copyOut(static_cast<InbreedInputs*>(h)->diploid.error, buf, n);
+  return 0;
+}
+// offsets[n_loci], n_alts[n_loci], af[n_loci][amax][6] (NaN = no value), bytes[n_loci][genomes]
+int kgxh_inbreed_copy(void* h, uint64_t* offsets, uint32_t* n_alts, double* af, uint32_t amax, uint8_t* bytes) {
+  if (!h) return -1;
+  const InbreedInputs& in = *static_cast<InbreedInputs*>(h);
+  for (size_t l = 0; l < in.reference.loci.size(); ++l) {
+    const auto& locus = in.reference.loci[l];
+    if (offsets) offsets[l] = locus.offset;
+    if (n_alts) n_alts[l] = static_cast<uint32_t>(locus.alts.size());
+    if (af)
+      for (uint32_t a = 0; a < amax; ++a)
+        for (int sp = 0; sp < 6; ++sp) af[(l * amax + a) * 6 + sp] = a < locus.alts.size() ? locus.alts[a].af[sp] : std::nan("");
+  }
+  if (bytes && !in.diploid.bytes.empty()) std::memcpy(bytes, in.diploid.bytes.data(), in.diploid.bytes.size());
+  return 0;
+}
+int kgxh_inbreed_genome_id(void* h, uint64_t i, char* buf, size_t n) {
+  if (!h || i >= static_cast<InbreedInputs*>(h)->diploid.genome_ids.size()) return -1;
+  copyOut(static_cast<InbreedInputs*>(h)->diploid.genome_ids[i], buf, n);
   return 0;
 }
 

@@ -4,7 +4,7 @@
 // -> finalizeAnalysis on the VirtualAnalysis interface.  Used by the parity tests; in the reference tree the
 // packages are registered in the factory map instead.
 //
-//   kgx_host_driver <IDENT> <work_dir> [key=value ...] -- <records.bin | vcf:<file.vcf>> ...
+//   kgx_host_driver <IDENT> <work_dir> [key=value ...] -- <records.bin | vcf:[<DataSource>:]<file.vcf> | ped:<file>> ...
 //
 // "vcf:<path>" hands the package a FilenameDataDB (the reference's "FileNameOnly" data file,
 // kgl_parser/kgl_variant_factory_parsers.cpp:65-66): the package reads the VCF itself.
@@ -18,6 +18,7 @@
 #include <cstring>
 #include <fstream>
 #include <iostream>
+#include <map>
 
 #include "kga_analysis_gpu_allele.h"
 #if __has_include("kga_analysis_gpu_inbreed.h")
@@ -155,9 +156,28 @@ int main(int argc, char** argv) {
   auto genealogy = std::make_shared<kgl::HsGenomeGenealogyData>("PED");
   for (; i < argc; ++i) {
     if (std::strncmp(argv[i], "vcf:", 4) == 0) {
+      // vcf:<path>  or  vcf:<DataSource>:<path>  (the data source the runtime XML gives the file)
+      static const std::map<std::string, kgl::DataSourceEnum> sources{
+          {"Genome1000", kgl::DataSourceEnum::Genome1000}, {"GnomadGenome3_1", kgl::DataSourceEnum::GnomadGenome3_1},
+          {"Falciparum", kgl::DataSourceEnum::Falciparum}, {"GnomadExomes3_1", kgl::DataSourceEnum::GnomadExomes3_1},
+          {"GnomadExomes2_1", kgl::DataSourceEnum::GnomadExomes2_1}, {"Gnomad3_1", kgl::DataSourceEnum::Gnomad3_1},
+          {"Gnomad3_0", kgl::DataSourceEnum::Gnomad3_0}, {"Gnomad2_1", kgl::DataSourceEnum::Gnomad2_1}};
+      std::string rest(argv[i] + 4);
+      kgl::DataSourceEnum source = kgl::DataSourceEnum::NotImplemented;
+      const size_t colon = rest.find(':');
+      if (colon != std::string::npos) {
+        auto it = sources.find(rest.substr(0, colon));
+        if (it != sources.end()) { source = it->second; rest = rest.substr(colon + 1); }
+      }
       LoadedFile f;
-      f.population = std::make_shared<kgl::FilenameDataDB>(kgl::DataSourceEnum::NotImplemented, std::string(argv[i] + 4));
+      f.population = std::make_shared<kgl::FilenameDataDB>(source, rest);
       files.push_back(std::move(f));
+      continue;
+    }
+    if (std::strncmp(argv[i], "ped:", 4) == 0) {        // genealogy resource: lines of "<genome>\t<super population>"
+      std::ifstream in(argv[i] + 4);
+      std::string genome, sp;
+      while (in >> genome >> sp) genealogy->addGenealogyRecord(kgl::HsGenealogyRecord(genome, sp));
       continue;
     }
     files.push_back(loadRecords(argv[i]));

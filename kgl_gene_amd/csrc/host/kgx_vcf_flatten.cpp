@@ -21,7 +21,9 @@
 #include <cstring>
 #include <limits>
 #include <numeric>
+#include <map>
 #include <thread>
+#include <unordered_map>
 
 #include "kgx_flatten.h"
 
@@ -471,6 +473,206 @@ FlatPopulation flattenVcfPf(std::string_view text, size_t threads, bool quality_
   FlatPopulation flat = mergeRecords(parsed, lines.samples, true);
   flat.contig_ids = lines.contigs;
   return flat;
+}
+
+// ---- INBREED inputs ----------------------------------------------------------------------------------------------
+
+namespace {
+
+// FrequencyDatabaseRead::infoFloatField on raw INFO text (kgl_variant_db_freq.cpp:72-122): a vector with one value per
+// alt gives this alt's value, a single value serves every alt, any other size gives nothing; missing values are nothing.
+double infoFrequency(std::string_view info, std::string_view field, size_t alt_index, size_t alt_count) {
+  const double none = std::numeric_limits<double>::quiet_NaN();
+  for (const auto item : split(info, ';')) {
+    if (item.size() <= field.size() || item[field.size()] != '=' || item.substr(0, field.size()) != field) continue;
+    const auto values = split(item.substr(field.size() + 1), ',');
+    float f;
+    if (values.size() == alt_count) f = infoFloat(values[alt_index]);
+    else if (values.size() == 1) f = infoFloat(values[0]);
+    else return none;
+    return std::isnan(f) ? none : static_cast<double>(f);
+  }
+  return none;
+}
+
+}  // namespace
+
+FlatReference flattenReferenceVcf(std::string_view text, DataSourceEnum data_source) {
+  const VcfLines lines = scanLines(text);
+  const auto& super_pops = FrequencyDatabaseRead::superPopulations();
+  std::vector<std::string> fields;
+  for (const auto& sp : super_pops) fields.push_back(FrequencyDatabaseRead::lookupVariantSuperPopField(data_source, sp).value_or(std::string()));
+  FlatReference out;
+  std::map<ContigOffset_t, ReferenceLocusRow> by_offset;
+  std::vector<std::string> contigs_seen;
+  for (const auto record : lines.records) {
+    const auto f = split(record, '\t', 10);
+    if (f.size() < 8) continue;
+    bool pos_ok = true;
+    const uint64_t pos = parseIndex(f[1], pos_ok);
+    if (!pos_ok) continue;
+    const std::string contig(f[0]);
+    if (std::find(contigs_seen.begin(), contigs_seen.end(), contig) == contigs_seen.end()) contigs_seen.push_back(contig);
+    std::string filter(f[6]);
+    for (auto& c : filter) c = static_cast<char>(std::toupper(static_cast<unsigned char>(c)));
+    if (filter != "PASS") continue;                                     // PassFilter
+    const std::string_view ref = f[3];
+    // "The alt field can be blank": no ',' or an empty field is ONE alt, taken as written (:68-70)
+    std::vector<std::string_view> alts;
+    if (f[4].find(',') == std::string_view::npos || f[4].empty()) alts.push_back(f[4]);
+    else alts = split(f[4], ',');
+    for (size_t a = 0; a < alts.size(); ++a) {
+      if (!isSnp(ref, alts[a])) continue;                               // SNPFilter
+      ReferenceAltRow alt;
+      alt.hgvs = contig + ":g." + std::to_string(pos - 1) + std::string(ref) + ">" + std::string(alts[a]);
+      for (size_t sp = 0; sp < 6 && sp < fields.size(); ++sp)
+        alt.af[sp] = fields[sp].empty() ? std::numeric_limits<double>::quiet_NaN() : infoFrequency(f[7], fields[sp], a, alts.size());
+      ReferenceLocusRow& locus = by_offset[pos - 1];
+      locus.offset = pos - 1;
+      locus.alts.push_back(std::move(alt));
+    }
+  }
+  out.contigs = contigs_seen.size();
+  if (!contigs_seen.empty()) out.contig_id = contigs_seen.front();
+  for (auto& [offset, locus] : by_offset) {
+    out.max_alts = std::max<uint32_t>(out.max_alts, static_cast<uint32_t>(locus.alts.size()));
+    out.loci.push_back(std::move(locus));
+  }
+  return out;
+}
+
+FlatDiploid flattenVcf1000Gt8(std::string_view text, const FlatReference& reference, size_t threads) {
+  const VcfLines lines = scanLines(text);
+  const size_t S = lines.samples.size();
+  FlatDiploid out;
+  out.n_loci = reference.loci.size();
+  std::unordered_map<ContigOffset_t, uint32_t> locus_of_offset;
+  locus_of_offset.reserve(reference.loci.size() * 2);
+  for (uint32_t l = 0; l < reference.loci.size(); ++l) locus_of_offset.emplace(reference.loci[l].offset, l);
+
+  // Per record: the locus it lands on (or none), per alt its code in that locus's list (0 = not a SNP: filtered out
+  // before the sweep, _freq.cpp:436), and per sample the two alt numbers.
+  struct RecordCalls {
+    int64_t locus{-1};
+    bool on_contig{false};
+    std::vector<uint8_t> code;            // [n_alt]
+    std::vector<uint8_t> calls;           // [S]: phase A alt | phase B alt << 4  (alt numbers up to 15 fit; larger ones are clipped below)
+    std::vector<std::pair<uint32_t, std::pair<uint32_t, uint32_t>>> wide;   // samples whose alt numbers need more than 4 bits
+    std::vector<uint8_t> carries;         // [S] 1 if the sample carries ANY alt of the record (SNP or not)
+  };
+  std::vector<RecordCalls> parsed(lines.records.size());
+  {
+    if (threads == 0) threads = std::max<size_t>(std::thread::hardware_concurrency(), 2) - 1;
+    std::atomic<size_t> next{0};
+    auto worker = [&]() {
+      for (size_t r = next.fetch_add(1); r < lines.records.size(); r = next.fetch_add(1)) {
+        RecordCalls& rc = parsed[r];
+        const auto f = split(lines.records[r], '\t', S + 10);
+        if (f.size() < 8) continue;
+        if (f[0] != reference.contig_id) continue;
+        bool pos_ok = true;
+        const uint64_t pos = parseIndex(f[1], pos_ok);
+        if (!pos_ok) continue;
+        rc.on_contig = true;
+        const std::string_view ref = f[3];
+        const std::string_view alt_field = f[4] == "." ? std::string_view() : f[4];
+        const auto alts = split(alt_field, ',');
+        const size_t A = alts.size();
+        const auto found = locus_of_offset.find(pos - 1);
+        rc.code.assign(A, 0);
+        if (found != locus_of_offset.end()) {
+          rc.locus = found->second;
+          const auto& list = reference.loci[found->second].alts;
+          for (size_t a = 0; a < A; ++a) {
+            if (!isSnp(ref, alts[a])) continue;
+            const std::string hgvs = std::string(f[0]) + ":g." + std::to_string(pos - 1) + std::string(ref) + ">" + std::string(alts[a]);
+            uint8_t c = 15;
+            for (size_t j = 0; j < list.size() && j < 14; ++j)
+              if (list[j].hgvs == hgvs) { c = static_cast<uint8_t>(j + 1); break; }
+            rc.code[a] = c;
+          }
+        }
+        rc.calls.assign(S, 0);
+        rc.carries.assign(S, 0);
+        const Chromosome chrom = chromosomeOf(f[0]);
+        for (size_t idx = 9; idx < f.size() && idx - 9 < S; ++idx) {
+          uint32_t pa, pb;
+          phasedAlleles(f[idx], A, chrom, pa, pb);
+          if (pa || pb) rc.carries[idx - 9] = 1;
+          if (pa > 15 || pb > 15) rc.wide.push_back({static_cast<uint32_t>(idx - 9), {pa, pb}});
+          else rc.calls[idx - 9] = static_cast<uint8_t>(pa | (pb << 4));
+        }
+      }
+    };
+    const size_t n = std::max<size_t>(1, std::min(threads, lines.records.size()));
+    std::vector<std::thread> pool;
+    for (size_t t = 1; t < n; ++t) pool.emplace_back(worker);
+    worker();
+    for (auto& th : pool) th.join();
+  }
+
+  // genomes that hold the contig, in id order; a sample named twice is one genome
+  std::vector<uint8_t> holds(S, 0);
+  for (const auto& rc : parsed)
+    if (rc.on_contig)
+      for (size_t s = 0; s < rc.carries.size(); ++s) holds[s] |= rc.carries[s];
+  std::vector<uint32_t> order;
+  for (uint32_t s = 0; s < S; ++s) if (holds[s]) order.push_back(s);
+  std::sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) { return lines.samples[x] < lines.samples[y]; });
+  std::vector<int64_t> genome_of_sample(S, -1);
+  for (uint32_t s : order) {
+    if (out.genome_ids.empty() || out.genome_ids.back() != lines.samples[s]) out.genome_ids.push_back(lines.samples[s]);
+    genome_of_sample[s] = static_cast<int64_t>(out.genome_ids.size()) - 1;
+  }
+  // a second column of an already-seen sample name
+  for (uint32_t s = 0; s < S; ++s)
+    if (genome_of_sample[s] < 0 && holds[s])
+      genome_of_sample[s] = std::lower_bound(out.genome_ids.begin(), out.genome_ids.end(), lines.samples[s]) - out.genome_ids.begin();
+  const size_t G = out.genome_ids.size();
+  out.bytes.assign(out.n_loci * G, 0);
+
+  // Assemble in record order.  Per (locus, genome): count of SNP variants so far, their codes and phases.
+  std::vector<uint8_t> count(out.n_loci * G, 0), first_phase(out.n_loci * G, 0);
+  auto add = [&](uint64_t cell, uint8_t code, uint8_t phase, uint32_t sample) -> bool {
+    const uint8_t n = count[cell];
+    if (n == 0) { out.bytes[cell] = code; first_phase[cell] = phase; }
+    else if (n == 1) {
+      const uint8_t c0 = out.bytes[cell] & 0xF;
+      if (c0 == code && code != 15 && first_phase[cell] == phase) {
+        out.error = "Genome: " + lines.samples[sample] + " holds two copies of one variant with the SAME phase; not representable";
+        return false;
+      }
+      out.bytes[cell] = static_cast<uint8_t>(c0 | (code << 4));
+    } else {
+      out.bytes[cell] = 0xFF;
+    }
+    if (n < 3) count[cell] = static_cast<uint8_t>(n + 1);
+    return true;
+  };
+  for (const auto& rc : parsed) {
+    if (rc.locus < 0) continue;
+    const size_t A = rc.code.size();
+    // Genome1000VCFImpl::addVariants: all phase A variants of the record are added first (by alt), then phase B
+    for (uint8_t phase = 0; phase < 2; ++phase) {
+      for (size_t s = 0; s < rc.calls.size(); ++s) {
+        if (genome_of_sample[s] < 0) continue;
+        const uint32_t alt = phase == 0 ? (rc.calls[s] & 0xFu) : (rc.calls[s] >> 4);
+        if (alt == 0 || alt > A) continue;
+        const uint8_t code = rc.code[alt - 1];
+        if (code == 0) continue;                                        // not a SNP
+        if (!add(static_cast<uint64_t>(rc.locus) * G + static_cast<uint64_t>(genome_of_sample[s]), code, phase, static_cast<uint32_t>(s))) return out;
+      }
+      for (const auto& [s, ab] : rc.wide) {
+        if (genome_of_sample[s] < 0) continue;
+        const uint32_t alt = phase == 0 ? ab.first : ab.second;
+        if (alt == 0 || alt > A) continue;
+        const uint8_t code = rc.code[alt - 1];
+        if (code == 0) continue;
+        if (!add(static_cast<uint64_t>(rc.locus) * G + static_cast<uint64_t>(genome_of_sample[s]), code, phase, s)) return out;
+      }
+    }
+  }
+  return out;
 }
 
 }  // namespace kellerberrin::genome::analysis::gpu

@@ -49,6 +49,7 @@ namespace kgo {
 std::pair<size_t, size_t> alternateIndex1000(const std::string& contig, const std::string& genotype, size_t n_alt);
 long addVcf1000(PopulationDB& population, std::string_view text, std::vector<std::string>* genome_names_out);
 long addVcfPf(PopulationDB& population, std::string_view text, std::vector<std::string>* genome_names_out);
+long addVcfMonoGenome(PopulationDB& population, std::string_view text, const std::string& source, const std::string& genome_id);
 bool p7VariantFilter(const Variant& v);
 void canonicalSequences(const std::string& ref, const std::string& alt, uint64_t offset, std::string& c_ref, std::string& c_alt, uint64_t& c_offset);
 }
@@ -162,6 +163,13 @@ long kgo_population_add_vcf_pf(kgo_pop* p, const char* text, uint64_t len) {
   const long n = addVcfPf(*p->pop, std::string_view(text, len), &names);
   if (p->input_ids.empty()) p->input_ids = names;
   return n;
+}
+
+// VCF text of a mono-genome frequency source (Gnomad ...) -> UNPHASED Variants in one genome; -1 for an unknown source.
+long kgo_population_add_vcf_mono(kgo_pop* p, const char* text, uint64_t len, const char* source, const char* genome_id) {
+  if (!p || !text || !source || !genome_id) return -1;
+  if (p->input_ids.empty()) p->input_ids = {genome_id};
+  return addVcfMonoGenome(*p->pop, std::string_view(text, len), source, genome_id);
 }
 
 // PopulationDB::viewFilter(P7VariantFilter()) (kga_analysis_lib_PfFilter.cpp:63-67).

@@ -102,9 +102,23 @@ static float convertToFloat(const std::string& value) {
 }
 
 // INFO "k=v;k2=a,b" -> per super-population AF vectors using the 1000-Genomes field names (kgl_variant_db_freq.h:84-96).
-static void parseInfoAF(std::string_view info, uint32_t n_alt, std::vector<float>& af, int& info_af_size) {
+static const char* const kFields1000[SUPER_POP_COUNT] = {"AFR_AF", "AMR_AF", "EAS_AF", "EUR_AF", "SAS_AF", "AF"};
+
+// Field names per data source (kgl_variant_db_freq.h:84-96); nullptr for a source the table does not hold.
+static const char* const* superPopFields(const std::string& source) {
+  static const char* const gnomad2_1[SUPER_POP_COUNT] = {"AF_afr", "AF_amr", "AF_eas", "AF_nfe", "AF", "AF"};
+  static const char* const gnomad_ex2_1[SUPER_POP_COUNT] = {"AF_afr", "AF_amr", "AF_eas", "AF_nfe", "AF_sas", "AF"};
+  static const char* const gnomad_genome3_1[SUPER_POP_COUNT] = {"gnomad_AF_afr", "gnomad_AF_amr", "gnomad_AF_eas", "gnomad_AF_nfe", "gnomad_AF_sas", "gnomad_AF"};
+  if (source == "Gnomad2_1") return gnomad2_1;
+  if (source == "GnomadExomes2_1" || source == "Gnomad3_1" || source == "GnomadExomes3_1" || source == "Gnomad3_0") return gnomad_ex2_1;
+  if (source == "GnomadGenome3_1") return gnomad_genome3_1;
+  if (source == "Genome1000") return kFields1000;
+  return nullptr;
+}
+
+static void parseInfoAF(std::string_view info, uint32_t n_alt, std::vector<float>& af, int& info_af_size,
+                        const char* const* fields = kFields1000) {
   info_af_size = -1;
-  static const char* fields[SUPER_POP_COUNT] = {"AFR_AF", "AMR_AF", "EAS_AF", "EUR_AF", "SAS_AF", "AF"};
   af.assign(static_cast<size_t>(SUPER_POP_COUNT) * n_alt, std::numeric_limits<float>::quiet_NaN());
   for (auto item : viewTokenizer(info, ';')) {
     const size_t eq = item.find('=');
@@ -113,7 +127,7 @@ static void parseInfoAF(std::string_view info, uint32_t n_alt, std::vector<float
     for (int sp = 0; sp < SUPER_POP_COUNT; ++sp) {
       if (key != fields[sp]) continue;
       auto values = viewTokenizer(value, ',');
-      if (sp == ALL) info_af_size = static_cast<int>(values.size());
+      if (sp == ALL && key == "AF") info_af_size = static_cast<int>(values.size());
       if (values.size() == n_alt) {
         for (uint32_t a = 0; a < n_alt; ++a) af[static_cast<size_t>(sp) * n_alt + a] = convertToFloat(std::string(values[a]));
       } else if (values.size() == 1) {       // scalar field: the same value for every alt (infoFloatField, kgl_variant_db_freq.cpp:78-81)
@@ -175,6 +189,41 @@ long addVcf1000(PopulationDB& population, std::string_view text, std::vector<std
     ++n_records;
   }
   if (genome_names_out) *genome_names_out = genome_names;
+  return n_records;
+}
+
+// ---- the unphased mono-genome frequency sources (Gnomad ...) -------------------------------------------------------
+
+// GrchVCFImpl::ProcessVCFRecord (kgl_parser/kgl_variant_factory_grch_impl.cpp:53-156): one UNPHASED Variant per alt, as
+// written (no canonicalisation), all in the one reference genome; an ALT without ',' (or empty) is a single alt.
+long addVcfMonoGenome(PopulationDB& population, std::string_view text, const std::string& source, const std::string& genome_id) {
+  const char* const* fields = superPopFields(source);
+  if (!fields) return -1;
+  long n_records = 0;
+  const std::vector<std::string> genome_vector{genome_id};
+  for (auto line : viewTokenizer(text, '\n')) {
+    if (!line.empty() && line.back() == '\r') line.remove_suffix(1);
+    if (line.empty() || line[0] == '#') continue;
+    auto field_views = viewTokenizer(line, '\t');
+    if (field_views.size() < 8) continue;
+    const std::string contig(field_views[0]);
+    const uint64_t offset = std::stoull(std::string(field_views[1])) - 1;
+    const std::string ref(field_views[3]);
+    const std::string alt(field_views[4]);
+    std::string filter_uc;
+    for (char c : field_views[6]) filter_uc += static_cast<char>(std::toupper(static_cast<unsigned char>(c)));
+    std::vector<std::string> alt_vector;
+    if (alt.find(',') == std::string::npos || alt.empty()) alt_vector.push_back(alt);
+    else for (auto a : viewTokenizer(alt, ',')) alt_vector.emplace_back(a);
+    auto ev = std::make_shared<RecordEvidence>();
+    ev->record_index = static_cast<uint64_t>(n_records);
+    ev->pass = filter_uc == "PASS";
+    ev->alt_count = static_cast<uint32_t>(alt_vector.size());
+    parseInfoAF(field_views[7], ev->alt_count, ev->af, ev->info_af_size, fields);
+    for (uint32_t a = 0; a < alt_vector.size(); ++a)
+      population.addVariant(std::make_shared<const Variant>(contig, offset, VariantPhase::UNPHASED, ref, alt_vector[a], ev, a), genome_vector);
+    ++n_records;
+  }
   return n_records;
 }
 

@@ -33,6 +33,15 @@ def lib():
         L.kgxh_flat_copy.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.kgxh_flat_hgvs.argtypes = [C.c_void_p, C.c_uint64, C.c_char_p, C.c_size_t]
         L.kgxh_flat_genome_id.argtypes = [C.c_void_p, C.c_uint64, C.c_char_p, C.c_size_t]
+        L.kgxh_inbreed_inputs.restype = C.c_void_p
+        L.kgxh_inbreed_inputs.argtypes = [C.c_char_p, C.c_uint64, C.c_int, C.c_char_p, C.c_uint64, C.c_int]
+        L.kgxh_inbreed_inputs_destroy.argtypes = [C.c_void_p]
+        for name in ("kgxh_inbreed_loci", "kgxh_inbreed_genomes", "kgxh_inbreed_max_alts", "kgxh_inbreed_contigs"):
+            getattr(L, name).restype = C.c_uint64
+            getattr(L, name).argtypes = [C.c_void_p]
+        L.kgxh_inbreed_error.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t]
+        L.kgxh_inbreed_copy.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]
+        L.kgxh_inbreed_genome_id.argtypes = [C.c_void_p, C.c_uint64, C.c_char_p, C.c_size_t]
         _lib = L
     return _lib
 
@@ -67,3 +76,31 @@ class FlatVcf:
                 self.genome_ids.append(buf.value.decode())
         finally:
             lib().kgxh_flat_destroy(h)
+
+
+class InbreedInputs:
+    """The INBREED package's two inputs flattened from VCF text: reference loci (offset, alts, AF per super population)
+    and the population's allele-index bytes [n_loci][genomes]."""
+
+    def __init__(self, reference_text: str, data_source: int, diploid_text: str, threads: int = 0):
+        rb, db = reference_text.encode(), diploid_text.encode()
+        h = lib().kgxh_inbreed_inputs(rb, len(rb), data_source, db, len(db), threads)
+        assert h
+        try:
+            self.L, self.G = int(lib().kgxh_inbreed_loci(h)), int(lib().kgxh_inbreed_genomes(h))
+            self.amax, self.contigs = int(lib().kgxh_inbreed_max_alts(h)), int(lib().kgxh_inbreed_contigs(h))
+            buf = C.create_string_buffer(1024)
+            lib().kgxh_inbreed_error(h, buf, 1024)
+            self.error = buf.value.decode()
+            self.offsets = np.zeros(self.L, dtype=np.uint64)
+            self.n_alts = np.zeros(self.L, dtype=np.uint32)
+            self.af = np.zeros((self.L, max(self.amax, 1), 6), dtype=np.float64)
+            self.bytes = np.zeros((self.L, self.G), dtype=np.uint8)
+            p = lambda a: C.c_void_p(a.ctypes.data)
+            lib().kgxh_inbreed_copy(h, p(self.offsets), p(self.n_alts), p(self.af), max(self.amax, 1), p(self.bytes) if self.G and not self.error else None)
+            self.genome_ids = []
+            for i in range(self.G):
+                lib().kgxh_inbreed_genome_id(h, i, buf, 1024)
+                self.genome_ids.append(buf.value.decode())
+        finally:
+            lib().kgxh_inbreed_inputs_destroy(h)

@@ -42,6 +42,7 @@ def lib() -> C.CDLL:
         "kgo_population_add_records": (C.c_int, [vp, C.c_int, C.c_char_p, u64, vp, vp, vp, vp, vp, vp, u64, vp, vp]),
         "kgo_population_add_vcf_1000": (C.c_long, [vp, C.c_char_p, u64]),
         "kgo_population_add_vcf_pf": (C.c_long, [vp, C.c_char_p, u64]),
+        "kgo_population_add_vcf_mono": (C.c_long, [vp, C.c_char_p, u64, C.c_char_p, C.c_char_p]),
         "kgo_hethom_present": (C.c_int, [vp, C.c_char_p, vp]),
         "kgo_population_filter_p7": (vp, [vp]),
         "kgo_canonical": (u64, [C.c_char_p, C.c_char_p, u64, C.c_char_p, C.c_char_p]),
@@ -170,6 +171,15 @@ class Population:
         b = text.encode()
         n = lib().kgo_population_add_vcf_pf(self._h, b, len(b))
         assert n >= 0
+        return int(n)
+
+    def add_vcf_mono(self, text: str, source: str, genome_id: str = "Reference") -> int:
+        """Parse the VCF of a mono-genome frequency source (Gnomad ...) the way GrchVCFImpl does."""
+        b = text.encode()
+        n = lib().kgo_population_add_vcf_mono(self._h, b, len(b), source.encode(), genome_id.encode())
+        assert n >= 0
+        if not self.genome_ids:
+            self.genome_ids = [genome_id]
         return int(n)
 
     def filter_p7(self):

@@ -231,3 +231,54 @@ def test_gpu_allele_package_reads_pf_vcf(tmp_path, kgx, quality_filter):
     assert n_rows == len(got)
     if not quality_filter:
         assert n_rows == 4 * G                                     # every genome holds every header contig
+
+
+@pytest.mark.parametrize("algorithm", ["Simple", "HallME"])
+def test_gpu_inbreed_package_reads_vcf_directly(tmp_path, kgx, algorithm):
+    """Both INBREED inputs as "FileNameOnly" VCF files: the package flattens the Gnomad site file into its reference
+    contig and the 1000-Genomes VCF into allele-index bytes itself.  Same window loop, same CSVs as from PopulationDB
+    objects -- checked against the oracle fed by its own restatements of the two parsers."""
+    from . import vcf_text as vt
+
+    G, L = 53, 1800
+    rec, gt = sv.multiallelic_block(G, L, rng_seed=17, missing_af_frac=0.03, dup_records=0)
+    for a in rec.af:
+        a[:, 4] = a[:, 5]                   # Gnomad 2.1 reads SAS from the same "AF" field as ALL
+    ids = sv.genome_ids(G, prefix="HG")
+    pops = ["AFR", "AMR", "EAS", "EUR", "SAS"]
+    ped = [(g, pops[i % 5]) for i, g in enumerate(ids) if i % 11 != 3]
+    ref_text = vt.write_vcf_mono(rec, "Gnomad2_1")
+    dip_text = vt.write_vcf_1000(rec, gt, ids, rng_seed=8)
+    (tmp_path / "gnomad.vcf").write_text(ref_text)
+    (tmp_path / "kg.vcf").write_text(dip_text)
+    (tmp_path / "ped.txt").write_text("".join(f"{g}\t{sp}\n" for g, sp in ped))
+    params = dict(AnalysisType="false", OutputFile="inbreed", Algorithm=algorithm, MinAlleleFreq=0.02, MaxAlleleFreq=0.9,
+                  LowerWindow=0, UpperWindow=60000, LociiCount=150, SamplingDistance=40)
+    res = rio.run_driver("GPU_INBREED", tmp_path, [f"vcf:Gnomad2_1:{tmp_path / 'gnomad.vcf'}", f"vcf:Genome1000:{tmp_path / 'kg.vcf'}",
+                                                    f"ped:{tmp_path / 'ped.txt'}"], **params)
+    assert res.returncode == 0, res.stderr
+
+    ref = oa.Population("gnomad")
+    ref.add_vcf_mono(ref_text, "Gnomad2_1")
+    dip = oa.Population("kg")
+    dip.add_vcf_1000(dip_text)
+    vdb_ids = [oa.VariantDB(dip).genome_id(i) for i in range(dip.genome_count())]
+    ped_map = dict(ped)
+    sp_of = np.array([oa.SUPER_POPS.index(ped_map[g]) if g in ped_map else -1 for g in vdb_ids], dtype=np.int32)
+    cols = oa.population_inbreeding(ref.filter_snp_pass(), dip, sp_of, algorithm, 0, 60000, 40, 150, 0.02, 0.9, seed=oa.FIXED_STARTS)
+    assert len(cols) >= 3
+    header, rows = rio.read_csv(tmp_path / "inbreed_detail.csv")
+    got = {(r[0], r[1]): ([int(r[2]), int(r[4]), int(r[6]), int(r[8]), int(r[10])], [float(r[3]), float(r[5]), float(r[7]), float(r[9]), float(r[11])])
+           for r in rows}
+    n_checked = 0
+    for ident, counts, freqs, present in cols:
+        for k, g in enumerate(vdb_ids):
+            if not present[k]:
+                assert (ident, g) not in got
+                continue
+            c, f = got[(ident, g)]
+            assert c == counts[k].tolist(), (ident, g)
+            assert np.allclose(f[:4], freqs[k, :4], rtol=1e-12, atol=1e-12)
+            assert abs(f[4] - freqs[k, 4]) <= {"Simple": 1e-10, "HallME": 1e-9}[algorithm], (ident, g, f[4], freqs[k, 4])
+            n_checked += 1
+    assert n_checked == len(got) and n_checked >= 3 * (G - 10)

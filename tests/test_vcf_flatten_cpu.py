@@ -143,3 +143,39 @@ def test_vcf_pf_edge_cases():
     # both records fail P7VariantFilter (VQSLOD < 0; QD < 2)
     assert ha.FlatVcf(hdr + body, flavour="Falciparum", quality_filter=True).V == 0
     assert o.filter_p7().variant_count() == 0
+
+
+@pytest.mark.parametrize("threads", [1, 4])
+def test_inbreed_inputs_from_vcf_match_the_scaffold_encoder(threads):
+    """Reference site VCF + 1000-Genomes VCF -> (reference loci, AF per super population, allele-index bytes): the
+    product's flatteners against tests/inbreed_inputs.py, the independent numpy restatement the kernel tests use."""
+    from . import inbreed_inputs as ii
+    from .records_io import DATA_SOURCE
+
+    G, L = 31, 1200
+    rec, gt = sv.multiallelic_block(G, L, rng_seed=5, missing_af_frac=0.05, dup_records=0)
+    for a in rec.af:
+        a[:, 4] = a[:, 5]
+    ids = [f"NA{i:05d}" for i in reversed(range(G))]
+    ref_text = vt.write_vcf_mono(rec, "Gnomad2_1")
+    dip_text = vt.write_vcf_1000(rec, gt, ids, rng_seed=1, quirks=False)
+    got = ha.InbreedInputs(ref_text, DATA_SOURCE["Gnomad2_1"], dip_text, threads)
+    assert got.error == "" and got.contigs == 1
+    loci = ii.ReferenceLoci(rec)
+    assert np.array_equal(got.offsets, loci.offsets)
+    assert got.n_alts.tolist() == [len(a) for a in loci.alts] and got.amax == max(len(a) for a in loci.alts)
+    for l in range(got.L):
+        want = np.asarray(loci.af[l], dtype=np.float64)
+        assert np.array_equal(np.isnan(got.af[l, :len(want)]), np.isnan(want)) and np.allclose(np.nan_to_num(got.af[l, :len(want)]), np.nan_to_num(want), rtol=0, atol=0)
+    # genomes: carriers of anything on the contig, in id order
+    carriers = sorted(ids[g] for g in range(G) if gt[:, g, :].any())
+    assert got.genome_ids == carriers
+    column = {name: g for g, name in enumerate(ids)}
+    want_bytes = ii.encode_gt8(rec, gt, loci)[:, [column[name] for name in carriers]]
+    assert np.array_equal(got.bytes, want_bytes)
+    # a second phase-A copy of one variant in one genome is refused: repeat a PASS SNP record some genome carries
+    l0 = next(l for l in range(got.L) if (got.bytes[l] & 0xF).any() and ((got.bytes[l] & 0xF) != 15).any())
+    pos = str(int(got.offsets[l0]) + 1)
+    repeated = [line for line in dip_text.split("\n") if line and not line.startswith("#") and line.split("\t")[1] == pos]
+    bad = ha.InbreedInputs(ref_text, DATA_SOURCE["Gnomad2_1"], dip_text + "\n".join(repeated) + "\n")
+    assert "SAME phase" in bad.error

@@ -170,3 +170,24 @@ def write_vcf_pf(n_records, ids, rng_seed=0, quirks=True):
         flt = "PASS" if r % 6 else "LowQual"
         lines.append("\t".join([contig, str(pos), ".", ref, ",".join(alts), "50", flt, ";".join(info), ":".join(fmt)] + cols))
     return "\n".join(lines) + "\n"
+
+
+def write_vcf_mono(rec, source="Gnomad2_1", contig=None):
+    """A mono-genome frequency source (Gnomad site file): no FORMAT / sample columns; the six super-population AF
+    vectors under the INFO names the reference's table gives the data source."""
+    from .records_io import AF_FIELDS
+
+    fields = AF_FIELDS[source]
+    contig = contig or rec.contig
+    lines = ["##fileformat=VCFv4.2", "#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO"]
+    for r in range(rec.n_records):
+        af = np.asarray(rec.af[r], dtype=np.float32).reshape(-1, 6)
+        info = []
+        for sp, name in enumerate(fields):
+            if name is None or any(x.startswith(name + "=") for x in info):
+                continue
+            info.append(f"{name}=" + ",".join("." if np.isnan(v) else repr(float(v)) for v in af[:, sp]))
+        passed = True if rec.passed is None else bool(rec.passed[r])
+        flt = ("PASS" if r % 3 else "pass") if passed else "AC0"
+        lines.append("\t".join([contig, str(int(rec.offsets[r]) + 1), f"rs{r}", rec.refs[r], ",".join(rec.alts[r]), "100", flt, ";".join(info)]))
+    return "\n".join(lines) + "\n"
