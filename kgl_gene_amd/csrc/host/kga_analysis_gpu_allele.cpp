@@ -4,6 +4,7 @@
 #include <iterator>
 
 #include "../../../include/kgx.h"
+#include "kgx_vcf_io.h"
 
 namespace kga = kellerberrin::genome::analysis;
 namespace kgl = kellerberrin::genome;
@@ -82,12 +83,11 @@ bool kga::GpuAlleleAnalysis::sweepPopulation(const PopulationDB& population) {
 }
 
 bool kga::GpuAlleleAnalysis::sweepVcfFile(const std::string& file_name) {
-  std::ifstream in(file_name, std::ios::binary);
-  if (!in.good()) {
-    ExecEnv::log().error("GpuAlleleAnalysis; cannot open VCF file: {}", file_name);
+  std::string text, io_error;
+  if (!gpu::readVcfText(file_name, text, io_error)) {                // plain text, .gz or .bgz
+    ExecEnv::log().error("GpuAlleleAnalysis; {}", io_error);
     return false;
   }
-  std::string text((std::istreambuf_iterator<char>(in)), std::istreambuf_iterator<char>());
   if (vcf_flavour_ == "Genome1000") return sweepFlat(gpu::flattenVcf1000(text), file_name);
   if (vcf_flavour_ != "Falciparum") {
     ExecEnv::log().error("GpuAlleleAnalysis; unknown VcfFlavour: {} (Genome1000 or Falciparum)", vcf_flavour_);

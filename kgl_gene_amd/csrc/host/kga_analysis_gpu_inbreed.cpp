@@ -9,6 +9,7 @@
 #include <unordered_map>
 
 #include "../../../include/kgx.h"
+#include "kgx_vcf_io.h"
 
 namespace kga = kellerberrin::genome::analysis;
 namespace kgl = kellerberrin::genome;
@@ -244,24 +245,15 @@ bool kga::GpuInbreedAnalysis::iterationAnalysis() {
   return ok;
 }
 
-namespace {
-bool readWholeFile(const std::string& file_name, std::string& text) {
-  std::ifstream in(file_name, std::ios::binary);
-  if (!in.good()) return false;
-  text.assign((std::istreambuf_iterator<char>(in)), std::istreambuf_iterator<char>());
-  return true;
-}
-}  // namespace
-
 bool kga::GpuInbreedAnalysis::referenceInput(GpuReferenceContig& reference) const {
   if (unphased_population_) {
     bool ok = false;
     reference = buildReference(*unphased_population_, ok);
     return ok;
   }
-  std::string text;
-  if (!readWholeFile(reference_vcf_, text)) {
-    ExecEnv::log().error("GpuInbreedAnalysis; cannot open reference VCF file: {}", reference_vcf_);
+  std::string text, io_error;
+  if (!gpu::readVcfText(reference_vcf_, text, io_error)) {           // plain text, .gz or .bgz
+    ExecEnv::log().error("GpuInbreedAnalysis; reference VCF: {}", io_error);
     return false;
   }
   gpu::FlatReference flat = gpu::flattenReferenceVcf(text, reference_vcf_source_);
@@ -334,9 +326,9 @@ bool kga::GpuInbreedAnalysis::diploidInput(const GpuReferenceContig& reference, 
     phased = diploid_population_->dataCharacteristic().data_structure == DataStructureEnum::DiploidPhased;
     diploid = diploidBytes(*diploid_population_, reference, phased);
   } else {
-    std::string text;
-    if (!readWholeFile(diploid_vcf_, text)) {
-      ExecEnv::log().error("GpuInbreedAnalysis; cannot open population VCF file: {}", diploid_vcf_);
+    std::string text, io_error;
+    if (!gpu::readVcfText(diploid_vcf_, text, io_error)) {
+      ExecEnv::log().error("GpuInbreedAnalysis; population VCF: {}", io_error);
       return false;
     }
     phased = true;                                                   // Genome1000: DiploidPhased (kgl_data_file_type.h:118-134)

@@ -1,9 +1,11 @@
 // Small extern "C" window onto the host-side flatteners so that they can be tested without a GPU (ctypes).
 // Not part of the device ABI (include/kgx.h): pure host code, no HIP calls.
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 
 #include "kgx_flatten.h"
+#include "kgx_vcf_io.h"
 
 using kellerberrin::genome::analysis::gpu::FlatPopulation;
 
@@ -57,6 +59,22 @@ int kgxh_flat_genome_id(void* h, uint64_t i, char* buf, size_t n) {
   copyOut(static_cast<FlatPopulation*>(h)->genome_ids[i], buf, n);
   return 0;
 }
+
+// File -> text (plain / gzip / block gzip).  Returns a malloc'd buffer the caller frees with kgxh_free, or null.
+char* kgxh_read_vcf_text(const char* path, uint64_t* len, int threads, char* error, size_t error_len) {
+  std::string text, err;
+  if (!path || !kellerberrin::genome::analysis::gpu::readVcfText(path, text, err, threads > 0 ? threads : 0)) {
+    copyOut(err, error, error_len);
+    return nullptr;
+  }
+  char* out = static_cast<char*>(std::malloc(text.size() + 1));
+  if (!out) return nullptr;
+  std::memcpy(out, text.data(), text.size());
+  out[text.size()] = 0;
+  if (len) *len = text.size();
+  return out;
+}
+void kgxh_free(void* p) { std::free(p); }
 
 // ---- INBREED inputs from VCF text: reference site file + 1000-Genomes population --------------------------------
 struct InbreedInputs {

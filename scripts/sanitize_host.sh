@@ -8,8 +8,8 @@ rm -rf $OUT && mkdir -p $OUT
 SAN="-O1 -g -fsanitize=address,undefined -fno-omit-frame-pointer -fno-sanitize-recover=undefined"
 cd $ROOT/kgl_gene_amd/csrc/host
 g++ $SAN -std=c++17 -fPIC -Wall -Wextra -Wno-unused-parameter -ffp-contract=off -pthread -shared -o $OUT/libkgx_analysis.so \
-    kgx_flatten.cpp kgx_vcf_flatten.cpp kgx_host_capi.cpp kga_analysis_gpu_allele.cpp kga_analysis_gpu_inbreed.cpp \
-    -L$ROOT/kgl_gene_amd/lib -lkgx -Wl,-rpath,$ROOT/kgl_gene_amd/lib
+    kgx_flatten.cpp kgx_vcf_flatten.cpp kgx_vcf_io.cpp kgx_host_capi.cpp kga_analysis_gpu_allele.cpp kga_analysis_gpu_inbreed.cpp \
+    -L$ROOT/kgl_gene_amd/lib -lkgx -lz -Wl,-rpath,$ROOT/kgl_gene_amd/lib
 cd $ROOT/oracle
 g++ $SAN -std=c++17 -fPIC -Wall -pthread -ffp-contract=off -shared -o $OUT/libkgo.so kgo_core.cpp kgo_analysis.cpp kgo_inbreed.cpp kgo_vcf.cpp kgo_capi.cpp
 cd $ROOT

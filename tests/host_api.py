@@ -33,6 +33,9 @@ def lib():
         L.kgxh_flat_copy.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.kgxh_flat_hgvs.argtypes = [C.c_void_p, C.c_uint64, C.c_char_p, C.c_size_t]
         L.kgxh_flat_genome_id.argtypes = [C.c_void_p, C.c_uint64, C.c_char_p, C.c_size_t]
+        L.kgxh_read_vcf_text.restype = C.c_void_p
+        L.kgxh_read_vcf_text.argtypes = [C.c_char_p, C.c_void_p, C.c_int, C.c_char_p, C.c_size_t]
+        L.kgxh_free.argtypes = [C.c_void_p]
         L.kgxh_inbreed_inputs.restype = C.c_void_p
         L.kgxh_inbreed_inputs.argtypes = [C.c_char_p, C.c_uint64, C.c_int, C.c_char_p, C.c_uint64, C.c_int]
         L.kgxh_inbreed_inputs_destroy.argtypes = [C.c_void_p]
@@ -104,3 +107,16 @@ class InbreedInputs:
                 self.genome_ids.append(buf.value.decode())
         finally:
             lib().kgxh_inbreed_inputs_destroy(h)
+
+
+def read_vcf_text(path, threads: int = 0) -> bytes:
+    """kgx_vcf_io.h: readVcfText.  Raises ValueError with the product's message on failure."""
+    n = C.c_uint64(0)
+    err = C.create_string_buffer(512)
+    ptr = lib().kgxh_read_vcf_text(str(path).encode(), C.byref(n), threads, err, 512)
+    if not ptr:
+        raise ValueError(err.value.decode())
+    try:
+        return C.string_at(ptr, n.value)
+    finally:
+        lib().kgxh_free(ptr)

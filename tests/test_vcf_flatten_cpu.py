@@ -179,3 +179,33 @@ def test_inbreed_inputs_from_vcf_match_the_scaffold_encoder(threads):
     repeated = [line for line in dip_text.split("\n") if line and not line.startswith("#") and line.split("\t")[1] == pos]
     bad = ha.InbreedInputs(ref_text, DATA_SOURCE["Gnomad2_1"], dip_text + "\n".join(repeated) + "\n")
     assert "SAME phase" in bad.error
+
+
+@pytest.mark.parametrize("threads", [1, 6])
+def test_vcf_reader_plain_gzip_and_block_gzip(tmp_path, threads):
+    import gzip
+
+    ids = [f"PF{i:04d}-C" for i in range(7)]
+    text = vt.write_vcf_pf(4000, ids, rng_seed=2).encode()        # a few hundred KiB: several bgzf blocks
+    assert len(text) > 3 * 0xFF00
+    (tmp_path / "a.vcf").write_bytes(text)
+    (tmp_path / "a.vcf.gz").write_bytes(gzip.compress(text[:100000]) + gzip.compress(text[100000:]))   # two members
+    (tmp_path / "a.vcf.bgz").write_bytes(vt.bgzip(text))
+    (tmp_path / "tiny.bgz").write_bytes(vt.bgzip(b""))
+    for name in ("a.vcf", "a.vcf.gz", "a.vcf.bgz"):
+        assert ha.read_vcf_text(tmp_path / name, threads) == text, name
+    assert ha.read_vcf_text(tmp_path / "tiny.bgz", threads) == b""
+    # a flipped byte inside a block's data fails that block's CRC / size check; a truncated gzip is refused
+    bad = bytearray(vt.bgzip(text))
+    bad[len(bad) // 2] ^= 0x55
+    (tmp_path / "bad.bgz").write_bytes(bytes(bad))
+    with pytest.raises(ValueError):
+        ha.read_vcf_text(tmp_path / "bad.bgz", threads)
+    (tmp_path / "cut.gz").write_bytes(gzip.compress(text)[:-20])
+    with pytest.raises(ValueError):
+        ha.read_vcf_text(tmp_path / "cut.gz", threads)
+    with pytest.raises(ValueError):
+        ha.read_vcf_text(tmp_path / "missing.vcf", threads)
+    # and the flattener sees the same population through any of them
+    flat = ha.FlatVcf(ha.read_vcf_text(tmp_path / "a.vcf.bgz", threads).decode(), flavour="Falciparum")
+    assert flat.G == len(ids) and flat.V > 0

@@ -191,3 +191,20 @@ def write_vcf_mono(rec, source="Gnomad2_1", contig=None):
         flt = ("PASS" if r % 3 else "pass") if passed else "AC0"
         lines.append("\t".join([contig, str(int(rec.offsets[r]) + 1), f"rs{r}", rec.refs[r], ",".join(rec.alts[r]), "100", flt, ";".join(info)]))
     return "\n".join(lines) + "\n"
+
+
+def bgzip(data: bytes, block: int = 0xFF00, level: int = 6) -> bytes:
+    """Block gzip as bgzip / htslib write it: gzip members of <= 64 KiB, each with the "BC" extra subfield holding its
+    total size - 1, closed by the empty end-of-file block."""
+    import struct
+    import zlib
+
+    def member(chunk: bytes) -> bytes:
+        c = zlib.compressobj(level, zlib.DEFLATED, -15)
+        body = c.compress(chunk) + c.flush()
+        size = 12 + 6 + len(body) + 8
+        head = struct.pack("<BBBBIBBH", 31, 139, 8, 4, 0, 0, 255, 6) + b"BC" + struct.pack("<HH", 2, size - 1)
+        return head + body + struct.pack("<II", zlib.crc32(chunk) & 0xFFFFFFFF, len(chunk))
+
+    out = b"".join(member(data[i:i + block]) for i in range(0, len(data), block))
+    return out + member(b"")
