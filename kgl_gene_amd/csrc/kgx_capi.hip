@@ -85,7 +85,10 @@ static void launch_count_w(const kgx_pop* pop, kgx_v4u* out, hipStream_t stream)
 int launch_allele_count(const kgx_pop* pop, void* d_out, hipStream_t stream) {
   if (pop->n_variants == 0) return KGX_OK;
   kgx_v4u* out = static_cast<kgx_v4u*>(d_out);
-  switch (lanes_per_row(pop->chunks_per_row)) {
+  int lanes = lanes_per_row(pop->chunks_per_row);
+  const int forced = env_int("KGX_K2_W", 0);             // tuning: fewer lanes per row than the covering power of two
+  if (forced > 0 && forced <= lanes && (forced & (forced - 1)) == 0) lanes = forced;
+  switch (lanes) {
     case 1:  launch_count_w<1>(pop, out, stream); break;
     case 2:  launch_count_w<2>(pop, out, stream); break;
     case 4:  launch_count_w<4>(pop, out, stream); break;
