@@ -953,7 +953,24 @@ int kgx_inbreed(kgx_gt8* h, uint64_t g0, uint64_t g1, const uint32_t* locus_inde
     if (ritland_lut) sweep(3);
     if (rc == KGX_OK) try_hip(hipEventRecord(g_state.sweep_end, st), KGX_EHIP, "hipEventRecord");
     hipLaunchKernelGGL(k_reduce_parts, dim3(stream_grid(n * kParts0, kBlock)), dim3(kBlock), 0, st, d_part, n_seg, n * kParts0, d_sums);
-    if (algorithm == 2) {
+    // Window-sized calls: the whole iteration in one launch, a wave per genome (k_inbreed_iterate_wave).
+    const bool wave_path = (algorithm == 2 || algorithm == 3) && n_sel > 0 && n_sel <= 64ull * kWaveCells && !env_int("KGX_K7_NO_WAVE", 0);
+    if (wave_path) {
+      const uint32_t wave_grid = static_cast<uint32_t>((n * kWave + kBlock - 1) / kBlock);
+      try_hip(hipMemsetAsync(d_running, 0, sizeof(unsigned int), st), KGX_EHIP, "memset(evaluations)");
+      if (algorithm == 2)
+        hipLaunchKernelGGL((k_inbreed_iterate_wave<1>), dim3(wave_grid), dim3(kBlock), 0, st, h->d_gt, h->pitch, g0, n, d_index, n_sel, d_table, d_valid,
+                           amax, phased, d_counts, d_f, d_running);
+      else
+        hipLaunchKernelGGL((k_inbreed_iterate_wave<2>), dim3(wave_grid), dim3(kBlock), 0, st, h->d_gt, h->pitch, g0, n, d_index, n_sel, d_table, d_valid,
+                           amax, phased, d_counts, d_f, d_running);
+      if (algorithm == 3) {
+        unsigned int evaluations = 0;
+        try_hip(hipMemcpyAsync(&evaluations, d_running, sizeof(unsigned int), hipMemcpyDeviceToHost, st), KGX_EHIP, "D2H(evaluations)");
+        try_hip(hipStreamSynchronize(st), KGX_EHIP, "sync");
+        g_state.last_evaluations = static_cast<int>(evaluations);
+      }
+    } else if (algorithm == 2) {
       // processHallME (_calc.cpp:225-307).  The reference restarts from U(0,0.5] and, through RetryCalcResult's
       // self-comparison, always stops after 5 restarts of exactly 50 expectation steps, keeping the last; the
       // fixed start 0.25 (the mean of its start distribution) replaces the random draw.

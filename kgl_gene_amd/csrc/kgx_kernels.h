@@ -1492,65 +1492,159 @@ k_golden_step(GoldenState* __restrict__ st, const double* __restrict__ f_eval, u
 // just publish the best point.  still_running counts the genomes that proposed a new point.
 struct BrentState { double a, b, x, w, v, fx, fw, fv, d, e, u; int done; int pad; };
 
-__global__ void __launch_bounds__(kBlock)
-k_brent_step(BrentState* __restrict__ st, const double* __restrict__ f_eval, uint64_t n, int mode, double* __restrict__ f_next,
-             unsigned int* __restrict__ still_running) {
+// One step of the search: take the objective value fu (= -loglikelihood) at the point proposed last (first: at the
+// start point), update the bracket and the three best points, and either finish (s.done) or propose the next point s.u.
+__device__ __forceinline__ void brent_advance(BrentState& s, double fu, bool first) {
   // Absolute tolerance: the search stops with the best point within 2 * tol1 = 5e-7 of the maximiser; the reference
   // stops its Nelder-Mead at an absolute parameter change of 1e-6 (_calc.cpp:139).  Asking for much less runs into the
   // rounding noise of the objective (a sum of ~1e6 logs), where parabolic steps stop working.
   constexpr double kGold = 0.3819660112501051, kTol = 0.0, kZeps = 2.5e-7;
+  if (first) {
+    s.fx = s.fw = s.fv = fu;
+  } else {
+    const double u = s.u;
+    if (fu <= s.fx) {
+      if (u >= s.x) s.a = s.x; else s.b = s.x;
+      s.v = s.w; s.w = s.x; s.x = u;
+      s.fv = s.fw; s.fw = s.fx; s.fx = fu;
+    } else {
+      if (u < s.x) s.a = u; else s.b = u;
+      if (fu <= s.fw || s.w == s.x) { s.v = s.w; s.w = u; s.fv = s.fw; s.fw = fu; }
+      else if (fu <= s.fv || s.v == s.x || s.v == s.w) { s.v = u; s.fv = fu; }
+    }
+  }
+  const double xm = 0.5 * (s.a + s.b);
+  const double tol1 = kTol * fabs(s.x) + kZeps, tol2 = 2.0 * tol1;
+  if (fabs(s.x - xm) <= (tol2 - 0.5 * (s.b - s.a))) {
+    s.done = 1;
+    return;
+  }
+  bool golden = true;
+  if (fabs(s.e) > tol1) {
+    const double r = (s.x - s.w) * (s.fx - s.fv);
+    double q = (s.x - s.v) * (s.fx - s.fw);
+    double p = (s.x - s.v) * q - (s.x - s.w) * r;
+    q = 2.0 * (q - r);
+    if (q > 0.0) p = -p;
+    q = fabs(q);
+    const double etemp = s.e;
+    s.e = s.d;
+    if (!(fabs(p) >= fabs(0.5 * q * etemp) || p <= q * (s.a - s.x) || p >= q * (s.b - s.x))) {
+      s.d = p / q;
+      const double u = s.x + s.d;
+      if (u - s.a < tol2 || s.b - u < tol2) s.d = copysign(tol1, xm - s.x);
+      golden = false;
+    }
+  }
+  if (golden) {
+    s.e = s.x >= xm ? s.a - s.x : s.b - s.x;
+    s.d = kGold * s.e;
+  }
+  s.u = fabs(s.d) >= tol1 ? s.x + s.d : s.x + copysign(tol1, s.d);
+}
+
+__device__ __forceinline__ BrentState brent_start() {
+  BrentState s{};
+  s.a = -1.0; s.b = 1.0;
+  s.x = s.w = s.v = s.a + 0.3819660112501051 * (s.b - s.a);
+  s.u = s.x;
+  return s;
+}
+
+__global__ void __launch_bounds__(kBlock)
+k_brent_step(BrentState* __restrict__ st, const double* __restrict__ f_eval, uint64_t n, int mode, double* __restrict__ f_next,
+             unsigned int* __restrict__ still_running) {
   for (uint64_t g = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x; g < n;
        g += static_cast<uint64_t>(gridDim.x) * blockDim.x) {
     BrentState s = st[g];
     if (mode == 2) { f_next[g] = s.x; continue; }
     if (!s.done) {
-      const double fu = -f_eval[g];
-      if (mode == 0) {
-        s.fx = s.fw = s.fv = fu;
-      } else {
-        const double u = s.u;
-        if (fu <= s.fx) {
-          if (u >= s.x) s.a = s.x; else s.b = s.x;
-          s.v = s.w; s.w = s.x; s.x = u;
-          s.fv = s.fw; s.fw = s.fx; s.fx = fu;
-        } else {
-          if (u < s.x) s.a = u; else s.b = u;
-          if (fu <= s.fw || s.w == s.x) { s.v = s.w; s.w = u; s.fv = s.fw; s.fw = fu; }
-          else if (fu <= s.fv || s.v == s.x || s.v == s.w) { s.v = u; s.fv = fu; }
-        }
-      }
-      const double xm = 0.5 * (s.a + s.b);
-      const double tol1 = kTol * fabs(s.x) + kZeps, tol2 = 2.0 * tol1;
-      if (fabs(s.x - xm) <= (tol2 - 0.5 * (s.b - s.a))) {
-        s.done = 1;
-      } else {
-        bool golden = true;
-        if (fabs(s.e) > tol1) {
-          const double r = (s.x - s.w) * (s.fx - s.fv);
-          double q = (s.x - s.v) * (s.fx - s.fw);
-          double p = (s.x - s.v) * q - (s.x - s.w) * r;
-          q = 2.0 * (q - r);
-          if (q > 0.0) p = -p;
-          q = fabs(q);
-          const double etemp = s.e;
-          s.e = s.d;
-          if (!(fabs(p) >= fabs(0.5 * q * etemp) || p <= q * (s.a - s.x) || p >= q * (s.b - s.x))) {
-            s.d = p / q;
-            const double u = s.x + s.d;
-            if (u - s.a < tol2 || s.b - u < tol2) s.d = copysign(tol1, xm - s.x);
-            golden = false;
-          }
-        }
-        if (golden) {
-          s.e = s.x >= xm ? s.a - s.x : s.b - s.x;
-          s.d = kGold * s.e;
-        }
-        s.u = fabs(s.d) >= tol1 ? s.x + s.d : s.x + copysign(tol1, s.d);
-        atomicAdd(still_running, 1u);
-      }
+      brent_advance(s, -f_eval[g], mode == 0);
+      if (!s.done) atomicAdd(still_running, 1u);
       st[g] = s;
     }
     f_next[g] = s.done ? s.x : s.u;
+  }
+}
+
+// Window-sized calls (what the INBREED package issues: ~1000 sampled loci x one super population): the whole iteration
+// of HallME (MODE 1) or Loglikelihood (MODE 2) in ONE launch.  A wave owns a genome; lane i owns loci i, i+64, ... and
+// keeps what each of its cells contributes in registers (as k_inbreed_eval_lut tabulates it: y, d with the cell's
+// probability or denominator y + F*d); a pass is a few fp64 operations per cell and a butterfly reduction over the
+// wave (every lane ends with the bitwise-same sum, so the search's control flow is wave-uniform); no block or grid
+// synchronisation, no partials in memory.  n_sel <= 64 * kWaveCells.
+constexpr int kWaveCells = 32;
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int offset = 32; offset >= 1; offset >>= 1) v += __shfl_xor(v, offset, kWave);
+  return v;
+}
+
+template <int MODE>
+__global__ void __launch_bounds__(kBlock)
+k_inbreed_iterate_wave(const uint8_t* __restrict__ gt, uint64_t pitch, uint64_t g0, uint64_t n_genomes,
+                       const uint32_t* __restrict__ locus_index, uint64_t n_sel, const double* __restrict__ table,
+                       const uint8_t* __restrict__ valid, uint32_t amax, int phased, const unsigned long long* __restrict__ counts,
+                       double* __restrict__ f_out, unsigned int* __restrict__ max_evaluations) {
+  const uint64_t g = (static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x) / kWave;
+  const uint32_t lane = threadIdx.x & (kWave - 1);
+  if (g >= n_genomes) return;                                 // whole waves only
+  const uint32_t stride = sweep_stride(amax);
+  double y[kWaveCells], d[kWaveCells];
+#pragma unroll
+  for (int c = 0; c < kWaveCells; ++c) {
+    y[c] = MODE == 2 ? 1.0 : 0.0;                             // contributes nothing
+    d[c] = 0.0;
+    const uint64_t s = static_cast<uint64_t>(c) * kWave + lane;
+    if (s < n_sel && (valid[s] & kLocusValid)) {
+      const uint64_t l = locus_index ? static_cast<uint64_t>(locus_index[s]) : s;
+      double f1 = 0.0, f2 = 0.0;
+      const int cls = classify_cell(gt[l * pitch + g0 + g], table + s * stride, amax, phased != 0, f1, f2);
+      if (cls == kMajorHom || cls == kMinorHom) {
+        if constexpr (MODE == 2) { y[c] = f1 * f1; d[c] = f1 - y[c]; }
+        else { y[c] = f1; d[c] = 1.0; }                       // d = 1 marks a homozygous cell, y its allele frequency
+      } else if (cls != kClassNone) {
+        if constexpr (MODE == 2) { y[c] = 2.0 * f1 * f2; d[c] = -y[c]; }
+      }
+    }
+  }
+  if constexpr (MODE == 1) {
+    // processHallME (_calc.cpp:255-285) from the fixed start 0.25, 50 expectation steps (see kgx_inbreed)
+    const double total = static_cast<double>(counts[g * 6 + 4]);
+    double F = 0.25;
+    for (int it = 0; it < 50; ++it) {
+      double sum = 0.0;
+#pragma unroll
+      for (int c = 0; c < kWaveCells; ++c) {
+        const double denominator = F + ((1.0 - F) * y[c]);
+        if (d[c] != 0.0 && denominator != 0) sum += F / denominator;
+      }
+      F = wave_sum(sum) / total;
+    }
+    if (lane == 0) f_out[g] = F;
+  } else {
+    BrentState s = brent_start();
+    unsigned int evaluations = 0;
+    for (int it = 0; it < 60; ++it) {
+      const double F = it == 0 ? s.x : s.u;
+      double log_sum = 0.0, prod = 1.0;
+#pragma unroll
+      for (int c = 0; c < kWaveCells; ++c) {
+        prod *= __builtin_fmin(__builtin_fmax(__builtin_fma(F, d[c], y[c]), 1e-10), 1.0);
+        if ((c & 15) == 15) {                                 // 16 factors >= 1e-10 cannot underflow
+          log_sum += log(prod);
+          prod = 1.0;
+        }
+      }
+      ++evaluations;
+      brent_advance(s, -wave_sum(log_sum), it == 0);
+      if (s.done) break;
+    }
+    if (lane == 0) {
+      f_out[g] = s.x;
+      atomicMax(max_evaluations, evaluations);
+    }
   }
 }
 
