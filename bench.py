@@ -47,7 +47,7 @@ def parse_args():
     ap.add_argument("--variants", type=int, default=0, help="override variant rows")
     ap.add_argument("--seed", type=int, default=1111)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample-variants", type=int, default=100_000)
+    ap.add_argument("--cpu-sample-variants", type=int, default=300_000)      # x 10k genomes = 3e9 cells: ~12 s of the port
     ap.add_argument("--algorithm", choices=["Simple", "RitlandLocus", "HallME", "Loglikelihood"], default="Simple",
                     help="estimator of the c5 workload")
     return ap.parse_args()
@@ -68,6 +68,12 @@ def cpu_baseline(capi, pop, G, V, k2_host_sample_rows, sample_variants):
     want = dense.summary_by_variant()
     seconds = dense.seconds
     ok = bool(np.array_equal(k2_host_sample_rows[:, :3].astype(np.uint64), want))
+    # second, clearly labelled figure: a tuned CPU sweep of the same 2-bit rows, every host thread
+    n_fast = min(V, 10 * nv)
+    fast_rows = pop.read_dosage2(0, n_fast)
+    fast_counts, fast_seconds, fast_threads = oa.fast_count_by_variant(fast_rows, G)
+    fast_ok = bool(np.array_equal(fast_counts[:nv], k2_host_sample_rows))
+    del fast_rows
     return {
         "value": G * nv / seconds,
         "unit": "variants·genomes/s",
@@ -77,6 +83,11 @@ def cpu_baseline(capi, pop, G, V, k2_host_sample_rows, sample_variants):
                   f"oracle dense tier = reference summaryByVariant loop (single-threaded in the reference); "
                   f"host has {os.cpu_count()} cpus; block parity vs GPU: {'bit-exact' if ok else 'MISMATCH'}",
         "parity_ok": ok,
+        "optimised_cpu": {
+            "value": G * n_fast / fast_seconds, "unit": "variants·genomes/s", "cores": fast_threads, "kind": "not the reference's algorithm",
+            "sample": f"first {n_fast} variants x all {G} genomes, same 2-bit rows as the GPU, 64-bit popcounts on {fast_threads} threads, "
+                      f"best of 3 ({fast_seconds * 1e3:.1f} ms); parity vs GPU: {'bit-exact' if fast_ok else 'MISMATCH'}",
+        },
     }
 
 

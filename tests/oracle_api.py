@@ -41,6 +41,7 @@ def lib() -> C.CDLL:
         "kgo_population_add_genomes": (C.c_int, [vp, u64, vp, C.c_int]),
         "kgo_population_add_records": (C.c_int, [vp, C.c_int, C.c_char_p, u64, vp, vp, vp, vp, vp, vp, u64, vp, vp]),
         "kgo_population_add_vcf_1000": (C.c_long, [vp, C.c_char_p, u64]),
+        "kgo_fast_count_by_variant": (C.c_int, [vp, u64, u64, u64, u64, vp, C.c_int, C.c_int, vp]),
         "kgo_population_add_vcf_pf": (C.c_long, [vp, C.c_char_p, u64]),
         "kgo_population_add_vcf_mono": (C.c_long, [vp, C.c_char_p, u64, C.c_char_p, C.c_char_p]),
         "kgo_hethom_present": (C.c_int, [vp, C.c_char_p, vp]),
@@ -324,6 +325,16 @@ class Dense:
         assert lib().kgo_dense_summary_by_genome(self._h, _p(m), _p(out), C.byref(sec)) == 0
         self.seconds = sec.value
         return out
+
+
+def fast_count_by_variant(rows: np.ndarray, n_genomes: int, threads: int = 0, repeats: int = 3):
+    """The tuned CPU comparator (oracle/kgo_fast.cpp; NOT the reference's algorithm): ([n][4] counts, best seconds, threads)."""
+    r = np.ascontiguousarray(rows, dtype=np.uint8)
+    out = np.zeros((r.shape[0], 4), dtype=np.uint32)
+    sec = C.c_double(0)
+    used = lib().kgo_fast_count_by_variant(_p(r), r.shape[0], r.shape[1], r.shape[1], n_genomes, _p(out), threads, repeats, C.byref(sec))
+    assert used > 0
+    return out, sec.value, int(used)
 
 
 def class_frequencies(minor_af, inbreeding, normalize=True):

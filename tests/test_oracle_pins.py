@@ -301,3 +301,18 @@ def test_synthetic_inbreeding_self_check(algorithm, slope_lo):
     else:
         assert slope > slope_lo and abs(intercept) < 0.05
         assert np.abs(calc - syn).max() < 0.12
+
+
+def test_tuned_cpu_comparator_counts_like_the_port():
+    # oracle/kgo_fast.cpp is bench.py's second CPU figure (not the reference's algorithm): it must still count right
+    from kgl_gene_amd import capi
+
+    for G in (1, 63, 64, 1003):
+        rows, _ = capi.synth_biallelic_host(7, 0, G, 0, 300)
+        rows = rows.copy()
+        rows[5, 0] |= 0x3            # a non-diploid code
+        codes = capi.unpack_dosage2(rows, G)
+        want = np.stack([(codes == k).sum(1) for k in range(4)], 1).astype(np.uint32)
+        for threads in (1, 3):
+            got, seconds, used = oa.fast_count_by_variant(rows, G, threads=threads, repeats=1)
+            assert np.array_equal(got, want) and used == threads and seconds > 0
