@@ -17,11 +17,15 @@
 #include <algorithm>
 #include <atomic>
 #include <cctype>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <cmath>
 #include <cstring>
 #include <limits>
 #include <numeric>
 #include <map>
+#include <mutex>
 #include <thread>
 #include <unordered_map>
 
@@ -190,10 +194,22 @@ std::vector<RecordRows> parseRecords(const VcfLines& lines, size_t threads, Pars
   return parsed;
 }
 
-// Variants: rows in lexicographic HGVS order; records repeating an HGVS add their copies.  every_sample: all samples are
-// genomes (the Pf parser creates them up front); otherwise only carriers exist (the 1000-Genomes parser creates a genome
-// when it first adds a variant to it).
-FlatPopulation mergeRecords(const std::vector<RecordRows>& parsed, const std::vector<std::string>& samples, bool every_sample) {
+// Run fn(begin, end) over [0, n) in chunks on `threads` threads.
+template <typename Fn>
+void parallelChunks(size_t n, size_t chunk, size_t threads, Fn fn) {
+  if (threads == 0) threads = std::max<size_t>(std::thread::hardware_concurrency(), 2) - 1;
+  std::atomic<size_t> next{0};
+  auto worker = [&]() {
+    for (size_t begin = next.fetch_add(chunk); begin < n; begin = next.fetch_add(chunk)) fn(begin, std::min(n, begin + chunk));
+  };
+  const size_t workers = std::max<size_t>(1, std::min(threads, (n + chunk - 1) / chunk));
+  std::vector<std::thread> pool;
+  for (size_t t = 1; t < workers; ++t) pool.emplace_back(worker);
+  worker();
+  for (auto& th : pool) th.join();
+}
+
+FlatPopulation mergeRecords(const std::vector<RecordRows>& parsed, const std::vector<std::string>& samples, bool every_sample, size_t threads = 0) {
   const size_t S = samples.size();
   struct Key { const std::string* hgvs; uint32_t record, alt; };
   std::vector<Key> keys;
@@ -201,11 +217,21 @@ FlatPopulation mergeRecords(const std::vector<RecordRows>& parsed, const std::ve
     for (uint32_t a = 0; a < parsed[r].rows.size(); ++a) keys.push_back({&parsed[r].rows[a].hgvs, r, a});
   std::stable_sort(keys.begin(), keys.end(), [](const Key& x, const Key& y) { return *x.hgvs < *y.hgvs; });
 
+  // Genomes: every sample (the Pf parser creates them up front) or only carriers (the 1000-Genomes parser creates a
+  // genome when it first adds a variant to it); std::map order.
   std::vector<uint8_t> carries(S, every_sample ? 1 : 0);
-  if (!every_sample)
-    for (const auto& rec : parsed)
-      for (size_t i = 0; i < rec.copies.size(); ++i)
-        if (rec.copies[i]) carries[i % S] = 1;
+  if (!every_sample) {
+    std::mutex merge_mutex;
+    parallelChunks(parsed.size(), 64, threads, [&](size_t begin, size_t end) {
+      std::vector<uint8_t> local(S, 0);
+      for (size_t r = begin; r < end; ++r) {
+        const auto& copies = parsed[r].copies;
+        for (size_t i = 0, s = 0; i < copies.size(); ++i, s = (s + 1 == S ? 0 : s + 1)) local[s] |= copies[i];
+      }
+      std::lock_guard<std::mutex> lock(merge_mutex);
+      for (size_t s = 0; s < S; ++s) carries[s] |= local[s] ? 1 : 0;
+    });
+  }
   std::vector<uint32_t> sample_order;
   for (uint32_t s = 0; s < S; ++s) if (carries[s]) sample_order.push_back(s);
   std::sort(sample_order.begin(), sample_order.end(), [&](uint32_t x, uint32_t y) { return samples[x] < samples[y]; });
@@ -219,36 +245,57 @@ FlatPopulation mergeRecords(const std::vector<RecordRows>& parsed, const std::ve
   }
   const size_t G = flat.genome_ids.size();
   flat.row_bytes = (G + 3) / 4;
-  std::vector<uint32_t> total(S);
-  for (size_t k = 0; k < keys.size();) {
-    size_t e = k + 1;
-    while (e < keys.size() && *keys[e].hgvs == *keys[k].hgvs) ++e;
-    std::fill(total.begin(), total.end(), 0u);
-    bool any = false;
-    for (size_t m = k; m < e; ++m) {
-      const uint8_t* c = &parsed[keys[m].record].copies[static_cast<size_t>(keys[m].alt) * S];
-      for (size_t s = 0; s < S; ++s) { total[s] += c[s]; any = any || c[s]; }
-    }
-    if (any) {                                      // a variant nobody carries never reaches the PopulationDB
-      const uint32_t row_index = static_cast<uint32_t>(flat.rows.size());
-      // the Variant kept for an HGVS is the first one added (uniqueVariants): the first record that has a carrier
-      size_t first = k;
+
+  // Variants: one row per distinct HGVS, in lexicographic order; records repeating an HGVS add their copies.  Groups are
+  // independent: each is summed and packed on its own, then the rows somebody carries are kept in order.
+  std::vector<size_t> group_begin;
+  for (size_t k = 0; k < keys.size(); ++k)
+    if (k == 0 || *keys[k].hgvs != *keys[k - 1].hgvs) group_begin.push_back(k);
+  const size_t n_groups = group_begin.size();
+  group_begin.push_back(keys.size());
+  std::vector<uint8_t> group_rows(n_groups * flat.row_bytes, 0), carried(n_groups, 0);
+  std::vector<size_t> first_key(n_groups, 0);
+  struct Wide { size_t group; uint32_t genome, dosage; };
+  std::vector<std::vector<Wide>> wide_of_chunk((n_groups + 63) / 64);
+  std::vector<size_t> objects_of_chunk((n_groups + 63) / 64, 0);
+  parallelChunks(n_groups, 64, threads, [&](size_t begin, size_t end) {
+    std::vector<uint32_t> total(S);
+    for (size_t grp = begin; grp < end; ++grp) {
+      const size_t k = group_begin[grp], e = group_begin[grp + 1];
+      std::fill(total.begin(), total.end(), 0u);
+      bool any = false;
       for (size_t m = k; m < e; ++m) {
         const uint8_t* c = &parsed[keys[m].record].copies[static_cast<size_t>(keys[m].alt) * S];
-        if (std::any_of(c, c + S, [](uint8_t x) { return x != 0; })) { first = m; break; }
+        bool here = false;
+        for (size_t s = 0; s < S; ++s) { total[s] += c[s]; here = here || c[s]; }
+        // the Variant kept for an HGVS is the first one added (uniqueVariants): the first record that has a carrier
+        if (here && !any) { any = true; first_key[grp] = m; }
       }
-      flat.rows.push_back(parsed[keys[first].record].rows[keys[first].alt]);
-      const size_t base = flat.packed.size();
-      flat.packed.resize(base + flat.row_bytes, 0);
+      if (!any) continue;                             // a variant nobody carries never reaches the PopulationDB
+      carried[grp] = 1;
+      uint8_t* row = &group_rows[grp * flat.row_bytes];
       for (size_t g = 0; g < G; ++g) {
         uint32_t d = 0;
         for (uint32_t column : columns_of[g]) d += total[column];
-        flat.variant_objects += d;
-        flat.packed[base + g / 4] |= static_cast<uint8_t>((d > 2 ? 3u : d) << (2 * (g % 4)));
-        if (d > 2) flat.non_diploid.push_back({row_index, static_cast<uint32_t>(g), d});
+        objects_of_chunk[begin / 64] += d;
+        row[g / 4] |= static_cast<uint8_t>((d > 2 ? 3u : d) << (2 * (g % 4)));
+        if (d > 2) wide_of_chunk[begin / 64].push_back({grp, static_cast<uint32_t>(g), d});
       }
     }
-    k = e;
+  });
+  std::vector<uint32_t> row_of_group(n_groups, 0);
+  size_t n_rows = 0;
+  for (size_t grp = 0; grp < n_groups; ++grp) if (carried[grp]) row_of_group[grp] = static_cast<uint32_t>(n_rows++);
+  flat.rows.reserve(n_rows);
+  flat.packed.resize(n_rows * flat.row_bytes);
+  for (size_t grp = 0; grp < n_groups; ++grp) {
+    if (!carried[grp]) continue;
+    flat.rows.push_back(parsed[keys[first_key[grp]].record].rows[keys[first_key[grp]].alt]);
+    if (flat.row_bytes) std::memcpy(&flat.packed[static_cast<size_t>(row_of_group[grp]) * flat.row_bytes], &group_rows[grp * flat.row_bytes], flat.row_bytes);
+  }
+  for (size_t chunk = 0; chunk < wide_of_chunk.size(); ++chunk) {
+    flat.variant_objects += objects_of_chunk[chunk];
+    for (const Wide& w : wide_of_chunk[chunk]) flat.non_diploid.push_back({row_of_group[w.group], w.genome, w.dosage});
   }
   return flat;
 }
@@ -269,7 +316,16 @@ void readInfoAf(std::string_view info, size_t A, std::vector<float>& af, bool& a
 }  // namespace
 
 FlatPopulation flattenVcf1000(std::string_view text, size_t threads) {
+  const bool trace = std::getenv("KGX_FLATTEN_TRACE") != nullptr;
+  auto t_last = std::chrono::steady_clock::now();
+  auto lap = [&](const char* what) {
+    if (!trace) return;
+    const auto now = std::chrono::steady_clock::now();
+    std::fprintf(stderr, "kgx flattenVcf1000: %s %.3f s\n", what, std::chrono::duration<double>(now - t_last).count());
+    t_last = now;
+  };
   const VcfLines lines = scanLines(text);
+  lap("scan lines");
   const size_t S = lines.samples.size();
   const auto parsed = parseRecords(lines, threads, [&](std::string_view record, RecordRows& out) {
     const auto f = split(record, '\t', S + 10);
@@ -305,7 +361,10 @@ FlatPopulation flattenVcf1000(std::string_view text, size_t threads) {
       if (pb) ++copies[(pb - 1) * S + (idx - 9)];
     }
   });
-  return mergeRecords(parsed, lines.samples, false);
+  lap("parse records");
+  FlatPopulation flat = mergeRecords(parsed, lines.samples, false, threads);
+  lap("merge");
+  return flat;
 }
 
 namespace {
@@ -470,7 +529,7 @@ FlatPopulation flattenVcfPf(std::string_view text, size_t threads, bool quality_
       }
     }
   });
-  FlatPopulation flat = mergeRecords(parsed, lines.samples, true);
+  FlatPopulation flat = mergeRecords(parsed, lines.samples, true, threads);
   flat.contig_ids = lines.contigs;
   return flat;
 }
@@ -542,7 +601,16 @@ FlatReference flattenReferenceVcf(std::string_view text, DataSourceEnum data_sou
 }
 
 FlatDiploid flattenVcf1000Gt8(std::string_view text, const FlatReference& reference, size_t threads) {
+  const bool trace = std::getenv("KGX_FLATTEN_TRACE") != nullptr;
+  auto t_last = std::chrono::steady_clock::now();
+  auto lap = [&](const char* what) {
+    if (!trace) return;
+    const auto now = std::chrono::steady_clock::now();
+    std::fprintf(stderr, "kgx flattenVcf1000Gt8: %s %.3f s\n", what, std::chrono::duration<double>(now - t_last).count());
+    t_last = now;
+  };
   const VcfLines lines = scanLines(text);
+  lap("scan lines");
   const size_t S = lines.samples.size();
   FlatDiploid out;
   out.n_loci = reference.loci.size();
@@ -611,6 +679,7 @@ FlatDiploid flattenVcf1000Gt8(std::string_view text, const FlatReference& refere
     for (auto& th : pool) th.join();
   }
 
+  lap("parse records");
   // genomes that hold the contig, in id order; a sample named twice is one genome
   std::vector<uint8_t> holds(S, 0);
   for (const auto& rc : parsed)
@@ -631,47 +700,83 @@ FlatDiploid flattenVcf1000Gt8(std::string_view text, const FlatReference& refere
   const size_t G = out.genome_ids.size();
   out.bytes.assign(out.n_loci * G, 0);
 
-  // Assemble in record order.  Per (locus, genome): count of SNP variants so far, their codes and phases.
-  std::vector<uint8_t> count(out.n_loci * G, 0), first_phase(out.n_loci * G, 0);
-  auto add = [&](uint64_t cell, uint8_t code, uint8_t phase, uint32_t sample) -> bool {
-    const uint8_t n = count[cell];
-    if (n == 0) { out.bytes[cell] = code; first_phase[cell] = phase; }
-    else if (n == 1) {
-      const uint8_t c0 = out.bytes[cell] & 0xF;
-      if (c0 == code && code != 15 && first_phase[cell] == phase) {
-        out.error = "Genome: " + lines.samples[sample] + " holds two copies of one variant with the SAME phase; not representable";
-        return false;
+  lap("genome order");
+  // Assemble locus by locus (rows are independent; the records of one locus are taken in file order).  Per genome of the
+  // row: count of SNP variants so far, their codes and phases.
+  std::vector<uint32_t> by_locus;                       // record indices sorted by (locus, record)
+  for (uint32_t r = 0; r < parsed.size(); ++r) if (parsed[r].locus >= 0) by_locus.push_back(r);
+  std::stable_sort(by_locus.begin(), by_locus.end(), [&](uint32_t a, uint32_t b) { return parsed[a].locus < parsed[b].locus; });
+  std::atomic<size_t> next_group{0};
+  std::atomic<bool> failed{false};
+  std::mutex error_mutex;
+  auto assemble = [&]() {
+    std::vector<uint8_t> count(G), first_phase(G);
+    constexpr size_t kChunk = 256;
+    for (size_t begin = next_group.fetch_add(kChunk); begin < by_locus.size() && !failed.load(); begin = next_group.fetch_add(kChunk)) {
+      // a chunk boundary must not split a locus: the thread that owns the chunk holding a locus' first record owns the locus
+      size_t k = begin;
+      if (k > 0 && parsed[by_locus[k]].locus == parsed[by_locus[k - 1]].locus) {
+        const int64_t shared = parsed[by_locus[k]].locus;
+        while (k < by_locus.size() && parsed[by_locus[k]].locus == shared) ++k;
       }
-      out.bytes[cell] = static_cast<uint8_t>(c0 | (code << 4));
-    } else {
-      out.bytes[cell] = 0xFF;
+      const size_t end = std::min(by_locus.size(), begin + kChunk);
+      while (k < end) {
+        const int64_t locus = parsed[by_locus[k]].locus;
+        uint8_t* row = &out.bytes[static_cast<uint64_t>(locus) * G];
+        std::fill(count.begin(), count.end(), 0);
+        auto add = [&](uint64_t g, uint8_t code, uint8_t phase, uint32_t sample) -> bool {
+          const uint8_t n = count[g];
+          if (n == 0) { row[g] = code; first_phase[g] = phase; }
+          else if (n == 1) {
+            const uint8_t c0 = row[g] & 0xF;
+            if (c0 == code && code != 15 && first_phase[g] == phase) {
+              std::lock_guard<std::mutex> lock(error_mutex);
+              if (out.error.empty())
+                out.error = "Genome: " + lines.samples[sample] + " holds two copies of one variant with the SAME phase; not representable";
+              failed.store(true);
+              return false;
+            }
+            row[g] = static_cast<uint8_t>(c0 | (code << 4));
+          } else {
+            row[g] = 0xFF;
+          }
+          if (n < 3) count[g] = static_cast<uint8_t>(n + 1);
+          return true;
+        };
+        for (; k < by_locus.size() && parsed[by_locus[k]].locus == locus; ++k) {
+          const RecordCalls& rc = parsed[by_locus[k]];
+          const size_t A = rc.code.size();
+          // Genome1000VCFImpl::addVariants: all phase A variants of the record are added first (by alt), then phase B
+          for (uint8_t phase = 0; phase < 2; ++phase) {
+            for (size_t s = 0; s < rc.calls.size(); ++s) {
+              if (rc.calls[s] == 0 || genome_of_sample[s] < 0) continue;
+              const uint32_t alt = phase == 0 ? (rc.calls[s] & 0xFu) : (rc.calls[s] >> 4);
+              if (alt == 0 || alt > A) continue;
+              const uint8_t code = rc.code[alt - 1];
+              if (code == 0) continue;                                        // not a SNP
+              if (!add(static_cast<uint64_t>(genome_of_sample[s]), code, phase, static_cast<uint32_t>(s))) return;
+            }
+            for (const auto& [s, ab] : rc.wide) {
+              if (genome_of_sample[s] < 0) continue;
+              const uint32_t alt = phase == 0 ? ab.first : ab.second;
+              if (alt == 0 || alt > A) continue;
+              const uint8_t code = rc.code[alt - 1];
+              if (code == 0) continue;
+              if (!add(static_cast<uint64_t>(genome_of_sample[s]), code, phase, s)) return;
+            }
+          }
+        }
+      }
     }
-    if (n < 3) count[cell] = static_cast<uint8_t>(n + 1);
-    return true;
   };
-  for (const auto& rc : parsed) {
-    if (rc.locus < 0) continue;
-    const size_t A = rc.code.size();
-    // Genome1000VCFImpl::addVariants: all phase A variants of the record are added first (by alt), then phase B
-    for (uint8_t phase = 0; phase < 2; ++phase) {
-      for (size_t s = 0; s < rc.calls.size(); ++s) {
-        if (genome_of_sample[s] < 0) continue;
-        const uint32_t alt = phase == 0 ? (rc.calls[s] & 0xFu) : (rc.calls[s] >> 4);
-        if (alt == 0 || alt > A) continue;
-        const uint8_t code = rc.code[alt - 1];
-        if (code == 0) continue;                                        // not a SNP
-        if (!add(static_cast<uint64_t>(rc.locus) * G + static_cast<uint64_t>(genome_of_sample[s]), code, phase, static_cast<uint32_t>(s))) return out;
-      }
-      for (const auto& [s, ab] : rc.wide) {
-        if (genome_of_sample[s] < 0) continue;
-        const uint32_t alt = phase == 0 ? ab.first : ab.second;
-        if (alt == 0 || alt > A) continue;
-        const uint8_t code = rc.code[alt - 1];
-        if (code == 0) continue;
-        if (!add(static_cast<uint64_t>(rc.locus) * G + static_cast<uint64_t>(genome_of_sample[s]), code, phase, s)) return out;
-      }
-    }
+  {
+    const size_t n = std::max<size_t>(1, std::min(threads, (by_locus.size() + 255) / 256));
+    std::vector<std::thread> pool;
+    for (size_t t = 1; t < n; ++t) pool.emplace_back(assemble);
+    assemble();
+    for (auto& th : pool) th.join();
   }
+  lap("assemble");
   return out;
 }
 
