@@ -1,6 +1,8 @@
 #include "kga_analysis_gpu_inbreed.h"
 
 #include <algorithm>
+#include <atomic>
+#include <thread>
 #include <cmath>
 #include <fstream>
 #include <iomanip>
@@ -393,12 +395,27 @@ bool kga::GpuInbreedAnalysis::populationInbreeding(GpuParamOutput& param_output)
 
   // Device column order = super-population groups; the flattened input is in genome-id order.
   const uint64_t input_genomes = diploid.genome_ids.size();
-  std::vector<uint8_t> bytes(n_loci * device_genomes, 0);
+  std::vector<int64_t> column_of(device_genomes, -1);          // -1: padding up to the next group's 16-genome boundary
   for (size_t sp = 0; sp < super_pops.size(); ++sp)
-    for (size_t k = 0; k < by_super_pop[sp].size(); ++k) {
-      const uint64_t g = range_begin[sp] + k, column = by_super_pop[sp][k].column;
-      for (uint64_t l = 0; l < n_loci; ++l) bytes[l * device_genomes + g] = diploid.bytes[l * input_genomes + column];
-    }
+    for (size_t k = 0; k < by_super_pop[sp].size(); ++k) column_of[range_begin[sp] + k] = static_cast<int64_t>(by_super_pop[sp][k].column);
+  std::vector<uint8_t> bytes(n_loci * device_genomes, 0);
+  {
+    std::atomic<uint64_t> next{0};
+    auto worker = [&]() {
+      for (uint64_t begin = next.fetch_add(1024); begin < n_loci; begin = next.fetch_add(1024))
+        for (uint64_t l = begin; l < std::min<uint64_t>(n_loci, begin + 1024); ++l) {
+          const uint8_t* in = &diploid.bytes[l * input_genomes];
+          uint8_t* row = &bytes[l * device_genomes];
+          for (uint64_t g = 0; g < device_genomes; ++g)
+            if (column_of[g] >= 0) row[g] = in[column_of[g]];
+        }
+    };
+    const size_t n_threads = std::max<size_t>(1, std::min<size_t>(std::max(2u, std::thread::hardware_concurrency()) - 1, (n_loci + 1023) / 1024));
+    std::vector<std::thread> pool;
+    for (size_t t = 1; t < n_threads; ++t) pool.emplace_back(worker);
+    worker();
+    for (auto& th : pool) th.join();
+  }
   diploid.bytes.clear();
   diploid.bytes.shrink_to_fit();
   DeviceMatrix dev;
