@@ -57,8 +57,50 @@ def inbreed_case():
     np.savez_compressed(HERE / "inbreed_40x700.npz", **out)
 
 
+def vcf_cases():
+    """The two VCF flavours and the INBREED inputs: VCF text in, flattened arrays out (the oracle's parsers)."""
+    from tests import vcf_text as vt
+
+    # P. falciparum flavour, with and without the Pf7 record filter
+    ids = [f"PF{i:04d}-C" for i in range(24)]
+    text = vt.write_vcf_pf(400, ids, rng_seed=41)
+    out = dict(pf_text=np.array([text]))
+    for tag, pop in (("raw", None), ("p7", "filter")):
+        o = oa.Population("pf")
+        o.add_vcf_pf(text)
+        if pop:
+            o = o.filter_p7()
+        variant_out, genome_out, vdb = o.fws()
+        out[f"pf_{tag}_hgvs"] = np.array([vdb.hgvs(i) for i in range(vdb.n_variants)])
+        out[f"pf_{tag}_genomes"] = np.array([vdb.genome_id(i) for i in range(vdb.n_genomes)])
+        out[f"pf_{tag}_dosage"] = vdb.dosage()                     # [G][V] copies
+        out[f"pf_{tag}_fws_genome_bins"] = genome_out
+    # INBREED inputs: Gnomad-style site file + 1000-Genomes population -> reference loci and allele-index bytes
+    G, L = 20, 1500
+    rec, gt = sv.multiallelic_block(G, L, rng_seed=43, missing_af_frac=0.05, dup_records=0)
+    for a in rec.af:
+        a[:, 4] = a[:, 5]
+    kg_ids = sv.genome_ids(G, prefix="HG")
+    ref_text, dip_text = vt.write_vcf_mono(rec, "Gnomad2_1"), vt.write_vcf_1000(rec, gt, kg_ids, rng_seed=44)
+    ref = oa.Population("gnomad")
+    ref.add_vcf_mono(ref_text, "Gnomad2_1")
+    dip = oa.Population("kg")
+    dip.add_vcf_1000(dip_text)
+    vdb = oa.VariantDB(dip)
+    genomes = [vdb.genome_id(i) for i in range(vdb.n_genomes)]
+    # the package's window loop (LociiCount 100, SamplingDistance 10) with every genome in the "ALL" super population
+    cols = oa.population_inbreeding(ref.filter_snp_pass(), dip, np.full(len(genomes), oa.ALL, dtype=np.int32), "Simple", 0, 10**9, 10, 100,
+                                    0.02, 0.9, seed=oa.FIXED_STARTS)
+    assert len(cols) >= 2
+    out.update(ref_text=np.array([ref_text]), kg_text=np.array([dip_text]), kg_genomes=np.array(genomes),
+               kg_column_ident=np.array([c[0] for c in cols]), kg_counts=np.stack([c[1] for c in cols]),
+               kg_freqs=np.stack([c[2] for c in cols]), kg_present=np.stack([c[3] for c in cols]))
+    np.savez_compressed(HERE / "vcf_cases.npz", **out)
+
+
 if __name__ == "__main__":
     allele_case()
     inbreed_case()
+    vcf_cases()
     for f in sorted(HERE.glob("*.npz")):
         print(f.name, f.stat().st_size, "bytes")

@@ -58,3 +58,55 @@ def test_gpu_matches_inbreed_golden(kgx, algorithm, tol):
         assert np.allclose(got[name], freqs[:, k], rtol=1e-12, atol=1e-12)
     assert np.abs(got["inbred_allele_sum"] - freqs[:, 4]).max() <= tol
     m.close()
+
+
+def test_pf_vcf_flattener_matches_golden():
+    """CPU: the product's Pf flattener (host C++) against the committed oracle outputs for a committed VCF text."""
+    from . import host_api as ha
+
+    g = np.load(GOLD / "vcf_cases.npz")
+    text = str(g["pf_text"][0])
+    for tag, quality_filter in (("raw", False), ("p7", True)):
+        flat = ha.FlatVcf(text, 3, flavour="Falciparum", quality_filter=quality_filter)
+        assert flat.hgvs == g[f"pf_{tag}_hgvs"].tolist()
+        assert flat.genome_ids == g[f"pf_{tag}_genomes"].tolist()
+        assert np.array_equal(capi.unpack_dosage2(flat.packed, flat.G), np.minimum(g[f"pf_{tag}_dosage"].T, 3))
+    assert len(g["pf_p7_hgvs"]) < len(g["pf_raw_hgvs"])
+    # and the oracle still reproduces its own committed parse
+    o = oa.Population("pf")
+    o.add_vcf_pf(text)
+    vdb = oa.VariantDB(o)
+    assert [vdb.hgvs(i) for i in range(vdb.n_variants)] == g["pf_raw_hgvs"].tolist()
+    assert np.array_equal(vdb.dosage(), g["pf_raw_dosage"])
+
+
+@pytest.mark.gpu
+def test_gpu_inbreed_from_vcf_matches_golden(kgx, tmp_path):
+    """GPU: GPU_INBREED fed the two committed VCF texts reproduces the committed oracle window (Simple)."""
+    from . import records_io as rio
+
+    g = np.load(GOLD / "vcf_cases.npz")
+    (tmp_path / "gnomad.vcf").write_text(str(g["ref_text"][0]))
+    (tmp_path / "kg.vcf").write_text(str(g["kg_text"][0]))
+    genomes = g["kg_genomes"].tolist()
+    (tmp_path / "ped.txt").write_text("".join(f"{name}\tALL\n" for name in genomes))
+    res = rio.run_driver("GPU_INBREED", tmp_path, [f"vcf:Gnomad2_1:{tmp_path / 'gnomad.vcf'}", f"vcf:Genome1000:{tmp_path / 'kg.vcf'}",
+                                                    f"ped:{tmp_path / 'ped.txt'}"],
+                         AnalysisType="false", OutputFile="inbreed", Algorithm="Simple", MinAlleleFreq=0.02, MaxAlleleFreq=0.9,
+                         LowerWindow=0, UpperWindow=10**9, LociiCount=100, SamplingDistance=10)
+    assert res.returncode == 0, res.stderr
+    header, rows = rio.read_csv(tmp_path / "inbreed_detail.csv")
+    got = {(r[0], r[1]): ([int(r[2]), int(r[4]), int(r[6]), int(r[8]), int(r[10])], [float(r[3]), float(r[5]), float(r[7]), float(r[9]), float(r[11])])
+           for r in rows}
+    n = 0
+    for c, ident in enumerate(g["kg_column_ident"].tolist()):
+        for k, name in enumerate(genomes):
+            if not g["kg_present"][c, k]:
+                assert (ident, name) not in got
+                continue
+            counts, freqs = got[(ident, name)]
+            assert counts == g["kg_counts"][c, k].tolist(), (ident, name)
+            assert np.allclose(freqs[:4], g["kg_freqs"][c, k, :4], rtol=1e-12, atol=1e-12)
+            assert abs(freqs[4] - g["kg_freqs"][c, k, 4]) <= 1e-10
+            n += 1
+    assert n == len(got) and n > 0
