@@ -103,7 +103,8 @@ bool kga::GpuAlleleAnalysis::sweepVcfFile(const std::string& file_name) {
 }
 
 bool kga::GpuAlleleAnalysis::sweepFlat(const gpu::FlatPopulation& flat, const std::string& label) {
-  const uint64_t G = flat.genomes(), V = flat.variants();
+  // V: the population's distinct variants; D >= V: rows on the device (the extra ones are per-bin splits, see VariantRow)
+  const uint64_t G = flat.genomes(), V = flat.variants(), D = flat.deviceRows();
   ExecEnv::log().info("GpuAlleleAnalysis; population: {}, genomes: {}, distinct variants: {}, Variant objects: {}",
                       label, G, V, flat.variant_objects);
   if (G == 0) return true;
@@ -114,18 +115,18 @@ bool kga::GpuAlleleAnalysis::sweepFlat(const gpu::FlatPopulation& flat, const st
   if (V == 0) return true;
 
   DevicePopulation dev;
-  dev.handle = kgx_population_create(G, V);
+  dev.handle = kgx_population_create(G, D);
   if (!dev.handle) {
     ExecEnv::log().error("GpuAlleleAnalysis; kgx_population_create failed: {}", kgx_last_error());
     return false;
   }
-  if (kgx_population_load_dosage2(dev.handle, flat.packed.data(), flat.row_bytes, 0, V) != KGX_OK) {
+  if (kgx_population_load_dosage2(dev.handle, flat.packed.data(), flat.row_bytes, 0, D) != KGX_OK) {
     ExecEnv::log().error("GpuAlleleAnalysis; upload failed: {}", kgx_last_error());
     return false;
   }
 
   // ---- K2: CalcFWS::updateVariantFWSMap -- summaryByVariant for every variant ------------------
-  std::vector<uint32_t> by_variant(V * 4);
+  std::vector<uint32_t> by_variant(D * 4);
   if (kgx_allele_count_by_locus(dev.handle, by_variant.data()) != KGX_OK) {
     ExecEnv::log().error("GpuAlleleAnalysis; allele count sweep failed: {}", kgx_last_error());
     return false;
@@ -142,8 +143,9 @@ bool kga::GpuAlleleAnalysis::sweepFlat(const gpu::FlatPopulation& flat, const st
 
   // ---- K3: CalcFWS::updateGenomeFWSMap over the 11 allele-frequency bins -----------------------
   {
-    std::vector<uint8_t> bin_of_variant(V);
-    for (uint64_t v = 0; v < V; ++v) bin_of_variant[v] = gpu::fwsBinOfFrequency(flat.rows[v].info_af);
+    std::vector<uint8_t> bin_of_variant(D);
+    for (uint64_t v = 0; v < D; ++v)
+      bin_of_variant[v] = flat.rows[v].fws_from_splits ? gpu::FWS_NO_BIN : gpu::fwsBinOfFrequency(flat.rows[v].info_af);
     std::vector<uint64_t> by_genome(G * gpu::FWS_FREQUENCY_ARRAY_SIZE * 4);
     if (kgx_count_by_genome_binned(dev.handle, bin_of_variant.data(), gpu::FWS_FREQUENCY_ARRAY_SIZE, by_genome.data()) != KGX_OK) {
       ExecEnv::log().error("GpuAlleleAnalysis; by-genome sweep failed: {}", kgx_last_error());
@@ -188,7 +190,7 @@ bool kga::GpuAlleleAnalysis::sweepFlat(const gpu::FlatPopulation& flat, const st
       v = e;
     }
     // bin = contig*4 + is_snp*2 + compound: dosage-weighted totals per class of row
-    std::vector<uint8_t> bin_of_variant(V);
+    std::vector<uint8_t> bin_of_variant(D, 0xFF);                 // split rows take no part here
     for (uint64_t v = 0; v < V; ++v)
       bin_of_variant[v] = static_cast<uint8_t>(contig_index.at(flat.rows[v].contig) * 4 + (flat.rows[v].is_snp ? 2 : 0) + compound[v]);
     const uint32_t n_bins = n_contigs * 4;

@@ -77,6 +77,31 @@ FlatPopulation flattenPopulation(const PopulationDB& population, size_t threads)
     for (const auto& [ptr, key] : seen) row_of.emplace(ptr, index_of_key.at(key));
   }
 
+  flat.primary_rows = flat.rows.size();
+  // Rows whose Variant objects come from records in different FWS bins get one split row per bin (see VariantRow).
+  std::unordered_map<const Variant*, uint32_t> split_row_of;
+  {
+    std::vector<std::vector<const Variant*>> objects_of_row(flat.primary_rows);
+    for (const auto& [ptr, r] : row_of) objects_of_row[r].push_back(ptr);
+    for (uint32_t r = 0; r < flat.primary_rows; ++r) {
+      if (objects_of_row[r].size() < 2) continue;
+      std::map<uint8_t, std::vector<const Variant*>> by_bin;
+      for (const Variant* ptr : objects_of_row[r]) by_bin[fwsBinOfFrequency(infoAF(*ptr))].push_back(ptr);
+      if (by_bin.size() < 2) continue;
+      flat.rows[r].fws_from_splits = true;
+      for (const auto& [bin, objects] : by_bin) {
+        if (bin == FWS_NO_BIN) continue;                  // copies of a record without a usable AF are in no bin's population
+        VariantRow split = flat.rows[r];
+        split.fws_from_splits = false;
+        split.split_of = r;
+        split.info_af = infoAF(*objects.front());
+        const uint32_t index = static_cast<uint32_t>(flat.rows.size());
+        flat.rows.push_back(std::move(split));
+        for (const Variant* ptr : objects) split_row_of.emplace(ptr, index);
+      }
+    }
+  }
+
   const size_t G = flat.genome_ids.size();
   const size_t V = flat.rows.size();
   flat.row_bytes = (G + 3) / 4;
@@ -102,12 +127,16 @@ FlatPopulation flattenPopulation(const PopulationDB& population, size_t threads)
             for (const auto& variant_ptr : offset_ptr->getVariantArray()) {
               const uint32_t r = row_of.at(variant_ptr.get());
               if (count[r]++ == 0) touched.push_back(r);
+              if (!split_row_of.empty()) {
+                auto split = split_row_of.find(variant_ptr.get());
+                if (split != split_row_of.end() && count[split->second]++ == 0) touched.push_back(split->second);
+              }
             }
         for (uint32_t r : touched) {
           const uint32_t d = count[r];
           count[r] = 0;
           flat.packed[static_cast<size_t>(r) * flat.row_bytes + q] |= static_cast<uint8_t>((d > 2 ? 3u : d) << (2 * j));
-          if (d > 2) overflow[t].push_back({r, static_cast<uint32_t>(g), d});
+          if (d > 2 && r < flat.primary_rows) overflow[t].push_back({r, static_cast<uint32_t>(g), d});
         }
       }
     }

@@ -27,6 +27,12 @@ struct VariantRow {
   bool is_snp{false};                      // Variant::isSNP()
   float info_af{0.0f};                     // "AF" INFO value for this alt (float32 as stored); NaN = missing
   std::shared_ptr<const Variant> variant;  // first Variant seen with this HGVS (uniqueVariants semantics)
+  // CalcFWS filters Variant OBJECTS by the AF of their own VCF record (kga_analysis_PfEMP_FWS.cpp:27-29), so when the
+  // copies of one HGVS come from records whose AF fall in different bins, each bin's population holds only its own
+  // copies.  Such a row is flagged (its by-genome bin counts come from its split rows) and one extra "split" row per bin
+  // -- the copies of that bin only -- follows the primary rows.
+  bool fws_from_splits{false};
+  int64_t split_of{-1};                    // >= 0: this is a split row of primary row split_of; info_af places it in its bin
 };
 
 // A (genome, row) cell whose real dosage exceeds 2: stored as code 3 on the device; kept here so that
@@ -39,7 +45,8 @@ struct NonDiploidCell {
 
 struct FlatPopulation {
   std::vector<GenomeId_t> genome_ids;      // std::map order = VariantDBGenomeIndex order (kgl_variant_db_variant.cpp:36-51)
-  std::vector<VariantRow> rows;            // lexicographic HGVS order = VariantDBVariantIndex order (:17-30)
+  std::vector<VariantRow> rows;            // primary rows: lexicographic HGVS order = VariantDBVariantIndex order (:17-30); then split rows
+  size_t primary_rows{0};                  // rows[0 .. primary_rows) are the population's distinct variants
   uint64_t row_bytes{0};                   // ceil(G/4)
   std::vector<uint8_t> packed;             // [rows][row_bytes] 2-bit dosage codes, genome g in bits 2*(g%4) of byte g/4
   std::vector<NonDiploidCell> non_diploid;
@@ -47,7 +54,8 @@ struct FlatPopulation {
   std::vector<ContigId_t> contig_ids;      // contigs EVERY genome holds, carrier or not (Pf flavour: the ##contig header lines)
 
   [[nodiscard]] size_t genomes() const { return genome_ids.size(); }
-  [[nodiscard]] size_t variants() const { return rows.size(); }
+  [[nodiscard]] size_t variants() const { return primary_rows; }
+  [[nodiscard]] size_t deviceRows() const { return rows.size(); }
 };
 
 // threads == 0: the reference's default, hardware_concurrency() - 1 (kel_thread/kel_workflow_threads.h:40).

@@ -27,17 +27,34 @@ uint64_t kgxh_flat_genomes(void* h) { return h ? static_cast<FlatPopulation*>(h)
 uint64_t kgxh_flat_variants(void* h) { return h ? static_cast<FlatPopulation*>(h)->variants() : 0; }
 uint64_t kgxh_flat_row_bytes(void* h) { return h ? static_cast<FlatPopulation*>(h)->row_bytes : 0; }
 uint64_t kgxh_flat_variant_objects(void* h) { return h ? static_cast<FlatPopulation*>(h)->variant_objects : 0; }
+uint64_t kgxh_flat_split_rows(void* h) { return h ? static_cast<FlatPopulation*>(h)->deviceRows() - static_cast<FlatPopulation*>(h)->variants() : 0; }
 uint64_t kgxh_flat_non_diploid(void* h) { return h ? static_cast<FlatPopulation*>(h)->non_diploid.size() : 0; }
 
 int kgxh_flat_copy(void* h, uint8_t* packed, float* info_af, uint8_t* is_snp, uint64_t* offsets) {
   if (!h) return -1;
   const FlatPopulation& f = *static_cast<FlatPopulation*>(h);
-  if (packed && !f.packed.empty()) std::memcpy(packed, f.packed.data(), f.packed.size());
-  for (size_t v = 0; v < f.rows.size(); ++v) {
+  if (packed && f.primary_rows) std::memcpy(packed, f.packed.data(), f.primary_rows * f.row_bytes);     // the split rows are not copied out
+  for (size_t v = 0; v < f.primary_rows; ++v) {
     if (info_af) info_af[v] = f.rows[v].info_af;
     if (is_snp) is_snp[v] = f.rows[v].is_snp ? 1 : 0;
     if (offsets) offsets[v] = f.rows[v].offset;
   }
+  return 0;
+}
+
+// The per-bin split rows (see VariantRow): packed[n_split][row_bytes], info_af[n_split], split_of[n_split]; and
+// from_splits[n_primary] = 1 where a primary row's FWS bin counts come from its split rows.
+int kgxh_flat_copy_splits(void* h, uint8_t* packed, float* info_af, int64_t* split_of, uint8_t* from_splits) {
+  if (!h) return -1;
+  const FlatPopulation& f = *static_cast<FlatPopulation*>(h);
+  const size_t n_split = f.rows.size() - f.primary_rows;
+  if (packed && n_split) std::memcpy(packed, f.packed.data() + f.primary_rows * f.row_bytes, n_split * f.row_bytes);
+  for (size_t v = 0; v < n_split; ++v) {
+    if (info_af) info_af[v] = f.rows[f.primary_rows + v].info_af;
+    if (split_of) split_of[v] = f.rows[f.primary_rows + v].split_of;
+  }
+  if (from_splits)
+    for (size_t v = 0; v < f.primary_rows; ++v) from_splits[v] = f.rows[v].fws_from_splits ? 1 : 0;
   return 0;
 }
 
@@ -49,7 +66,7 @@ static void copyOut(const std::string& s, char* buf, size_t n) {
 }
 
 int kgxh_flat_hgvs(void* h, uint64_t i, char* buf, size_t n) {
-  if (!h || i >= static_cast<FlatPopulation*>(h)->rows.size()) return -1;
+  if (!h || i >= static_cast<FlatPopulation*>(h)->primary_rows) return -1;
   copyOut(static_cast<FlatPopulation*>(h)->rows[i].hgvs, buf, n);
   return 0;
 }

@@ -256,6 +256,8 @@ FlatPopulation mergeRecords(const std::vector<RecordRows>& parsed, const std::ve
   std::vector<uint8_t> group_rows(n_groups * flat.row_bytes, 0), carried(n_groups, 0);
   std::vector<size_t> first_key(n_groups, 0);
   struct Wide { size_t group; uint32_t genome, dosage; };
+  struct Split { size_t group; size_t key; std::vector<uint8_t> row; };   // the copies of one FWS bin of a mixed group (see VariantRow)
+  std::vector<std::vector<Split>> splits_of_chunk((n_groups + 63) / 64);
   std::vector<std::vector<Wide>> wide_of_chunk((n_groups + 63) / 64);
   std::vector<size_t> objects_of_chunk((n_groups + 63) / 64, 0);
   parallelChunks(n_groups, 64, threads, [&](size_t begin, size_t end) {
@@ -273,6 +275,38 @@ FlatPopulation mergeRecords(const std::vector<RecordRows>& parsed, const std::ve
       }
       if (!any) continue;                             // a variant nobody carries never reaches the PopulationDB
       carried[grp] = 1;
+      if (e - k > 1) {
+        // records in different FWS bins: one split row per bin, holding that bin's copies only
+        std::map<uint8_t, std::vector<size_t>> by_bin;
+        for (size_t m = k; m < e; ++m) {
+          const uint8_t* c = &parsed[keys[m].record].copies[static_cast<size_t>(keys[m].alt) * S];
+          if (std::any_of(c, c + S, [](uint8_t x) { return x != 0; })) by_bin[fwsBinOfFrequency(parsed[keys[m].record].rows[keys[m].alt].info_af)].push_back(m);
+        }
+        if (by_bin.size() > 1) {
+          for (const auto& [bin, members] : by_bin) {
+            if (bin == FWS_NO_BIN) continue;
+            Split split{grp, members.front(), std::vector<uint8_t>(flat.row_bytes, 0)};
+            std::fill(total.begin(), total.end(), 0u);
+            for (size_t m : members) {
+              const uint8_t* c = &parsed[keys[m].record].copies[static_cast<size_t>(keys[m].alt) * S];
+              for (size_t s = 0; s < S; ++s) total[s] += c[s];
+            }
+            for (size_t g = 0; g < G; ++g) {
+              uint32_t d = 0;
+              for (uint32_t column : columns_of[g]) d += total[column];
+              split.row[g / 4] |= static_cast<uint8_t>((d > 2 ? 3u : d) << (2 * (g % 4)));
+            }
+            splits_of_chunk[begin / 64].push_back(std::move(split));
+          }
+          // restore the group's totals for the primary row below
+          std::fill(total.begin(), total.end(), 0u);
+          for (size_t m = k; m < e; ++m) {
+            const uint8_t* c = &parsed[keys[m].record].copies[static_cast<size_t>(keys[m].alt) * S];
+            for (size_t s = 0; s < S; ++s) total[s] += c[s];
+          }
+          carried[grp] = 2;                             // primary row's bin counts come from its splits
+        }
+      }
       uint8_t* row = &group_rows[grp * flat.row_bytes];
       for (size_t g = 0; g < G; ++g) {
         uint32_t d = 0;
@@ -291,12 +325,21 @@ FlatPopulation mergeRecords(const std::vector<RecordRows>& parsed, const std::ve
   for (size_t grp = 0; grp < n_groups; ++grp) {
     if (!carried[grp]) continue;
     flat.rows.push_back(parsed[keys[first_key[grp]].record].rows[keys[first_key[grp]].alt]);
+    flat.rows.back().fws_from_splits = carried[grp] == 2;
     if (flat.row_bytes) std::memcpy(&flat.packed[static_cast<size_t>(row_of_group[grp]) * flat.row_bytes], &group_rows[grp * flat.row_bytes], flat.row_bytes);
   }
+  flat.primary_rows = flat.rows.size();
   for (size_t chunk = 0; chunk < wide_of_chunk.size(); ++chunk) {
     flat.variant_objects += objects_of_chunk[chunk];
     for (const Wide& w : wide_of_chunk[chunk]) flat.non_diploid.push_back({row_of_group[w.group], w.genome, w.dosage});
   }
+  for (const auto& chunk : splits_of_chunk)
+    for (const Split& split : chunk) {
+      VariantRow row = parsed[keys[split.key].record].rows[keys[split.key].alt];
+      row.split_of = row_of_group[split.group];
+      flat.rows.push_back(std::move(row));
+      flat.packed.insert(flat.packed.end(), split.row.begin(), split.row.end());
+    }
   return flat;
 }
 

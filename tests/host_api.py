@@ -27,7 +27,9 @@ def lib():
         L.kgxh_flatten_vcf_pf.restype = C.c_void_p
         L.kgxh_flatten_vcf_pf.argtypes = [C.c_char_p, C.c_uint64, C.c_int, C.c_int]
         L.kgxh_flat_destroy.argtypes = [C.c_void_p]
-        for name in ("kgxh_flat_genomes", "kgxh_flat_variants", "kgxh_flat_row_bytes", "kgxh_flat_variant_objects", "kgxh_flat_non_diploid"):
+        L.kgxh_flat_copy_splits.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        for name in ("kgxh_flat_genomes", "kgxh_flat_variants", "kgxh_flat_row_bytes", "kgxh_flat_variant_objects", "kgxh_flat_non_diploid",
+                     "kgxh_flat_split_rows"):
             getattr(L, name).restype = C.c_uint64
             getattr(L, name).argtypes = [C.c_void_p]
         L.kgxh_flat_copy.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
@@ -69,6 +71,13 @@ class FlatVcf:
             self.offsets = np.zeros(self.V, dtype=np.uint64)
             p = lambda a: C.c_void_p(a.ctypes.data)
             lib().kgxh_flat_copy(h, p(self.packed), p(self.info_af), p(self.is_snp), p(self.offsets))
+            # per-bin split rows of variants whose repeated records fall in different FWS bins
+            self.n_split = int(lib().kgxh_flat_split_rows(h))
+            self.split_packed = np.zeros((self.n_split, self.row_bytes), dtype=np.uint8)
+            self.split_info_af = np.zeros(self.n_split, dtype=np.float32)
+            self.split_of = np.zeros(self.n_split, dtype=np.int64)
+            self.from_splits = np.zeros(self.V, dtype=np.uint8)
+            lib().kgxh_flat_copy_splits(h, p(self.split_packed), p(self.split_info_af), p(self.split_of), p(self.from_splits))
             buf = C.create_string_buffer(1024)
             self.hgvs, self.genome_ids = [], []
             for i in range(self.V):
@@ -79,6 +88,24 @@ class FlatVcf:
                 self.genome_ids.append(buf.value.decode())
         finally:
             lib().kgxh_flat_destroy(h)
+
+
+def fws_genome_bins(flat) -> np.ndarray:
+    """[G][11][3] by-genome counts per FWS bin from a FlatVcf, the way GpuAlleleAnalysis assigns rows to bins."""
+    from kgl_gene_amd import capi
+    from kgl_gene_amd.fws import fws_bin_of_variant
+
+    out = np.zeros((flat.G, 11, 3), dtype=np.uint64)
+    dose = capi.unpack_dosage2(flat.packed, flat.G) if flat.V else np.zeros((0, flat.G), dtype=np.uint8)
+    bins = fws_bin_of_variant(np.where(np.isinf(flat.info_af), np.nan, flat.info_af)).astype(np.int64)
+    bins[flat.from_splits.astype(bool)] = 255
+    if flat.n_split:
+        dose = np.concatenate([dose, capi.unpack_dosage2(flat.split_packed, flat.G)])
+        bins = np.concatenate([bins, fws_bin_of_variant(np.where(np.isinf(flat.split_info_af), np.nan, flat.split_info_af)).astype(np.int64)])
+    for b in range(11):
+        sel = dose[bins == b]
+        out[:, b, :] = np.stack([(sel == 0).sum(0), (sel == 1).sum(0), (sel == 2).sum(0)], 1)
+    return out
 
 
 class InbreedInputs:

@@ -282,3 +282,41 @@ def test_gpu_inbreed_package_reads_vcf_directly(tmp_path, kgx, algorithm):
             assert abs(f[4] - freqs[k, 4]) <= {"Simple": 1e-10, "HallME": 1e-9}[algorithm], (ident, g, f[4], freqs[k, 4])
             n_checked += 1
     assert n_checked == len(got) and n_checked >= 3 * (G - 10)
+
+
+@pytest.mark.parametrize("via", ["records", "vcf"])
+def test_gpu_allele_package_bins_each_copy_by_its_own_record(tmp_path, kgx, via):
+    """Repeated records of one variant with DIFFERENT AF: CalcFWS puts each Variant object into the bin of its own
+    record.  Both flatteners (PopulationDB objects, VCF text) emit per-bin split rows for such variants; the by-genome
+    bin counts must equal the oracle's, and the per-variant counts still merge every copy."""
+    from . import vcf_text as vt
+
+    G, L = 31, 900
+    rec, gt = sv.multiallelic_block(G, L, rng_seed=77, dup_records=60)
+    rng = np.random.default_rng(9)
+    for a in rec.af:
+        a[:, 5] = rng.uniform(0, 0.6, a.shape[0]).astype(np.float32)      # every record its own AF
+    ids = sv.genome_ids(G, prefix="HG")
+    if via == "records":
+        path = tmp_path / "pop.bin"
+        rio.write_records(path, rec, gt, ids, oa.Population.PHASED, "Genome1000", population_id="kg")
+        res = rio.run_driver("GPU_ALLELE", tmp_path, [path])
+        opop = sv.oracle_population(rec, gt, ids, oa.Population.PHASED)
+    else:
+        text = vt.write_vcf_1000(rec, gt, ids, rng_seed=2, quirks=False)
+        (tmp_path / "kg.vcf").write_text(text)
+        res = rio.run_driver("GPU_ALLELE", tmp_path, [f"vcf:{tmp_path / 'kg.vcf'}"])
+        opop = oa.Population("kg")
+        opop.add_vcf_1000(text)
+    assert res.returncode == 0, res.stderr
+    variant_out, genome_out, vdb = opop.fws()
+    header, rows = rio.read_csv(tmp_path / "VariantFWS.csv")
+    assert [r[0] for r in rows] == [vdb.hgvs(i) for i in range(vdb.n_variants)]
+    assert np.array_equal(np.array([[int(x) for x in r[-3:]] for r in rows], dtype=np.uint64), variant_out)
+    header, rows = rio.read_csv(tmp_path / "GenomeFWS.csv")
+    got = np.array([[int(r[1 + 8 * b + 5 + k]) for b in range(11) for k in range(3)] for r in rows], dtype=np.uint64)
+    assert np.array_equal(got.reshape(len(rows), 11, 3), genome_out)
+    header, rows = rio.read_csv(tmp_path / "VariantStatistics.csv")
+    want = opop.hethom(rec.contig)
+    got = np.array([[int(r[2]), int(r[3]), int(r[4]), int(r[7]), int(r[8]), int(r[6]), int(r[5])] for r in rows], dtype=np.uint64)
+    assert np.array_equal(got, want)

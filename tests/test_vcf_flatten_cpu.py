@@ -209,3 +209,47 @@ def test_vcf_reader_plain_gzip_and_block_gzip(tmp_path, threads):
     # and the flattener sees the same population through any of them
     flat = ha.FlatVcf(ha.read_vcf_text(tmp_path / "a.vcf.bgz", threads).decode(), flavour="Falciparum")
     assert flat.G == len(ids) and flat.V > 0
+
+
+def test_repeated_records_in_different_fws_bins_are_split_per_bin():
+    """CalcFWS filters Variant objects by their own record's AF: when the records of one variant disagree, each bin's
+    population holds only that record's copies.  The flatteners emit per-bin split rows for exactly those variants."""
+    hdr = "##contig=<ID=c1>\n#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\tS1\tS2\tS3\n"
+    body = ("c1\t10\t.\tA\tT\t.\tPASS\tAF=0.02\tGT:AD\t0/1:5,5\t0/0:5,0\t1/1:0,9\n"      # bin 0
+            "c1\t10\t.\tA\tT\t.\tPASS\tAF=0.22\tGT:AD\t0/1:5,5\t0/1:5,5\t0/0:9,0\n"      # same variant, bin 4
+            "c1\t10\t.\tA\tT\t.\tPASS\t.\tGT:AD\t0/0:5,0\t0/1:5,5\t0/0:9,0\n"            # same variant, no AF: in no bin
+            "c1\t20\t.\tG\tC\t.\tPASS\tAF=0.31\tGT:AD\t0/1:5,5\t0/0:5,0\t0/0:9,0\n"
+            "c1\t20\t.\tG\tC\t.\tPASS\tAF=0.33\tGT:AD\t0/0:5,0\t1/1:0,5\t0/0:9,0\n")     # same variant, SAME bin 6: no split
+    flat = ha.FlatVcf(hdr + body, flavour="Falciparum")
+    assert flat.hgvs == ["c1:g.19G>C", "c1:g.9A>T"] and flat.from_splits.tolist() == [0, 1] and flat.n_split == 2
+    assert capi.unpack_dosage2(flat.packed, 3).tolist() == [[1, 2, 0], [2, 2, 2]]                 # merged rows: every copy
+    assert sorted(zip([round(float(x), 2) for x in flat.split_info_af], capi.unpack_dosage2(flat.split_packed, 3).tolist())) == \
+        [(0.02, [1, 0, 2]), (0.22, [1, 1, 0])]
+    o = oa.Population("x")
+    o.add_vcf_pf(hdr + body)
+    _, genome_out, _ = o.fws()
+    assert np.array_equal(ha.fws_genome_bins(flat), genome_out)
+    assert genome_out[:, 0, :].tolist() == [[0, 1, 0], [1, 0, 0], [0, 0, 1]]                      # bin 0 sees the first record only
+
+
+@pytest.mark.parametrize("flavour", ["Falciparum", "Genome1000"])
+def test_fws_bins_with_disagreeing_repeats_match_oracle(flavour):
+    if flavour == "Falciparum":
+        ids = [f"PF{i:04d}-C" for i in range(19)]
+        text = vt.write_vcf_pf(2500, ids, rng_seed=31, same_af_for_repeats=False)
+        o = oa.Population("pf")
+        o.add_vcf_pf(text)
+    else:
+        G, L = 23, 900
+        rec, gt = sv.multiallelic_block(G, L, rng_seed=12, dup_records=40)
+        rng = np.random.default_rng(5)
+        for a in rec.af:                                      # every record its own AF: repeats of a locus disagree
+            a[:, 5] = rng.uniform(0, 0.6, a.shape[0]).astype(np.float32)
+        text = vt.write_vcf_1000(rec, gt, [f"NA{i:05d}" for i in range(G)], rng_seed=3, quirks=False)
+        o = oa.Population("kg")
+        o.add_vcf_1000(text)
+    flat = ha.FlatVcf(text, 3, flavour=flavour)
+    assert flat.n_split > 0 and flat.from_splits.sum() > 0
+    _, genome_out, vdb = o.fws()
+    assert flat.hgvs == [vdb.hgvs(i) for i in range(vdb.n_variants)]
+    assert np.array_equal(ha.fws_genome_bins(flat), genome_out)

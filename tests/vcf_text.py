@@ -61,7 +61,7 @@ def write_vcf_1000(rec, gt, ids, rng_seed=0, quirks=True, contig=None):
     return "\n".join(lines) + "\n"
 
 
-def write_vcf_pf(n_records, ids, rng_seed=0, quirks=True):
+def write_vcf_pf(n_records, ids, rng_seed=0, quirks=True, same_af_for_repeats=True):
     """Returns the text.  Several contigs (one of them the mitochondrion, one never used), multi-base alleles, repeated
     positions."""
     rng = np.random.default_rng(rng_seed)
@@ -103,7 +103,8 @@ def write_vcf_pf(n_records, ids, rng_seed=0, quirks=True):
         # reference bins each copy by its own record's AF; the product bins the row once)
         import zlib
         from . import oracle_api as oa
-        af = np.array([(zlib.crc32(f"{contig}:{oa.canonical(ref, a, pos - 1)}".encode()) % 6000) / 10000.0 for a in alts])
+        salt = "" if same_af_for_repeats else f"#{r}"          # different AF per record: a repeated variant's copies land in different bins
+        af = np.array([(zlib.crc32(f"{contig}:{oa.canonical(ref, a, pos - 1)}{salt}".encode()) % 6000) / 10000.0 for a in alts])
         if zlib.crc32(f"{contig}:{pos}".encode()) % 13 != 6:
             info.append("AF=" + ",".join(f"{x:.4f}" for x in af))
         u = rng.random()
