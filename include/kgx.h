@@ -152,7 +152,10 @@ int kgx_population_summary(kgx_pop* pop, uint64_t out[4]);
  * not hold); high nibble = the second SNP variant (0 = none); 0xFF = three or more.  Indels never enter:
  * INBREED filters the reference population to SNP & PASS (kga_analysis_inbreed.cpp:79) and each genome's
  * contig to SNPs (kga_analysis_inbreed_freq.cpp:436).  The order of the two nibbles is the order of the
- * genome's OffsetDB array (front()/back() at _freq.cpp:462,476,493). */
+ * genome's OffsetDB array (front()/back() at _freq.cpp:462,476,493).  With phased input a byte (a, a) is one variant
+ * on both phases (homozygous); two copies of one variant on the SAME phase -- a repeated VCF record -- are written
+ * (0, a): analogous but not homozygous() (kgl_variant_db.h:135-143), which the reference classifies as a minor
+ * heterozygote with that allele twice.  Bytes outside this description are skipped, never read through. */
 typedef struct kgx_gt8 kgx_gt8;
 kgx_gt8* kgx_gt8_create(uint64_t n_genomes, uint64_t n_loci);
 void     kgx_gt8_destroy(kgx_gt8* gt);

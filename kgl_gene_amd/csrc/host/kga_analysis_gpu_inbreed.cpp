@@ -310,12 +310,9 @@ kgl::analysis::gpu::FlatDiploid kga::GpuInbreedAnalysis::diploidBytes(const Popu
       uint8_t b;
       if (n >= 3) b = 0xFF;
       else {
-        if (n == 2 && code[0] == code[1] && code[0] != 15 && phased && phase[0] == phase[1]) {
-          out.error = "Genome: " + out.genome_ids[g] + " holds two copies of one variant with the SAME phase at offset " + std::to_string(offset) +
-                      "; not representable";
-          return out;
-        }
-        b = static_cast<uint8_t>(code[0] | (code[1] << 4));
+        // two copies of one variant on ONE phase (a repeated record): analogous, not homozygous -> the (0, a) byte
+        if (n == 2 && code[0] == code[1] && code[0] != 15 && phased && phase[0] == phase[1]) b = static_cast<uint8_t>(code[0] << 4);
+        else b = static_cast<uint8_t>(code[0] | (code[1] << 4));
       }
       out.bytes[static_cast<uint64_t>(lit->second) * G + g] = b;
     }

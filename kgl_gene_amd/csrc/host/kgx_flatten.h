@@ -100,13 +100,14 @@ struct FlatReference {
 // The phased diploid population (1000-Genomes flavour, as flattenVcf1000) as the allele-index bytes of the inbreeding
 // sweep: for every reference locus and genome, the genome's SNP variants at that offset in the order the parser adds
 // them (phase A alts, then phase B, record by record), each as 1 + its index in the locus's reference alt list (15 =
-// not in the list), two per byte, 0xFF for three or more.  Genomes = samples carrying any variant on the reference's
+// not in the list), two per byte, 0xFF for three or more; two copies of one variant on the SAME phase (a repeated record)
+// are the byte (0, code): the reference treats them as two analogous, not homozygous, variants.  Genomes = samples carrying any variant on the reference's
 // contig (the parser creates a genome's contig when it first adds a variant to it), in id order.
 struct FlatDiploid {
   std::vector<GenomeId_t> genome_ids;
   uint64_t n_loci{0};
   std::vector<uint8_t> bytes;              // [n_loci][genome_ids.size()]
-  std::string error;                       // non-empty: not representable (two same-phase copies of one variant)
+  std::string error;                       // reserved: every population the parser accepts is representable
 };
 [[nodiscard]] FlatDiploid flattenVcf1000Gt8(std::string_view text, const FlatReference& reference, size_t threads = 0);
 

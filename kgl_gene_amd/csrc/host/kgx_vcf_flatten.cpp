@@ -772,14 +772,10 @@ FlatDiploid flattenVcf1000Gt8(std::string_view text, const FlatReference& refere
           if (n == 0) { row[g] = code; first_phase[g] = phase; }
           else if (n == 1) {
             const uint8_t c0 = row[g] & 0xF;
-            if (c0 == code && code != 15 && first_phase[g] == phase) {
-              std::lock_guard<std::mutex> lock(error_mutex);
-              if (out.error.empty())
-                out.error = "Genome: " + lines.samples[sample] + " holds two copies of one variant with the SAME phase; not representable";
-              failed.store(true);
-              return false;
-            }
-            row[g] = static_cast<uint8_t>(c0 | (code << 4));
+            (void)sample;
+            // two copies of one variant on ONE phase (a repeated record): analogous, not homozygous -> the (0, a) byte
+            if (c0 == code && code != 15 && first_phase[g] == phase) row[g] = static_cast<uint8_t>(code << 4);
+            else row[g] = static_cast<uint8_t>(c0 | (code << 4));
           } else {
             row[g] = 0xFF;
           }

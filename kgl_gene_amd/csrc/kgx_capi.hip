@@ -790,7 +790,7 @@ int kgx_inbreed(kgx_gt8* h, uint64_t g0, uint64_t g1, const uint32_t* locus_inde
   // the estimator needs no Ritland terms; otherwise 4 genomes per lane.
   // RitlandLocus with allele indices that fit the tables: the plain frequency sweep, then one table pass for its terms.
   const bool ritland_lut = algorithm == KGX_ALGO_RITLAND_LOCUS && !env_int("KGX_K5_GENERIC", 0) && !env_int("KGX_K5_NO_EVAL_LUT", 0) &&
-                           !env_int("KGX_K5_NO_SWAR", 0) && amax <= 4;
+                           amax <= 4;
   const bool swar16 = !env_int("KGX_K5_GENERIC", 0) && !env_int("KGX_K5_NO_SWAR16", 0) && amax <= 4 && (g0 & 15u) == 0 &&
                       (algorithm != KGX_ALGO_RITLAND_LOCUS || ritland_lut);
   // The evaluation passes of HallME / Loglikelihood go through the per-batch LDS tables when the allele indices fit them.
@@ -814,7 +814,6 @@ int kgx_inbreed(kgx_gt8* h, uint64_t g0, uint64_t g1, const uint32_t* locus_inde
   uint32_t* d_index = nullptr;
   unsigned long long* d_counts = nullptr;
   LocusResultsDev* d_out = nullptr;
-  LocusBits* d_bits = nullptr;
   uint32_t* d_meta = nullptr;
   GoldenState* d_golden = nullptr;
   BrentState* d_brent = nullptr;
@@ -831,7 +830,7 @@ int kgx_inbreed(kgx_gt8* h, uint64_t g0, uint64_t g1, const uint32_t* locus_inde
   const uint64_t n_tab = n_sel ? n_sel : 1;
   ScratchPlan plan;
   const size_t o_af = plan.add(n_tab * amax * sizeof(double)), o_table = plan.add(n_tab * stride * sizeof(double));
-  const size_t o_valid = plan.add(n_tab), o_bits = plan.add(n_tab * sizeof(LocusBits)), o_meta = plan.add((n_tab + 8) * sizeof(uint32_t));
+  const size_t o_valid = plan.add(n_tab), o_meta = plan.add((n_tab + 8) * sizeof(uint32_t));
   const size_t o_part = plan.add(n_seg * n * kParts0 * sizeof(double)), o_segdef = plan.add(n_seg * kSegDefaults * sizeof(double));
   const size_t o_sums = plan.add(n * kParts0 * sizeof(double)), o_counts = plan.add(n * 6 * sizeof(unsigned long long));
   const size_t o_f = plan.add(n * sizeof(double)), o_eval = plan.add(n * sizeof(double)), o_out = plan.add(n * sizeof(LocusResultsDev));
@@ -842,7 +841,6 @@ int kgx_inbreed(kgx_gt8* h, uint64_t g0, uint64_t g1, const uint32_t* locus_inde
   d_af = reinterpret_cast<double*>(arena + o_af);
   d_table = reinterpret_cast<double*>(arena + o_table);
   d_valid = reinterpret_cast<uint8_t*>(arena + o_valid);
-  d_bits = reinterpret_cast<LocusBits*>(arena + o_bits);
   d_meta = reinterpret_cast<uint32_t*>(arena + o_meta);
   d_part = reinterpret_cast<double*>(arena + o_part);
   d_segdef = reinterpret_cast<double*>(arena + o_segdef);
@@ -875,7 +873,7 @@ int kgx_inbreed(kgx_gt8* h, uint64_t g0, uint64_t g1, const uint32_t* locus_inde
     if (n_sel == 0) return;
     if (mode == 0) {
       if (swar16) {
-        hipLaunchKernelGGL(k_locus_bits, dim3(stream_grid(n_sel, kBlock)), dim3(kBlock), 0, st, d_table, d_valid, n_sel, amax, d_bits, d_meta);
+        hipLaunchKernelGGL(k_locus_bits, dim3(stream_grid(n_sel, kBlock)), dim3(kBlock), 0, st, d_table, d_valid, n_sel, amax, d_meta);
         hipLaunchKernelGGL(k_segment_defaults, dim3(static_cast<uint32_t>(n_seg)), dim3(kWave), 0, st, d_table, d_valid, n_sel, per_seg, amax, d_segdef);
         hipLaunchKernelGGL(k_fill_defaults, dim3(stream_grid(n_seg * n, kBlock)), dim3(kBlock), 0, st, d_segdef, n_seg, n, d_part);
         const dim3 grid16(gx16, static_cast<uint32_t>(n_seg));
@@ -886,35 +884,18 @@ int kgx_inbreed(kgx_gt8* h, uint64_t g0, uint64_t g1, const uint32_t* locus_inde
         else
           hipLaunchKernelGGL((k_inbreed_sweep_swar16<false>), grid16, dim3(kBlock), 0, st, gt128, h->pitch / 16, g0, n, d_index, n_sel, per_seg,
                              d_table, d_meta, amax, phased, d_segdef, d_counts, d_part);
-      } else if (env_int("KGX_K5_GENERIC", 0) || amax > 4) {
+      } else if (env_int("KGX_K5_GENERIC", 0) || amax > 4 || (algorithm == KGX_ALGO_RITLAND_LOCUS && !ritland_lut)) {
         hipLaunchKernelGGL((k_inbreed_sweep<0>), grid, dim3(kBlock), 0, st, gt32, dwords_per_row, g0, n, d_index, n_sel, per_seg, d_table,
                            d_valid, amax, phased, d_f, d_counts, d_part);
       } else {
-        hipLaunchKernelGGL(k_locus_bits, dim3(stream_grid(n_sel, kBlock)), dim3(kBlock), 0, st, d_table, d_valid, n_sel, amax, d_bits, d_meta);
+        hipLaunchKernelGGL(k_locus_bits, dim3(stream_grid(n_sel, kBlock)), dim3(kBlock), 0, st, d_table, d_valid, n_sel, amax, d_meta);
         hipLaunchKernelGGL(k_segment_defaults, dim3(static_cast<uint32_t>(n_seg)), dim3(kWave), 0, st, d_table, d_valid, n_sel, per_seg, amax, d_segdef);
-        const bool ritland = algorithm == KGX_ALGO_RITLAND_LOCUS && !ritland_lut;
-        if (env_int("KGX_K5_NO_SWAR", 0)) {
-          if (ritland)
-            hipLaunchKernelGGL((k_inbreed_sweep_fast<true>), grid, dim3(kBlock), 0, st, gt32, dwords_per_row, g0, n, d_index, n_sel, per_seg,
-                               d_table, d_valid, d_bits, amax, phased, d_segdef, d_counts, d_part);
-          else
-            hipLaunchKernelGGL((k_inbreed_sweep_fast<false>), grid, dim3(kBlock), 0, st, gt32, dwords_per_row, g0, n, d_index, n_sel, per_seg,
-                               d_table, d_valid, d_bits, amax, phased, d_segdef, d_counts, d_part);
-        } else if (d_index) {
-          if (ritland)
-            hipLaunchKernelGGL((k_inbreed_sweep_swar<true, true>), grid, dim3(kBlock), 0, st, gt32, dwords_per_row, g0, n, d_index, n_sel, per_seg,
-                               d_table, d_meta, amax, phased, d_segdef, d_counts, d_part);
-          else
-            hipLaunchKernelGGL((k_inbreed_sweep_swar<true, false>), grid, dim3(kBlock), 0, st, gt32, dwords_per_row, g0, n, d_index, n_sel, per_seg,
-                               d_table, d_meta, amax, phased, d_segdef, d_counts, d_part);
-        } else {
-          if (ritland)
-            hipLaunchKernelGGL((k_inbreed_sweep_swar<false, true>), grid, dim3(kBlock), 0, st, gt32, dwords_per_row, g0, n, d_index, n_sel, per_seg,
-                               d_table, d_meta, amax, phased, d_segdef, d_counts, d_part);
-          else
-            hipLaunchKernelGGL((k_inbreed_sweep_swar<false, false>), grid, dim3(kBlock), 0, st, gt32, dwords_per_row, g0, n, d_index, n_sel, per_seg,
-                               d_table, d_meta, amax, phased, d_segdef, d_counts, d_part);
-        }
+        if (d_index)
+          hipLaunchKernelGGL((k_inbreed_sweep_swar<true>), grid, dim3(kBlock), 0, st, gt32, dwords_per_row, g0, n, d_index, n_sel, per_seg,
+                             d_table, d_meta, amax, phased, d_segdef, d_counts, d_part);
+        else
+          hipLaunchKernelGGL((k_inbreed_sweep_swar<false>), grid, dim3(kBlock), 0, st, gt32, dwords_per_row, g0, n, d_index, n_sel, per_seg,
+                             d_table, d_meta, amax, phased, d_segdef, d_counts, d_part);
       }
     } else if (eval_lut || mode == 3) {
       const dim3 grid_eval(static_cast<uint32_t>(((n + eval_gpl - 1) / eval_gpl + kBlock - 1) / kBlock), static_cast<uint32_t>(n_seg));

@@ -594,8 +594,16 @@ __device__ __forceinline__ int classify_cell(uint32_t b, const double* __restric
     return kClassNone;
   }
   const uint32_t a1 = b & 15u, a2 = b >> 4;
-  // unknown alt, >= 3 variants (0xFF), or a byte no flattener writes (second variant without a first)
-  if (a1 == 0u || a1 == 15u || a2 == 15u || a1 > amax || a2 > amax) return kClassNone;
+  if (a1 == 15u || a2 == 15u || a1 > amax || a2 > amax) return kClassNone;    // unknown alt, >= 3 variants (0xFF), past the table
+  if (a1 == 0u) {
+    // (0, a): two copies of alt a on ONE phase (a repeated VCF record).  They are analogous but not homozygous()
+    // (kgl_variant_db.h:135-143), so the offset takes the two-variant branch with the same allele found twice
+    // (_freq.cpp:488-506): MINOR_HETEROZYGOUS with both frequencies that allele's.
+    f1 = row[a2 - 1];
+    if (!(f1 == f1)) return kClassNone;
+    f2 = f1;
+    return kMinorHet;
+  }
   f1 = row[a1 - 1];
   if (!(f1 == f1)) return kClassNone;                                         // front() not in the AF list
   if (a2 == 0) { f2 = p_major; return kMajorHet; }
@@ -935,23 +943,18 @@ k_segment_defaults(const double* __restrict__ table, const uint8_t* __restrict__
   if (threadIdx.x == 0) seg_def[seg * kSegDefaults + 7] = 0.0;
 }
 
-// K5 fast path (MODE 0 of k_inbreed_sweep, same results up to fp64 summation order).  Every class-frequency sum
-// of generateFrequencies is class independent (_freq.cpp:549-556) and a reference-homozygous genome behaves the
-// same at a locus for every genome, so a genome's results are the segment defaults (k_segment_defaults) corrected
-// at the loci where it carries a variant.  The per-cell decision (_freq.cpp:452-543) is branch-free integer logic on
-// per-locus bit masks held in scalar registers (which alts are in the AlleleFreqVector, which have AF > 0.001), so
-// a wave never diverges on genotype; class counts accumulate in packed 16-bit fields (a segment holds <= 65535
-// loci); only the rare cells whose classification disagrees with the locus default touch fp64 class sums.
-// RITLAND adds the two fp64 sums processRitlandLocus needs.  amax <= 4 (wider loci take the generic kernel).
-struct LocusBits {          // per selected locus, built by k_locus_bits from the table
-  uint16_t in_list;         // bit a (1..amax): alt a is in the AlleleFreqVector
-  uint16_t rit_ok;          // bit a: af[a] > 0.001 (minimum_frequency, _calc.cpp:380)
-};
+// K5 frequency pass, the idea shared by the SWAR kernels below (same results as MODE 0 of k_inbreed_sweep up to fp64
+// summation order).  Every class-frequency sum of generateFrequencies is class independent (_freq.cpp:549-556) and a
+// reference-homozygous genome behaves the same at a locus for every genome, so a genome's results are the segment
+// defaults (k_segment_defaults) corrected at the loci where it carries a variant.  The per-cell decision
+// (_freq.cpp:452-543) is branch-free integer logic on per-locus bit masks held in scalar registers (which alts are in
+// the AlleleFreqVector, which have AF > 0.001), so a wave never diverges on genotype; only the rare cells whose
+// classification disagrees with the locus default touch fp64 class sums.  amax <= 4 (wider loci take the generic kernel).
 
 // meta[s] (for amax <= 7): flag bits (kLocus*) | in_list bits 0..7 << 8 | rit_ok bits << 16 — one scalar dword per locus.
 __global__ void __launch_bounds__(kBlock)
 k_locus_bits(const double* __restrict__ table, const uint8_t* __restrict__ flags, uint64_t n_sel, uint32_t amax,
-             LocusBits* __restrict__ bits, uint32_t* __restrict__ meta) {
+             uint32_t* __restrict__ meta) {
   const uint32_t stride = sweep_stride(amax);
   for (uint64_t s = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x; s < n_sel;
        s += static_cast<uint64_t>(gridDim.x) * blockDim.x) {
@@ -961,136 +964,7 @@ k_locus_bits(const double* __restrict__ table, const uint8_t* __restrict__ flags
       const double f = row[a];
       if (f == f) { in_list |= 1u << (a + 1); if (f > 0.001) rit_ok |= 1u << (a + 1); }
     }
-    bits[s] = LocusBits{static_cast<uint16_t>(in_list), static_cast<uint16_t>(rit_ok)};
     meta[s] = static_cast<uint32_t>(flags[s]) | ((in_list & 0xFFu) << 8) | ((rit_ok & 0xFFFFu) << 16);
-  }
-}
-
-template <bool RITLAND>
-__global__ void __launch_bounds__(kBlock)
-k_inbreed_sweep_fast(const uint32_t* __restrict__ gt, uint64_t dwords_per_row, uint64_t g0, uint64_t n_genomes,
-                     const uint32_t* __restrict__ locus_index, uint64_t n_sel, uint64_t loci_per_seg,
-                     const double* __restrict__ table, const uint8_t* __restrict__ flags, const LocusBits* __restrict__ bits,
-                     uint32_t amax, int phased, const double* __restrict__ seg_def, unsigned long long* __restrict__ counts,
-                     double* __restrict__ part) {
-  const uint64_t quad = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
-  if (quad * 4 >= n_genomes) return;
-  const uint64_t seg = blockIdx.y;
-  const uint64_t s_begin = seg * loci_per_seg;
-  const uint64_t s_end = s_begin + loci_per_seg < n_sel ? s_begin + loci_per_seg : n_sel;
-  const uint32_t stride = sweep_stride(amax);
-  const uint64_t col = (g0 >> 2) + quad;
-  const uint32_t ph = phased ? 1u : 0u;
-
-  uint32_t acc0[4], acc1[4], acc2[4];   // majorHet | minorHom<<16 ; minorHet | missDefault<<16 ; ritCount | missRit<<16
-  double cf_corr[4][4], s_inv[4], s_miss[4];
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    acc0[j] = acc1[j] = acc2[j] = 0;
-    cf_corr[j][0] = cf_corr[j][1] = cf_corr[j][2] = cf_corr[j][3] = 0.0;
-    s_inv[j] = s_miss[j] = 0.0;
-  }
-
-  constexpr int kBatch = 8;
-  for (uint64_t s0 = s_begin; s0 < s_end; s0 += kBatch) {
-    uint32_t w[kBatch];
-#pragma unroll
-    for (int i = 0; i < kBatch; ++i) {
-      const uint64_t s = s0 + i;
-      uint32_t v = 0;
-      if (s < s_end) {
-        const uint64_t l = locus_index ? static_cast<uint64_t>(locus_index[s]) : s;
-        v = __builtin_nontemporal_load(gt + l * dwords_per_row + col);
-      }
-      w[i] = v;
-    }
-#pragma unroll
-    for (int i = 0; i < kBatch; ++i) {
-      const uint64_t s = s0 + i;
-      if (s >= s_end) break;
-      const uint32_t f = flags[s];                       // wave-uniform
-      if (!(f & kLocusValid)) continue;
-      const LocusBits lb = bits[s];
-      const uint32_t in_list = lb.in_list, rit_ok = lb.rit_ok;
-      const uint32_t def = (f & kLocusDefault) ? 1u : 0u, ritdef = (f & kLocusRitlandDefault) ? 1u : 0u;
-      const double* row = table + s * stride;
-      uint32_t rare_any = 0;
-      uint32_t rare[4];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const uint32_t b = (w[i] >> (8 * j)) & 0xFFu;
-        const uint32_t a1 = b & 15u, a2 = b >> 4;
-        const uint32_t nz = b != 0 ? 1u : 0u;
-        const uint32_t ok1 = (in_list >> a1) & 1u, ok2 = (in_list >> a2) & 1u;     // bit 0 and bit 15 are never set
-        const uint32_t single = a2 == 0 ? 1u : 0u;
-        const uint32_t hom = (a1 == a2 ? 1u : 0u) & ph;
-        const uint32_t major_het = ok1 & single;
-        const uint32_t minor_hom = ok1 & hom & (single ^ 1u);
-        const uint32_t minor_het = ok1 & ok2 & (single ^ 1u) & (hom ^ 1u);
-        const uint32_t classified = major_het | minor_hom | minor_het;
-        acc0[j] += major_het | (minor_hom << 16);
-        acc1[j] += minor_het | ((nz & def) << 16);
-        rare[j] = nz & (def ^ classified);
-        rare_any |= rare[j];
-        if constexpr (RITLAND) {
-          const uint32_t hom_counts = minor_hom & ((rit_ok >> a1) & 1u);
-          acc2[j] += (hom_counts | major_het | minor_het) | ((nz & ritdef) << 16);
-          double inv = 0.0;
-#pragma unroll
-          for (uint32_t a = 1; a <= 4; ++a)
-            if (a <= amax) inv = (hom_counts && a1 == a) ? row[amax + kTableExtra + a - 1] : inv;
-          s_inv[j] += inv;
-          s_miss[j] += (nz & ritdef) ? row[2 * amax + kTableExtra] : 0.0;
-        }
-      }
-      if (rare_any) {     // the cell's classification disagrees with the locus default: adjust the class-frequency sums
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          if (!rare[j]) continue;
-          const double sign = def ? -1.0 : 1.0;
-          cf_corr[j][0] += sign * row[amax + 1]; cf_corr[j][1] += sign * row[amax + 2];
-          cf_corr[j][2] += sign * row[amax + 3]; cf_corr[j][3] += sign * row[amax + 4];
-        }
-      }
-    }
-  }
-
-  const double* def_row = seg_def + seg * kSegDefaults;
-  const unsigned long long n_def = static_cast<unsigned long long>(def_row[5]);
-  const unsigned long long n_rit = static_cast<unsigned long long>(def_row[6]);
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const uint64_t g = quad * 4 + j;
-    if (g >= n_genomes) continue;
-    const unsigned long long major_het = acc0[j] & 0xFFFFu, minor_hom = acc0[j] >> 16;
-    const unsigned long long minor_het = acc1[j] & 0xFFFFu, miss_def = acc1[j] >> 16;
-    const unsigned long long major_hom = n_def - miss_def;
-    const unsigned long long total = major_hom + major_het + minor_hom + minor_het;
-    unsigned long long* c = counts + g * 6;
-    if (major_hom) atomicAdd(c + 0, major_hom);
-    if (major_het) atomicAdd(c + 1, major_het);
-    if (minor_hom) atomicAdd(c + 2, minor_hom);
-    if (minor_het) atomicAdd(c + 3, minor_het);
-    if (total) atomicAdd(c + 4, total);
-    double* p = part + (seg * n_genomes + g) * kParts0;
-    p[0] = def_row[0] + cf_corr[j][0];
-    p[1] = def_row[1] + cf_corr[j][1];
-    p[2] = def_row[2] + cf_corr[j][2];
-    p[3] = def_row[3] + cf_corr[j][3];
-    if constexpr (RITLAND) {
-      const unsigned long long rit_cnt = acc2[j] & 0xFFFFu, miss_rit = acc2[j] >> 16;
-      const unsigned long long rit = n_rit - miss_rit + rit_cnt;
-      if (rit) atomicAdd(c + 5, rit);
-      // default sum, minus the defaults this genome does not take ((1/p_major - 1) each), plus its own terms
-      double r = def_row[4];
-      r -= s_miss[j];
-      r += static_cast<double>(miss_rit);
-      r += s_inv[j];
-      r -= static_cast<double>(rit_cnt);
-      p[4] = r;
-    } else {
-      p[4] = 0.0;
-    }
   }
 }
 
@@ -1129,9 +1003,30 @@ __device__ __forceinline__ SwarClasses swar_classify(uint32_t x, uint32_t lut_lo
   return c;
 }
 
+// The cells the byte algebra cannot settle, decided one by one by classify_cell: the (0, a) pair (two copies of one
+// variant on one phase) at a default locus, and every carrier of a non-default locus (no defaults to correct there).
+// Kept out of line: it runs for repeated records and near-monomorphic loci only, and inlining it sixteen times cost
+// the sweep a third of its registers.  Returns 0x01-per-byte masks: count one more minor heterozygote / take the
+// locus's class frequencies off / add them.
+struct SwarSpecial { uint32_t minor_het, minus, plus; };
+__device__ __noinline__ SwarSpecial swar_special_cells(uint32_t x, uint32_t special, uint32_t classed, int is_default,
+                                                       const double* __restrict__ row, uint32_t amax, int phased) {
+  SwarSpecial r{0u, 0u, 0u};
+  for (int j = 0; j < 4; ++j) {
+    if (!((special >> (8 * j)) & 1u)) continue;
+    double f1 = 0.0, f2 = 0.0;
+    const int cls = classify_cell((x >> (8 * j)) & 0xFFu, row, amax, phased != 0, f1, f2);
+    const uint32_t bit = 1u << (8 * j);
+    if (cls != kClassNone && !(classed & bit)) r.minor_het |= bit;
+    if (is_default) { if (cls == kClassNone) r.minus |= bit; }
+    else if (cls != kClassNone) r.plus |= bit;
+  }
+  return r;
+}
+
 // locus_index and meta are padded by 8 entries past n_sel (whole batches are fetched with one scalar load each);
 // loci_per_seg is a multiple of 8.
-template <bool INDEXED, bool RITLAND>
+template <bool INDEXED>
 __global__ void __launch_bounds__(kBlock)
 k_inbreed_sweep_swar(const uint32_t* __restrict__ gt, uint64_t dwords_per_row, uint64_t g0, uint64_t n_genomes,
                      const uint32_t* __restrict__ locus_index, uint64_t n_sel, uint64_t loci_per_seg,
@@ -1149,13 +1044,9 @@ k_inbreed_sweep_swar(const uint32_t* __restrict__ gt, uint64_t dwords_per_row, u
 
   uint32_t b_major_het = 0, b_minor_hom = 0, b_minor_het = 0, b_miss = 0;     // 4 x 8-bit lanes
   uint32_t n_major_het[4] = {0, 0, 0, 0}, n_minor_hom[4] = {0, 0, 0, 0}, n_minor_het[4] = {0, 0, 0, 0}, n_miss[4] = {0, 0, 0, 0};
-  uint32_t b_rit = 0, b_miss_rit = 0, n_rit[4] = {0, 0, 0, 0}, n_miss_rit[4] = {0, 0, 0, 0};   // RITLAND only
-  double cf_corr[4][4], s_inv[4], s_miss[4];
+  double cf_corr[4][4];
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    cf_corr[j][0] = cf_corr[j][1] = cf_corr[j][2] = cf_corr[j][3] = 0.0;
-    s_inv[j] = s_miss[j] = 0.0;
-  }
+  for (int j = 0; j < 4; ++j) cf_corr[j][0] = cf_corr[j][1] = cf_corr[j][2] = cf_corr[j][3] = 0.0;
   uint32_t since_flush = 0;
 
   auto flush = [&]() {
@@ -1165,12 +1056,8 @@ k_inbreed_sweep_swar(const uint32_t* __restrict__ gt, uint64_t dwords_per_row, u
       n_minor_hom[j] += (b_minor_hom >> (8 * j)) & 0xFFu;
       n_minor_het[j] += (b_minor_het >> (8 * j)) & 0xFFu;
       n_miss[j] += (b_miss >> (8 * j)) & 0xFFu;
-      if constexpr (RITLAND) {
-        n_rit[j] += (b_rit >> (8 * j)) & 0xFFu;
-        n_miss_rit[j] += (b_miss_rit >> (8 * j)) & 0xFFu;
-      }
     }
-    b_major_het = b_minor_hom = b_minor_het = b_miss = b_rit = b_miss_rit = 0;
+    b_major_het = b_minor_hom = b_minor_het = b_miss = 0;
     since_flush = 0;
   };
 
@@ -1188,7 +1075,7 @@ k_inbreed_sweep_swar(const uint32_t* __restrict__ gt, uint64_t dwords_per_row, u
       const uint64_t l = INDEXED ? static_cast<uint64_t>(idx[i]) : s;
       w[i] = (s < s_end) ? __builtin_nontemporal_load(gt + l * dwords_per_row + col) : 0u;
     }
-    if (since_flush + kBatch > 255) flush();
+    if (since_flush + kBatch > 255) flush();            // a locus adds at most 1 to a byte lane (the rare path included)
     since_flush += kBatch;
 #pragma unroll
     for (int i = 0; i < kBatch; ++i) {
@@ -1202,42 +1089,29 @@ k_inbreed_sweep_swar(const uint32_t* __restrict__ gt, uint64_t dwords_per_row, u
       const uint32_t lut_hi = ((in_list >> 4) & 1u) | (((in_list >> 5) & 1u) << 8) | (((in_list >> 6) & 1u) << 16);
       const bool is_default = (f & kLocusDefault) != 0;       // wave-uniform
       const SwarClasses c = swar_classify(w[i], lut_lo, lut_hi, same_lut);
-      const uint32_t lo = w[i] & 0x07070707u;
-      const uint32_t major_het = c.major_het, minor_hom = c.minor_hom, minor_het = c.minor_het;
-      b_major_het += major_het;
-      b_minor_hom += minor_hom;
-      b_minor_het += minor_het;
+      b_major_het += c.major_het;
+      b_minor_hom += c.minor_hom;
+      b_minor_het += c.minor_het;
       if (is_default) b_miss += c.nonzero;
-      if constexpr (RITLAND) {
-        // processRitlandLocus (_calc.cpp:390-423): a homozygous cell enters only if its allele frequency > 0.001
-        const uint32_t rit_bits = (m[i] >> 16) & 0xFFu;
-        const uint32_t rit_lo = ((rit_bits >> 0) & 1u) | (((rit_bits >> 1) & 1u) << 8) | (((rit_bits >> 2) & 1u) << 16) | (((rit_bits >> 3) & 1u) << 24);
-        const uint32_t rit_hi = ((rit_bits >> 4) & 1u) | (((rit_bits >> 5) & 1u) << 8) | (((rit_bits >> 6) & 1u) << 16);
-        const uint32_t hom_counts = minor_hom & __builtin_amdgcn_perm(rit_hi, rit_lo, lo);
-        const uint32_t miss_rit = (f & kLocusRitlandDefault) ? c.nonzero : 0u;
-        b_rit += hom_counts | major_het | minor_het;
-        b_miss_rit += miss_rit;
+      const uint32_t classed = c.major_het | c.minor_hom | c.minor_het;    // a subset of nonzero
+      // Cells the defaults do not cover: at a default locus the carriers the byte algebra left unclassified (their class
+      // frequencies come off), at any other locus every carrier.
+      const uint32_t rare = is_default ? (c.nonzero ^ classed) : c.nonzero;
+      if (rare) {
         const double* row = table + s * stride;
-        const double inv_major = row[2 * amax + kTableExtra];
-        double inv_alt[4];
-#pragma unroll
-        for (uint32_t a = 0; a < 4; ++a) inv_alt[a] = a < amax ? row[amax + kTableExtra + a] : 0.0;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          s_miss[j] += ((miss_rit >> (8 * j)) & 1u) ? inv_major : 0.0;
-          const uint32_t a1 = (lo >> (8 * j)) & 0xFu;
-          double inv = a1 == 1 ? inv_alt[0] : (a1 == 2 ? inv_alt[1] : (a1 == 3 ? inv_alt[2] : inv_alt[3]));
-          s_inv[j] += ((hom_counts >> (8 * j)) & 1u) ? inv : 0.0;
+        // the (0, a) pairs among them, and all of a non-default locus, are decided by classify_cell
+        const uint32_t special = is_default ? (rare & (bytes_nonzero(w[i] & 0x0F0F0F0Fu) ^ 0x01010101u)) : rare;
+        uint32_t minus = is_default ? (rare ^ special) : 0u, plus = 0u;
+        if (special) {
+          const SwarSpecial sp = swar_special_cells(w[i], special, classed, is_default ? 1 : 0, row, amax, phased);
+          b_minor_het += sp.minor_het;
+          minus |= sp.minus;
+          plus |= sp.plus;
         }
-      }
-      const uint32_t classed = major_het | minor_hom | minor_het;          // a subset of nonzero
-      const uint32_t rare = is_default ? (c.nonzero ^ classed) : classed;
-      if (rare) {     // classification disagrees with the locus default: adjust the class-frequency sums
-        const double* row = table + s * stride;
-        const double sign = is_default ? -1.0 : 1.0;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          if (!((rare >> (8 * j)) & 1u)) continue;
+          const double sign = ((plus >> (8 * j)) & 1u) ? 1.0 : (((minus >> (8 * j)) & 1u) ? -1.0 : 0.0);
+          if (sign == 0.0) continue;
           cf_corr[j][0] += sign * row[amax + 1]; cf_corr[j][1] += sign * row[amax + 2];
           cf_corr[j][2] += sign * row[amax + 3]; cf_corr[j][3] += sign * row[amax + 4];
         }
@@ -1265,19 +1139,7 @@ k_inbreed_sweep_swar(const uint32_t* __restrict__ gt, uint64_t dwords_per_row, u
     p[1] = def_row[1] + cf_corr[j][1];
     p[2] = def_row[2] + cf_corr[j][2];
     p[3] = def_row[3] + cf_corr[j][3];
-    if constexpr (RITLAND) {
-      const unsigned long long rit = static_cast<unsigned long long>(def_row[6]) - n_miss_rit[j] + n_rit[j];
-      if (rit) atomicAdd(c + 5, rit);
-      // default Ritland sum, minus the (1/p_major - 1) defaults this genome does not take, plus its own terms
-      double r = def_row[4];
-      r -= s_miss[j];
-      r += static_cast<double>(n_miss_rit[j]);
-      r += s_inv[j];
-      r -= static_cast<double>(n_rit[j]);
-      p[4] = r;
-    } else {
-      p[4] = 0.0;
-    }
+    p[4] = 0.0;                       // RitlandLocus' terms come from k_inbreed_eval_lut<3>
   }
 }
 
@@ -1288,7 +1150,7 @@ k_inbreed_sweep_swar(const uint32_t* __restrict__ gt, uint64_t dwords_per_row, u
 // so the result is deterministic — which keeps fp64 out of the register file.  part[] must be pre-filled with the
 // segment defaults (k_fill_defaults).
 template <bool INDEXED>
-__global__ void __launch_bounds__(kBlock)
+__global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(3)))      // three waves per SIMD: <= 170 VGPRs
 k_inbreed_sweep_swar16(const kgx_v4u* __restrict__ gt, uint64_t chunks_per_row, uint64_t g0, uint64_t n_genomes,
                        const uint32_t* __restrict__ locus_index, uint64_t n_sel, uint64_t loci_per_seg,
                        const double* __restrict__ table, const uint32_t* __restrict__ meta, uint32_t amax, int phased,
@@ -1353,7 +1215,7 @@ k_inbreed_sweep_swar16(const kgx_v4u* __restrict__ gt, uint64_t chunks_per_row, 
       const uint32_t lut_lo = ((in_list >> 0) & 1u) | (((in_list >> 1) & 1u) << 8) | (((in_list >> 2) & 1u) << 16) | (((in_list >> 3) & 1u) << 24);
       const uint32_t lut_hi = ((in_list >> 4) & 1u) | (((in_list >> 5) & 1u) << 8) | (((in_list >> 6) & 1u) << 16);
       const bool is_default = (f & kLocusDefault) != 0;       // wave-uniform
-      uint32_t rare[4];
+      uint32_t rare[4], classed[4];
       uint32_t rare_any = 0;
 #pragma unroll
       for (int d = 0; d < 4; ++d) {
@@ -1361,24 +1223,35 @@ k_inbreed_sweep_swar16(const kgx_v4u* __restrict__ gt, uint64_t chunks_per_row, 
         b_mhet[d] += c.major_het;
         b_mhom[d] += c.minor_hom;
         b_nhet[d] += c.minor_het;
-        const uint32_t classed = c.major_het | c.minor_hom | c.minor_het;        // a subset of nonzero
+        classed[d] = c.major_het | c.minor_hom | c.minor_het;                     // a subset of nonzero
+        // cells the defaults do not cover: at a default locus the carriers the byte algebra left unclassified, at any
+        // other locus every carrier
         if (is_default) {
           b_miss[d] += c.nonzero;
-          rare[d] = c.nonzero ^ classed;
+          rare[d] = c.nonzero ^ classed[d];
         } else {
-          rare[d] = classed;
+          rare[d] = c.nonzero;
         }
         rare_any |= rare[d];
       }
       if (rare_any) {
         const double* row = table + s * stride;
-        const double sign = is_default ? -1.0 : 1.0;
 #pragma unroll
         for (int d = 0; d < 4; ++d) {
           if (!rare[d]) continue;
+          // the (0, a) pairs among them, and all of a non-default locus, are decided by classify_cell
+          const uint32_t special = is_default ? (rare[d] & (bytes_nonzero(w[i][d] & 0x0F0F0F0Fu) ^ 0x01010101u)) : rare[d];
+          uint32_t minus = is_default ? (rare[d] ^ special) : 0u, plus = 0u;
+          if (special) {
+            const SwarSpecial sp = swar_special_cells(w[i][d], special, classed[d], is_default ? 1 : 0, row, amax, phased);
+            b_nhet[d] += sp.minor_het;
+            minus |= sp.minus;
+            plus |= sp.plus;
+          }
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
-            if (!((rare[d] >> (8 * j)) & 1u)) continue;
+            const double sign = ((plus >> (8 * j)) & 1u) ? 1.0 : (((minus >> (8 * j)) & 1u) ? -1.0 : 0.0);
+            if (sign == 0.0) continue;
             const uint64_t g = lane16 * 16 + d * 4 + j;
             if (g >= n_genomes) continue;
             double* p = part + (seg * n_genomes + g) * kParts0;     // single writer: this lane

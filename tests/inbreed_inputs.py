@@ -119,5 +119,8 @@ def encode_gt8(rec, gt, loci: ReferenceLoci, phased_order=True):
             else:
                 a1 = c[0][3]
                 a2 = c[1][3] if len(c) == 2 else 0
-                out[l, g] = a1 | (a2 << 4)
+                if phased_order and len(c) == 2 and a1 == a2 and a1 != 15 and c[0][2] == c[1][2]:
+                    out[l, g] = a1 << 4          # two copies on ONE phase (a repeated record): the (0, a) byte
+                else:
+                    out[l, g] = a1 | (a2 << 4)
     return out

@@ -20,7 +20,7 @@ F_BAND = 2e-4
 
 
 def build(G, L, mode, seed):
-    rec, gt = sv.multiallelic_block(G, L, rng_seed=seed, missing_af_frac=0.03, dup_records=3)
+    rec, gt = sv.multiallelic_block(G, L, rng_seed=seed, missing_af_frac=0.03, dup_records=60)   # repeated records: same-phase pairs, >= 3 variants
     ids = sv.genome_ids(G)
     ref = oa.Population("gnomad")
     ref.add_genomes(["Reference"])
@@ -53,8 +53,18 @@ def test_class_frequency_table_is_bit_exact(kgx):
 
 
 @pytest.mark.parametrize("mode", [oa.Population.PHASED, oa.Population.UNPHASED])
-@pytest.mark.parametrize("algorithm", ["Simple", "RitlandLocus", "HallME", "Loglikelihood"])
-def test_inbreed_window_vs_oracle(kgx, mode, algorithm):
+@pytest.mark.parametrize("algorithm,path", [("Simple", "default"), ("RitlandLocus", "default"), ("HallME", "default"), ("Loglikelihood", "default"),
+                                            ("HallME", "passes"), ("Loglikelihood", "passes"), ("Loglikelihood", "golden"),
+                                            ("Simple", "generic"), ("RitlandLocus", "generic"), ("HallME", "generic"), ("Loglikelihood", "generic"),
+                                            ("Simple", "swar4"), ("RitlandLocus", "no-table")])
+def test_inbreed_window_vs_oracle(kgx, mode, algorithm, path, monkeypatch):
+    # every kernel flavour against the same oracle window: the window-sized fused iteration (default), the multi-kernel
+    # table passes, plain golden section, the generic per-cell kernels, the 4-genomes-per-lane SWAR sweep
+    env = {"passes": {"KGX_K7_NO_WAVE": "1"}, "golden": {"KGX_K7_NO_WAVE": "1", "KGX_K7_GOLDEN": "1"},
+           "generic": {"KGX_K5_GENERIC": "1", "KGX_K7_NO_WAVE": "1"}, "swar4": {"KGX_K5_NO_SWAR16": "1"},
+           "no-table": {"KGX_K5_NO_EVAL_LUT": "1"}}.get(path, {})
+    for key, value in env.items():
+        monkeypatch.setenv(key, value)
     G, L = 101, 1200
     rec, gt, ids, ref, dip = build(G, L, mode, seed=5)
     loci = ii.ReferenceLoci(rec)
@@ -234,8 +244,9 @@ def test_synth_inbred_draws_follow_class_frequencies(kgx):
 @pytest.mark.parametrize("amax", [3, 6])
 def test_inbreed_survives_bytes_no_flattener_writes(kgx, algorithm, amax):
     """Every one of the 256 byte values, valid or not, in every genome column: bytes the layout does not define
-    (second variant without a first, indices past the table) must be skipped by every sweep flavour, never read
-    through.  Checked against a numpy restatement of generateFrequencies' class decision."""
+    (indices past the table, unknown alts) must be skipped by every sweep flavour, never read through, and the (0, a)
+    byte counts as the same-phase pair it stands for.  Checked against a numpy restatement of generateFrequencies'
+    class decision."""
     L, G = 512, 64
     rng = np.random.default_rng(amax)
     table = np.full((L, amax), np.nan)
@@ -259,7 +270,8 @@ def test_inbreed_survives_bytes_no_flattener_writes(kgx, algorithm, amax):
     major_hom = rows == 0
     major_het = ~bad & in1 & (a2 == 0)
     minor_hom = ~bad & in1 & (a2 != 0) & (a1 == a2)
-    minor_het = ~bad & in1 & (a2 != 0) & (a1 != a2) & in2
+    # (0, a): two copies of alt a on one phase -> a minor heterozygote with that allele twice
+    minor_het = (~bad & in1 & (a2 != 0) & (a1 != a2) & in2) | (~bad & (a1 == 0) & in2)
     assert np.array_equal(res["major_homo_count"], major_hom.sum(axis=0).astype(np.uint64))
     assert np.array_equal(res["major_hetero_count"], major_het.sum(axis=0).astype(np.uint64))
     assert np.array_equal(res["minor_homo_count"], minor_hom.sum(axis=0).astype(np.uint64))

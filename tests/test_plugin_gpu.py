@@ -69,7 +69,7 @@ def test_gpu_allele_package_disables_itself_on_bad_device(tmp_path, kgx):
 def test_gpu_inbreed_package_matches_oracle_window_loop(tmp_path, kgx, algorithm, mode, source):
     """GPU_INBREED through the VirtualAnalysis surface vs the oracle's populationInbreeding window loop."""
     G, L = 67, 2000
-    rec, gt = sv.multiallelic_block(G, L, rng_seed=31, missing_af_frac=0.03, dup_records=0)
+    rec, gt = sv.multiallelic_block(G, L, rng_seed=31, missing_af_frac=0.03, dup_records=50)
     for a in rec.af:                       # Gnomad 2.1 reads SAS from the same "AF" field as ALL (kgl_variant_db_freq.h:92)
         a[:, 4] = a[:, 5]
     ids = sv.genome_ids(G, prefix="NA")
@@ -241,7 +241,7 @@ def test_gpu_inbreed_package_reads_vcf_directly(tmp_path, kgx, algorithm):
     from . import vcf_text as vt
 
     G, L = 53, 1800
-    rec, gt = sv.multiallelic_block(G, L, rng_seed=17, missing_af_frac=0.03, dup_records=0)
+    rec, gt = sv.multiallelic_block(G, L, rng_seed=17, missing_af_frac=0.03, dup_records=50)
     for a in rec.af:
         a[:, 4] = a[:, 5]                   # Gnomad 2.1 reads SAS from the same "AF" field as ALL
     ids = sv.genome_ids(G, prefix="HG")
