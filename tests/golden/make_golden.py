@@ -34,7 +34,7 @@ def allele_case():
 
 def inbreed_case():
     G, L = 40, 700
-    rec, gt = sv.multiallelic_block(G, L, rng_seed=3, missing_af_frac=0.03, dup_records=0)   # duplicate records can put two same-phase copies of one variant in a genome, which the gt8 encoding rejects
+    rec, gt = sv.multiallelic_block(G, L, rng_seed=3, missing_af_frac=0.03, dup_records=25)   # repeated records: same-phase pairs ((0, a) bytes) and >= 3 variants (0xFF)
     ids = sv.genome_ids(G)
     ref = oa.Population("gnomad")
     ref.add_genomes(["Reference"])
