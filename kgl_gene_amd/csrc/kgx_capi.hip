@@ -941,10 +941,10 @@ int kgx_inbreed(kgx_gt8* h, uint64_t g0, uint64_t g1, const uint32_t* locus_inde
       try_hip(hipMemsetAsync(d_running, 0, sizeof(unsigned int), st), KGX_EHIP, "memset(evaluations)");
       if (algorithm == 2)
         hipLaunchKernelGGL((k_inbreed_iterate_wave<1>), dim3(wave_grid), dim3(kBlock), 0, st, h->d_gt, h->pitch, g0, n, d_index, n_sel, d_table, d_valid,
-                           amax, phased, d_counts, d_f, d_running);
+                           amax, phased, d_counts, d_sums, d_f, d_running);
       else
         hipLaunchKernelGGL((k_inbreed_iterate_wave<2>), dim3(wave_grid), dim3(kBlock), 0, st, h->d_gt, h->pitch, g0, n, d_index, n_sel, d_table, d_valid,
-                           amax, phased, d_counts, d_f, d_running);
+                           amax, phased, d_counts, env_int("KGX_K7_ESTIMATE_START", 0) ? d_sums : nullptr, d_f, d_running);
       if (algorithm == 3) {
         unsigned int evaluations = 0;
         try_hip(hipMemcpyAsync(&evaluations, d_running, sizeof(unsigned int), hipMemcpyDeviceToHost, st), KGX_EHIP, "D2H(evaluations)");
@@ -971,15 +971,11 @@ int kgx_inbreed(kgx_gt8* h, uint64_t g0, uint64_t g1, const uint32_t* locus_inde
       // (un-vendored, unpinned), to within 5e-7 in F where the reference stops at an absolute change of 1e-6.  KGX_K7_GOLDEN=1 runs the
       // plain golden-section search instead (38 evaluations, bracket 6e-8).
       if (!env_int("KGX_K7_GOLDEN", 0)) {
-        BrentState init{};
-        init.a = -1.0; init.b = 1.0;
-        init.x = init.w = init.v = init.a + 0.3819660112501051 * (init.b - init.a);
-        init.u = init.x;
-        std::vector<BrentState> bs(n, init);
-        std::vector<double> f0(n, init.x);
-        try_hip(hipMemcpyAsync(d_brent, bs.data(), n * sizeof(BrentState), hipMemcpyHostToDevice, st), KGX_EHIP, "H2D(brent)");
-        try_hip(hipMemcpyAsync(d_f, f0.data(), n * sizeof(double), hipMemcpyHostToDevice, st), KGX_EHIP, "H2D(f0)");
-        try_hip(hipStreamSynchronize(st), KGX_EHIP, "sync");
+        // Start: [-1, 1] from its golden point.  KGX_K7_ESTIMATE_START=1 starts in a window around the Simple estimate
+        // instead (brent_start): 11 instead of 15 evaluations on a population with F in [0, 0.1], but where the clamped
+        // objective has several local maxima (F < 0) it may settle on another one than a search from the middle does --
+        // the reference itself lands on one or another from its random starts -- so it is not the default.
+        hipLaunchKernelGGL(k_brent_init, dim3(lin_grid), dim3(kBlock), 0, st, d_counts, d_sums, n, env_int("KGX_K7_ESTIMATE_START", 0), d_brent, d_f);
         constexpr int kMaxEvaluations = 60;        // golden section alone would need 38; Brent's safeguard keeps that bound
         for (int it = 0; it < kMaxEvaluations && rc == KGX_OK; ++it) {
           sweep(2);

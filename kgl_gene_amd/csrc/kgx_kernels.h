@@ -1363,7 +1363,7 @@ k_golden_step(GoldenState* __restrict__ st, const double* __restrict__ f_eval, u
 // genome, one objective evaluation (= one sweep over the genotype bytes) per step for every genome that has not
 // converged.  mode 0: f_eval is the value at the start point; 1: at the point proposed last; 2: no evaluation,
 // just publish the best point.  still_running counts the genomes that proposed a new point.
-struct BrentState { double a, b, x, w, v, fx, fw, fv, d, e, u; int done; int pad; };
+struct BrentState { double a, b, x, w, v, fx, fw, fv, d, e, u, a0, b0; int done; int widened; };
 
 // One step of the search: take the objective value fu (= -loglikelihood) at the point proposed last (first: at the
 // start point), update the bracket and the three best points, and either finish (s.done) or propose the next point s.u.
@@ -1386,11 +1386,21 @@ __device__ __forceinline__ void brent_advance(BrentState& s, double fu, bool fir
       else if (fu <= s.fv || s.v == s.x || s.v == s.w) { s.v = u; s.fv = fu; }
     }
   }
-  const double xm = 0.5 * (s.a + s.b);
+  double xm = 0.5 * (s.a + s.b);
   const double tol1 = kTol * fabs(s.x) + kZeps, tol2 = 2.0 * tol1;
   if (fabs(s.x - xm) <= (tol2 - 0.5 * (s.b - s.a))) {
-    s.done = 1;
-    return;
+    // Converged inside the bracket.  The search starts in a window around the Simple estimate (brent_start); a best point
+    // sitting on an edge of that window means the maximum lies beyond it: open the bracket to [-1, 1] once and go on
+    // (the best points kept so far stay valid).
+    const bool on_edge = (s.a0 > -1.0 && s.x - s.a0 < 1.0e-5) || (s.b0 < 1.0 && s.b0 - s.x < 1.0e-5);
+    if (!on_edge || s.widened) {
+      s.done = 1;
+      return;
+    }
+    s.widened = 1;
+    s.a = -1.0; s.b = 1.0; s.a0 = -1.0; s.b0 = 1.0;
+    s.e = 0.0;
+    xm = 0.0;
   }
   bool golden = true;
   if (fabs(s.e) > tol1) {
@@ -1416,12 +1426,37 @@ __device__ __forceinline__ void brent_advance(BrentState& s, double fu, bool fir
   s.u = fabs(s.d) >= tol1 ? s.x + s.d : s.x + copysign(tol1, s.d);
 }
 
-__device__ __forceinline__ BrentState brent_start() {
+// Start of the search for one genome: a +-0.25 window around the Simple estimate (obsHom - expHom) / (N - expHom)
+// (processSimple, _calc.cpp:318-365; counts and class-frequency sums of the frequency sweep), which is within a few
+// hundredths of the likelihood maximum on any real population; brent_advance opens the window to [-1, 1] if the
+// maximum turns out to lie outside.  No usable estimate (no loci): the whole interval from its golden point.
+__device__ __forceinline__ BrentState brent_start(const unsigned long long* __restrict__ counts, const double* __restrict__ sums) {
   BrentState s{};
-  s.a = -1.0; s.b = 1.0;
-  s.x = s.w = s.v = s.a + 0.3819660112501051 * (s.b - s.a);
-  s.u = s.x;
+  s.a = s.a0 = -1.0; s.b = s.b0 = 1.0;
+  s.x = s.a + 0.3819660112501051 * (s.b - s.a);
+  if (counts && sums) {
+    const double observed = static_cast<double>(counts[0] + counts[2]), expected = sums[0] + sums[2];
+    const double simple = (observed - expected) / (static_cast<double>(counts[4]) - expected);
+    if (simple == simple && fabs(simple) <= 2.0) {
+      const double x0 = simple < -0.9 ? -0.9 : (simple > 0.9 ? 0.9 : simple);
+      s.a = s.a0 = x0 - 0.25 < -1.0 ? -1.0 : x0 - 0.25;
+      s.b = s.b0 = x0 + 0.25 > 1.0 ? 1.0 : x0 + 0.25;
+      s.x = x0;
+    }
+  }
+  s.w = s.v = s.u = s.x;
   return s;
+}
+
+__global__ void __launch_bounds__(kBlock)
+k_brent_init(const unsigned long long* __restrict__ counts, const double* __restrict__ sums, uint64_t n, int use_estimate,
+             BrentState* __restrict__ st, double* __restrict__ f_next) {
+  for (uint64_t g = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x; g < n;
+       g += static_cast<uint64_t>(gridDim.x) * blockDim.x) {
+    const BrentState s = use_estimate ? brent_start(counts + g * 6, sums + g * kParts0) : brent_start(nullptr, nullptr);
+    st[g] = s;
+    f_next[g] = s.x;
+  }
 }
 
 __global__ void __launch_bounds__(kBlock)
@@ -1459,7 +1494,7 @@ __global__ void __launch_bounds__(kBlock)
 k_inbreed_iterate_wave(const uint8_t* __restrict__ gt, uint64_t pitch, uint64_t g0, uint64_t n_genomes,
                        const uint32_t* __restrict__ locus_index, uint64_t n_sel, const double* __restrict__ table,
                        const uint8_t* __restrict__ valid, uint32_t amax, int phased, const unsigned long long* __restrict__ counts,
-                       double* __restrict__ f_out, unsigned int* __restrict__ max_evaluations) {
+                       const double* __restrict__ sums, double* __restrict__ f_out, unsigned int* __restrict__ max_evaluations) {
   const uint64_t g = (static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x) / kWave;
   const uint32_t lane = threadIdx.x & (kWave - 1);
   if (g >= n_genomes) return;                                 // whole waves only
@@ -1497,7 +1532,7 @@ k_inbreed_iterate_wave(const uint8_t* __restrict__ gt, uint64_t pitch, uint64_t 
     }
     if (lane == 0) f_out[g] = F;
   } else {
-    BrentState s = brent_start();
+    BrentState s = sums ? brent_start(counts + g * 6, sums + g * kParts0) : brent_start(nullptr, nullptr);
     unsigned int evaluations = 0;
     for (int it = 0; it < 60; ++it) {
       const double F = it == 0 ? s.x : s.u;
