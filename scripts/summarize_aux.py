@@ -62,5 +62,19 @@ Per call, in launch order (3 x all rows in one bin, then 2 x 11 FWS bins): {", "
 {k5_txt.strip()}
 ```
 """
+# optional: HBM fetch traffic of the K5 kernels (scripts/pmc_k5.sh "FETCH_SIZE" fetch), corrected as the K2 profile is
+pmc = glob.glob(str(ROOT / "gpurun_out" / "pmc_k5_fetch" / "*" / "*counter_collection.csv"))
+if pmc:
+    import collections
+    agg = collections.defaultdict(list)
+    for r in csv.DictReader(open(pmc[0])):
+        if r["Counter_Name"] == "FETCH_SIZE" and "k_inbreed" in r["Kernel_Name"] and "finish" not in r["Kernel_Name"]:
+            agg[short(r["Kernel_Name"])].append(float(r["Counter_Value"]))
+    (dst / f"{tag}_k5_pmc.csv").write_text("kernel,launches,fetch_size_kib_avg\n" + "".join(f"{k},{len(v)},{sum(v) / len(v)}\n" for k, v in agg.items()))
+    md += "\n## K5 HBM read traffic (separate `rocprofv3 --pmc FETCH_SIZE` pass; read = 2 x FETCH_SIZE x 1024, the gfx950 wide-stream correction)\n\n"
+    md += "| kernel | launches | HBM read per launch | x algorithmic |\n|---|---|---|---|\n"
+    for k, v in agg.items():
+        read = 2.0 * 1024.0 * sum(v) / len(v)
+        md += f"| `{k}` | {len(v)} | {read / 1e9:.2f} GB | {read / k5_bytes:.3f} |\n"
 (dst / f"{tag}_aux_summary.md").write_text(md)
 print(md)
