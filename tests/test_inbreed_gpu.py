@@ -277,3 +277,72 @@ def test_inbreed_survives_bytes_no_flattener_writes(kgx, algorithm, amax):
     assert np.array_equal(res["minor_homo_count"], minor_hom.sum(axis=0).astype(np.uint64))
     assert np.array_equal(res["minor_hetero_count"], minor_het.sum(axis=0).astype(np.uint64))
     assert np.all(np.isfinite(res["inbred_allele_sum"]))
+
+
+def test_kernel_flavours_agree_on_random_shapes(kgx, monkeypatch):
+    """Differential fuzz: random shapes (genome counts off every lane width, sub-ranges, indexed and dense loci, 1..14
+    alleles, every byte value incl. the (0, a) pair, 0xFF and unknown alts, loci without defaults, missing AFs) through
+    every kernel flavour -- the generic per-cell kernels are the ones pinned to the oracle above; the SWAR sweeps, the
+    table passes and the fused wave iteration must reproduce them."""
+    rng = np.random.default_rng(2024)
+    flavours = {"default": {}, "generic": {"KGX_K5_GENERIC": "1", "KGX_K7_NO_WAVE": "1"}, "passes": {"KGX_K7_NO_WAVE": "1"},
+                "swar4": {"KGX_K5_NO_SWAR16": "1"}}
+    knobs = sorted({k for env in flavours.values() for k in env})
+    for trial in range(150):
+        G = int(rng.choice([1, 3, 4, 5, 15, 16, 17, 63, 64, 65, 100, 257, 1000]))
+        L = int(rng.choice([1, 7, 8, 9, 63, 64, 65, 500, 3000]))
+        amax = int(rng.choice([1, 2, 3, 4, 5, 7, 8, 14]))
+        phased = bool(rng.integers(0, 2))
+        table = np.full((L, amax), np.nan)
+        n_alt = rng.integers(1, amax + 1, L)
+        for l in range(L):
+            f = rng.uniform(0.001, 0.6 / n_alt[l], n_alt[l])
+            if rng.random() < 0.03:
+                f *= 4.0                                     # sums past 1: invalid / rescaled loci
+            if rng.random() < 0.02:
+                f[:] = 0.999 / n_alt[l]                      # p_major <= 0.01: a locus without defaults
+            table[l, :n_alt[l]] = f
+            if rng.random() < 0.05:
+                table[l, rng.integers(0, n_alt[l])] = np.nan  # an alt without AF
+        values = np.array([0] * 12 + [1, 1, 1, 2, 3, 0x11, 0x21, 0x12, 0x22, 0x10, 0x20, 0x1F, 0xF1, 0xFF, 0x31, 0x4, 0x44, 0x80, 0x08, 0xE1],
+                          dtype=np.uint8)
+        rows = rng.choice(values, size=(L, G))
+        if rng.random() < 0.3:
+            rows = rng.integers(0, 256, size=(L, G), dtype=np.uint8)
+        m = kgx.GenotypeMatrix(G, L)
+        m.load_rows(rows)
+        g0 = int(rng.choice([0, 4, 16])) if G > 20 else 0
+        g1 = int(rng.integers(g0 + 1, G + 1))
+        index = None
+        sub = table
+        if L > 8 and rng.random() < 0.5:
+            index = np.sort(rng.choice(L, int(rng.integers(1, L)), replace=False)).astype(np.uint32)
+            sub = np.ascontiguousarray(table[index])
+        for algorithm, tol in (("Simple", 1e-9), ("RitlandLocus", 1e-9), ("HallME", 1e-8), ("Loglikelihood", 2e-5)):
+            results = {}
+            for name, env in flavours.items():
+                for k in knobs:
+                    monkeypatch.delenv(k, raising=False)
+                for k, v in env.items():
+                    monkeypatch.setenv(k, v)
+                results[name] = m.inbreed(sub, algorithm, phased=phased, locus_index=index, g0=g0, g1=g1)
+            ref = results["generic"]
+            for name, got in results.items():
+                ctx = (trial, G, L, amax, phased, algorithm, name, g0, g1, None if index is None else len(index))
+                for field in ("major_hetero_count", "minor_hetero_count", "minor_homo_count", "major_homo_count", "total_allele_count"):
+                    assert np.array_equal(got[field], ref[field]), ctx + (field,)
+                for field in ("major_hetero_freq", "minor_hetero_freq", "minor_homo_freq", "major_homo_freq"):
+                    assert np.allclose(got[field], ref[field], rtol=1e-11, atol=1e-11), ctx + (field,)
+                a, b = got["inbred_allele_sum"], ref["inbred_allele_sum"]
+                both = np.isfinite(a) & np.isfinite(b)
+                # finiteness may differ only at a 0/0: Simple's denominator N - expected homozygotes, Ritland's / Hall's
+                # zero counts -- where the last bit of a sum decides between nan and a number
+                odd = np.isfinite(a) != np.isfinite(b)
+                if odd.any():
+                    n = ref["total_allele_count"][odd].astype(np.float64)
+                    het = (ref["major_hetero_freq"] + ref["minor_hetero_freq"])[odd]
+                    assert algorithm == "Simple" and np.all(np.abs(het) <= 1e-9 * np.maximum(n, 1.0)), ctx
+                if algorithm == "Loglikelihood":
+                    continue        # several local maxima on adversarial bytes: compared on realistic data above
+                assert np.all(np.abs(a[both] - b[both]) <= tol * np.maximum(1.0, np.abs(b[both]))), ctx
+        m.close()
