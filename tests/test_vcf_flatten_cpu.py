@@ -259,3 +259,41 @@ def test_fws_bins_with_disagreeing_repeats_match_oracle(flavour):
     _, genome_out, vdb = o.fws()
     assert flat.hgvs == [vdb.hgvs(i) for i in range(vdb.n_variants)]
     assert np.array_equal(ha.fws_genome_bins(flat), genome_out)
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_flatteners_vs_oracle_over_seeds(seed):
+    """More draws of both VCF flavours (token quirks on, repeated records with their own AF, duplicate sample names)
+    through the product's flatteners and the oracle's parsers: same genomes, variants, dosages, FWS bins."""
+    rng = np.random.default_rng(1000 + seed)
+    # 1000-Genomes flavour
+    G, L = int(rng.integers(3, 40)), int(rng.integers(50, 600))
+    rec, gt = sv.multiallelic_block(G, L, rng_seed=200 + seed, dup_records=int(rng.integers(0, 30)))
+    for a in rec.af:
+        a[:, 5] = rng.uniform(0, 0.6, a.shape[0]).astype(np.float32)
+    ids = [f"NA{i:05d}" for i in rng.permutation(G)]
+    if G > 4:
+        ids[1] = ids[0]                                         # one genome named twice: its columns add up
+    text = vt.write_vcf_1000(rec, gt, ids, rng_seed=seed, quirks=True)
+    o = oa.Population("kg")
+    o.add_vcf_1000(text)
+    flat = ha.FlatVcf(text, 1 + seed % 4)
+    _, genome_out, vdb = o.fws()
+    assert flat.genome_ids == [vdb.genome_id(i) for i in range(vdb.n_genomes)]
+    assert flat.hgvs == [vdb.hgvs(i) for i in range(vdb.n_variants)]
+    assert np.array_equal(capi.unpack_dosage2(flat.packed, flat.G), np.minimum(vdb.dosage().T, 3))
+    assert np.array_equal(ha.fws_genome_bins(flat), genome_out)
+    # P. falciparum flavour, with and without the record filter
+    ids = [f"PF{i:04d}-C" for i in rng.permutation(int(rng.integers(2, 30)))]
+    text = vt.write_vcf_pf(int(rng.integers(100, 1200)), ids, rng_seed=300 + seed, same_af_for_repeats=bool(seed % 2))
+    for quality_filter in (False, True):
+        o = oa.Population("pf")
+        o.add_vcf_pf(text)
+        if quality_filter:
+            o = o.filter_p7()
+        flat = ha.FlatVcf(text, 1 + seed % 3, flavour="Falciparum", quality_filter=quality_filter)
+        _, genome_out, vdb = o.fws()
+        assert flat.genome_ids == [vdb.genome_id(i) for i in range(vdb.n_genomes)]
+        assert flat.hgvs == [vdb.hgvs(i) for i in range(vdb.n_variants)]
+        assert np.array_equal(capi.unpack_dosage2(flat.packed, flat.G), np.minimum(vdb.dosage().T, 3))
+        assert np.array_equal(ha.fws_genome_bins(flat), genome_out)
