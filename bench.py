@@ -171,6 +171,9 @@ def main():
     dev = torch.device("cuda", device_index)
     if n_gpus > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        # the exchange of batch i runs beside the sweep of batch i+1: give RCCL's stream priority so that its few workgroups
+        # are placed as soon as the sweep's (many, short) workgroups free slots
+        os.environ.setdefault("TORCH_NCCL_HIGH_PRIORITY", "1")
         if rehearsal:
             dist.init_process_group(backend="gloo")
         else:
