@@ -72,6 +72,7 @@ _SIGNATURES = {
     "kgx_locus_class_frequencies": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint32, C.c_double, C.c_void_p, C.c_void_p]),
     "kgx_inbreed": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint32, C.c_int,
                               C.c_int, C.c_void_p]),
+    "kgx_release_scratch": (C.c_int, []),
     "kgx_inbreed_last_sweep_ms": (C.c_double, []),
     "kgx_inbreed_last_evaluations": (C.c_int, []),
     "kgx_gt8_synth_multiallelic": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64, C.c_void_p]),
@@ -389,6 +390,11 @@ class GenotypeMatrix:
         check(lib().kgx_inbreed(self._h, g0, g1, None if idx is None else ptr(idx), n_sel, ptr(a), amax, int(bool(phased)),
                                 ALGORITHMS[algorithm], ptr(out)))
         return out
+
+
+def release_scratch() -> None:
+    """Free the arena kgx_inbreed keeps its per-call device buffers in."""
+    check(lib().kgx_release_scratch())
 
 
 def inbreed_last_sweep_ms() -> float:

@@ -579,6 +579,7 @@ bool kga::GpuInbreedAnalysis::syntheticInbreeding(GpuParamOutput& param_output) 
 
 bool kga::GpuInbreedAnalysis::finalizeAnalysis() {
   ExecEnv::log().info("Finalize called for Analysis Id: {}", ident());
+  (void)kgx_release_scratch();            // the sweep's arena is not needed past the last iteration
   return writeResults();
 }
 

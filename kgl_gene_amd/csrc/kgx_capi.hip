@@ -1031,6 +1031,16 @@ int kgx_inbreed(kgx_gt8* h, uint64_t g0, uint64_t g1, const uint32_t* locus_inde
   return rc;
 }
 
+int kgx_release_scratch(void) {
+  if (g_state.scratch) {
+    if (g_state.stream) (void)hipStreamSynchronize(g_state.stream);
+    (void)hipFree(g_state.scratch);
+  }
+  g_state.scratch = nullptr;
+  g_state.scratch_bytes = 0;
+  return KGX_OK;
+}
+
 double kgx_inbreed_last_sweep_ms(void) { return g_state.last_sweep_ms; }
 int kgx_inbreed_last_evaluations(void) { return g_state.last_evaluations; }
 
