@@ -203,7 +203,8 @@ int kgx_inbreed(kgx_gt8* gt, uint64_t g0, uint64_t g1, const uint32_t* locus_ind
  * pass over the genotype bytes that every estimator makes -- of the most recent successful kgx_inbreed call on this
  * process; 0 before the first.  For bench.py / profiles: algorithmic bytes = kgx_gt8_sweep_bytes(). */
 /* kgx_inbreed keeps its per-call device buffers in one grow-only arena between calls (a window loop calls it
- * thousands of times); this frees the arena (it is re-created on the next call). */
+ * thousands of times), and a large Loglikelihood call two more buffers holding the genotype columns of the genomes
+ * still searching (at most ~3/4 of the swept bytes together); this frees them (they are re-created when needed). */
 int kgx_release_scratch(void);
 double kgx_inbreed_last_sweep_ms(void);
 /* Objective evaluations (= passes over the genotype bytes) the most recent KGX_ALGO_LOGLIKELIHOOD call needed. */

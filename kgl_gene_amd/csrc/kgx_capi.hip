@@ -255,6 +255,11 @@ int kgx_init(int device) {
     if (g_state.scratch) (void)hipFree(g_state.scratch);
     g_state.scratch = nullptr;
     g_state.scratch_bytes = 0;
+    for (int k = 0; k < 2; ++k) {
+      if (g_state.compact[k]) (void)hipFree(g_state.compact[k]);
+      g_state.compact[k] = nullptr;
+      g_state.compact_bytes[k] = 0;
+    }
   }
   KGX_HIP(hipStreamCreateWithFlags(&g_state.stream, hipStreamNonBlocking));
   g_state.device = device;
@@ -977,19 +982,105 @@ int kgx_inbreed(kgx_gt8* h, uint64_t g0, uint64_t g1, const uint32_t* locus_inde
         // the reference itself lands on one or another from its random starts -- so it is not the default.
         hipLaunchKernelGGL(k_brent_init, dim3(lin_grid), dim3(kBlock), 0, st, d_counts, d_sums, n, env_int("KGX_K7_ESTIMATE_START", 0), d_brent, d_f);
         constexpr int kMaxEvaluations = 60;        // golden section alone would need 38; Brent's safeguard keeps that bound
+        // The genomes still searching.  When at most half of them are left -- and the call is big enough for it to pay --
+        // their genotype columns and states are compacted (dense in the selected loci) and the remaining passes sweep
+        // only those: on populations with F of both signs the last genomes need twice the evaluations of the first.
+        // A genome's sums do not depend on its neighbours, so the results are bit-identical (KGX_K7_NO_COMPACT=1 to compare).
+        uint64_t n_act = n, act_g0 = g0, act_dwords_per_row = dwords_per_row;
+        const uint32_t* act_gt = gt32;
+        const uint32_t* act_index = d_index;
+        BrentState* act_brent = d_brent;
+        double* act_f = d_f;
+        uint32_t* act_global = nullptr;
+        int act_gpl = eval_gpl;
+        std::vector<uint32_t> global_of(n);
+        for (uint64_t g = 0; g < n; ++g) global_of[g] = static_cast<uint32_t>(g);
+        std::vector<BrentState> host_states;
+        auto evaluate = [&]() {
+          if (act_gt == gt32) { sweep(2); return; }
+          const dim3 grid_eval(static_cast<uint32_t>(((n_act + act_gpl - 1) / act_gpl + kBlock - 1) / kBlock), static_cast<uint32_t>(n_seg));
+#define KGX_EVAL2(W, B)                                                                                                              \
+  hipLaunchKernelGGL((k_inbreed_eval_lut<2, W, B>), grid_eval, dim3(kBlock), 0, st, act_gt, act_dwords_per_row, act_g0, n_act, act_index, \
+                     n_sel, per_seg, d_table, d_valid, amax, phased, act_f, d_part, d_counts)
+          if (amax <= 1) KGX_EVAL2(8, 1); else if (amax <= 3) KGX_EVAL2(8, 2); else KGX_EVAL2(8, 3);
+#undef KGX_EVAL2
+        };
+        const bool may_compact = eval_lut && !env_int("KGX_K7_NO_COMPACT", 0);
+        bool may_compact_now = may_compact;
+        int compaction_level = 0;
         for (int it = 0; it < kMaxEvaluations && rc == KGX_OK; ++it) {
-          sweep(2);
-          hipLaunchKernelGGL(k_reduce_parts, dim3(lin_grid), dim3(kBlock), 0, st, d_part, n_seg, n, d_eval);
+          evaluate();
+          const uint32_t act_grid = stream_grid(n_act, kBlock);
+          hipLaunchKernelGGL(k_reduce_parts, dim3(act_grid), dim3(kBlock), 0, st, d_part, n_seg, n_act, d_eval);
           try_hip(hipMemsetAsync(d_running, 0, sizeof(unsigned int), st), KGX_EHIP, "memset(running)");
-          hipLaunchKernelGGL(k_brent_step, dim3(lin_grid), dim3(kBlock), 0, st, d_brent, d_eval, n, it == 0 ? 0 : 1, d_f, d_running);
+          hipLaunchKernelGGL(k_brent_step, dim3(act_grid), dim3(kBlock), 0, st, act_brent, d_eval, n_act, it == 0 ? 0 : 1, act_f, d_running,
+                             act_global, d_f);
           unsigned int running = 0;
           try_hip(hipMemcpyAsync(&running, d_running, sizeof(unsigned int), hipMemcpyDeviceToHost, st), KGX_EHIP, "D2H(running)");
           try_hip(hipStreamSynchronize(st), KGX_EHIP, "sync");
           g_state.last_evaluations = it + 1;
-          if (env_int("KGX_K7_TRACE", 0)) std::fprintf(stderr, "kgx: Loglikelihood evaluation %d: %u of %llu genomes still searching\n", it + 1, running, (unsigned long long)n);
+          if (env_int("KGX_K7_TRACE", 0)) std::fprintf(stderr, "kgx: Loglikelihood evaluation %d: %u of %llu genomes still searching\n", it + 1, running, (unsigned long long)n_act);
           if (running == 0) break;
+          const uint64_t new_pitch = (static_cast<uint64_t>(running) + 127) / 128 * 128;
+          // worth it from ~64 M cells left (a gather costs about one pass); the two knobs are for the tests
+          const uint64_t min_genomes = static_cast<uint64_t>(env_int("KGX_K7_COMPACT_MIN_GENOMES", 2048));
+          const uint64_t min_cells = static_cast<uint64_t>(env_int("KGX_K7_COMPACT_MIN_CELLS", 1 << 26));
+          if (!may_compact_now || static_cast<uint64_t>(running) * 2 > n_act || n_act < min_genomes || n_sel * static_cast<uint64_t>(running) < min_cells) continue;
+          host_states.resize(n_act);
+          try_hip(hipMemcpyAsync(host_states.data(), act_brent, n_act * sizeof(BrentState), hipMemcpyDeviceToHost, st), KGX_EHIP, "D2H(states)");
+          try_hip(hipStreamSynchronize(st), KGX_EHIP, "sync");
+          if (rc != KGX_OK) break;
+          std::vector<uint32_t> columns, new_global;
+          for (uint64_t g = 0; g < n_act; ++g)
+            if (!host_states[g].done) { columns.push_back(static_cast<uint32_t>(g)); new_global.push_back(global_of[g]); }
+          const uint64_t n_new = columns.size();
+          // Level k lives in the library's ping-pong buffer k & 1 (what that buffer held, level k - 2, is no longer read);
+          // the buffers stay allocated between calls like the scratch arena (kgx_release_scratch frees them).
+          ScratchPlan level;
+          const size_t o_gt = level.add(n_sel * new_pitch), o_st = level.add(n_new * sizeof(BrentState)), o_nf = level.add(n_new * sizeof(double));
+          const size_t o_col = level.add(n_new * sizeof(uint32_t)), o_glob = level.add(n_new * sizeof(uint32_t));
+          const int slot = compaction_level & 1;
+          if (g_state.compact_bytes[slot] < level.total) {
+            if (g_state.compact[slot]) (void)hipFree(g_state.compact[slot]);
+            g_state.compact[slot] = nullptr;
+            g_state.compact_bytes[slot] = 0;
+            size_t free_bytes = 0, total_bytes = 0;
+            if (hipMemGetInfo(&free_bytes, &total_bytes) != hipSuccess || free_bytes < level.total + (4ull << 30) ||
+                hipMalloc(&g_state.compact[slot], level.total) != hipSuccess) {
+              (void)hipGetLastError();
+              g_state.compact[slot] = nullptr;
+              may_compact_now = false;                                     // no room: carry on as is
+              continue;
+            }
+            g_state.compact_bytes[slot] = level.total;
+          }
+          ++compaction_level;
+          char* base = g_state.compact[slot];
+          uint8_t* new_gt = reinterpret_cast<uint8_t*>(base + o_gt);
+          BrentState* new_brent = reinterpret_cast<BrentState*>(base + o_st);
+          double* new_f = reinterpret_cast<double*>(base + o_nf);
+          uint32_t* new_columns = reinterpret_cast<uint32_t*>(base + o_col);
+          uint32_t* d_new_global = reinterpret_cast<uint32_t*>(base + o_glob);
+          try_hip(hipMemcpyAsync(new_columns, columns.data(), n_new * sizeof(uint32_t), hipMemcpyHostToDevice, st), KGX_EHIP, "H2D(columns)");
+          try_hip(hipMemcpyAsync(d_new_global, new_global.data(), n_new * sizeof(uint32_t), hipMemcpyHostToDevice, st), KGX_EHIP, "H2D(global)");
+          const dim3 gather_grid(static_cast<uint32_t>((new_pitch / 4 + kBlock - 1) / kBlock), static_cast<uint32_t>(std::min<uint64_t>(n_sel, 8192)));
+          hipLaunchKernelGGL(k_gather_columns, gather_grid, dim3(kBlock), 0, st, reinterpret_cast<const uint8_t*>(act_gt), act_dwords_per_row * 4,
+                             act_g0, act_index, n_sel, new_columns, n_new, new_gt, new_pitch);
+          hipLaunchKernelGGL(k_gather_states, dim3(stream_grid(n_new, kBlock)), dim3(kBlock), 0, st, act_brent, act_f, new_columns, n_new, new_brent, new_f);
+          try_hip(hipStreamSynchronize(st), KGX_EHIP, "sync");           // columns / new_global leave scope
+          act_gt = reinterpret_cast<const uint32_t*>(new_gt);
+          act_dwords_per_row = new_pitch / 4;
+          act_g0 = 0;
+          act_index = nullptr;
+          act_brent = new_brent;
+          act_f = new_f;
+          act_global = d_new_global;
+          act_gpl = 8;
+          n_act = n_new;
+          global_of.swap(new_global);
         }
-        hipLaunchKernelGGL(k_brent_step, dim3(lin_grid), dim3(kBlock), 0, st, d_brent, d_eval, n, 2, d_f, d_running);
+        hipLaunchKernelGGL(k_brent_step, dim3(stream_grid(n_act, kBlock)), dim3(kBlock), 0, st, act_brent, d_eval, n_act, 2, act_f, d_running, act_global, d_f);
+        try_hip(hipStreamSynchronize(st), KGX_EHIP, "sync");
       } else {
       const double inv_phi = 0.6180339887498949;
       constexpr int kGoldenSteps = 38;     // bracket 2 * 0.618^36 = 6e-8 after the two start-up evaluations
@@ -1038,6 +1129,11 @@ int kgx_release_scratch(void) {
   }
   g_state.scratch = nullptr;
   g_state.scratch_bytes = 0;
+  for (int k = 0; k < 2; ++k) {
+    if (g_state.compact[k]) (void)hipFree(g_state.compact[k]);
+    g_state.compact[k] = nullptr;
+    g_state.compact_bytes[k] = 0;
+  }
   return KGX_OK;
 }
 

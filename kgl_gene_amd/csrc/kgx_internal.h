@@ -40,6 +40,8 @@ struct State {
   int last_evaluations = 0;                                // objective evaluations of the last Loglikelihood call
   char* scratch = nullptr;                                 // grow-only arena for kgx_inbreed's per-call buffers
   size_t scratch_bytes = 0;
+  char* compact[2] = {nullptr, nullptr};                   // ping-pong buffers of the Loglikelihood search's compaction levels
+  size_t compact_bytes[2] = {0, 0};
 };
 
 extern State g_state;

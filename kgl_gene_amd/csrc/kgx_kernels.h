@@ -1459,19 +1459,58 @@ k_brent_init(const unsigned long long* __restrict__ counts, const double* __rest
   }
 }
 
+// global_of / result (both or neither): the states are a compacted subset of the call's genomes (see kgx_inbreed);
+// a genome's coefficient goes to result[global_of[g]] when its search ends.
 __global__ void __launch_bounds__(kBlock)
 k_brent_step(BrentState* __restrict__ st, const double* __restrict__ f_eval, uint64_t n, int mode, double* __restrict__ f_next,
-             unsigned int* __restrict__ still_running) {
+             unsigned int* __restrict__ still_running, const uint32_t* __restrict__ global_of, double* __restrict__ result) {
   for (uint64_t g = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x; g < n;
        g += static_cast<uint64_t>(gridDim.x) * blockDim.x) {
     BrentState s = st[g];
-    if (mode == 2) { f_next[g] = s.x; continue; }
+    if (mode == 2) {
+      f_next[g] = s.x;
+      if (global_of) result[global_of[g]] = s.x;
+      continue;
+    }
     if (!s.done) {
       brent_advance(s, -f_eval[g], mode == 0);
       if (!s.done) atomicAdd(still_running, 1u);
+      else if (global_of) result[global_of[g]] = s.x;
       st[g] = s;
     }
     f_next[g] = s.done ? s.x : s.u;
+  }
+}
+
+// Compaction of the genomes still searching (kgx_inbreed, Loglikelihood): their genotype columns, dense in the selected
+// loci, and their search states.
+__global__ void __launch_bounds__(kBlock)
+k_gather_columns(const uint8_t* __restrict__ src, uint64_t src_pitch, uint64_t src_g0, const uint32_t* __restrict__ locus_index,
+                 uint64_t n_sel, const uint32_t* __restrict__ columns, uint64_t n_columns, uint8_t* __restrict__ dst, uint64_t dst_pitch) {
+  // a thread owns four consecutive output columns: four byte reads out of one (cached) source row, one dword store
+  const uint64_t j4 = (static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x) * 4;
+  if (j4 >= dst_pitch) return;
+  uint64_t column[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) column[k] = j4 + k < n_columns ? src_g0 + columns[j4 + k] : ~0ull;
+  for (uint64_t s = blockIdx.y; s < n_sel; s += gridDim.y) {
+    const uint64_t l = locus_index ? static_cast<uint64_t>(locus_index[s]) : s;
+    const uint8_t* row = src + l * src_pitch;
+    uint32_t packed = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      if (column[k] != ~0ull) packed |= static_cast<uint32_t>(row[column[k]]) << (8 * k);
+    *reinterpret_cast<uint32_t*>(dst + s * dst_pitch + j4) = packed;      // the tail of the row is zero
+  }
+}
+
+__global__ void __launch_bounds__(kBlock)
+k_gather_states(const BrentState* __restrict__ st, const double* __restrict__ f, const uint32_t* __restrict__ columns, uint64_t n_columns,
+                BrentState* __restrict__ st_out, double* __restrict__ f_out) {
+  for (uint64_t j = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x; j < n_columns;
+       j += static_cast<uint64_t>(gridDim.x) * blockDim.x) {
+    st_out[j] = st[columns[j]];
+    f_out[j] = f[columns[j]];
   }
 }
 

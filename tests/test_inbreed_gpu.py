@@ -55,12 +55,14 @@ def test_class_frequency_table_is_bit_exact(kgx):
 @pytest.mark.parametrize("mode", [oa.Population.PHASED, oa.Population.UNPHASED])
 @pytest.mark.parametrize("algorithm,path", [("Simple", "default"), ("RitlandLocus", "default"), ("HallME", "default"), ("Loglikelihood", "default"),
                                             ("HallME", "passes"), ("Loglikelihood", "passes"), ("Loglikelihood", "golden"),
+                                            ("Loglikelihood", "compacting"),
                                             ("Simple", "generic"), ("RitlandLocus", "generic"), ("HallME", "generic"), ("Loglikelihood", "generic"),
                                             ("Simple", "swar4"), ("RitlandLocus", "no-table")])
 def test_inbreed_window_vs_oracle(kgx, mode, algorithm, path, monkeypatch):
     # every kernel flavour against the same oracle window: the window-sized fused iteration (default), the multi-kernel
     # table passes, plain golden section, the generic per-cell kernels, the 4-genomes-per-lane SWAR sweep
-    env = {"passes": {"KGX_K7_NO_WAVE": "1"}, "golden": {"KGX_K7_NO_WAVE": "1", "KGX_K7_GOLDEN": "1"},
+    env = {"passes": {"KGX_K7_NO_WAVE": "1"},
+           "compacting": {"KGX_K7_NO_WAVE": "1", "KGX_K7_COMPACT_MIN_GENOMES": "4", "KGX_K7_COMPACT_MIN_CELLS": "1"}, "golden": {"KGX_K7_NO_WAVE": "1", "KGX_K7_GOLDEN": "1"},
            "generic": {"KGX_K5_GENERIC": "1", "KGX_K7_NO_WAVE": "1"}, "swar4": {"KGX_K5_NO_SWAR16": "1"},
            "no-table": {"KGX_K5_NO_EVAL_LUT": "1"}}.get(path, {})
     for key, value in env.items():
@@ -346,3 +348,33 @@ def test_kernel_flavours_agree_on_random_shapes(kgx, monkeypatch):
                     continue        # several local maxima on adversarial bytes: compared on realistic data above
                 assert np.all(np.abs(a[both] - b[both]) <= tol * np.maximum(1.0, np.abs(b[both]))), ctx
         m.close()
+
+
+def test_loglikelihood_compaction_is_bit_identical(kgx, monkeypatch):
+    """The multi-kernel Loglikelihood search drops finished genomes from its passes (compacted columns and states).  A
+    genome's sums do not depend on its neighbours: with and without compaction the coefficients are the same bits."""
+    rng = np.random.default_rng(8)
+    G, L = 3000, 6000
+    table = np.full((L, 3), np.nan)
+    table[:, 0] = rng.uniform(0.02, 0.45, L).astype(np.float32)
+    two = rng.random(L) < 0.3
+    table[two, 1] = rng.uniform(0.01, 0.2, int(two.sum())).astype(np.float32)
+    F = rng.uniform(-0.3, 0.3, G)
+    m = kgx.GenotypeMatrix(G, L)
+    m.synth_inbred(table, F, seed=3)
+    index = np.sort(rng.choice(L, 4000, replace=False)).astype(np.uint32)
+    sub = np.ascontiguousarray(table[index])
+    monkeypatch.setenv("KGX_K7_NO_WAVE", "1")
+    results = {}
+    for name, env in (("plain", {"KGX_K7_NO_COMPACT": "1"}), ("compacting", {"KGX_K7_COMPACT_MIN_GENOMES": "64", "KGX_K7_COMPACT_MIN_CELLS": "1000"})):
+        for k in ("KGX_K7_NO_COMPACT", "KGX_K7_COMPACT_MIN_GENOMES", "KGX_K7_COMPACT_MIN_CELLS"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        results[name] = (m.inbreed(sub, "Loglikelihood", phased=True, locus_index=index, g0=16, g1=G - 7), kgx.inbreed_last_evaluations())
+    (a, evals_a), (b, evals_b) = results["plain"], results["compacting"]
+    assert evals_a == evals_b and evals_a > 12
+    assert np.array_equal(a["inbred_allele_sum"], b["inbred_allele_sum"])
+    assert np.array_equal(a["total_allele_count"], b["total_allele_count"])
+    assert np.abs(a["inbred_allele_sum"] - F[16:G - 7]).max() < 0.25 and np.median(np.abs(a["inbred_allele_sum"] - F[16:G - 7])) < 0.03
+    m.close()
