@@ -297,3 +297,37 @@ def test_flatteners_vs_oracle_over_seeds(seed):
         assert flat.hgvs == [vdb.hgvs(i) for i in range(vdb.n_variants)]
         assert np.array_equal(capi.unpack_dosage2(flat.packed, flat.G), np.minimum(vdb.dosage().T, 3))
         assert np.array_equal(ha.fws_genome_bins(flat), genome_out)
+
+
+def test_flatteners_survive_mangled_text():
+    """Robustness, not parity: truncated lines, deleted tabs, random bytes, missing header lines.  The flatteners must
+    return (possibly empty) populations, never crash or hang (scripts/sanitize_host.sh runs this under ASan/UBSan)."""
+    from .records_io import DATA_SOURCE
+
+    rng = np.random.default_rng(99)
+    rec, gt = sv.multiallelic_block(9, 120, rng_seed=4, dup_records=5)
+    ids = [f"NA{i:05d}" for i in range(9)]
+    texts = [vt.write_vcf_1000(rec, gt, ids, rng_seed=1), vt.write_vcf_pf(150, [f"PF{i}" for i in range(7)], rng_seed=6),
+             vt.write_vcf_mono(rec, "Gnomad2_1")]
+    for trial in range(60):
+        base = texts[trial % 3]
+        raw = bytearray(base.encode())
+        kind = trial % 5
+        if kind == 0:                                            # random byte flips (printable range)
+            for pos in rng.integers(0, len(raw), 40):
+                raw[pos] = int(rng.integers(9, 127))
+        elif kind == 1:                                          # drop tabs
+            for pos in [i for i, c in enumerate(raw) if c == 9][:: int(rng.integers(3, 40))]:
+                raw[pos] = ord(" ")
+        elif kind == 2:                                          # truncate in the middle of a line
+            raw = raw[: int(rng.integers(1, len(raw)))]
+        elif kind == 3:                                          # no header at all
+            raw = bytearray(b"\\n".join(line for line in bytes(raw).split(b"\\n") if not line.startswith(b"#")))
+        else:                                                    # huge numbers, empty fields
+            raw = bytearray(bytes(raw).replace(b"\\t1|", b"\\t99999999999999999999|", 3).replace(b"\\tPASS\\t", b"\\t\\t", 2))
+        text = raw.decode("latin-1")
+        for flavour in ("Genome1000", "Falciparum"):
+            flat = ha.FlatVcf(text, 2, flavour=flavour, quality_filter=bool(trial & 1))
+            assert flat.V >= 0 and flat.G >= 0
+        got = ha.InbreedInputs(texts[2] if trial % 2 else text, DATA_SOURCE["Gnomad2_1"], text)
+        assert got.L >= 0
