@@ -211,6 +211,7 @@ void parallelChunks(size_t n, size_t chunk, size_t threads, Fn fn) {
 
 FlatPopulation mergeRecords(const std::vector<RecordRows>& parsed, const std::vector<std::string>& samples, bool every_sample, size_t threads = 0) {
   const size_t S = samples.size();
+  if (S == 0) return FlatPopulation{};              // no #CHROM line / no sample columns: no genomes, hence no variants
   struct Key { const std::string* hgvs; uint32_t record, alt; };
   std::vector<Key> keys;
   for (uint32_t r = 0; r < parsed.size(); ++r)
@@ -742,6 +743,7 @@ FlatDiploid flattenVcf1000Gt8(std::string_view text, const FlatReference& refere
       genome_of_sample[s] = std::lower_bound(out.genome_ids.begin(), out.genome_ids.end(), lines.samples[s]) - out.genome_ids.begin();
   const size_t G = out.genome_ids.size();
   out.bytes.assign(out.n_loci * G, 0);
+  if (G == 0 || out.n_loci == 0) return out;          // nobody holds the contig, or no reference locus: nothing to assemble
 
   lap("genome order");
   // Assemble locus by locus (rows are independent; the records of one locus are taken in file order).  Per genome of the

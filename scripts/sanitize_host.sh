@@ -16,4 +16,5 @@ cd $ROOT
 export KGX_SANITIZED_HOST_LIB=$OUT/libkgx_analysis.so KGX_SANITIZED_ORACLE_LIB=$OUT/libkgo.so
 export ASAN_OPTIONS=detect_leaks=0:verify_asan_link_order=0 UBSAN_OPTIONS=print_stacktrace=1
 LD_PRELOAD=$(gcc -print-file-name=libasan.so):$(gcc -print-file-name=libubsan.so) \
-  python -m pytest tests/test_vcf_flatten_cpu.py tests/test_oracle_pins.py -x -q -p no:cacheprovider "$@"
+  python -m pytest tests/test_vcf_flatten_cpu.py tests/test_oracle_pins.py tests/test_golden.py -x -q -s -m "not gpu" -p no:cacheprovider "$@"
+# -s: a sanitizer report goes to stderr and the process _exit()s; under pytest's capture it would be lost
