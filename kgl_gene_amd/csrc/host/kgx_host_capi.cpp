@@ -4,7 +4,11 @@
 #include <cstdlib>
 #include <cstring>
 
+#include <chrono>
+#include <sstream>
+
 #include "kgx_flatten.h"
+#include "kgx_variant_sort.h"
 #include "kgx_vcf_io.h"
 
 using kellerberrin::genome::analysis::gpu::FlatPopulation;
@@ -137,6 +141,82 @@ int kgxh_inbreed_genome_id(void* h, uint64_t i, char* buf, size_t n) {
   if (!h || i >= static_cast<InbreedInputs*>(h)->diploid.genome_ids.size()) return -1;
   copyOut(static_cast<InbreedInputs*>(h)->diploid.genome_ids[i], buf, n);
   return 0;
+}
+
+
+// ---- the rsid / Ensembl indexes (kgx_variant_sort.h) as text, one entry per line in index order --------------------
+// flavour: 0 = mono-genome site file (genome_id names the genome), 1 = phased 1000-Genomes population.
+// what: "ensembl" (list = optional '\n'-separated gene codes to keep), "filter" (filterEnsembl of the list),
+// "allele_ensembl", "non_ensembl", "id", "genome_id".  Fields are tab separated: key, Variant HGVS_Phase (or the
+// ','-joined codes); "genome_id" lines start with the genome.  Returns a malloc'd text the caller frees with kgxh_free.
+char* kgxh_variant_sort(const char* text, uint64_t len, int flavour, const char* genome_id, const char* what, const char* list, int threads) {
+  if (!text || !what) return nullptr;
+  namespace g = kellerberrin::genome::analysis::gpu;
+  std::vector<std::string> names;
+  if (list) {
+    std::string item;
+    for (const char* c = list;; ++c) {
+      if (*c == '\n' || *c == 0) { if (!item.empty()) names.push_back(item); item.clear(); if (*c == 0) break; }
+      else item += *c;
+    }
+  }
+  const auto t_begin = std::chrono::steady_clock::now();
+  const g::SortColumns columns = g::sortColumnsFromVcf(std::string_view(text, len), flavour == 0 ? g::SortVcfFlavour::MonoGenome : g::SortVcfFlavour::Phased1000,
+                                                       genome_id ? genome_id : "Reference", threads > 0 ? threads : 0);
+  const std::string kind(what);
+  std::ostringstream out;
+  auto dumpEnsembl = [&](const g::EnsemblIndex& index) {
+    for (size_t k = 0; k < index.genes().size(); ++k) {
+      const auto [first, last] = index.equalRange(index.genes()[k]);
+      for (size_t e = first; e < last; ++e) out << index.genes()[k] << '\t' << columns.hgvsPhase(index.variants()[e]) << '\n';
+    }
+  };
+  if (kind == "ensembl") {
+    dumpEnsembl(g::VariantSortIndex::ensemblIndex(columns, names));
+  } else if (kind == "filter") {
+    dumpEnsembl(g::VariantSortIndex::ensemblIndex(columns).filterEnsembl(names));
+  } else if (kind == "non_ensembl") {
+    out << g::VariantSortIndex::ensemblIndex(columns).nonEnsemblIdentifiers() << '\n';
+  } else if (kind == "allele_ensembl") {
+    for (const auto& [id, codes] : g::VariantSortIndex::ensemblIndex(columns).alleleEnsemblMap(columns)) {
+      out << id << '\t';
+      bool first = true;
+      for (const auto& code : codes) { out << (first ? "" : ",") << code; first = false; }
+      out << '\n';
+    }
+  } else if (kind == "id") {
+    const auto index = g::VariantSortIndex::variantIdIndex(columns);
+    for (size_t k = 0; k < index.size(); ++k) out << index.ids()[k] << '\t' << columns.hgvsPhase(index.variants()[k]) << '\n';
+  } else if (kind == "timing") {      // build times in ms, no dump: columns, then each index
+    auto ms = [](std::chrono::steady_clock::time_point from) { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - from).count(); };
+    out << "columns\t" << ms(t_begin) << '\n';
+    auto t = std::chrono::steady_clock::now();
+    const auto ensembl = g::VariantSortIndex::ensemblIndex(columns, names);
+    out << "ensembl\t" << ms(t) << '\t' << ensembl.size() << '\n';
+    t = std::chrono::steady_clock::now();
+    const auto ids = g::VariantSortIndex::variantIdIndex(columns);
+    out << "id\t" << ms(t) << '\t' << ids.size() << '\n';
+    t = std::chrono::steady_clock::now();
+    const auto by_genome = g::VariantSortIndex::variantGenomeIndex(columns, threads > 0 ? threads : 0);
+    size_t entries = 0;
+    for (size_t gi = 0; gi < by_genome.genomes(); ++gi) entries += by_genome.size(gi);
+    out << "genome_id\t" << ms(t) << '\t' << entries << '\n';
+  } else if (kind == "genome_id") {
+    const auto index = g::VariantSortIndex::variantGenomeIndex(columns, threads > 0 ? threads : 0);
+    for (size_t gi = 0; gi < index.genomes(); ++gi)
+      for (size_t e = 0; e < index.size(gi); ++e) {
+        // every entry must also be found by bisection
+        const g::SortVariant* found = index.find(gi, index.id(gi, e));
+        if (!found || !(*found == index.variant(gi, e))) return nullptr;
+        out << columns.genome_ids[gi] << '\t' << index.id(gi, e) << '\t' << columns.hgvsPhase(index.variant(gi, e)) << '\n';
+      }
+  } else {
+    return nullptr;
+  }
+  const std::string dump = out.str();
+  char* result = static_cast<char*>(std::malloc(dump.size() + 1));
+  if (result) std::memcpy(result, dump.c_str(), dump.size() + 1);
+  return result;
 }
 
 }  // extern "C"

@@ -30,6 +30,7 @@
 #include <unordered_map>
 
 #include "kgx_flatten.h"
+#include "kgx_variant_sort.h"
 
 namespace kellerberrin::genome::analysis::gpu {
 
@@ -506,7 +507,7 @@ FlatPopulation flattenVcfPf(std::string_view text, size_t threads, bool quality_
     if (!pos_ok) return;
     const uint64_t offset = pos - 1;
     const std::string_view ref = f[3];
-    const auto alts = split(f[4], ',');
+    const auto alts = split(f[4] == "." ? std::string_view() : f[4], ',');   // "." is a missing alt (kgl_variant_vcf_impl.cpp:133-141)
     const size_t A = alts.size();
     const auto format = split(f[8], ':');
     size_t gt_index = format.size(), ad_index = format.size();
@@ -622,8 +623,9 @@ FlatReference flattenReferenceVcf(std::string_view text, DataSourceEnum data_sou
     const std::string_view ref = f[3];
     // "The alt field can be blank": no ',' or an empty field is ONE alt, taken as written (:68-70)
     std::vector<std::string_view> alts;
-    if (f[4].find(',') == std::string_view::npos || f[4].empty()) alts.push_back(f[4]);
-    else alts = split(f[4], ',');
+    const std::string_view alt_field = f[4] == "." ? std::string_view() : f[4];     // "." is a missing alt (kgl_variant_vcf_impl.cpp:133-141)
+    if (alt_field.find(',') == std::string_view::npos || alt_field.empty()) alts.push_back(alt_field);
+    else alts = split(alt_field, ',');
     for (size_t a = 0; a < alts.size(); ++a) {
       if (!isSnp(ref, alts[a])) continue;                               // SNPFilter
       ReferenceAltRow alt;
@@ -818,6 +820,209 @@ FlatDiploid flattenVcf1000Gt8(std::string_view text, const FlatReference& refere
     for (auto& th : pool) th.join();
   }
   lap("assemble");
+  return out;
+}
+
+
+// ---- record columns for the rsid / Ensembl indexes (kgx_variant_sort.h) --------------------------
+
+namespace {
+
+// The sub-field names of the vep INFO field, from its header line: what VCFParseHeader::parseVcfHeader +
+// tokenizeVcfHeaderKeyValues (kgl_parser/kgl_variant_factory_vcf_parse_header.cpp:113-265) and
+// VEPSubFieldHeader::parseHeader (kgl_evidence/kgl_variant_factory_vcf_evidence.cpp:24-58) make of
+//   ##INFO=<ID=vep,Number=.,Type=String,Description="... Format: Allele|Consequence|...">
+// Angle brackets vanish wherever they stand, items separate at commas outside double quotes (backslash escapes the next
+// character), an item is cut at '=' signs with empty pieces skipped (so a description stops at its first '='), a line
+// without Type or Number is no INFO record, a later line of the same ID replaces an earlier one, and a name listed
+// twice voids the header.
+std::vector<std::string> vepHeaderNames(std::string_view text) {
+  std::vector<std::string> names;
+  for (size_t begin = 0; begin < text.size();) {
+    size_t end = text.find('\n', begin);
+    if (end == std::string_view::npos) end = text.size();
+    std::string_view line = text.substr(begin, end - begin);
+    begin = end + 1;
+    if (!line.empty() && line.back() == '\r') line.remove_suffix(1);
+    if (line.empty() || line[0] != '#') { if (!line.empty()) break; else continue; }
+    if (line.rfind("#CHROM", 0) == 0) break;
+    const size_t eq = line.find('=');
+    if (eq == std::string_view::npos) continue;
+    std::string key(line.substr(0, eq));
+    if (key.size() < 2 || key[0] != '#') continue;
+    key.erase(0, 2);
+    for (auto& c : key) c = static_cast<char>(std::toupper(static_cast<unsigned char>(c)));
+    if (key != "INFO") continue;
+    std::map<std::string, std::string> pairs;
+    std::string item;
+    bool quoted = false;
+    auto closeItem = [&]() {
+      std::string name, value;
+      int piece = 0;
+      for (const auto token : split(item, '=')) {
+        if (token.empty()) continue;
+        if (piece == 0) name = std::string(token);
+        else if (piece == 1) value = std::string(token);
+        ++piece;
+      }
+      item.clear();
+      if (piece == 0) return;
+      for (auto& c : name) c = static_cast<char>(std::toupper(static_cast<unsigned char>(c)));
+      pairs[name] = value;
+    };
+    const std::string_view body = line.substr(eq + 1);
+    for (size_t i = 0; i < body.size(); ++i) {
+      const char c = body[i];
+      if (c == '<' || c == '>') continue;
+      if (c == '\\' && i + 1 < body.size()) { ++i; item += body[i] == 'n' ? '\n' : body[i]; continue; }
+      if (c == '"') { quoted = !quoted; continue; }
+      if (c == ',' && !quoted) { closeItem(); continue; }
+      item += c;
+    }
+    closeItem();
+    const auto id = pairs.find("ID");
+    if (id == pairs.end() || id->second != "vep" || !pairs.count("TYPE") || !pairs.count("NUMBER")) continue;
+    names.clear();
+    const auto description = pairs.find("DESCRIPTION");
+    if (description == pairs.end()) continue;
+    const size_t format = description->second.find("Format: ");
+    if (format == std::string::npos) continue;
+    for (const auto name : split(std::string_view(description->second).substr(format + 8), '|')) names.emplace_back(name);
+    std::vector<std::string> sorted = names;
+    std::sort(sorted.begin(), sorted.end());
+    if (std::adjacent_find(sorted.begin(), sorted.end()) != sorted.end()) names.clear();
+  }
+  return names;
+}
+
+struct SortParsed {
+  SortRecord record;
+  bool kept{false};
+  struct Call { uint32_t sample; uint16_t a, b; };      // 1-based alts of a sample column that is not all reference
+  std::vector<Call> calls;
+};
+
+}  // namespace
+
+SortColumns sortColumnsFromVcf(std::string_view text, SortVcfFlavour flavour, const GenomeId_t& genome_id, size_t threads) {
+  SortColumns out;
+  out.vep_header = vepHeaderNames(text);
+  const auto gene_at = std::find(out.vep_header.begin(), out.vep_header.end(), std::string("Gene"));
+  const size_t gene_column = static_cast<size_t>(gene_at - out.vep_header.begin());
+  const bool have_gene = gene_at != out.vep_header.end();
+  const size_t vep_columns = out.vep_header.size();
+  const VcfLines lines = scanLines(text);
+  const size_t S = lines.samples.size();
+  const bool phased = flavour == SortVcfFlavour::Phased1000;
+
+  std::vector<SortParsed> parsed(lines.records.size());
+  parallelChunks(parsed.size(), 256, threads, [&](size_t begin, size_t end) {
+    for (size_t r = begin; r < end; ++r) {
+      SortParsed& p = parsed[r];
+      const auto f = split(lines.records[r], '\t', phased ? S + 10 : 10);
+      if (f.size() < 8) continue;                                        // fewer than the mandatory fields: record dropped
+      bool pos_ok = true;
+      const uint64_t pos = parseIndex(f[1], pos_ok);
+      if (!pos_ok) continue;
+      p.kept = true;
+      SortRecord& rec = p.record;
+      rec.contig = std::string(f[0]);
+      rec.offset = pos - 1;
+      if (f[2] != ".") {                                                  // "." is no identifier; otherwise trimEndWhiteSpace
+        std::string_view id = f[2];
+        while (!id.empty() && std::isspace(static_cast<unsigned char>(id.back()))) id.remove_suffix(1);
+        rec.identifier = std::string(id);
+      }
+      rec.ref = std::string(f[3]);
+      const std::string_view alt_field = f[4] == "." ? std::string_view() : f[4];
+      // GrchVCFImpl takes an ALT without ',' (or empty) as one alt; Genome1000VCFImpl tokenizes: the same list either way
+      for (const auto alt : split(alt_field, ',')) rec.alts.emplace_back(alt);
+      // the vep INFO vector: fields at ';', key before the FIRST '=', the first of two equal keys counts
+      if (have_gene) {
+        for (const auto item : split(f[7], ';')) {
+          const size_t eq = item.find('=');
+          if ((eq == std::string_view::npos ? item : item.substr(0, eq)) != "vep") continue;
+          if (eq != std::string_view::npos) {
+            for (const auto entry : split(item.substr(eq + 1), ',')) {
+              const auto sub_fields = split(entry, '|');
+              if (sub_fields.size() != vep_columns) continue;              // the Gnomad 3 work-around: entries of another size are dropped
+              rec.vep_usable = true;
+              if (!sub_fields[gene_column].empty()) rec.genes.emplace_back(sub_fields[gene_column]);
+            }
+          }
+          break;
+        }
+        std::sort(rec.genes.begin(), rec.genes.end());
+        rec.genes.erase(std::unique(rec.genes.begin(), rec.genes.end()), rec.genes.end());
+      }
+      if (phased) {
+        const Chromosome chrom = chromosomeOf(rec.contig);
+        for (size_t idx = 9; idx < f.size() && idx - 9 < S; ++idx) {
+          uint32_t pa, pb;
+          phasedAlleles(f[idx], rec.alts.size(), chrom, pa, pb);
+          if (pa || pb) p.calls.push_back({static_cast<uint32_t>(idx - 9), static_cast<uint16_t>(pa), static_cast<uint16_t>(pb)});
+        }
+      }
+    }
+  });
+
+  // genomes: the one named genome, or the sample names that carry anything (PopulationDB creates a genome on its first variant)
+  std::vector<uint32_t> genome_of_sample(S, UINT32_MAX);
+  if (!phased) {
+    out.genome_ids.push_back(genome_id);
+  } else {
+    std::vector<uint8_t> carries(S, 0);
+    for (const auto& p : parsed) for (const auto& call : p.calls) carries[call.sample] = 1;
+    std::map<std::string, uint32_t> by_name;
+    for (size_t s = 0; s < S; ++s) if (carries[s]) by_name.emplace(lines.samples[s], 0);
+    uint32_t next = 0;
+    for (auto& [name, index] : by_name) { index = next++; out.genome_ids.push_back(name); }
+    for (size_t s = 0; s < S; ++s) if (carries[s]) genome_of_sample[s] = by_name[lines.samples[s]];
+  }
+
+  // records in a genome's visiting order: contig id, offset, then the order the (single-threaded) file gives
+  std::vector<uint32_t> order;
+  for (size_t r = 0; r < parsed.size(); ++r) if (parsed[r].kept) order.push_back(static_cast<uint32_t>(r));
+  std::stable_sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) {
+    const SortRecord& a = parsed[x].record;
+    const SortRecord& b = parsed[y].record;
+    if (a.contig != b.contig) return a.contig < b.contig;
+    return a.offset < b.offset;
+  });
+  out.records.reserve(order.size());
+  for (const uint32_t r : order) out.records.push_back(std::move(parsed[r].record));
+
+  // Variant objects per genome.  Within one record the parser adds phase A's alts in ascending order, then phase B's
+  // (kgl_variant_factory_1000_impl.cpp:118-140), each to its genomes in sample order.
+  const size_t G = out.genome_ids.size();
+  out.genome_begin.assign(G + 1, 0);
+  if (!phased) {
+    for (const auto& rec : out.records) out.genome_begin[1] += rec.alts.size();
+    out.visits.reserve(out.genome_begin[1]);
+    for (size_t r = 0; r < out.records.size(); ++r)
+      for (size_t a = 0; a < out.records[r].alts.size(); ++a) out.visits.push_back({static_cast<uint32_t>(r), static_cast<uint16_t>(a), 255});
+    return out;
+  }
+  for (const uint32_t r : order)
+    for (const auto& call : parsed[r].calls) out.genome_begin[genome_of_sample[call.sample] + 1] += (call.a ? 1 : 0) + (call.b ? 1 : 0);
+  for (size_t g = 0; g < G; ++g) out.genome_begin[g + 1] += out.genome_begin[g];
+  out.visits.resize(out.genome_begin[G]);
+  std::vector<uint64_t> cursor(out.genome_begin.begin(), out.genome_begin.end() - 1);
+  struct Added { uint8_t phase; uint16_t alt; uint32_t sample; };
+  std::vector<Added> added;
+  for (size_t i = 0; i < order.size(); ++i) {
+    added.clear();
+    for (const auto& call : parsed[order[i]].calls) {
+      if (call.a) added.push_back({1, static_cast<uint16_t>(call.a - 1), call.sample});
+      if (call.b) added.push_back({2, static_cast<uint16_t>(call.b - 1), call.sample});
+    }
+    std::sort(added.begin(), added.end(), [](const Added& x, const Added& y) {
+      if (x.phase != y.phase) return x.phase < y.phase;
+      if (x.alt != y.alt) return x.alt < y.alt;
+      return x.sample < y.sample;
+    });
+    for (const auto& add : added) out.visits[cursor[genome_of_sample[add.sample]]++] = {static_cast<uint32_t>(i), add.alt, add.phase};
+  }
   return out;
 }
 

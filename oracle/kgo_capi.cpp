@@ -1,11 +1,13 @@
 // ORACLE — TEST INFRASTRUCTURE ONLY.  PARITY UNPINNED (see kgo_core.h).
 // extern "C" surface so tests/ (ctypes) can drive the restatement.  Nothing in the product links this.
 #include <chrono>
+#include <cstdlib>
 #include <cstring>
 #include <sstream>
 
 #include "kgo_analysis.h"
 #include "kgo_inbreed.h"
+#include "kgo_sort.h"
 
 using namespace kgo;
 
@@ -609,5 +611,59 @@ int64_t kgo_synthetic_check(kgo_pop* reference, int super_pop, const char* algor
   }
   return static_cast<int64_t>(results.size());
 }
+
+
+// ---- VariantSort / SortedVariantAnalysis (kgo_sort.h) as text -----------------------------------------------------
+// what: "ensembl" (EnsemblIndexMap, optional '\n'-separated gene list = ensemblAddIndex), "filter" (filterEnsembl of the
+// list), "allele_ensembl" (alleleEnsemblMap), "id" (variantIdIndex), "genome_id" / "genome_id_mt" (variantGenomeIndex[MT]),
+// "non_ensembl" (nonEnsemblIdentifiers of the full index).  One entry per line in map order, fields tab separated:
+// key, HGVS_Phase of the Variant (or the ','-joined code set); the per-genome maps put the genome id first.  The caller
+// frees the text with kgo_free_text.
+char* kgo_variant_sort(kgo_pop* p, const char* what, const char* list) {
+  if (!p || !what) return nullptr;
+  std::vector<std::string> names;
+  if (list) {
+    std::string item;
+    for (const char* c = list; ; ++c) {
+      if (*c == '\n' || *c == 0) { if (!item.empty()) names.push_back(item); item.clear(); if (*c == 0) break; }
+      else item += *c;
+    }
+  }
+  std::shared_ptr<const PopulationDB> population = p->pop;
+  const std::string kind(what);
+  std::ostringstream out;
+  if (kind == "ensembl") {
+    auto index = std::make_shared<EnsemblIndexMap>();
+    VariantSort::ensemblAddIndex(population, names, index);
+    for (const auto& [gene, variant] : *index) out << gene << '\t' << variant->HGVS_Phase() << '\n';
+  } else if (kind == "non_ensembl") {
+    out << VariantSort::nonEnsemblIdentifiers(*VariantSort::ensemblIndex(population)) << '\n';
+  } else if (kind == "filter") {
+    for (const auto& [gene, variant] : SortedVariantAnalysis(population).filterEnsembl(names)) out << gene << '\t' << variant->HGVS_Phase() << '\n';
+  } else if (kind == "allele_ensembl") {
+    SortedVariantAnalysis sorted(population);
+    for (const auto& [id, codes] : *sorted.alleleEnsemblMap()) {
+      out << id << '\t';
+      bool first = true;
+      for (const auto& code : codes) { out << (first ? "" : ",") << code; first = false; }
+      out << '\n';
+    }
+  } else if (kind == "id") {
+    const auto index = VariantSort::variantIdIndex(population);
+    for (const auto& [id, variant] : *index) out << id << '\t' << variant->HGVS_Phase() << '\n';
+  } else if (kind == "genome_id" || kind == "genome_id_mt") {
+    const auto index = kind == "genome_id" ? VariantSort::variantGenomeIndex(population) : VariantSort::variantGenomeIndexMT(population);
+    for (const auto& [genome, id_map] : *index)
+      for (const auto& [id, variant] : *id_map) out << genome << '\t' << id << '\t' << variant->HGVS_Phase() << '\n';
+  } else {
+    return nullptr;
+  }
+  const std::string text = out.str();
+  char* result = static_cast<char*>(std::malloc(text.size() + 1));
+  if (result) std::memcpy(result, text.c_str(), text.size() + 1);
+  return result;
+}
+
+void kgo_free_text(char* text) { std::free(text); }
 
 }  // extern "C"

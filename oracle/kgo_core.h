@@ -56,6 +56,12 @@ struct RecordEvidence {
   // Scalar Float INFO fields that hold a value (a missing value is not stored): what
   // InfoEvidenceAnalysis::getTypedInfoData<double> returns (kgl_variant_factory_vcf_evidence_analysis.h:141-166).
   std::vector<std::pair<std::string, float>> info_scalar;
+  // Variant::identifier(): the VCF ID column, verbatim (kgl_variant_db.h:125,164; every parser passes vcf_record_ptr->id).
+  std::string identifier;
+  // The "vep" INFO string vector (',' separated; empty = key absent) and the sub-field names of the
+  // ##INFO=<ID=vep,...Description="... Format: a|b|c"> header line (VEPSubFieldHeader, kgl_variant_factory_vcf_evidence.cpp:24-58).
+  std::vector<std::string> vep;
+  std::shared_ptr<const std::vector<std::string>> vep_header;
   std::optional<double> infoScalar(const std::string& field) const {
     for (const auto& [name, value] : info_scalar)
       if (name == field) return static_cast<double>(value);
@@ -80,6 +86,7 @@ class Variant {
   uint32_t altVariantIndex() const { return alt_index_; }
   uint32_t altVariantCount() const { return evidence_->alt_count; }
   bool passFilter() const { return evidence_->pass; }
+  const std::string& identifier() const { return evidence_->identifier; }
 
   // kgl_variant_db.cpp:287-298.  std::format("{}", uint8_t) prints the integer.
   std::string HGVS() const;

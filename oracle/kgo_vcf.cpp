@@ -137,10 +137,87 @@ static void parseInfoAF(std::string_view info, uint32_t n_alt, std::vector<float
   }
 }
 
+// VCFParseHeader::parseHeader / parseVcfHeader / tokenizeVcfHeaderKeyValues (kgl_parser/kgl_variant_factory_vcf_parse_header.cpp:17-265)
+// for the one header line VariantSort needs: ##INFO=<ID=vep,...,Description="... Format: a|b|c">.  '<' and '>' are erased
+// everywhere in the value; items split on ',' outside double quotes ('\\' escapes, quotes dropped:
+// boost::escaped_list_separator); an item splits on '=' with empty tokens dropped, so a value ends at its first '='; a
+// record without Type or Number is ignored; the sub-field names follow "Format: " and a repeated name voids the header
+// (VEPSubFieldHeader::parseHeader, kgl_evidence/kgl_variant_factory_vcf_evidence.cpp:24-58).
+std::shared_ptr<const std::vector<std::string>> parseVepHeader(std::string_view text) {
+  std::shared_ptr<const std::vector<std::string>> result;
+  for (auto line : viewTokenizer(text, '\n')) {
+    if (!line.empty() && line.back() == '\r') line.remove_suffix(1);
+    if (line.rfind("#CHROM", 0) == 0) break;
+    const size_t eq = line.find('=');
+    if (eq == std::string_view::npos) continue;
+    std::string key(line.substr(0, eq));
+    if (const size_t hash = key.find('#'); hash != std::string::npos) key.erase(hash, hash + 2);
+    for (char& c : key) c = static_cast<char>(std::toupper(static_cast<unsigned char>(c)));
+    if (key != "INFO") continue;
+    std::string value;
+    for (char c : line.substr(eq + 1)) if (c != '<' && c != '>') value += c;
+    std::vector<std::string> items(1);
+    bool in_quote = false;
+    for (size_t i = 0; i < value.size(); ++i) {
+      const char c = value[i];
+      if (c == '\\' && i + 1 < value.size()) { items.back() += value[++i] == 'n' ? '\n' : value[i]; continue; }
+      if (c == '"') { in_quote = !in_quote; continue; }
+      if (c == ',' && !in_quote) { items.emplace_back(); continue; }
+      items.back() += c;
+    }
+    std::map<std::string, std::string> item_map;
+    for (const auto& item : items) {
+      std::vector<std::string> item_vec;
+      for (auto token : viewTokenizer(item, '=')) if (!token.empty()) item_vec.emplace_back(token);
+      if (item_vec.empty()) continue;
+      for (char& c : item_vec[0]) c = static_cast<char>(std::toupper(static_cast<unsigned char>(c)));
+      item_map[item_vec[0]] = item_vec.size() >= 2 ? item_vec[1] : std::string();
+    }
+    const auto id = item_map.find("ID");
+    if (id == item_map.end() || id->second != "vep") continue;
+    if (item_map.find("TYPE") == item_map.end() || item_map.find("NUMBER") == item_map.end()) continue;
+    const auto description = item_map.find("DESCRIPTION");
+    auto headers = std::make_shared<std::vector<std::string>>();
+    if (description != item_map.end()) {
+      const size_t at = description->second.find("Format: ");
+      if (at != std::string::npos) {
+        const std::string unparsed_header = description->second.substr(at + 8);   // lives past the views cut from it
+        for (auto sub_field : viewTokenizer(unparsed_header, '|')) headers->emplace_back(sub_field);
+        std::map<std::string, size_t> index_map;
+        for (size_t i = 0; i < headers->size(); ++i)
+          if (!index_map.try_emplace((*headers)[i], i).second) { headers->clear(); break; }
+      }
+    }
+    result = headers;    // vcf_info_map[ID] = record: a later header line of the same ID replaces an earlier one
+  }
+  return result;
+}
+
+// What a record hands every Variant cut from it beyond PASS and AF: the ID column and the "vep" INFO vector
+// (VCFInfoParser::infoTokenParser, kgl_parser/kgl_variant_factory_vcf_parse_info.cpp:14-146: fields split on ';', key and
+// value on the FIRST '=', the first of two equal keys is kept; a String vector splits on ',').
+static void recordAnnotation(RecordEvidence& ev, std::string_view id, std::string_view info,
+                             const std::shared_ptr<const std::vector<std::string>>& vep_header) {
+  // moveToVcfRecord (kgl_variant_vcf_impl.cpp:119-130): "." is no identifier; otherwise the text less its trailing white space
+  if (id != ".") {
+    ev.identifier = std::string(id);
+    while (!ev.identifier.empty() && std::isspace(static_cast<unsigned char>(ev.identifier.back()))) ev.identifier.pop_back();
+  }
+  ev.vep_header = vep_header;
+  for (auto item : viewTokenizer(info, ';')) {
+    const size_t eq = item.find('=');
+    if ((eq == std::string_view::npos ? item : item.substr(0, eq)) != "vep") continue;
+    if (eq != std::string_view::npos)
+      for (auto value : viewTokenizer(item.substr(eq + 1), ',')) ev.vep.emplace_back(value);
+    break;
+  }
+}
+
 // The whole path: text -> records -> Variants added to genomes.  Returns the number of records parsed, -1 on a
 // malformed file.  sample names come from the #CHROM line.
 long addVcf1000(PopulationDB& population, std::string_view text, std::vector<std::string>* genome_names_out) {
   std::vector<std::string> genome_names;
+  const auto vep_header = parseVepHeader(text);
   long n_records = 0;
   size_t line_number = 0;
   for (auto line : viewTokenizer(text, '\n')) {
@@ -170,6 +247,7 @@ long addVcf1000(PopulationDB& population, std::string_view text, std::vector<std
     ev->pass = passed_filter;
     ev->alt_count = static_cast<uint32_t>(alt_vector.size());
     parseInfoAF(field_views[7], ev->alt_count, ev->af, ev->info_af_size);
+    recordAnnotation(*ev, field_views[2], field_views[7], vep_header);
 
     std::map<size_t, std::vector<std::string>> phase_A_map, phase_B_map;
     for (size_t idx = 9; idx < field_views.size(); ++idx) {
@@ -200,6 +278,7 @@ long addVcfMonoGenome(PopulationDB& population, std::string_view text, const std
   const char* const* fields = superPopFields(source);
   if (!fields) return -1;
   long n_records = 0;
+  const auto vep_header = parseVepHeader(text);
   const std::vector<std::string> genome_vector{genome_id};
   for (auto line : viewTokenizer(text, '\n')) {
     if (!line.empty() && line.back() == '\r') line.remove_suffix(1);
@@ -209,7 +288,7 @@ long addVcfMonoGenome(PopulationDB& population, std::string_view text, const std
     const std::string contig(field_views[0]);
     const uint64_t offset = std::stoull(std::string(field_views[1])) - 1;
     const std::string ref(field_views[3]);
-    const std::string alt(field_views[4]);
+    const std::string alt = field_views[4] == "." ? std::string() : std::string(field_views[4]);   // moveToVcfRecord: "." is a missing alt (kgl_variant_vcf_impl.cpp:133-141)
     std::string filter_uc;
     for (char c : field_views[6]) filter_uc += static_cast<char>(std::toupper(static_cast<unsigned char>(c)));
     std::vector<std::string> alt_vector;
@@ -220,6 +299,7 @@ long addVcfMonoGenome(PopulationDB& population, std::string_view text, const std
     ev->pass = filter_uc == "PASS";
     ev->alt_count = static_cast<uint32_t>(alt_vector.size());
     parseInfoAF(field_views[7], ev->alt_count, ev->af, ev->info_af_size, fields);
+    recordAnnotation(*ev, field_views[2], field_views[7], vep_header);
     for (uint32_t a = 0; a < alt_vector.size(); ++a)
       population.addVariant(std::make_shared<const Variant>(contig, offset, VariantPhase::UNPHASED, ref, alt_vector[a], ev, a), genome_vector);
     ++n_records;
@@ -301,6 +381,7 @@ bool p7VariantFilter(const Variant& v) {
 // genome holding every contig of the ##contig header lines (setupPopulationStructure), carrier or not.
 long addVcfPf(PopulationDB& population, std::string_view text, std::vector<std::string>* genome_names_out) {
   std::vector<std::string> genome_names, header_contigs;
+  const auto vep_header = parseVepHeader(text);
   bool structure_done = false;
   auto setupPopulationStructure = [&]() {
     if (structure_done) return;
@@ -335,7 +416,7 @@ long addVcfPf(PopulationDB& population, std::string_view text, std::vector<std::
     const uint64_t offset = std::stoull(std::string(field_views[1])) - 1;
     const std::string reference(field_views[3]);
     std::vector<std::string> alleles;
-    for (auto a : viewTokenizer(field_views[4], ',')) alleles.emplace_back(a);
+    for (auto a : viewTokenizer(field_views[4] == "." ? std::string_view() : field_views[4], ',')) alleles.emplace_back(a);   // "." = missing alt (kgl_variant_vcf_impl.cpp:133-141)
     std::string filter_uc;
     for (char c : field_views[6]) filter_uc += static_cast<char>(std::toupper(static_cast<unsigned char>(c)));
     std::vector<std::string> format_fields;
@@ -354,6 +435,7 @@ long addVcfPf(PopulationDB& population, std::string_view text, std::vector<std::
     ev_base->pass = filter_uc == "PASS";
     ev_base->alt_count = static_cast<uint32_t>(alleles.size());
     parseInfoAF(field_views[7], ev_base->alt_count, ev_base->af, ev_base->info_af_size);
+    recordAnnotation(*ev_base, field_views[2], field_views[7], vep_header);
     for (auto item : viewTokenizer(field_views[7], ';')) {
       const size_t eq = item.find('=');
       if (eq == std::string_view::npos) continue;

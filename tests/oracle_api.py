@@ -79,6 +79,8 @@ def lib() -> C.CDLL:
         "kgo_columns_count": (u64, [vp]),
         "kgo_columns_ident": (C.c_int, [vp, u64, C.c_char_p, C.c_size_t]),
         "kgo_columns_results": (C.c_int, [vp, u64, vp, vp, vp]),
+        "kgo_variant_sort": (vp, [vp, C.c_char_p, C.c_char_p]),
+        "kgo_free_text": (None, [vp]),
         "kgo_synthetic_check": (i64, [vp, C.c_int, C.c_char_p, u64, u64, u64, dbl, dbl, u64, vp, vp, u64]),
     }
     for name, (res, args) in sig.items():
@@ -182,6 +184,17 @@ class Population:
         if not self.genome_ids:
             self.genome_ids = [genome_id]
         return int(n)
+
+    def variant_sort(self, what: str, names=None) -> list[tuple[str, ...]]:
+        """VariantSort / SortedVariantAnalysis on this population (oracle/kgo_sort.h): the index `what` as rows of strings."""
+        listed = None if names is None else "\n".join(names).encode()
+        ptr = lib().kgo_variant_sort(self._h, what.encode(), listed)
+        assert ptr, what
+        try:
+            text = C.string_at(ptr).decode()
+        finally:
+            lib().kgo_free_text(ptr)
+        return [tuple(line.split("\t")) for line in text.split("\n") if line]
 
     def filter_p7(self):
         """viewFilter(P7VariantFilter()), the per-record quality filter of FilterPf7::qualityFilter."""

@@ -145,6 +145,30 @@ def test_vcf_pf_edge_cases():
     assert o.filter_p7().variant_count() == 0
 
 
+def test_missing_alt_is_the_empty_allele_in_every_flavour():
+    """ParseVCF::moveToVcfRecord (kgl_variant_vcf_impl.cpp:133-141) turns an ALT of "." into "" before any parser sees
+    it: the variant is REF>"" -- a deletion, not a SNP -- in the mono-genome, Pf and 1000-Genomes flavours alike."""
+    from .records_io import DATA_SOURCE
+
+    mono = "#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\n1\t10\t.\tA\t.\t.\tPASS\tAF=0.25\n1\t20\t.\tC\tT\t.\tPASS\tAF=0.5\n"
+    dip = "#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\tS1\n1\t10\t.\tA\t.\t.\tPASS\t.\tGT\t1|0\n1\t20\t.\tC\tT\t.\tPASS\t.\tGT\t1|1\n"
+    o = oa.Population("mono")
+    o.add_vcf_mono(mono, "Gnomad2_1")
+    vdb = oa.VariantDB(o)
+    assert sorted(vdb.hgvs(i) for i in range(vdb.n_variants)) == ["1:g.19C>T", "1:g.9A>"]
+    assert o.filter_snp_pass().variant_count() == 1                      # "A" > "" is not a SNP
+    got = ha.InbreedInputs(mono, DATA_SOURCE["Gnomad2_1"], dip)
+    assert got.error == "" and got.offsets.tolist() == [19]
+    flat = ha.FlatVcf(dip)
+    assert flat.hgvs == ["1:g.19C>T", "1:g.9A>"]
+    pf = "##contig=<ID=1>\n#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\tS1\n1\t10\t.\tAC\t.\t.\tPASS\t.\tGT:AD\t0/1:3,4\n"
+    o = oa.Population("pf")
+    o.add_vcf_pf(pf)
+    vdb = oa.VariantDB(o)
+    flat = ha.FlatVcf(pf, flavour="Falciparum")
+    assert [vdb.hgvs(i) for i in range(vdb.n_variants)] == flat.hgvs and len(flat.hgvs) == 1
+
+
 @pytest.mark.parametrize("threads", [1, 4])
 def test_inbreed_inputs_from_vcf_match_the_scaffold_encoder(threads):
     """Reference site VCF + 1000-Genomes VCF -> (reference loci, AF per super population, allele-index bytes): the
