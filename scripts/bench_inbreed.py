@@ -13,7 +13,11 @@ t0 = time.perf_counter(); table = m.synth_multiallelic(1111, 0, 0); t_syn = time
 alg_bytes = int(capi.lib().kgx_gt8_sweep_bytes(G, L, 3))
 print(f"synth {t_syn:.2f}s; algorithmic bytes per frequency sweep: {alg_bytes/1e9:.2f} GB", flush=True)
 for algo in ("Simple", "RitlandLocus", "HallME", "Loglikelihood"):
-    if algo in ("HallME", "Loglikelihood") and G * L > 2e10 and "--all" not in sys.argv:
+    iterative = algo in ("HallME", "Loglikelihood")
+    if "--only-iterative" in sys.argv:
+        if not iterative:
+            continue
+    elif iterative and G * L > 2e10 and "--all" not in sys.argv:
         continue
     t0 = time.perf_counter(); res = m.inbreed(table, algo, phased=True); dt_first = time.perf_counter() - t0
     t0 = time.perf_counter(); res = m.inbreed(table, algo, phased=True); dt = time.perf_counter() - t0

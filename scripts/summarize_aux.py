@@ -62,6 +62,25 @@ Per call, in launch order (3 x all rows in one bin, then 2 x 11 FWS bins): {", "
 {k5_txt.strip()}
 ```
 """
+# optional: the iterative estimators (HallME, Loglikelihood) at C5, each called twice
+if (src / "k7.txt").exists() and glob.glob(str(src / "k7" / "*" / "*kernel_stats.csv")):
+    k7_rows = stats("k7")
+    md += f"""
+## K7 iterative estimators at C5 (10k x 5M multi-allelic; HallME then Loglikelihood, each called twice)
+
+Every `k_inbreed_eval_lut<1|2, ...>` launch is one pass over the genotype bytes of the genomes still iterating (all 10k for
+HallME; Loglikelihood compacts the columns of the genomes still searching, so its later launches are shorter and the
+GB/s column, which prices every launch at the full {k5_bytes / 1e9:.1f} GB, understates them).
+
+{table(k7_rows, k5_bytes, ["k_inbreed_sweep", "k_inbreed_eval_lut"])}
+
+Loglikelihood passes in launch order (ms): {", ".join(f"{ms:.1f}" for ms in calls("k7", "k_inbreed_eval_lut<2"))}
+
+```
+{(src / "k7.txt").read_text().strip()}
+```
+"""
+
 # optional: HBM fetch traffic of the K5 kernels (scripts/pmc_k5.sh "FETCH_SIZE" fetch), corrected as the K2 profile is
 pmc = glob.glob(str(ROOT / "gpurun_out" / "pmc_k5_fetch" / "*" / "*counter_collection.csv"))
 if pmc:
