@@ -9,7 +9,7 @@ import numpy as np
 ROOT = Path(__file__).resolve().parent.parent
 import os as _os
 
-LIB = Path(_os.environ.get("KGX_SANITIZED_HOST_LIB") or ROOT / "kgl_gene_amd" / "lib" / "libkgx_analysis.so")   # see scripts/sanitize_host.sh
+LIB = Path(_os.environ.get("KGX_SANITIZED_HOST_LIB") or ROOT / "kgl_gene_amd" / "lib" / "libkgx_analysis.so")   # see tests/tools/sanitize_host.sh
 _lib = None
 
 

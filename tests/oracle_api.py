@@ -13,7 +13,7 @@ import numpy as np
 ROOT = Path(__file__).resolve().parent.parent
 import os as _os
 
-# scripts/sanitize_host.sh points these at ASan/UBSan-instrumented builds of the same sources
+# tests/tools/sanitize_host.sh points these at ASan/UBSan-instrumented builds of the same sources
 LIB_PATH = Path(_os.environ.get("KGX_SANITIZED_ORACLE_LIB") or ROOT / "oracle" / "_build" / "libkgo.so")
 
 SUPER_POPS = ["AFR", "AMR", "EAS", "EUR", "SAS", "ALL"]

@@ -325,7 +325,7 @@ def test_flatteners_vs_oracle_over_seeds(seed):
 
 def test_flatteners_survive_mangled_text():
     """Robustness, not parity: truncated lines, deleted tabs, random bytes, missing header lines.  The flatteners must
-    return (possibly empty) populations, never crash or hang (scripts/sanitize_host.sh runs this under ASan/UBSan)."""
+    return (possibly empty) populations, never crash or hang (tests/tools/sanitize_host.sh runs this under ASan/UBSan)."""
     from .records_io import DATA_SOURCE
 
     rng = np.random.default_rng(99)

@@ -1,6 +1,6 @@
 """The phases of the path timed separately, oracle ("port" of the reference's CPU path:
 nested std::map store, HGVS string keys, uint8 dosage rows, one pool task per genome) beside the GPU sweeps on the same
-population, with parity checked in the same run.  Run on the GPU box:  python scripts/bench_cpu_phases.py [--md]
+population, with parity checked in the same run.  Run on the GPU box:  python tests/tools/bench_cpu_phases.py [--md]
 
 C1: 100 genomes x 50 k biallelic SNPs, one contig (the reference's own CPU-runnable case), in full.
 C2 slice: 1 000 genomes x 20 k of C2's 1 M SNPs through the same sparse store (the full 1 M needs ~4e8 Variant pointers);
@@ -13,7 +13,7 @@ from pathlib import Path
 
 import numpy as np
 
-sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent.parent))
 from kgl_gene_amd import capi                                    # noqa: E402
 from tests import inbreed_inputs as ii, oracle_api as oa, synth_vcf as sv   # noqa: E402
 

@@ -1,10 +1,10 @@
 """End-to-end GPU_INBREED from compressed VCF files through the package (C++ host code + the GPU), stage by stage on
 the host side, then the whole package run; and the oracle's parse-to-objects + window loop on a slice for scale.
-    python scripts/bench_inbreed_vcf.py [samples] [records]           (defaults 2504 x 40000: one 1000-Genomes-like chunk)"""
+    python tests/tools/bench_inbreed_vcf.py [samples] [records]           (defaults 2504 x 40000: one 1000-Genomes-like chunk)"""
 import os, subprocess, sys, tempfile, time
 from pathlib import Path
 import numpy as np
-sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent.parent))
 from tests import host_api as ha, oracle_api as oa, records_io as rio, synth_vcf as sv, vcf_text as vt
 
 G = int(sys.argv[1]) if len(sys.argv) > 1 else 2504

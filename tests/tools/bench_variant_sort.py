@@ -1,10 +1,10 @@
 """Host-side timing of the rsid / Ensembl indexes on columns (kgx_variant_sort.h) beside the oracle's restatement of
-VariantSort (node-per-entry maps over Variant objects) on the same VCF text.   python scripts/bench_variant_sort.py"""
+VariantSort (node-per-entry maps over Variant objects) on the same VCF text.   python tests/tools/bench_variant_sort.py"""
 import sys
 import time
 from pathlib import Path
 
-sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent.parent))
 from tests import host_api as H, oracle_api as O, test_variant_sort_cpu as T   # noqa: E402
 
 

@@ -2,7 +2,7 @@
 import sys, time
 from pathlib import Path
 import numpy as np
-sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent.parent))
 from tests import host_api as ha, oracle_api as oa, synth_vcf as sv, vcf_text as vt
 
 G = int(sys.argv[1]) if len(sys.argv) > 1 else 1000

@@ -1,8 +1,8 @@
 #!/bin/bash
 # AddressSanitizer + UBSan over the host-side C++ (flatteners, packages' host logic) and the oracle, CPU only:
-# builds instrumented copies under /tmp and runs the CPU tests that drive them.   bash scripts/sanitize_host.sh
+# builds instrumented copies under /tmp and runs the CPU tests that drive them.   bash tests/tools/sanitize_host.sh
 set -e
-ROOT=$(cd "$(dirname "$0")/.." && pwd)
+ROOT=$(cd "$(dirname "$0")/../.." && pwd)
 OUT=/tmp/kgx_san
 rm -rf $OUT && mkdir -p $OUT
 SAN="-O1 -g -fsanitize=address,undefined -fno-omit-frame-pointer -fno-sanitize-recover=undefined"
