@@ -153,12 +153,14 @@ static int count_by_genome_impl(kgx_pop* pop, const uint8_t* bin_of_variant, uin
   } else if (V > 0) {
     const uint32_t n_chunks = static_cast<uint32_t>((V + kBinChunk - 1) / kBinChunk);
     try_hip(hipMalloc(&d_bins, V), KGX_ENOMEM, "hipMalloc(bins)");
-    try_hip(hipMalloc(&d_index, V * sizeof(uint32_t)), KGX_ENOMEM, "hipMalloc(index)");
+    try_hip(hipMalloc(&d_index, (V + 8) * sizeof(uint32_t)), KGX_ENOMEM, "hipMalloc(index)");      // + 8: whole 8-entry scalar fetches
+    try_hip(hipMemsetAsync(d_index + V, 0, 8 * sizeof(uint32_t), st), KGX_EHIP, "memset(index pad)");
     try_hip(hipMalloc(&d_chunks, static_cast<uint64_t>(n_chunks) * n_bins * sizeof(uint32_t)), KGX_ENOMEM, "hipMalloc(chunk counts)");
     try_hip(hipMemcpyAsync(d_bins, bin_of_variant, V, hipMemcpyHostToDevice, st), KGX_EHIP, "H2D(bins)");
     if (rc == KGX_OK) {
       hipLaunchKernelGGL(k_bin_count, dim3(n_chunks), dim3(kBlock), 0, st, d_bins, V, n_bins, d_chunks);
-      hipLaunchKernelGGL(k_bin_scan, dim3(1), dim3(kMaxBins), 0, st, d_chunks, n_chunks, n_bins, d_nbin, d_binoff);
+      hipLaunchKernelGGL(k_bin_totals, dim3(n_bins), dim3(kBlock), 0, st, d_chunks, n_chunks, d_nbin);
+      hipLaunchKernelGGL(k_bin_scan, dim3(n_bins), dim3(kBlock), 0, st, d_chunks, n_chunks, n_bins, d_nbin, d_binoff);
       hipLaunchKernelGGL(k_bin_scatter, dim3(n_chunks), dim3(kBlock), 0, st, d_bins, V, n_bins, d_chunks, d_index);
       try_hip(hipGetLastError(), KGX_EHIP, "bin grouping kernels");
       try_hip(hipMemcpyAsync(bin_offset.data(), d_binoff, (n_bins + 1) * sizeof(unsigned long long), hipMemcpyDeviceToHost, st), KGX_EHIP, "D2H(bin offsets)");

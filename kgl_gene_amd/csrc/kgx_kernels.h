@@ -246,17 +246,36 @@ __device__ __forceinline__ void by_genome_pass(const kgx_v4u* __restrict__ rows,
     blocks = 0;
   };
 
-  for (uint64_t p0 = wk.begin + slot; p0 < wk.end; p0 += static_cast<uint64_t>(kRowSlots) * 8) {
+  // Gathered rows (the bins) with one row per wave-step slot (W == 64): a wave takes 8 CONSECUTIVE list positions per
+  // step, so their row numbers are one wave-uniform 32-byte scalar load -- on the scalar memory counter, where it does
+  // not queue behind the row loads already in flight as a per-lane index load would (vector memory returns in order).
+  // row_index is padded by 8 entries past the list.
+  const bool scalar_index = (W == kWave) && row_index != nullptr;
+  const uint32_t wave_slot = __builtin_amdgcn_readfirstlane(slot);
+  for (uint64_t p0 = wk.begin + slot; p0 - slot < wk.end; p0 += static_cast<uint64_t>(kRowSlots) * 8) {
     kgx_v4u x[8];
+    if (scalar_index) {
+      const uint64_t base = (p0 - slot) + static_cast<uint64_t>(wave_slot) * 8;     // wave-uniform
+      uint32_t r[8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const uint64_t p = p0 + static_cast<uint64_t>(j) * kRowSlots;
-      kgx_v4u v = {0u, 0u, 0u, 0u};
-      if (p < wk.end && col_ok) {
-        const uint64_t r = row_index ? static_cast<uint64_t>(row_index[p]) : p;
-        v = __builtin_nontemporal_load(rows + r * chunks_per_row + col);
+      for (int j = 0; j < 8; ++j) r[j] = row_index[base + j];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        kgx_v4u v = {0u, 0u, 0u, 0u};
+        if (base + j < wk.end && col_ok) v = __builtin_nontemporal_load(rows + static_cast<uint64_t>(r[j]) * chunks_per_row + col);
+        x[j] = v;
       }
-      x[j] = v;
+    } else {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const uint64_t p = p0 + static_cast<uint64_t>(j) * kRowSlots;
+        kgx_v4u v = {0u, 0u, 0u, 0u};
+        if (p < wk.end && col_ok) {
+          const uint64_t r = row_index ? static_cast<uint64_t>(row_index[p]) : p;
+          v = __builtin_nontemporal_load(rows + r * chunks_per_row + col);
+        }
+        x[j] = v;
+      }
     }
     if constexpr (MODE == 0) {
 #pragma unroll
@@ -366,31 +385,53 @@ k_bin_count(const uint8_t* __restrict__ bin_of_row, uint64_t n_rows, uint32_t n_
 }
 
 // Exclusive scan of chunk_counts in (bin-major, chunk) order; rows_in_bin[b] and bin_offset[b] as by-products.
-// One thread per bin walks its chunks (n_chunks is a few thousand); bins are then chained by thread 0.
-__global__ void __launch_bounds__(kMaxBins)
-k_bin_scan(uint32_t* __restrict__ chunk_counts, uint32_t n_chunks, uint32_t n_bins, unsigned long long* __restrict__ rows_in_bin,
+// Two small launches of one workgroup per bin: totals first, then every workgroup chains the bins before it (n_bins
+// adds) and scans its own chunks, a contiguous run of chunks per thread with the runs' sums scanned in LDS.
+__global__ void __launch_bounds__(kBlock)
+k_bin_totals(const uint32_t* __restrict__ chunk_counts, uint32_t n_chunks, unsigned long long* __restrict__ rows_in_bin) {
+  __shared__ unsigned long long part[kBlock / kWave];
+  const uint32_t b = blockIdx.x;
+  unsigned long long t = 0;
+  for (uint32_t c = threadIdx.x; c < n_chunks; c += kBlock) t += chunk_counts[static_cast<uint64_t>(b) * n_chunks + c];
+  for (int off = 32; off > 0; off >>= 1) t += __shfl_xor(t, off);
+  if ((threadIdx.x & (kWave - 1)) == 0) part[threadIdx.x / kWave] = t;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    unsigned long long total = 0;
+    for (int w = 0; w < kBlock / kWave; ++w) total += part[w];
+    rows_in_bin[b] = total;
+  }
+}
+
+__global__ void __launch_bounds__(kBlock)
+k_bin_scan(uint32_t* __restrict__ chunk_counts, uint32_t n_chunks, uint32_t n_bins, const unsigned long long* __restrict__ rows_in_bin,
            unsigned long long* __restrict__ bin_offset) {
-  __shared__ unsigned long long total[kMaxBins];
-  const uint32_t b = threadIdx.x;
-  if (b < n_bins) {
-    unsigned long long t = 0;
-    for (uint32_t c = 0; c < n_chunks; ++c) t += chunk_counts[static_cast<uint64_t>(b) * n_chunks + c];
-    total[b] = t;
+  __shared__ unsigned long long run_sum[kBlock];
+  const uint32_t b = blockIdx.x;
+  unsigned long long base = 0;
+  for (uint32_t k = 0; k < b; ++k) base += rows_in_bin[k];
+  if (threadIdx.x == 0) {
+    bin_offset[b] = base;
+    if (b + 1 == n_bins) bin_offset[n_bins] = base + rows_in_bin[b];
+  }
+  const uint32_t per_thread = (n_chunks + kBlock - 1) / kBlock;
+  const uint32_t c0 = threadIdx.x * per_thread;
+  const uint32_t c1 = c0 + per_thread < n_chunks ? c0 + per_thread : n_chunks;
+  uint32_t* mine = chunk_counts + static_cast<uint64_t>(b) * n_chunks;
+  unsigned long long t = 0;
+  for (uint32_t c = c0; c < c1; ++c) t += mine[c];
+  run_sum[threadIdx.x] = t;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    unsigned long long run = base;
+    for (int i = 0; i < kBlock; ++i) { const unsigned long long v = run_sum[i]; run_sum[i] = run; run += v; }
   }
   __syncthreads();
-  if (b == 0) {
-    unsigned long long off = 0;
-    for (uint32_t k = 0; k < n_bins; ++k) { bin_offset[k] = off; rows_in_bin[k] = total[k]; off += total[k]; }
-    bin_offset[n_bins] = off;
-  }
-  __syncthreads();
-  if (b < n_bins) {
-    unsigned long long run = bin_offset[b];
-    for (uint32_t c = 0; c < n_chunks; ++c) {
-      const uint32_t v = chunk_counts[static_cast<uint64_t>(b) * n_chunks + c];
-      chunk_counts[static_cast<uint64_t>(b) * n_chunks + c] = static_cast<uint32_t>(run);   // < 2^32 rows in total
-      run += v;
-    }
+  unsigned long long run = run_sum[threadIdx.x];
+  for (uint32_t c = c0; c < c1; ++c) {
+    const uint32_t v = mine[c];
+    mine[c] = static_cast<uint32_t>(run);   // < 2^32 rows in total
+    run += v;
   }
 }
 
