@@ -9,8 +9,14 @@ tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
 src = ROOT / "gpurun_out" / f"prof_{tag}_aux"
 dst = ROOT / "profiles"
 
+def newest(files):
+    """gpurun merges every run's files into the same local directory: keep the latest run's."""
+    import os
+    return sorted(files, key=os.path.getmtime, reverse=True)
+
+
 def stats(sub):
-    files = glob.glob(str(src / sub / "*" / "*kernel_stats.csv"))
+    files = newest(glob.glob(str(src / sub / "*" / "*kernel_stats.csv")))
     if not files:
         sys.exit(f"missing kernel_stats.csv under {src / sub}")
     text = Path(files[0]).read_text()
@@ -19,7 +25,7 @@ def stats(sub):
 
 def calls(sub, needle):
     """Per-call durations (ms) of the kernels whose name contains needle, in launch order."""
-    files = glob.glob(str(src / sub / "*" / "*kernel_trace.csv"))
+    files = newest(glob.glob(str(src / sub / "*" / "*kernel_trace.csv")))
     rows = [r for r in csv.DictReader(open(files[0])) if needle in r["Kernel_Name"]]
     rows.sort(key=lambda r: int(r["Start_Timestamp"]))
     return [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6 for r in rows]
