@@ -758,7 +758,7 @@ k_inbreed_sweep(const uint32_t* __restrict__ gt, uint64_t dwords_per_row, uint64
 //           (segment, genome) is taken at the end: sum(log p) = log(prod p).
 //   MODE 1  v = the denominator F + (1-F)*f1 of a homozygous cell: y = f1, d = 1 - f1; every other cell (1, 0), i.e.
 //           v = 1 exactly.  The terms 1/v of ALL cells of a batch are summed as one fraction N/D (N <- N*v + D,
-//           D <- D*v; one division per batch), so part[] holds  sum_hom 1/v + #(other cells the lane walked);
+//           D <- D*v; one division per kHallBatches batches), so part[] holds  sum_hom 1/v + #(other cells the lane walked);
 //           k_hall_update subtracts that count (it is known: loci walked - homozygous cells counted by the frequency
 //           sweep) and multiplies by F.  The reference's zero-denominator guard (_calc.cpp:272) can only fire at
 //           F = 0, where every term F/v is 0: such a genome is walked with F = 1 (v = 1 everywhere) and the
@@ -775,6 +775,7 @@ k_inbreed_sweep(const uint32_t* __restrict__ gt, uint64_t dwords_per_row, uint64
 // table build, so there is no early return.
 struct alignas(16) EvalEntry { double y, d; };
 constexpr int kEvalBatch = 8;
+constexpr int kHallBatches = 8;    // MODE 1: batches summed as one fraction before the division
 constexpr uint32_t kEvalSlots = 160;
 
 // Only the (amax+1)^2 entries whose two allele indices are <= amax can ever be classified; the rest of the 160 are
@@ -871,6 +872,7 @@ k_inbreed_eval_lut(const uint32_t* __restrict__ gt, uint64_t dwords_per_row, uin
   build_eval_table<MODE, BITS>(lut[0], rows[0], flags[0], stride, amax, phased != 0);
   __syncthreads();
   int buf = 0;
+  int batches_open = 0;            // batches since the running fraction / product was last closed
   for (uint64_t s0 = s_begin; s0 < s_end; s0 += kEvalBatch, buf ^= 1) {
     uint32_t w[kEvalBatch][DW];
 #pragma unroll
@@ -922,17 +924,26 @@ k_inbreed_eval_lut(const uint32_t* __restrict__ gt, uint64_t dwords_per_row, uin
           }
         }
       }
+      // MODE 1: the fraction N/D runs on over up to kHallBatches batches before its one division -- the division is a
+      // dozen fp64 instructions, a quarter of the pass when taken every 8 cells.  D is a product of denominators
+      // F + (1-F)*f1 <= 1 and shrinks; a lane whose D has fallen below 1e-100 divides at once (8 more factors would
+      // have to average 1e-26 to take it under).  The last batch of the segment always divides.
+      const bool closing = s0 + kEvalBatch >= s_end;            // block-uniform
+      ++batches_open;
 #pragma unroll
       for (int j = 0; j < GPL; ++j) {
         if constexpr (MODE == 2) {                          // 8 factors >= 1e-10: no underflow before the exponent is peeled
           expo[j] += __builtin_amdgcn_frexp_exp(run_a[j]);
           run_a[j] = __builtin_amdgcn_frexp_mant(run_a[j]);
         } else if constexpr (MODE == 1) {
-          acc[j] += run_a[j] / run_b[j];
-          run_a[j] = 0.0;
-          run_b[j] = 1.0;
+          if (closing || batches_open >= kHallBatches || run_b[j] < 1e-100) {
+            acc[j] += run_a[j] / run_b[j];
+            run_a[j] = 0.0;
+            run_b[j] = 1.0;
+          }
         }
       }
+      if (closing || batches_open >= kHallBatches) batches_open = 0;
     }
     stash(buf);          // rows[buf] fed this batch's table one iteration ago: free for the batch after next
     __syncthreads();
