@@ -98,9 +98,27 @@ def vcf_cases():
     np.savez_compressed(HERE / "vcf_cases.npz", **out)
 
 
+def variant_sort_case():
+    """VCF text in, the rsid / Ensembl indexes out (the oracle's restatement of VariantSort), as tab-joined lines."""
+    from tests import test_variant_sort_cpu as ts
+
+    out = {}
+    for flavour in ("MonoGenome", "Genome1000"):
+        text = ts.sort_vcf(21, flavour, n_records=120, n_samples=7)
+        population = ts.oracle_population(text, flavour)
+        out[f"{flavour}_text"] = np.array([text])
+        for what in ts.KINDS_ALL:
+            out[f"{flavour}_{what}"] = np.array(["\t".join(row) for row in population.variant_sort(what)])
+        listed = [ts.GENES[0], ts.GENES[2], ts.GENES[0]]
+        out[f"{flavour}_filter_list"] = np.array(listed)
+        out[f"{flavour}_filter"] = np.array(["\t".join(row) for row in population.variant_sort("filter", listed)])
+    np.savez_compressed(HERE / "variant_sort.npz", **out)
+
+
 if __name__ == "__main__":
     allele_case()
     inbreed_case()
     vcf_cases()
+    variant_sort_case()
     for f in sorted(HERE.glob("*.npz")):
         print(f.name, f.stat().st_size, "bytes")

@@ -80,6 +80,26 @@ def test_pf_vcf_flattener_matches_golden():
     assert np.array_equal(vdb.dosage(), g["pf_raw_dosage"])
 
 
+def test_variant_sort_indexes_match_golden():
+    """CPU: the rsid / Ensembl indexes on columns against the committed oracle outputs for a committed VCF text; and the
+    oracle still reproduces them."""
+    from . import host_api as ha
+    from . import test_variant_sort_cpu as ts
+
+    g = np.load(GOLD / "variant_sort.npz")
+    for flavour in ("MonoGenome", "Genome1000"):
+        text = str(g[f"{flavour}_text"][0])
+        population = ts.oracle_population(text, flavour)
+        for what in ts.KINDS_ALL:
+            want = [tuple(line.split("\t")) for line in g[f"{flavour}_{what}"].tolist()]
+            assert ha.variant_sort(text, flavour, what, threads=2) == want, (flavour, what)
+            assert population.variant_sort(what) == want, (flavour, what)
+            assert what == "non_ensembl" or len(want) > 10
+        listed = g[f"{flavour}_filter_list"].tolist()
+        want = [tuple(line.split("\t")) for line in g[f"{flavour}_filter"].tolist()]
+        assert ha.variant_sort(text, flavour, "filter", listed) == want and len(want) > 0
+
+
 @pytest.mark.gpu
 def test_gpu_inbreed_from_vcf_matches_golden(kgx, tmp_path):
     """GPU: GPU_INBREED fed the two committed VCF texts reproduces the committed oracle window (Simple)."""
