@@ -141,8 +141,14 @@ bool isSnp(std::string_view ref, std::string_view alt) {   // Variant::isSNP (kg
 
 struct RecordRows {            // what one VCF record contributes
   std::vector<VariantRow> rows;          // one per alt
-  std::vector<uint8_t> copies;           // [n_alt][n_samples] copies of the alt in the sample (0..2)
+  std::vector<uint8_t> copies;           // [n_alt][ceil(n_samples / 4)] copies of the alt in the sample (0..2), 2 bits each
 };
+// A sample column calls at most two alleles, so a 2-bit field never carries into its neighbour.
+inline size_t copyRowBytes(size_t n_samples) { return (n_samples + 3) / 4; }
+inline void addCopy(uint8_t* copies, size_t row_bytes, size_t alt, size_t sample) {
+  copies[alt * row_bytes + (sample >> 2)] = static_cast<uint8_t>(copies[alt * row_bytes + (sample >> 2)] + (1u << (2 * (sample & 3))));
+}
+inline uint32_t copyAt(const uint8_t* row, size_t sample) { return (row[sample >> 2] >> (2 * (sample & 3))) & 3u; }
 
 struct VcfLines {
   std::vector<std::string> samples;            // #CHROM columns 10..
@@ -221,18 +227,21 @@ FlatPopulation mergeRecords(const std::vector<RecordRows>& parsed, const std::ve
 
   // Genomes: every sample (the Pf parser creates them up front) or only carriers (the 1000-Genomes parser creates a
   // genome when it first adds a variant to it); std::map order.
+  const size_t SB = copyRowBytes(S);
   std::vector<uint8_t> carries(S, every_sample ? 1 : 0);
   if (!every_sample) {
     std::mutex merge_mutex;
+    std::vector<uint8_t> any_copy(SB, 0);             // the packed rows OR-ed together: a field is non-zero iff the sample carries something
     parallelChunks(parsed.size(), 64, threads, [&](size_t begin, size_t end) {
-      std::vector<uint8_t> local(S, 0);
+      std::vector<uint8_t> local(SB, 0);
       for (size_t r = begin; r < end; ++r) {
         const auto& copies = parsed[r].copies;
-        for (size_t i = 0, s = 0; i < copies.size(); ++i, s = (s + 1 == S ? 0 : s + 1)) local[s] |= copies[i];
+        for (size_t i = 0, b = 0; i < copies.size(); ++i, b = (b + 1 == SB ? 0 : b + 1)) local[b] |= copies[i];
       }
       std::lock_guard<std::mutex> lock(merge_mutex);
-      for (size_t s = 0; s < S; ++s) carries[s] |= local[s] ? 1 : 0;
+      for (size_t b = 0; b < SB; ++b) any_copy[b] |= local[b];
     });
+    for (size_t smp = 0; smp < S; ++smp) carries[smp] = copyAt(any_copy.data(), smp) ? 1 : 0;
   }
   std::vector<uint32_t> sample_order;
   for (uint32_t s = 0; s < S; ++s) if (carries[s]) sample_order.push_back(s);
@@ -269,9 +278,9 @@ FlatPopulation mergeRecords(const std::vector<RecordRows>& parsed, const std::ve
       std::fill(total.begin(), total.end(), 0u);
       bool any = false;
       for (size_t m = k; m < e; ++m) {
-        const uint8_t* c = &parsed[keys[m].record].copies[static_cast<size_t>(keys[m].alt) * S];
+        const uint8_t* c = &parsed[keys[m].record].copies[static_cast<size_t>(keys[m].alt) * SB];
         bool here = false;
-        for (size_t s = 0; s < S; ++s) { total[s] += c[s]; here = here || c[s]; }
+        for (size_t smp = 0; smp < S; ++smp) { const uint32_t n = copyAt(c, smp); total[smp] += n; here = here || n; }
         // the Variant kept for an HGVS is the first one added (uniqueVariants): the first record that has a carrier
         if (here && !any) { any = true; first_key[grp] = m; }
       }
@@ -281,8 +290,8 @@ FlatPopulation mergeRecords(const std::vector<RecordRows>& parsed, const std::ve
         // records in different FWS bins: one split row per bin, holding that bin's copies only
         std::map<uint8_t, std::vector<size_t>> by_bin;
         for (size_t m = k; m < e; ++m) {
-          const uint8_t* c = &parsed[keys[m].record].copies[static_cast<size_t>(keys[m].alt) * S];
-          if (std::any_of(c, c + S, [](uint8_t x) { return x != 0; })) by_bin[fwsBinOfFrequency(parsed[keys[m].record].rows[keys[m].alt].info_af)].push_back(m);
+          const uint8_t* c = &parsed[keys[m].record].copies[static_cast<size_t>(keys[m].alt) * SB];
+          if (std::any_of(c, c + SB, [](uint8_t x) { return x != 0; })) by_bin[fwsBinOfFrequency(parsed[keys[m].record].rows[keys[m].alt].info_af)].push_back(m);
         }
         if (by_bin.size() > 1) {
           for (const auto& [bin, members] : by_bin) {
@@ -290,8 +299,8 @@ FlatPopulation mergeRecords(const std::vector<RecordRows>& parsed, const std::ve
             Split split{grp, members.front(), std::vector<uint8_t>(flat.row_bytes, 0)};
             std::fill(total.begin(), total.end(), 0u);
             for (size_t m : members) {
-              const uint8_t* c = &parsed[keys[m].record].copies[static_cast<size_t>(keys[m].alt) * S];
-              for (size_t s = 0; s < S; ++s) total[s] += c[s];
+              const uint8_t* c = &parsed[keys[m].record].copies[static_cast<size_t>(keys[m].alt) * SB];
+              for (size_t smp = 0; smp < S; ++smp) total[smp] += copyAt(c, smp);
             }
             for (size_t g = 0; g < G; ++g) {
               uint32_t d = 0;
@@ -303,8 +312,8 @@ FlatPopulation mergeRecords(const std::vector<RecordRows>& parsed, const std::ve
           // restore the group's totals for the primary row below
           std::fill(total.begin(), total.end(), 0u);
           for (size_t m = k; m < e; ++m) {
-            const uint8_t* c = &parsed[keys[m].record].copies[static_cast<size_t>(keys[m].alt) * S];
-            for (size_t s = 0; s < S; ++s) total[s] += c[s];
+            const uint8_t* c = &parsed[keys[m].record].copies[static_cast<size_t>(keys[m].alt) * SB];
+            for (size_t smp = 0; smp < S; ++smp) total[smp] += copyAt(c, smp);
           }
           carried[grp] = 2;                             // primary row's bin counts come from its splits
         }
@@ -388,7 +397,8 @@ FlatPopulation flattenVcf1000(std::string_view text, size_t threads) {
     bool af_bad_size = false;
     readInfoAf(f[7], A, af, af_bad_size);
     out.rows.resize(A);
-    out.copies.assign(A * S, 0);
+    const size_t SB = copyRowBytes(S);
+    out.copies.assign(A * SB, 0);
     for (size_t a = 0; a < A; ++a) {
       VariantRow& row = out.rows[a];
       row.contig = std::string(contig);
@@ -402,8 +412,8 @@ FlatPopulation flattenVcf1000(std::string_view text, size_t threads) {
     for (size_t idx = 9; idx < f.size() && idx - 9 < S; ++idx) {
       uint32_t pa, pb;
       phasedAlleles(f[idx], A, chrom, pa, pb);
-      if (pa) ++copies[(pa - 1) * S + (idx - 9)];
-      if (pb) ++copies[(pb - 1) * S + (idx - 9)];
+      if (pa) addCopy(copies, SB, pa - 1, idx - 9);
+      if (pb) addCopy(copies, SB, pb - 1, idx - 9);
     }
   });
   lap("parse records");
@@ -521,7 +531,8 @@ FlatPopulation flattenVcfPf(std::string_view text, size_t threads, bool quality_
     bool af_bad_size = false;
     readInfoAf(f[7], A, af, af_bad_size);
     out.rows.resize(A);
-    out.copies.assign(A * S, 0);
+    const size_t SB = copyRowBytes(S);
+    out.copies.assign(A * SB, 0);
     for (size_t a = 0; a < A; ++a) {
       VariantRow& row = out.rows[a];
       std::string c_ref, c_alt;
@@ -570,7 +581,7 @@ FlatPopulation flattenVcfPf(std::string_view text, size_t threads, bool quality_
         if (allele < 0 || static_cast<uint64_t>(allele) > A || static_cast<uint64_t>(allele) >= depth.size()) continue;
         if (alts[allele - 1] == "*") continue;                        // upstream deletion
         if (depth[0] == 0 && depth[allele] == 0) continue;            // the spanning ("downstream") call of one
-        ++copies[(allele - 1) * S + (idx - 9)];
+        addCopy(copies, SB, static_cast<size_t>(allele - 1), idx - 9);
       }
     }
   });
