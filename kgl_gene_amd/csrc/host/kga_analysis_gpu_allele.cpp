@@ -83,17 +83,20 @@ bool kga::GpuAlleleAnalysis::sweepPopulation(const PopulationDB& population) {
 }
 
 bool kga::GpuAlleleAnalysis::sweepVcfFile(const std::string& file_name) {
-  std::string text, io_error;
-  if (!gpu::readVcfText(file_name, text, io_error)) {                // plain text, .gz or .bgz
-    ExecEnv::log().error("GpuAlleleAnalysis; {}", io_error);
-    return false;
-  }
-  if (vcf_flavour_ == "Genome1000") return sweepFlat(gpu::flattenVcf1000(text), file_name);
-  if (vcf_flavour_ != "Falciparum") {
+  // plain text, .gz or .bgz, read and flattened a bounded piece at a time: the text never has to fit in memory
+  std::string io_error;
+  gpu::FlatPopulation flat;
+  if (vcf_flavour_ != "Genome1000" && vcf_flavour_ != "Falciparum") {
     ExecEnv::log().error("GpuAlleleAnalysis; unknown VcfFlavour: {} (Genome1000 or Falciparum)", vcf_flavour_);
     return false;
   }
-  const gpu::FlatPopulation flat = gpu::flattenVcfPf(text, 0, pf7_quality_filter_);
+  const bool read_ok = vcf_flavour_ == "Genome1000" ? gpu::flattenVcf1000File(file_name, flat, io_error)
+                                                    : gpu::flattenVcfPfFile(file_name, flat, io_error, 0, pf7_quality_filter_);
+  if (!read_ok) {
+    ExecEnv::log().error("GpuAlleleAnalysis; {}", io_error);
+    return false;
+  }
+  if (vcf_flavour_ == "Genome1000") return sweepFlat(flat, file_name);
   // every genome holds every contig of the header, carrier or not (PfVCFImpl::setupPopulationStructure): zero records
   for (const auto& genome_id : flat.genome_ids) {
     auto& contig_map = variant_analysis_map_[genome_id];

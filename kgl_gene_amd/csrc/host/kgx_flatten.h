@@ -73,6 +73,14 @@ struct FlatPopulation {
 // against the reference genome's sequence (ParseVCFRecord) -- the VCF is taken at its word.
 [[nodiscard]] FlatPopulation flattenVcfPf(std::string_view text, size_t threads = 0, bool quality_filter = false);
 
+// The same two straight from a file (plain / gzip / block gzip), read a bounded piece of whole lines at a time
+// (VcfChunkReader, kgx_vcf_io.h): a piece's text is dropped once its records are parsed into 2-bit rows, so the working
+// set is the genotypes, not the text.  chunk_bytes = text per piece.  false + error on an I/O or format error.
+[[nodiscard]] bool flattenVcf1000File(const std::string& file_name, FlatPopulation& flat, std::string& error, size_t threads = 0,
+                                      size_t chunk_bytes = size_t{64} << 20);
+[[nodiscard]] bool flattenVcfPfFile(const std::string& file_name, FlatPopulation& flat, std::string& error, size_t threads = 0,
+                                    bool quality_filter = false, size_t chunk_bytes = size_t{64} << 20);
+
 // ---- the INBREED package's two inputs straight from VCF text (SURVEY.md §8f #1 for the K5 path) ------------------
 //
 // The unphased mono-genome reference (Gnomad / 1000-Genomes site files; GrchVCFImpl::ProcessVCFRecord,

@@ -26,6 +26,24 @@ void* kgxh_flatten_vcf_pf(const char* text, uint64_t len, int threads, int quali
   return new FlatPopulation(kellerberrin::genome::analysis::gpu::flattenVcfPf(std::string_view(text, len), threads > 0 ? threads : 0, quality_filter != 0));
 }
 
+// The same from a file, a bounded piece of text at a time (chunk_bytes of text per piece; 0 = the default 64 MiB).
+// flavour 0 = 1000 Genomes, 1 = P. falciparum.  Null + message on an I/O or format error.
+void* kgxh_flatten_vcf_file(const char* path, int flavour, int threads, int quality_filter, uint64_t chunk_bytes, char* error, size_t error_len) {
+  if (!path) return nullptr;
+  namespace g = kellerberrin::genome::analysis::gpu;
+  auto* flat = new FlatPopulation();
+  std::string err;
+  const size_t piece = chunk_bytes ? static_cast<size_t>(chunk_bytes) : (size_t{64} << 20);
+  const bool ok = flavour == 0 ? g::flattenVcf1000File(path, *flat, err, threads > 0 ? threads : 0, piece)
+                               : g::flattenVcfPfFile(path, *flat, err, threads > 0 ? threads : 0, quality_filter != 0, piece);
+  if (!ok) {
+    if (error && error_len) { std::strncpy(error, err.c_str(), error_len - 1); error[error_len - 1] = 0; }
+    delete flat;
+    return nullptr;
+  }
+  return flat;
+}
+
 void kgxh_flat_destroy(void* h) { delete static_cast<FlatPopulation*>(h); }
 uint64_t kgxh_flat_genomes(void* h) { return h ? static_cast<FlatPopulation*>(h)->genomes() : 0; }
 uint64_t kgxh_flat_variants(void* h) { return h ? static_cast<FlatPopulation*>(h)->variants() : 0; }

@@ -31,6 +31,7 @@
 
 #include "kgx_flatten.h"
 #include "kgx_variant_sort.h"
+#include "kgx_vcf_io.h"
 
 namespace kellerberrin::genome::analysis::gpu {
 
@@ -369,7 +370,18 @@ void readInfoAf(std::string_view info, size_t A, std::vector<float>& af, bool& a
 
 }  // namespace
 
-FlatPopulation flattenVcf1000(std::string_view text, size_t threads) {
+namespace {
+
+// Append b's records to a (a run of whole lines at a time: the text of a piece is gone once its records are parsed).
+void appendRecords(std::vector<RecordRows>& a, std::vector<RecordRows>&& b) {
+  if (a.empty()) { a = std::move(b); return; }
+  a.insert(a.end(), std::make_move_iterator(b.begin()), std::make_move_iterator(b.end()));
+}
+
+// next(text): the next run of whole lines of the file, false when there is none.  The sample names are those of the
+// first piece that holds a #CHROM line (the header precedes the records).
+template <typename NextChunk>
+FlatPopulation flattenVcf1000Chunks(NextChunk&& next, size_t threads) {
   const bool trace = std::getenv("KGX_FLATTEN_TRACE") != nullptr;
   auto t_last = std::chrono::steady_clock::now();
   auto lap = [&](const char* what) {
@@ -378,10 +390,15 @@ FlatPopulation flattenVcf1000(std::string_view text, size_t threads) {
     std::fprintf(stderr, "kgx flattenVcf1000: %s %.3f s\n", what, std::chrono::duration<double>(now - t_last).count());
     t_last = now;
   };
+  std::vector<std::string> samples;
+  std::vector<RecordRows> all_parsed;
+  std::string_view text;
+  while (next(text)) {
   const VcfLines lines = scanLines(text);
   lap("scan lines");
-  const size_t S = lines.samples.size();
-  const auto parsed = parseRecords(lines, threads, [&](std::string_view record, RecordRows& out) {
+  if (samples.empty()) samples = lines.samples;
+  const size_t S = samples.size();
+  auto parsed = parseRecords(lines, threads, [&](std::string_view record, RecordRows& out) {
     const auto f = split(record, '\t', S + 10);
     if (f.size() < 8) return;                                      // fewer than the mandatory fields: record dropped
     const std::string_view contig = f[0];
@@ -417,9 +434,41 @@ FlatPopulation flattenVcf1000(std::string_view text, size_t threads) {
     }
   });
   lap("parse records");
-  FlatPopulation flat = mergeRecords(parsed, lines.samples, false, threads);
+  appendRecords(all_parsed, std::move(parsed));
+  }
+  FlatPopulation flat = mergeRecords(all_parsed, samples, false, threads);
   lap("merge");
   return flat;
+}
+
+// One piece: the whole text.
+struct WholeText {
+  std::string_view text;
+  bool given{false};
+  bool operator()(std::string_view& out) { if (given) return false; given = true; out = text; return true; }
+};
+
+// Pieces of a file; an I/O or format error ends the run and is kept.
+struct FilePieces {
+  VcfChunkReader reader;
+  std::string piece, error;
+  bool operator()(std::string_view& out) {
+    if (!error.empty() || !reader.next(piece, error)) return false;
+    out = piece;
+    return true;
+  }
+};
+
+}  // namespace
+
+FlatPopulation flattenVcf1000(std::string_view text, size_t threads) { return flattenVcf1000Chunks(WholeText{text}, threads); }
+
+bool flattenVcf1000File(const std::string& file_name, FlatPopulation& flat, std::string& error, size_t threads, size_t chunk_bytes) {
+  FilePieces pieces;
+  if (!pieces.reader.open(file_name, error, threads, chunk_bytes)) return false;
+  flat = flattenVcf1000Chunks(pieces, threads);
+  error = pieces.error;
+  return error.empty();
 }
 
 namespace {
@@ -505,10 +554,19 @@ bool passesP7VariantFilter(std::string_view info, std::string_view contig) {
 
 }  // namespace
 
-FlatPopulation flattenVcfPf(std::string_view text, size_t threads, bool quality_filter) {
+namespace {
+
+template <typename NextChunk>
+FlatPopulation flattenVcfPfChunks(NextChunk&& next, size_t threads, bool quality_filter) {
+  std::vector<std::string> samples, contigs;
+  std::vector<RecordRows> all_parsed;
+  std::string_view text;
+  while (next(text)) {
   const VcfLines lines = scanLines(text);
-  const size_t S = lines.samples.size();
-  const auto parsed = parseRecords(lines, threads, [&](std::string_view record, RecordRows& out) {
+  if (samples.empty()) samples = lines.samples;
+  contigs.insert(contigs.end(), lines.contigs.begin(), lines.contigs.end());
+  const size_t S = samples.size();
+  auto parsed = parseRecords(lines, threads, [&](std::string_view record, RecordRows& out) {
     const auto f = split(record, '\t', S + 10);
     if (f.size() < 9) return;
     const std::string_view contig = f[0];
@@ -585,9 +643,23 @@ FlatPopulation flattenVcfPf(std::string_view text, size_t threads, bool quality_
       }
     }
   });
-  FlatPopulation flat = mergeRecords(parsed, lines.samples, true, threads);
-  flat.contig_ids = lines.contigs;
+  appendRecords(all_parsed, std::move(parsed));
+  }
+  FlatPopulation flat = mergeRecords(all_parsed, samples, true, threads);
+  flat.contig_ids = contigs;
   return flat;
+}
+
+}  // namespace
+
+FlatPopulation flattenVcfPf(std::string_view text, size_t threads, bool quality_filter) { return flattenVcfPfChunks(WholeText{text}, threads, quality_filter); }
+
+bool flattenVcfPfFile(const std::string& file_name, FlatPopulation& flat, std::string& error, size_t threads, bool quality_filter, size_t chunk_bytes) {
+  FilePieces pieces;
+  if (!pieces.reader.open(file_name, error, threads, chunk_bytes)) return false;
+  flat = flattenVcfPfChunks(pieces, threads, quality_filter);
+  error = pieces.error;
+  return error.empty();
 }
 
 // ---- INBREED inputs ----------------------------------------------------------------------------------------------

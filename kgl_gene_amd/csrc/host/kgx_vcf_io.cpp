@@ -140,4 +140,183 @@ bool readVcfText(const std::string& file_name, std::string& text, std::string& e
   return true;
 }
 
+// ---- bounded pieces ---------------------------------------------------------------------------------------------------
+
+struct VcfChunkReader::State {
+  enum class Kind { Plain, Gzip, BlockGzip } kind{Kind::Plain};
+  std::ifstream in;
+  std::string file_name;
+  size_t threads{1};
+  size_t chunk_bytes{0};
+  bool source_done{false};
+  std::string carry;            // the incomplete last line of the previous piece
+  std::string raw;              // compressed bytes read but not yet consumed (block gzip: a partial block; gzip: input window)
+  z_stream zs;                  // plain gzip
+  bool zs_open{false};
+  size_t zs_in_at{0};           // consumed prefix of raw
+
+  // Append up to `want` bytes of the file to raw; false when nothing was left.
+  bool readMore(size_t want) {
+    const size_t had = raw.size();
+    raw.resize(had + want);
+    in.read(&raw[had], static_cast<std::streamsize>(want));
+    const size_t got = static_cast<size_t>(in.gcount());
+    raw.resize(had + got);
+    return got > 0;
+  }
+};
+
+VcfChunkReader::VcfChunkReader() : state_(new State()) {}
+VcfChunkReader::~VcfChunkReader() {
+  if (state_->zs_open) inflateEnd(&state_->zs);
+  delete state_;
+}
+
+bool VcfChunkReader::open(const std::string& file_name, std::string& error, size_t threads, size_t chunk_bytes) {
+  State& st = *state_;
+  st.in.open(file_name, std::ios::binary);
+  if (!st.in.good()) { error = "cannot open file: " + file_name; return false; }
+  st.file_name = file_name;
+  st.threads = threads ? threads : std::max<size_t>(std::thread::hardware_concurrency(), 2) - 1;
+  st.chunk_bytes = std::max<size_t>(chunk_bytes, 1);
+  st.readMore(1 << 16);
+  const auto* p = reinterpret_cast<const unsigned char*>(st.raw.data());
+  if (st.raw.size() < 2 || p[0] != 31 || p[1] != 139) {
+    st.kind = State::Kind::Plain;
+  } else {
+    // a first member with the "BC" subfield is block gzip; every later member must be one too
+    bool bgzf = st.raw.size() >= 18 && p[2] == 8 && p[3] == 4;
+    if (bgzf) {
+      const size_t xlen = le16(p + 10);
+      bgzf = false;
+      for (size_t x = 12; x + 4 <= 12 + xlen && x + 4 <= st.raw.size();) {
+        const size_t len = le16(p + x + 2);
+        if (p[x] == 'B' && p[x + 1] == 'C' && len == 2) bgzf = true;
+        x += 4 + len;
+      }
+    }
+    st.kind = bgzf ? State::Kind::BlockGzip : State::Kind::Gzip;
+    if (!bgzf) {
+      std::memset(&st.zs, 0, sizeof(st.zs));
+      if (inflateInit2(&st.zs, 15 + 16) != Z_OK) { error = "zlib initialisation failed"; return false; }
+      st.zs_open = true;
+    }
+  }
+  return true;
+}
+
+bool VcfChunkReader::next(std::string& text, std::string& error) {
+  State& st = *state_;
+  error.clear();
+  text = std::move(st.carry);
+  st.carry.clear();
+  // fill: append about chunk_bytes of text
+  while (!st.source_done && text.size() < st.chunk_bytes) {
+    if (st.kind == State::Kind::Plain) {
+      if (!st.raw.empty()) { text += st.raw; st.raw.clear(); continue; }
+      if (!st.readMore(std::min<size_t>(st.chunk_bytes, size_t{64} << 20))) st.source_done = true;
+    } else if (st.kind == State::Kind::BlockGzip) {
+      // whole blocks held in raw -> text, in parallel; a partial block stays for the next read
+      std::vector<Block> blocks;
+      const auto* p = reinterpret_cast<const unsigned char*>(st.raw.data());
+      size_t at = 0, total = 0;
+      while (st.raw.size() - at >= 18) {
+        if (p[at] != 31 || p[at + 1] != 139 || p[at + 2] != 8 || p[at + 3] != 4) { error = "not a block gzip member in: " + st.file_name; return false; }
+        const size_t xlen = le16(p + at + 10);
+        if (st.raw.size() - at < 12 + xlen) break;
+        size_t block_size = 0;
+        for (size_t x = at + 12; x + 4 <= at + 12 + xlen;) {
+          const size_t len = le16(p + x + 2);
+          if (p[x] == 'B' && p[x + 1] == 'C' && len == 2 && x + 6 <= at + 12 + xlen) block_size = static_cast<size_t>(le16(p + x + 4)) + 1;
+          x += 4 + len;
+        }
+        if (block_size == 0 || block_size < 12 + xlen + 8) { error = "not a block gzip member in: " + st.file_name; return false; }
+        if (st.raw.size() - at < block_size) break;
+        Block b;
+        b.data_begin = at + 12 + xlen;
+        b.data_size = block_size - (12 + xlen) - 8;
+        b.crc = le32(p + at + block_size - 8);
+        b.out_size = le32(p + at + block_size - 4);
+        if (b.out_size > 65536) { error = "block gzip member larger than 64 KiB in: " + st.file_name; return false; }
+        b.out_begin = total;
+        total += b.out_size;
+        blocks.push_back(b);
+        at += block_size;
+        if (text.size() + total >= st.chunk_bytes) break;
+      }
+      if (!blocks.empty()) {
+        const size_t base = text.size();
+        text.resize(base + total);
+        std::atomic<size_t> next_block{0};
+        std::atomic<bool> failed{false};
+        auto worker = [&]() {
+          for (size_t b = next_block.fetch_add(1); b < blocks.size() && !failed.load(); b = next_block.fetch_add(1))
+            if (!inflateBlock(st.raw, blocks[b], &text[base + blocks[b].out_begin])) failed.store(true);
+        };
+        const size_t n = std::max<size_t>(1, std::min(st.threads, blocks.size()));
+        std::vector<std::thread> pool;
+        for (size_t t = 1; t < n; ++t) pool.emplace_back(worker);
+        worker();
+        for (auto& th : pool) th.join();
+        if (failed.load()) { error = "block gzip file fails its size / CRC check: " + st.file_name; return false; }
+        st.raw.erase(0, at);
+        continue;
+      }
+      if (!st.readMore(std::max<size_t>(size_t{1} << 20, std::min<size_t>(st.chunk_bytes / 4, size_t{64} << 20)))) {
+        if (!st.raw.empty()) { error = "truncated block gzip file: " + st.file_name; return false; }
+        st.source_done = true;
+      }
+    } else {
+      // plain gzip: members concatenated, one stream
+      if (st.zs_in_at >= st.raw.size()) {
+        st.raw.clear();
+        st.zs_in_at = 0;
+        if (!st.readMore(size_t{4} << 20)) {
+          error = "truncated gzip file: " + st.file_name;      // the stream's end is seen below, before the input runs dry
+          return false;
+        }
+      }
+      const size_t base = text.size();
+      const size_t room = std::max<size_t>(size_t{1} << 20, std::min<size_t>(st.chunk_bytes - std::min(st.chunk_bytes, base), size_t{64} << 20));
+      text.resize(base + room);
+      st.zs.next_in = reinterpret_cast<Bytef*>(&st.raw[st.zs_in_at]);
+      st.zs.avail_in = static_cast<uInt>(st.raw.size() - st.zs_in_at);
+      st.zs.next_out = reinterpret_cast<Bytef*>(&text[base]);
+      st.zs.avail_out = static_cast<uInt>(room);
+      const int rc = inflate(&st.zs, Z_NO_FLUSH);
+      st.zs_in_at = st.raw.size() - st.zs.avail_in;
+      text.resize(base + (room - st.zs.avail_out));
+      if (rc == Z_STREAM_END) {
+        if (st.zs_in_at >= st.raw.size()) {                       // more members?
+          st.raw.clear();
+          st.zs_in_at = 0;
+          if (!st.readMore(size_t{4} << 20)) { st.source_done = true; continue; }
+        }
+        if (inflateReset(&st.zs) != Z_OK) { error = "zlib reset failed"; return false; }
+      } else if (rc != Z_OK && rc != Z_BUF_ERROR) {
+        error = "not a valid gzip file: " + st.file_name;
+        return false;
+      }
+    }
+  }
+  if (st.source_done) return !text.empty();
+  // cut at the last line end; the rest opens the next piece
+  const size_t cut = text.rfind('\n');
+  if (cut == std::string::npos) {
+    // one line longer than a piece: keep filling
+    std::string more, err;
+    st.carry = std::move(text);
+    const size_t keep = st.chunk_bytes;
+    st.chunk_bytes = st.carry.size() * 2;
+    const bool got = next(more, err);
+    st.chunk_bytes = keep;
+    if (!err.empty()) { error = err; return false; }
+    text = std::move(more);
+    return got;
+  }
+  st.carry.assign(text, cut + 1, std::string::npos);
+  text.resize(cut + 1);
+  return true;
+}
+
 }  // namespace kellerberrin::genome::analysis::gpu

@@ -13,6 +13,25 @@ namespace kellerberrin::genome::analysis::gpu {
 // threads == 0: hardware_concurrency() - 1.  Returns false with a message in error.
 [[nodiscard]] bool readVcfText(const std::string& file_name, std::string& text, std::string& error, size_t threads = 0);
 
+// The same file a bounded piece at a time, for VCFs whose text does not fit in memory (a 10 k-sample x 10 M-record
+// file is ~400 GB of text for 25 GB of genotypes): every call to next() yields the next run of WHOLE lines, about
+// chunk_bytes of text.  Plain files are read in slices; block gzip is read a batch of blocks at a time, the blocks
+// inflated in parallel and checked like readVcfText's; plain gzip is inflated as a stream by one thread.
+class VcfChunkReader {
+ public:
+  VcfChunkReader();
+  ~VcfChunkReader();
+  VcfChunkReader(const VcfChunkReader&) = delete;
+  VcfChunkReader& operator=(const VcfChunkReader&) = delete;
+  [[nodiscard]] bool open(const std::string& file_name, std::string& error, size_t threads = 0, size_t chunk_bytes = size_t{64} << 20);
+  // false at the end of the file, or on an error (then error is not empty).  text is overwritten.
+  [[nodiscard]] bool next(std::string& text, std::string& error);
+
+ private:
+  struct State;
+  State* state_;
+};
+
 }  // namespace kellerberrin::genome::analysis::gpu
 
 #endif  // KGX_VCF_IO_H

@@ -26,6 +26,8 @@ def lib():
         L.kgxh_flatten_vcf1000.argtypes = [C.c_char_p, C.c_uint64, C.c_int]
         L.kgxh_flatten_vcf_pf.restype = C.c_void_p
         L.kgxh_flatten_vcf_pf.argtypes = [C.c_char_p, C.c_uint64, C.c_int, C.c_int]
+        L.kgxh_flatten_vcf_file.restype = C.c_void_p
+        L.kgxh_flatten_vcf_file.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_uint64, C.c_char_p, C.c_size_t]
         L.kgxh_flat_destroy.argtypes = [C.c_void_p]
         L.kgxh_flat_copy_splits.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         for name in ("kgxh_flat_genomes", "kgxh_flat_variants", "kgxh_flat_row_bytes", "kgxh_flat_variant_objects", "kgxh_flat_non_diploid",
@@ -67,13 +69,22 @@ def variant_sort(text: str, flavour: str, what: str, names=None, genome_id: str 
 
 
 class FlatVcf:
-    def __init__(self, text: str, threads: int = 0, flavour: str = "Genome1000", quality_filter: bool = False):
-        b = text.encode()
-        if flavour == "Genome1000":
-            h = lib().kgxh_flatten_vcf1000(b, len(b), threads)
+    def __init__(self, text: str | None, threads: int = 0, flavour: str = "Genome1000", quality_filter: bool = False, path=None,
+                 chunk_bytes: int = 0):
+        """From text, or (path=...) from a file read chunk_bytes of text at a time (kgxh_flatten_vcf_file)."""
+        assert flavour in ("Genome1000", "Falciparum")
+        if path is not None:
+            err = C.create_string_buffer(512)
+            h = lib().kgxh_flatten_vcf_file(str(path).encode(), 0 if flavour == "Genome1000" else 1, threads, int(quality_filter),
+                                            chunk_bytes, err, 512)
+            if not h:
+                raise IOError(err.value.decode())
         else:
-            assert flavour == "Falciparum"
-            h = lib().kgxh_flatten_vcf_pf(b, len(b), threads, int(quality_filter))
+            b = text.encode()
+            if flavour == "Genome1000":
+                h = lib().kgxh_flatten_vcf1000(b, len(b), threads)
+            else:
+                h = lib().kgxh_flatten_vcf_pf(b, len(b), threads, int(quality_filter))
         assert h
         try:
             self.G, self.V = int(lib().kgxh_flat_genomes(h)), int(lib().kgxh_flat_variants(h))

@@ -241,6 +241,49 @@ def test_vcf_reader_plain_gzip_and_block_gzip(tmp_path, threads):
     assert flat.G == len(ids) and flat.V > 0
 
 
+def same_flat(a, b):
+    return (a.hgvs == b.hgvs and a.genome_ids == b.genome_ids and np.array_equal(a.packed, b.packed) and a.variant_objects == b.variant_objects
+            and a.non_diploid == b.non_diploid and np.array_equal(a.info_af, b.info_af, equal_nan=True) and np.array_equal(a.split_packed, b.split_packed)
+            and np.array_equal(a.split_of, b.split_of) and np.array_equal(a.from_splits, b.from_splits))
+
+
+@pytest.mark.parametrize("flavour", ["Genome1000", "Falciparum"])
+def test_flatten_from_file_in_pieces_equals_flatten_of_the_text(tmp_path, flavour):
+    """The file entry points read a bounded piece of whole lines at a time (plain, gzip, block gzip); whatever the piece
+    size -- smaller than a line, a few lines, the whole file -- the population is the one the whole text flattens to."""
+    import gzip
+
+    if flavour == "Genome1000":
+        G, L = 37, 900
+        rec, gt = sv.multiallelic_block(G, L, rng_seed=9, dup_records=12)
+        text = vt.write_vcf_1000(rec, gt, [f"HG{i:05d}" for i in reversed(range(G))], rng_seed=2)
+    else:
+        text = vt.write_vcf_pf(500, [f"PF{i:04d}-C" for i in range(19)], rng_seed=5)
+    whole = ha.FlatVcf(text, 3, flavour=flavour, quality_filter=(flavour == "Falciparum"))
+    assert whole.V > 300
+    data = text.encode()
+    files = {"plain": data, "gzip": gzip.compress(data[:len(data) // 3]) + gzip.compress(data[len(data) // 3:]), "bgzf": vt.bgzip(data, block=4000)}
+    for kind, payload in files.items():
+        path = tmp_path / f"population.{kind}"
+        path.write_bytes(payload)
+        for chunk_bytes in (1, 777, 50_000, 0):
+            got = ha.FlatVcf(None, 2, flavour=flavour, quality_filter=(flavour == "Falciparum"), path=path, chunk_bytes=chunk_bytes)
+            assert same_flat(got, whole), (kind, chunk_bytes)
+    # no final newline; an empty file; a truncated block-gzip file; a missing file
+    (tmp_path / "open_end").write_bytes(data.rstrip(b"\n"))
+    assert same_flat(ha.FlatVcf(None, 2, flavour=flavour, quality_filter=(flavour == "Falciparum"), path=tmp_path / "open_end", chunk_bytes=3000), whole)
+    (tmp_path / "empty").write_bytes(b"")
+    assert ha.FlatVcf(None, 1, flavour=flavour, path=tmp_path / "empty").V == 0
+    (tmp_path / "cut.bgz").write_bytes(files["bgzf"][:len(files["bgzf"]) // 2])
+    with pytest.raises(IOError):
+        ha.FlatVcf(None, 1, flavour=flavour, path=tmp_path / "cut.bgz", chunk_bytes=5000)
+    (tmp_path / "cut.gz").write_bytes(files["gzip"][:len(files["gzip"]) // 2])
+    with pytest.raises(IOError):
+        ha.FlatVcf(None, 1, flavour=flavour, path=tmp_path / "cut.gz", chunk_bytes=5000)
+    with pytest.raises(IOError):
+        ha.FlatVcf(None, 1, flavour=flavour, path=tmp_path / "not_there")
+
+
 def test_repeated_records_in_different_fws_bins_are_split_per_bin():
     """CalcFWS filters Variant objects by their own record's AF: when the records of one variant disagree, each bin's
     population holds only that record's copies.  The flatteners emit per-bin split rows for exactly those variants."""
