@@ -325,16 +325,15 @@ bool kga::GpuInbreedAnalysis::diploidInput(const GpuReferenceContig& reference, 
     phased = diploid_population_->dataCharacteristic().data_structure == DataStructureEnum::DiploidPhased;
     diploid = diploidBytes(*diploid_population_, reference, phased);
   } else {
-    std::string text, io_error;
-    if (!gpu::readVcfText(diploid_vcf_, text, io_error)) {
-      ExecEnv::log().error("GpuInbreedAnalysis; population VCF: {}", io_error);
-      return false;
-    }
     phased = true;                                                   // Genome1000: DiploidPhased (kgl_data_file_type.h:118-134)
     gpu::FlatReference flat;
     flat.contig_id = reference.contig_id;
     flat.loci = reference.loci;
-    diploid = gpu::flattenVcf1000Gt8(text, flat);
+    std::string io_error;                                            // the file is read a bounded piece at a time: its text need not fit in memory
+    if (!gpu::flattenVcf1000Gt8File(diploid_vcf_, flat, diploid, io_error)) {
+      ExecEnv::log().error("GpuInbreedAnalysis; population VCF: {}", io_error);
+      return false;
+    }
   }
   if (!diploid.error.empty()) {
     ExecEnv::log().error("GpuInbreedAnalysis; {}", diploid.error);

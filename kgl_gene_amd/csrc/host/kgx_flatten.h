@@ -118,6 +118,10 @@ struct FlatDiploid {
   std::string error;                       // reserved: every population the parser accepts is representable
 };
 [[nodiscard]] FlatDiploid flattenVcf1000Gt8(std::string_view text, const FlatReference& reference, size_t threads = 0);
+// The same from a file read a bounded piece at a time (see flattenVcf1000File): between pieces only the calls of the
+// records that land on a reference locus are kept, a byte per cell of the result.
+[[nodiscard]] bool flattenVcf1000Gt8File(const std::string& file_name, const FlatReference& reference, FlatDiploid& diploid, std::string& error,
+                                         size_t threads = 0, size_t chunk_bytes = size_t{64} << 20);
 
 // P7FrequencyFilter / CalcFWS bins on the "AF" INFO value of a row (kgl_variant_filter_Pf7.cpp:20-66,
 // kga_analysis_PfEMP_FWS.cpp:15-38,104-145): bin index 0..10, or 0xFF when the row is in no bin

@@ -130,6 +130,21 @@ void* kgxh_inbreed_inputs(const char* reference_text, uint64_t reference_len, in
   out->diploid = g::flattenVcf1000Gt8(std::string_view(diploid_text, diploid_len), out->reference, threads > 0 ? threads : 0);
   return out;
 }
+// The population from a FILE, read diploid_chunk_bytes of text at a time (0 = default); null on an I/O error.
+void* kgxh_inbreed_inputs_file(const char* reference_text, uint64_t reference_len, int data_source, const char* diploid_path, int threads,
+                               uint64_t diploid_chunk_bytes) {
+  if (!reference_text || !diploid_path) return nullptr;
+  namespace g = kellerberrin::genome::analysis::gpu;
+  auto* out = new InbreedInputs();
+  out->reference = g::flattenReferenceVcf(std::string_view(reference_text, reference_len), static_cast<kellerberrin::genome::DataSourceEnum>(data_source));
+  std::string error;
+  if (!g::flattenVcf1000Gt8File(diploid_path, out->reference, out->diploid, error, threads > 0 ? threads : 0,
+                                diploid_chunk_bytes ? static_cast<size_t>(diploid_chunk_bytes) : (size_t{64} << 20))) {
+    delete out;
+    return nullptr;
+  }
+  return out;
+}
 void kgxh_inbreed_inputs_destroy(void* h) { delete static_cast<InbreedInputs*>(h); }
 uint64_t kgxh_inbreed_loci(void* h) { return h ? static_cast<InbreedInputs*>(h)->reference.loci.size() : 0; }
 uint64_t kgxh_inbreed_genomes(void* h) { return h ? static_cast<InbreedInputs*>(h)->diploid.genome_ids.size() : 0; }

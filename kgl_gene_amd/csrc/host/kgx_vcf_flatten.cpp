@@ -729,7 +729,10 @@ FlatReference flattenReferenceVcf(std::string_view text, DataSourceEnum data_sou
   return out;
 }
 
-FlatDiploid flattenVcf1000Gt8(std::string_view text, const FlatReference& reference, size_t threads) {
+namespace {
+
+template <typename NextChunk>
+FlatDiploid flattenVcf1000Gt8Chunks(NextChunk&& next_piece, const FlatReference& reference, size_t threads) {
   const bool trace = std::getenv("KGX_FLATTEN_TRACE") != nullptr;
   auto t_last = std::chrono::steady_clock::now();
   auto lap = [&](const char* what) {
@@ -738,47 +741,54 @@ FlatDiploid flattenVcf1000Gt8(std::string_view text, const FlatReference& refere
     std::fprintf(stderr, "kgx flattenVcf1000Gt8: %s %.3f s\n", what, std::chrono::duration<double>(now - t_last).count());
     t_last = now;
   };
-  const VcfLines lines = scanLines(text);
-  lap("scan lines");
-  const size_t S = lines.samples.size();
   FlatDiploid out;
   out.n_loci = reference.loci.size();
   std::unordered_map<ContigOffset_t, uint32_t> locus_of_offset;
   locus_of_offset.reserve(reference.loci.size() * 2);
   for (uint32_t l = 0; l < reference.loci.size(); ++l) locus_of_offset.emplace(reference.loci[l].offset, l);
 
-  // Per record: the locus it lands on (or none), per alt its code in that locus's list (0 = not a SNP: filtered out
-  // before the sweep, _freq.cpp:436), and per sample the two alt numbers.
+  // Per record that lands on a reference locus: per alt its code in that locus's list (0 = not a SNP: filtered out
+  // before the sweep, _freq.cpp:436), and per sample the two alt numbers.  A record off the loci only says who holds
+  // the contig (holds[]) and keeps nothing: what stays in memory between the pieces of a file is a byte per cell of
+  // the result.
   struct RecordCalls {
     int64_t locus{-1};
-    bool on_contig{false};
     std::vector<uint8_t> code;            // [n_alt]
     std::vector<uint8_t> calls;           // [S]: phase A alt | phase B alt << 4  (alt numbers up to 15 fit; larger ones are clipped below)
     std::vector<std::pair<uint32_t, std::pair<uint32_t, uint32_t>>> wide;   // samples whose alt numbers need more than 4 bits
-    std::vector<uint8_t> carries;         // [S] 1 if the sample carries ANY alt of the record (SNP or not)
   };
-  std::vector<RecordCalls> parsed(lines.records.size());
+  std::vector<RecordCalls> parsed;
+  std::vector<std::string> samples;
+  std::vector<uint8_t> holds;             // [S] 1 if the sample carries ANY alt (SNP or not) of a record on the contig
+  if (threads == 0) threads = std::max<size_t>(std::thread::hardware_concurrency(), 2) - 1;
+  std::string_view text;
+  while (next_piece(text)) {
+  const VcfLines lines = scanLines(text);
+  lap("scan lines");
+  if (samples.empty()) { samples = lines.samples; holds.assign(samples.size(), 0); }
+  const size_t S = samples.size();
+  std::vector<RecordCalls> piece(lines.records.size());
   {
-    if (threads == 0) threads = std::max<size_t>(std::thread::hardware_concurrency(), 2) - 1;
     std::atomic<size_t> next{0};
+    std::mutex holds_mutex;
     auto worker = [&]() {
+      std::vector<uint8_t> local_holds(S, 0);
       for (size_t r = next.fetch_add(1); r < lines.records.size(); r = next.fetch_add(1)) {
-        RecordCalls& rc = parsed[r];
+        RecordCalls& rc = piece[r];
         const auto f = split(lines.records[r], '\t', S + 10);
         if (f.size() < 8) continue;
         if (f[0] != reference.contig_id) continue;
         bool pos_ok = true;
         const uint64_t pos = parseIndex(f[1], pos_ok);
         if (!pos_ok) continue;
-        rc.on_contig = true;
         const std::string_view ref = f[3];
         const std::string_view alt_field = f[4] == "." ? std::string_view() : f[4];
         const auto alts = split(alt_field, ',');
         const size_t A = alts.size();
         const auto found = locus_of_offset.find(pos - 1);
-        rc.code.assign(A, 0);
         if (found != locus_of_offset.end()) {
           rc.locus = found->second;
+          rc.code.assign(A, 0);
           const auto& list = reference.loci[found->second].alts;
           for (size_t a = 0; a < A; ++a) {
             if (!isSnp(ref, alts[a])) continue;
@@ -788,18 +798,20 @@ FlatDiploid flattenVcf1000Gt8(std::string_view text, const FlatReference& refere
               if (list[j].hgvs == hgvs) { c = static_cast<uint8_t>(j + 1); break; }
             rc.code[a] = c;
           }
+          rc.calls.assign(S, 0);
         }
-        rc.calls.assign(S, 0);
-        rc.carries.assign(S, 0);
         const Chromosome chrom = chromosomeOf(f[0]);
         for (size_t idx = 9; idx < f.size() && idx - 9 < S; ++idx) {
           uint32_t pa, pb;
           phasedAlleles(f[idx], A, chrom, pa, pb);
-          if (pa || pb) rc.carries[idx - 9] = 1;
+          if (pa || pb) local_holds[idx - 9] = 1;
+          if (rc.locus < 0) continue;
           if (pa > 15 || pb > 15) rc.wide.push_back({static_cast<uint32_t>(idx - 9), {pa, pb}});
           else rc.calls[idx - 9] = static_cast<uint8_t>(pa | (pb << 4));
         }
       }
+      std::lock_guard<std::mutex> lock(holds_mutex);
+      for (size_t smp = 0; smp < S; ++smp) holds[smp] |= local_holds[smp];
     };
     const size_t n = std::max<size_t>(1, std::min(threads, lines.records.size()));
     std::vector<std::thread> pool;
@@ -807,25 +819,24 @@ FlatDiploid flattenVcf1000Gt8(std::string_view text, const FlatReference& refere
     worker();
     for (auto& th : pool) th.join();
   }
+  for (auto& rc : piece) if (rc.locus >= 0) parsed.push_back(std::move(rc));      // file order kept
+  }
+  const size_t S = samples.size();
 
   lap("parse records");
   // genomes that hold the contig, in id order; a sample named twice is one genome
-  std::vector<uint8_t> holds(S, 0);
-  for (const auto& rc : parsed)
-    if (rc.on_contig)
-      for (size_t s = 0; s < rc.carries.size(); ++s) holds[s] |= rc.carries[s];
   std::vector<uint32_t> order;
   for (uint32_t s = 0; s < S; ++s) if (holds[s]) order.push_back(s);
-  std::sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) { return lines.samples[x] < lines.samples[y]; });
+  std::sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) { return samples[x] < samples[y]; });
   std::vector<int64_t> genome_of_sample(S, -1);
   for (uint32_t s : order) {
-    if (out.genome_ids.empty() || out.genome_ids.back() != lines.samples[s]) out.genome_ids.push_back(lines.samples[s]);
+    if (out.genome_ids.empty() || out.genome_ids.back() != samples[s]) out.genome_ids.push_back(samples[s]);
     genome_of_sample[s] = static_cast<int64_t>(out.genome_ids.size()) - 1;
   }
   // a second column of an already-seen sample name
   for (uint32_t s = 0; s < S; ++s)
     if (genome_of_sample[s] < 0 && holds[s])
-      genome_of_sample[s] = std::lower_bound(out.genome_ids.begin(), out.genome_ids.end(), lines.samples[s]) - out.genome_ids.begin();
+      genome_of_sample[s] = std::lower_bound(out.genome_ids.begin(), out.genome_ids.end(), samples[s]) - out.genome_ids.begin();
   const size_t G = out.genome_ids.size();
   out.bytes.assign(out.n_loci * G, 0);
   if (G == 0 || out.n_loci == 0) return out;          // nobody holds the contig, or no reference locus: nothing to assemble
@@ -904,6 +915,21 @@ FlatDiploid flattenVcf1000Gt8(std::string_view text, const FlatReference& refere
   }
   lap("assemble");
   return out;
+}
+
+}  // namespace
+
+FlatDiploid flattenVcf1000Gt8(std::string_view text, const FlatReference& reference, size_t threads) {
+  return flattenVcf1000Gt8Chunks(WholeText{text}, reference, threads);
+}
+
+bool flattenVcf1000Gt8File(const std::string& file_name, const FlatReference& reference, FlatDiploid& diploid, std::string& error, size_t threads,
+                           size_t chunk_bytes) {
+  FilePieces pieces;
+  if (!pieces.reader.open(file_name, error, threads, chunk_bytes)) return false;
+  diploid = flattenVcf1000Gt8Chunks(pieces, reference, threads);
+  error = pieces.error;
+  return error.empty();
 }
 
 

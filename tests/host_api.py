@@ -42,6 +42,8 @@ def lib():
         L.kgxh_free.argtypes = [C.c_void_p]
         L.kgxh_inbreed_inputs.restype = C.c_void_p
         L.kgxh_inbreed_inputs.argtypes = [C.c_char_p, C.c_uint64, C.c_int, C.c_char_p, C.c_uint64, C.c_int]
+        L.kgxh_inbreed_inputs_file.restype = C.c_void_p
+        L.kgxh_inbreed_inputs_file.argtypes = [C.c_char_p, C.c_uint64, C.c_int, C.c_char_p, C.c_int, C.c_uint64]
         L.kgxh_inbreed_inputs_destroy.argtypes = [C.c_void_p]
         for name in ("kgxh_inbreed_loci", "kgxh_inbreed_genomes", "kgxh_inbreed_max_alts", "kgxh_inbreed_contigs"):
             getattr(L, name).restype = C.c_uint64
@@ -138,9 +140,15 @@ class InbreedInputs:
     """The INBREED package's two inputs flattened from VCF text: reference loci (offset, alts, AF per super population)
     and the population's allele-index bytes [n_loci][genomes]."""
 
-    def __init__(self, reference_text: str, data_source: int, diploid_text: str, threads: int = 0):
-        rb, db = reference_text.encode(), diploid_text.encode()
-        h = lib().kgxh_inbreed_inputs(rb, len(rb), data_source, db, len(db), threads)
+    def __init__(self, reference_text: str, data_source: int, diploid_text: str | None, threads: int = 0, diploid_path=None, chunk_bytes: int = 0):
+        rb = reference_text.encode()
+        if diploid_path is not None:
+            h = lib().kgxh_inbreed_inputs_file(rb, len(rb), data_source, str(diploid_path).encode(), threads, chunk_bytes)
+            if not h:
+                raise IOError(str(diploid_path))
+        else:
+            db = diploid_text.encode()
+            h = lib().kgxh_inbreed_inputs(rb, len(rb), data_source, db, len(db), threads)
         assert h
         try:
             self.L, self.G = int(lib().kgxh_inbreed_loci(h)), int(lib().kgxh_inbreed_genomes(h))

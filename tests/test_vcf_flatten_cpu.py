@@ -197,6 +197,19 @@ def test_inbreed_inputs_from_vcf_match_the_scaffold_encoder(threads):
     column = {name: g for g, name in enumerate(ids)}
     want_bytes = ii.encode_gt8(rec, gt, loci)[:, [column[name] for name in carriers]]
     assert np.array_equal(got.bytes, want_bytes)
+    # the population from a file read in pieces (a line or so, a few lines, everything): the same bytes
+    if threads == 1:
+        import tempfile
+        from pathlib import Path
+
+        with tempfile.TemporaryDirectory() as tmp:
+            for name, payload in (("plain.vcf", dip_text.encode()), ("block.vcf.bgz", vt.bgzip(dip_text.encode(), block=3000))):
+                (Path(tmp) / name).write_bytes(payload)
+                for chunk_bytes in (1, 2500, 0):
+                    piecewise = ha.InbreedInputs(ref_text, DATA_SOURCE["Gnomad2_1"], None, 2, diploid_path=Path(tmp) / name, chunk_bytes=chunk_bytes)
+                    assert piecewise.genome_ids == got.genome_ids and np.array_equal(piecewise.bytes, got.bytes), (name, chunk_bytes)
+            with pytest.raises(IOError):
+                ha.InbreedInputs(ref_text, DATA_SOURCE["Gnomad2_1"], None, diploid_path=Path(tmp) / "missing.vcf")
     # a repeated record gives its carriers a second copy on the SAME phase: the (0, a) byte, as the scaffold encoder writes it
     l0 = next(l for l in range(got.L) if (got.bytes[l] & 0xF).any() and ((got.bytes[l] & 0xF) != 15).any())
     pos = str(int(got.offsets[l0]) + 1)
