@@ -916,7 +916,10 @@ k_inbreed_eval_lut(const uint32_t* __restrict__ gt, uint64_t dwords_per_row, uin
             }
             const double v = __builtin_fma(F[MODE == 3 ? 0 : j], e.d, e.y);
             if constexpr (MODE == 2) {
-              run_a[j] *= __builtin_fmin(__builtin_fmax(v, 1e-10), 1.0);   // the clamp of logLikelihood (:117-121)
+              // the clamp of logLikelihood (:117-121).  Its upper bound cannot bind here: for -1 <= F <= 1 (the search
+              // interval) F*f + (1-F)*f*f <= max(f, 2*f*f - f) <= 1 and 2*(1-F)*f1*f2 <= 4*f1*f2 <= 1 (f1 + f2 <= 1), with
+              // equality only at f = 1, where y = 1, d = 0 and the fma is exact; unclassified entries are (1, 0).
+              run_a[j] *= __builtin_fmax(v, 1e-10);
             } else {
               run_a[j] = __builtin_fma(run_a[j], v, run_b[j]);
               run_b[j] *= v;
