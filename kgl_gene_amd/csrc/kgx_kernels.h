@@ -9,6 +9,7 @@
 #define KGX_KERNELS_H
 
 #include <hip/hip_runtime.h>
+#include <type_traits>
 #include <stdint.h>
 
 #include "kgx_synth.h"
@@ -784,7 +785,8 @@ constexpr uint32_t kEvalSlots = 160;
 // segment), so that no global-load latency sits between a batch's arithmetic and the next.
 template <int MODE, int BITS>
 __device__ __forceinline__ void build_eval_table(EvalEntry* __restrict__ lut, const double* __restrict__ rows,
-                                                 const uint8_t* __restrict__ flags, uint32_t stride, uint32_t amax, bool phased) {
+                                                 const uint8_t* __restrict__ flags, uint32_t stride, uint32_t amax, bool phased,
+                                                 uint32_t* __restrict__ upper_binds, uint32_t batch_tag) {
   // e enumerates (locus, a2, a1) with just enough bits per allele index for amax, so that at amax <= 3 two waves
   // build the whole batch in one step and the other two go straight on to the arithmetic
   constexpr uint32_t bits = BITS, mask = (1u << bits) - 1u;       // BITS = 1, 2, 3 for amax <= 1, 3, 7
@@ -800,7 +802,12 @@ __device__ __forceinline__ void build_eval_table(EvalEntry* __restrict__ lut, co
         else if constexpr (MODE == 1) { y = f1; d = 1.0 - f1; }
         else if (f1 > 0.001) { y = 1.0 / f1; y -= 1.0; d = 1.0; }     // minimum_frequency (_calc.cpp:380,396)
       } else if (cls != kClassNone) {
-        if constexpr (MODE == 2) { y = 2.0 * f1 * f2; d = -y; }
+        if constexpr (MODE == 2) {
+          y = 2.0 * f1 * f2; d = -y;
+          // (1-F)*y can pass 1 on [-1, 1] only if y > 1/2: two minor alleles near 1/2 each whose sum checkValidAlleleVector
+          // let through up to 1e-5 over 1.  The batch is then walked with the upper clamp (see the kernel).
+          if (y > 0.5) *upper_binds = batch_tag;
+        }
         else if constexpr (MODE == 3) { y = -1.0; d = 1.0; }
       }
     }
@@ -820,6 +827,10 @@ k_inbreed_eval_lut(const uint32_t* __restrict__ gt, uint64_t dwords_per_row, uin
   __shared__ EvalEntry lut[2][kEvalBatch * kEvalSlots];
   __shared__ double rows[2][kEvalBatch * sweep_stride(7)];
   __shared__ uint8_t flags[2][kEvalBatch];
+  // MODE 2: upper_binds[b] == tag of the batch in lut[b]  <=>  some entry of that batch can exceed probability 1
+  // (tags are batch numbers + 1, so a word never has to be cleared between uses of its buffer)
+  __shared__ uint32_t upper_binds[2];
+  if (threadIdx.x < 2) upper_binds[threadIdx.x] = 0;
   const uint64_t lane = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x;   // genomes g0 + GPL*lane ..
   const bool active = lane * GPL < n_genomes;
   const uint64_t seg = blockIdx.y;
@@ -869,7 +880,7 @@ k_inbreed_eval_lut(const uint32_t* __restrict__ gt, uint64_t dwords_per_row, uin
   fetch(s_begin + kEvalBatch);
   stash(1);
   __syncthreads();
-  build_eval_table<MODE, BITS>(lut[0], rows[0], flags[0], stride, amax, phased != 0);
+  build_eval_table<MODE, BITS>(lut[0], rows[0], flags[0], stride, amax, phased != 0, &upper_binds[0], 1u);
   __syncthreads();
   int buf = 0;
   int batches_open = 0;            // batches since the running fraction / product was last closed
@@ -896,33 +907,60 @@ k_inbreed_eval_lut(const uint32_t* __restrict__ gt, uint64_t dwords_per_row, uin
       }
     }
     fetch(s0 + 2 * kEvalBatch);
-    if (s0 + kEvalBatch < s_end) build_eval_table<MODE, BITS>(lut[buf ^ 1], rows[buf ^ 1], flags[buf ^ 1], stride, amax, phased != 0);
+    const uint32_t batch_tag = static_cast<uint32_t>((s0 - s_begin) / kEvalBatch) + 1u;
+    const bool clamp_above = MODE == 2 && upper_binds[buf] == batch_tag;          // block-uniform; written before the last barrier
+    if (s0 + kEvalBatch < s_end)
+      build_eval_table<MODE, BITS>(lut[buf ^ 1], rows[buf ^ 1], flags[buf ^ 1], stride, amax, phased != 0, &upper_binds[buf ^ 1], batch_tag + 1u);
     if (active) {
       const EvalEntry* __restrict__ cur = lut[buf];
+      // A cell's table entry: slot a1 + 20*a2 of its locus (bit 7 of the byte folded onto bit 3: "unclassified").
+      auto slots_of = [](uint32_t x) {
+        const uint32_t xf = (x & 0x7F7F7F7Fu) | ((x >> 4) & 0x08080808u);
+        return xf + ((xf >> 2) & 0x1C1C1C1Cu);                             // a1 + 16*a2 + 4*a2 per byte, < 156: no carry
+      };
+      if constexpr (MODE == 2) {
+        // The clamp of logLikelihood (:117-121).  For -1 <= F <= 1 (the search interval) its upper bound cannot bind on a
+        // homozygous cell, F*f + (1-F)*f*f <= max(f, 2*f*f - f) <= 1 (at f = 1: y = 1, d = 0, the fma exact), nor on an
+        // unclassified one (1, 0); on a heterozygous cell, 2*(1-F)*f1*f2 <= 4*f1*f2, only if y > 1/2.  So the batch's
+        // cells are compiled twice, and the form with the fp64 min per cell runs only where build_eval_table saw such an
+        // entry (one block-uniform branch per batch).
+        auto walk_cells = [&](auto above_c) {
+          constexpr bool kClampAbove = decltype(above_c)::value;
 #pragma unroll
-      for (int i = 0; i < kEvalBatch; ++i) {
+          for (int i = 0; i < kEvalBatch; ++i) {
 #pragma unroll
-        for (int k = 0; k < DW; ++k) {
-          const uint32_t xf = (w[i][k] & 0x7F7F7F7Fu) | ((w[i][k] >> 4) & 0x08080808u);
-          const uint32_t slots = xf + ((xf >> 2) & 0x1C1C1C1Cu);          // a1 + 16*a2 + 4*a2 per byte, < 156: no carry
+            for (int k = 0; k < DW; ++k) {
+              const uint32_t slots = slots_of(w[i][k]);
 #pragma unroll
-          for (int b = 0; b < 4; ++b) {
-            const int j = 4 * k + b;
-            const EvalEntry e = cur[i * kEvalSlots + ((slots >> (8 * b)) & 0xFFu)];
-            if constexpr (MODE == 3) {
-              run_a[j] += e.y;
-              run_b[j] += e.d;
-              continue;
+              for (int b = 0; b < 4; ++b) {
+                const int j = 4 * k + b;
+                const EvalEntry e = cur[i * kEvalSlots + ((slots >> (8 * b)) & 0xFFu)];
+                const double floored = __builtin_fmax(__builtin_fma(F[MODE == 3 ? 0 : j], e.d, e.y), 1e-10);
+                run_a[j] *= kClampAbove ? __builtin_fmin(floored, 1.0) : floored;
+              }
             }
-            const double v = __builtin_fma(F[MODE == 3 ? 0 : j], e.d, e.y);
-            if constexpr (MODE == 2) {
-              // the clamp of logLikelihood (:117-121).  Its upper bound cannot bind here: for -1 <= F <= 1 (the search
-              // interval) F*f + (1-F)*f*f <= max(f, 2*f*f - f) <= 1 and 2*(1-F)*f1*f2 <= 4*f1*f2 <= 1 (f1 + f2 <= 1), with
-              // equality only at f = 1, where y = 1, d = 0 and the fma is exact; unclassified entries are (1, 0).
-              run_a[j] *= __builtin_fmax(v, 1e-10);
-            } else {
-              run_a[j] = __builtin_fma(run_a[j], v, run_b[j]);
-              run_b[j] *= v;
+          }
+        };
+        if (clamp_above) walk_cells(std::true_type{});
+        else walk_cells(std::false_type{});
+      } else {
+#pragma unroll
+        for (int i = 0; i < kEvalBatch; ++i) {
+#pragma unroll
+          for (int k = 0; k < DW; ++k) {
+            const uint32_t slots = slots_of(w[i][k]);
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+              const int j = 4 * k + b;
+              const EvalEntry e = cur[i * kEvalSlots + ((slots >> (8 * b)) & 0xFFu)];
+              if constexpr (MODE == 3) {
+                run_a[j] += e.y;
+                run_b[j] += e.d;
+              } else {
+                const double v = __builtin_fma(F[MODE == 3 ? 0 : j], e.d, e.y);
+                run_a[j] = __builtin_fma(run_a[j], v, run_b[j]);
+                run_b[j] *= v;
+              }
             }
           }
         }

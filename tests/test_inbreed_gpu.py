@@ -350,6 +350,34 @@ def test_kernel_flavours_agree_on_random_shapes(kgx, monkeypatch):
         m.close()
 
 
+def test_loglikelihood_where_the_upper_clamp_binds(kgx, monkeypatch):
+    """Two minor alleles of 0.500004 each pass checkValidAlleleVector (sum <= 1 + 1e-5) and make 2(1-F)f1f2 exceed 1 next
+    to F = -1: the one place the upper bound of logLikelihood's clamp (_calc.cpp:117-121) binds.  The table pass applies
+    it only in batches whose table can get there; the generic kernel clamps every cell as the reference does."""
+    rng = np.random.default_rng(8)
+    G, L = 70, 900
+    table = np.full((L, 2), np.nan)
+    table[:, 0] = rng.uniform(0.05, 0.4, L)
+    corner = rng.random(L) < 0.4
+    table[corner, 0] = table[corner, 1] = 0.500004
+    rows = rng.choice(np.array([0, 0, 1, 0x11, 0x21], dtype=np.uint8), size=(L, G))
+    rows[~corner] = np.where(rows[~corner] == 0x21, 1, rows[~corner])   # one alt only elsewhere
+    rows[:, :20] = np.where(corner[:, None], 0x21, 1)                   # genomes 0..19: heterozygous everywhere -> the maximum is at F = -1
+    m = kgx.GenotypeMatrix(G, L)
+    m.load_rows(rows)
+    results = {}
+    for name, env in {"default": {}, "passes": {"KGX_K7_NO_WAVE": "1"}, "generic": {"KGX_K5_GENERIC": "1", "KGX_K7_NO_WAVE": "1"}}.items():
+        for k in ("KGX_K7_NO_WAVE", "KGX_K5_GENERIC"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        results[name] = m.inbreed(table, "Loglikelihood", phased=True)["inbred_allele_sum"]
+    assert results["generic"][:20].max() < -0.9                          # the search did go where the clamp binds
+    for name in ("default", "passes"):
+        assert np.abs(results[name] - results["generic"]).max() <= 2e-5, name
+    m.close()
+
+
 def test_loglikelihood_compaction_is_bit_identical(kgx, monkeypatch):
     """The multi-kernel Loglikelihood search drops finished genomes from its passes (compacted columns and states).  A
     genome's sums do not depend on its neighbours: with and without compaction the coefficients are the same bits."""
