@@ -282,6 +282,11 @@ def test_flatten_from_file_in_pieces_equals_flatten_of_the_text(tmp_path, flavou
         for chunk_bytes in (1, 777, 50_000, 0):
             got = ha.FlatVcf(None, 2, flavour=flavour, quality_filter=(flavour == "Falciparum"), path=path, chunk_bytes=chunk_bytes)
             assert same_flat(got, whole), (kind, chunk_bytes)
+    rng = np.random.default_rng(12)
+    for kind in files:                                  # and random piece sizes, from a few bytes to several lines
+        for chunk_bytes in rng.integers(2, 30_000, 6):
+            got = ha.FlatVcf(None, 3, flavour=flavour, quality_filter=(flavour == "Falciparum"), path=tmp_path / f"population.{kind}", chunk_bytes=int(chunk_bytes))
+            assert same_flat(got, whole), (kind, int(chunk_bytes))
     # no final newline; an empty file; a truncated block-gzip file; a missing file
     (tmp_path / "open_end").write_bytes(data.rstrip(b"\n"))
     assert same_flat(ha.FlatVcf(None, 2, flavour=flavour, quality_filter=(flavour == "Falciparum"), path=tmp_path / "open_end", chunk_bytes=3000), whole)
