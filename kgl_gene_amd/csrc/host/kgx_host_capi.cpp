@@ -182,9 +182,7 @@ int kgxh_inbreed_genome_id(void* h, uint64_t i, char* buf, size_t n) {
 // what: "ensembl" (list = optional '\n'-separated gene codes to keep), "filter" (filterEnsembl of the list),
 // "allele_ensembl", "non_ensembl", "id", "genome_id".  Fields are tab separated: key, Variant HGVS_Phase (or the
 // ','-joined codes); "genome_id" lines start with the genome.  Returns a malloc'd text the caller frees with kgxh_free.
-char* kgxh_variant_sort(const char* text, uint64_t len, int flavour, const char* genome_id, const char* what, const char* list, int threads) {
-  if (!text || !what) return nullptr;
-  namespace g = kellerberrin::genome::analysis::gpu;
+static std::vector<std::string> splitNames(const char* list) {
   std::vector<std::string> names;
   if (list) {
     std::string item;
@@ -193,9 +191,12 @@ char* kgxh_variant_sort(const char* text, uint64_t len, int flavour, const char*
       else item += *c;
     }
   }
-  const auto t_begin = std::chrono::steady_clock::now();
-  const g::SortColumns columns = g::sortColumnsFromVcf(std::string_view(text, len), flavour == 0 ? g::SortVcfFlavour::MonoGenome : g::SortVcfFlavour::Phased1000,
-                                                       genome_id ? genome_id : "Reference", threads > 0 ? threads : 0);
+  return names;
+}
+
+static char* dumpVariantSort(const kellerberrin::genome::analysis::gpu::SortColumns& columns, const char* what, const std::vector<std::string>& names,
+                             int threads, std::chrono::steady_clock::time_point t_begin) {
+  namespace g = kellerberrin::genome::analysis::gpu;
   const std::string kind(what);
   std::ostringstream out;
   auto dumpEnsembl = [&](const g::EnsemblIndex& index) {
@@ -250,6 +251,28 @@ char* kgxh_variant_sort(const char* text, uint64_t len, int flavour, const char*
   char* result = static_cast<char*>(std::malloc(dump.size() + 1));
   if (result) std::memcpy(result, dump.c_str(), dump.size() + 1);
   return result;
+}
+
+char* kgxh_variant_sort(const char* text, uint64_t len, int flavour, const char* genome_id, const char* what, const char* list, int threads) {
+  if (!text || !what) return nullptr;
+  namespace g = kellerberrin::genome::analysis::gpu;
+  const auto t_begin = std::chrono::steady_clock::now();
+  const g::SortColumns columns = g::sortColumnsFromVcf(std::string_view(text, len), flavour == 0 ? g::SortVcfFlavour::MonoGenome : g::SortVcfFlavour::Phased1000,
+                                                       genome_id ? genome_id : "Reference", threads > 0 ? threads : 0);
+  return dumpVariantSort(columns, what, splitNames(list), threads, t_begin);
+}
+
+// The same with the VCF read from a file chunk_bytes of text at a time (0 = default); null on an I/O error.
+char* kgxh_variant_sort_file(const char* path, int flavour, const char* genome_id, const char* what, const char* list, int threads, uint64_t chunk_bytes) {
+  if (!path || !what) return nullptr;
+  namespace g = kellerberrin::genome::analysis::gpu;
+  const auto t_begin = std::chrono::steady_clock::now();
+  g::SortColumns columns;
+  std::string error;
+  if (!g::sortColumnsFromVcfFile(path, flavour == 0 ? g::SortVcfFlavour::MonoGenome : g::SortVcfFlavour::Phased1000, columns, error,
+                                 genome_id ? genome_id : "Reference", threads > 0 ? threads : 0, chunk_bytes ? static_cast<size_t>(chunk_bytes) : (size_t{64} << 20)))
+    return nullptr;
+  return dumpVariantSort(columns, what, splitNames(list), threads, t_begin);
 }
 
 }  // extern "C"

@@ -57,6 +57,11 @@ enum class SortVcfFlavour {
 [[nodiscard]] SortColumns sortColumnsFromVcf(std::string_view text, SortVcfFlavour flavour, const GenomeId_t& genome_id = "Reference",
                                              size_t threads = 0);
 
+// The same from a file (plain / gzip / block gzip) read a bounded piece at a time (VcfChunkReader): only the record
+// columns and the carriers stay between pieces.  false + error on an I/O or format error.
+[[nodiscard]] bool sortColumnsFromVcfFile(const std::string& file_name, SortVcfFlavour flavour, SortColumns& columns, std::string& error,
+                                          const GenomeId_t& genome_id = "Reference", size_t threads = 0, size_t chunk_bytes = size_t{64} << 20);
+
 // EnsemblIndexMap (kgl_variant_sort.h:27): gene code -> Variants, equal codes in visiting order.
 class EnsemblIndex {
  public:

@@ -1013,21 +1013,36 @@ struct SortParsed {
 
 }  // namespace
 
-SortColumns sortColumnsFromVcf(std::string_view text, SortVcfFlavour flavour, const GenomeId_t& genome_id, size_t threads) {
-  SortColumns out;
-  out.vep_header = vepHeaderNames(text);
-  const auto gene_at = std::find(out.vep_header.begin(), out.vep_header.end(), std::string("Gene"));
-  const size_t gene_column = static_cast<size_t>(gene_at - out.vep_header.begin());
-  const bool have_gene = gene_at != out.vep_header.end();
-  const size_t vep_columns = out.vep_header.size();
-  const VcfLines lines = scanLines(text);
-  const size_t S = lines.samples.size();
-  const bool phased = flavour == SortVcfFlavour::Phased1000;
+namespace {
 
-  std::vector<SortParsed> parsed(lines.records.size());
-  parallelChunks(parsed.size(), 256, threads, [&](size_t begin, size_t end) {
+// next_piece(text): the next run of whole lines; the header (the vep line, #CHROM) is in the first piece.
+template <typename NextChunk>
+SortColumns sortColumnsChunks(NextChunk&& next_piece, SortVcfFlavour flavour, const GenomeId_t& genome_id, size_t threads) {
+  SortColumns out;
+  const bool phased = flavour == SortVcfFlavour::Phased1000;
+  std::vector<SortParsed> parsed;
+  std::vector<std::string> samples;
+  bool first_piece = true;
+  size_t gene_column = 0, vep_columns = 0;
+  bool have_gene = false;
+  std::string_view text;
+  while (next_piece(text)) {
+  if (first_piece) {
+    out.vep_header = vepHeaderNames(text);
+    const auto gene_at = std::find(out.vep_header.begin(), out.vep_header.end(), std::string("Gene"));
+    gene_column = static_cast<size_t>(gene_at - out.vep_header.begin());
+    have_gene = gene_at != out.vep_header.end();
+    vep_columns = out.vep_header.size();
+    first_piece = false;
+  }
+  const VcfLines lines = scanLines(text);
+  if (samples.empty()) samples = lines.samples;
+  const size_t S = samples.size();
+  const size_t parsed_base = parsed.size();
+  parsed.resize(parsed_base + lines.records.size());
+  parallelChunks(lines.records.size(), 256, threads, [&](size_t begin, size_t end) {
     for (size_t r = begin; r < end; ++r) {
-      SortParsed& p = parsed[r];
+      SortParsed& p = parsed[parsed_base + r];
       const auto f = split(lines.records[r], '\t', phased ? S + 10 : 10);
       if (f.size() < 8) continue;                                        // fewer than the mandatory fields: record dropped
       bool pos_ok = true;
@@ -1074,6 +1089,8 @@ SortColumns sortColumnsFromVcf(std::string_view text, SortVcfFlavour flavour, co
       }
     }
   });
+  }
+  const size_t S = samples.size();
 
   // genomes: the one named genome, or the sample names that carry anything (PopulationDB creates a genome on its first variant)
   std::vector<uint32_t> genome_of_sample(S, UINT32_MAX);
@@ -1083,10 +1100,10 @@ SortColumns sortColumnsFromVcf(std::string_view text, SortVcfFlavour flavour, co
     std::vector<uint8_t> carries(S, 0);
     for (const auto& p : parsed) for (const auto& call : p.calls) carries[call.sample] = 1;
     std::map<std::string, uint32_t> by_name;
-    for (size_t s = 0; s < S; ++s) if (carries[s]) by_name.emplace(lines.samples[s], 0);
+    for (size_t s = 0; s < S; ++s) if (carries[s]) by_name.emplace(samples[s], 0);
     uint32_t next = 0;
     for (auto& [name, index] : by_name) { index = next++; out.genome_ids.push_back(name); }
-    for (size_t s = 0; s < S; ++s) if (carries[s]) genome_of_sample[s] = by_name[lines.samples[s]];
+    for (size_t s = 0; s < S; ++s) if (carries[s]) genome_of_sample[s] = by_name[samples[s]];
   }
 
   // records in a genome's visiting order: contig id, offset, then the order the (single-threaded) file gives
@@ -1133,6 +1150,21 @@ SortColumns sortColumnsFromVcf(std::string_view text, SortVcfFlavour flavour, co
     for (const auto& add : added) out.visits[cursor[genome_of_sample[add.sample]]++] = {static_cast<uint32_t>(i), add.alt, add.phase};
   }
   return out;
+}
+
+}  // namespace
+
+SortColumns sortColumnsFromVcf(std::string_view text, SortVcfFlavour flavour, const GenomeId_t& genome_id, size_t threads) {
+  return sortColumnsChunks(WholeText{text}, flavour, genome_id, threads);
+}
+
+bool sortColumnsFromVcfFile(const std::string& file_name, SortVcfFlavour flavour, SortColumns& columns, std::string& error, const GenomeId_t& genome_id,
+                            size_t threads, size_t chunk_bytes) {
+  FilePieces pieces;
+  if (!pieces.reader.open(file_name, error, threads, chunk_bytes)) return false;
+  columns = sortColumnsChunks(pieces, flavour, genome_id, threads);
+  error = pieces.error;
+  return error.empty();
 }
 
 }  // namespace kellerberrin::genome::analysis::gpu

@@ -51,17 +51,27 @@ def lib():
         L.kgxh_inbreed_error.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t]
         L.kgxh_inbreed_copy.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]
         L.kgxh_inbreed_genome_id.argtypes = [C.c_void_p, C.c_uint64, C.c_char_p, C.c_size_t]
+        L.kgxh_variant_sort_file.restype = C.c_void_p
+        L.kgxh_variant_sort_file.argtypes = [C.c_char_p, C.c_int, C.c_char_p, C.c_char_p, C.c_char_p, C.c_int, C.c_uint64]
         L.kgxh_variant_sort.restype = C.c_void_p
         L.kgxh_variant_sort.argtypes = [C.c_char_p, C.c_uint64, C.c_int, C.c_char_p, C.c_char_p, C.c_char_p, C.c_int]
         _lib = L
     return _lib
 
 
-def variant_sort(text: str, flavour: str, what: str, names=None, genome_id: str = "Reference", threads: int = 0) -> list[tuple[str, ...]]:
-    """The rsid / Ensembl indexes of kgx_variant_sort.h over VCF text, as rows of strings in index order."""
-    b = text.encode()
+def variant_sort(text: str | None, flavour: str, what: str, names=None, genome_id: str = "Reference", threads: int = 0, path=None,
+                 chunk_bytes: int = 0) -> list[tuple[str, ...]]:
+    """The rsid / Ensembl indexes of kgx_variant_sort.h over VCF text (or a file read chunk_bytes at a time), as rows of strings
+    in index order."""
     listed = None if names is None else "\n".join(names).encode()
-    ptr = lib().kgxh_variant_sort(b, len(b), {"MonoGenome": 0, "Genome1000": 1}[flavour], genome_id.encode(), what.encode(), listed, threads)
+    code = {"MonoGenome": 0, "Genome1000": 1}[flavour]
+    if path is not None:
+        ptr = lib().kgxh_variant_sort_file(str(path).encode(), code, genome_id.encode(), what.encode(), listed, threads, chunk_bytes)
+        if not ptr:
+            raise IOError(str(path))
+    else:
+        b = text.encode()
+        ptr = lib().kgxh_variant_sort(b, len(b), code, genome_id.encode(), what.encode(), listed, threads)
     assert ptr, what
     try:
         out = C.string_at(ptr).decode()

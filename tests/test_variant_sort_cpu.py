@@ -191,6 +191,22 @@ def test_hand_worked_indexes():
         assert population.variant_sort(what) == H.variant_sort(text, "Genome1000", what), what
 
 
+@pytest.mark.parametrize("flavour", ["MonoGenome", "Genome1000"])
+def test_indexes_from_a_file_read_in_pieces(tmp_path, flavour):
+    from . import vcf_text as vt
+
+    text = sort_vcf(31, flavour)
+    (tmp_path / "sites.vcf").write_text(text)
+    (tmp_path / "sites.vcf.bgz").write_bytes(vt.bgzip(text.encode(), block=2000))
+    for what in KINDS_ALL:
+        want = H.variant_sort(text, flavour, what)
+        for name in ("sites.vcf", "sites.vcf.bgz"):
+            for chunk_bytes in (1, 900, 0):
+                assert H.variant_sort(None, flavour, what, path=tmp_path / name, chunk_bytes=chunk_bytes, threads=2) == want, (what, name, chunk_bytes)
+    with pytest.raises(IOError):
+        H.variant_sort(None, flavour, "id", path=tmp_path / "missing.vcf")
+
+
 def test_empty_inputs():
     for flavour in ("MonoGenome", "Genome1000"):
         for text in ("", "##fileformat=VCFv4.2\n", "#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\n", "1\t5\n"):
