@@ -253,12 +253,12 @@ bool kga::GpuInbreedAnalysis::referenceInput(GpuReferenceContig& reference) cons
     reference = buildReference(*unphased_population_, ok);
     return ok;
   }
-  std::string text, io_error;
-  if (!gpu::readVcfText(reference_vcf_, text, io_error)) {           // plain text, .gz or .bgz
+  std::string io_error;
+  gpu::FlatReference flat;                                           // plain text, .gz or .bgz, a bounded piece at a time
+  if (!gpu::flattenReferenceVcfFile(reference_vcf_, reference_vcf_source_, flat, io_error)) {
     ExecEnv::log().error("GpuInbreedAnalysis; reference VCF: {}", io_error);
     return false;
   }
-  gpu::FlatReference flat = gpu::flattenReferenceVcf(text, reference_vcf_source_);
   if (flat.contigs != 1) {
     ExecEnv::log().error("InbreedingAnalysis::populationInbreeding; Unphased Population: {} has unexpected contig count: {}", reference_vcf_, flat.contigs);
     return false;

@@ -104,6 +104,9 @@ struct FlatReference {
   std::vector<ReferenceLocusRow> loci;     // ascending offset
 };
 [[nodiscard]] FlatReference flattenReferenceVcf(std::string_view text, DataSourceEnum data_source);
+// The same from a file read a bounded piece at a time (threads: the block-gzip inflate; the records are walked in order).
+[[nodiscard]] bool flattenReferenceVcfFile(const std::string& file_name, DataSourceEnum data_source, FlatReference& reference, std::string& error,
+                                           size_t threads = 0, size_t chunk_bytes = size_t{64} << 20);
 
 // The phased diploid population (1000-Genomes flavour, as flattenVcf1000) as the allele-index bytes of the inbreeding
 // sweep: for every reference locus and genome, the genome's SNP variants at that offset in the order the parser adds

@@ -130,14 +130,24 @@ void* kgxh_inbreed_inputs(const char* reference_text, uint64_t reference_len, in
   out->diploid = g::flattenVcf1000Gt8(std::string_view(diploid_text, diploid_len), out->reference, threads > 0 ? threads : 0);
   return out;
 }
-// The population from a FILE, read diploid_chunk_bytes of text at a time (0 = default); null on an I/O error.
+// The population from a FILE, read diploid_chunk_bytes of text at a time (0 = default); null on an I/O error.  With
+// reference_len == 0, reference_text names the reference site FILE, read the same way.
 void* kgxh_inbreed_inputs_file(const char* reference_text, uint64_t reference_len, int data_source, const char* diploid_path, int threads,
                                uint64_t diploid_chunk_bytes) {
   if (!reference_text || !diploid_path) return nullptr;
   namespace g = kellerberrin::genome::analysis::gpu;
   auto* out = new InbreedInputs();
-  out->reference = g::flattenReferenceVcf(std::string_view(reference_text, reference_len), static_cast<kellerberrin::genome::DataSourceEnum>(data_source));
   std::string error;
+  const size_t piece = diploid_chunk_bytes ? static_cast<size_t>(diploid_chunk_bytes) : (size_t{64} << 20);
+  if (reference_len == 0) {
+    if (!g::flattenReferenceVcfFile(reference_text, static_cast<kellerberrin::genome::DataSourceEnum>(data_source), out->reference, error,
+                                    threads > 0 ? threads : 0, piece)) {
+      delete out;
+      return nullptr;
+    }
+  } else {
+    out->reference = g::flattenReferenceVcf(std::string_view(reference_text, reference_len), static_cast<kellerberrin::genome::DataSourceEnum>(data_source));
+  }
   if (!g::flattenVcf1000Gt8File(diploid_path, out->reference, out->diploid, error, threads > 0 ? threads : 0,
                                 diploid_chunk_bytes ? static_cast<size_t>(diploid_chunk_bytes) : (size_t{64} << 20))) {
     delete out;

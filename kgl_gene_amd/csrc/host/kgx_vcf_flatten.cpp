@@ -684,14 +684,19 @@ double infoFrequency(std::string_view info, std::string_view field, size_t alt_i
 
 }  // namespace
 
-FlatReference flattenReferenceVcf(std::string_view text, DataSourceEnum data_source) {
-  const VcfLines lines = scanLines(text);
+namespace {
+
+template <typename NextChunk>
+FlatReference flattenReferenceChunks(NextChunk&& next_piece, DataSourceEnum data_source) {
   const auto& super_pops = FrequencyDatabaseRead::superPopulations();
   std::vector<std::string> fields;
   for (const auto& sp : super_pops) fields.push_back(FrequencyDatabaseRead::lookupVariantSuperPopField(data_source, sp).value_or(std::string()));
   FlatReference out;
   std::map<ContigOffset_t, ReferenceLocusRow> by_offset;
   std::vector<std::string> contigs_seen;
+  std::string_view text;
+  while (next_piece(text)) {
+  const VcfLines lines = scanLines(text);
   for (const auto record : lines.records) {
     const auto f = split(record, '\t', 10);
     if (f.size() < 8) continue;
@@ -720,6 +725,7 @@ FlatReference flattenReferenceVcf(std::string_view text, DataSourceEnum data_sou
       locus.alts.push_back(std::move(alt));
     }
   }
+  }
   out.contigs = contigs_seen.size();
   if (!contigs_seen.empty()) out.contig_id = contigs_seen.front();
   for (auto& [offset, locus] : by_offset) {
@@ -727,6 +733,19 @@ FlatReference flattenReferenceVcf(std::string_view text, DataSourceEnum data_sou
     out.loci.push_back(std::move(locus));
   }
   return out;
+}
+
+}  // namespace
+
+FlatReference flattenReferenceVcf(std::string_view text, DataSourceEnum data_source) { return flattenReferenceChunks(WholeText{text}, data_source); }
+
+bool flattenReferenceVcfFile(const std::string& file_name, DataSourceEnum data_source, FlatReference& reference, std::string& error, size_t threads,
+                             size_t chunk_bytes) {
+  FilePieces pieces;
+  if (!pieces.reader.open(file_name, error, threads, chunk_bytes)) return false;
+  reference = flattenReferenceChunks(pieces, data_source);
+  error = pieces.error;
+  return error.empty();
 }
 
 namespace {

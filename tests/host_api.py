@@ -150,10 +150,15 @@ class InbreedInputs:
     """The INBREED package's two inputs flattened from VCF text: reference loci (offset, alts, AF per super population)
     and the population's allele-index bytes [n_loci][genomes]."""
 
-    def __init__(self, reference_text: str, data_source: int, diploid_text: str | None, threads: int = 0, diploid_path=None, chunk_bytes: int = 0):
+    def __init__(self, reference_text: str, data_source: int, diploid_text: str | None, threads: int = 0, diploid_path=None, chunk_bytes: int = 0,
+                 reference_path=None):
         rb = reference_text.encode()
         if diploid_path is not None:
-            h = lib().kgxh_inbreed_inputs_file(rb, len(rb), data_source, str(diploid_path).encode(), threads, chunk_bytes)
+            # reference_path: the reference site file is read in pieces too (reference_text is then ignored)
+            if reference_path is not None:
+                h = lib().kgxh_inbreed_inputs_file(str(reference_path).encode(), 0, data_source, str(diploid_path).encode(), threads, chunk_bytes)
+            else:
+                h = lib().kgxh_inbreed_inputs_file(rb, len(rb), data_source, str(diploid_path).encode(), threads, chunk_bytes)
             if not h:
                 raise IOError(str(diploid_path))
         else:

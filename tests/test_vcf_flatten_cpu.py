@@ -208,6 +208,12 @@ def test_inbreed_inputs_from_vcf_match_the_scaffold_encoder(threads):
                 for chunk_bytes in (1, 2500, 0):
                     piecewise = ha.InbreedInputs(ref_text, DATA_SOURCE["Gnomad2_1"], None, 2, diploid_path=Path(tmp) / name, chunk_bytes=chunk_bytes)
                     assert piecewise.genome_ids == got.genome_ids and np.array_equal(piecewise.bytes, got.bytes), (name, chunk_bytes)
+            # and the reference site file in pieces as well
+            (Path(tmp) / "sites.vcf.bgz").write_bytes(vt.bgzip(ref_text.encode(), block=5000))
+            for chunk_bytes in (1, 4000, 0):
+                both = ha.InbreedInputs(ref_text, DATA_SOURCE["Gnomad2_1"], None, 2, diploid_path=Path(tmp) / "plain.vcf", chunk_bytes=chunk_bytes,
+                                        reference_path=Path(tmp) / "sites.vcf.bgz")
+                assert np.array_equal(both.offsets, got.offsets) and np.array_equal(both.af, got.af, equal_nan=True) and np.array_equal(both.bytes, got.bytes)
             with pytest.raises(IOError):
                 ha.InbreedInputs(ref_text, DATA_SOURCE["Gnomad2_1"], None, diploid_path=Path(tmp) / "missing.vcf")
     # a repeated record gives its carriers a second copy on the SAME phase: the (0, a) byte, as the scaffold encoder writes it
