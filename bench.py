@@ -98,8 +98,9 @@ def cpu_baseline(capi, pop, G, V, k2_host_sample_rows, sample_variants):
 def inbreed_workload(args, capi, dist, torch, dev, wl, L, n_gpus, rank):
     """C5: every rank sweeps its own genomes (no collective: per-genome results only need that genome's bytes and the
     per-locus tables).  A step = one kgx_inbreed call = the frequency sweep + the estimator's passes.  The boundary
-    hands the per-locus AF table over from the host each call, so ms_per_step includes that upload; roofline.achieved
-    is the frequency-sweep kernel time alone (HIP events inside the library)."""
+    takes the per-locus AF table from the host or from device memory; here it is resident in HBM with the genotypes
+    before the timed region starts (a host table adds a 120 MB upload to every call: see DESIGN.md); roofline.achieved is
+    the frequency-sweep kernel time alone (HIP events inside the library)."""
     G = args.genomes or wl["genomes_per_gpu"]
     m = capi.GenotypeMatrix(G, L)
     table = m.synth_multiallelic(args.seed, rank * G, 0)
@@ -110,14 +111,16 @@ def inbreed_workload(args, capi, dist, torch, dev, wl, L, n_gpus, rank):
             dist.barrier()
         torch.cuda.synchronize(dev)
 
+    table_dev = torch.from_numpy(np.ascontiguousarray(table, dtype=np.float64)).to(dev)
+    n_sel, amax = table.shape
     res = None
     for _ in range(args.warmup):
-        res = m.inbreed(table, args.algorithm, phased=True)
+        res = m.inbreed_resident(table_dev.data_ptr(), n_sel, amax, args.algorithm, phased=True)
     fence()
     t0 = time.perf_counter()
     sweep_ms = []
     for _ in range(args.steps):
-        res = m.inbreed(table, args.algorithm, phased=True)
+        res = m.inbreed_resident(table_dev.data_ptr(), n_sel, amax, args.algorithm, phased=True)
         sweep_ms.append(capi.inbreed_last_sweep_ms())
     fence()
     elapsed = time.perf_counter() - t0

@@ -196,7 +196,8 @@ int kgx_locus_class_frequencies(const double* minor_af, uint64_t n_loci, uint32_
  * locus_index[n_selected]: rows of the matrix, ascending (NULL = rows 0..n_selected-1);
  * minor_af[n_selected][amax]: super-population allele frequency of each reference alt (double(float32)), NaN = the
  * alt is not in the locus's AlleleFreqVector; phased != 0 when the two copies of a homozygous alt carry different
- * phases (1000-Genomes style); algorithm = KGX_ALGO_*.  out[g1-g0]. */
+ * phases (1000-Genomes style); algorithm = KGX_ALGO_*.  out[g1-g0] (host).  locus_index and minor_af may be host
+ * pointers or pointers to memory of this device (a table kept resident between calls is then copied device to device). */
 int kgx_inbreed(kgx_gt8* gt, uint64_t g0, uint64_t g1, const uint32_t* locus_index, uint64_t n_selected,
                 const double* minor_af, uint32_t amax, int phased, int algorithm, kgx_locus_results* out);
 /* Device time (HIP events on the library stream) of the frequency sweep -- locus helpers + the K5 kernel, i.e. the one

@@ -391,6 +391,14 @@ class GenotypeMatrix:
                                 ALGORITHMS[algorithm], ptr(out)))
         return out
 
+    def inbreed_resident(self, minor_af_dev: int, n_selected: int, amax: int, algorithm: str, phased: bool, g0: int = 0, g1: int | None = None):
+        """inbreed() with the allele-frequency table already on this device: minor_af_dev is the device address of
+        float64 [n_selected][amax] (e.g. a torch tensor's data_ptr())."""
+        g1 = self.n_genomes if g1 is None else g1
+        out = np.zeros(g1 - g0, dtype=LOCUS_RESULTS_DTYPE)
+        check(lib().kgx_inbreed(self._h, g0, g1, None, n_selected, C.c_void_p(minor_af_dev), amax, int(bool(phased)), ALGORITHMS[algorithm], ptr(out)))
+        return out
+
 
 def release_scratch() -> None:
     """Free the arena kgx_inbreed keeps its per-call device buffers in."""

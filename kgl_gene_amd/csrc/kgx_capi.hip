@@ -866,8 +866,9 @@ int kgx_inbreed(kgx_gt8* h, uint64_t g0, uint64_t g1, const uint32_t* locus_inde
   }
   hipStream_t st = g_state.stream;
   if (rc == KGX_OK && n_sel) {
-    try_hip(hipMemcpyAsync(d_af, minor_af, n_sel * amax * sizeof(double), hipMemcpyHostToDevice, st), KGX_EHIP, "H2D(af)");
-    if (d_index) try_hip(hipMemcpyAsync(d_index, locus_index, n_sel * sizeof(uint32_t), hipMemcpyHostToDevice, st), KGX_EHIP, "H2D(index)");
+    // hipMemcpyDefault: the caller's tables may live on the host or already on this device (kgx.h)
+    try_hip(hipMemcpyAsync(d_af, minor_af, n_sel * amax * sizeof(double), hipMemcpyDefault, st), KGX_EHIP, "copy(af)");
+    if (d_index) try_hip(hipMemcpyAsync(d_index, locus_index, n_sel * sizeof(uint32_t), hipMemcpyDefault, st), KGX_EHIP, "copy(index)");
   }
   try_hip(hipMemsetAsync(d_counts, 0, n * 6 * sizeof(unsigned long long), st), KGX_EHIP, "memset(counts)");
   try_hip(hipMemsetAsync(d_part, 0, n_seg * n * kParts0 * sizeof(double), st), KGX_EHIP, "memset(partials)");

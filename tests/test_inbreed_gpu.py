@@ -106,6 +106,29 @@ def test_inbreed_window_vs_oracle(kgx, mode, algorithm, path, monkeypatch):
     m.close()
 
 
+def test_inbreed_takes_a_device_resident_af_table(kgx):
+    import ctypes as C
+
+    hip = C.CDLL("libamdhip64.so")          # the runtime libkgx.so itself is linked against (already loaded)
+    G, L = 90, 400
+    rng = np.random.default_rng(3)
+    rows = rng.choice(np.array([0, 0, 0, 1, 0x11, 0x21, 2, 0x12], dtype=np.uint8), size=(L, G))
+    af = rng.uniform(0.01, 0.3, (L, 2))
+    m = kgx.GenotypeMatrix(G, L)
+    m.load_rows(rows)
+    af_dev = C.c_void_p()
+    assert hip.hipMalloc(C.byref(af_dev), C.c_size_t(af.nbytes)) == 0
+    assert hip.hipMemcpy(af_dev, C.c_void_p(af.ctypes.data), C.c_size_t(af.nbytes), 1) == 0      # hipMemcpyHostToDevice
+    try:
+        for algorithm in ("Simple", "Loglikelihood"):
+            host = m.inbreed(af, algorithm, phased=True)
+            resident = m.inbreed_resident(af_dev.value, L, 2, algorithm, phased=True)
+            assert host.tobytes() == resident.tobytes(), algorithm
+    finally:
+        hip.hipFree(af_dev)
+        m.close()
+
+
 def test_genome_major_loader_and_subranges(kgx):
     G, L = 75, 300
     rng = np.random.default_rng(1)
