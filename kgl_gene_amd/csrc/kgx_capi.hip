@@ -665,6 +665,7 @@ int kgx_gt8_load(kgx_gt8* h, const uint8_t* src, uint64_t g0, uint64_t g1) {
   if (!h || !src) return fail(KGX_EINVAL, "null handle or source");
   if (g0 > g1 || g1 > h->n_genomes) return fail(KGX_EINVAL, "genome range out of bounds");
   if (g0 == g1 || h->n_loci == 0) return KGX_OK;
+  h->wide_nibbles = 0;              // the bytes change: look again (kgx_inbreed)
   const uint64_t L = h->n_loci;
   uint64_t slab = (1ull << 30) / L;
   if (slab < 1) slab = 1;
@@ -692,6 +693,7 @@ int kgx_gt8_load_rows(kgx_gt8* h, const uint8_t* src, uint64_t src_pitch, uint64
   if (!h || !src) return fail(KGX_EINVAL, "null handle or source");
   if (l0 > l1 || l1 > h->n_loci || src_pitch < h->n_genomes) return fail(KGX_EINVAL, "bad locus range or pitch");
   if (l0 == l1) return KGX_OK;
+  h->wide_nibbles = 0;
   KGX_HIP(hipMemcpy2DAsync(h->d_gt + l0 * h->pitch, h->pitch, src, src_pitch, h->n_genomes, l1 - l0, hipMemcpyHostToDevice, g_state.stream));
   KGX_HIP(hipStreamSynchronize(g_state.stream));
   return KGX_OK;
@@ -877,6 +879,25 @@ int kgx_inbreed(kgx_gt8* h, uint64_t g0, uint64_t g1, const uint32_t* locus_inde
   const dim3 grid(gx, static_cast<uint32_t>(n_seg));
   const uint32_t* gt32 = reinterpret_cast<const uint32_t*>(h->d_gt);
   const uint64_t dwords_per_row = h->pitch / 4;
+  // The SWAR sweeps guard against allele indexes 8..14 (past their 8-entry tables) only if the matrix holds any: looked
+  // up once per content of the matrix, by one pass over its bytes (KGX_K5_ALWAYS_GUARD=1 skips the look and guards).
+  bool guard = true;
+  if (rc == KGX_OK && n_sel && (swar16 || amax <= 4) && env_int("KGX_K5_ALWAYS_GUARD", 0) == 0) {
+    if (h->wide_nibbles == 0) {
+      unsigned int found = 0;
+      try_hip(hipMemsetAsync(d_running, 0, sizeof(unsigned int), st), KGX_EHIP, "memset(scan flag)");
+      const uint64_t n_chunks = h->n_loci * (h->pitch / 16);
+      if (rc == KGX_OK) {
+        hipLaunchKernelGGL(k_scan_wide_nibbles, dim3(stream_grid(n_chunks, kBlock)), dim3(kBlock), 0, st, reinterpret_cast<const kgx_v4u*>(h->d_gt),
+                           n_chunks, d_running);
+        try_hip(hipGetLastError(), KGX_EHIP, "k_scan_wide_nibbles launch");
+        try_hip(hipMemcpyAsync(&found, d_running, sizeof(found), hipMemcpyDeviceToHost, st), KGX_EHIP, "D2H(scan flag)");
+        try_hip(hipStreamSynchronize(st), KGX_EHIP, "sync");
+      }
+      if (rc == KGX_OK) h->wide_nibbles = found ? 2 : 1;
+    }
+    guard = h->wide_nibbles != 1;
+  }
   auto sweep = [&](int mode) {
     if (n_sel == 0) return;
     if (mode == 0) {
@@ -886,24 +907,24 @@ int kgx_inbreed(kgx_gt8* h, uint64_t g0, uint64_t g1, const uint32_t* locus_inde
         hipLaunchKernelGGL(k_fill_defaults, dim3(stream_grid(n_seg * n, kBlock)), dim3(kBlock), 0, st, d_segdef, n_seg, n, d_part);
         const dim3 grid16(gx16, static_cast<uint32_t>(n_seg));
         const kgx_v4u* gt128 = reinterpret_cast<const kgx_v4u*>(h->d_gt);
-        if (d_index)
-          hipLaunchKernelGGL((k_inbreed_sweep_swar16<true>), grid16, dim3(kBlock), 0, st, gt128, h->pitch / 16, g0, n, d_index, n_sel, per_seg,
-                             d_table, d_meta, amax, phased, d_segdef, d_counts, d_part);
-        else
-          hipLaunchKernelGGL((k_inbreed_sweep_swar16<false>), grid16, dim3(kBlock), 0, st, gt128, h->pitch / 16, g0, n, d_index, n_sel, per_seg,
-                             d_table, d_meta, amax, phased, d_segdef, d_counts, d_part);
+#define KGX_SWAR16(INDEXED, GUARD)                                                                                                  \
+  hipLaunchKernelGGL((k_inbreed_sweep_swar16<INDEXED, GUARD>), grid16, dim3(kBlock), 0, st, gt128, h->pitch / 16, g0, n, d_index, n_sel, \
+                     per_seg, d_table, d_meta, amax, phased, d_segdef, d_counts, d_part)
+        if (d_index) { if (guard) KGX_SWAR16(true, true); else KGX_SWAR16(true, false); }
+        else { if (guard) KGX_SWAR16(false, true); else KGX_SWAR16(false, false); }
+#undef KGX_SWAR16
       } else if (env_int("KGX_K5_GENERIC", 0) || amax > 4 || (algorithm == KGX_ALGO_RITLAND_LOCUS && !ritland_lut)) {
         hipLaunchKernelGGL((k_inbreed_sweep<0>), grid, dim3(kBlock), 0, st, gt32, dwords_per_row, g0, n, d_index, n_sel, per_seg, d_table,
                            d_valid, amax, phased, d_f, d_counts, d_part);
       } else {
         hipLaunchKernelGGL(k_locus_bits, dim3(stream_grid(n_sel, kBlock)), dim3(kBlock), 0, st, d_table, d_valid, n_sel, amax, d_meta);
         hipLaunchKernelGGL(k_segment_defaults, dim3(static_cast<uint32_t>(n_seg)), dim3(kWave), 0, st, d_table, d_valid, n_sel, per_seg, amax, d_segdef);
-        if (d_index)
-          hipLaunchKernelGGL((k_inbreed_sweep_swar<true>), grid, dim3(kBlock), 0, st, gt32, dwords_per_row, g0, n, d_index, n_sel, per_seg,
-                             d_table, d_meta, amax, phased, d_segdef, d_counts, d_part);
-        else
-          hipLaunchKernelGGL((k_inbreed_sweep_swar<false>), grid, dim3(kBlock), 0, st, gt32, dwords_per_row, g0, n, d_index, n_sel, per_seg,
-                             d_table, d_meta, amax, phased, d_segdef, d_counts, d_part);
+#define KGX_SWAR(INDEXED, GUARD)                                                                                                   \
+  hipLaunchKernelGGL((k_inbreed_sweep_swar<INDEXED, GUARD>), grid, dim3(kBlock), 0, st, gt32, dwords_per_row, g0, n, d_index, n_sel,    \
+                     per_seg, d_table, d_meta, amax, phased, d_segdef, d_counts, d_part)
+        if (d_index) { if (guard) KGX_SWAR(true, true); else KGX_SWAR(true, false); }
+        else { if (guard) KGX_SWAR(false, true); else KGX_SWAR(false, false); }
+#undef KGX_SWAR
       }
     } else if (eval_lut || mode == 3) {
       const dim3 grid_eval(static_cast<uint32_t>(((n + eval_gpl - 1) / eval_gpl + kBlock - 1) / kBlock), static_cast<uint32_t>(n_seg));
@@ -1147,6 +1168,7 @@ int kgx_gt8_synth_multiallelic(kgx_gt8* h, uint64_t seed, uint64_t genome_base, 
   if (int rc = require_device()) return rc;
   if (!h) return fail(KGX_EINVAL, "null handle");
   if (h->n_loci == 0) return KGX_OK;
+  h->wide_nibbles = 0;
   double* d_table = nullptr;
   if (af_table) KGX_HIP_MEM(hipMalloc(&d_table, h->n_loci * KGX_SYNTH_MAX_ALTS * sizeof(double)));
   const uint64_t work = h->n_loci * ((h->n_genomes + 3) / 4);
@@ -1199,6 +1221,7 @@ int kgx_gt8_synth_inbred(kgx_gt8* h, const double* minor_af, uint32_t amax, cons
   if (!h || !minor_af || !inbreeding) return fail(KGX_EINVAL, "null argument");
   if (amax == 0 || amax > 14) return fail(KGX_EINVAL, "amax %u outside [1,14]", amax);
   if (h->n_loci == 0) return KGX_OK;
+  h->wide_nibbles = 0;
   double *d_table = nullptr, *d_f = nullptr;
   KGX_HIP_MEM(hipMalloc(&d_table, h->n_loci * amax * sizeof(double)));
   if (hipMalloc(&d_f, h->n_genomes * sizeof(double)) != hipSuccess) { (void)hipGetLastError(); (void)hipFree(d_table); return fail(KGX_ENOMEM, "hipMalloc failed"); }

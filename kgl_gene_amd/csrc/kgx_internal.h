@@ -23,6 +23,10 @@ struct kgx_gt8 {
   uint64_t n_loci = 0;
   uint64_t pitch = 0;            // bytes per locus row, multiple of 128
   uint8_t* d_gt = nullptr;       // [n_loci][pitch]
+  // Does any byte hold an allele index 8..14 (a nibble with bit 3 set that is not 15)?  0 = not looked at since the
+  // bytes last changed, 1 = none, 2 = some.  Without them the SWAR sweeps need no guard against indexes past their
+  // 8-entry tables (k_scan_wide_nibbles; every flattener output at <= 7 reference alts is such a matrix).
+  int wide_nibbles = 0;
 };
 
 namespace kgx {

@@ -1044,6 +1044,22 @@ k_segment_defaults(const double* __restrict__ table, const uint8_t* __restrict__
 // the AlleleFreqVector, which have AF > 0.001), so a wave never diverges on genotype; only the rare cells whose
 // classification disagrees with the locus default touch fp64 class sums.  amax <= 4 (wider loci take the generic kernel).
 
+// Sets *found when some byte of the matrix holds an allele index 8..14 (bit 3 of a nibble set, the nibble not 15).
+__global__ void __launch_bounds__(kBlock)
+k_scan_wide_nibbles(const kgx_v4u* __restrict__ gt, uint64_t n_chunks, unsigned int* __restrict__ found) {
+  uint32_t any = 0;
+  for (uint64_t i = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n_chunks; i += static_cast<uint64_t>(gridDim.x) * blockDim.x) {
+    const kgx_v4u v = __builtin_nontemporal_load(gt + i);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const uint32_t x = v[k];
+      const uint32_t fifteen = x & (x >> 1) & (x >> 2) & (x >> 3) & 0x11111111u;      // 1 at the nibbles that are 15
+      any |= ((x >> 3) & 0x11111111u) & ~fifteen;
+    }
+  }
+  if (__any(any != 0) && (threadIdx.x & (kWave - 1)) == 0) atomicOr(found, 1u);
+}
+
 // meta[s] (for amax <= 7): flag bits (kLocus*) | in_list bits 0..7 << 8 | rit_ok bits << 16 — one scalar dword per locus.
 __global__ void __launch_bounds__(kBlock)
 k_locus_bits(const double* __restrict__ table, const uint8_t* __restrict__ flags, uint64_t n_sel, uint32_t amax,
@@ -1080,11 +1096,14 @@ __device__ __forceinline__ uint32_t bytes_nonzero(uint32_t x) {   // x: bytes <=
 struct SwarClasses {
   uint32_t major_het, minor_hom, minor_het, nonzero;
 };
+// GUARD = false: the matrix is known to hold no allele index 8..14 (kgx_gt8::wide_nibbles == 1).  15 aliases onto
+// selector 7, whose LUT entry is 0, so "unknown alt" and 0xFF need no guard; only 8..14 would alias onto real entries.
+template <bool GUARD>
 __device__ __forceinline__ SwarClasses swar_classify(uint32_t x, uint32_t lut_lo, uint32_t lut_hi, uint32_t same_lut) {
   const uint32_t xs = x >> 4;
   const uint32_t lo = x & 0x07070707u, hi = xs & 0x07070707u;
   const uint32_t t = x | xs;                                                     // low nibble of each byte: lo | hi
-  const uint32_t ok1 = __builtin_amdgcn_perm(lut_hi, lut_lo, lo) & ~(t >> 3);
+  const uint32_t ok1 = GUARD ? (__builtin_amdgcn_perm(lut_hi, lut_lo, lo) & ~(t >> 3)) : __builtin_amdgcn_perm(lut_hi, lut_lo, lo);
   const uint32_t ok2 = __builtin_amdgcn_perm(lut_hi, lut_lo, hi);
   const uint32_t hom = __builtin_amdgcn_perm(0u, same_lut, lo ^ hi);             // homozygous(): same HGVS, different phase
   const uint32_t single = __builtin_amdgcn_perm(0u, 1u, hi);
@@ -1119,7 +1138,7 @@ __device__ __noinline__ SwarSpecial swar_special_cells(uint32_t x, uint32_t spec
 
 // locus_index and meta are padded by 8 entries past n_sel (whole batches are fetched with one scalar load each);
 // loci_per_seg is a multiple of 8.
-template <bool INDEXED>
+template <bool INDEXED, bool GUARD>
 __global__ void __launch_bounds__(kBlock)
 k_inbreed_sweep_swar(const uint32_t* __restrict__ gt, uint64_t dwords_per_row, uint64_t g0, uint64_t n_genomes,
                      const uint32_t* __restrict__ locus_index, uint64_t n_sel, uint64_t loci_per_seg,
@@ -1181,7 +1200,7 @@ k_inbreed_sweep_swar(const uint32_t* __restrict__ gt, uint64_t dwords_per_row, u
       const uint32_t lut_lo = ((in_list >> 0) & 1u) | (((in_list >> 1) & 1u) << 8) | (((in_list >> 2) & 1u) << 16) | (((in_list >> 3) & 1u) << 24);
       const uint32_t lut_hi = ((in_list >> 4) & 1u) | (((in_list >> 5) & 1u) << 8) | (((in_list >> 6) & 1u) << 16);
       const bool is_default = (f & kLocusDefault) != 0;       // wave-uniform
-      const SwarClasses c = swar_classify(w[i], lut_lo, lut_hi, same_lut);
+      const SwarClasses c = swar_classify<GUARD>(w[i], lut_lo, lut_hi, same_lut);
       b_major_het += c.major_het;
       b_minor_hom += c.minor_hom;
       b_minor_het += c.minor_het;
@@ -1242,7 +1261,7 @@ k_inbreed_sweep_swar(const uint32_t* __restrict__ gt, uint64_t dwords_per_row, u
 // default adjust the lane's own (segment, genome) partial slot in memory directly — the slot has exactly one writer,
 // so the result is deterministic — which keeps fp64 out of the register file.  part[] must be pre-filled with the
 // segment defaults (k_fill_defaults).
-template <bool INDEXED>
+template <bool INDEXED, bool GUARD>
 __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(3)))      // three waves per SIMD: <= 170 VGPRs
 k_inbreed_sweep_swar16(const kgx_v4u* __restrict__ gt, uint64_t chunks_per_row, uint64_t g0, uint64_t n_genomes,
                        const uint32_t* __restrict__ locus_index, uint64_t n_sel, uint64_t loci_per_seg,
@@ -1312,7 +1331,7 @@ k_inbreed_sweep_swar16(const kgx_v4u* __restrict__ gt, uint64_t chunks_per_row, 
       uint32_t rare_any = 0;
 #pragma unroll
       for (int d = 0; d < 4; ++d) {
-        const SwarClasses c = swar_classify(w[i][d], lut_lo, lut_hi, same_lut);
+        const SwarClasses c = swar_classify<GUARD>(w[i][d], lut_lo, lut_hi, same_lut);
         b_mhet[d] += c.major_het;
         b_mhom[d] += c.minor_hom;
         b_nhet[d] += c.minor_het;
