@@ -1102,8 +1102,16 @@ template <bool GUARD>
 __device__ __forceinline__ SwarClasses swar_classify(uint32_t x, uint32_t lut_lo, uint32_t lut_hi, uint32_t same_lut) {
   const uint32_t xs = x >> 4;
   const uint32_t lo = x & 0x07070707u, hi = xs & 0x07070707u;
-  const uint32_t t = x | xs;                                                     // low nibble of each byte: lo | hi
-  const uint32_t ok1 = GUARD ? (__builtin_amdgcn_perm(lut_hi, lut_lo, lo) & ~(t >> 3)) : __builtin_amdgcn_perm(lut_hi, lut_lo, lo);
+  uint32_t ok1, nonzero;
+  if constexpr (GUARD) {
+    const uint32_t t = x | xs;                                                   // low nibble of each byte: lo | hi
+    ok1 = __builtin_amdgcn_perm(lut_hi, lut_lo, lo) & ~(t >> 3);
+    nonzero = bytes_nonzero(t & 0x0F0F0F0Fu);
+  } else {
+    // nibbles are 0..7 or 15 here, so lo | hi (3-bit) is 0 exactly where both nibbles are 0: one more byte LUT
+    ok1 = __builtin_amdgcn_perm(lut_hi, lut_lo, lo);
+    nonzero = __builtin_amdgcn_perm(0x01010101u, 0x01010100u, lo | hi);
+  }
   const uint32_t ok2 = __builtin_amdgcn_perm(lut_hi, lut_lo, hi);
   const uint32_t hom = __builtin_amdgcn_perm(0u, same_lut, lo ^ hi);             // homozygous(): same HGVS, different phase
   const uint32_t single = __builtin_amdgcn_perm(0u, 1u, hi);
@@ -1111,7 +1119,7 @@ __device__ __forceinline__ SwarClasses swar_classify(uint32_t x, uint32_t lut_lo
   c.major_het = ok1 & single;
   c.minor_hom = ok1 & hom;
   c.minor_het = (ok1 & ok2) ^ c.minor_hom;       // hom => ok2 == ok1; ok2 => a second variant (LUT entry 0 is 0)
-  c.nonzero = bytes_nonzero(t & 0x0F0F0F0Fu);
+  c.nonzero = nonzero;
   return c;
 }
 
