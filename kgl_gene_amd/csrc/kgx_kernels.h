@@ -1284,13 +1284,17 @@ k_inbreed_sweep_swar16(const kgx_v4u* __restrict__ gt, uint64_t chunks_per_row, 
   const uint64_t col = (g0 >> 4) + lane16;                 // g0 is a multiple of 16
   const uint32_t same_lut = phased ? 1u : 0u;
 
-  uint32_t b_mhet[4] = {0, 0, 0, 0}, b_mhom[4] = {0, 0, 0, 0}, b_nhet[4] = {0, 0, 0, 0}, b_miss[4] = {0, 0, 0, 0};   // byte lanes
+  uint32_t b_mhet[4] = {0, 0, 0, 0}, b_mhom[4] = {0, 0, 0, 0}, b_nhet[4] = {0, 0, 0, 0};   // byte lanes
   // wide counters: [dword d][pair p] holds genomes 4d+p (low 16 bits) and 4d+p+2 (high 16 bits)
-  uint32_t n_mhet[4][2], n_mhom[4][2], n_nhet[4][2], n_miss[4][2];
+  uint32_t n_mhet[4][2], n_mhom[4][2], n_nhet[4][2];
 #pragma unroll
   for (int d = 0; d < 4; ++d)
 #pragma unroll
-    for (int p = 0; p < 2; ++p) n_mhet[d][p] = n_mhom[d][p] = n_nhet[d][p] = n_miss[d][p] = 0;
+    for (int p = 0; p < 2; ++p) n_mhet[d][p] = n_mhom[d][p] = n_nhet[d][p] = 0;
+  // Carriers at default loci (what the major-homozygote count is the complement of) are not counted cell by cell: they
+  // are the classified cells of ALL loci, plus the unclassified carriers of default loci, minus the classified cells
+  // of the other loci -- and those two corrections are exactly the cells the rare path below visits with sign -1 / +1.
+  // It keeps their balance in slot 4 of the lane's own partial (zero on entry, read back and zeroed at the end).
   uint32_t since_flush = 0;
 
   auto flush = [&]() {
@@ -1300,8 +1304,7 @@ k_inbreed_sweep_swar16(const kgx_v4u* __restrict__ gt, uint64_t chunks_per_row, 
       n_mhet[d][0] += b_mhet[d] & 0x00FF00FFu;  n_mhet[d][1] += (b_mhet[d] >> 8) & 0x00FF00FFu;
       n_mhom[d][0] += b_mhom[d] & 0x00FF00FFu;  n_mhom[d][1] += (b_mhom[d] >> 8) & 0x00FF00FFu;
       n_nhet[d][0] += b_nhet[d] & 0x00FF00FFu;  n_nhet[d][1] += (b_nhet[d] >> 8) & 0x00FF00FFu;
-      n_miss[d][0] += b_miss[d] & 0x00FF00FFu;  n_miss[d][1] += (b_miss[d] >> 8) & 0x00FF00FFu;
-      b_mhet[d] = b_mhom[d] = b_nhet[d] = b_miss[d] = 0;
+      b_mhet[d] = b_mhom[d] = b_nhet[d] = 0;
     }
     since_flush = 0;
   };
@@ -1346,12 +1349,7 @@ k_inbreed_sweep_swar16(const kgx_v4u* __restrict__ gt, uint64_t chunks_per_row, 
         classed[d] = c.major_het | c.minor_hom | c.minor_het;                     // a subset of nonzero
         // cells the defaults do not cover: at a default locus the carriers the byte algebra left unclassified, at any
         // other locus every carrier
-        if (is_default) {
-          b_miss[d] += c.nonzero;
-          rare[d] = c.nonzero ^ classed[d];
-        } else {
-          rare[d] = c.nonzero;
-        }
+        rare[d] = is_default ? (c.nonzero ^ classed[d]) : c.nonzero;
         rare_any |= rare[d];
       }
       if (rare_any) {
@@ -1376,6 +1374,7 @@ k_inbreed_sweep_swar16(const kgx_v4u* __restrict__ gt, uint64_t chunks_per_row, 
             if (g >= n_genomes) continue;
             double* p = part + (seg * n_genomes + g) * kParts0;     // single writer: this lane
             p[0] += sign * row[amax + 1]; p[1] += sign * row[amax + 2]; p[2] += sign * row[amax + 3]; p[3] += sign * row[amax + 4];
+            p[4] -= sign;                                           // carriers at default loci beyond / short of the classified cells
           }
         }
       }
@@ -1392,8 +1391,11 @@ k_inbreed_sweep_swar16(const kgx_v4u* __restrict__ gt, uint64_t chunks_per_row, 
       if (g >= n_genomes) continue;
       const int pair = j & 1, shift = (j & 2) ? 16 : 0;
       const unsigned long long mhet = (n_mhet[d][pair] >> shift) & 0xFFFFu, mhom = (n_mhom[d][pair] >> shift) & 0xFFFFu;
-      const unsigned long long nhet = (n_nhet[d][pair] >> shift) & 0xFFFFu, miss = (n_miss[d][pair] >> shift) & 0xFFFFu;
-      const unsigned long long major_hom = n_def - miss;
+      const unsigned long long nhet = (n_nhet[d][pair] >> shift) & 0xFFFFu;
+      double* balance = part + (seg * n_genomes + g) * kParts0 + 4;
+      const long long miss = static_cast<long long>(mhet + mhom + nhet) + static_cast<long long>(*balance);   // small integers: exact
+      *balance = 0.0;                                              // the slot is RitlandLocus' afterwards (k_inbreed_eval_lut<3>)
+      const unsigned long long major_hom = n_def - static_cast<unsigned long long>(miss);
       const unsigned long long total = major_hom + mhet + mhom + nhet;
       unsigned long long* c = counts + g * 6;
       if (major_hom) atomicAdd(c + 0, major_hom);
