@@ -11,7 +11,10 @@ A step = one pass of the hot path over this rank's genome shard.  Workload (conf
   c2            1,000 genomes x 1M SNPs per GPU                      (configs[1]; fits the 256 MiB L3)
   c5            10,000 genomes x 5,000,000 multi-allelic loci per GPU: the inbreeding sweep (K5 + the estimator named by
                 --algorithm; configs[4]); genomes are independent, so N ranks are N shards with no exchange at all
-One JSON line is printed by rank 0.  PyTorch is plumbing only (device tensors, RCCL all-reduce).
+One JSON line is printed by rank 0.  At N = 1 the default (c3) run also carries, under "aux", the two other sweeps of
+the path on the same box in the same run -- the 11-bin by-genome sweep (K3) on the C3 population and the inbreeding
+sweep + Simple (K5) on the C5 population -- each with its own roofline and its own CPU baseline (--no-aux skips them).
+PyTorch is plumbing only (device tensors, RCCL all-reduce).
 """
 from __future__ import annotations
 
@@ -47,16 +50,44 @@ def parse_args():
     ap.add_argument("--variants", type=int, default=0, help="override variant rows")
     ap.add_argument("--seed", type=int, default=1111)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-aux", action="store_true", help="skip the K3 / C5 side measurements of the default run")
     ap.add_argument("--cpu-sample-variants", type=int, default=300_000)      # x 10k genomes = 3e9 cells: ~12 s of the port
+    ap.add_argument("--aux-genomes", type=int, default=10_000, help="genomes of the aux C5 population")
+    ap.add_argument("--aux-loci", type=int, default=5_000_000, help="loci of the aux C5 population")
     ap.add_argument("--algorithm", choices=["Simple", "RitlandLocus", "HallME", "Loglikelihood"], default="Simple",
                     help="estimator of the c5 workload")
     return ap.parse_args()
 
 
-def cpu_baseline(capi, pop, G, V, k2_host_sample_rows, sample_variants):
+def workload_label(args, wl, genomes, variants) -> str:
+    """The preset's label only when the preset's shape was run; an overridden shape names itself."""
+    preset_g = wl.get("genomes_per_gpu")
+    if (not args.genomes or args.genomes == preset_g) and (not args.variants or args.variants == wl["variants"]):
+        return wl["label"]
+    what = "multi-allelic loci, inbreeding sweep" if args.workload == "c5" else "biallelic SNPs"
+    return f"custom ({args.workload} shape overridden): {genomes} genomes x {variants} {what} per GPU"
+
+
+def k2_traffic(G, V):
+    """HBM bytes per K2 launch from the committed rocprofv3 --pmc passes (profiles/): a constant of an earlier profiling
+    run of this exact shape, not something a bench run can measure -- hence traffic_source beside it."""
+    tf = ROOT / "profiles" / "k2_traffic.json"
+    if tf.exists():
+        try:
+            rec = json.loads(tf.read_text()).get(f"{G}x{V}")
+            if rec:
+                return rec["hbm_bytes_per_launch"], (f"profiles/k2_traffic.json: 2 x FETCH_SIZE + WRITE_SIZE of separate rocprofv3 --pmc "
+                                                     f"passes over this shape ({rec.get('profile', 'earlier profiling run')}); not measured in this run")
+        except Exception:
+            pass
+    return None, "no rocprofv3 --pmc pass committed for this shape"
+
+
+def cpu_baseline(capi, pop, G, V, k2_host_sample_rows, sample_variants, seed):
     """The oracle's dense tier (the reference's summaryByVariant column walk over VariantDBGenomeData,
     single-threaded as in CalcFWS::updateVariantFWSMap) timed on this box's host cores, on the first
-    `sample_variants` rows x all genomes of the same population.  Also a parity check of that block."""
+    `sample_variants` rows x all genomes of the same population.  Also a parity check of that block.
+    Returns (record, dense oracle object, sample width) -- the by-genome aux leg reuses the matrix."""
     from tests import oracle_api as oa
 
     nv = min(sample_variants, V)
@@ -78,7 +109,7 @@ def cpu_baseline(capi, pop, G, V, k2_host_sample_rows, sample_variants):
             fast_counts, fast_seconds, fast_threads = counts_t, seconds_t, used_t
     fast_ok = bool(np.array_equal(fast_counts[:nv], k2_host_sample_rows))
     del fast_rows
-    return {
+    record = {
         "value": G * nv / seconds,
         "unit": "variants·genomes/s",
         "cores": 1,
@@ -87,12 +118,171 @@ def cpu_baseline(capi, pop, G, V, k2_host_sample_rows, sample_variants):
                   f"oracle dense tier = reference summaryByVariant loop (single-threaded in the reference); "
                   f"host has {os.cpu_count()} cpus; block parity vs GPU: {'bit-exact' if ok else 'MISMATCH'}",
         "parity_ok": ok,
+        "multithreaded_path": multithreaded_reference_path(capi, seed),
         "optimised_cpu": {
             "value": G * n_fast / fast_seconds, "unit": "variants·genomes/s", "cores": fast_threads, "kind": "not the reference's algorithm",
             "sample": f"first {n_fast} variants x all {G} genomes, same 2-bit rows as the GPU, 64-bit popcounts on {fast_threads} threads, "
                       f"best of 3 ({fast_seconds * 1e3:.1f} ms); parity vs GPU: {'bit-exact' if fast_ok else 'MISMATCH'}",
         },
     }
+    return record, dense, nv
+
+
+def multithreaded_reference_path(capi, seed, G=1000, V=20_000):
+    """north_star's "multithreaded CPU path" end to end on a slice the pointer-chasing store can hold: the sparse
+    PopulationDB of G x V of the same synthetic population -> createVariantDB (processAll_MT, hw - 1 threads, one task per
+    genome, HGVS string keys: kgl_variant_db_variant.cpp:11-123) -> summaryByVariant for every variant (serial, as
+    CalcFWS::updateVariantFWSMap calls it).  The store itself is the parser's output and is not timed."""
+    from tests import oracle_api as oa
+
+    rows, af = capi.synth_biallelic_host(seed, 0, G, 0, V)
+    codes = capi.unpack_dosage2(rows, G)                                   # [V][G]
+    rng = np.random.default_rng(7)
+    offsets = np.cumsum(rng.integers(1, 51, V)).astype(np.uint64)
+    ref_code = rng.integers(0, 4, V).astype(np.uint8)
+    alt_code = ((ref_code + rng.integers(1, 4, V)) % 4).astype(np.uint8)
+    gt = np.zeros((V, G, 2), dtype=np.uint8)
+    het_phase = rng.integers(0, 2, (V, G)).astype(np.uint8)
+    gt[..., 0] = np.where(codes == 2, 1, np.where((codes == 1) & (het_phase == 0), 1, 0))
+    gt[..., 1] = np.where(codes == 2, 1, np.where((codes == 1) & (het_phase == 1), 1, 0))
+    opop = oa.Population("synthetic")
+    opop.add_genomes([f"HG{i:06d}" for i in range(G)])
+    opop.add_records_coded("chr1", offsets, ref_code, np.ones(V, dtype=np.uint8), alt_code, np.repeat(af[:, None], 6, axis=1), gt,
+                           oa.Population.PHASED)
+    vdb = oa.VariantDB(opop)                                               # createVariantDB, timed inside the oracle
+    by_variant = vdb.summary_by_variant()
+    threads = int(oa.lib().kgo_pool_threads(G))
+    # parity of the slice against the GPU sweep of the same genotypes
+    small = capi.Population(G, V)
+    small.load_dosage2(rows)
+    k2 = small.allele_count_by_locus()
+    small.close()
+    rec_idx, _ = vdb.variant_keys()
+    ok = bool(np.array_equal(k2[rec_idx.astype(np.int64), :3].astype(np.uint64), by_variant))
+    seconds = vdb.build_seconds + vdb.by_variant_seconds
+    return {
+        "value": G * V / seconds, "unit": "variants·genomes/s", "cores": threads, "kind": "port",
+        "phases_s": {"createVariantDB": round(vdb.build_seconds, 3), "summaryByVariant": round(vdb.by_variant_seconds, 3)},
+        "sample": f"{G} genomes x {V} variants of the same population through the sparse store ({G * V:.3g} cells): createVariantDB on {threads} "
+                  f"pool threads (hardware_concurrency() - 1 capped by the genome count, the reference's rule) + serial summaryByVariant; "
+                  f"parity vs GPU: {'bit-exact' if ok else 'MISMATCH'}",
+        "parity_ok": ok,
+    }
+
+
+def aux_by_genome(capi, torch, pop, counts, G, V, dense, nv):
+    """K3: CalcFWS's eleven allele-frequency bins x every genome (kga_analysis_PfEMP_FWS.cpp:15-38,72-101) on the population
+    the headline ran on: one kgx_count_by_genome_binned call = the reference's 11 x (viewFilter + createVariantDB +
+    summaryByGenome).  Kernel time from HIP events inside the library; CPU leg: the oracle's summaryByGenome loop over each
+    bin's variants of the dense sample (single-threaded, as the reference's), parity asserted on that block."""
+    from kgl_gene_amd.fws import fws_bin_of_variant
+
+    carried = ((counts[:, 1] + counts[:, 2] + counts[:, 3]) > 0).cpu().numpy()
+    bins = fws_bin_of_variant(pop.get_af(), carried)
+    selected = int((bins != 0xFF).sum())
+    walls, kernels = [], []
+    for i in range(6):
+        t = time.perf_counter()
+        pop.count_by_genome_binned(bins, 11)
+        if i:
+            walls.append((time.perf_counter() - t) * 1e3)
+            kernels.append(capi.count_by_genome_last_ms())
+    wall_ms, kernel_ms = float(np.median(walls)), float(np.median(kernels))
+    algorithmic = selected * ((G + 3) // 4) + 32 * G * 11
+    achieved = algorithmic / (kernel_ms * 1e-3) / 1e9
+    record = {
+        "metric": "variants·genomes/sec (by-genome sweep, 11 FWS allele-frequency bins)",
+        "value": G * selected / (wall_ms * 1e-3), "unit": "variants·genomes/s", "ms_per_call": wall_ms, "calls": len(walls),
+        "config": {"workload": f"K3 on the headline population: {G} genomes x {selected} binned variants of {V}",
+                   "note": "wall per call includes the 10 MB bin-map upload, the device-side grouping and the result download"},
+        "roofline": {"bound": "hbm", "kernel": "k_count_by_genome", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": None, "traffic_source": "see profiles/ (FETCH_SIZE pass of the same kernel)",
+                     "algorithmic_bytes_per_launch": algorithmic, "kernel_ms": kernel_ms},
+        "cpu_baseline": None,
+    }
+    if dense is not None:
+        sample_bins = bins.copy()
+        sample_bins[nv:] = 0xFF
+        got = pop.count_by_genome_binned(sample_bins, 11)
+        seconds, ok = 0.0, True
+        for b in range(11):
+            want = dense.summary_by_genome((sample_bins[:nv] == b).astype(np.uint8))
+            seconds += dense.seconds
+            ok = ok and bool(np.array_equal(got[:, b, :3], want))
+        cells = G * int((sample_bins != 0xFF).sum())
+        record["cpu_baseline"] = {
+            "value": cells / seconds, "unit": "variants·genomes/s", "cores": 1, "kind": "port",
+            "sample": f"the 11 bins of the first {nv} variants x all {G} genomes ({cells:.3g} cells, {seconds:.1f} s): oracle dense tier = "
+                      f"the reference's summaryByGenome row walk per bin (serial in the reference); parity vs GPU: {'bit-exact' if ok else 'MISMATCH'}",
+            "parity_ok": ok}
+    return record
+
+
+def aux_inbreeding(args, capi, torch, dev, cpu):
+    """C5 (BASELINE.json configs[4]) on this GPU: generateFrequencies + processSimple for every genome over every locus
+    (kga_analysis_inbreed_freq.cpp:425-583, _calc.cpp:318-365) = one kgx_inbreed call; the AF table is resident in HBM.
+    CPU leg: the oracle's processResults (one pool task per genome, hw - 1 threads) on a >= 1e8-cell slice of the same
+    population, regenerated by the host twin; parity asserted on that slice in the same run."""
+    from tests import oracle_api as oa
+    from tests import synth_vcf as sv
+
+    G, L = args.aux_genomes, args.aux_loci
+    m = capi.GenotypeMatrix(G, L)
+    table = m.synth_multiallelic(args.seed, 0, 0)
+    n_sel, amax = table.shape
+    sweep_bytes = int(capi.lib().kgx_gt8_sweep_bytes(G, L, amax))
+    table_dev = torch.from_numpy(np.ascontiguousarray(table, dtype=np.float64)).to(dev)
+    walls, sweeps = [], []
+    res = None
+    for i in range(7):
+        t = time.perf_counter()
+        res = m.inbreed_resident(table_dev.data_ptr(), n_sel, amax, "Simple", phased=True)
+        if i >= 2:
+            walls.append((time.perf_counter() - t) * 1e3)
+            sweeps.append(capi.inbreed_last_sweep_ms())
+    wall_ms, sweep_ms = float(np.median(walls)), float(np.median(sweeps))
+    achieved = sweep_bytes / (sweep_ms * 1e-3) / 1e9
+    label = WORKLOADS["c5"]["label"] if (G, L) == (10_000, 5_000_000) else f"custom: {G} genomes x {L} multi-allelic loci, inbreeding sweep"
+    record = {
+        "metric": "genomes·loci/sec (inbreeding sweep + Simple)",
+        "value": G * L / (wall_ms * 1e-3), "unit": "genomes·loci/s", "ms_per_call": wall_ms, "calls": len(walls), "dtype": "u8 classes, f64 sums",
+        "config": {"workload": label, "genomes": G, "loci": L, "algorithm": "Simple", "layout": "gt8 allele-index bytes, locus-major",
+                   "mean_F": float(res["inbred_allele_sum"].mean())},
+        "roofline": {"bound": "hbm", "kernel": "k_inbreed_sweep_swar16 (+ per-locus helper kernels)", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                     "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                     "traffic_source": "see profiles/ (FETCH_SIZE pass of the same kernel)",
+                     "algorithmic_bytes_per_launch": sweep_bytes, "kernel_ms": sweep_ms},
+        "cpu_baseline": None,
+    }
+    if cpu:
+        Gs, Ls = min(G, 200), min(L, 500_000)                              # 1e8 cells
+        d = sv.synth_multiallelic_coded(Gs, 0, Ls, genome_base=0, seed=args.seed)
+        ref = oa.Population("gnomad")
+        ref.add_genomes(["Reference"])
+        ref.add_records_coded("chr1", d["offsets"], d["ref_code"], d["n_alts"], d["alt_code"], d["af_flat"], None, oa.Population.REFERENCE)
+        dip = oa.Population("diploid")
+        dip.add_genomes(sv.genome_ids(Gs))
+        dip.add_records_coded("chr1", d["offsets"], d["ref_code"], d["n_alts"], d["alt_code"], d["af_flat"], d["alleles"], oa.Population.PHASED)
+        counts, freqs, present, seconds = oa.inbreed_window(ref.filter_snp_pass(), dip, np.full(Gs, oa.ALL, dtype=np.int32), "Simple", 0,
+                                                            int(d["offsets"][-1]) + 1, 1, 10**9, 0.0, 1.0)
+        threads = int(oa.lib().kgo_pool_threads(Gs))
+        got = m.inbreed(np.ascontiguousarray(table[:Ls]), "Simple", phased=True, locus_index=np.arange(Ls, dtype=np.uint32), g0=0, g1=Gs)
+        got = got[dip.genome_order()]
+        names = ["major_hetero_count", "minor_hetero_count", "minor_homo_count", "major_homo_count", "total_allele_count"]
+        ok = bool(present.all()) and all(np.array_equal(got[name], counts[:, k]) for k, name in enumerate(names))
+        f_err = float(np.abs(got["inbred_allele_sum"] - freqs[:, 4]).max())
+        ok = ok and f_err <= 1e-10
+        record["cpu_baseline"] = {
+            "value": Gs * Ls / seconds, "unit": "genomes·loci/s", "cores": threads, "kind": "port",
+            "sample": f"genomes 0..{Gs - 1} x loci 0..{Ls - 1} of the same population ({Gs * Ls:.3g} cells, {seconds:.1f} s): oracle "
+                      f"getLocusList x 6 super populations + processResults (generateFrequencies + processSimple, one pool task per genome, "
+                      f"{threads} threads = hardware_concurrency() - 1 capped by the genome count; host has {os.cpu_count()} cpus); the sparse "
+                      f"store itself is the parser's output and is not timed; parity vs GPU on the slice: class counts "
+                      f"{'bit-exact' if ok else 'MISMATCH'}, |dF| max {f_err:.1e}",
+            "parity_ok": ok}
+    m.close()
+    capi.release_scratch()
+    return record
 
 
 def inbreed_workload(args, capi, dist, torch, dev, wl, L, n_gpus, rank):
@@ -128,7 +318,7 @@ def inbreed_workload(args, capi, dist, torch, dev, wl, L, n_gpus, rank):
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    k5_ms = float(np.mean(sweep_ms))
+    k5_ms = float(np.median(sweep_ms))
     achieved = sweep_bytes / (k5_ms * 1e-3) / 1e9
     if rank != 0:
         return None
@@ -139,12 +329,13 @@ def inbreed_workload(args, capi, dist, torch, dev, wl, L, n_gpus, rank):
         "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": elapsed / args.steps * 1e3,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8 classes, f64 sums", "data": "synthetic",
-        "config": {"workload": wl["label"], "genomes_per_gpu": G, "loci": L, "algorithm": args.algorithm,
+        "config": {"workload": workload_label(args, wl, G, L), "genomes_per_gpu": G, "loci": L, "algorithm": args.algorithm,
                    "layout": "gt8 allele-index bytes, locus-major", "exchange": "none (genomes are independent)",
                    "mean_F": float(res["inbred_allele_sum"].mean()), "seed": args.seed},
         "roofline": {"bound": "hbm", "kernel": "k_inbreed_sweep_swar16 (+ locus helpers)", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                     "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None, "algorithmic_bytes_per_launch": sweep_bytes,
-                     "kernel_ms": k5_ms},
+                     "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                     "traffic_source": "see profiles/ (FETCH_SIZE pass of the same kernel)", "algorithmic_bytes_per_launch": sweep_bytes,
+                     "kernel_ms": k5_ms, "kernel_ms_statistic": "median"},
         "cpu_baseline": None,
     }
 
@@ -168,8 +359,6 @@ def main():
 
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a GPU (there is no CPU fallback)")
-    if local_rank == 0:
-        capi.ensure_built()
     # Rehearsal on a 1-GPU box only: KGX_BENCH_REHEARSAL=1 puts every rank on device 0 and exchanges through gloo
     # (RCCL refuses two ranks on one device).  The driver's runs use one GPU per rank and RCCL.
     rehearsal = os.environ.get("KGX_BENCH_REHEARSAL") == "1"
@@ -185,7 +374,12 @@ def main():
             dist.init_process_group(backend="gloo")
         else:
             dist.init_process_group(backend="nccl", device_id=dev)
-    capi.init(device_index)
+    # One rank per node builds the extension if it is missing; the others load it only after that rank is done.
+    if local_rank == 0:
+        capi.ensure_built()
+    if n_gpus > 1:
+        dist.barrier()
+    capi.init(device_index)                                           # this process owns ONE device: one shard per handle
 
     wl = WORKLOADS[args.workload]
     V = args.variants or wl["variants"]
@@ -264,25 +458,19 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    # Dominant kernel (K2) timed alone with HIP events on the launch stream.
+    # Dominant kernel (K2) timed alone with HIP events on the launch stream: the median launch.
     scratch = torch.empty((V, 4), dtype=torch.int32, device=dev)
     ms = pop.allele_count_timed(scratch.data_ptr(), stream, 2, max(args.steps, 10))
-    k2_ms = float(np.mean(ms))
+    del scratch
+    k2_ms = float(np.median(ms))
     sweep_bytes = pop.sweep_bytes                                     # V*ceil(G/4) + 16*V
     achieved = sweep_bytes / (k2_ms * 1e-3) / 1e9
 
     result = None
     if rank == 0:
         value = total_genomes * V * args.steps / elapsed
-        traffic = None
-        tf = ROOT / "profiles" / "k2_traffic.json"
-        if tf.exists():
-            try:
-                rec = json.loads(tf.read_text()).get(f"{G}x{V}")
-                if rec:
-                    traffic = rec["hbm_bytes_per_launch"]
-            except Exception:
-                traffic = None
+        traffic, traffic_source = k2_traffic(G, V)
+        label = wl["label"] if args.workload == "c4" and not args.genomes else workload_label(args, wl, G, V)
         result = {
             "metric": "variants·genomes/sec (allele-freq sweep)",
             "value": value,
@@ -297,7 +485,7 @@ def main():
             "dtype": "u32",
             "data": "synthetic",
             "config": {
-                "workload": wl["label"],
+                "workload": label,
                 "genomes_per_gpu": G,
                 "total_genomes": total_genomes,
                 "variants": V,
@@ -315,16 +503,27 @@ def main():
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
                 "traffic": traffic,
+                "traffic_source": traffic_source,
                 "algorithmic_bytes_per_launch": sweep_bytes,
                 "kernel_ms": k2_ms,
+                "kernel_ms_statistic": f"median of {len(ms)} launches (HIP events on the launch stream); mean {float(np.mean(ms)):.3f}, min {float(np.min(ms)):.3f}",
             },
         }
+        dense, nv = None, 0
         if n_gpus == 1 and not args.no_cpu_baseline:
             nv = min(args.cpu_sample_variants, V)
             k2_rows = counts[:nv].cpu().numpy().view(np.uint32)
-            result["cpu_baseline"] = cpu_baseline(capi, pop, G, V, k2_rows, nv)
+            result["cpu_baseline"], dense, nv = cpu_baseline(capi, pop, G, V, k2_rows, nv, args.seed)
         else:
             result["cpu_baseline"] = None
+        if n_gpus == 1 and args.workload == "c3" and not args.no_aux:
+            aux = {"k3_fws_bins": aux_by_genome(capi, torch, pop, counts.view(torch.int32), G, V, dense, nv)}
+            del dense
+            pop.close()
+            del bufs, counts, af
+            torch.cuda.empty_cache()
+            aux["c5_simple"] = aux_inbreeding(args, capi, torch, dev, not args.no_cpu_baseline)
+            result["aux"] = aux
 
     pop.close()
     if n_gpus > 1:

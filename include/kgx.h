@@ -14,9 +14,15 @@
  *     kgx_last_error() then holds a message (thread-local).  The C++ layer maps failure to
  *     `return false` + log().error, the reference's error convention
  *     (kgl_app/kgl_package_analysis.cpp:72-76).
- *   - an opaque kgx_pop owns device memory for ONE genome shard on ONE device; functions are not
- *     re-entrant per handle (the reference calls its analysis virtuals from a single thread,
- *     kgl_app/kgl_package.cpp:41-75).
+ *   - the library is bound to ONE OR MORE devices by kgx_init().  An opaque handle (kgx_pop, kgx_gt8) owns device
+ *     memory on every bound device: its genomes are split into contiguous shards, one per device, and every entry
+ *     point works on the whole population -- per-variant counts are summed over the shards by ONE exchange step
+ *     (a direct RCCL ncclAllReduce(sum, uint32) over xGMI when the shards sit on different devices), per-genome
+ *     results are concatenated in genome order.  This is the shape of the reference, which is ONE process fanning
+ *     out one task per genome (kgl_variant_db_population.cpp:386-433).  A process that owns a single GPU (one rank
+ *     of a torch.distributed job) binds that one device and exchanges counts itself.
+ *   - functions are not re-entrant per handle (the reference calls its analysis virtuals from a single thread,
+ *     kgl_app/kgl_package.cpp:41-75); different handles may be used from different threads.
  *   - "variant row" v: one distinct HGVS variant (locus × alt); biallelic ⇒ one row per locus.
  *     Row order is the caller's; the reference's lexicographic-HGVS order
  *     (kgl_variant_db_variant.cpp:17-30) is applied host-side by the C++ layer.
@@ -51,27 +57,43 @@ const char* kgx_version(void);
 const char* kgx_last_error(void);
 /* Number of visible HIP devices (0 if none / runtime unavailable). Never fails. */
 int kgx_device_count(void);
-/* Bind this process to `device` and create the library stream.  Must precede all other calls. */
-int kgx_init(int device);
-/* Device properties a caller needs for roofline reporting. */
-int kgx_device_info(char* name, size_t name_len, char* arch, size_t arch_len,
+/* Bind the library to device_count devices: device_ids[i] = HIP ordinal of slot i (NULL = ordinals 0..device_count-1;
+ * device_count 0 = every visible device).  Must precede all other calls; every handle created afterwards is sharded
+ * over these devices.  With more than one slot a RCCL communicator over the slots is created
+ * (ncclCommInitAll) for the count exchange.  Calling it again rebinds the library; handles created before keep their
+ * devices until they are destroyed.  An ordinal may be listed more than once (two shards on one device: a way to
+ * exercise the sharded paths on a one-GPU box); RCCL cannot span such a binding, so the counts are then summed by
+ * device-to-device copies + an add kernel ("peer" exchange). */
+int kgx_init(int device_count, const int* device_ids);
+/* Slots bound by the last successful kgx_init (0 before). */
+int kgx_bound_devices(void);
+/* How per-variant counts of different shards are summed: "none" (one slot), "rccl" or "peer". */
+const char* kgx_exchange_kind(void);
+/* Device properties of one slot a caller needs for roofline reporting. */
+int kgx_device_info(int slot, char* name, size_t name_len, char* arch, size_t arch_len,
                     int* compute_units, uint64_t* hbm_bytes);
-/* The library's own (non-blocking) hipStream_t, used by every host-returning entry point. */
-void* kgx_stream(void);
+/* The library's own (non-blocking) hipStream_t of a slot, used by every host-returning entry point. */
+void* kgx_stream(int slot);
+/* Wait for all work of the library on every bound device. */
 int kgx_synchronize(void);
 
 /* ---- population shard: replaces PopulationDB→VariantDBVariant (kgl_variant_db_variant.h:53-76)
  *      D[g][v] uint8 rows become variant-major 2-bit rows in HBM.                                */
 
-/* n_genomes in THIS shard, n_variants rows.  Rows are zero (all reference-homozygous) after create. */
+/* n_genomes genomes (split over the bound devices in contiguous shards of whole 64-genome chunks), n_variants rows.
+ * Rows are zero (all reference-homozygous) after create. */
 kgx_pop* kgx_population_create(uint64_t n_genomes, uint64_t n_variants);
+/* Shard geometry: how many shards, and for shard i its device slot, first genome and genome count. */
+uint32_t kgx_population_shards(const kgx_pop* pop);
+int kgx_population_shard_info(const kgx_pop* pop, uint32_t shard, int* slot, uint64_t* genome_base, uint64_t* n_genomes);
 void     kgx_population_destroy(kgx_pop* pop);
 uint64_t kgx_population_genomes(const kgx_pop* pop);
 uint64_t kgx_population_variants(const kgx_pop* pop);
-/* Device row pitch in bytes: ceil(n_genomes/4) rounded up to 16, or to 128 when a row exceeds 512 B
- * (line-aligned rows: every 1 KiB wave load then covers whole 128-B lines). */
+/* Device row pitch in bytes of the first shard: ceil(shard genomes/4) rounded up to 16, or to 128 when a row exceeds
+ * 512 B (line-aligned rows: every 1 KiB wave load then covers whole 128-B lines). */
 uint64_t kgx_population_row_pitch(const kgx_pop* pop);
-/* Algorithmic HBM bytes of one allele-count sweep: n_variants*ceil(n_genomes/4) + 16*n_variants. */
+/* Algorithmic HBM bytes of one allele-count sweep, summed over the shards: n_variants*ceil(shard genomes/4) +
+ * 16*n_variants each (one shard: n_variants*ceil(n_genomes/4) + 16*n_variants). */
 uint64_t kgx_population_sweep_bytes(const kgx_pop* pop);
 
 /* Host → device, packed 2-bit rows [v0,v1): src row r at src + r*src_pitch, ceil(G/4) bytes used,
@@ -107,16 +129,19 @@ int kgx_synth_biallelic_host(uint64_t seed, uint64_t genome_base, uint64_t n_gen
  *      (kgl_variant_db_variant.cpp:126-178, caller kga_analysis_PfEMP_FWS.cpp:41-70).
  *      out[v] = { referenceHomozygous, minorHeterozygous, minorHomozygous, nonDiploid } (uint32 each). */
 int kgx_allele_count_by_locus(kgx_pop* pop, uint32_t* out /* host [n_variants][4] */);
-/* Same, result left in device memory (caller's buffer, e.g. a torch tensor to all-reduce);
- * launched asynchronously on `stream`, taken literally as a hipStream_t (NULL = the legacy default
- * stream, which is what torch.cuda.current_stream().cuda_stream is unless a side stream is current). */
+/* Same, result left in device memory on the FIRST slot's device (caller's buffer, e.g. a torch tensor the caller
+ * all-reduces across processes); asynchronous on `stream`, taken literally as a hipStream_t of that device (NULL = the
+ * legacy default stream, which is what torch.cuda.current_stream().cuda_stream is unless a side stream is current).
+ * With several shards the other devices sweep on the library's streams, the exchange follows, and `stream` is made to
+ * wait for the summed counts. */
 int kgx_allele_count_by_locus_dev(kgx_pop* pop, void* d_out /* device [n_variants][4] u32 */,
                                   void* stream);
 /* Epilogue on (all-reduced) device counts: af[v] = (het + 2*hom) / (2*total_genomes) in fp64. */
 int kgx_allele_frequency_dev(const void* d_counts /* device [n][4] u32 */, uint64_t n_variants,
                              uint64_t total_genomes, void* d_af /* device [n] f64 */, void* stream);
 /* Timed repetition of the K2 launch with HIP events on the launch stream: per-iteration kernel
- * durations (ms) into ms_each[iters].  d_out as above. */
+ * durations (ms) into ms_each[iters] (several shards: the slowest shard's kernel of each iteration; no exchange).
+ * d_out as above. */
 int kgx_allele_count_timed(kgx_pop* pop, void* d_out, void* stream, int warmup, int iters,
                            float* ms_each);
 
@@ -130,6 +155,11 @@ int kgx_count_by_genome(kgx_pop* pop, const uint8_t* variant_mask /* host [n_var
  * out[g][b] = 4 x uint64 as above. */
 int kgx_count_by_genome_binned(kgx_pop* pop, const uint8_t* bin_of_variant /* host [n_variants] */,
                                uint32_t n_bins, uint64_t* out /* host [n_genomes][n_bins][4] */);
+
+/* Device time (HIP events on the library streams) of the k_count_by_genome kernel of the most recent by-genome sweep
+ * (the slowest shard's); 0 before the first or when no row was selected.  Algorithmic bytes of that launch:
+ * selected rows x ceil(G/4) + 32 x G x n_bins. */
+double kgx_count_by_genome_last_ms(void);
 
 /* ---- K8: compound offsets of HeteroHomoZygous::updateVariantAnalysisType
  *      (kga_analytic/kga_PfEMP/kga_analysis_PfEMP_heterozygous.cpp:61-105).  A group is a contig offset at
@@ -157,7 +187,10 @@ int kgx_population_summary(kgx_pop* pop, uint64_t out[4]);
  * (0, a): analogous but not homozygous() (kgl_variant_db.h:135-143), which the reference classifies as a minor
  * heterozygote with that allele twice.  Bytes outside this description are skipped, never read through. */
 typedef struct kgx_gt8 kgx_gt8;
+/* Genomes are split over the bound devices in contiguous shards of whole 128-genome units (kgx_init). */
 kgx_gt8* kgx_gt8_create(uint64_t n_genomes, uint64_t n_loci);
+uint32_t kgx_gt8_shards(const kgx_gt8* gt);
+int kgx_gt8_shard_info(const kgx_gt8* gt, uint32_t shard, int* slot, uint64_t* genome_base, uint64_t* n_genomes);
 void     kgx_gt8_destroy(kgx_gt8* gt);
 uint64_t kgx_gt8_genomes(const kgx_gt8* gt);
 uint64_t kgx_gt8_loci(const kgx_gt8* gt);
@@ -197,12 +230,13 @@ int kgx_locus_class_frequencies(const double* minor_af, uint64_t n_loci, uint32_
  * minor_af[n_selected][amax]: super-population allele frequency of each reference alt (double(float32)), NaN = the
  * alt is not in the locus's AlleleFreqVector; phased != 0 when the two copies of a homozygous alt carry different
  * phases (1000-Genomes style); algorithm = KGX_ALGO_*.  out[g1-g0] (host).  locus_index and minor_af may be host
- * pointers or pointers to memory of this device (a table kept resident between calls is then copied device to device). */
+ * pointers or pointers to memory of a bound device (a table kept resident between calls is then copied device to
+ * device).  Genomes are independent: every shard the range touches is swept on its own device at the same time, no exchange. */
 int kgx_inbreed(kgx_gt8* gt, uint64_t g0, uint64_t g1, const uint32_t* locus_index, uint64_t n_selected,
                 const double* minor_af, uint32_t amax, int phased, int algorithm, kgx_locus_results* out);
-/* Device time (HIP events on the library stream) of the frequency sweep -- locus helpers + the K5 kernel, i.e. the one
- * pass over the genotype bytes that every estimator makes -- of the most recent successful kgx_inbreed call on this
- * process; 0 before the first.  For bench.py / profiles: algorithmic bytes = kgx_gt8_sweep_bytes(). */
+/* Device time (HIP events on the library streams) of the frequency sweep -- locus helpers + the K5 kernel, i.e. the one
+ * pass over the genotype bytes that every estimator makes -- of the most recent successful kgx_inbreed call (the
+ * slowest shard's); 0 before the first.  For bench.py / profiles: algorithmic bytes = kgx_gt8_sweep_bytes(). */
 /* kgx_inbreed keeps its per-call device buffers in one grow-only arena between calls (a window loop calls it
  * thousands of times), and a large Loglikelihood call two more buffers holding the genotype columns of the genomes
  * still searching (at most ~3/4 of the swept bytes together); this frees them (they are re-created when needed). */
@@ -221,6 +255,8 @@ int kgx_gt8_synth_multiallelic(kgx_gt8* gt, uint64_t seed, uint64_t genome_base,
 int kgx_synth_multiallelic_host(uint64_t seed, uint64_t genome_base, uint64_t n_genomes, uint64_t l0, uint64_t l1,
                                 uint8_t* gt8, uint64_t pitch, double* af_table, uint8_t* alleles);
 int kgx_synth_locus_host(uint64_t seed, uint64_t l, int* n_alt, float af[3], int is_indel[3]);
+/* The same for loci [l0,l1) at once: n_alt[l1-l0], af[l1-l0][3], is_indel[l1-l0][3] (uint8). */
+int kgx_synth_loci_host(uint64_t seed, uint64_t l0, uint64_t l1, uint8_t* n_alt, float* af, uint8_t* is_indel);
 
 /* The reference's synthetic-inbreeding self-check population (InbreedSynthetic::generateSyntheticPopulation,
  * kga_analysis_inbreed_syngen.cpp:20-196) written into the matrix: locus l has the minor allele frequencies

@@ -26,18 +26,36 @@ HIP_FLAGS = [
     "-std=c++17",
     "-ffp-contract=off",  # host and device fp64 must agree bit for bit (synthetic generator, K6)
     "-fPIC",
-    "-shared",
     "-Wall",
     "-Wno-unused-function",
 ]
+OBJDIR = LIBDIR / "obj"
 
 
 def _sources() -> list[Path]:
     return sorted(CSRC.glob("*.hip"))
 
 
-def _deps() -> list[Path]:
-    return sorted(list(CSRC.glob("*.hip")) + list(CSRC.glob("*.h")) + [ROOT / "include" / "kgx.h"])
+def _headers() -> list[Path]:
+    return sorted(CSRC.glob("*.h")) + [ROOT / "include" / "kgx.h"]
+
+
+def _includes(src: Path) -> list[Path]:
+    """The in-tree headers one translation unit pulls in (transitively), so that editing the inbreeding kernels does
+    not recompile the dosage side."""
+    seen, todo = {}, [src]
+    while todo:
+        f = todo.pop()
+        for line in f.read_text().splitlines():
+            line = line.strip()
+            if not line.startswith('#include "'):
+                continue
+            name = line.split('"')[1]
+            h = (f.parent / name).resolve()
+            if h.exists() and h not in seen:
+                seen[h] = True
+                todo.append(h)
+    return list(seen)
 
 
 def _stale(target: Path, deps: list[Path]) -> bool:
@@ -48,15 +66,27 @@ def _stale(target: Path, deps: list[Path]) -> bool:
 
 
 def build_kgx(force: bool = False, verbose: bool = False) -> Path:
-    """Compile every HIP translation unit into kgl_gene_amd/lib/libkgx.so."""
+    """Compile every HIP translation unit (in parallel, one hipcc per unit) and link kgl_gene_amd/lib/libkgx.so."""
     LIBDIR.mkdir(parents=True, exist_ok=True)
-    if not force and not _stale(LIBKGX, _deps()):
-        return LIBKGX
+    OBJDIR.mkdir(parents=True, exist_ok=True)
     extra = os.environ.get("KGX_HIPCC_FLAGS", "").split()   # experiments only (e.g. -DKGX_EXP_...); the default build has none
-    cmd = [HIPCC, *HIP_FLAGS, *extra, "-I", str(ROOT / "include"), "-o", str(LIBKGX), *map(str, _sources())]
-    if verbose:
-        print(" ".join(cmd), file=sys.stderr)
-    subprocess.run(cmd, check=True, cwd=str(ROOT))
+    jobs, objects = [], []
+    for src in _sources():
+        obj = OBJDIR / (src.stem + ".o")
+        objects.append(obj)
+        if force or extra or _stale(obj, [src] + _includes(src)):
+            cmd = [HIPCC, *HIP_FLAGS, *extra, "-I", str(ROOT / "include"), "-c", "-o", str(obj), str(src)]
+            if verbose:
+                print(" ".join(cmd), file=sys.stderr)
+            jobs.append((cmd, subprocess.Popen(cmd, cwd=str(ROOT))))
+    failed = [cmd for cmd, proc in jobs if proc.wait() != 0]
+    if failed:
+        raise subprocess.CalledProcessError(1, failed[0])
+    if jobs or not LIBKGX.exists() or _stale(LIBKGX, objects):
+        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", str(LIBKGX), *map(str, objects), "-ldl", "-pthread"]
+        if verbose:
+            print(" ".join(cmd), file=sys.stderr)
+        subprocess.run(cmd, check=True, cwd=str(ROOT))
     return LIBKGX
 
 

@@ -36,12 +36,16 @@ _SIGNATURES = {
     "kgx_version": (C.c_char_p, []),
     "kgx_last_error": (C.c_char_p, []),
     "kgx_device_count": (C.c_int, []),
-    "kgx_init": (C.c_int, [C.c_int]),
-    "kgx_device_info": (C.c_int, [C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t, C.POINTER(C.c_int), _u64p]),
-    "kgx_stream": (C.c_void_p, []),
+    "kgx_init": (C.c_int, [C.c_int, C.POINTER(C.c_int)]),
+    "kgx_bound_devices": (C.c_int, []),
+    "kgx_exchange_kind": (C.c_char_p, []),
+    "kgx_device_info": (C.c_int, [C.c_int, C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t, C.POINTER(C.c_int), _u64p]),
+    "kgx_stream": (C.c_void_p, [C.c_int]),
     "kgx_synchronize": (C.c_int, []),
     "kgx_population_create": (C.c_void_p, [C.c_uint64, C.c_uint64]),
     "kgx_population_destroy": (None, [C.c_void_p]),
+    "kgx_population_shards": (C.c_uint32, [C.c_void_p]),
+    "kgx_population_shard_info": (C.c_int, [C.c_void_p, C.c_uint32, C.POINTER(C.c_int), _u64p, _u64p]),
     "kgx_population_genomes": (C.c_uint64, [C.c_void_p]),
     "kgx_population_variants": (C.c_uint64, [C.c_void_p]),
     "kgx_population_row_pitch": (C.c_uint64, [C.c_void_p]),
@@ -60,9 +64,12 @@ _SIGNATURES = {
     "kgx_allele_count_timed": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "kgx_count_by_genome": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "kgx_count_by_genome_binned": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]),
+    "kgx_count_by_genome_last_ms": (C.c_double, []),
     "kgx_population_summary": (C.c_int, [C.c_void_p, C.c_void_p]),
     "kgx_gt8_create": (C.c_void_p, [C.c_uint64, C.c_uint64]),
     "kgx_gt8_destroy": (None, [C.c_void_p]),
+    "kgx_gt8_shards": (C.c_uint32, [C.c_void_p]),
+    "kgx_gt8_shard_info": (C.c_int, [C.c_void_p, C.c_uint32, C.POINTER(C.c_int), _u64p, _u64p]),
     "kgx_gt8_genomes": (C.c_uint64, [C.c_void_p]),
     "kgx_gt8_loci": (C.c_uint64, [C.c_void_p]),
     "kgx_gt8_sweep_bytes": (C.c_uint64, [C.c_uint64, C.c_uint64, C.c_uint32]),
@@ -79,6 +86,7 @@ _SIGNATURES = {
     "kgx_synth_multiallelic_host": (C.c_int, [C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64, C.c_void_p, C.c_uint64,
                                               C.c_void_p, C.c_void_p]),
     "kgx_synth_locus_host": (C.c_int, [C.c_uint64, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "kgx_synth_loci_host": (C.c_int, [C.c_uint64, C.c_uint64, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p]),
     "kgx_gt8_synth_inbred": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint64]),
     "kgx_compound_offsets": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_void_p]),
 }
@@ -133,27 +141,52 @@ def device_count() -> int:
     return int(lib().kgx_device_count())
 
 
-def init(device: int = 0) -> None:
-    check(lib().kgx_init(int(device)))
+def init(devices=0) -> None:
+    """Bind the library: `devices` = one HIP ordinal, or a list of ordinals (one genome shard per entry; [] = every
+    visible device)."""
+    ids = [int(devices)] if isinstance(devices, (int, np.integer)) else [int(d) for d in devices]
+    if not ids:
+        check(lib().kgx_init(0, None))
+        return
+    arr = (C.c_int * len(ids))(*ids)
+    check(lib().kgx_init(len(ids), arr))
 
 
-def device_info() -> dict:
+def bound_devices() -> int:
+    return int(lib().kgx_bound_devices())
+
+
+def exchange_kind() -> str:
+    """How the shards' per-variant counts are summed: "none", "rccl" or "peer"."""
+    return lib().kgx_exchange_kind().decode()
+
+
+def device_info(slot: int = 0) -> dict:
     name = C.create_string_buffer(128)
     arch = C.create_string_buffer(64)
     cus = C.c_int(0)
     hbm = C.c_uint64(0)
-    check(lib().kgx_device_info(name, 128, arch, 64, C.byref(cus), C.byref(hbm)))
+    check(lib().kgx_device_info(int(slot), name, 128, arch, 64, C.byref(cus), C.byref(hbm)))
     return {"name": name.value.decode(), "arch": arch.value.decode(), "compute_units": cus.value,
             "hbm_bytes": hbm.value}
 
 
-def stream() -> int:
-    """The library's own hipStream_t (as an integer handle)."""
-    return int(lib().kgx_stream() or 0)
+def stream(slot: int = 0) -> int:
+    """The library's own hipStream_t of a device slot (as an integer handle)."""
+    return int(lib().kgx_stream(int(slot)) or 0)
 
 
 def synchronize() -> None:
     check(lib().kgx_synchronize())
+
+
+def _shards(count_fn, info_fn, handle):
+    out = []
+    for i in range(int(count_fn(handle))):
+        slot, base, n = C.c_int(0), C.c_uint64(0), C.c_uint64(0)
+        check(info_fn(handle, i, C.byref(slot), C.byref(base), C.byref(n)))
+        out.append({"slot": slot.value, "genome_base": base.value, "n_genomes": n.value})
+    return out
 
 
 def synth_biallelic_host(seed: int, genome_base: int, n_genomes: int, v0: int, v1: int):
@@ -216,6 +249,11 @@ class Population:
     @property
     def handle(self):
         return self._h
+
+    @property
+    def shards(self) -> list[dict]:
+        """One dict per device slot: slot, genome_base, n_genomes."""
+        return _shards(lib().kgx_population_shards, lib().kgx_population_shard_info, self._h)
 
     @property
     def row_pitch(self) -> int:
@@ -307,6 +345,11 @@ class Population:
         return out
 
 
+def count_by_genome_last_ms() -> float:
+    """Device time of the K3 kernel of the most recent by-genome sweep (HIP events)."""
+    return float(lib().kgx_count_by_genome_last_ms())
+
+
 def allele_frequency_dev(d_counts: int, n_variants: int, total_genomes: int, d_af: int, stream: int = 0) -> None:
     check(lib().kgx_allele_frequency_dev(C.c_void_p(d_counts), n_variants, total_genomes, C.c_void_p(d_af),
                                          C.c_void_p(stream)))
@@ -352,6 +395,10 @@ class GenotypeMatrix:
             self.close()
         except Exception:
             pass
+
+    @property
+    def shards(self) -> list[dict]:
+        return _shards(lib().kgx_gt8_shards, lib().kgx_gt8_shard_info, self._h)
 
     def load_rows(self, rows: np.ndarray, l0: int = 0) -> None:
         r = np.ascontiguousarray(rows, dtype=np.uint8)
@@ -413,6 +460,16 @@ def inbreed_last_sweep_ms() -> float:
 def inbreed_last_evaluations() -> int:
     """Objective evaluations the most recent Loglikelihood call needed."""
     return int(lib().kgx_inbreed_last_evaluations())
+
+
+def synth_loci_host(seed: int, l0: int, l1: int):
+    """The synthetic multi-allelic loci [l0,l1): (n_alt uint8 [n], af float32 [n][3], is_indel uint8 [n][3])."""
+    n = l1 - l0
+    n_alt = np.zeros(n, dtype=np.uint8)
+    af = np.zeros((n, 3), dtype=np.float32)
+    indel = np.zeros((n, 3), dtype=np.uint8)
+    check(lib().kgx_synth_loci_host(seed, l0, l1, ptr(n_alt), ptr(af), ptr(indel)))
+    return n_alt, af, indel
 
 
 def synth_multiallelic_host(seed: int, genome_base: int, n_genomes: int, l0: int, l1: int):

@@ -4,6 +4,7 @@
 #include <iterator>
 
 #include "../../../include/kgx.h"
+#include "kgx_device_binding.h"
 #include "kgx_vcf_io.h"
 
 namespace kga = kellerberrin::genome::analysis;
@@ -31,7 +32,6 @@ bool kga::GpuAlleleAnalysis::initializeAnalysis(const std::string& work_director
   work_directory_ = work_directory;
   for (const auto& [block_name, named_vector] : named_parameters.getMap()) {
     for (const auto& parameter_map : named_vector.second) {
-      if (auto v = parameter_map.getSize("Device")) device_ = static_cast<int>(v.value().front());
       if (auto v = parameter_map.getString("VariantFile")) variant_file_ = v.value().front();
       if (auto v = parameter_map.getString("GenomeFile")) genome_file_ = v.value().front();
       if (auto v = parameter_map.getString("HetHomFile")) hethom_file_ = v.value().front();
@@ -41,11 +41,13 @@ bool kga::GpuAlleleAnalysis::initializeAnalysis(const std::string& work_director
       if (auto v = parameter_map.getBool("Pf7QualityFilter")) pf7_quality_filter_ = v.value();
     }
   }
-  if (kgx_init(device_) != KGX_OK) {
+  std::string binding, binding_error;
+  if (!gpu::bindDevices(named_parameters, binding, binding_error)) {
     // No CPU fallback: the analysis is disabled, other packages continue (kgl_package_analysis.cpp:41-42).
-    ExecEnv::log().error("GpuAlleleAnalysis::initializeAnalysis; cannot bind MI355X device {}: {}", device_, kgx_last_error());
+    ExecEnv::log().error("GpuAlleleAnalysis::initializeAnalysis; cannot bind the MI355X devices: {}", binding_error);
     return false;
   }
+  ExecEnv::log().info("GpuAlleleAnalysis; genomes sharded over {}", binding);
   device_ready_ = true;
   return true;
 }

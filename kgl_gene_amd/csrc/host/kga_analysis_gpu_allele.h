@@ -61,7 +61,8 @@ class GpuAlleleAnalysis : public VirtualAnalysis {
   [[nodiscard]] std::string ident() const override { return IDENT; }
   [[nodiscard]] static std::unique_ptr<VirtualAnalysis> factory() { return std::make_unique<GpuAlleleAnalysis>(); }
 
-  // Parameters (all optional, first parameter block wins): "Device" (int, default 0),
+  // Parameters (all optional, first parameter block wins): "DeviceList" / "Devices" / "Device" (which MI355X devices the
+  // genomes are sharded over: kgx_device_binding.h; default device 0),
   // "VariantFile" / "GenomeFile" / "HetHomFile" (output file stems, default VariantFWS / GenomeFWS / VariantStatistics).
   [[nodiscard]] bool initializeAnalysis(const std::string& work_directory, const ActiveParameterList& named_parameters,
                                         const std::shared_ptr<const AnalysisResources>& resource_ptr) override;
@@ -91,7 +92,6 @@ class GpuAlleleAnalysis : public VirtualAnalysis {
   std::string vcf_flavour_{"Genome1000"};
   bool pf7_quality_filter_{false};
   std::string variant_file_{"VariantFWS"}, genome_file_{"GenomeFWS"}, hethom_file_{"VariantStatistics"};
-  int device_{0};
   bool device_ready_{false};
   GpuGenomeFWSMap genome_fws_map_;
   GpuVariantFWSMap variant_fws_map_;

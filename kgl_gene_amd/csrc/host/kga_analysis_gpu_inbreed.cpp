@@ -11,6 +11,7 @@
 #include <unordered_map>
 
 #include "../../../include/kgx.h"
+#include "kgx_device_binding.h"
 #include "kgx_vcf_io.h"
 
 namespace kga = kellerberrin::genome::analysis;
@@ -169,7 +170,6 @@ bool kga::GpuInbreedAnalysis::initializeAnalysis(const std::string& work_directo
   for (const auto& [block_name, named_vector] : named_parameters.getMap())
     for (const auto& parameter_map : named_vector.second)
     {
-      if (auto v = parameter_map.getSize("Device")) device_ = static_cast<int>(v.value().front());
       if (auto v = parameter_map.getSize("SyntheticSeed")) synthetic_seed_ = v.value().front();
     }
   for (const auto& parameter : extractParameters(named_parameters)) {
@@ -177,10 +177,12 @@ bool kga::GpuInbreedAnalysis::initializeAnalysis(const std::string& work_directo
     out.parameters = parameter;
     parameter_output_vector_.push_back(std::move(out));
   }
-  if (kgx_init(device_) != KGX_OK) {
-    ExecEnv::log().error("GpuInbreedAnalysis::initializeAnalysis; cannot bind MI355X device {}: {}", device_, kgx_last_error());
+  std::string binding, binding_error;
+  if (!gpu::bindDevices(named_parameters, binding, binding_error)) {
+    ExecEnv::log().error("GpuInbreedAnalysis::initializeAnalysis; cannot bind the MI355X devices: {}", binding_error);
     return false;
   }
+  ExecEnv::log().info("GpuInbreedAnalysis; genomes sharded over {}", binding);
   device_ready_ = true;
   return true;
 }

@@ -130,7 +130,6 @@ class GpuInbreedAnalysis : public VirtualAnalysis {
 
   std::vector<GpuParamOutput> parameter_output_vector_;
   std::string work_directory_;
-  int device_{0};
   bool device_ready_{false};
   std::shared_ptr<const PopulationDB> diploid_population_;
   std::shared_ptr<const PopulationDB> unphased_population_;

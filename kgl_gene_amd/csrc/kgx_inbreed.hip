@@ -1,0 +1,785 @@
+// C ABI (include/kgx.h) of the inbreeding sweep: the allele-index matrix (gt8), K6 (per-locus class frequencies),
+// K5 (generateFrequencies + Simple / RitlandLocus) and K7 (HallME, Loglikelihood), and the synthetic populations.
+// A matrix is one shard of genomes per bound device; genomes are independent, so a call sweeps every shard it touches
+// on its own device at the same time and concatenates the per-genome results: no exchange.  No CPU fallback exists.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "kgx_kernels_inbreed.h"
+#include "kgx_internal.h"
+
+namespace kgx {
+namespace {
+
+int require_runtime(std::shared_ptr<Runtime>& rt) {
+  rt = current_runtime();
+  if (!rt) return fail(KGX_ENODEVICE, "kgx_init() has not succeeded: no gfx950 device bound (there is no CPU fallback)");
+  return KGX_OK;
+}
+
+int sync_shards(const kgx_gt8* h) {
+  for (const auto& sh : h->shards) {
+    if (int rc = use_device(*sh.dev)) return rc;
+    KGX_HIP(hipStreamSynchronize(sh.dev->stream));
+  }
+  return use_device(*h->shards[0].dev);
+}
+
+void destroy_shards(kgx_gt8* h) {
+  for (auto& sh : h->shards)
+    if (sh.d_gt && use_device(*sh.dev) == KGX_OK) (void)hipFree(sh.d_gt);
+  if (!h->shards.empty()) (void)use_device(*h->shards[0].dev);
+}
+
+struct ScratchPlan {
+  size_t total = 0;
+  size_t add(size_t bytes) {
+    const size_t at = total;
+    total += (bytes + 255u) & ~static_cast<size_t>(255u);
+    return at;
+  }
+};
+int scratch_reserve(Device& dev, size_t bytes, char** out) {
+  if (bytes > dev.scratch_bytes) {
+    if (dev.scratch) (void)hipFree(dev.scratch);
+    dev.scratch = nullptr;
+    dev.scratch_bytes = 0;
+    const size_t want = bytes + bytes / 8;            // headroom: windows of a contig differ a little in locus count
+    if (hipMalloc(&dev.scratch, want) != hipSuccess) {
+      (void)hipGetLastError();
+      if (hipMalloc(&dev.scratch, bytes) != hipSuccess) {
+        (void)hipGetLastError();
+        dev.scratch = nullptr;
+        return fail(KGX_ENOMEM, "hipMalloc of %llu scratch bytes failed", static_cast<unsigned long long>(bytes));
+      }
+      dev.scratch_bytes = bytes;
+    } else {
+      dev.scratch_bytes = want;
+    }
+  }
+  *out = dev.scratch;
+  return KGX_OK;
+}
+// kgx_inbreed for the genomes [g0, g1) of ONE shard (shard-local indices, g0 a multiple of 4); arguments checked by the caller.
+int inbreed_shard(kgx_gt8_shard& sh, uint64_t g0, uint64_t g1, const uint32_t* locus_index, uint64_t n_sel, const double* minor_af,
+                  uint32_t amax, int phased, int algorithm, kgx_locus_results* out) {
+  Device& dev = *sh.dev;
+  std::lock_guard<std::mutex> device_lock(dev.mutex);          // the arena, the compaction buffers and the timing events are the device's
+  if (int rc = use_device(dev)) return rc;
+  const uint64_t n = g1 - g0;
+  if (n == 0) return KGX_OK;
+  static_assert(sizeof(kgx_locus_results) == sizeof(LocusResultsDev), "LocusResults layout");
+
+  const uint32_t stride = sweep_stride(amax);
+  // Frequency pass flavour: 16 genomes per lane (SWAR, 16-byte loads) when the group starts on a 16-genome boundary and
+  // the estimator needs no Ritland terms; otherwise 4 genomes per lane.
+  // RitlandLocus with allele indices that fit the tables: the plain frequency sweep, then one table pass for its terms.
+  const bool ritland_lut = algorithm == KGX_ALGO_RITLAND_LOCUS && !env_int("KGX_K5_GENERIC", 0) && !env_int("KGX_K5_NO_EVAL_LUT", 0) &&
+                           amax <= 4;
+  const bool swar16 = !env_int("KGX_K5_GENERIC", 0) && !env_int("KGX_K5_NO_SWAR16", 0) && amax <= 4 && (g0 & 15u) == 0 &&
+                      (algorithm != KGX_ALGO_RITLAND_LOCUS || ritland_lut);
+  // The evaluation passes of HallME / Loglikelihood go through the per-batch LDS tables when the allele indices fit them.
+  const bool eval_lut = !env_int("KGX_K5_GENERIC", 0) && !env_int("KGX_K5_NO_EVAL_LUT", 0) && amax <= 7;
+  int eval_gpl = env_int("KGX_K5_EVAL_GPL", 8);            // genomes per lane: the widest load the group's alignment allows
+  if (eval_gpl != 4 && eval_gpl != 8) eval_gpl = 8;
+  while (eval_gpl > 4 && (g0 % static_cast<uint64_t>(eval_gpl)) != 0) eval_gpl /= 2;
+  const uint32_t gx = static_cast<uint32_t>(((n + 3) / 4 + kBlock - 1) / kBlock);
+  const uint32_t gx16 = static_cast<uint32_t>(((n + 15) / 16 + kBlock - 1) / kBlock);
+  uint64_t n_seg = (static_cast<uint64_t>(dev.compute_units) * env_int("KGX_K5_BLOCKS_PER_CU", 8) + (swar16 ? gx16 : gx) - 1) / (swar16 ? gx16 : gx);
+  if (n_seg > (n_sel + 63) / 64) n_seg = (n_sel + 63) / 64;
+  if (n_seg < (n_sel + 65534) / 65535) n_seg = (n_sel + 65534) / 65535;   // 16-bit class counters per segment
+  if (n_seg < 1) n_seg = 1;
+  if (n_seg > 65535) n_seg = 65535;
+  uint64_t per_seg = n_sel ? (n_sel + n_seg - 1) / n_seg : 8;
+  per_seg = (per_seg + 7) / 8 * 8;                                          // whole 8-locus batches per segment
+  n_seg = n_sel ? (n_sel + per_seg - 1) / per_seg : 1;
+
+  double *d_af = nullptr, *d_table = nullptr, *d_part = nullptr, *d_sums = nullptr, *d_f = nullptr, *d_eval = nullptr, *d_segdef = nullptr;
+  uint8_t* d_valid = nullptr;
+  uint32_t* d_index = nullptr;
+  unsigned long long* d_counts = nullptr;
+  LocusResultsDev* d_out = nullptr;
+  uint32_t* d_meta = nullptr;
+  GoldenState* d_golden = nullptr;
+  BrentState* d_brent = nullptr;
+  unsigned int* d_running = nullptr;
+  int rc = KGX_OK;
+  auto try_hip = [&](hipError_t e, int code, const char* what) {
+    if (rc == KGX_OK && e != hipSuccess) {
+      (void)hipGetLastError();
+      rc = fail(code, "kgx_inbreed: %s failed: %s", what, hipGetErrorString(e));
+    }
+  };
+  // Scratch comes out of one grow-only device arena kept by the library (a window loop calls this hundreds of times;
+  // fourteen hipMalloc/hipFree pairs per call cost more than the sweep).  The call is synchronous, so reuse is safe.
+  const uint64_t n_tab = n_sel ? n_sel : 1;
+  ScratchPlan plan;
+  const size_t o_af = plan.add(n_tab * amax * sizeof(double)), o_table = plan.add(n_tab * stride * sizeof(double));
+  const size_t o_valid = plan.add(n_tab), o_meta = plan.add((n_tab + 8) * sizeof(uint32_t));
+  const size_t o_part = plan.add(n_seg * n * kParts0 * sizeof(double)), o_segdef = plan.add(n_seg * kSegDefaults * sizeof(double));
+  const size_t o_sums = plan.add(n * kParts0 * sizeof(double)), o_counts = plan.add(n * 6 * sizeof(unsigned long long));
+  const size_t o_f = plan.add(n * sizeof(double)), o_eval = plan.add(n * sizeof(double)), o_out = plan.add(n * sizeof(LocusResultsDev));
+  const size_t o_index = plan.add((n_sel + 8) * sizeof(uint32_t)), o_golden = plan.add(n * sizeof(GoldenState));
+  const size_t o_brent = plan.add(n * sizeof(BrentState)), o_running = plan.add(sizeof(unsigned int));
+  // The class-frequency sums of the defaults in the reference's own (sequential) summation order (k_seq_* kernels): from
+  // the size at which a tree reduction and a sequential sum part by more than a tenth of the tolerance.
+  const bool swar_family = !env_int("KGX_K5_GENERIC", 0) && amax <= 4 && (swar16 || algorithm != KGX_ALGO_RITLAND_LOCUS || ritland_lut);
+  const bool sequential_defaults = swar_family && n_sel >= static_cast<uint64_t>(env_int("KGX_K5_SEQUENTIAL_MIN", 1 << 16));
+  const uint64_t n_seq_blocks = (n_sel + kSeqBlock - 1) / kSeqBlock;
+  const size_t o_seq_sum = plan.add(n_seq_blocks * 4 * sizeof(double)), o_seq_e = plan.add(n_seq_blocks * 4 * sizeof(int));
+  const size_t o_seq_n = plan.add(n_seq_blocks * 4 * sizeof(long long)), o_seq_out = plan.add(kParts0 * sizeof(double));
+  char* arena = nullptr;
+  if (int arc = scratch_reserve(dev, plan.total, &arena)) return arc;
+  d_af = reinterpret_cast<double*>(arena + o_af);
+  d_table = reinterpret_cast<double*>(arena + o_table);
+  d_valid = reinterpret_cast<uint8_t*>(arena + o_valid);
+  d_meta = reinterpret_cast<uint32_t*>(arena + o_meta);
+  d_part = reinterpret_cast<double*>(arena + o_part);
+  d_segdef = reinterpret_cast<double*>(arena + o_segdef);
+  d_sums = reinterpret_cast<double*>(arena + o_sums);
+  d_counts = reinterpret_cast<unsigned long long*>(arena + o_counts);
+  d_f = reinterpret_cast<double*>(arena + o_f);
+  d_eval = reinterpret_cast<double*>(arena + o_eval);
+  d_out = reinterpret_cast<LocusResultsDev*>(arena + o_out);
+  d_golden = reinterpret_cast<GoldenState*>(arena + o_golden);
+  d_brent = reinterpret_cast<BrentState*>(arena + o_brent);
+  d_running = reinterpret_cast<unsigned int*>(arena + o_running);
+  double* d_seq_sum = reinterpret_cast<double*>(arena + o_seq_sum);
+  int* d_seq_e = reinterpret_cast<int*>(arena + o_seq_e);
+  long long* d_seq_n = reinterpret_cast<long long*>(arena + o_seq_n);
+  double* d_seq_out = reinterpret_cast<double*>(arena + o_seq_out);
+  try_hip(hipMemsetAsync(d_meta, 0, (n_tab + 8) * sizeof(uint32_t), dev.stream), KGX_EHIP, "memset(meta)");
+  if (locus_index && n_sel) {
+    d_index = reinterpret_cast<uint32_t*>(arena + o_index);
+    try_hip(hipMemsetAsync(d_index, 0, (n_sel + 8) * sizeof(uint32_t), dev.stream), KGX_EHIP, "memset(index)");
+  }
+  hipStream_t st = dev.stream;
+  if (rc == KGX_OK && n_sel) {
+    // hipMemcpyDefault: the caller's tables may live on the host or already on this device (kgx.h)
+    try_hip(hipMemcpyAsync(d_af, minor_af, n_sel * amax * sizeof(double), hipMemcpyDefault, st), KGX_EHIP, "copy(af)");
+    if (d_index) try_hip(hipMemcpyAsync(d_index, locus_index, n_sel * sizeof(uint32_t), hipMemcpyDefault, st), KGX_EHIP, "copy(index)");
+  }
+  try_hip(hipMemsetAsync(d_counts, 0, n * 6 * sizeof(unsigned long long), st), KGX_EHIP, "memset(counts)");
+  try_hip(hipMemsetAsync(d_part, 0, n_seg * n * kParts0 * sizeof(double), st), KGX_EHIP, "memset(partials)");
+  try_hip(hipMemsetAsync(d_f, 0, n * sizeof(double), st), KGX_EHIP, "memset(f)");
+
+  const dim3 grid(gx, static_cast<uint32_t>(n_seg));
+  const uint32_t* gt32 = reinterpret_cast<const uint32_t*>(sh.d_gt);
+  const uint64_t dwords_per_row = sh.pitch / 4;
+  // The SWAR sweeps guard against allele indexes 8..14 (past their 8-entry tables) only if the matrix holds any: looked
+  // up once per content of the matrix, by one pass over its bytes (KGX_K5_ALWAYS_GUARD=1 skips the look and guards).
+  bool guard = true;
+  if (rc == KGX_OK && n_sel && (swar16 || amax <= 4) && env_int("KGX_K5_ALWAYS_GUARD", 0) == 0) {
+    if (sh.wide_nibbles == 0) {
+      unsigned int found = 0;
+      try_hip(hipMemsetAsync(d_running, 0, sizeof(unsigned int), st), KGX_EHIP, "memset(scan flag)");
+      const uint64_t n_chunks = sh.n_loci * (sh.pitch / 16);
+      if (rc == KGX_OK) {
+        hipLaunchKernelGGL(k_scan_wide_nibbles, dim3(stream_grid(dev, n_chunks, kBlock)), dim3(kBlock), 0, st, reinterpret_cast<const kgx_v4u*>(sh.d_gt),
+                           n_chunks, d_running);
+        try_hip(hipGetLastError(), KGX_EHIP, "k_scan_wide_nibbles launch");
+        try_hip(hipMemcpyAsync(&found, d_running, sizeof(found), hipMemcpyDeviceToHost, st), KGX_EHIP, "D2H(scan flag)");
+        try_hip(hipStreamSynchronize(st), KGX_EHIP, "sync");
+      }
+      if (rc == KGX_OK) sh.wide_nibbles = found ? 2 : 1;
+    }
+    guard = sh.wide_nibbles != 1;
+  }
+  auto sweep = [&](int mode) {
+    if (n_sel == 0) return;
+    if (mode == 0 && sequential_defaults) {
+      const dim3 seq_grid(static_cast<uint32_t>(n_seq_blocks));
+      hipLaunchKernelGGL(k_seq_block_sums, seq_grid, dim3(kBlock), 0, st, d_table, d_valid, n_sel, amax, d_seq_sum);
+      hipLaunchKernelGGL(k_seq_block_predict, dim3(1), dim3(kBlock), 0, st, d_seq_sum, n_seq_blocks, d_seq_e);
+      hipLaunchKernelGGL(k_seq_block_quantize, seq_grid, dim3(kBlock), 0, st, d_table, d_valid, n_sel, amax, d_seq_e, d_seq_n);
+      hipLaunchKernelGGL(k_seq_chain, dim3(1), dim3(kBlock), 0, st, d_table, d_valid, n_sel, amax, d_seq_e, d_seq_n, n_seq_blocks, d_seq_out);
+    }
+    if (mode == 0) {
+      if (swar16) {
+        hipLaunchKernelGGL(k_locus_bits, dim3(stream_grid(dev, n_sel, kBlock)), dim3(kBlock), 0, st, d_table, d_valid, n_sel, amax, d_meta);
+        hipLaunchKernelGGL(k_segment_defaults, dim3(static_cast<uint32_t>(n_seg)), dim3(kWave), 0, st, d_table, d_valid, n_sel, per_seg, amax, sequential_defaults ? 1 : 0, d_segdef);
+        hipLaunchKernelGGL(k_fill_defaults, dim3(stream_grid(dev, n_seg * n, kBlock)), dim3(kBlock), 0, st, d_segdef, n_seg, n, d_part);
+        const dim3 grid16(gx16, static_cast<uint32_t>(n_seg));
+        const kgx_v4u* gt128 = reinterpret_cast<const kgx_v4u*>(sh.d_gt);
+#define KGX_SWAR16(INDEXED, GUARD)                                                                                                  \
+  hipLaunchKernelGGL((k_inbreed_sweep_swar16<INDEXED, GUARD>), grid16, dim3(kBlock), 0, st, gt128, sh.pitch / 16, g0, n, d_index, n_sel, \
+                     per_seg, d_table, d_meta, amax, phased, d_segdef, d_counts, d_part)
+        if (d_index) { if (guard) KGX_SWAR16(true, true); else KGX_SWAR16(true, false); }
+        else { if (guard) KGX_SWAR16(false, true); else KGX_SWAR16(false, false); }
+#undef KGX_SWAR16
+      } else if (env_int("KGX_K5_GENERIC", 0) || amax > 4 || (algorithm == KGX_ALGO_RITLAND_LOCUS && !ritland_lut)) {
+        hipLaunchKernelGGL((k_inbreed_sweep<0>), grid, dim3(kBlock), 0, st, gt32, dwords_per_row, g0, n, d_index, n_sel, per_seg, d_table,
+                           d_valid, amax, phased, d_f, d_counts, d_part);
+      } else {
+        hipLaunchKernelGGL(k_locus_bits, dim3(stream_grid(dev, n_sel, kBlock)), dim3(kBlock), 0, st, d_table, d_valid, n_sel, amax, d_meta);
+        hipLaunchKernelGGL(k_segment_defaults, dim3(static_cast<uint32_t>(n_seg)), dim3(kWave), 0, st, d_table, d_valid, n_sel, per_seg, amax, sequential_defaults ? 1 : 0, d_segdef);
+#define KGX_SWAR(INDEXED, GUARD)                                                                                                   \
+  hipLaunchKernelGGL((k_inbreed_sweep_swar<INDEXED, GUARD>), grid, dim3(kBlock), 0, st, gt32, dwords_per_row, g0, n, d_index, n_sel,    \
+                     per_seg, d_table, d_meta, amax, phased, d_segdef, d_counts, d_part)
+        if (d_index) { if (guard) KGX_SWAR(true, true); else KGX_SWAR(true, false); }
+        else { if (guard) KGX_SWAR(false, true); else KGX_SWAR(false, false); }
+#undef KGX_SWAR
+      }
+    } else if (eval_lut || mode == 3) {
+      const dim3 grid_eval(static_cast<uint32_t>(((n + eval_gpl - 1) / eval_gpl + kBlock - 1) / kBlock), static_cast<uint32_t>(n_seg));
+#define KGX_EVAL(M, W, B)                                                                                                         \
+  hipLaunchKernelGGL((k_inbreed_eval_lut<M, W, B>), grid_eval, dim3(kBlock), 0, st, gt32, dwords_per_row, g0, n, d_index, n_sel,  \
+                     per_seg, d_table, d_valid, amax, phased, d_f, d_part, d_counts)
+#define KGX_EVAL_BITS(M, W)                                                                \
+  do {                                                                                     \
+    if (amax <= 1) KGX_EVAL(M, W, 1); else if (amax <= 3) KGX_EVAL(M, W, 2); else KGX_EVAL(M, W, 3); \
+  } while (0)
+      if (mode == 1) {
+        if (eval_gpl == 8) KGX_EVAL_BITS(1, 8); else KGX_EVAL_BITS(1, 4);
+      } else if (mode == 2) {
+        if (eval_gpl == 8) KGX_EVAL_BITS(2, 8); else KGX_EVAL_BITS(2, 4);
+      } else {
+        if (eval_gpl == 8) KGX_EVAL_BITS(3, 8); else KGX_EVAL_BITS(3, 4);
+      }
+#undef KGX_EVAL_BITS
+#undef KGX_EVAL
+    } else if (mode == 1)
+      hipLaunchKernelGGL((k_inbreed_sweep<1>), grid, dim3(kBlock), 0, st, gt32, dwords_per_row, g0, n, d_index, n_sel, per_seg, d_table,
+                         d_valid, amax, phased, d_f, d_counts, d_part);
+    else
+      hipLaunchKernelGGL((k_inbreed_sweep<2>), grid, dim3(kBlock), 0, st, gt32, dwords_per_row, g0, n, d_index, n_sel, per_seg, d_table,
+                         d_valid, amax, phased, d_f, d_counts, d_part);
+  };
+  const uint32_t lin_grid = stream_grid(dev, n, kBlock);
+  if (rc == KGX_OK) {
+    if (n_sel) hipLaunchKernelGGL((k_locus_tables<true>), dim3(stream_grid(dev, n_sel, kBlock)), dim3(kBlock), 0, st, d_af, n_sel, amax, 0.0, d_table, d_valid);
+    if (rc == KGX_OK) try_hip(hipEventRecord(dev.sweep_begin, st), KGX_EHIP, "hipEventRecord");
+    sweep(0);
+    if (ritland_lut) sweep(3);
+    if (rc == KGX_OK) try_hip(hipEventRecord(dev.sweep_end, st), KGX_EHIP, "hipEventRecord");
+    hipLaunchKernelGGL(k_reduce_parts, dim3(stream_grid(dev, n * kParts0, kBlock)), dim3(kBlock), 0, st, d_part, n_seg, n * kParts0,
+                       (sequential_defaults && n_sel) ? d_seq_out : nullptr, d_sums);
+    // Window-sized calls: the whole iteration in one launch, a wave per genome (k_inbreed_iterate_wave).
+    const bool wave_path = (algorithm == 2 || algorithm == 3) && n_sel > 0 && n_sel <= 64ull * kWaveCells && !env_int("KGX_K7_NO_WAVE", 0);
+    if (wave_path) {
+      const uint32_t wave_grid = static_cast<uint32_t>((n * kWave + kBlock - 1) / kBlock);
+      try_hip(hipMemsetAsync(d_running, 0, sizeof(unsigned int), st), KGX_EHIP, "memset(evaluations)");
+      if (algorithm == 2)
+        hipLaunchKernelGGL((k_inbreed_iterate_wave<1>), dim3(wave_grid), dim3(kBlock), 0, st, sh.d_gt, sh.pitch, g0, n, d_index, n_sel, d_table, d_valid,
+                           amax, phased, d_counts, d_sums, d_f, d_running);
+      else
+        hipLaunchKernelGGL((k_inbreed_iterate_wave<2>), dim3(wave_grid), dim3(kBlock), 0, st, sh.d_gt, sh.pitch, g0, n, d_index, n_sel, d_table, d_valid,
+                           amax, phased, d_counts, env_int("KGX_K7_ESTIMATE_START", 0) ? d_sums : nullptr, d_f, d_running);
+      if (algorithm == 3) {
+        unsigned int evaluations = 0;
+        try_hip(hipMemcpyAsync(&evaluations, d_running, sizeof(unsigned int), hipMemcpyDeviceToHost, st), KGX_EHIP, "D2H(evaluations)");
+        try_hip(hipStreamSynchronize(st), KGX_EHIP, "sync");
+        dev.last_evaluations = static_cast<int>(evaluations);
+      }
+    } else if (algorithm == 2) {
+      // processHallME (_calc.cpp:225-307).  The reference restarts from U(0,0.5] and, through RetryCalcResult's
+      // self-comparison, always stops after 5 restarts of exactly 50 expectation steps, keeping the last; the
+      // fixed start 0.25 (the mean of its start distribution) replaces the random draw.
+      std::vector<double> f0(n, 0.25);
+      // locus slots every lane of k_inbreed_eval_lut walks: whole batches of 8 in every segment
+      const unsigned long long walked = eval_lut && n_sel ? (n_seg - 1) * per_seg + (n_sel - (n_seg - 1) * per_seg + 7) / 8 * 8 : 0ull;
+      try_hip(hipMemcpyAsync(d_f, f0.data(), n * sizeof(double), hipMemcpyHostToDevice, st), KGX_EHIP, "H2D(f0)");
+      try_hip(hipStreamSynchronize(st), KGX_EHIP, "sync");
+      for (int it = 0; it < 50 && rc == KGX_OK; ++it) {
+        sweep(1);
+        hipLaunchKernelGGL(k_reduce_parts, dim3(lin_grid), dim3(kBlock), 0, st, d_part, n_seg, n, nullptr, d_eval);
+        hipLaunchKernelGGL(k_hall_update, dim3(lin_grid), dim3(kBlock), 0, st, d_eval, d_counts, n, walked, d_f);
+      }
+    } else if (algorithm == 3) {
+      // processLogLikelihood (_calc.cpp:153-216): maximise over [-1,1].  The objective is a sum of logs of
+      // clamped linear functions of F; Brent's method on that same clamped objective replaces nlopt's Nelder-Mead
+      // (un-vendored, unpinned), to within 5e-7 in F where the reference stops at an absolute change of 1e-6.  KGX_K7_GOLDEN=1 runs the
+      // plain golden-section search instead (38 evaluations, bracket 6e-8).
+      if (!env_int("KGX_K7_GOLDEN", 0)) {
+        // Start: [-1, 1] from its golden point.  KGX_K7_ESTIMATE_START=1 starts in a window around the Simple estimate
+        // instead (brent_start): 11 instead of 15 evaluations on a population with F in [0, 0.1], but where the clamped
+        // objective has several local maxima (F < 0) it may settle on another one than a search from the middle does --
+        // the reference itself lands on one or another from its random starts -- so it is not the default.
+        hipLaunchKernelGGL(k_brent_init, dim3(lin_grid), dim3(kBlock), 0, st, d_counts, d_sums, n, env_int("KGX_K7_ESTIMATE_START", 0), d_brent, d_f);
+        constexpr int kMaxEvaluations = 60;        // golden section alone would need 38; Brent's safeguard keeps that bound
+        // The genomes still searching.  When at most half of them are left -- and the call is big enough for it to pay --
+        // their genotype columns and states are compacted (dense in the selected loci) and the remaining passes sweep
+        // only those: on populations with F of both signs the last genomes need twice the evaluations of the first.
+        // A genome's sums do not depend on its neighbours, so the results are bit-identical (KGX_K7_NO_COMPACT=1 to compare).
+        uint64_t n_act = n, act_g0 = g0, act_dwords_per_row = dwords_per_row;
+        const uint32_t* act_gt = gt32;
+        const uint32_t* act_index = d_index;
+        BrentState* act_brent = d_brent;
+        double* act_f = d_f;
+        uint32_t* act_global = nullptr;
+        int act_gpl = eval_gpl;
+        std::vector<uint32_t> global_of(n);
+        for (uint64_t g = 0; g < n; ++g) global_of[g] = static_cast<uint32_t>(g);
+        std::vector<BrentState> host_states;
+        auto evaluate = [&]() {
+          if (act_gt == gt32) { sweep(2); return; }
+          const dim3 grid_eval(static_cast<uint32_t>(((n_act + act_gpl - 1) / act_gpl + kBlock - 1) / kBlock), static_cast<uint32_t>(n_seg));
+#define KGX_EVAL2(W, B)                                                                                                              \
+  hipLaunchKernelGGL((k_inbreed_eval_lut<2, W, B>), grid_eval, dim3(kBlock), 0, st, act_gt, act_dwords_per_row, act_g0, n_act, act_index, \
+                     n_sel, per_seg, d_table, d_valid, amax, phased, act_f, d_part, d_counts)
+          if (amax <= 1) KGX_EVAL2(8, 1); else if (amax <= 3) KGX_EVAL2(8, 2); else KGX_EVAL2(8, 3);
+#undef KGX_EVAL2
+        };
+        const bool may_compact = eval_lut && !env_int("KGX_K7_NO_COMPACT", 0);
+        bool may_compact_now = may_compact;
+        int compaction_level = 0;
+        for (int it = 0; it < kMaxEvaluations && rc == KGX_OK; ++it) {
+          evaluate();
+          const uint32_t act_grid = stream_grid(dev, n_act, kBlock);
+          hipLaunchKernelGGL(k_reduce_parts, dim3(act_grid), dim3(kBlock), 0, st, d_part, n_seg, n_act, nullptr, d_eval);
+          try_hip(hipMemsetAsync(d_running, 0, sizeof(unsigned int), st), KGX_EHIP, "memset(running)");
+          hipLaunchKernelGGL(k_brent_step, dim3(act_grid), dim3(kBlock), 0, st, act_brent, d_eval, n_act, it == 0 ? 0 : 1, act_f, d_running,
+                             act_global, d_f);
+          unsigned int running = 0;
+          try_hip(hipMemcpyAsync(&running, d_running, sizeof(unsigned int), hipMemcpyDeviceToHost, st), KGX_EHIP, "D2H(running)");
+          try_hip(hipStreamSynchronize(st), KGX_EHIP, "sync");
+          dev.last_evaluations = it + 1;
+          if (env_int("KGX_K7_TRACE", 0)) std::fprintf(stderr, "kgx: Loglikelihood evaluation %d: %u of %llu genomes still searching\n", it + 1, running, (unsigned long long)n_act);
+          if (running == 0) break;
+          const uint64_t new_pitch = (static_cast<uint64_t>(running) + 127) / 128 * 128;
+          // worth it from ~64 M cells left (a gather costs about one pass); the two knobs are for the tests
+          const uint64_t min_genomes = static_cast<uint64_t>(env_int("KGX_K7_COMPACT_MIN_GENOMES", 2048));
+          const uint64_t min_cells = static_cast<uint64_t>(env_int("KGX_K7_COMPACT_MIN_CELLS", 1 << 26));
+          if (!may_compact_now || static_cast<uint64_t>(running) * 2 > n_act || n_act < min_genomes || n_sel * static_cast<uint64_t>(running) < min_cells) continue;
+          host_states.resize(n_act);
+          try_hip(hipMemcpyAsync(host_states.data(), act_brent, n_act * sizeof(BrentState), hipMemcpyDeviceToHost, st), KGX_EHIP, "D2H(states)");
+          try_hip(hipStreamSynchronize(st), KGX_EHIP, "sync");
+          if (rc != KGX_OK) break;
+          std::vector<uint32_t> columns, new_global;
+          for (uint64_t g = 0; g < n_act; ++g)
+            if (!host_states[g].done) { columns.push_back(static_cast<uint32_t>(g)); new_global.push_back(global_of[g]); }
+          const uint64_t n_new = columns.size();
+          // Level k lives in the library's ping-pong buffer k & 1 (what that buffer held, level k - 2, is no longer read);
+          // the buffers stay allocated between calls like the scratch arena (kgx_release_scratch frees them).
+          ScratchPlan level;
+          const size_t o_gt = level.add(n_sel * new_pitch), o_st = level.add(n_new * sizeof(BrentState)), o_nf = level.add(n_new * sizeof(double));
+          const size_t o_col = level.add(n_new * sizeof(uint32_t)), o_glob = level.add(n_new * sizeof(uint32_t));
+          const int slot = compaction_level & 1;
+          if (dev.compact_bytes[slot] < level.total) {
+            if (dev.compact[slot]) (void)hipFree(dev.compact[slot]);
+            dev.compact[slot] = nullptr;
+            dev.compact_bytes[slot] = 0;
+            size_t free_bytes = 0, total_bytes = 0;
+            if (hipMemGetInfo(&free_bytes, &total_bytes) != hipSuccess || free_bytes < level.total + (4ull << 30) ||
+                hipMalloc(&dev.compact[slot], level.total) != hipSuccess) {
+              (void)hipGetLastError();
+              dev.compact[slot] = nullptr;
+              may_compact_now = false;                                     // no room: carry on as is
+              continue;
+            }
+            dev.compact_bytes[slot] = level.total;
+          }
+          ++compaction_level;
+          char* base = dev.compact[slot];
+          uint8_t* new_gt = reinterpret_cast<uint8_t*>(base + o_gt);
+          BrentState* new_brent = reinterpret_cast<BrentState*>(base + o_st);
+          double* new_f = reinterpret_cast<double*>(base + o_nf);
+          uint32_t* new_columns = reinterpret_cast<uint32_t*>(base + o_col);
+          uint32_t* d_new_global = reinterpret_cast<uint32_t*>(base + o_glob);
+          try_hip(hipMemcpyAsync(new_columns, columns.data(), n_new * sizeof(uint32_t), hipMemcpyHostToDevice, st), KGX_EHIP, "H2D(columns)");
+          try_hip(hipMemcpyAsync(d_new_global, new_global.data(), n_new * sizeof(uint32_t), hipMemcpyHostToDevice, st), KGX_EHIP, "H2D(global)");
+          const dim3 gather_grid(static_cast<uint32_t>((new_pitch / 4 + kBlock - 1) / kBlock), static_cast<uint32_t>(std::min<uint64_t>(n_sel, 8192)));
+          hipLaunchKernelGGL(k_gather_columns, gather_grid, dim3(kBlock), 0, st, reinterpret_cast<const uint8_t*>(act_gt), act_dwords_per_row * 4,
+                             act_g0, act_index, n_sel, new_columns, n_new, new_gt, new_pitch);
+          hipLaunchKernelGGL(k_gather_states, dim3(stream_grid(dev, n_new, kBlock)), dim3(kBlock), 0, st, act_brent, act_f, new_columns, n_new, new_brent, new_f);
+          try_hip(hipStreamSynchronize(st), KGX_EHIP, "sync");           // columns / new_global leave scope
+          act_gt = reinterpret_cast<const uint32_t*>(new_gt);
+          act_dwords_per_row = new_pitch / 4;
+          act_g0 = 0;
+          act_index = nullptr;
+          act_brent = new_brent;
+          act_f = new_f;
+          act_global = d_new_global;
+          act_gpl = 8;
+          n_act = n_new;
+          global_of.swap(new_global);
+        }
+        hipLaunchKernelGGL(k_brent_step, dim3(stream_grid(dev, n_act, kBlock)), dim3(kBlock), 0, st, act_brent, d_eval, n_act, 2, act_f, d_running, act_global, d_f);
+        try_hip(hipStreamSynchronize(st), KGX_EHIP, "sync");
+      } else {
+      const double inv_phi = 0.6180339887498949;
+      constexpr int kGoldenSteps = 38;     // bracket 2 * 0.618^36 = 6e-8 after the two start-up evaluations
+      GoldenState init;
+      init.a = -1.0; init.b = 1.0;
+      init.c = init.b - inv_phi * (init.b - init.a);
+      init.d = init.a + inv_phi * (init.b - init.a);
+      init.fc = init.fd = 0.0; init.last_was_c = 0; init.pad = 0;
+      std::vector<GoldenState> gs(n, init);
+      std::vector<double> f0(n, init.c);
+      try_hip(hipMemcpyAsync(d_golden, gs.data(), n * sizeof(GoldenState), hipMemcpyHostToDevice, st), KGX_EHIP, "H2D(golden)");
+      try_hip(hipMemcpyAsync(d_f, f0.data(), n * sizeof(double), hipMemcpyHostToDevice, st), KGX_EHIP, "H2D(f0)");
+      try_hip(hipStreamSynchronize(st), KGX_EHIP, "sync");
+      for (int it = 0; it < kGoldenSteps && rc == KGX_OK; ++it) {
+        sweep(2);
+        hipLaunchKernelGGL(k_reduce_parts, dim3(lin_grid), dim3(kBlock), 0, st, d_part, n_seg, n, nullptr, d_eval);
+        hipLaunchKernelGGL(k_golden_step, dim3(lin_grid), dim3(kBlock), 0, st, d_golden, d_eval, n, it < 2 ? it : 2, d_f);
+      }
+      // coefficient = the better interior point of the final bracket
+      if (rc == KGX_OK) {
+        try_hip(hipMemcpyAsync(gs.data(), d_golden, n * sizeof(GoldenState), hipMemcpyDeviceToHost, st), KGX_EHIP, "D2H(golden)");
+        try_hip(hipStreamSynchronize(st), KGX_EHIP, "sync");
+        for (uint64_t g = 0; g < n; ++g) f0[g] = 0.5 * (gs[g].a + gs[g].b);
+        try_hip(hipMemcpyAsync(d_f, f0.data(), n * sizeof(double), hipMemcpyHostToDevice, st), KGX_EHIP, "H2D(f)");
+        try_hip(hipStreamSynchronize(st), KGX_EHIP, "sync");
+      }
+      dev.last_evaluations = kGoldenSteps;
+      }
+    }
+    hipLaunchKernelGGL(k_finish_inbreed, dim3(lin_grid), dim3(kBlock), 0, st, d_counts, d_sums, n, algorithm, d_f, d_out);
+    try_hip(hipGetLastError(), KGX_EHIP, "kernel launch");
+    try_hip(hipMemcpyAsync(out, d_out, n * sizeof(LocusResultsDev), hipMemcpyDeviceToHost, st), KGX_EHIP, "D2H(out)");
+    try_hip(hipStreamSynchronize(st), KGX_EHIP, "stream synchronize");
+    if (rc == KGX_OK) {
+      float ms = 0.f;
+      if (hipEventElapsedTime(&ms, dev.sweep_begin, dev.sweep_end) == hipSuccess) dev.last_sweep_ms = ms;
+    }
+  }
+  return rc;
+}
+
+
+}  // namespace
+}  // namespace kgx
+
+using namespace kgx;
+
+extern "C" {
+
+kgx_gt8* kgx_gt8_create(uint64_t n_genomes, uint64_t n_loci) {
+  std::shared_ptr<Runtime> rt;
+  if (require_runtime(rt)) return nullptr;
+  if (n_genomes == 0) { fail(KGX_EINVAL, "n_genomes must be > 0"); return nullptr; }
+  if (n_loci > 0xFFFFFFFFull) { fail(KGX_EINVAL, "n_loci exceeds the 32-bit locus index"); return nullptr; }
+  kgx_gt8* h = new (std::nothrow) kgx_gt8();
+  if (!h) { fail(KGX_ENOMEM, "host allocation failed"); return nullptr; }
+  h->rt = rt;
+  h->n_genomes = n_genomes;
+  h->n_loci = n_loci;
+  // Contiguous genome shards of whole 128-genome units (a row's pitch; every sweep's widest lane load divides it).
+  const uint64_t n_slots = rt->devs.size();
+  const uint64_t units = (n_genomes + 127) / 128, per = units / n_slots, extra = units % n_slots;
+  uint64_t base = 0;
+  for (uint64_t s = 0; s < n_slots; ++s) {
+    kgx_gt8_shard sh;
+    sh.dev = rt->devs[s].get();
+    sh.genome_base = base;
+    const uint64_t want = (per + (s < extra ? 1 : 0)) * 128;
+    sh.n_genomes = want < n_genomes - base ? want : n_genomes - base;
+    sh.n_loci = n_loci;
+    sh.pitch = (sh.n_genomes + 127) / 128 * 128;
+    base += sh.n_genomes;
+    h->shards.push_back(sh);
+  }
+  for (auto& sh : h->shards) {
+    const uint64_t bytes = sh.pitch * n_loci;
+    if (!bytes) continue;
+    if (use_device(*sh.dev) != KGX_OK || hipMalloc(&sh.d_gt, bytes) != hipSuccess) {
+      (void)hipGetLastError();
+      fail(KGX_ENOMEM, "hipMalloc of %llu bytes for the %llu x %llu genotype matrix on device %d failed", (unsigned long long)bytes,
+           (unsigned long long)n_loci, (unsigned long long)sh.n_genomes, sh.dev->id);
+      destroy_shards(h);
+      delete h;
+      return nullptr;
+    }
+    if (hipMemsetAsync(sh.d_gt, 0, bytes, sh.dev->stream) != hipSuccess) {
+      (void)hipGetLastError();
+      fail(KGX_EHIP, "memset of the genotype matrix failed");
+      destroy_shards(h);
+      delete h;
+      return nullptr;
+    }
+  }
+  if (sync_shards(h) != KGX_OK) {
+    destroy_shards(h);
+    delete h;
+    return nullptr;
+  }
+  return h;
+}
+
+void kgx_gt8_destroy(kgx_gt8* h) {
+  if (!h) return;
+  destroy_shards(h);
+  delete h;
+}
+
+uint64_t kgx_gt8_genomes(const kgx_gt8* h) { return h ? h->n_genomes : 0; }
+uint64_t kgx_gt8_loci(const kgx_gt8* h) { return h ? h->n_loci : 0; }
+uint64_t kgx_gt8_sweep_bytes(uint64_t n_genomes, uint64_t n_selected, uint32_t amax) {
+  return n_genomes * n_selected + 8ull * amax * n_selected + 80ull * n_genomes;
+}
+uint32_t kgx_gt8_shards(const kgx_gt8* h) { return h ? static_cast<uint32_t>(h->shards.size()) : 0; }
+int kgx_gt8_shard_info(const kgx_gt8* h, uint32_t shard, int* slot, uint64_t* genome_base, uint64_t* n_genomes) {
+  if (int bound = require_bound()) return bound;
+  if (!h || shard >= h->shards.size()) return fail(KGX_EINVAL, "no such shard");
+  const auto& sh = h->shards[shard];
+  if (slot) *slot = sh.dev->slot;
+  if (genome_base) *genome_base = sh.genome_base;
+  if (n_genomes) *n_genomes = sh.n_genomes;
+  return KGX_OK;
+}
+
+int kgx_gt8_load(kgx_gt8* h, const uint8_t* src, uint64_t g0, uint64_t g1) {
+  if (int bound = require_bound()) return bound;
+  if (!h || !src) return fail(KGX_EINVAL, "null handle or source");
+  if (g0 > g1 || g1 > h->n_genomes) return fail(KGX_EINVAL, "genome range out of bounds");
+  if (g0 == g1 || h->n_loci == 0) return KGX_OK;
+  const uint64_t L = h->n_loci;
+  const int rc = for_each_parallel(h->shards.size(), [&](size_t s) -> int {
+    kgx_gt8_shard& sh = h->shards[s];
+    const uint64_t lo = g0 > sh.genome_base ? g0 : sh.genome_base;
+    const uint64_t hi = g1 < sh.genome_base + sh.n_genomes ? g1 : sh.genome_base + sh.n_genomes;
+    if (lo >= hi) return KGX_OK;
+    if (int e = use_device(*sh.dev)) return e;
+    sh.wide_nibbles = 0;              // the bytes change: look again (kgx_inbreed)
+    uint64_t slab = (1ull << 30) / L;
+    if (slab < 1) slab = 1;
+    const uint64_t max_rows = (hi - lo) < slab ? (hi - lo) : slab;
+    uint8_t* d_stage = nullptr;
+    KGX_HIP_MEM(hipMalloc(&d_stage, max_rows * L));
+    int r = KGX_OK;
+    for (uint64_t g = lo; g < hi && r == KGX_OK; g += slab) {
+      const uint64_t n = (hi - g) < slab ? (hi - g) : slab;
+      if (hipMemcpyAsync(d_stage, src + (g - g0) * L, n * L, hipMemcpyHostToDevice, sh.dev->stream) != hipSuccess) {
+        r = fail(KGX_EHIP, "H2D copy of genotype bytes failed");
+        break;
+      }
+      hipLaunchKernelGGL(k_gt8_transpose, dim3(stream_grid(*sh.dev, n * L, kBlock)), dim3(kBlock), 0, sh.dev->stream, d_stage, n, L,
+                         g - sh.genome_base, sh.d_gt, sh.pitch);
+      if (hipGetLastError() != hipSuccess || hipStreamSynchronize(sh.dev->stream) != hipSuccess)
+        r = fail(KGX_EHIP, "genotype transpose kernel failed");
+    }
+    (void)hipFree(d_stage);
+    return r;
+  });
+  (void)use_device(*h->shards[0].dev);
+  return rc;
+}
+
+int kgx_gt8_load_rows(kgx_gt8* h, const uint8_t* src, uint64_t src_pitch, uint64_t l0, uint64_t l1) {
+  if (int bound = require_bound()) return bound;
+  if (!h || !src) return fail(KGX_EINVAL, "null handle or source");
+  if (l0 > l1 || l1 > h->n_loci || src_pitch < h->n_genomes) return fail(KGX_EINVAL, "bad locus range or pitch");
+  if (l0 == l1) return KGX_OK;
+  for (auto& sh : h->shards) {
+    if (sh.n_genomes == 0) continue;
+    if (int rc = use_device(*sh.dev)) return rc;
+    sh.wide_nibbles = 0;
+    KGX_HIP(hipMemcpy2DAsync(sh.d_gt + l0 * sh.pitch, sh.pitch, src + sh.genome_base, src_pitch, sh.n_genomes, l1 - l0,
+                             hipMemcpyHostToDevice, sh.dev->stream));
+  }
+  return sync_shards(h);
+}
+
+int kgx_gt8_read_rows(const kgx_gt8* h, uint8_t* dst, uint64_t dst_pitch, uint64_t l0, uint64_t l1) {
+  if (int bound = require_bound()) return bound;
+  if (!h || !dst) return fail(KGX_EINVAL, "null handle or destination");
+  if (l0 > l1 || l1 > h->n_loci || dst_pitch < h->n_genomes) return fail(KGX_EINVAL, "bad locus range or pitch");
+  if (l0 == l1) return KGX_OK;
+  for (const auto& sh : h->shards) {
+    if (sh.n_genomes == 0) continue;
+    if (int rc = use_device(*sh.dev)) return rc;
+    KGX_HIP(hipMemcpy2DAsync(dst + sh.genome_base, dst_pitch, sh.d_gt + l0 * sh.pitch, sh.pitch, sh.n_genomes, l1 - l0,
+                             hipMemcpyDeviceToHost, sh.dev->stream));
+  }
+  return sync_shards(h);
+}
+
+int kgx_locus_class_frequencies(const double* minor_af, uint64_t n_loci, uint32_t amax, double inbreeding, double* out, uint8_t* valid) {
+  std::shared_ptr<Runtime> rt;
+  if (int rc = require_runtime(rt)) return rc;
+  if (!minor_af || !out || amax == 0 || amax > 14) return fail(KGX_EINVAL, "bad arguments (amax must be 1..14)");
+  if (n_loci == 0) return KGX_OK;
+  Device& dev = *rt->devs[0];
+  if (int rc = use_device(dev)) return rc;
+  const uint32_t stride = amax + kTableExtra;
+  double *d_in = nullptr, *d_table = nullptr;
+  uint8_t* d_valid = nullptr;
+  int rc = KGX_OK;
+  if (hipMalloc(&d_in, n_loci * amax * sizeof(double)) != hipSuccess || hipMalloc(&d_table, n_loci * stride * sizeof(double)) != hipSuccess ||
+      hipMalloc(&d_valid, n_loci) != hipSuccess) {
+    (void)hipGetLastError();
+    rc = fail(KGX_ENOMEM, "locus_class_frequencies: hipMalloc failed");
+  }
+  if (rc == KGX_OK) {
+    std::vector<double> table(n_loci * stride);
+    std::vector<uint8_t> v(n_loci);
+    if (hipMemcpyAsync(d_in, minor_af, n_loci * amax * sizeof(double), hipMemcpyHostToDevice, dev.stream) != hipSuccess) rc = fail(KGX_EHIP, "H2D failed");
+    if (rc == KGX_OK) {
+      hipLaunchKernelGGL((k_locus_tables<false>), dim3(stream_grid(dev, n_loci, kBlock)), dim3(kBlock), 0, dev.stream, d_in, n_loci, amax, inbreeding, d_table, d_valid);
+      if (hipGetLastError() != hipSuccess ||
+          hipMemcpyAsync(table.data(), d_table, table.size() * sizeof(double), hipMemcpyDeviceToHost, dev.stream) != hipSuccess ||
+          hipMemcpyAsync(v.data(), d_valid, n_loci, hipMemcpyDeviceToHost, dev.stream) != hipSuccess ||
+          hipStreamSynchronize(dev.stream) != hipSuccess)
+        rc = fail(KGX_EHIP, "locus table kernel failed");
+    }
+    if (rc == KGX_OK) {
+      for (uint64_t l = 0; l < n_loci; ++l) {
+        for (int k = 0; k < 5; ++k) out[l * 5 + k] = table[l * stride + amax + k];
+        if (valid) valid[l] = v[l] ? 1 : 0;
+      }
+    }
+  }
+  if (d_in) (void)hipFree(d_in);
+  if (d_table) (void)hipFree(d_table);
+  if (d_valid) (void)hipFree(d_valid);
+  return rc;
+}
+
+int kgx_inbreed(kgx_gt8* h, uint64_t g0, uint64_t g1, const uint32_t* locus_index, uint64_t n_sel, const double* minor_af,
+                uint32_t amax, int phased, int algorithm, kgx_locus_results* out) {
+  if (int bound = require_bound()) return bound;
+  if (!h || !out || (n_sel && !minor_af)) return fail(KGX_EINVAL, "null argument");
+  if (g0 > g1 || g1 > h->n_genomes || (g0 & 3u)) return fail(KGX_EINVAL, "genome range must lie in the matrix and start on a multiple of 4");
+  if (amax == 0 || amax > 14) return fail(KGX_EINVAL, "amax %u outside [1,14] (4-bit allele indices)", amax);
+  if (algorithm < 0 || algorithm > 3) return fail(KGX_EINVAL, "unknown algorithm %d", algorithm);
+  if (!locus_index && n_sel > h->n_loci) return fail(KGX_EINVAL, "n_sel exceeds the locus count");
+  if (locus_index) {
+    hipPointerAttribute_t attr;                                  // a device-resident index cannot be range-checked from here
+    const bool on_device = hipPointerGetAttributes(&attr, locus_index) == hipSuccess && attr.type == hipMemoryTypeDevice;
+    if (!on_device) {
+      (void)hipGetLastError();
+      for (uint64_t i = 0; i < n_sel; ++i)
+        if (locus_index[i] >= h->n_loci) return fail(KGX_EINVAL, "locus_index[%llu] out of range", (unsigned long long)i);
+    }
+  }
+  if (g0 == g1) return KGX_OK;
+  const int rc = for_each_parallel(h->shards.size(), [&](size_t s) -> int {
+    kgx_gt8_shard& sh = h->shards[s];
+    const uint64_t lo = g0 > sh.genome_base ? g0 : sh.genome_base;
+    const uint64_t hi = g1 < sh.genome_base + sh.n_genomes ? g1 : sh.genome_base + sh.n_genomes;
+    if (lo >= hi) return KGX_OK;
+    return inbreed_shard(sh, lo - sh.genome_base, hi - sh.genome_base, locus_index, n_sel, minor_af, amax, phased, algorithm, out + (lo - g0));
+  });
+  (void)use_device(*h->shards[0].dev);
+  return rc;
+}
+
+double kgx_inbreed_last_sweep_ms(void) {
+  const auto rt = current_runtime();
+  double worst = 0.0;
+  if (rt)
+    for (const auto& dev : rt->devs) worst = dev->last_sweep_ms > worst ? dev->last_sweep_ms : worst;
+  return worst;
+}
+
+int kgx_inbreed_last_evaluations(void) {
+  const auto rt = current_runtime();
+  int most = 0;
+  if (rt)
+    for (const auto& dev : rt->devs) most = dev->last_evaluations > most ? dev->last_evaluations : most;
+  return most;
+}
+
+int kgx_gt8_synth_multiallelic(kgx_gt8* h, uint64_t seed, uint64_t genome_base, uint64_t locus_base, double* af_table) {
+  if (int bound = require_bound()) return bound;
+  if (!h) return fail(KGX_EINVAL, "null handle");
+  if (h->n_loci == 0) return KGX_OK;
+  const int rc = for_each_parallel(h->shards.size(), [&](size_t s) -> int {
+    kgx_gt8_shard& sh = h->shards[s];
+    if (sh.n_genomes == 0) return KGX_OK;
+    if (int e = use_device(*sh.dev)) return e;
+    sh.wide_nibbles = 0;
+    const bool want_table = af_table && s == 0;               // the table does not depend on the genomes: the first shard writes it
+    double* d_table = nullptr;
+    if (want_table) KGX_HIP_MEM(hipMalloc(&d_table, sh.n_loci * KGX_SYNTH_MAX_ALTS * sizeof(double)));
+    const uint64_t work = sh.n_loci * ((sh.n_genomes + 3) / 4);
+    hipLaunchKernelGGL(k_synth_gt8, dim3(stream_grid(*sh.dev, work, kBlock)), dim3(kBlock), 0, sh.dev->stream,
+                       reinterpret_cast<uint32_t*>(sh.d_gt), sh.pitch / 4, sh.n_loci, sh.n_genomes, seed, genome_base + sh.genome_base, locus_base, d_table);
+    int r = KGX_OK;
+    if (hipGetLastError() != hipSuccess) r = fail(KGX_EHIP, "synthetic genotype kernel launch failed");
+    if (r == KGX_OK && want_table &&
+        hipMemcpyAsync(af_table, d_table, sh.n_loci * KGX_SYNTH_MAX_ALTS * sizeof(double), hipMemcpyDeviceToHost, sh.dev->stream) != hipSuccess)
+      r = fail(KGX_EHIP, "D2H of the allele-frequency table failed");
+    if (r == KGX_OK && hipStreamSynchronize(sh.dev->stream) != hipSuccess) r = fail(KGX_EHIP, "synthetic genotype kernel failed");
+    if (d_table) (void)hipFree(d_table);
+    return r;
+  });
+  (void)use_device(*h->shards[0].dev);
+  return rc;
+}
+
+int kgx_synth_multiallelic_host(uint64_t seed, uint64_t genome_base, uint64_t n_genomes, uint64_t l0, uint64_t l1, uint8_t* gt8,
+                                uint64_t pitch, double* af_table, uint8_t* alleles) {
+  if (l0 > l1 || (gt8 && pitch < n_genomes)) return fail(KGX_EINVAL, "bad range or pitch");
+  for (uint64_t l = l0; l < l1; ++l) {
+    const kgx_synth_locus loc = kgx_synth_make_locus(seed, l);
+    if (af_table) {
+      double* row = af_table + (l - l0) * KGX_SYNTH_MAX_ALTS;
+      for (int a = 0; a < KGX_SYNTH_MAX_ALTS; ++a) row[a] = std::nan("");
+      for (int a = 0; a < loc.n_alt; ++a)
+        if (!loc.is_indel[a]) row[loc.snp_index[a] - 1] = static_cast<double>(loc.af[a]);
+    }
+    for (uint64_t g = 0; g < n_genomes; ++g) {
+      int a1, a2;
+      kgx_synth_multi_genotype(seed, l, genome_base + g, loc, a1, a2);
+      if (gt8) gt8[(l - l0) * pitch + g] = static_cast<uint8_t>(kgx_synth_gt8_byte(loc, a1, a2));
+      if (alleles) {
+        alleles[((l - l0) * n_genomes + g) * 2 + 0] = static_cast<uint8_t>(a1);
+        alleles[((l - l0) * n_genomes + g) * 2 + 1] = static_cast<uint8_t>(a2);
+      }
+    }
+  }
+  return KGX_OK;
+}
+
+int kgx_synth_locus_host(uint64_t seed, uint64_t l, int* n_alt, float af[3], int is_indel[3]) {
+  if (!n_alt || !af || !is_indel) return fail(KGX_EINVAL, "null argument");
+  const kgx_synth_locus loc = kgx_synth_make_locus(seed, l);
+  *n_alt = loc.n_alt;
+  for (int a = 0; a < KGX_SYNTH_MAX_ALTS; ++a) { af[a] = loc.af[a]; is_indel[a] = loc.is_indel[a]; }
+  return KGX_OK;
+}
+
+int kgx_synth_loci_host(uint64_t seed, uint64_t l0, uint64_t l1, uint8_t* n_alt, float* af, uint8_t* is_indel) {
+  if (!n_alt || !af || !is_indel || l0 > l1) return fail(KGX_EINVAL, "bad argument");
+  for (uint64_t l = l0; l < l1; ++l) {
+    const kgx_synth_locus loc = kgx_synth_make_locus(seed, l);
+    n_alt[l - l0] = static_cast<uint8_t>(loc.n_alt);
+    for (int a = 0; a < KGX_SYNTH_MAX_ALTS; ++a) {
+      af[(l - l0) * KGX_SYNTH_MAX_ALTS + a] = loc.af[a];
+      is_indel[(l - l0) * KGX_SYNTH_MAX_ALTS + a] = static_cast<uint8_t>(loc.is_indel[a]);
+    }
+  }
+  return KGX_OK;
+}
+
+int kgx_gt8_synth_inbred(kgx_gt8* h, const double* minor_af, uint32_t amax, const double* inbreeding, uint64_t seed) {
+  if (int bound = require_bound()) return bound;
+  if (!h || !minor_af || !inbreeding) return fail(KGX_EINVAL, "null argument");
+  if (amax == 0 || amax > 14) return fail(KGX_EINVAL, "amax %u outside [1,14]", amax);
+  if (h->n_loci == 0) return KGX_OK;
+  const int rc = for_each_parallel(h->shards.size(), [&](size_t s) -> int {
+    kgx_gt8_shard& sh = h->shards[s];
+    if (sh.n_genomes == 0) return KGX_OK;
+    if (int e = use_device(*sh.dev)) return e;
+    sh.wide_nibbles = 0;
+    double *d_table = nullptr, *d_f = nullptr;
+    KGX_HIP_MEM(hipMalloc(&d_table, sh.n_loci * amax * sizeof(double)));
+    if (hipMalloc(&d_f, sh.n_genomes * sizeof(double)) != hipSuccess) { (void)hipGetLastError(); (void)hipFree(d_table); return fail(KGX_ENOMEM, "hipMalloc failed"); }
+    int r = KGX_OK;
+    if (hipMemcpyAsync(d_table, minor_af, sh.n_loci * amax * sizeof(double), hipMemcpyHostToDevice, sh.dev->stream) != hipSuccess ||
+        hipMemcpyAsync(d_f, inbreeding + sh.genome_base, sh.n_genomes * sizeof(double), hipMemcpyHostToDevice, sh.dev->stream) != hipSuccess)
+      r = fail(KGX_EHIP, "H2D of the allele-frequency table failed");
+    if (r == KGX_OK) {
+      hipLaunchKernelGGL(k_synth_inbred, dim3(stream_grid(*sh.dev, sh.n_loci * sh.n_genomes, kBlock)), dim3(kBlock), 0, sh.dev->stream, sh.d_gt,
+                         sh.pitch, sh.n_loci, sh.n_genomes, d_table, amax, d_f, seed, sh.genome_base);
+      if (hipGetLastError() != hipSuccess || hipStreamSynchronize(sh.dev->stream) != hipSuccess) r = fail(KGX_EHIP, "synthetic inbred genome kernel failed");
+    }
+    (void)hipFree(d_table);
+    (void)hipFree(d_f);
+    return r;
+  });
+  (void)use_device(*h->shards[0].dev);
+  return rc;
+}
+
+}  // extern "C"

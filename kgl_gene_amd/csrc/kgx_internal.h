@@ -1,13 +1,108 @@
-// Internal declarations shared by the C-ABI translation units.
+// Internal declarations shared by the C-ABI translation units (kgx_runtime.hip, kgx_dosage.hip, kgx_inbreed.hip).
+//
+// A Runtime is one binding of the library to a list of devices (kgx_init).  Every handle keeps the Runtime it was
+// created under alive and owns one shard per device slot; nothing per-device lives in process globals -- the only
+// global is the pointer to the binding new handles are created under.
 #ifndef KGX_INTERNAL_H
 #define KGX_INTERNAL_H
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
-struct kgx_pop {
-  uint64_t n_genomes = 0;        // genomes in this shard
-  uint64_t n_variants = 0;       // variant rows
+#include <memory>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "../../include/kgx.h"
+
+namespace kgx {
+
+// One device slot of a binding: its own stream, scratch arena and timing events.
+struct Device {
+  int slot = 0;                  // index in Runtime::devs
+  int id = -1;                   // HIP ordinal
+  int compute_units = 0;
+  uint64_t hbm_bytes = 0;
+  hipStream_t stream = nullptr;  // the library's stream on this device (non-blocking)
+  char name[128] = {0};
+  char arch[64] = {0};
+  hipEvent_t sweep_begin = nullptr, sweep_end = nullptr;   // bracket the frequency sweep of the last kgx_inbreed call here
+  hipEvent_t ready = nullptr;                              // cross-stream ordering (kgx_allele_count_by_locus_dev)
+  hipEvent_t by_genome_begin = nullptr, by_genome_end = nullptr;   // bracket the K3 kernel of the last by-genome sweep here
+  double last_by_genome_ms = 0.0;
+  double last_sweep_ms = 0.0;
+  int last_evaluations = 0;                                // objective evaluations of the last Loglikelihood call here
+  char* scratch = nullptr;                                 // grow-only arena for kgx_inbreed's per-call buffers
+  size_t scratch_bytes = 0;
+  char* compact[2] = {nullptr, nullptr};                   // ping-pong buffers of the Loglikelihood search's compaction levels
+  size_t compact_bytes[2] = {0, 0};
+  void* exchange_stage = nullptr;                          // "peer" exchange: staging for another shard's counts
+  size_t exchange_stage_bytes = 0;
+  std::mutex mutex;                                        // serialises the per-device state above between handles
+  ~Device();
+};
+
+enum class Exchange { None, Rccl, Peer };
+
+struct Runtime {
+  std::vector<std::unique_ptr<Device>> devs;
+  Exchange exchange = Exchange::None;
+  std::vector<void*> comms;       // ncclComm_t per slot (Exchange::Rccl)
+  ~Runtime();
+};
+
+// The binding new handles are created under (null before kgx_init).
+std::shared_ptr<Runtime> current_runtime();
+// KGX_ENODEVICE (with the "no CPU fallback" message) until kgx_init has succeeded: the first check of every compute entry point.
+int require_bound();
+
+int fail(int code, const char* fmt, ...) __attribute__((format(printf, 2, 3)));
+const std::string& last_error();
+void set_last_error(const std::string& message);
+int env_int(const char* name, int dflt);
+uint32_t stream_grid(const Device& dev, uint64_t work_items, uint32_t items_per_block);
+
+// Makes `dev` the calling thread's current HIP device.
+int use_device(const Device& dev);
+
+// Run fn(i) for i in [0, n): inline when n == 1, otherwise one host thread per item (each shard drives its own device
+// and blocks on its own stream).  Returns the first non-zero code; the failing worker's message becomes this thread's.
+template <typename Fn>
+int for_each_parallel(size_t n, Fn&& fn) {
+  if (n == 0) return KGX_OK;
+  if (n == 1) return fn(static_cast<size_t>(0));
+  std::vector<int> codes(n, KGX_OK);
+  std::vector<std::string> messages(n);
+  std::vector<std::thread> workers;
+  workers.reserve(n);
+  for (size_t i = 0; i < n; ++i)
+    workers.emplace_back([&, i]() {
+      codes[i] = fn(i);
+      if (codes[i] != KGX_OK) messages[i] = last_error();
+    });
+  for (auto& w : workers) w.join();
+  for (size_t i = 0; i < n; ++i)
+    if (codes[i] != KGX_OK) {
+      set_last_error(messages[i]);
+      return codes[i];
+    }
+  return KGX_OK;
+}
+
+// Sum d_counts[slot] (uint32 x n_words each, one buffer per slot, in place) over the slots; queued behind the work
+// already on each slot's `streams[slot]`, complete on every slot's stream afterwards.
+int exchange_counts(Runtime& rt, const std::vector<void*>& d_counts, uint64_t n_words, const std::vector<hipStream_t>& streams);
+
+}  // namespace kgx
+
+// One genome shard of a population on one device slot.
+struct kgx_pop_shard {
+  kgx::Device* dev = nullptr;
+  uint64_t genome_base = 0;      // first genome of the shard (a multiple of 64)
+  uint64_t n_genomes = 0;
+  uint64_t n_variants = 0;
   uint64_t row_bytes = 0;        // ceil(n_genomes / 4): algorithmic bytes per row
   uint64_t pitch = 0;            // device row pitch, multiple of 16
   uint32_t chunks_per_row = 0;   // pitch / 16
@@ -15,10 +110,19 @@ struct kgx_pop {
   uint8_t* d_rows = nullptr;     // [n_variants][pitch] dosage2
   float* d_af = nullptr;         // [n_variants] INFO allele frequency (float32, NaN = missing)
   void* d_counts = nullptr;      // [n_variants][4] u32 scratch for the host-returning entry points
+};
+
+struct kgx_pop {
+  std::shared_ptr<kgx::Runtime> rt;
+  uint64_t n_genomes = 0;        // all shards
+  uint64_t n_variants = 0;
+  std::vector<kgx_pop_shard> shards;
   bool has_af = false;
 };
 
-struct kgx_gt8 {
+struct kgx_gt8_shard {
+  kgx::Device* dev = nullptr;
+  uint64_t genome_base = 0;      // first genome of the shard (a multiple of 128)
   uint64_t n_genomes = 0;
   uint64_t n_loci = 0;
   uint64_t pitch = 0;            // bytes per locus row, multiple of 128
@@ -29,34 +133,12 @@ struct kgx_gt8 {
   int wide_nibbles = 0;
 };
 
-namespace kgx {
-
-struct State {
-  bool ready = false;
-  int device = -1;
-  int compute_units = 0;
-  uint64_t hbm_bytes = 0;
-  hipStream_t stream = nullptr;
-  char name[128] = {0};
-  char arch[64] = {0};
-  hipEvent_t sweep_begin = nullptr, sweep_end = nullptr;   // bracket the frequency sweep of the last kgx_inbreed call
-  double last_sweep_ms = 0.0;
-  int last_evaluations = 0;                                // objective evaluations of the last Loglikelihood call
-  char* scratch = nullptr;                                 // grow-only arena for kgx_inbreed's per-call buffers
-  size_t scratch_bytes = 0;
-  char* compact[2] = {nullptr, nullptr};                   // ping-pong buffers of the Loglikelihood search's compaction levels
-  size_t compact_bytes[2] = {0, 0};
+struct kgx_gt8 {
+  std::shared_ptr<kgx::Runtime> rt;
+  uint64_t n_genomes = 0;
+  uint64_t n_loci = 0;
+  std::vector<kgx_gt8_shard> shards;
 };
-
-extern State g_state;
-
-int fail(int code, const char* fmt, ...) __attribute__((format(printf, 2, 3)));
-int require_device();
-uint32_t stream_grid(uint64_t work_items, uint32_t items_per_block);
-int launch_allele_count(const kgx_pop* pop, void* d_out, hipStream_t stream);
-int ensure_counts(kgx_pop* pop);
-
-}  // namespace kgx
 
 #define KGX_HIP(call)                                                                             \
   do {                                                                                            \

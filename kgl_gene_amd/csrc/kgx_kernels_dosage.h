@@ -1,0 +1,613 @@
+// HIP kernels for gfx950 (MI355X, CDNA4): the 2-bit dosage sweeps (K2/K3/K4/K8).  Integer counting over 2-bit
+// dosage rows: HBM-bound, no MFMA.  Included only by kgx_dosage.hip.
+//
+// HBM layout ("dosage2"): variant-major rows, row v at rows + v*pitch, pitch = multiple of 16 B.
+// Genome g of the shard sits in bits 2*(g%4) of byte g/4; bits past n_genomes are zero.  One
+// 16-byte chunk = 64 genomes = one lane-load; a wave64 load instruction moves 1 KiB of one or more
+// adjacent rows, fully coalesced.
+#ifndef KGX_KERNELS_DOSAGE_H
+#define KGX_KERNELS_DOSAGE_H
+
+#include "kgx_kernels_common.h"
+#include "kgx_synth.h"
+
+namespace kgx {
+// ---------------------------------------------------------------------------------------------
+// DPP lane-group sums.  After group_sum<W>(x) the LAST lane of every aligned W-lane group holds
+// the sum over that group (for W <= 16 every lane of the group does).
+// ---------------------------------------------------------------------------------------------
+template <int CTRL, int ROW_MASK = 0xF>
+__device__ __forceinline__ uint32_t dpp_add(uint32_t x) {
+  // x + lane-permuted x; lanes with no source (bound_ctrl) add 0.
+  return x + static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(x), CTRL, ROW_MASK, 0xF, true));
+}
+
+template <int W>
+__device__ __forceinline__ uint32_t group_sum(uint32_t x) {
+  if constexpr (W >= 2) x = dpp_add<0xB1>(x);    // quad_perm [1,0,3,2]  : xor 1
+  if constexpr (W >= 4) x = dpp_add<0x4E>(x);    // quad_perm [2,3,0,1]  : xor 2
+  if constexpr (W >= 8) x = dpp_add<0x141>(x);   // row_half_mirror      : 8-lane sums
+  if constexpr (W >= 16) x = dpp_add<0x140>(x);  // row_mirror           : 16-lane (row) sums
+  if constexpr (W >= 32) x = dpp_add<0x142, 0xA>(x);  // row_bcast15 into rows 1,3 : 32-lane sums in rows 1,3
+  if constexpr (W >= 64) x = dpp_add<0x143, 0xC>(x);  // row_bcast31 into rows 2,3 : wave sum in row 3
+  return x;
+}
+
+// Three running popcounts of one 16-byte chunk (64 genomes):
+//   a += #(code & 1)  = het + nondiploid,  b += #(code & 2) = hom + nondiploid,  c += #(code == 3).
+__device__ __forceinline__ void count_chunk(const kgx_v4u x, uint32_t& a, uint32_t& b, uint32_t& c) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const uint32_t w = x[i];
+    a += __builtin_popcount(w & 0x55555555u);
+    b += __builtin_popcount(w & 0xAAAAAAAAu);
+    c += __builtin_popcount(w & (w >> 1) & 0x55555555u);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// K2  allele_count_by_locus: VariantDBVariant::summaryByVariant for every variant row
+// (kgl_variant_db_variant.cpp:126-178).  W lanes cooperate on one row, 64/W rows per wave, U such
+// row sets in flight per wave (U independent 16-B loads per lane per step).
+// out[v] = { refHom, het, minorHom, nonDiploid }.
+// ---------------------------------------------------------------------------------------------
+template <int W, int U, bool NT = true>
+__global__ void __launch_bounds__(kBlock)
+k_allele_count(const kgx_v4u* __restrict__ rows, uint32_t chunks_per_row, uint64_t n_rows,
+               uint32_t n_genomes, kgx_v4u* __restrict__ out) {
+  constexpr int kRowsPerSet = kWave / W;
+  constexpr int kRowsPerIter = kRowsPerSet * U;
+  const uint32_t lane = threadIdx.x & (kWave - 1);
+  const uint32_t sub = lane & (W - 1);
+  const uint32_t grp = lane / W;
+  const uint64_t waves_per_block = blockDim.x / kWave;
+  const uint64_t wave = static_cast<uint64_t>(blockIdx.x) * waves_per_block + threadIdx.x / kWave;
+  const uint64_t n_waves = static_cast<uint64_t>(gridDim.x) * waves_per_block;
+
+  for (uint64_t base = wave * kRowsPerIter; base < n_rows; base += n_waves * kRowsPerIter) {
+    uint32_t a[U], b[U], c[U];
+    const kgx_v4u* rp[U];
+    uint64_t row[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      a[u] = b[u] = c[u] = 0;
+      row[u] = base + static_cast<uint64_t>(u) * kRowsPerSet + grp;
+      const uint64_t r = row[u] < n_rows ? row[u] : n_rows - 1;   // clamp: tail lanes re-read the last row
+      rp[u] = rows + r * chunks_per_row;
+    }
+    for (uint32_t k = sub; k < chunks_per_row; k += W) {
+      kgx_v4u x[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) x[u] = NT ? __builtin_nontemporal_load(rp[u] + k) : rp[u][k];
+#pragma unroll
+      for (int u = 0; u < U; ++u) count_chunk(x[u], a[u], b[u], c[u]);
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const uint32_t sa = group_sum<W>(a[u]);
+      const uint32_t sb = group_sum<W>(b[u]);
+      const uint32_t sc = group_sum<W>(c[u]);
+      if (sub == W - 1 && row[u] < n_rows) {
+        kgx_v4u r;
+        r[0] = n_genomes - sa - sb + sc;   // reference homozygous (implicit in the reference's store)
+        r[1] = sa - sc;                    // minor heterozygous
+        r[2] = sb - sc;                    // minor homozygous
+        r[3] = sc;                         // non-diploid, not counted by the reference
+        out[row[u]] = r;
+      }
+    }
+  }
+}
+
+// af[v] = (het + 2*hom) / (2*total_genomes), fp64 (IEEE divide: bit-identical to the host).
+__global__ void __launch_bounds__(kBlock)
+k_allele_frequency(const kgx_v4u* __restrict__ counts, uint64_t n, uint64_t total_genomes,
+                   double* __restrict__ af) {
+  const double denom = 2.0 * static_cast<double>(total_genomes);
+  for (uint64_t i = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n;
+       i += static_cast<uint64_t>(gridDim.x) * blockDim.x) {
+    const kgx_v4u c = counts[i];
+    af[i] = static_cast<double>(static_cast<uint64_t>(c[1]) + 2u * static_cast<uint64_t>(c[2])) / denom;
+  }
+}
+
+// K4  populationSummary (kgl_variant_db_variant.cpp:234-279) = column sums of the K2 output.
+__global__ void __launch_bounds__(kBlock)
+k_sum_counts(const kgx_v4u* __restrict__ counts, uint64_t n, unsigned long long* __restrict__ total4) {
+  unsigned long long s[4] = {0, 0, 0, 0};
+  for (uint64_t i = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n;
+       i += static_cast<uint64_t>(gridDim.x) * blockDim.x) {
+    const kgx_v4u c = counts[i];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) s[j] += c[j];
+  }
+  __shared__ unsigned long long sh[4][kBlock / kWave];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    unsigned long long v = s[j];
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+    if ((threadIdx.x & 63) == 0) sh[j][threadIdx.x / kWave] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < 4) {
+    unsigned long long v = 0;
+    for (int w = 0; w < kBlock / kWave; ++w) v += sh[threadIdx.x][w];
+    atomicAdd(&total4[threadIdx.x], v);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// K3  genotype_count_by_genome: VariantDBVariant::summaryByGenome for every genome
+// (kgl_variant_db_variant.cpp:180-231) over a selected set of variant rows (the FWS allele-frequency
+// bins, kga_analysis_PfEMP_FWS.cpp:15-38,72-101).
+//
+// Same rows, other reduction axis.  A lane owns one 16-byte chunk column (64 genomes) and walks
+// down the selected rows; each of the 128 bits of the chunk is a 1-bit stream to be counted over
+// rows ("positional popcount").  Streams are counted bit-sliced: a carry-save adder tree folds 8
+// rows into weight-1/2/4 planes and ripples one weight-8 carry word into HI planes, ~6 VALU ops per
+// input word instead of one add per genome.  Planes are unpacked into per-workgroup LDS counters
+// every 255 blocks, and LDS goes to HBM with integer atomics once per workgroup: exact in any order.
+//
+// Accumulates raw stream counts acc[g][bin] = { #(code&1), #(code&2), #(code==3) }; k_finish_by_genome
+// turns them into the reference's { refHom, het, minorHom, nonDiploid }.
+// ---------------------------------------------------------------------------------------------
+struct GenomeWork {
+  uint64_t begin;       // first position in the selected-row list
+  uint64_t end;         // one past the last position
+  uint32_t col_group;   // 64-chunk column group (genomes [4096*col_group, ...))
+  uint32_t bin;         // output bin
+};
+
+constexpr int kHiPlanes = 8;                 // weights 8 .. 1024
+constexpr int kBlocksPerFlush = 255;         // 255*8 + 7 < 8 * 2^kHiPlanes
+constexpr int kLdsStride = 64;               // lanes per counter row in LDS
+
+__device__ __forceinline__ void csa(uint32_t& carry, uint32_t& sum, uint32_t a, uint32_t b, uint32_t c) {
+  const uint32_t u = a ^ b;
+  carry = (a & b) | (u & c);
+  sum = u ^ c;
+}
+
+template <int NW>
+struct SlicedCounters {
+  uint32_t ones[NW], twos[NW], fours[NW], hi[NW][kHiPlanes];
+  __device__ __forceinline__ void clear() {
+#pragma unroll
+    for (int i = 0; i < NW; ++i) {
+      ones[i] = twos[i] = fours[i] = 0;
+#pragma unroll
+      for (int p = 0; p < kHiPlanes; ++p) hi[i][p] = 0;
+    }
+  }
+  // Fold 8 input words of stream-word i.
+  __device__ __forceinline__ void add8(int i, const uint32_t x[8]) {
+    uint32_t t2a, t2b, f4a, f4b, e8;
+    csa(t2a, ones[i], ones[i], x[0], x[1]);
+    csa(t2b, ones[i], ones[i], x[2], x[3]);
+    csa(f4a, twos[i], twos[i], t2a, t2b);
+    csa(t2a, ones[i], ones[i], x[4], x[5]);
+    csa(t2b, ones[i], ones[i], x[6], x[7]);
+    csa(f4b, twos[i], twos[i], t2a, t2b);
+    csa(e8, fours[i], fours[i], f4a, f4b);
+#pragma unroll
+    for (int p = 0; p < kHiPlanes; ++p) {
+      const uint32_t t = hi[i][p] & e8;
+      hi[i][p] ^= e8;
+      e8 = t;
+    }
+  }
+  // Integer count of bit position b of stream-word i.
+  __device__ __forceinline__ uint32_t value(int i, int b) const {
+    uint32_t v = ((ones[i] >> b) & 1u) | (((twos[i] >> b) & 1u) << 1) | (((fours[i] >> b) & 1u) << 2);
+#pragma unroll
+    for (int p = 0; p < kHiPlanes; ++p) v |= ((hi[i][p] >> b) & 1u) << (3 + p);
+    return v;
+  }
+};
+
+// MODE 0: stream words are the 4 chunk dwords (bit 2j = code&1, bit 2j+1 = code&2 of genome j).
+// MODE 1: two words of (code==3) indicators: word0 = t(dw0) | t(dw1)<<1, word1 = t(dw2) | t(dw3)<<1.
+template <int W, int MODE>
+__device__ __forceinline__ void by_genome_pass(const kgx_v4u* __restrict__ rows, uint32_t chunks_per_row,
+                                               const uint32_t* __restrict__ row_index,
+                                               const GenomeWork wk, uint32_t* lds, uint32_t& saw_nondiploid) {
+  constexpr int NW = MODE == 0 ? 4 : 2;
+  constexpr int kRowSlots = (kWave / W) * (kBlock / kWave);   // rows visited per step by the workgroup
+  const uint32_t lane = threadIdx.x & (kWave - 1);
+  const uint32_t sub = lane & (W - 1);
+  const uint32_t slot = (threadIdx.x / kWave) * (kWave / W) + lane / W;
+  const uint32_t col = wk.col_group * 64u + sub;
+  const bool col_ok = col < chunks_per_row;
+
+  SlicedCounters<NW> cnt;
+  cnt.clear();
+  int blocks = 0;
+  uint32_t seen = 0;
+
+  auto flush = [&]() {
+#pragma unroll
+    for (int i = 0; i < NW; ++i) {
+#pragma unroll
+      for (int b = 0; b < 32; ++b) {
+        const uint32_t v = cnt.value(i, b);
+        if (v) atomicAdd(&lds[(i * 32 + b) * kLdsStride + sub], v);
+      }
+    }
+    cnt.clear();
+    blocks = 0;
+  };
+
+  // Gathered rows (the bins) with one row per wave-step slot (W == 64): a wave takes 8 CONSECUTIVE list positions per
+  // step, so their row numbers are one wave-uniform 32-byte scalar load -- on the scalar memory counter, where it does
+  // not queue behind the row loads already in flight as a per-lane index load would (vector memory returns in order).
+  // row_index is padded by 8 entries past the list.
+  const bool scalar_index = (W == kWave) && row_index != nullptr;
+  const uint32_t wave_slot = __builtin_amdgcn_readfirstlane(slot);
+  for (uint64_t p0 = wk.begin + slot; p0 - slot < wk.end; p0 += static_cast<uint64_t>(kRowSlots) * 8) {
+    kgx_v4u x[8];
+    if (scalar_index) {
+      const uint64_t base = (p0 - slot) + static_cast<uint64_t>(wave_slot) * 8;     // wave-uniform
+      uint32_t r[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) r[j] = row_index[base + j];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        kgx_v4u v = {0u, 0u, 0u, 0u};
+        if (base + j < wk.end && col_ok) v = __builtin_nontemporal_load(rows + static_cast<uint64_t>(r[j]) * chunks_per_row + col);
+        x[j] = v;
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const uint64_t p = p0 + static_cast<uint64_t>(j) * kRowSlots;
+        kgx_v4u v = {0u, 0u, 0u, 0u};
+        if (p < wk.end && col_ok) {
+          const uint64_t r = row_index ? static_cast<uint64_t>(row_index[p]) : p;
+          v = __builtin_nontemporal_load(rows + r * chunks_per_row + col);
+        }
+        x[j] = v;
+      }
+    }
+    if constexpr (MODE == 0) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        uint32_t w[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          w[j] = x[j][i];
+          seen |= w[j] & (w[j] >> 1) & 0x55555555u;
+        }
+        cnt.add8(i, w);
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        uint32_t w[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const uint32_t d0 = x[j][2 * i], d1 = x[j][2 * i + 1];
+          w[j] = (d0 & (d0 >> 1) & 0x55555555u) | ((d1 & (d1 >> 1) & 0x55555555u) << 1);
+        }
+        cnt.add8(i, w);
+      }
+    }
+    if (++blocks == kBlocksPerFlush) flush();
+  }
+  flush();
+  saw_nondiploid |= seen;
+}
+
+template <int W>
+__global__ void __launch_bounds__(kBlock)
+k_count_by_genome(const kgx_v4u* __restrict__ rows, uint32_t chunks_per_row, uint64_t n_genomes,
+                  const uint32_t* __restrict__ row_index, const GenomeWork* __restrict__ work,
+                  uint32_t n_bins, unsigned long long* __restrict__ acc /* [n_genomes][n_bins][3] */) {
+  __shared__ uint32_t lds[128 * kLdsStride];
+  const GenomeWork wk = work[blockIdx.x];
+  for (int i = threadIdx.x; i < 128 * kLdsStride; i += kBlock) lds[i] = 0;
+  __syncthreads();
+
+  uint32_t seen = 0;
+  by_genome_pass<W, 0>(rows, chunks_per_row, row_index, wk, lds, seen);
+  __syncthreads();
+  // LDS counter (i*32+b, sub): genome = (col_group*64 + sub)*64 + i*16 + b/2, stream = b&1.
+  for (int idx = threadIdx.x; idx < 128 * kLdsStride; idx += kBlock) {
+    const uint32_t v = lds[idx];
+    const uint32_t sub = idx % kLdsStride, ib = idx / kLdsStride;
+    const uint64_t g = (static_cast<uint64_t>(wk.col_group) * 64u + sub) * 64u + (ib / 32) * 16u + (ib % 32) / 2;
+    if (v && g < n_genomes) atomicAdd(&acc[(g * n_bins + wk.bin) * 3 + (ib & 1u)], static_cast<unsigned long long>(v));
+  }
+  // Non-diploid codes are exceptional: count them in a second pass only if this workgroup saw one.
+  if (__syncthreads_or(seen != 0)) {
+    for (int i = threadIdx.x; i < 64 * kLdsStride; i += kBlock) lds[i] = 0;
+    __syncthreads();
+    uint32_t unused = 0;
+    by_genome_pass<W, 1>(rows, chunks_per_row, row_index, wk, lds, unused);
+    __syncthreads();
+    // LDS counter (i*32+b, sub): chunk dword = 2*i + (b&1), genome within dword = b/2.
+    for (int idx = threadIdx.x; idx < 64 * kLdsStride; idx += kBlock) {
+      const uint32_t v = lds[idx];
+      const uint32_t sub = idx % kLdsStride, ib = idx / kLdsStride;
+      const uint32_t dw = 2u * (ib / 32) + (ib & 1u);
+      const uint64_t g = (static_cast<uint64_t>(wk.col_group) * 64u + sub) * 64u + dw * 16u + (ib % 32) / 2;
+      if (v && g < n_genomes) atomicAdd(&acc[(g * n_bins + wk.bin) * 3 + 2], static_cast<unsigned long long>(v));
+    }
+  }
+}
+
+// acc {a,b,c} -> { refHom = n_rows(bin) - a - b + c, het = a - c, minorHom = b - c, nonDiploid = c }.
+__global__ void __launch_bounds__(kBlock)
+k_finish_by_genome(const unsigned long long* __restrict__ acc, const unsigned long long* __restrict__ rows_in_bin,
+                   uint64_t n_genomes, uint32_t n_bins, unsigned long long* __restrict__ out) {
+  const uint64_t total = n_genomes * n_bins;
+  for (uint64_t i = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < total;
+       i += static_cast<uint64_t>(gridDim.x) * blockDim.x) {
+    const unsigned long long a = acc[i * 3], b = acc[i * 3 + 1], c = acc[i * 3 + 2];
+    const unsigned long long n = rows_in_bin[i % n_bins];
+    out[i * 4 + 0] = n - a - b + c;
+    out[i * 4 + 1] = a - c;
+    out[i * 4 + 2] = b - c;
+    out[i * 4 + 3] = c;
+  }
+}
+
+// Group the selected rows by bin on the device (counting sort in two passes).  A chunk of kBinChunk consecutive rows
+// goes to one workgroup: pass 1 counts rows per bin per chunk; after an exclusive scan over (bin, chunk) on one
+// small kernel, pass 2 scatters row numbers into their bin's range.  Within a chunk the order is arbitrary (LDS
+// atomics) — integer sums do not care — while chunks keep their order, so gathered rows stay nearly sequential.
+constexpr int kBinChunk = 4096;
+constexpr int kMaxBins = 256;
+
+__global__ void __launch_bounds__(kBlock)
+k_bin_count(const uint8_t* __restrict__ bin_of_row, uint64_t n_rows, uint32_t n_bins, uint32_t* __restrict__ chunk_counts) {
+  __shared__ uint32_t cnt[kMaxBins];
+  for (uint32_t b = threadIdx.x; b < n_bins; b += kBlock) cnt[b] = 0;
+  __syncthreads();
+  const uint64_t base = static_cast<uint64_t>(blockIdx.x) * kBinChunk;
+  for (uint32_t i = threadIdx.x; i < kBinChunk; i += kBlock) {
+    const uint64_t r = base + i;
+    if (r < n_rows) {
+      const uint32_t b = bin_of_row[r];
+      if (b < n_bins) atomicAdd(&cnt[b], 1u);
+    }
+  }
+  __syncthreads();
+  for (uint32_t b = threadIdx.x; b < n_bins; b += kBlock) chunk_counts[static_cast<uint64_t>(b) * gridDim.x + blockIdx.x] = cnt[b];
+}
+
+// Exclusive scan of chunk_counts in (bin-major, chunk) order; rows_in_bin[b] and bin_offset[b] as by-products.
+// Two small launches of one workgroup per bin: totals first, then every workgroup chains the bins before it (n_bins
+// adds) and scans its own chunks, a contiguous run of chunks per thread with the runs' sums scanned in LDS.
+__global__ void __launch_bounds__(kBlock)
+k_bin_totals(const uint32_t* __restrict__ chunk_counts, uint32_t n_chunks, unsigned long long* __restrict__ rows_in_bin) {
+  __shared__ unsigned long long part[kBlock / kWave];
+  const uint32_t b = blockIdx.x;
+  unsigned long long t = 0;
+  for (uint32_t c = threadIdx.x; c < n_chunks; c += kBlock) t += chunk_counts[static_cast<uint64_t>(b) * n_chunks + c];
+  for (int off = 32; off > 0; off >>= 1) t += __shfl_xor(t, off);
+  if ((threadIdx.x & (kWave - 1)) == 0) part[threadIdx.x / kWave] = t;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    unsigned long long total = 0;
+    for (int w = 0; w < kBlock / kWave; ++w) total += part[w];
+    rows_in_bin[b] = total;
+  }
+}
+
+__global__ void __launch_bounds__(kBlock)
+k_bin_scan(uint32_t* __restrict__ chunk_counts, uint32_t n_chunks, uint32_t n_bins, const unsigned long long* __restrict__ rows_in_bin,
+           unsigned long long* __restrict__ bin_offset) {
+  __shared__ unsigned long long run_sum[kBlock];
+  const uint32_t b = blockIdx.x;
+  unsigned long long base = 0;
+  for (uint32_t k = 0; k < b; ++k) base += rows_in_bin[k];
+  if (threadIdx.x == 0) {
+    bin_offset[b] = base;
+    if (b + 1 == n_bins) bin_offset[n_bins] = base + rows_in_bin[b];
+  }
+  const uint32_t per_thread = (n_chunks + kBlock - 1) / kBlock;
+  const uint32_t c0 = threadIdx.x * per_thread;
+  const uint32_t c1 = c0 + per_thread < n_chunks ? c0 + per_thread : n_chunks;
+  uint32_t* mine = chunk_counts + static_cast<uint64_t>(b) * n_chunks;
+  unsigned long long t = 0;
+  for (uint32_t c = c0; c < c1; ++c) t += mine[c];
+  run_sum[threadIdx.x] = t;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    unsigned long long run = base;
+    for (int i = 0; i < kBlock; ++i) { const unsigned long long v = run_sum[i]; run_sum[i] = run; run += v; }
+  }
+  __syncthreads();
+  unsigned long long run = run_sum[threadIdx.x];
+  for (uint32_t c = c0; c < c1; ++c) {
+    const uint32_t v = mine[c];
+    mine[c] = static_cast<uint32_t>(run);   // < 2^32 rows in total
+    run += v;
+  }
+}
+
+__global__ void __launch_bounds__(kBlock)
+k_bin_scatter(const uint8_t* __restrict__ bin_of_row, uint64_t n_rows, uint32_t n_bins, const uint32_t* __restrict__ chunk_offsets,
+              uint32_t* __restrict__ index) {
+  __shared__ uint32_t cursor[kMaxBins];
+  for (uint32_t b = threadIdx.x; b < n_bins; b += kBlock) cursor[b] = chunk_offsets[static_cast<uint64_t>(b) * gridDim.x + blockIdx.x];
+  __syncthreads();
+  const uint64_t base = static_cast<uint64_t>(blockIdx.x) * kBinChunk;
+  for (uint32_t i = threadIdx.x; i < kBinChunk; i += kBlock) {
+    const uint64_t r = base + i;
+    if (r < n_rows) {
+      const uint32_t b = bin_of_row[r];
+      if (b < n_bins) index[atomicAdd(&cursor[b], 1u)] = static_cast<uint32_t>(r);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// K8  compound offsets of HeteroHomoZygous::updateVariantAnalysisType
+// (kga_analytic/kga_PfEMP/kga_analysis_PfEMP_heterozygous.cpp:61-105).  At a contig offset where the
+// population holds k >= 2 distinct variants (adjacent rows), a genome with n variant copies there counts
+//   n == 1 : heterozygous_reference_minor_alleles_ += 1
+//   n >= 2 : homozygous_minor_alleles_ += #distinct variants carried   (UniqueUnphasedFilter; the
+//            reference's quirk: every distinct alt counts, not only homozygous ones)
+//            heterozygous_minor_alleles_ += #variants carried exactly once (HeterozygousFilter)
+// Offsets with a single row need no kernel: they follow from the by-genome sweep (K3).
+// A lane owns 16 genomes (one dword per row) and keeps their counters in registers; a workgroup walks a
+// slice of the groups; results are added to acc[g][bin][3] = {het_ref_minor, hom_minor, het_minor} with
+// integer atomics.  Reads only the rows of compound offsets.
+// ---------------------------------------------------------------------------------------------
+struct OffsetGroup {
+  uint32_t first_row;
+  uint32_t n_rows;
+  uint32_t bin;        // output bin (contig index)
+  uint32_t pad;
+};
+
+__global__ void __launch_bounds__(kBlock)
+k_compound_offsets(const uint32_t* __restrict__ rows, uint64_t dwords_per_row, uint64_t n_genomes,
+                   const OffsetGroup* __restrict__ groups, uint64_t n_groups, uint64_t groups_per_slice,
+                   uint32_t n_bins, unsigned long long* __restrict__ acc) {
+  const uint64_t col = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x;   // dword column = 16 genomes
+  if (col * 16 >= n_genomes) return;
+  const uint64_t g_begin = static_cast<uint64_t>(blockIdx.y) * groups_per_slice;
+  const uint64_t g_end = g_begin + groups_per_slice < n_groups ? g_begin + groups_per_slice : n_groups;
+  uint32_t het_ref[16], hom_minor[16], het_minor[16];
+#pragma unroll
+  for (int j = 0; j < 16; ++j) het_ref[j] = hom_minor[j] = het_minor[j] = 0;
+  uint32_t current_bin = g_begin < g_end ? groups[g_begin].bin : 0;
+
+  auto flush = [&](uint32_t bin) {
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      const uint64_t g = col * 16 + j;
+      if (g < n_genomes) {
+        unsigned long long* a = acc + (g * n_bins + bin) * 3;
+        if (het_ref[j]) atomicAdd(a + 0, static_cast<unsigned long long>(het_ref[j]));
+        if (hom_minor[j]) atomicAdd(a + 1, static_cast<unsigned long long>(hom_minor[j]));
+        if (het_minor[j]) atomicAdd(a + 2, static_cast<unsigned long long>(het_minor[j]));
+      }
+      het_ref[j] = hom_minor[j] = het_minor[j] = 0;
+    }
+  };
+
+  for (uint64_t gi = g_begin; gi < g_end; ++gi) {
+    const OffsetGroup grp = groups[gi];
+    if (grp.bin != current_bin) {
+      flush(current_bin);
+      current_bin = grp.bin;
+    }
+    // Field-wise sums in 2-bit fields would overflow for k > 3, so split even/odd genomes into 4-bit fields.
+    uint32_t present_e = 0, present_o = 0, single_e = 0, single_o = 0, ge2 = 0;
+    for (uint32_t r = 0; r < grp.n_rows; ++r) {
+      const uint32_t w = rows[(static_cast<uint64_t>(grp.first_row) + r) * dwords_per_row + col];
+      const uint32_t lo = w & 0x55555555u, hi = (w >> 1) & 0x55555555u;
+      const uint32_t present = lo | hi, single = lo & ~hi;
+      present_e += present & 0x11111111u;
+      present_o += (present >> 2) & 0x11111111u;
+      single_e += single & 0x11111111u;
+      single_o += (single >> 2) & 0x11111111u;
+      ge2 |= hi;
+    }
+    if ((present_e | present_o) == 0) continue;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      // genome j of the dword sits in bits 2j..2j+1: even j -> nibble j/2 of *_e, odd j -> nibble j/2 of *_o
+      const uint32_t np = ((j & 1) ? present_o : present_e) >> (4 * (j >> 1)) & 0xFu;
+      const uint32_t ns = ((j & 1) ? single_o : single_e) >> (4 * (j >> 1)) & 0xFu;
+      const uint32_t two = (ge2 >> (2 * j)) & 1u;
+      const bool n_ge2 = two || np >= 2;
+      het_ref[j] += (!n_ge2 && np == 1) ? 1u : 0u;
+      hom_minor[j] += n_ge2 ? np : 0u;
+      het_minor[j] += n_ge2 ? ns : 0u;
+    }
+  }
+  flush(current_bin);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Flattening helpers.
+// ---------------------------------------------------------------------------------------------
+
+// Pack the reference's VariantDBGenomeData rows (one uint8 dosage vector per genome,
+// kgl_variant_db_variant.h:49-51) into dosage2 rows.  One thread per output byte (4 genomes).
+// src: [n_src_genomes][n_variants] staged in device memory; genome (g0 + j) of the shard.
+__global__ void __launch_bounds__(kBlock)
+k_pack_dosage_u8(const uint8_t* __restrict__ src, uint64_t n_src_genomes, uint64_t n_variants,
+                 uint64_t g0, uint8_t* __restrict__ rows, uint64_t pitch) {
+  // g0 is a multiple of 4 (checked on the host); quads of source genomes map to whole bytes.
+  const uint64_t n_quads = (n_src_genomes + 3) / 4;
+  const uint64_t total = n_quads * n_variants;
+  for (uint64_t i = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < total;
+       i += static_cast<uint64_t>(gridDim.x) * blockDim.x) {
+    const uint64_t v = i % n_variants;          // consecutive threads read consecutive variants
+    const uint64_t q = i / n_variants;
+    uint32_t byte = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const uint64_t g = q * 4 + j;
+      if (g < n_src_genomes) {
+        uint32_t d = src[g * n_variants + v];
+        d = d > 2u ? 3u : d;
+        byte |= d << (2 * j);
+      }
+    }
+    rows[v * pitch + g0 / 4 + q] = static_cast<uint8_t>(byte);
+  }
+}
+
+// Zero the bit pairs at and past n_genomes in rows [v0,v1) (after a host upload).
+__global__ void __launch_bounds__(kBlock)
+k_mask_row_tail(uint8_t* __restrict__ rows, uint64_t pitch, uint64_t n_genomes, uint64_t v0, uint64_t v1) {
+  const uint64_t used = (n_genomes + 3) / 4;
+  const uint32_t rem = static_cast<uint32_t>(n_genomes & 3u);
+  const uint64_t tail = pitch - used + (rem ? 1 : 0);   // bytes to touch per row
+  const uint64_t first = rem ? used - 1 : used;
+  const uint64_t total = (v1 - v0) * tail;
+  for (uint64_t i = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < total;
+       i += static_cast<uint64_t>(gridDim.x) * blockDim.x) {
+    const uint64_t v = v0 + i / tail;
+    const uint64_t k = first + i % tail;
+    uint8_t* p = rows + v * pitch + k;
+    if (rem && k == used - 1) *p &= static_cast<uint8_t>((1u << (2 * rem)) - 1u);
+    else *p = 0;
+  }
+}
+
+// Synthetic biallelic population straight into HBM.  One thread per 16-byte chunk.
+__global__ void __launch_bounds__(kBlock)
+k_synth_biallelic(kgx_v4u* __restrict__ rows, uint32_t chunks_per_row, uint64_t n_rows,
+                  uint64_t n_genomes, uint64_t seed, uint64_t genome_base, uint64_t variant_base,
+                  float* __restrict__ af_out) {
+  const uint64_t total = n_rows * chunks_per_row;
+  for (uint64_t i = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < total;
+       i += static_cast<uint64_t>(gridDim.x) * blockDim.x) {
+    const uint64_t r = i / chunks_per_row;
+    const uint32_t k = static_cast<uint32_t>(i % chunks_per_row);
+    const uint64_t v = variant_base + r;
+    const float af = kgx_synth_af(seed, v);
+    if (k == 0 && af_out) af_out[r] = af;
+    const double p = static_cast<double>(af);
+    kgx_v4u x;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      uint32_t word = 0;
+      for (int q = 0; q < 4; ++q) {
+        const uint64_t g_local = static_cast<uint64_t>(k) * 64 + w * 16 + q * 4;   // first genome of the quad
+        uint32_t byte = 0;
+        if (g_local + 3 < n_genomes && ((genome_base & 3u) == 0)) {
+          byte = kgx_synth_quad(seed, v, (genome_base + g_local) >> 2, p);
+        } else {
+          for (int j = 0; j < 4; ++j)
+            if (g_local + j < n_genomes)
+              byte |= kgx_synth_dosage(seed, v, genome_base + g_local + j, p) << (2 * j);
+        }
+        word |= byte << (8 * q);
+      }
+      x[w] = word;
+    }
+    rows[i] = x;
+  }
+}
+
+}  // namespace kgx
+
+#endif  // KGX_KERNELS_DOSAGE_H

@@ -4,6 +4,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <sstream>
+#include <thread>
 
 #include "kgo_analysis.h"
 #include "kgo_inbreed.h"
@@ -145,6 +146,108 @@ int kgo_population_add_records(kgo_pop* p, int mode, const char* contig, uint64_
       return -1;
     }
     alt_cursor += A;
+  }
+  return 0;
+}
+
+// kgo_population_add_records for large synthetic blocks, with the sequences given as codes instead of C strings
+// (ten million Python strings are the slow part of a 5M-locus test, not the oracle): ref_code[r] in 0..3 = "ACGT";
+// alt_code (flat, per alt) 0..3 = that base (a SNP), 0x80 | k = an insertion: the reference base followed by k + 1
+// bases 'G' (k even) or 'A' (k odd).  Everything else as kgo_population_add_records -- the same Variant objects in the
+// same per-genome order -- except that for mode 0 (the phased 1000-Genomes expansion) the genomes are filled by a pool
+// of threads, each owning a block of genomes: the store a parser hands over is the INPUT of the path, and filling
+// 10^8 map nodes from one thread would dominate every large test and the bench's CPU leg without being timed by either.
+int kgo_population_add_records_coded(kgo_pop* p, int mode, const char* contig, uint64_t n_records, const uint64_t* offsets,
+                                     const uint8_t* ref_code, const uint8_t* n_alts, const uint8_t* alt_code,
+                                     const uint8_t* pass, const float* af_flat, uint64_t n_genomes,
+                                     const char* const* genome_ids, const uint8_t* gt) {
+  if (!p || !contig || !offsets || !ref_code || !n_alts || !alt_code) return -1;
+  static const char bases[] = "ACGT";
+  auto sequences = [&](uint64_t r, uint64_t alt_cursor, std::string& ref, std::vector<std::string>& alts) {
+    ref.assign(1, bases[ref_code[r] & 3u]);
+    alts.clear();
+    for (uint32_t a = 0; a < n_alts[r]; ++a) {
+      const uint8_t code = alt_code[alt_cursor + a];
+      if (code & 0x80u) alts.push_back(ref + std::string((code & 0x7Fu) + 1u, (code & 1u) ? 'A' : 'G'));
+      else alts.emplace_back(1, bases[code & 3u]);
+    }
+  };
+  if (mode != 0 || n_genomes < 8 || !gt) {
+    constexpr uint64_t kChunk = 1u << 16;
+    uint64_t alt_cursor = 0;
+    for (uint64_t r0 = 0; r0 < n_records; r0 += kChunk) {
+      const uint64_t r1 = std::min(n_records, r0 + kChunk);
+      std::vector<std::string> refs, alts, record_alts;
+      uint64_t cursor = alt_cursor;
+      for (uint64_t r = r0; r < r1; ++r) {
+        refs.emplace_back();
+        sequences(r, cursor, refs.back(), record_alts);
+        for (auto& x : record_alts) alts.push_back(std::move(x));
+        cursor += n_alts[r];
+      }
+      std::vector<const char*> ref_ptrs, alt_ptrs;
+      for (const auto& x : refs) ref_ptrs.push_back(x.c_str());
+      for (const auto& x : alts) alt_ptrs.push_back(x.c_str());
+      const int rc = kgo_population_add_records(p, mode, contig, r1 - r0, offsets + r0, ref_ptrs.data(), n_alts + r0, alt_ptrs.data(),
+                                                pass ? pass + r0 : nullptr, af_flat ? af_flat + alt_cursor * SUPER_POP_COUNT : nullptr,
+                                                n_genomes, genome_ids, gt ? gt + r0 * n_genomes * 2 : nullptr);
+      if (rc != 0) return rc;
+      alt_cursor = cursor;
+    }
+    return 0;
+  }
+  // mode 0, threaded.  Genome1000VCFImpl::ParseRecord (kgl_variant_factory_1000_impl.cpp:63-145): per record one shared
+  // Variant per (alt, phase) that some genome carries; a genome receives its phase-A variant before its phase-B one.
+  const std::string contig_id(contig);
+  std::vector<uint64_t> first_alt(n_records + 1, 0);
+  for (uint64_t r = 0; r < n_records; ++r) first_alt[r + 1] = first_alt[r] + n_alts[r];
+  std::vector<VariantPtr> variants(first_alt[n_records] * 2);           // [(first_alt[r] + a) * 2 + phase]
+  const uint64_t first_record_index = p->next_record;
+  p->next_record += n_records;
+  std::vector<std::shared_ptr<GenomeDB>> genomes(n_genomes);
+  for (uint64_t g = 0; g < n_genomes; ++g) genomes[g] = p->pop->getCreateGenome(genome_ids[g]);
+  const size_t n_threads = std::max<size_t>(1, std::min<size_t>(poolThreads(n_genomes), 64));
+  {
+    // the Variant objects of every record, records split over the threads
+    std::vector<std::thread> pool;
+    for (size_t t = 0; t < n_threads; ++t)
+      pool.emplace_back([&, t]() {
+        std::string ref;
+        std::vector<std::string> alts;
+        for (uint64_t r = n_records * t / n_threads; r < n_records * (t + 1) / n_threads; ++r) {
+          const uint32_t A = n_alts[r];
+          auto ev = std::make_shared<RecordEvidence>();
+          ev->record_index = first_record_index + r;
+          ev->pass = pass ? pass[r] != 0 : true;
+          ev->alt_count = A;
+          if (af_flat) {
+            ev->af.resize(static_cast<size_t>(SUPER_POP_COUNT) * A);
+            for (uint32_t a = 0; a < A; ++a)
+              for (int sp = 0; sp < SUPER_POP_COUNT; ++sp)
+                ev->af[static_cast<size_t>(sp) * A + a] = af_flat[(first_alt[r] + a) * SUPER_POP_COUNT + sp];
+          }
+          sequences(r, first_alt[r], ref, alts);
+          for (uint32_t a = 0; a < A; ++a)
+            for (int phase = 0; phase < 2; ++phase)
+              variants[(first_alt[r] + a) * 2 + phase] = std::make_shared<const Variant>(
+                  contig_id, offsets[r], phase == 0 ? VariantPhase::DIPLOID_PHASE_A : VariantPhase::DIPLOID_PHASE_B, ref, alts[a], ev, a);
+        }
+      });
+    for (auto& th : pool) th.join();
+  }
+  {
+    std::vector<std::thread> pool;
+    for (size_t t = 0; t < n_threads; ++t)
+      pool.emplace_back([&, t]() {
+        const uint64_t g_begin = n_genomes * t / n_threads, g_end = n_genomes * (t + 1) / n_threads;
+        for (uint64_t r = 0; r < n_records; ++r)
+          for (uint64_t g = g_begin; g < g_end; ++g)
+            for (int phase = 0; phase < 2; ++phase) {
+              const uint32_t idx = gt[(r * n_genomes + g) * 2 + phase];
+              if (idx != 0 && idx <= n_alts[r]) genomes[g]->addVariant(variants[(first_alt[r] + idx - 1) * 2 + phase]);
+            }
+      });
+    for (auto& th : pool) th.join();
   }
   return 0;
 }
@@ -538,6 +641,30 @@ int kgo_inbreed_window(kgo_pop* reference, kgo_pop* diploid, const int32_t* supe
     ++g;
   }
   return 0;
+}
+
+// Dense tier of one window (oracle/kgo_inbreed_dense.cpp): every genome of allele_pairs [n_records][n_genomes][2]
+// (raw GT allele indices of the record at record_offsets[r]) against the locus list of `super_pop` from [lower, upper].
+// counts_out [G][5] as kgo_inbreed_window; freqs_out [G][6] = the four class-frequency sums, Simple, RitlandLocus.
+int kgo_inbreed_dense(kgo_pop* reference_all, kgo_pop* reference_snp_pass, int super_pop, uint64_t lower, uint64_t upper,
+                      uint64_t spacing, double min_af, double max_af, const uint64_t* record_offsets, uint64_t n_records,
+                      const uint8_t* allele_pairs, uint64_t n_genomes, int phased, uint64_t* counts_out, double* freqs_out,
+                      double* seconds) {
+  if (!reference_all || !reference_snp_pass || !record_offsets || !allele_pairs || !counts_out || !freqs_out) return -1;
+  auto single_contig = [](kgo_pop* p) -> const ContigDB* {
+    if (p->pop->getMap().size() != 1) return nullptr;
+    const auto& genome = p->pop->getMap().begin()->second;
+    return genome->getMap().size() == 1 ? genome->getMap().begin()->second.get() : nullptr;
+  };
+  const ContigDB* all = single_contig(reference_all);
+  const ContigDB* snp_pass = single_contig(reference_snp_pass);
+  if (!all || !snp_pass) return -1;
+  LociiVectorArguments args;
+  args.lower_offset = lower; args.upper_offset = upper; args.spacing = spacing;
+  args.allele_frequency_min = std::clamp(min_af, 0.0, 1.0);
+  args.allele_frequency_max = std::clamp(max_af, 0.0, 1.0);
+  return inbreedDense(*all, *snp_pass, super_pop, args, record_offsets, n_records, allele_pairs, n_genomes, phased != 0, counts_out,
+                      freqs_out, seconds);
 }
 
 // The whole window loop (populationInbreeding, _diploid.cpp:18-79).

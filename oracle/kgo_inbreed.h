@@ -189,6 +189,12 @@ std::vector<std::pair<std::string, ResultsMap>> populationInbreeding(const Popul
                                                                      const std::map<std::string, int>& super_pop_of_genome,
                                                                      const InbreedingParameters& params);
 
+// Dense tier (kgo_inbreed_dense.cpp): generateFrequencies + processSimple / processRitlandLocus for genomes given as the
+// raw GT allele pairs of a population with one VCF record per reference offset.
+int inbreedDense(const ContigDB& reference_all, const ContigDB& reference_snp_pass, int super_pop, const LociiVectorArguments& args,
+                 const uint64_t* record_offsets, uint64_t n_records, const uint8_t* allele_pairs, uint64_t n_genomes, bool phased,
+                 uint64_t* counts_out, double* freqs_out, double* seconds);
+
 // InbreedSynthetic::generateSyntheticPopulation (_syngen.cpp:20-196) with a seeded mt19937_64.
 std::shared_ptr<PopulationDB> generateSyntheticPopulation(double lower_inbreeding, double upper_inbreeding,
                                                           double step_inbreeding, int super_pop,

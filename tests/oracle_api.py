@@ -40,6 +40,7 @@ def lib() -> C.CDLL:
         "kgo_population_destroy": (None, [vp]),
         "kgo_population_add_genomes": (C.c_int, [vp, u64, vp, C.c_int]),
         "kgo_population_add_records": (C.c_int, [vp, C.c_int, C.c_char_p, u64, vp, vp, vp, vp, vp, vp, u64, vp, vp]),
+        "kgo_population_add_records_coded": (C.c_int, [vp, C.c_int, C.c_char_p, u64, vp, vp, vp, vp, vp, vp, u64, vp, vp]),
         "kgo_population_add_vcf_1000": (C.c_long, [vp, C.c_char_p, u64]),
         "kgo_fast_count_by_variant": (C.c_int, [vp, u64, u64, u64, u64, vp, C.c_int, C.c_int, vp]),
         "kgo_population_add_vcf_pf": (C.c_long, [vp, C.c_char_p, u64]),
@@ -74,6 +75,7 @@ def lib() -> C.CDLL:
         "kgo_class_frequencies": (C.c_int, [vp, C.c_uint32, dbl, C.c_int, vp]),
         "kgo_sample_locii": (i64, [vp, C.c_int, C.c_int, u64, u64, u64, u64, dbl, dbl, vp, u64]),
         "kgo_inbreed_window": (C.c_int, [vp, vp, vp, C.c_char_p, u64, u64, u64, u64, dbl, dbl, u64, vp, vp, vp, vp]),
+        "kgo_inbreed_dense": (C.c_int, [vp, vp, C.c_int, u64, u64, u64, dbl, dbl, vp, u64, vp, u64, C.c_int, vp, vp, vp]),
         "kgo_population_inbreeding": (vp, [vp, vp, vp, C.c_char_p, u64, u64, u64, u64, dbl, dbl, u64]),
         "kgo_columns_destroy": (None, [vp]),
         "kgo_columns_count": (u64, [vp]),
@@ -160,6 +162,21 @@ class Population:
         rc = lib().kgo_population_add_records(self._h, mode, rec.contig.encode(), rec.n_records, _p(rec.offsets),
                                               C.cast(refs, C.c_void_p), _p(rec.n_alts), C.cast(alts, C.c_void_p),
                                               _p(rec.passed), _p(af), len(self.genome_ids), C.cast(ids, C.c_void_p), _p(gt))
+        assert rc == 0
+
+    def add_records_coded(self, contig, offsets, ref_code, n_alts, alt_code, af_flat, gt, mode, passed=None):
+        """add_records for large synthetic blocks: sequences as codes (kgo_population_add_records_coded), numpy in."""
+        ids = _strs(self.genome_ids)
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        ref_code = np.ascontiguousarray(ref_code, dtype=np.uint8)
+        n_alts = np.ascontiguousarray(n_alts, dtype=np.uint8)
+        alt_code = np.ascontiguousarray(alt_code, dtype=np.uint8)
+        af_flat = None if af_flat is None else np.ascontiguousarray(af_flat, dtype=np.float32)
+        if gt is not None:
+            gt = np.ascontiguousarray(gt, dtype=np.uint8)
+            assert gt.shape == (len(offsets), len(self.genome_ids), 2)
+        rc = lib().kgo_population_add_records_coded(self._h, mode, contig.encode(), len(offsets), _p(offsets), _p(ref_code), _p(n_alts),
+                                                    _p(alt_code), _p(passed), _p(af_flat), len(self.genome_ids), C.cast(ids, C.c_void_p), _p(gt))
         assert rc == 0
 
     def add_vcf_1000(self, text: str) -> int:
@@ -378,6 +395,24 @@ def inbreed_window(reference: Population, diploid: Population, super_pop_of_geno
                                   count, min_af, max_af, seed, _p(counts), _p(freqs), _p(present), C.byref(sec))
     assert rc == 0
     return counts, freqs, present.astype(bool), sec.value
+
+
+def inbreed_dense(reference_all: Population, reference_snp_pass: Population, super_pop, lower, upper, spacing, min_af, max_af,
+                  record_offsets, allele_pairs, phased=True):
+    """The oracle's dense tier (oracle/kgo_inbreed_dense.cpp): generateFrequencies + Simple + RitlandLocus for genomes given
+    as raw GT allele pairs [n_records][G][2] of a one-record-per-offset population.
+    Returns (counts [G][5], freqs [G][6] = four class-frequency sums, Simple, Ritland; seconds)."""
+    offsets = np.ascontiguousarray(record_offsets, dtype=np.uint64)
+    pairs = np.ascontiguousarray(allele_pairs, dtype=np.uint8)
+    assert pairs.ndim == 3 and pairs.shape[0] == len(offsets) and pairs.shape[2] == 2
+    G = pairs.shape[1]
+    counts = np.zeros((G, 5), dtype=np.uint64)
+    freqs = np.zeros((G, 6), dtype=np.float64)
+    sec = C.c_double(0)
+    rc = lib().kgo_inbreed_dense(reference_all.handle, reference_snp_pass.handle, super_pop, lower, upper, spacing, min_af, max_af,
+                                 _p(offsets), len(offsets), _p(pairs), G, int(bool(phased)), _p(counts), _p(freqs), C.byref(sec))
+    assert rc == 0
+    return counts, freqs, sec.value
 
 
 def population_inbreeding(reference: Population, diploid: Population, super_pop_of_genome, algorithm, lower, upper,

@@ -129,3 +129,21 @@ def synth_multiallelic_block(G, L, seed=1111, contig="chr1"):
         afs.append(np.tile(np.array([af[a] for a in range(n_alt.value)], dtype=np.float32).reshape(-1, 1), (1, 6)))
     rec = oa.Records(contig, offsets, refs, alts, af=afs)
     return rec, alleles, gt8, table
+
+
+def synth_multiallelic_coded(G, l0, l1, genome_base=0, seed=1111):
+    """Loci [l0, l1) x genomes [genome_base, genome_base + G) of the product's synthetic multi-allelic population in the
+    coded form of oracle_api.Population.add_records_coded (no Python strings: usable at millions of loci).
+    Returns dict(offsets, ref_code, n_alts, alt_code, af_flat, alleles [n][G][2], gt8 [n][G], table [n][3])."""
+    gt8, table, alleles = capi.synth_multiallelic_host(seed, genome_base, G, l0, l1)
+    n_alt, af, indel = capi.synth_loci_host(seed, l0, l1)
+    loci = np.arange(l0, l1, dtype=np.uint64)
+    ref_code = (loci % 4).astype(np.uint8)
+    cand = np.array([[1, 2, 3], [0, 2, 3], [0, 1, 3], [0, 1, 2]], dtype=np.uint8)     # the bases that are not the reference's
+    a_idx = np.arange(3, dtype=np.uint8)[None, :]
+    codes = np.where(indel != 0, np.uint8(0x80) | a_idx, cand[ref_code])              # [n][3]
+    keep = a_idx < n_alt[:, None]
+    alt_code = codes[keep]
+    af_flat = np.repeat(af[keep].astype(np.float32)[:, None], 6, axis=1)
+    return dict(offsets=10 * loci + 1, ref_code=ref_code, n_alts=n_alt, alt_code=alt_code, af_flat=af_flat,
+                alleles=alleles, gt8=gt8, table=table)

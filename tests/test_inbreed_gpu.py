@@ -57,14 +57,17 @@ def test_class_frequency_table_is_bit_exact(kgx):
                                             ("HallME", "passes"), ("Loglikelihood", "passes"), ("Loglikelihood", "golden"),
                                             ("Loglikelihood", "compacting"),
                                             ("Simple", "generic"), ("RitlandLocus", "generic"), ("HallME", "generic"), ("Loglikelihood", "generic"),
-                                            ("Simple", "swar4"), ("RitlandLocus", "no-table")])
+                                            ("Simple", "swar4"), ("RitlandLocus", "no-table"),
+                                            ("Simple", "sequential"), ("RitlandLocus", "sequential"), ("Simple", "sequential-swar4")])
 def test_inbreed_window_vs_oracle(kgx, mode, algorithm, path, monkeypatch):
     # every kernel flavour against the same oracle window: the window-sized fused iteration (default), the multi-kernel
     # table passes, plain golden section, the generic per-cell kernels, the 4-genomes-per-lane SWAR sweep
     env = {"passes": {"KGX_K7_NO_WAVE": "1"},
            "compacting": {"KGX_K7_NO_WAVE": "1", "KGX_K7_COMPACT_MIN_GENOMES": "4", "KGX_K7_COMPACT_MIN_CELLS": "1"}, "golden": {"KGX_K7_NO_WAVE": "1", "KGX_K7_GOLDEN": "1"},
            "generic": {"KGX_K5_GENERIC": "1", "KGX_K7_NO_WAVE": "1"}, "swar4": {"KGX_K5_NO_SWAR16": "1"},
-           "no-table": {"KGX_K5_NO_EVAL_LUT": "1"}}.get(path, {})
+           "no-table": {"KGX_K5_NO_EVAL_LUT": "1"},
+           # the class-frequency sums of the defaults in the reference's sequential order (the path every call >= 65536 loci takes)
+           "sequential": {"KGX_K5_SEQUENTIAL_MIN": "1"}, "sequential-swar4": {"KGX_K5_SEQUENTIAL_MIN": "1", "KGX_K5_NO_SWAR16": "1"}}.get(path, {})
     for key, value in env.items():
         monkeypatch.setenv(key, value)
     G, L = 101, 1200
@@ -311,7 +314,7 @@ def test_kernel_flavours_agree_on_random_shapes(kgx, monkeypatch):
     table passes and the fused wave iteration must reproduce them."""
     rng = np.random.default_rng(2024)
     flavours = {"default": {}, "generic": {"KGX_K5_GENERIC": "1", "KGX_K7_NO_WAVE": "1"}, "passes": {"KGX_K7_NO_WAVE": "1"},
-                "swar4": {"KGX_K5_NO_SWAR16": "1"}}
+                "swar4": {"KGX_K5_NO_SWAR16": "1"}, "sequential": {"KGX_K5_SEQUENTIAL_MIN": "1"}}
     knobs = sorted({k for env in flavours.values() for k in env})
     for trial in range(150):
         G = int(rng.choice([1, 3, 4, 5, 15, 16, 17, 63, 64, 65, 100, 257, 1000]))
@@ -428,4 +431,102 @@ def test_loglikelihood_compaction_is_bit_identical(kgx, monkeypatch):
     assert np.array_equal(a["inbred_allele_sum"], b["inbred_allele_sum"])
     assert np.array_equal(a["total_allele_count"], b["total_allele_count"])
     assert np.abs(a["inbred_allele_sum"] - F[16:G - 7]).max() < 0.25 and np.median(np.abs(a["inbred_allele_sum"] - F[16:G - 7])) < 0.03
+    m.close()
+
+
+def _reference_population(d):
+    ref = oa.Population("gnomad")
+    ref.add_genomes(["Reference"])
+    ref.add_records_coded("chr1", d["offsets"], d["ref_code"], d["n_alts"], d["alt_code"], d["af_flat"], None, oa.Population.REFERENCE)
+    return ref
+
+
+def test_c5_full_size_fp64_sums_vs_oracle(kgx):
+    """BASELINE config 4 at full size against the oracle, not only against its own identities: the device sweeps 10k
+    genomes x 5M multi-allelic loci; a 64-genome slice of the same population (regenerated by the host twin as VCF-like
+    records + GT pairs) goes through the oracle.  Class counts bit-exact; the four class-frequency sums, Simple and
+    RitlandLocus within 1e-12 * max(1, |x|) of the oracle's sequential sums over all 5M loci.
+    (a) all 5M loci x 64 genomes through the oracle's dense tier (bit-identical to generateFrequencies where both
+    apply: tests/test_oracle_pins.py); (b) the first 1M loci x 16 genomes through generateFrequencies itself."""
+    G, L = 10_000, 5_000_000
+    g0, n_slice = 4032, 64                                      # a slice off the 128-genome unit boundary, mixed F
+    m = kgx.GenotypeMatrix(G, L)
+    table = m.synth_multiallelic(1111, 0, 0)
+    simple = m.inbreed(table, "Simple", phased=True)
+    ritland = m.inbreed(table, "RitlandLocus", phased=True)
+    for name in simple.dtype.names:
+        if name != "inbred_allele_sum":
+            assert np.array_equal(simple[name], ritland[name]), name            # one frequency sweep, whatever the estimator
+
+    def close(got, want, what):
+        err = np.abs(got - want) / np.maximum(1.0, np.abs(want))
+        assert err.max() <= 1e-12, (what, float(err.max()))
+
+    count_fields = ["major_hetero_count", "minor_hetero_count", "minor_homo_count", "major_homo_count", "total_allele_count"]
+    freq_fields = ["major_hetero_freq", "minor_hetero_freq", "minor_homo_freq", "major_homo_freq"]
+
+    # (a) dense tier, every locus
+    d = sv.synth_multiallelic_coded(n_slice, 0, L, genome_base=g0)
+    assert np.array_equal(m.read_rows(77_000, 77_064)[:, g0:g0 + n_slice], d["gt8"][77_000:77_064])
+    ref = _reference_population(d)
+    ref_snp = ref.filter_snp_pass()
+    upper = int(d["offsets"][-1]) + 1
+    counts, freqs, _ = oa.inbreed_dense(ref, ref_snp, oa.ALL, 0, upper, 1, 0.0, 1.0, d["offsets"], d["alleles"], phased=True)
+    for k, name in enumerate(count_fields):
+        assert np.array_equal(simple[name][g0:g0 + n_slice], counts[:, k]), name
+    for k, name in enumerate(freq_fields):
+        close(simple[name][g0:g0 + n_slice], freqs[:, k], name)
+    close(simple["inbred_allele_sum"][g0:g0 + n_slice], freqs[:, 4], "Simple")
+    close(ritland["inbred_allele_sum"][g0:g0 + n_slice], freqs[:, 5], "RitlandLocus")
+    assert counts[:, 4].min() > 4_000_000
+
+    # (b) generateFrequencies itself (the pointer-chasing store) on the first 1M loci x 16 genomes of the slice
+    L1, n1 = 1_000_000, 16
+    index = np.arange(L1, dtype=np.uint32)
+    sub_table = np.ascontiguousarray(table[:L1])
+    d1 = {k: (v[:L1] if k in ("offsets", "ref_code", "n_alts", "alleles", "gt8", "table") else v) for k, v in d.items()}
+    n_flat = int(d["n_alts"][:L1].sum())
+    d1["alt_code"], d1["af_flat"] = d["alt_code"][:n_flat], d["af_flat"][:n_flat]
+    ref1 = _reference_population(d1).filter_snp_pass()
+    dip = oa.Population("diploid")
+    dip.add_genomes(sv.genome_ids(n1))
+    dip.add_records_coded("chr1", d1["offsets"], d1["ref_code"], d1["n_alts"], d1["alt_code"], d1["af_flat"],
+                          np.ascontiguousarray(d1["alleles"][:, :n1]), oa.Population.PHASED)
+    upper1 = int(d1["offsets"][-1]) + 1
+    for algorithm in ("Simple", "RitlandLocus"):
+        c1, f1, present, _ = oa.inbreed_window(ref1, dip, np.full(n1, oa.ALL, dtype=np.int32), algorithm, 0, upper1, 1, 10**9, 0.0, 1.0)
+        assert present.all()
+        got = m.inbreed(sub_table, algorithm, phased=True, locus_index=index, g0=g0, g1=g0 + n1)[dip.genome_order()]
+        for k, name in enumerate(count_fields):
+            assert np.array_equal(got[name], c1[:, k]), (algorithm, name)
+        for k, name in enumerate(freq_fields):
+            close(got[name], f1[:, k], (algorithm, name))
+        close(got["inbred_allele_sum"], f1[:, 4], algorithm)
+    m.close()
+
+
+def test_iterative_estimators_at_scale_vs_oracle(kgx):
+    """HallME and Loglikelihood through the multi-kernel table passes (the path C5 takes) at 1,000 genomes x 100,000 loci
+    of the C5 population against the oracle run from the same fixed starts: class counts bit-exact, HallME within 1e-9,
+    Loglikelihood within 1e-5 (two maximisers of one objective, each converged to <= 1e-6)."""
+    G, L = 1000, 100_000
+    m = kgx.GenotypeMatrix(G, L)
+    table = m.synth_multiallelic(1111, 0, 0)
+    d = sv.synth_multiallelic_coded(G, 0, L)
+    assert np.array_equal(m.read_rows(5000, 5016), d["gt8"][5000:5016])
+    ref = _reference_population(d).filter_snp_pass()
+    dip = oa.Population("diploid")
+    dip.add_genomes(sv.genome_ids(G))
+    dip.add_records_coded("chr1", d["offsets"], d["ref_code"], d["n_alts"], d["alt_code"], d["af_flat"], d["alleles"], oa.Population.PHASED)
+    upper = int(d["offsets"][-1]) + 1
+    order = dip.genome_order()
+    for algorithm, tol in (("HallME", 1e-9), ("Loglikelihood", 1e-5)):
+        counts, freqs, present, _ = oa.inbreed_window(ref, dip, np.full(G, oa.ALL, dtype=np.int32), algorithm, 0, upper, 1, 10**9, 0.0, 1.0,
+                                                      seed=oa.FIXED_STARTS)
+        assert present.all()
+        got = m.inbreed(table, algorithm, phased=True)[order]
+        assert np.array_equal(got["total_allele_count"], counts[:, 4])
+        assert np.array_equal(got["minor_homo_count"], counts[:, 2]) and np.array_equal(got["major_homo_count"], counts[:, 3])
+        err = np.abs(got["inbred_allele_sum"] - freqs[:, 4])
+        assert err.max() <= tol, (algorithm, float(err.max()), int(err.argmax()))
     m.close()

@@ -1,0 +1,181 @@
+"""The sharded paths of the C ABI on the one GPU of the test box.  kgx_init takes a list of device slots; listing the
+device twice (or three times) makes every handle split its genomes into that many shards with separate memory and
+streams, swept by separate host threads, and the per-variant counts summed by the "peer" exchange.  What cannot run
+here is RCCL across several devices; its call path (dlopen, ncclCommInitAll, grouped ncclAllReduce(sum, uint32) on the
+library's streams) is exercised over ONE rank with KGX_EXCHANGE=rccl.  Everything is compared with the unsharded
+run of the same population, which the other test files pin to the oracle."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture
+def rebind(kgx, monkeypatch):
+    """Bind other device lists inside a test; the session's one-device binding is restored afterwards."""
+    def bind(devices, exchange=None):
+        if exchange is None:
+            monkeypatch.delenv("KGX_EXCHANGE", raising=False)
+        else:
+            monkeypatch.setenv("KGX_EXCHANGE", exchange)
+        kgx.init(devices)
+    yield bind
+    monkeypatch.delenv("KGX_EXCHANGE", raising=False)
+    kgx.init(0)
+    assert kgx.bound_devices() == 1 and kgx.exchange_kind() == "none"
+
+
+def dosage_results(kgx, G, V, codes, bins, n_bins, groups):
+    pop = kgx.Population(G, V)
+    pop.load_dosage2(kgx.pack_dosage2(codes))
+    out = {
+        "shards": pop.shards,
+        "rows": pop.read_dosage2(),
+        "k2": pop.allele_count_by_locus(),
+        "k4": pop.population_summary(),
+        "k3": pop.count_by_genome(),
+        "k3_binned": pop.count_by_genome_binned(bins, n_bins),
+        "k8": pop.compound_offsets(*groups, 3),
+    }
+    pop.close()
+    return out
+
+
+@pytest.mark.parametrize("slots", [2, 3])
+@pytest.mark.parametrize("G", [1, 70, 1000, 4099])
+def test_sharded_dosage_sweeps_equal_the_unsharded_ones(kgx, rebind, slots, G):
+    rng = np.random.default_rng(G + slots)
+    V = 1500
+    codes = rng.choice(4, size=(V, G), p=[0.6, 0.25, 0.13, 0.02]).astype(np.uint8)
+    bins = rng.integers(0, 11, V).astype(np.uint8)
+    bins[rng.random(V) < 0.1] = 0xFF
+    first = np.arange(0, V - 3, 7, dtype=np.uint32)
+    groups = (first, np.full(len(first), 3, dtype=np.uint32), (first % 3).astype(np.uint32))
+    want = dosage_results(kgx, G, V, codes, bins, 11, groups)
+    assert len(want["shards"]) == 1
+    rebind([0] * slots)
+    assert kgx.bound_devices() == slots and kgx.exchange_kind() == "peer"
+    got = dosage_results(kgx, G, V, codes, bins, 11, groups)
+    shards = got["shards"]
+    assert len(shards) == slots and sum(s["n_genomes"] for s in shards) == G
+    assert all(s["genome_base"] % 64 == 0 for s in shards)
+    assert [s["genome_base"] for s in shards] == list(np.cumsum([0] + [s["n_genomes"] for s in shards[:-1]]))
+    for key in ("rows", "k2", "k4", "k3", "k3_binned", "k8"):
+        assert np.array_equal(got[key], want[key]), key
+
+
+def test_sharded_loaders_and_synthetic_population(kgx, rebind):
+    G, V = 3000, 4000
+    one = kgx.Population(G, V)
+    one.synth_biallelic(1111, 500, 10)
+    want_rows, want_af, want_k2 = one.read_dosage2(), one.get_af(), one.allele_count_by_locus()
+    dosage = np.ascontiguousarray(kgx.unpack_dosage2(want_rows, G).T)                  # the reference's [G][V] uint8 rows
+    one.close()
+    rebind([0, 0, 0])
+    many = kgx.Population(G, V)
+    many.synth_biallelic(1111, 500, 10)                          # every shard draws its own genomes of the same population
+    assert np.array_equal(many.read_dosage2(), want_rows) and np.array_equal(many.get_af(), want_af)
+    assert np.array_equal(many.allele_count_by_locus(), want_k2)
+    many.close()
+    loaded = kgx.Population(G, V)
+    loaded.load_dosage_u8(dosage[:1028], 0)                      # genome-major uploads that straddle shard boundaries
+    loaded.load_dosage_u8(dosage[1028:], 1028)
+    assert np.array_equal(loaded.read_dosage2(), want_rows)
+    assert np.array_equal(loaded.allele_count_by_locus(), want_k2)
+    loaded.close()
+
+
+def test_counts_left_on_the_device_are_exchanged_too(kgx, rebind):
+    """kgx_allele_count_by_locus_dev / kgx_allele_frequency_dev (what bench.py drives) on a sharded population: the
+    caller's buffer on the first slot's device receives the summed counts on the caller's stream."""
+    import torch
+
+    G, V = 5000, 20_000
+    one = kgx.Population(G, V)
+    one.synth_biallelic(1111, 0, 0)
+    want = one.allele_count_by_locus()
+    one.close()
+    rebind([0, 0])
+    pop = kgx.Population(G, V)
+    pop.synth_biallelic(1111, 0, 0)
+    dev = torch.device("cuda", 0)
+    counts = torch.zeros((V, 4), dtype=torch.int32, device=dev)
+    af = torch.zeros(V, dtype=torch.float64, device=dev)
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    for _ in range(3):
+        pop.allele_count_by_locus_dev(counts.data_ptr(), stream)
+        kgx.allele_frequency_dev(counts.data_ptr(), V, G, af.data_ptr(), stream)
+    torch.cuda.synchronize(dev)
+    got = counts.cpu().numpy().view(np.uint32)
+    assert np.array_equal(got, want)
+    assert np.array_equal(af.cpu().numpy(), (want[:, 1].astype(np.float64) + 2.0 * want[:, 2]) / (2.0 * G))
+    ms = pop.allele_count_timed(counts.data_ptr(), stream, 1, 3)
+    assert ms.shape == (3,) and np.all(ms > 0)
+    pop.close()
+
+
+def test_rccl_all_reduce_call_path_over_one_rank(kgx, rebind):
+    """KGX_EXCHANGE=rccl on one device: librccl is loaded, a communicator created (ncclCommInitAll) and every count sweep
+    goes through ncclAllReduce(sum, uint32) on the library's stream -- over a single rank, so the sums are the shard's own."""
+    G, V = 2500, 30_000
+    plain = kgx.Population(G, V)
+    plain.synth_biallelic(1111, 0, 0)
+    want = plain.allele_count_by_locus()
+    plain.close()
+    rebind([0], exchange="rccl")
+    assert kgx.exchange_kind() == "rccl" and kgx.bound_devices() == 1
+    pop = kgx.Population(G, V)
+    pop.synth_biallelic(1111, 0, 0)
+    for _ in range(3):
+        assert np.array_equal(pop.allele_count_by_locus(), want)
+    pop.close()
+
+
+@pytest.mark.parametrize("algorithm", ["Simple", "RitlandLocus", "HallME", "Loglikelihood"])
+def test_sharded_inbreeding_equals_the_unsharded_one(kgx, rebind, algorithm):
+    G, L = 700, 3000
+    one = kgx.GenotypeMatrix(G, L)
+    table = one.synth_multiallelic(1111, 0, 0)
+    want_rows = one.read_rows()
+    index = np.arange(0, L, 2, dtype=np.uint32)
+    sub = np.ascontiguousarray(table[index])
+    want_all = one.inbreed(table, algorithm, phased=True)
+    want_part = one.inbreed(sub, algorithm, phased=True, locus_index=index, g0=100, g1=650)
+    one.close()
+    rebind([0, 0, 0])
+    many = kgx.GenotypeMatrix(G, L)
+    shards = many.shards
+    assert len(shards) == 3 and sum(s["n_genomes"] for s in shards) == G and all(s["genome_base"] % 128 == 0 for s in shards)
+    table2 = many.synth_multiallelic(1111, 0, 0)
+    assert np.array_equal(many.read_rows(), want_rows)
+    assert np.array_equal(np.nan_to_num(table2), np.nan_to_num(table))
+    got_all = many.inbreed(table, algorithm, phased=True)
+    got_part = many.inbreed(sub, algorithm, phased=True, locus_index=index, g0=100, g1=650)      # a range that straddles shards
+    for got, want in ((got_all, want_all), (got_part, want_part)):
+        for name in want.dtype.names:
+            if name.endswith("_count"):
+                assert np.array_equal(got[name], want[name]), name
+            else:   # a genome's fp64 sums do not depend on which shard holds it: its lane's arithmetic is the same
+                assert np.allclose(got[name], want[name], rtol=1e-11, atol=1e-11), name
+    # host uploads split across the shards as well
+    loaded = kgx.GenotypeMatrix(G, L)
+    loaded.load_rows(want_rows)
+    assert np.array_equal(loaded.read_rows(), want_rows)
+    loaded.load_genomes(np.ascontiguousarray(want_rows.T[:300]), 0)
+    loaded.load_genomes(np.ascontiguousarray(want_rows.T[300:]), 300)
+    assert np.array_equal(loaded.read_rows(), want_rows)
+    many.close(); loaded.close()
+
+
+def test_handles_outlive_a_rebinding(kgx, rebind):
+    """A handle keeps the binding it was created under: created sharded, used after the library was rebound."""
+    rebind([0, 0])
+    pop = kgx.Population(900, 1000)
+    pop.synth_biallelic(1111, 0, 0)
+    kgx.init(0)
+    single = kgx.Population(900, 1000)
+    single.synth_biallelic(1111, 0, 0)
+    assert len(pop.shards) == 2 and len(single.shards) == 1
+    assert np.array_equal(pop.allele_count_by_locus(), single.allele_count_by_locus())
+    assert np.array_equal(pop.count_by_genome(), single.count_by_genome())
+    pop.close(); single.close()

@@ -316,3 +316,33 @@ def test_tuned_cpu_comparator_counts_like_the_port():
         for threads in (1, 3):
             got, seconds, used = oa.fast_count_by_variant(rows, G, threads=threads, repeats=1)
             assert np.array_equal(got, want) and used == threads and seconds > 0
+
+
+def test_dense_inbreeding_tier_is_generate_frequencies_bit_for_bit():
+    """oracle/kgo_inbreed_dense.cpp (the tier the full-size C5 test runs 64 genomes x 5M loci through) against
+    generateFrequencies + processSimple / processRitlandLocus on populations both can take: every count, every fp64
+    sum and both coefficients are the SAME bits -- same per-locus objects, same summation order."""
+    from . import synth_vcf as sv
+
+    for G, L, phased in ((12, 6000, True), (7, 2500, False)):
+        d = sv.synth_multiallelic_coded(G, 100, 100 + L, genome_base=37)
+        ref = oa.Population("gnomad")
+        ref.add_genomes(["Reference"])
+        ref.add_records_coded("chr1", d["offsets"], d["ref_code"], d["n_alts"], d["alt_code"], d["af_flat"], None, oa.Population.REFERENCE)
+        ref_snp = ref.filter_snp_pass()
+        dip = oa.Population("diploid")
+        dip.add_genomes(sv.genome_ids(G))
+        dip.add_records_coded("chr1", d["offsets"], d["ref_code"], d["n_alts"], d["alt_code"], d["af_flat"], d["alleles"],
+                              oa.Population.PHASED if phased else oa.Population.UNPHASED)
+        lower, upper = int(d["offsets"][50]), int(d["offsets"][-20])
+        for spacing, min_af, max_af in ((1, 0.0, 1.0), (35, 0.05, 0.5)):
+            counts, freqs, _ = oa.inbreed_dense(ref, ref_snp, oa.ALL, lower, upper, spacing, min_af, max_af, d["offsets"], d["alleles"], phased=phased)
+            for algorithm, column in (("Simple", 4), ("RitlandLocus", 5)):
+                c, f, present, _ = oa.inbreed_window(ref_snp, dip, np.full(G, oa.ALL, dtype=np.int32), algorithm, lower, upper, spacing,
+                                                     10**9, min_af, max_af)
+                assert present.all()
+                assert np.array_equal(c, counts)
+                assert np.array_equal(f[:, :4], freqs[:, :4])
+                assert np.array_equal(f[:, 4], freqs[:, column]), algorithm
+            assert counts[:, 4].min() > 10 and counts[:, 1].sum() > 0
+            assert (counts[:, 2].sum() > 0) == phased          # unphased 1/1 is not homozygous(): a minor heterozygote (SURVEY 8a)
