@@ -584,8 +584,11 @@ bool kga::GpuInbreedAnalysis::finalizeAnalysis() {
   return writeResults();
 }
 
-// Layout of InbreedingOutput::writePedResults (kga_analysis_inbreed_output.cpp:188-305) with the PED columns this
-// shim knows (super population); plus "<OutputFile>_detail.csv" carrying every LocusResults field at full precision.
+// InbreedingOutput::writeSynthetic / writePedResults / writeNoPedResults (kga_analysis_inbreed_output.cpp:85-395), chosen as
+// InbreedAnalysis::finalizeAnalysis chooses (kga_analysis_inbreed.cpp:134-150): the same header lines, the same columns
+// (Sample, Population, Description, SuperPopulation, Description, Relationship, Sex, Mother, Father, then one per window),
+// the same default stream formatting and the trailing delimiter of every data row -- the files diff clean against the
+// reference's.  Beside it "<OutputFile>_detail.csv" (not a reference file) carries every LocusResults field at full precision.
 bool kga::GpuInbreedAnalysis::writeResults() const {
   for (const auto& param_output : parameter_output_vector_) {
     if (param_output.columns.empty()) {
@@ -603,9 +606,14 @@ bool kga::GpuInbreedAnalysis::writeResults() const {
     outfile << p.parameter_ident << DELIMITER_ << "Algorithm:" << p.inbreeding_algorithm << DELIMITER_ << "Min_AF:" << p.locii.allele_frequency_min
             << DELIMITER_ << "Max_AF:" << p.locii.allele_frequency_max << DELIMITER_ << "Spacing:" << p.locii.spacing << DELIMITER_
             << "Count:" << p.locii.locii_count << '\n';
-    if (p.analyze_synthetic) outfile << "Sample" << DELIMITER_ << "SynInbreed" << DELIMITER_ << "CalcInbreed" << '\n';   // writeSynthetic (_output.cpp:353)
-    else {
-      outfile << "Sample" << DELIMITER_ << "SuperPopulation";
+    const bool with_ped = !p.analyze_synthetic && genealogy_data_;
+    if (p.analyze_synthetic) {
+      outfile << "Sample" << DELIMITER_ << "SynInbreed" << DELIMITER_ << "CalcInbreed" << '\n';                      // writeSynthetic (:353)
+    } else {
+      outfile << "Sample";
+      if (with_ped)                                                                                                    // writePedResults (:232-240)
+        outfile << DELIMITER_ << "Population" << DELIMITER_ << "Description" << DELIMITER_ << "SuperPopulation" << DELIMITER_ << "Description"
+                << DELIMITER_ << "Relationship" << DELIMITER_ << "Sex" << DELIMITER_ << "Mother" << DELIMITER_ << "Father";
       for (const auto& column : param_output.columns) outfile << DELIMITER_ << column.column_ident;
       outfile << '\n';
     }
@@ -614,9 +622,18 @@ bool kga::GpuInbreedAnalysis::writeResults() const {
     for (const auto& [genome_id, first] : param_output.columns.front().results) {
       if (p.analyze_synthetic) {
         outfile << genome_id << DELIMITER_ << generateInbreeding(genome_id).second << DELIMITER_;
+      } else if (with_ped) {
+        auto record_opt = genealogy_data_->getGenomeGenealogyRecord(genome_id);
+        if (!record_opt) {
+          ExecEnv::log().error("InbreedingAnalysis::writeColumnResults, Genome sample: {} does not have a PED record", genome_id);
+          continue;
+        }
+        const auto& ped_record = record_opt.value();
+        outfile << genome_id << DELIMITER_ << ped_record.population() << DELIMITER_ << ped_record.populationDescription() << DELIMITER_
+                << ped_record.superPopulation() << DELIMITER_ << ped_record.superDescription() << DELIMITER_ << ped_record.relationship() << DELIMITER_
+                << ped_record.sex() << DELIMITER_ << ped_record.maternalId() << DELIMITER_ << ped_record.paternalId() << DELIMITER_;
       } else {
-        auto record_opt = genealogy_data_ ? genealogy_data_->getGenomeGenealogyRecord(genome_id) : std::nullopt;
-        outfile << genome_id << DELIMITER_ << (record_opt ? record_opt.value().superPopulation() : std::string()) << DELIMITER_;
+        outfile << genome_id << DELIMITER_;
       }
       for (const auto& column : param_output.columns) {
         auto found = column.results.find(genome_id);

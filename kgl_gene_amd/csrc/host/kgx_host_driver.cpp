@@ -174,10 +174,34 @@ int main(int argc, char** argv) {
       files.push_back(std::move(f));
       continue;
     }
-    if (std::strncmp(argv[i], "ped:", 4) == 0) {        // genealogy resource: lines of "<genome>\t<super population>"
+    if (std::strncmp(argv[i], "ped:", 4) == 0) {
+      // The genealogy resource.  Either the reference's PED file -- a header line, then 15 tab-separated fields per sample
+      // (ParseHsGenomeGenealogyFile::moveToRecord, kgl_parser/kgl_hsgenealogy_parser.cpp) -- or lines of "<genome>\t<super population>".
       std::ifstream in(argv[i] + 4);
-      std::string genome, sp;
-      while (in >> genome >> sp) genealogy->addGenealogyRecord(kgl::HsGenealogyRecord(genome, sp));
+      std::string line;
+      bool first_line = true;
+      while (std::getline(in, line)) {
+        if (!line.empty() && line.back() == '\r') line.pop_back();
+        if (line.empty()) continue;
+        std::vector<std::string> fields;
+        size_t begin = 0;
+        for (size_t tab = line.find('\t'); ; tab = line.find('\t', begin)) {
+          fields.push_back(line.substr(begin, tab == std::string::npos ? std::string::npos : tab - begin));
+          if (tab == std::string::npos) break;
+          begin = tab + 1;
+        }
+        if (fields.size() == kgl::HsGenealogyRecord::genealogyFieldCount()) {
+          if (!first_line)      // the reference skips the header row
+            genealogy->addGenealogyRecord(kgl::HsGenealogyRecord(fields[0], fields[1], fields[2], fields[3], fields[4], fields[5], fields[6], fields[7],
+                                                                 fields[8], fields[9], fields[10], fields[11], fields[12], fields[13], fields[14]));
+        } else if (fields.size() == 2) {
+          genealogy->addGenealogyRecord(kgl::HsGenealogyRecord(fields[0], fields[1]));
+        } else {
+          ExecEnv::log().error("ParseHsGenomeGenealogyFile::moveToRecord; field count: {} not equal mandatory count: {}", fields.size(),
+                               kgl::HsGenealogyRecord::genealogyFieldCount());
+        }
+        first_line = false;
+      }
       continue;
     }
     files.push_back(loadRecords(argv[i]));

@@ -436,13 +436,40 @@ struct ResourceProperties {   // kgl_app/kgl_properties_resource.h:70
 };
 
 // kgl_parser/kgl_hsgenealogy_parser.h:22-135 — the PED table: genome -> super population.
+// kgl_parser/kgl_hsgenealogy_parser.h:23-110 -- the PED record, every field and accessor of the reference's class.
 class HsGenealogyRecord {
  public:
-  HsGenealogyRecord(std::string individual, std::string super_population) : individual_(std::move(individual)), super_population_(std::move(super_population)) {}
-  [[nodiscard]] const std::string& individualId() const { return individual_; }
+  HsGenealogyRecord(std::string family_id, std::string individual_id, std::string paternal_id, std::string maternal_id, std::string sex,
+                    std::string pheno_type, std::string population, std::string population_description, std::string super_population,
+                    std::string super_description, std::string relationship, std::string siblings, std::string second_order,
+                    std::string third_order, std::string comments)
+      : family_id_(std::move(family_id)), individual_id_(std::move(individual_id)), paternal_id_(std::move(paternal_id)),
+        maternal_id_(std::move(maternal_id)), sex_(std::move(sex)), pheno_type_(std::move(pheno_type)), population_(std::move(population)),
+        population_description_(std::move(population_description)), super_population_(std::move(super_population)),
+        super_description_(std::move(super_description)), relationship_(std::move(relationship)), siblings_(std::move(siblings)),
+        second_order_(std::move(second_order)), third_order_(std::move(third_order)), comments_(std::move(comments)) {}
+  // the two fields the sweep itself needs (tests that carry no PED file)
+  HsGenealogyRecord(std::string individual, std::string super_population)
+      : individual_id_(std::move(individual)), super_population_(std::move(super_population)) {}
+  [[nodiscard]] const std::string& familyId() const { return family_id_; }
+  [[nodiscard]] const std::string& individualId() const { return individual_id_; }
+  [[nodiscard]] const std::string& paternalId() const { return paternal_id_; }
+  [[nodiscard]] const std::string& maternalId() const { return maternal_id_; }
+  [[nodiscard]] const std::string& sex() const { return sex_; }
+  [[nodiscard]] const std::string& phenoType() const { return pheno_type_; }
+  [[nodiscard]] const std::string& population() const { return population_; }
+  [[nodiscard]] const std::string& populationDescription() const { return population_description_; }
   [[nodiscard]] const std::string& superPopulation() const { return super_population_; }
+  [[nodiscard]] const std::string& superDescription() const { return super_description_; }
+  [[nodiscard]] const std::string& relationship() const { return relationship_; }
+  [[nodiscard]] const std::string& siblings() const { return siblings_; }
+  [[nodiscard]] const std::string& secondOrder() const { return second_order_; }
+  [[nodiscard]] const std::string& thirdOrder() const { return third_order_; }
+  [[nodiscard]] const std::string& comments() const { return comments_; }
+  [[nodiscard]] static size_t genealogyFieldCount() { return 15; }
  private:
-  std::string individual_, super_population_;
+  std::string family_id_, individual_id_, paternal_id_, maternal_id_, sex_, pheno_type_, population_, population_description_,
+      super_population_, super_description_, relationship_, siblings_, second_order_, third_order_, comments_;
 };
 class HsGenomeGenealogyData : public ResourceBase {
  public:

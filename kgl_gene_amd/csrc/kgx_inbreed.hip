@@ -79,18 +79,20 @@ int inbreed_shard(kgx_gt8_shard& sh, uint64_t g0, uint64_t g1, const uint32_t* l
   static_assert(sizeof(kgx_locus_results) == sizeof(LocusResultsDev), "LocusResults layout");
 
   const uint32_t stride = sweep_stride(amax);
-  // Frequency pass flavour: 16 genomes per lane (SWAR, 16-byte loads) when the group starts on a 16-genome boundary and
-  // the estimator needs no Ritland terms; otherwise 4 genomes per lane.
-  // RitlandLocus with allele indices that fit the tables: the plain frequency sweep, then one table pass for its terms.
+  // Frequency pass flavour: 16 genomes per lane (SWAR, 16-byte loads) when the group starts on a 16-genome boundary,
+  // otherwise 4 genomes per lane.  RitlandLocus with allele indices that fit the tables: ONE table pass that yields the
+  // class counts, the class-frequency sums and the Ritland terms together (k_inbreed_eval_lut<3>), no SWAR sweep.
   const bool ritland_lut = algorithm == KGX_ALGO_RITLAND_LOCUS && !env_int("KGX_K5_GENERIC", 0) && !env_int("KGX_K5_NO_EVAL_LUT", 0) &&
-                           amax <= 4;
+                           amax <= 7 && n_sel <= 65535ull * kRitlandSegment;
   const bool swar16 = !env_int("KGX_K5_GENERIC", 0) && !env_int("KGX_K5_NO_SWAR16", 0) && amax <= 4 && (g0 & 15u) == 0 &&
-                      (algorithm != KGX_ALGO_RITLAND_LOCUS || ritland_lut);
+                      algorithm != KGX_ALGO_RITLAND_LOCUS;
   // The evaluation passes of HallME / Loglikelihood go through the per-batch LDS tables when the allele indices fit them.
   const bool eval_lut = !env_int("KGX_K5_GENERIC", 0) && !env_int("KGX_K5_NO_EVAL_LUT", 0) && amax <= 7;
-  int eval_gpl = env_int("KGX_K5_EVAL_GPL", 8);            // genomes per lane: the widest load the group's alignment allows
+  // genomes per lane of the table passes: Loglikelihood 8 (a dwordx2 load per locus) where the group's alignment allows;
+  // HallME and RitlandLocus, whose per-genome state is wider, 4 -- what keeps each at four workgroups per CU
+  int eval_gpl = algorithm == KGX_ALGO_LOGLIKELIHOOD ? env_int("KGX_K5_EVAL_GPL", 8) : 4;
   if (eval_gpl != 4 && eval_gpl != 8) eval_gpl = 8;
-  while (eval_gpl > 4 && (g0 % static_cast<uint64_t>(eval_gpl)) != 0) eval_gpl /= 2;
+  if (g0 & 7u) eval_gpl = 4;
   const uint32_t gx = static_cast<uint32_t>(((n + 3) / 4 + kBlock - 1) / kBlock);
   const uint32_t gx16 = static_cast<uint32_t>(((n + 15) / 16 + kBlock - 1) / kBlock);
   uint64_t n_seg = (static_cast<uint64_t>(dev.compute_units) * env_int("KGX_K5_BLOCKS_PER_CU", 8) + (swar16 ? gx16 : gx) - 1) / (swar16 ? gx16 : gx);
@@ -101,6 +103,24 @@ int inbreed_shard(kgx_gt8_shard& sh, uint64_t g0, uint64_t g1, const uint32_t* l
   uint64_t per_seg = n_sel ? (n_sel + n_seg - 1) / n_seg : 8;
   per_seg = (per_seg + 7) / 8 * 8;                                          // whole 8-locus batches per segment
   n_seg = n_sel ? (n_sel + per_seg - 1) / per_seg : 1;
+  // The table passes cut the loci for their own launch shape: 256-thread workgroups, 3 or 4 resident per CU, about eight
+  // rounds of them and never a workgroup more than that (a ninth, nearly empty round costs an eighth of the pass).
+  uint64_t eval_n_seg = n_seg, eval_per_seg = per_seg;
+  if (eval_lut || ritland_lut) {
+    const uint64_t eval_gx = ((n + eval_gpl - 1) / eval_gpl + kEvalThreads - 1) / kEvalThreads;
+    const uint64_t resident = static_cast<uint64_t>(dev.compute_units) * 4u;
+    uint64_t want = resident * static_cast<uint64_t>(env_int("KGX_K5_EVAL_ROUNDS", 8)) / eval_gx;
+    if (want < 1) want = 1;
+    if (want > 65535) want = 65535;
+    eval_per_seg = n_sel ? (n_sel + want - 1) / want : kEvalBatch;
+    eval_per_seg = (eval_per_seg + 7) / 8 * 8;
+    if (eval_per_seg < 64) eval_per_seg = 64;
+    if (algorithm == KGX_ALGO_RITLAND_LOCUS && eval_per_seg > kRitlandSegment) eval_per_seg = kRitlandSegment;
+    eval_n_seg = n_sel ? (n_sel + eval_per_seg - 1) / eval_per_seg : 1;
+    if (ritland_lut) { n_seg = eval_n_seg; per_seg = eval_per_seg; }          // its one pass fills the frequency sweep's partials
+  }
+  const uint64_t max_seg = eval_n_seg > n_seg ? eval_n_seg : n_seg;
+  const uint64_t pass_n_seg = eval_lut ? eval_n_seg : n_seg;                  // segments of an estimator pass (modes 1, 2)
 
   double *d_af = nullptr, *d_table = nullptr, *d_part = nullptr, *d_sums = nullptr, *d_f = nullptr, *d_eval = nullptr, *d_segdef = nullptr;
   uint8_t* d_valid = nullptr;
@@ -124,14 +144,14 @@ int inbreed_shard(kgx_gt8_shard& sh, uint64_t g0, uint64_t g1, const uint32_t* l
   ScratchPlan plan;
   const size_t o_af = plan.add(n_tab * amax * sizeof(double)), o_table = plan.add(n_tab * stride * sizeof(double));
   const size_t o_valid = plan.add(n_tab), o_meta = plan.add((n_tab + 8) * sizeof(uint32_t));
-  const size_t o_part = plan.add(n_seg * n * kParts0 * sizeof(double)), o_segdef = plan.add(n_seg * kSegDefaults * sizeof(double));
+  const size_t o_part = plan.add(max_seg * n * kParts0 * sizeof(double)), o_segdef = plan.add(max_seg * kSegDefaults * sizeof(double));
   const size_t o_sums = plan.add(n * kParts0 * sizeof(double)), o_counts = plan.add(n * 6 * sizeof(unsigned long long));
   const size_t o_f = plan.add(n * sizeof(double)), o_eval = plan.add(n * sizeof(double)), o_out = plan.add(n * sizeof(LocusResultsDev));
   const size_t o_index = plan.add((n_sel + 8) * sizeof(uint32_t)), o_golden = plan.add(n * sizeof(GoldenState));
   const size_t o_brent = plan.add(n * sizeof(BrentState)), o_running = plan.add(sizeof(unsigned int));
   // The class-frequency sums of the defaults in the reference's own (sequential) summation order (k_seq_* kernels): from
   // the size at which a tree reduction and a sequential sum part by more than a tenth of the tolerance.
-  const bool swar_family = !env_int("KGX_K5_GENERIC", 0) && amax <= 4 && (swar16 || algorithm != KGX_ALGO_RITLAND_LOCUS || ritland_lut);
+  const bool swar_family = ritland_lut || (!env_int("KGX_K5_GENERIC", 0) && amax <= 4 && algorithm != KGX_ALGO_RITLAND_LOCUS);
   const bool sequential_defaults = swar_family && n_sel >= static_cast<uint64_t>(env_int("KGX_K5_SEQUENTIAL_MIN", 1 << 16));
   const uint64_t n_seq_blocks = (n_sel + kSeqBlock - 1) / kSeqBlock;
   const size_t o_seq_sum = plan.add(n_seq_blocks * 4 * sizeof(double)), o_seq_e = plan.add(n_seq_blocks * 4 * sizeof(int));
@@ -196,13 +216,22 @@ int inbreed_shard(kgx_gt8_shard& sh, uint64_t g0, uint64_t g1, const uint32_t* l
   auto sweep = [&](int mode) {
     if (n_sel == 0) return;
     if (mode == 0 && sequential_defaults) {
+      // beside the sweep, on the side stream: it reads the per-locus table only, and only the final reduction reads its sums
       const dim3 seq_grid(static_cast<uint32_t>(n_seq_blocks));
-      hipLaunchKernelGGL(k_seq_block_sums, seq_grid, dim3(kBlock), 0, st, d_table, d_valid, n_sel, amax, d_seq_sum);
-      hipLaunchKernelGGL(k_seq_block_predict, dim3(1), dim3(kBlock), 0, st, d_seq_sum, n_seq_blocks, d_seq_e);
-      hipLaunchKernelGGL(k_seq_block_quantize, seq_grid, dim3(kBlock), 0, st, d_table, d_valid, n_sel, amax, d_seq_e, d_seq_n);
-      hipLaunchKernelGGL(k_seq_chain, dim3(1), dim3(kBlock), 0, st, d_table, d_valid, n_sel, amax, d_seq_e, d_seq_n, n_seq_blocks, d_seq_out);
+      hipStream_t side = dev.side_stream;
+      try_hip(hipEventRecord(dev.side_begin, st), KGX_EHIP, "hipEventRecord");
+      try_hip(hipStreamWaitEvent(side, dev.side_begin, 0), KGX_EHIP, "hipStreamWaitEvent");
+      hipLaunchKernelGGL(k_seq_block_sums, seq_grid, dim3(kBlock), 0, side, d_table, d_valid, n_sel, amax, d_seq_sum);
+      hipLaunchKernelGGL(k_seq_block_predict, dim3(1), dim3(kBlock), 0, side, d_seq_sum, n_seq_blocks, d_seq_e);
+      hipLaunchKernelGGL(k_seq_block_quantize, seq_grid, dim3(kBlock), 0, side, d_table, d_valid, n_sel, amax, d_seq_e, d_seq_n);
+      hipLaunchKernelGGL(k_seq_chain, dim3(1), dim3(kBlock), 0, side, d_table, d_valid, n_sel, amax, d_seq_e, d_seq_n, n_seq_blocks, d_seq_out);
+      try_hip(hipEventRecord(dev.side_end, side), KGX_EHIP, "hipEventRecord");
     }
-    if (mode == 0) {
+    if (mode == 0 && ritland_lut) {
+      // segment defaults into the partials, then the one table pass (below, as mode 3) corrects and counts
+      hipLaunchKernelGGL(k_segment_defaults, dim3(static_cast<uint32_t>(n_seg)), dim3(kWave), 0, st, d_table, d_valid, n_sel, per_seg, amax, sequential_defaults ? 1 : 0, d_segdef);
+      hipLaunchKernelGGL(k_fill_defaults, dim3(stream_grid(dev, n_seg * n, kBlock)), dim3(kBlock), 0, st, d_segdef, n_seg, n, d_part);
+    } else if (mode == 0) {
       if (swar16) {
         hipLaunchKernelGGL(k_locus_bits, dim3(stream_grid(dev, n_sel, kBlock)), dim3(kBlock), 0, st, d_table, d_valid, n_sel, amax, d_meta);
         hipLaunchKernelGGL(k_segment_defaults, dim3(static_cast<uint32_t>(n_seg)), dim3(kWave), 0, st, d_table, d_valid, n_sel, per_seg, amax, sequential_defaults ? 1 : 0, d_segdef);
@@ -215,7 +244,7 @@ int inbreed_shard(kgx_gt8_shard& sh, uint64_t g0, uint64_t g1, const uint32_t* l
         if (d_index) { if (guard) KGX_SWAR16(true, true); else KGX_SWAR16(true, false); }
         else { if (guard) KGX_SWAR16(false, true); else KGX_SWAR16(false, false); }
 #undef KGX_SWAR16
-      } else if (env_int("KGX_K5_GENERIC", 0) || amax > 4 || (algorithm == KGX_ALGO_RITLAND_LOCUS && !ritland_lut)) {
+      } else if (env_int("KGX_K5_GENERIC", 0) || amax > 4 || algorithm == KGX_ALGO_RITLAND_LOCUS) {
         hipLaunchKernelGGL((k_inbreed_sweep<0>), grid, dim3(kBlock), 0, st, gt32, dwords_per_row, g0, n, d_index, n_sel, per_seg, d_table,
                            d_valid, amax, phased, d_f, d_counts, d_part);
       } else {
@@ -229,22 +258,14 @@ int inbreed_shard(kgx_gt8_shard& sh, uint64_t g0, uint64_t g1, const uint32_t* l
 #undef KGX_SWAR
       }
     } else if (eval_lut || mode == 3) {
-      const dim3 grid_eval(static_cast<uint32_t>(((n + eval_gpl - 1) / eval_gpl + kBlock - 1) / kBlock), static_cast<uint32_t>(n_seg));
-#define KGX_EVAL(M, W, B)                                                                                                         \
-  hipLaunchKernelGGL((k_inbreed_eval_lut<M, W, B>), grid_eval, dim3(kBlock), 0, st, gt32, dwords_per_row, g0, n, d_index, n_sel,  \
-                     per_seg, d_table, d_valid, amax, phased, d_f, d_part, d_counts)
-#define KGX_EVAL_BITS(M, W)                                                                \
-  do {                                                                                     \
-    if (amax <= 1) KGX_EVAL(M, W, 1); else if (amax <= 3) KGX_EVAL(M, W, 2); else KGX_EVAL(M, W, 3); \
-  } while (0)
-      if (mode == 1) {
-        if (eval_gpl == 8) KGX_EVAL_BITS(1, 8); else KGX_EVAL_BITS(1, 4);
-      } else if (mode == 2) {
-        if (eval_gpl == 8) KGX_EVAL_BITS(2, 8); else KGX_EVAL_BITS(2, 4);
-      } else {
-        if (eval_gpl == 8) KGX_EVAL_BITS(3, 8); else KGX_EVAL_BITS(3, 4);
-      }
-#undef KGX_EVAL_BITS
+#define KGX_EVAL(M, GPL, WAVES)                                                                                                      \
+  hipLaunchKernelGGL((k_inbreed_eval_lut<M, GPL, WAVES>),                                                                            \
+                     dim3(static_cast<uint32_t>(((n + GPL - 1) / GPL + kEvalThreads - 1) / kEvalThreads), static_cast<uint32_t>(eval_n_seg)), \
+                     dim3(kEvalThreads), 0, st, gt32, dwords_per_row, g0, n, d_index, n_sel,                                         \
+                     eval_per_seg, d_table, d_valid, amax, phased, d_f, d_part, d_counts)
+      if (mode == 1) KGX_EVAL(1, 4, 4);
+      else if (mode == 2) { if (eval_gpl == 8) KGX_EVAL(2, 8, 4); else KGX_EVAL(2, 4, 4); }
+      else KGX_EVAL(3, 4, 4);
 #undef KGX_EVAL
     } else if (mode == 1)
       hipLaunchKernelGGL((k_inbreed_sweep<1>), grid, dim3(kBlock), 0, st, gt32, dwords_per_row, g0, n, d_index, n_sel, per_seg, d_table,
@@ -260,6 +281,7 @@ int inbreed_shard(kgx_gt8_shard& sh, uint64_t g0, uint64_t g1, const uint32_t* l
     sweep(0);
     if (ritland_lut) sweep(3);
     if (rc == KGX_OK) try_hip(hipEventRecord(dev.sweep_end, st), KGX_EHIP, "hipEventRecord");
+    if (sequential_defaults && n_sel) try_hip(hipStreamWaitEvent(st, dev.side_end, 0), KGX_EHIP, "hipStreamWaitEvent");
     hipLaunchKernelGGL(k_reduce_parts, dim3(stream_grid(dev, n * kParts0, kBlock)), dim3(kBlock), 0, st, d_part, n_seg, n * kParts0,
                        (sequential_defaults && n_sel) ? d_seq_out : nullptr, d_sums);
     // Window-sized calls: the whole iteration in one launch, a wave per genome (k_inbreed_iterate_wave).
@@ -285,12 +307,12 @@ int inbreed_shard(kgx_gt8_shard& sh, uint64_t g0, uint64_t g1, const uint32_t* l
       // fixed start 0.25 (the mean of its start distribution) replaces the random draw.
       std::vector<double> f0(n, 0.25);
       // locus slots every lane of k_inbreed_eval_lut walks: whole batches of 8 in every segment
-      const unsigned long long walked = eval_lut && n_sel ? (n_seg - 1) * per_seg + (n_sel - (n_seg - 1) * per_seg + 7) / 8 * 8 : 0ull;
+      const unsigned long long walked = eval_lut && n_sel ? (eval_n_seg - 1) * eval_per_seg + (n_sel - (eval_n_seg - 1) * eval_per_seg + kEvalBatch - 1) / kEvalBatch * kEvalBatch : 0ull;
       try_hip(hipMemcpyAsync(d_f, f0.data(), n * sizeof(double), hipMemcpyHostToDevice, st), KGX_EHIP, "H2D(f0)");
       try_hip(hipStreamSynchronize(st), KGX_EHIP, "sync");
       for (int it = 0; it < 50 && rc == KGX_OK; ++it) {
         sweep(1);
-        hipLaunchKernelGGL(k_reduce_parts, dim3(lin_grid), dim3(kBlock), 0, st, d_part, n_seg, n, nullptr, d_eval);
+        hipLaunchKernelGGL(k_reduce_parts, dim3(lin_grid), dim3(kBlock), 0, st, d_part, pass_n_seg, n, nullptr, d_eval);
         hipLaunchKernelGGL(k_hall_update, dim3(lin_grid), dim3(kBlock), 0, st, d_eval, d_counts, n, walked, d_f);
       }
     } else if (algorithm == 3) {
@@ -321,11 +343,12 @@ int inbreed_shard(kgx_gt8_shard& sh, uint64_t g0, uint64_t g1, const uint32_t* l
         std::vector<BrentState> host_states;
         auto evaluate = [&]() {
           if (act_gt == gt32) { sweep(2); return; }
-          const dim3 grid_eval(static_cast<uint32_t>(((n_act + act_gpl - 1) / act_gpl + kBlock - 1) / kBlock), static_cast<uint32_t>(n_seg));
-#define KGX_EVAL2(W, B)                                                                                                              \
-  hipLaunchKernelGGL((k_inbreed_eval_lut<2, W, B>), grid_eval, dim3(kBlock), 0, st, act_gt, act_dwords_per_row, act_g0, n_act, act_index, \
-                     n_sel, per_seg, d_table, d_valid, amax, phased, act_f, d_part, d_counts)
-          if (amax <= 1) KGX_EVAL2(8, 1); else if (amax <= 3) KGX_EVAL2(8, 2); else KGX_EVAL2(8, 3);
+#define KGX_EVAL2(GPL)                                                                                                               \
+  hipLaunchKernelGGL((k_inbreed_eval_lut<2, GPL, 4>),                                                                                \
+                     dim3(static_cast<uint32_t>(((n_act + GPL - 1) / GPL + kEvalThreads - 1) / kEvalThreads), static_cast<uint32_t>(eval_n_seg)), \
+                     dim3(kEvalThreads), 0, st, act_gt, act_dwords_per_row, act_g0, n_act, act_index,                                \
+                     n_sel, eval_per_seg, d_table, d_valid, amax, phased, act_f, d_part, d_counts)
+          if (act_gpl == 8) KGX_EVAL2(8); else KGX_EVAL2(4);
 #undef KGX_EVAL2
         };
         const bool may_compact = eval_lut && !env_int("KGX_K7_NO_COMPACT", 0);
@@ -334,7 +357,7 @@ int inbreed_shard(kgx_gt8_shard& sh, uint64_t g0, uint64_t g1, const uint32_t* l
         for (int it = 0; it < kMaxEvaluations && rc == KGX_OK; ++it) {
           evaluate();
           const uint32_t act_grid = stream_grid(dev, n_act, kBlock);
-          hipLaunchKernelGGL(k_reduce_parts, dim3(act_grid), dim3(kBlock), 0, st, d_part, n_seg, n_act, nullptr, d_eval);
+          hipLaunchKernelGGL(k_reduce_parts, dim3(act_grid), dim3(kBlock), 0, st, d_part, pass_n_seg, n_act, nullptr, d_eval);
           try_hip(hipMemsetAsync(d_running, 0, sizeof(unsigned int), st), KGX_EHIP, "memset(running)");
           hipLaunchKernelGGL(k_brent_step, dim3(act_grid), dim3(kBlock), 0, st, act_brent, d_eval, n_act, it == 0 ? 0 : 1, act_f, d_running,
                              act_global, d_f);
@@ -398,7 +421,7 @@ int inbreed_shard(kgx_gt8_shard& sh, uint64_t g0, uint64_t g1, const uint32_t* l
           act_brent = new_brent;
           act_f = new_f;
           act_global = d_new_global;
-          act_gpl = 8;
+          act_gpl = env_int("KGX_K5_EVAL_GPL", 8) == 4 ? 4 : 8;          // the compacted columns start at genome 0
           n_act = n_new;
           global_of.swap(new_global);
         }
@@ -419,7 +442,7 @@ int inbreed_shard(kgx_gt8_shard& sh, uint64_t g0, uint64_t g1, const uint32_t* l
       try_hip(hipStreamSynchronize(st), KGX_EHIP, "sync");
       for (int it = 0; it < kGoldenSteps && rc == KGX_OK; ++it) {
         sweep(2);
-        hipLaunchKernelGGL(k_reduce_parts, dim3(lin_grid), dim3(kBlock), 0, st, d_part, n_seg, n, nullptr, d_eval);
+        hipLaunchKernelGGL(k_reduce_parts, dim3(lin_grid), dim3(kBlock), 0, st, d_part, pass_n_seg, n, nullptr, d_eval);
         hipLaunchKernelGGL(k_golden_step, dim3(lin_grid), dim3(kBlock), 0, st, d_golden, d_eval, n, it < 2 ? it : 2, d_f);
       }
       // coefficient = the better interior point of the final bracket

@@ -224,9 +224,9 @@ k_inbreed_sweep(const uint32_t* __restrict__ gt, uint64_t dwords_per_row, uint64
 
 // K5 evaluation passes (MODE 1: one Hall expectation step; MODE 2: the log-likelihood at F) for amax <= 7, the passes
 // HallME runs 50 times and Loglikelihood ~40 times per call.  What a cell contributes depends only on (locus, byte
-// value, F of the genome), so per batch of 8 loci the block first tabulates, in LDS, a pair (y, d) for each of the
-// 128 values of (byte & 0x7F) -- classify_cell decides every entry, so the class logic is the generic kernel's own --
-// and each cell is then one LDS read, one fma  v = y + F*d  and a few more fp64 operations:
+// value, F of the genome), so per batch of 8 loci the block first tabulates, in LDS, a pair (y, d) per byte value --
+// classify_cell decides every entry, so the class logic is the generic kernel's own -- and each cell is then one LDS
+// read, one fma  v = y + F*d  and a few more fp64 operations:
 //   MODE 2  v = the cell's probability.  hom: y = f1*f1, d = f1 - f1*f1   (F*f + (1-F)*f*f,  _calc.cpp:94-129)
 //                                        het: y = 2*f1*f2, d = -y         (2*(1-F)*f1*f2)
 //                                        unclassified: (1, 0) -> probability 1, log 0.
@@ -240,43 +240,76 @@ k_inbreed_sweep(const uint32_t* __restrict__ gt, uint64_t dwords_per_row, uint64
 //           sweep) and multiplies by F.  The reference's zero-denominator guard (_calc.cpp:272) can only fire at
 //           F = 0, where every term F/v is 0: such a genome is walked with F = 1 (v = 1 everywhere) and the
 //           multiplication by its F = 0 happens in k_hall_update.
-//   MODE 3  RitlandLocus (processRitlandLocus, _calc.cpp:367-431): y = the cell's term -- homozygous with f1 > 0.001:
-//           1/f1 - 1, heterozygous: -1, anything else 0 -- and d = 1 where the cell is counted; both are summed per
-//           genome in fp64 (the count is exact) and written to the Ritland slot of the frequency sweep's partials
-//           and to counts[g][5].  Runs after the (non-Ritland) SWAR frequency sweep.
-// Bit 7 of the byte (second allele index >= 8) is folded onto bit 3, and every entry with bit 3 set is "unclassified".
-// Entry (a1, a2) sits at slot a1 + 20*a2 of the locus's 160-slot table (a1 < 16, a2 < 8: injective), so the 16-byte
-// slots of the cells a 16-lane ds_read_b128 group meets together -- a1, a2 in 0..3 -- fall on 16 different bank quads
-// ((a1 + 4*a2) mod 16); at slot a1 + 16*a2 every a2 shared a1's banks (SQ_LDS_BANK_CONFLICT: 2.7 extra cycles a read).
-// GPL genomes per lane (4, 8 or 16: one dword / dwordx2 / dwordx4 load per locus); the whole block takes part in the
-// table build, so there is no early return.
+//   MODE 3  RitlandLocus in ONE pass over the bytes: generateFrequencies (_freq.cpp:425-583) and processRitlandLocus
+//           (_calc.cpp:367-431) from the same table read.  y = the cell's Ritland term -- homozygous with f1 > 0.001:
+//           1/f1 - 1, heterozygous: -1, anything else 0 -- summed per genome in fp64; the other 8 bytes of the entry are
+//           two packed integer words added to two packed counters per genome: lo = majorHom | majorHet << 12,
+//           hi = minorHom | minorHet << 12 | odd << 28 (12-bit fields: a segment holds at most kRitlandSegment loci).
+//           The four class-frequency sums are class independent, so they are the segment's defaults (pre-filled into
+//           part[], k_fill_defaults) corrected where a cell is "odd": unclassified at a locus whose reference-
+//           homozygote is classified, classified at a locus whose reference-homozygote is not, a homozygote of an
+//           allele with f <= 0.001 (no Ritland term), or a byte past the table.  An odd entry adds 1 to the top four
+//           bits of hi and says in the top bits of lo what is odd; once per batch the wave looks at the top of hi and,
+//           if any lane saw one, walks the batch's entries again and lets the odd ones adjust the lane's own
+//           (segment, genome) partial slot in memory -- a second look at 32 entries, only where such a cell is.
+// The locus's table has one 16-byte entry per BYTE VALUE (256 slots, 4 KB), so a cell's address is its byte times 16 --
+// one SDWA shift, no index arithmetic and no guard: a byte the layout does not define (an index past the alt list, an
+// unknown alt, 0xFF) lands on an entry that was written "unclassified" once, before the first batch.  Only the
+// (amax+1)^2 entries whose two allele indices are <= amax can ever be classified and are rebuilt per batch.
+// Two table buffers of 4 loci = 32 KB of LDS per workgroup of 256 threads (three or four per CU); a lane owns
+// GPL genomes (one dword or dwordx2 load per locus), the next batch's genotype words are loaded while this batch is
+// walked, its table is built by the whole block meanwhile, and its per-locus rows were staged two batches ahead.
 struct alignas(16) EvalEntry { double y, d; };
-constexpr int kEvalBatch = 8;
-constexpr int kHallBatches = 8;    // MODE 1: batches summed as one fraction before the division
-constexpr uint32_t kEvalSlots = 160;
+constexpr int kEvalBatch = 4;      // loci per table buffer: 2 x 4 x 4 KB = 32 KB of LDS per workgroup
+constexpr int kEvalThreads = 256;
+constexpr int kHallBatches = 16;   // MODE 1: batches (of 4 loci) summed as one fraction before the division
+constexpr uint32_t kEvalSlots = 256;
+constexpr uint64_t kRitlandSegment = 4088;        // MODE 3: loci per segment, below the 12-bit class counters' range
+constexpr uint32_t kOddCell = 1u << 28;           // MODE 3: in the entry's hi word: one more odd cell (a 4-bit count per batch)
+// ... and what is odd about it, in the entry's lo word (bits the 12-bit class counters never reach):
+constexpr uint32_t kOddMinus = 1u << 24;          // unclassified carrier at a locus with defaults: its class frequencies come off
+constexpr uint32_t kOddPlus = 1u << 25;           // classified at a locus without defaults: they are added
+constexpr uint32_t kOddNoRitland = 1u << 26;      // a homozygote of an allele with f <= 0.001: classified, no Ritland term
+constexpr uint32_t kOddOutside = 1u << 27;        // a byte past the table: off wherever the locus has defaults
 
-// Only the (amax+1)^2 entries whose two allele indices are <= amax can ever be classified; the rest of the 160 are
-// written "unclassified" once, before the first batch, and never touched again.
-// rows / flags: the batch's 8 per-locus table rows and valid[] flags, staged in LDS two batches ahead (flag 0 past the
+// Slot of a byte value in the locus's table: the byte itself with two bits of its high nibble XORed onto bits 2..3 -- the
+// entries a 16-lane ds_read_b128 group meets together (allele indices 0..3 in either nibble) then sit on 16 different
+// bank quads; at slot = byte every second-allele index shared the first one's banks (SQ_LDS_BANK_CONFLICT: 2.7 extra
+// cycles per read).  The walk applies it to four bytes at once (swizzle_bytes).
+__host__ __device__ constexpr uint32_t eval_slot(uint32_t byte) { return byte ^ ((byte >> 2) & 0x0Cu); }
+__device__ __forceinline__ uint32_t swizzle_bytes(uint32_t w) { return w ^ ((w >> 2) & 0x0C0C0C0Cu); }
+
+// rows / flags: the batch's per-locus table rows and valid[] flags, staged in LDS two batches ahead (flag 0 past the
 // segment), so that no global-load latency sits between a batch's arithmetic and the next.
-template <int MODE, int BITS>
+template <int MODE>
 __device__ __forceinline__ void build_eval_table(EvalEntry* __restrict__ lut, const double* __restrict__ rows,
                                                  const uint8_t* __restrict__ flags, uint32_t stride, uint32_t amax, bool phased,
                                                  uint32_t* __restrict__ upper_binds, uint32_t batch_tag) {
-  // e enumerates (locus, a2, a1) with just enough bits per allele index for amax, so that at amax <= 3 two waves
-  // build the whole batch in one step and the other two go straight on to the arithmetic
-  constexpr uint32_t bits = BITS, mask = (1u << bits) - 1u;       // BITS = 1, 2, 3 for amax <= 1, 3, 7
-  for (uint32_t e = threadIdx.x; e < (static_cast<uint32_t>(kEvalBatch) << (2u * bits)); e += kBlock) {
-    const uint32_t a1 = e & mask, a2 = (e >> bits) & mask, i = e >> (2u * bits);
-    if (a1 > amax || a2 > amax) continue;
+  const uint32_t n1 = amax + 1u, per_locus = n1 * n1;
+  for (uint32_t e = threadIdx.x; e < static_cast<uint32_t>(kEvalBatch) * per_locus; e += blockDim.x) {
+    const uint32_t i = e / per_locus, r = e - i * per_locus, a2 = r / n1, a1 = r - a2 * n1;
     double y = MODE == 3 ? 0.0 : 1.0, d = 0.0;
     if (flags[i] & kLocusValid) {
       double f1 = 0.0, f2 = 0.0;
       const int cls = classify_cell(a1 | (a2 << 4), rows + i * stride, amax, phased, f1, f2);
-      if (cls == kMajorHom || cls == kMinorHom) {
+      if constexpr (MODE == 3) {
+        uint32_t lo = 0, hi = 0;
+        if (cls == kMajorHom) lo = 1u; else if (cls == kMajorHet) lo = 1u << 12;
+        else if (cls == kMinorHom) hi = 1u; else if (cls == kMinorHet) hi = 1u << 12;
+        // odd: the cell's share of the class-frequency sums is not the segment default's
+        if (flags[i] & kLocusDefault) { if (cls == kClassNone && (a1 | a2) != 0u) lo |= kOddMinus; }
+        else if (cls != kClassNone) lo |= kOddPlus;
+        if (cls == kMajorHom || cls == kMinorHom) {
+          if (f1 > 0.001) { y = 1.0 / f1; y -= 1.0; }                  // minimum_frequency (_calc.cpp:380,396)
+          else lo |= kOddNoRitland;
+        } else if (cls != kClassNone) {
+          y = -1.0;
+        }
+        if (lo >> 24) hi |= kOddCell;
+        d = __builtin_bit_cast(double, (static_cast<uint64_t>(hi) << 32) | lo);
+      } else if (cls == kMajorHom || cls == kMinorHom) {
         if constexpr (MODE == 2) { y = f1 * f1; d = f1 - y; }
-        else if constexpr (MODE == 1) { y = f1; d = 1.0 - f1; }
-        else if (f1 > 0.001) { y = 1.0 / f1; y -= 1.0; d = 1.0; }     // minimum_frequency (_calc.cpp:380,396)
+        else { y = f1; d = 1.0 - f1; }
       } else if (cls != kClassNone) {
         if constexpr (MODE == 2) {
           y = 2.0 * f1 * f2; d = -y;
@@ -284,17 +317,29 @@ __device__ __forceinline__ void build_eval_table(EvalEntry* __restrict__ lut, co
           // let through up to 1e-5 over 1.  The batch is then walked with the upper clamp (see the kernel).
           if (y > 0.5) *upper_binds = batch_tag;
         }
-        else if constexpr (MODE == 3) { y = -1.0; d = 1.0; }
       }
     }
-    EvalEntry* slot = lut + i * kEvalSlots + (a1 + 20u * a2);
+    EvalEntry* slot = lut + i * kEvalSlots + eval_slot(a1 | (a2 << 4));
     slot->y = y;
     slot->d = d;
   }
 }
 
-template <int MODE, int GPL, int BITS>
-__global__ void __launch_bounds__(kBlock)
+// 16 * (byte B of w): the LDS byte offset of that cell's entry, one SDWA shift.
+template <int B>
+__device__ __forceinline__ uint32_t byte_times_16(uint32_t w, uint32_t four) {
+  uint32_t r;
+  if constexpr (B == 0) asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0" : "=v"(r) : "v"(four), "v"(w));
+  else if constexpr (B == 1) asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1" : "=v"(r) : "v"(four), "v"(w));
+  else if constexpr (B == 2) asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_2" : "=v"(r) : "v"(four), "v"(w));
+  else asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_3" : "=v"(r) : "v"(four), "v"(w));
+  return r;
+}
+
+// Workgroups of 256 threads (one wave per SIMD), WAVES of them per CU: 4 (<= 128 VGPRs) or 3 (<= 168) as the mode's
+// registers allow; 34 KB of LDS each.
+template <int MODE, int GPL, int WAVES>
+__global__ void __launch_bounds__(kEvalThreads) __attribute__((amdgpu_waves_per_eu(WAVES)))
 k_inbreed_eval_lut(const uint32_t* __restrict__ gt, uint64_t dwords_per_row, uint64_t g0, uint64_t n_genomes,
                    const uint32_t* __restrict__ locus_index, uint64_t n_sel, uint64_t loci_per_seg,
                    const double* __restrict__ table, const uint8_t* __restrict__ valid, uint32_t amax, int phased,
@@ -314,9 +359,11 @@ k_inbreed_eval_lut(const uint32_t* __restrict__ gt, uint64_t dwords_per_row, uin
   const uint64_t s_end = s_begin + loci_per_seg < n_sel ? s_begin + loci_per_seg : n_sel;
   const uint32_t stride = sweep_stride(amax);
   const uint64_t col = (g0 >> 2) + lane * DW;              // g0 is a multiple of GPL
+  const uint32_t four = 4u;
 
-  double F[MODE == 3 ? 1 : GPL], acc[MODE == 1 ? GPL : 1], run_a[GPL], run_b[MODE == 2 ? 1 : GPL];
-  int expo[MODE == 2 ? GPL : 1];   // MODE 2: run_a = product;  MODE 1: run_a / run_b = N / D;  MODE 3: run_a = sum, run_b = count
+  double F[MODE == 3 ? 1 : GPL], acc[MODE == 1 ? GPL : 1], run_a[GPL], run_b[MODE == 1 ? GPL : 1];
+  int expo[MODE == 2 ? GPL : 1];   // MODE 2: run_a = product;  MODE 1: run_a / run_b = N / D;  MODE 3: run_a = Ritland sum
+  uint32_t cnt_lo[MODE == 3 ? GPL : 1], cnt_hi[MODE == 3 ? GPL : 1];   // MODE 3: packed class counters (see above)
 #pragma unroll
   for (int j = 0; j < GPL; ++j) {
     const uint64_t g = lane * GPL + j;
@@ -328,13 +375,14 @@ k_inbreed_eval_lut(const uint32_t* __restrict__ gt, uint64_t dwords_per_row, uin
     } else if constexpr (MODE == 2) {
       expo[j] = 0;
     } else {
-      run_b[j] = 0.0;
+      cnt_lo[j] = cnt_hi[j] = 0u;
     }
   }
 
-  for (uint32_t e = threadIdx.x; e < 2u * kEvalBatch * kEvalSlots; e += kBlock) {
+  for (uint32_t e = threadIdx.x; e < 2u * kEvalBatch * kEvalSlots; e += blockDim.x) {
     (&lut[0][0] + e)->y = MODE == 3 ? 0.0 : 1.0;
-    (&lut[0][0] + e)->d = 0.0;
+    // MODE 3: a byte past the table is counted as nothing but is odd wherever the locus has defaults
+    (&lut[0][0] + e)->d = MODE == 3 ? __builtin_bit_cast(double, (static_cast<uint64_t>(kOddCell) << 32) | kOddOutside) : 0.0;
   }
   // stage(batch): thread t < 8*stride carries one double of the batch's contiguous table rows, t < 8 one valid[] flag
   double staged_row = 0.0;
@@ -351,48 +399,72 @@ k_inbreed_eval_lut(const uint32_t* __restrict__ gt, uint64_t dwords_per_row, uin
     if (threadIdx.x < kEvalBatch * stride) rows[rb][threadIdx.x] = staged_row;
     if (threadIdx.x < kEvalBatch) flags[rb][threadIdx.x] = staged_flag;
   };
-  fetch(s_begin);
-  stash(0);
-  fetch(s_begin + kEvalBatch);
-  stash(1);
-  __syncthreads();
-  build_eval_table<MODE, BITS>(lut[0], rows[0], flags[0], stride, amax, phased != 0, &upper_binds[0], 1u);
-  __syncthreads();
-  int buf = 0;
-  int batches_open = 0;            // batches since the running fraction / product was last closed
-  for (uint64_t s0 = s_begin; s0 < s_end; s0 += kEvalBatch, buf ^= 1) {
-    uint32_t w[kEvalBatch][DW];
+  // the genotype words of one batch: past the segment a word that contributes nothing (MODE 3: byte 0 of a locus whose
+  // flag is 0 -- an all-zero entry; else a byte past every table: (1, 0))
+  auto load_words = [&](uint64_t s0, uint32_t (&w)[kEvalBatch][DW]) {
 #pragma unroll
     for (int i = 0; i < kEvalBatch; ++i) {
       const uint64_t s = s0 + i;
 #pragma unroll
-      for (int k = 0; k < DW; ++k) w[i][k] = 0x08080808u;  // past the segment: unclassified
+      for (int k = 0; k < DW; ++k) w[i][k] = MODE == 3 ? 0u : 0x08080808u;
       if (active && s < s_end) {
         const uint64_t l = locus_index ? static_cast<uint64_t>(locus_index[s]) : s;
         const uint32_t* src = gt + l * dwords_per_row + col;
         if constexpr (DW == 1) {
           w[i][0] = __builtin_nontemporal_load(src);
-        } else if constexpr (DW == 2) {
+        } else {
           typedef uint32_t v2u __attribute__((ext_vector_type(2)));
           const v2u v = __builtin_nontemporal_load(reinterpret_cast<const v2u*>(src));
           w[i][0] = v.x; w[i][1] = v.y;
-        } else {
-          const kgx_v4u v = __builtin_nontemporal_load(reinterpret_cast<const kgx_v4u*>(src));
-          w[i][0] = v.x; w[i][1] = v.y; w[i][2] = v.z; w[i][3] = v.w;
         }
       }
     }
+  };
+  // (the padding words are their own swizzle: 0x08 has no high-nibble bits, 0 neither)
+  fetch(s_begin);
+  stash(0);
+  fetch(s_begin + kEvalBatch);
+  stash(1);
+  uint32_t w[kEvalBatch][DW], w_next[kEvalBatch][DW];
+  load_words(s_begin, w);
+  __syncthreads();
+  build_eval_table<MODE>(lut[0], rows[0], flags[0], stride, amax, phased != 0, &upper_binds[0], 1u);
+  __syncthreads();
+  int batches_open = 0;            // batches since the running fraction / product was last closed
+
+  // One batch, its table in lut[BUF] (a compile-time buffer: the table's LDS address folds into the read's offset).
+  auto batch = [&](auto buf_c, uint64_t s0) {
+    constexpr int BUF = decltype(buf_c)::value;
+    load_words(s0 + kEvalBatch, w_next);
     fetch(s0 + 2 * kEvalBatch);
     const uint32_t batch_tag = static_cast<uint32_t>((s0 - s_begin) / kEvalBatch) + 1u;
-    const bool clamp_above = MODE == 2 && upper_binds[buf] == batch_tag;          // block-uniform; written before the last barrier
+    const bool clamp_above = MODE == 2 && upper_binds[BUF] == batch_tag;          // block-uniform; written before the last barrier
     if (s0 + kEvalBatch < s_end)
-      build_eval_table<MODE, BITS>(lut[buf ^ 1], rows[buf ^ 1], flags[buf ^ 1], stride, amax, phased != 0, &upper_binds[buf ^ 1], batch_tag + 1u);
+      build_eval_table<MODE>(lut[BUF ^ 1], rows[BUF ^ 1], flags[BUF ^ 1], stride, amax, phased != 0, &upper_binds[BUF ^ 1], batch_tag + 1u);
     if (active) {
-      const EvalEntry* __restrict__ cur = lut[buf];
-      // A cell's table entry: slot a1 + 20*a2 of its locus (bit 7 of the byte folded onto bit 3: "unclassified").
-      auto slots_of = [](uint32_t x) {
-        const uint32_t xf = (x & 0x7F7F7F7Fu) | ((x >> 4) & 0x08080808u);
-        return xf + ((xf >> 2) & 0x1C1C1C1Cu);                             // a1 + 16*a2 + 4*a2 per byte, < 156: no carry
+      const char* __restrict__ cur = reinterpret_cast<const char*>(&lut[BUF][0]);
+      auto entry = [&](int i, uint32_t offset) {
+        return *reinterpret_cast<const EvalEntry*>(cur + i * static_cast<int>(kEvalSlots * sizeof(EvalEntry)) + offset);
+      };
+      // The cells of the batch, a locus (GPL table reads) at a time: the reads of a locus are issued together, then its
+      // arithmetic; the scheduling barrier keeps the compiler from hoisting every read of the batch to the front
+      // (32 reads x 4 registers: it spills at four waves per SIMD, and four waves hide the LDS latency anyway).
+      auto for_each_cell = [&](auto&& fn) {
+#pragma unroll
+        for (int i = 0; i < kEvalBatch; ++i) {
+          EvalEntry e[GPL];
+#pragma unroll
+          for (int k = 0; k < DW; ++k) {
+            const uint32_t slots = swizzle_bytes(w[i][k]);
+            e[4 * k + 0] = entry(i, byte_times_16<0>(slots, four));
+            e[4 * k + 1] = entry(i, byte_times_16<1>(slots, four));
+            e[4 * k + 2] = entry(i, byte_times_16<2>(slots, four));
+            e[4 * k + 3] = entry(i, byte_times_16<3>(slots, four));
+          }
+#pragma unroll
+          for (int j = 0; j < GPL; ++j) fn(j, e[j], i);
+          __builtin_amdgcn_sched_barrier(0);
+        }
       };
       if constexpr (MODE == 2) {
         // The clamp of logLikelihood (:117-121).  For -1 <= F <= 1 (the search interval) its upper bound cannot bind on a
@@ -400,42 +472,56 @@ k_inbreed_eval_lut(const uint32_t* __restrict__ gt, uint64_t dwords_per_row, uin
         // unclassified one (1, 0); on a heterozygous cell, 2*(1-F)*f1*f2 <= 4*f1*f2, only if y > 1/2.  So the batch's
         // cells are compiled twice, and the form with the fp64 min per cell runs only where build_eval_table saw such an
         // entry (one block-uniform branch per batch).
-        auto walk_cells = [&](auto above_c) {
-          constexpr bool kClampAbove = decltype(above_c)::value;
-#pragma unroll
-          for (int i = 0; i < kEvalBatch; ++i) {
-#pragma unroll
-            for (int k = 0; k < DW; ++k) {
-              const uint32_t slots = slots_of(w[i][k]);
-#pragma unroll
-              for (int b = 0; b < 4; ++b) {
-                const int j = 4 * k + b;
-                const EvalEntry e = cur[i * kEvalSlots + ((slots >> (8 * b)) & 0xFFu)];
-                const double floored = __builtin_fmax(__builtin_fma(F[MODE == 3 ? 0 : j], e.d, e.y), 1e-10);
-                run_a[j] *= kClampAbove ? __builtin_fmin(floored, 1.0) : floored;
-              }
-            }
-          }
-        };
-        if (clamp_above) walk_cells(std::true_type{});
-        else walk_cells(std::false_type{});
+        if (clamp_above)
+          for_each_cell([&](int j, const EvalEntry e, int) { run_a[j] *= __builtin_fmin(__builtin_fmax(__builtin_fma(F[j], e.d, e.y), 1e-10), 1.0); });
+        else
+          for_each_cell([&](int j, const EvalEntry e, int) { run_a[j] *= __builtin_fmax(__builtin_fma(F[j], e.d, e.y), 1e-10); });
+      } else if constexpr (MODE == 1) {
+        for_each_cell([&](int j, const EvalEntry e, int) {
+          const double v = __builtin_fma(F[j], e.d, e.y);
+          run_a[j] = __builtin_fma(run_a[j], v, run_b[j]);
+          run_b[j] *= v;
+        });
       } else {
+        for_each_cell([&](int j, const EvalEntry e, int) {
+          run_a[j] += e.y;
+          const uint64_t packed = __builtin_bit_cast(uint64_t, e.d);
+          cnt_lo[j] += static_cast<uint32_t>(packed);
+          cnt_hi[j] += static_cast<uint32_t>(packed >> 32);
+        });
+        uint32_t seen = 0;
 #pragma unroll
-        for (int i = 0; i < kEvalBatch; ++i) {
+        for (int j = 0; j < GPL; ++j) seen |= cnt_hi[j];
+        if (__any((seen >> 28) != 0u)) {                    // some lane of the wave met an odd cell in this batch
 #pragma unroll
-          for (int k = 0; k < DW; ++k) {
-            const uint32_t slots = slots_of(w[i][k]);
-#pragma unroll
-            for (int b = 0; b < 4; ++b) {
-              const int j = 4 * k + b;
-              const EvalEntry e = cur[i * kEvalSlots + ((slots >> (8 * b)) & 0xFFu)];
-              if constexpr (MODE == 3) {
-                run_a[j] += e.y;
-                run_b[j] += e.d;
-              } else {
-                const double v = __builtin_fma(F[MODE == 3 ? 0 : j], e.d, e.y);
-                run_a[j] = __builtin_fma(run_a[j], v, run_b[j]);
-                run_b[j] *= v;
+          for (int j = 0; j < GPL; ++j) cnt_hi[j] &= kOddCell - 1u;
+          // The lanes that met one look at their 32 cells of the batch once more, this time for what is odd about them: an
+          // odd cell adjusts the lane's own (segment, genome) partial slot in memory (single writer) or the genome's
+          // Ritland count.  Rolled loops over bytes re-read from the matrix (L2 hits), entries re-read from LDS.
+          if ((seen >> 28) != 0u) {
+#pragma nounroll
+            for (int i = 0; i < kEvalBatch; ++i) {
+              const uint64_t s = s0 + i;
+              if (s >= s_end) break;
+              // the locus's row from memory, not from rows[BUF]: a faster wave may already have stashed the batch after
+              // next's rows there (only the table build reads those, behind the barrier)
+              const uint8_t flag = valid[s];
+              const double* row = table + s * stride;
+              const uint64_t l = locus_index ? static_cast<uint64_t>(locus_index[s]) : s;
+              const uint8_t* bytes = reinterpret_cast<const uint8_t*>(gt + l * dwords_per_row + col);
+#pragma nounroll
+              for (int j = 0; j < GPL; ++j) {
+                const uint64_t g = lane * GPL + j;
+                if (g >= n_genomes) break;
+                const uint32_t odd = static_cast<uint32_t>(__builtin_bit_cast(uint64_t, lut[BUF][i * kEvalSlots + eval_slot(bytes[j])].d)) >> 24;
+                if (odd == 0u) continue;
+                const double sign = (odd & (kOddMinus >> 24)) ? -1.0 : (odd & (kOddPlus >> 24)) ? 1.0
+                                    : ((odd & (kOddOutside >> 24)) && (flag & kLocusDefault)) ? -1.0 : 0.0;
+                if (sign != 0.0) {
+                  double* p = part + (seg * n_genomes + g) * kParts0;
+                  p[0] += sign * row[amax + 1]; p[1] += sign * row[amax + 2]; p[2] += sign * row[amax + 3]; p[3] += sign * row[amax + 4];
+                }
+                if (odd & (kOddNoRitland >> 24)) atomicAdd(&counts[g * 6 + 5], ~0ull);       // counted with the classes, not by Ritland
               }
             }
           }
@@ -443,8 +529,8 @@ k_inbreed_eval_lut(const uint32_t* __restrict__ gt, uint64_t dwords_per_row, uin
       }
       // MODE 1: the fraction N/D runs on over up to kHallBatches batches before its one division -- the division is a
       // dozen fp64 instructions, a quarter of the pass when taken every 8 cells.  D is a product of denominators
-      // F + (1-F)*f1 <= 1 and shrinks; a lane whose D has fallen below 1e-100 divides at once (8 more factors would
-      // have to average 1e-26 to take it under).  The last batch of the segment always divides.
+      // F + (1-F)*f1 <= 1 and shrinks; a lane whose D has fallen below 1e-100 divides at once (4 more factors would
+      // have to average 1e-50 to take it under).  The last batch of the segment always divides.
       const bool closing = s0 + kEvalBatch >= s_end;            // block-uniform
       ++batches_open;
 #pragma unroll
@@ -462,8 +548,16 @@ k_inbreed_eval_lut(const uint32_t* __restrict__ gt, uint64_t dwords_per_row, uin
       }
       if (closing || batches_open >= kHallBatches) batches_open = 0;
     }
-    stash(buf);          // rows[buf] fed this batch's table one iteration ago: free for the batch after next
+    stash(BUF);          // rows[BUF] fed this batch's table one iteration ago: free for the batch after next
     __syncthreads();
+#pragma unroll
+    for (int i = 0; i < kEvalBatch; ++i)
+#pragma unroll
+      for (int k = 0; k < DW; ++k) w[i][k] = w_next[i][k];
+  };
+  for (uint64_t s0 = s_begin; s0 < s_end; s0 += 2 * kEvalBatch) {
+    batch(std::integral_constant<int, 0>{}, s0);
+    if (s0 + kEvalBatch < s_end) batch(std::integral_constant<int, 1>{}, s0 + kEvalBatch);
   }
 
   if (!active) return;
@@ -477,8 +571,15 @@ k_inbreed_eval_lut(const uint32_t* __restrict__ gt, uint64_t dwords_per_row, uin
       part[seg * n_genomes + g] = acc[j];
     } else {
       part[(seg * n_genomes + g) * kParts0 + 4] = run_a[j];
-      const unsigned long long counted = static_cast<unsigned long long>(run_b[j]);
-      if (counted) atomicAdd(&counts[g * 6 + 5], counted);
+      const unsigned long long major_hom = cnt_lo[j] & 0xFFFu, major_het = (cnt_lo[j] >> 12) & 0xFFFu;
+      const unsigned long long minor_hom = cnt_hi[j] & 0xFFFu, minor_het = (cnt_hi[j] >> 12) & 0xFFFu;
+      const unsigned long long total = major_hom + major_het + minor_hom + minor_het;
+      unsigned long long* c = counts + g * 6;
+      if (major_hom) atomicAdd(c + 0, major_hom);
+      if (major_het) atomicAdd(c + 1, major_het);
+      if (minor_hom) atomicAdd(c + 2, minor_hom);
+      if (minor_het) atomicAdd(c + 3, minor_het);
+      if (total) { atomicAdd(c + 4, total); atomicAdd(c + 5, total); }      // Ritland counts every classified cell but the few taken off above
     }
   }
 }
@@ -1032,7 +1133,10 @@ k_seq_block_quantize(const double* __restrict__ table, const uint8_t* __restrict
 
 // One workgroup of four waves, wave k the running sum of class frequency k over all blocks in order (see above).
 // out[0..3] = the four sums, out[4] = 0 (the Ritland slot of a kParts0 row).  Everything a wave decides on is
-// wave-uniform: every lane carries the same running sum.
+// wave-uniform: every lane carries the same running sum.  Blocks go 64 at a time: where all 64 share one predicted
+// binade their integer sums are added up across the lanes and taken in one step (every partial sum lies between the two
+// ends, so it stays in the binade as well); otherwise block by block; a block that has to be walked has its 1024 values
+// fetched first (16 loads in flight) and then added one by one, as the reference adds them.
 __global__ void __launch_bounds__(kBlock)
 k_seq_chain(const double* __restrict__ table, const uint8_t* __restrict__ flags, uint64_t n_sel, uint32_t amax,
             const int* __restrict__ e_pred, const long long* __restrict__ block_n, uint64_t n_blocks, double* __restrict__ out /* [kParts0] */) {
@@ -1040,27 +1144,37 @@ k_seq_chain(const double* __restrict__ table, const uint8_t* __restrict__ flags,
   const uint32_t lane = threadIdx.x & (kWave - 1);
   const uint32_t stride = sweep_stride(amax);
   double running = 0.0;
+  auto take = [&](int e, long long n) {                    // add n ulps of binade e if the sum is in that binade before and after
+    if (e == kSeqWalk || !(running > 0.0) || ilogb(running) != e) return false;
+    const double next = running + ldexp(static_cast<double>(n), e - 52);        // exact while it stays in the binade
+    if (ilogb(next) != e) return false;
+    running = next;
+    return true;
+  };
   for (uint64_t b0 = 0; b0 < n_blocks; b0 += kWave) {
     const uint64_t mine = b0 + lane;
     const int e_lane = mine < n_blocks ? e_pred[mine * 4 + k] : kSeqWalk;
     const long long n_lane = mine < n_blocks ? block_n[mine * 4 + k] : 0;
     const int in_batch = static_cast<int>(n_blocks - b0 < static_cast<uint64_t>(kWave) ? n_blocks - b0 : kWave);
+    const int e_first = __shfl(e_lane, 0, kWave);
+    if (in_batch == kWave && e_first != kSeqWalk && __all(e_lane == e_first)) {
+      long long total = n_lane;
+      for (int off = 32; off > 0; off >>= 1) total += __shfl_xor(total, off, kWave);
+      if (total < (1ll << 52) && take(e_first, total)) continue;
+    }
     for (int i = 0; i < in_batch; ++i) {
-      const int e = __shfl(e_lane, i, kWave);
-      const long long n = __shfl(n_lane, i, kWave);
-      bool walked = true;
-      if (e != kSeqWalk && running > 0.0 && ilogb(running) == e) {
-        const double next = running + ldexp(static_cast<double>(n), e - 52);     // exact while it stays in the binade
-        if (ilogb(next) == e) { running = next; walked = false; }
+      if (take(__shfl(e_lane, i, kWave), __shfl(n_lane, i, kWave))) continue;
+      // the reference's own loop over this block's loci
+      const uint64_t s0 = (b0 + i) * static_cast<uint64_t>(kSeqBlock);
+      double x[kSeqBlock / kWave];
+#pragma unroll
+      for (int c = 0; c < kSeqBlock / kWave; ++c) {
+        const uint64_t s = s0 + static_cast<uint64_t>(c) * kWave + lane;
+        x[c] = (s < n_sel && (flags[s] & kLocusDefault)) ? table[s * stride + amax + 1 + k] : 0.0;
       }
-      if (walked) {                                         // the reference's own loop over this block's loci
-        const uint64_t s0 = (b0 + i) * static_cast<uint64_t>(kSeqBlock);
-        for (uint64_t c = 0; c < static_cast<uint64_t>(kSeqBlock); c += kWave) {
-          const uint64_t s = s0 + c + lane;
-          const double x = (s < n_sel && (flags[s] & kLocusDefault)) ? table[s * stride + amax + 1 + k] : 0.0;
-          for (int j = 0; j < kWave; ++j) running += __shfl(x, j, kWave);       // + 0.0 where no default locus: exact
-        }
-      }
+#pragma unroll
+      for (int c = 0; c < kSeqBlock / kWave; ++c)
+        for (int j = 0; j < kWave; ++j) running += __shfl(x[c], j, kWave);      // + 0.0 where no default locus: exact
     }
   }
   if (lane == 0) out[k] = running;

@@ -141,6 +141,9 @@ Device::~Device() {
   if (ready) (void)hipEventDestroy(ready);
   if (by_genome_begin) (void)hipEventDestroy(by_genome_begin);
   if (by_genome_end) (void)hipEventDestroy(by_genome_end);
+  if (side_begin) (void)hipEventDestroy(side_begin);
+  if (side_end) (void)hipEventDestroy(side_end);
+  if (side_stream) (void)hipStreamDestroy(side_stream);
   if (stream) (void)hipStreamDestroy(stream);
 }
 
@@ -268,6 +271,9 @@ int kgx_init(int device_count, const int* device_ids) {
     std::snprintf(dev->name, sizeof(dev->name), "%s", prop.name);
     std::snprintf(dev->arch, sizeof(dev->arch), "%s", prop.gcnArchName);
     KGX_HIP(hipStreamCreateWithFlags(&dev->stream, hipStreamNonBlocking));
+    KGX_HIP(hipStreamCreateWithFlags(&dev->side_stream, hipStreamNonBlocking));
+    KGX_HIP(hipEventCreateWithFlags(&dev->side_begin, hipEventDisableTiming));
+    KGX_HIP(hipEventCreateWithFlags(&dev->side_end, hipEventDisableTiming));
     KGX_HIP(hipEventCreate(&dev->sweep_begin));
     KGX_HIP(hipEventCreate(&dev->sweep_end));
     KGX_HIP(hipEventCreateWithFlags(&dev->ready, hipEventDisableTiming));

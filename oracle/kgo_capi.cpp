@@ -4,6 +4,8 @@
 #include <cstdlib>
 #include <cstring>
 #include <sstream>
+#include <set>
+#include <fstream>
 #include <thread>
 
 #include "kgo_analysis.h"
@@ -643,6 +645,45 @@ int kgo_inbreed_window(kgo_pop* reference, kgo_pop* diploid, const int32_t* supe
   return 0;
 }
 
+// logLikelihood (_calc.cpp:94-129) of every genome at a caller-chosen coefficient: the objective processLogLikelihood
+// maximises, over the same window and locus lists as kgo_inbreed_window.  f[G] / out[G] in genome-id order.
+int kgo_loglikelihood_at(kgo_pop* reference, kgo_pop* diploid, const int32_t* super_pop_of_genome, uint64_t lower, uint64_t upper,
+                         uint64_t spacing, double min_af, double max_af, const double* f, double* out) {
+  if (!reference || !diploid || !f || !out) return -1;
+  if (reference->pop->getMap().size() != 1) return -1;
+  const auto& ref_genome = reference->pop->getMap().begin()->second;
+  if (ref_genome->getMap().size() != 1) return -1;
+  const auto& [contig_id, contig_ptr] = *ref_genome->getMap().begin();
+  LociiVectorArguments args;
+  args.lower_offset = lower; args.upper_offset = upper; args.spacing = spacing;
+  args.allele_frequency_min = std::clamp(min_af, 0.0, 1.0);
+  args.allele_frequency_max = std::clamp(max_af, 0.0, 1.0);
+  std::map<int, std::shared_ptr<const ContigDB>> locus_map;
+  WorkflowThreads thread_pool(poolThreads(diploid->pop->getMap().size()));
+  std::vector<std::future<double>> futures;
+  std::vector<size_t> slot;
+  size_t g = 0;
+  for (const auto& [id, genome] : diploid->pop->getMap()) {
+    const int sp = super_pop_of_genome[g];
+    auto contig_opt = genome->getContig(contig_id);
+    if (sp >= 0 && contig_opt) {
+      if (!locus_map.count(sp)) locus_map[sp] = getLocusList(*contig_ptr, sp, args);
+      std::shared_ptr<const ContigDB> contig = contig_opt.value();
+      std::shared_ptr<const ContigDB> locus_list = locus_map[sp];
+      const std::string gid = id;
+      const double coefficient = f[g];
+      futures.push_back(thread_pool.enqueueFuture([=]() {
+        auto [frequency_vector, locus_results] = generateFrequencies(gid, *contig, sp, *locus_list);
+        return logLikelihood(coefficient, frequency_vector);
+      }));
+      slot.push_back(g);
+    }
+    ++g;
+  }
+  for (size_t i = 0; i < futures.size(); ++i) out[slot[i]] = futures[i].get();
+  return 0;
+}
+
 // Dense tier of one window (oracle/kgo_inbreed_dense.cpp): every genome of allele_pairs [n_records][n_genomes][2]
 // (raw GT allele indices of the record at record_offsets[r]) against the locus list of `super_pop` from [lower, upper].
 // counts_out [G][5] as kgo_inbreed_window; freqs_out [G][6] = the four class-frequency sums, Simple, RitlandLocus.
@@ -689,6 +730,45 @@ kgo_columns* kgo_population_inbreeding(kgo_pop* reference, kgo_pop* diploid, con
   }
   out->columns = populationInbreeding(*reference->pop, *diploid->pop, sp_map, params);
   return out;
+}
+
+// InbreedingOutput::writePedResults (kga_analysis_inbreed_output.cpp:188-305) on the columns of a window loop, the way
+// InbreedAnalysis::finalizeAnalysis calls it (kga_analysis_inbreed.cpp:140-142).  ped: n_ped rows of 9 strings
+// { genome, population, population description, super population, super description, relationship, sex, maternal id,
+// paternal id } -- the HsGenealogyRecord fields the writer prints.  Same header lines, default stream formatting and the
+// trailing delimiter after the last column as the reference.
+int kgo_columns_write_ped(kgo_columns* c, const char* path, const char* param_ident, const char* algorithm, double min_af, double max_af,
+                          uint64_t spacing, uint64_t count, const char* const* ped, uint64_t n_ped) {
+  if (!c || !path || !param_ident || !algorithm || c->columns.empty()) return -1;
+  constexpr char DELIMITER_ = ',';
+  std::map<std::string, const char* const*> ped_of;
+  for (uint64_t i = 0; i < n_ped; ++i) ped_of[ped[i * 9]] = ped + i * 9;
+  std::ofstream outfile(path, std::ofstream::out | std::ofstream::trunc);
+  if (!outfile.good()) return -1;
+  outfile << param_ident << DELIMITER_ << "Algorithm:" << algorithm << DELIMITER_ << "Min_AF:" << std::clamp(min_af, 0.0, 1.0) << DELIMITER_
+          << "Max_AF:" << std::clamp(max_af, 0.0, 1.0) << DELIMITER_ << "Spacing:" << spacing << DELIMITER_ << "Count:" << count << '\n';
+  outfile << "Sample" << DELIMITER_ << "Population" << DELIMITER_ << "Description" << DELIMITER_ << "SuperPopulation" << DELIMITER_ << "Description"
+          << DELIMITER_ << "Relationship" << DELIMITER_ << "Sex" << DELIMITER_ << "Mother" << DELIMITER_ << "Father";
+  for (const auto& column : c->columns) outfile << DELIMITER_ << column.first;
+  outfile << '\n';
+  std::set<std::string> genome_set;
+  for (const auto& [genome, data] : c->columns.front().second) genome_set.insert(genome);
+  for (const auto& genome_id : genome_set) {
+    auto record = ped_of.find(genome_id);
+    if (record == ped_of.end()) continue;                 // "does not have a PED record" (:263-268)
+    const char* const* f = record->second;
+    outfile << genome_id << DELIMITER_;
+    for (int k = 1; k <= 4; ++k) outfile << f[k] << DELIMITER_;        // population, description, super population, description
+    outfile << f[5] << DELIMITER_ << f[6] << DELIMITER_ << f[7] << DELIMITER_ << f[8] << DELIMITER_;   // relationship, sex, mother, father
+    for (const auto& column : c->columns) {
+      auto find_result = column.second.find(genome_id);
+      if (find_result == column.second.end()) return -2;
+      outfile << find_result->second.inbred_allele_sum << DELIMITER_;
+    }
+    outfile << '\n';
+  }
+  outfile.flush();
+  return 0;
 }
 
 void kgo_columns_destroy(kgo_columns* c) { delete c; }

@@ -75,9 +75,11 @@ def lib() -> C.CDLL:
         "kgo_class_frequencies": (C.c_int, [vp, C.c_uint32, dbl, C.c_int, vp]),
         "kgo_sample_locii": (i64, [vp, C.c_int, C.c_int, u64, u64, u64, u64, dbl, dbl, vp, u64]),
         "kgo_inbreed_window": (C.c_int, [vp, vp, vp, C.c_char_p, u64, u64, u64, u64, dbl, dbl, u64, vp, vp, vp, vp]),
+        "kgo_loglikelihood_at": (C.c_int, [vp, vp, vp, u64, u64, u64, dbl, dbl, vp, vp]),
         "kgo_inbreed_dense": (C.c_int, [vp, vp, C.c_int, u64, u64, u64, dbl, dbl, vp, u64, vp, u64, C.c_int, vp, vp, vp]),
         "kgo_population_inbreeding": (vp, [vp, vp, vp, C.c_char_p, u64, u64, u64, u64, dbl, dbl, u64]),
         "kgo_columns_destroy": (None, [vp]),
+        "kgo_columns_write_ped": (C.c_int, [vp, C.c_char_p, C.c_char_p, C.c_char_p, dbl, dbl, u64, u64, vp, u64]),
         "kgo_columns_count": (u64, [vp]),
         "kgo_columns_ident": (C.c_int, [vp, u64, C.c_char_p, C.c_size_t]),
         "kgo_columns_results": (C.c_int, [vp, u64, vp, vp, vp]),
@@ -397,6 +399,15 @@ def inbreed_window(reference: Population, diploid: Population, super_pop_of_geno
     return counts, freqs, present.astype(bool), sec.value
 
 
+def loglikelihood_at(reference: Population, diploid: Population, super_pop_of_genome, lower, upper, spacing, min_af, max_af, f):
+    """logLikelihood (_calc.cpp:94-129) of every genome at its own coefficient f[g] (genome-id order), over the window's locus list."""
+    sp = np.ascontiguousarray(super_pop_of_genome, dtype=np.int32)
+    f = np.ascontiguousarray(f, dtype=np.float64)
+    out = np.full(len(f), np.nan)
+    assert lib().kgo_loglikelihood_at(reference.handle, diploid.handle, _p(sp), lower, upper, spacing, min_af, max_af, _p(f), _p(out)) == 0
+    return out
+
+
 def inbreed_dense(reference_all: Population, reference_snp_pass: Population, super_pop, lower, upper, spacing, min_af, max_af,
                   record_offsets, allele_pairs, phased=True):
     """The oracle's dense tier (oracle/kgo_inbreed_dense.cpp): generateFrequencies + Simple + RitlandLocus for genomes given
@@ -416,7 +427,10 @@ def inbreed_dense(reference_all: Population, reference_snp_pass: Population, sup
 
 
 def population_inbreeding(reference: Population, diploid: Population, super_pop_of_genome, algorithm, lower, upper,
-                          spacing, count, min_af, max_af, seed=0):
+                          spacing, count, min_af, max_af, seed=0, ped_file=None):
+    """ped_file = (path, param_ident, ped_rows): also write the reference's PED result file (InbreedingOutput::writePedResults)
+    from the columns; ped_rows = per genome the 9 strings genome, population, description, super population, description,
+    relationship, sex, mother, father."""
     G = diploid.genome_count()
     sp = np.ascontiguousarray(super_pop_of_genome, dtype=np.int32)
     h = lib().kgo_population_inbreeding(reference.handle, diploid.handle, _p(sp), algorithm.encode(), lower, upper,
@@ -424,6 +438,13 @@ def population_inbreeding(reference: Population, diploid: Population, super_pop_
     assert h
     cols = []
     try:
+        if ped_file is not None:
+            path, ident, rows = ped_file
+            flat = _strs([x for row in rows for x in row])
+            assert all(len(row) == 9 for row in rows)
+            rc = lib().kgo_columns_write_ped(h, str(path).encode(), ident.encode(), algorithm.encode(), min_af, max_af, spacing, count,
+                                             C.cast(flat, C.c_void_p), len(rows))
+            assert rc == 0, rc
         for i in range(int(lib().kgo_columns_count(h))):
             buf = C.create_string_buffer(256)
             lib().kgo_columns_ident(h, i, buf, 256)

@@ -58,7 +58,7 @@ def test_sharded_dosage_sweeps_equal_the_unsharded_ones(kgx, rebind, slots, G):
     got = dosage_results(kgx, G, V, codes, bins, 11, groups)
     shards = got["shards"]
     assert len(shards) == slots and sum(s["n_genomes"] for s in shards) == G
-    assert all(s["genome_base"] % 64 == 0 for s in shards)
+    assert all(s["genome_base"] % 64 == 0 for s in shards if s["n_genomes"])
     assert [s["genome_base"] for s in shards] == list(np.cumsum([0] + [s["n_genomes"] for s in shards[:-1]]))
     for key in ("rows", "k2", "k4", "k3", "k3_binned", "k8"):
         assert np.array_equal(got[key], want[key]), key
@@ -145,7 +145,7 @@ def test_sharded_inbreeding_equals_the_unsharded_one(kgx, rebind, algorithm):
     rebind([0, 0, 0])
     many = kgx.GenotypeMatrix(G, L)
     shards = many.shards
-    assert len(shards) == 3 and sum(s["n_genomes"] for s in shards) == G and all(s["genome_base"] % 128 == 0 for s in shards)
+    assert len(shards) == 3 and sum(s["n_genomes"] for s in shards) == G and all(s["genome_base"] % 128 == 0 for s in shards if s["n_genomes"])
     table2 = many.synth_multiallelic(1111, 0, 0)
     assert np.array_equal(many.read_rows(), want_rows)
     assert np.array_equal(np.nan_to_num(table2), np.nan_to_num(table))

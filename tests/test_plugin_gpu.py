@@ -122,7 +122,8 @@ def test_gpu_inbreed_package_matches_oracle_window_loop(tmp_path, kgx, algorithm
     # the summary CSV: header line, one column per window with the reference's ident contig_lower_upper
     lines = (tmp_path / "inbreed.csv").read_text().strip().split("\n")
     assert lines[0].startswith("DriverParameters,Algorithm:" + algorithm)
-    assert lines[1].split(",")[2:] == [c[0] for c in cols]
+    assert lines[1].split(",")[:9] == ["Sample", "Population", "Description", "SuperPopulation", "Description", "Relationship", "Sex", "Mother", "Father"]
+    assert lines[1].split(",")[9:] == [c[0] for c in cols]
     assert len(lines) == 2 + int(np.sum(sp_of >= 0))
 
 
@@ -329,3 +330,89 @@ def test_gpu_allele_package_bins_each_copy_by_its_own_record(tmp_path, kgx, via)
     want = opop.hethom(rec.contig)
     got = np.array([[int(r[2]), int(r[3]), int(r[4]), int(r[7]), int(r[8]), int(r[6]), int(r[5])] for r in rows], dtype=np.uint64)
     assert np.array_equal(got, want)
+
+
+@pytest.mark.parametrize("algorithm", ["Simple", "RitlandLocus", "HallME", "Loglikelihood"])
+def test_gpu_inbreed_package_writes_the_reference_ped_file(tmp_path, kgx, algorithm):
+    """the result file of INBREED.  The package reads the reference's own PED file format (header +
+    15 tab-separated fields, ParseHsGenomeGenealogyFile) and writes InbreedingOutput::writePedResults' layout; the oracle
+    writes the same file from its own window loop with the reference's writer restated.  Byte for byte equal wherever the
+    coefficients agree past the six digits the reference prints (Simple, RitlandLocus, HallME); Loglikelihood's 1e-5 band
+    is compared field by field."""
+    G, L = 120, 2000
+    rec, gt = sv.multiallelic_block(G, L, rng_seed=33, missing_af_frac=0.02, dup_records=20)
+    for a in rec.af:
+        a[:, 4] = a[:, 5]
+    ids = sv.genome_ids(G, prefix="NA")
+    pops = [("ACB", "African Caribbean in Barbados", "AFR", "African"), ("MXL", "Mexican Ancestry in Los Angeles", "AMR", "American"),
+            ("CHB", "Han Chinese in Beijing", "EAS", "East Asian"), ("GBR", "British in England and Scotland", "EUR", "European"),
+            ("PJL", "Punjabi in Lahore", "SAS", "South Asian")]
+    ped_rows, ped_lines = [], ["Family ID\tIndividual ID\tPaternal ID\tMaternal ID\tGender\tPhenotype\tPopulation\tPopulation Description\t"
+                               "Super Population\tSuper Description\tRelationship\tSiblings\tSecond Order\tThird Order\tOther Comments"]
+    for i, g in enumerate(ids):
+        if i % 17 == 5:
+            continue                                          # no PED record: the genome is skipped by the sweep and the writer
+        pop, pop_desc, sp, sp_desc = pops[i % 5]
+        father, mother = (ids[i - 1], ids[i - 2]) if i % 9 == 8 else ("0", "0")
+        relationship = "child" if i % 9 == 8 else "unrel"
+        sex = "1" if i % 2 else "2"
+        ped_lines.append("\t".join([f"FAM{i // 3}", g, father, mother, sex, "0", pop, pop_desc, sp, sp_desc, relationship, "0", "0", "0", "0"]))
+        ped_rows.append([g, pop, pop_desc, sp, sp_desc, relationship, sex, mother, father])
+    ped_path = tmp_path / "samples.ped"
+    ped_path.write_text("\n".join(ped_lines) + "\n")
+    ref_path, dip_path = tmp_path / "gnomad.bin", tmp_path / "diploid.bin"
+    rio.write_records(ref_path, rec, None, ["Reference"], oa.Population.REFERENCE, "Gnomad2_1", population_id="Gnomad")
+    rio.write_records(dip_path, rec, gt, ids, oa.Population.PHASED, "Genome1000", population_id="Diploid")
+    params = dict(AnalysisType="false", OutputFile="inbreed", Algorithm=algorithm, MinAlleleFreq=0.02, MaxAlleleFreq=0.9,
+                  LowerWindow=0, UpperWindow=60000, LociiCount=150, SamplingDistance=40)
+    res = rio.run_driver("GPU_INBREED", tmp_path, [f"ped:{ped_path}", ref_path, dip_path], **params)
+    assert res.returncode == 0, res.stderr
+
+    ref = oa.Population("gnomad")
+    ref.add_genomes(["Reference"])
+    ref.add_records(rec, None, oa.Population.REFERENCE)
+    dip = sv.oracle_population(rec, gt, ids, oa.Population.PHASED)
+    sp_of_genome = {row[0]: oa.SUPER_POPS.index(row[3]) for row in ped_rows}
+    sp_of = np.array([sp_of_genome.get(g, -1) for g in sorted(ids)], dtype=np.int32)
+    want_path = tmp_path / "oracle_inbreed.csv"
+    cols = oa.population_inbreeding(ref.filter_snp_pass(), dip, sp_of, algorithm, 0, 60000, 40, 150, 0.02, 0.9, seed=oa.FIXED_STARTS,
+                                    ped_file=(want_path, "DriverParameters", ped_rows))
+    assert len(cols) >= 3
+    got_text, want_text = (tmp_path / "inbreed.csv").read_text(), want_path.read_text()
+    got_lines, want_lines = got_text.split("\n"), want_text.split("\n")
+    assert got_lines[:2] == want_lines[:2]                                       # parameter line and column header, verbatim
+    assert got_lines[1].startswith("Sample,Population,Description,SuperPopulation,Description,Relationship,Sex,Mother,Father,")
+    assert len(got_lines) == len(want_lines) == 2 + len(ped_rows) + 1           # header lines, one row per genome with a PED record, final newline
+    if algorithm != "Loglikelihood":
+        assert got_text == want_text
+    else:
+        for got_line, want_line in zip(got_lines[2:], want_lines[2:]):
+            g, w = got_line.split(","), want_line.split(",")
+            assert g[:9] == w[:9] and len(g) == len(w)
+            assert np.allclose([float(x) for x in g[9:-1]], [float(x) for x in w[9:-1]], rtol=0, atol=2e-5)
+
+
+def test_gpu_inbreed_package_synthetic_file_layout(tmp_path, kgx):
+    """AnalysisType=true: InbreedingOutput::writeSynthetic's file (kga_analysis_inbreed_output.cpp:308-395) -- Sample,
+    SynInbreed (decoded from the synthetic genome id), one CalcInbreed per window, trailing delimiter."""
+    rec, gt = sv.multiallelic_block(8, 3000, rng_seed=35, missing_af_frac=0.0, dup_records=0)
+    for a in rec.af:
+        a[:, 4] = a[:, 5]
+    ref_path = tmp_path / "gnomad.bin"
+    rio.write_records(ref_path, rec, None, ["Reference"], oa.Population.REFERENCE, "Gnomad2_1", population_id="Gnomad")
+    params = dict(AnalysisType="true", OutputFile="synthetic", Algorithm="Simple", MinAlleleFreq=0.02, MaxAlleleFreq=0.9,
+                  LowerWindow=0, UpperWindow=90000, LociiCount=400, SamplingDistance=20)
+    res = rio.run_driver("GPU_INBREED", tmp_path, [ref_path], **params)
+    assert res.returncode == 0, res.stderr
+    lines = (tmp_path / "synthetic.csv").read_text().split("\n")
+    assert lines[0] == "DriverParameters,Algorithm:Simple,Min_AF:0.02,Max_AF:0.9,Spacing:20,Count:400"
+    assert lines[1] == "Sample,SynInbreed,CalcInbreed"
+    rows = [ln.split(",") for ln in lines[2:] if ln]
+    assert len(rows) == 6 * 101 and all(r[-1] == "" for r in rows)
+    for r in rows[:50]:
+        encoded = r[0].split("_")[1]
+        want = -int(encoded[1:]) / 1e6 if encoded.startswith("N") else int(encoded) / 1e6
+        assert float(r[1]) == pytest.approx(want, abs=1e-6)
+    syn = np.array([float(r[1]) for r in rows])
+    calc = np.array([float(r[2]) for r in rows])
+    assert np.corrcoef(syn, calc)[0, 1] > 0.9
