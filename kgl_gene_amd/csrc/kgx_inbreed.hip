@@ -88,11 +88,9 @@ int inbreed_shard(kgx_gt8_shard& sh, uint64_t g0, uint64_t g1, const uint32_t* l
                       algorithm != KGX_ALGO_RITLAND_LOCUS;
   // The evaluation passes of HallME / Loglikelihood go through the per-batch LDS tables when the allele indices fit them.
   const bool eval_lut = !env_int("KGX_K5_GENERIC", 0) && !env_int("KGX_K5_NO_EVAL_LUT", 0) && amax <= 7;
-  // genomes per lane of the table passes: Loglikelihood 8 (a dwordx2 load per locus) where the group's alignment allows;
-  // HallME and RitlandLocus, whose per-genome state is wider, 4 -- what keeps each at four workgroups per CU
-  int eval_gpl = algorithm == KGX_ALGO_LOGLIKELIHOOD ? env_int("KGX_K5_EVAL_GPL", 8) : 4;
+  int eval_gpl = env_int("KGX_K5_EVAL_GPL", 8);            // genomes per lane: the widest load the group's alignment allows
   if (eval_gpl != 4 && eval_gpl != 8) eval_gpl = 8;
-  if (g0 & 7u) eval_gpl = 4;
+  while (eval_gpl > 4 && (g0 % static_cast<uint64_t>(eval_gpl)) != 0) eval_gpl /= 2;
   const uint32_t gx = static_cast<uint32_t>(((n + 3) / 4 + kBlock - 1) / kBlock);
   const uint32_t gx16 = static_cast<uint32_t>(((n + 15) / 16 + kBlock - 1) / kBlock);
   uint64_t n_seg = (static_cast<uint64_t>(dev.compute_units) * env_int("KGX_K5_BLOCKS_PER_CU", 8) + (swar16 ? gx16 : gx) - 1) / (swar16 ? gx16 : gx);
@@ -103,12 +101,13 @@ int inbreed_shard(kgx_gt8_shard& sh, uint64_t g0, uint64_t g1, const uint32_t* l
   uint64_t per_seg = n_sel ? (n_sel + n_seg - 1) / n_seg : 8;
   per_seg = (per_seg + 7) / 8 * 8;                                          // whole 8-locus batches per segment
   n_seg = n_sel ? (n_sel + per_seg - 1) / per_seg : 1;
-  // The table passes cut the loci for their own launch shape: 256-thread workgroups, 3 or 4 resident per CU, about eight
-  // rounds of them and never a workgroup more than that (a ninth, nearly empty round costs an eighth of the pass).
+  // The table passes cut the loci for their own launch shape: 256-thread workgroups of eval_gpl genomes per lane, two or
+  // three resident per CU (registers), about eight rounds of them and never a workgroup more than that (one more, nearly
+  // empty round costs an eighth of the pass).
   uint64_t eval_n_seg = n_seg, eval_per_seg = per_seg;
   if (eval_lut || ritland_lut) {
-    const uint64_t eval_gx = ((n + eval_gpl - 1) / eval_gpl + kEvalThreads - 1) / kEvalThreads;
-    const uint64_t resident = static_cast<uint64_t>(dev.compute_units) * 4u;
+    const uint64_t eval_gx = ((n + eval_gpl - 1) / eval_gpl + kBlock - 1) / kBlock;
+    const uint64_t resident = static_cast<uint64_t>(dev.compute_units) * static_cast<uint64_t>(env_int("KGX_K5_EVAL_RESIDENT", 2));
     uint64_t want = resident * static_cast<uint64_t>(env_int("KGX_K5_EVAL_ROUNDS", 8)) / eval_gx;
     if (want < 1) want = 1;
     if (want > 65535) want = 65535;
@@ -258,14 +257,23 @@ int inbreed_shard(kgx_gt8_shard& sh, uint64_t g0, uint64_t g1, const uint32_t* l
 #undef KGX_SWAR
       }
     } else if (eval_lut || mode == 3) {
-#define KGX_EVAL(M, GPL, WAVES)                                                                                                      \
-  hipLaunchKernelGGL((k_inbreed_eval_lut<M, GPL, WAVES>),                                                                            \
-                     dim3(static_cast<uint32_t>(((n + GPL - 1) / GPL + kEvalThreads - 1) / kEvalThreads), static_cast<uint32_t>(eval_n_seg)), \
-                     dim3(kEvalThreads), 0, st, gt32, dwords_per_row, g0, n, d_index, n_sel,                                         \
+#define KGX_EVAL(M, W, B)                                                                                                            \
+  hipLaunchKernelGGL((k_inbreed_eval_lut<M, W, B>),                                                                                  \
+                     dim3(static_cast<uint32_t>(((n + W - 1) / W + kBlock - 1) / kBlock), static_cast<uint32_t>(eval_n_seg)),        \
+                     dim3(kBlock), 0, st, gt32, dwords_per_row, g0, n, d_index, n_sel,                                               \
                      eval_per_seg, d_table, d_valid, amax, phased, d_f, d_part, d_counts)
-      if (mode == 1) KGX_EVAL(1, 4, 4);
-      else if (mode == 2) { if (eval_gpl == 8) KGX_EVAL(2, 8, 4); else KGX_EVAL(2, 4, 4); }
-      else KGX_EVAL(3, 4, 4);
+#define KGX_EVAL_BITS(M, W)                                                                \
+  do {                                                                                     \
+    if (amax <= 1) KGX_EVAL(M, W, 1); else if (amax <= 3) KGX_EVAL(M, W, 2); else KGX_EVAL(M, W, 3); \
+  } while (0)
+      if (mode == 1) {
+        if (eval_gpl == 8) KGX_EVAL_BITS(1, 8); else KGX_EVAL_BITS(1, 4);
+      } else if (mode == 2) {
+        if (eval_gpl == 8) KGX_EVAL_BITS(2, 8); else KGX_EVAL_BITS(2, 4);
+      } else {
+        if (eval_gpl == 8) KGX_EVAL_BITS(3, 8); else KGX_EVAL_BITS(3, 4);
+      }
+#undef KGX_EVAL_BITS
 #undef KGX_EVAL
     } else if (mode == 1)
       hipLaunchKernelGGL((k_inbreed_sweep<1>), grid, dim3(kBlock), 0, st, gt32, dwords_per_row, g0, n, d_index, n_sel, per_seg, d_table,
@@ -307,7 +315,7 @@ int inbreed_shard(kgx_gt8_shard& sh, uint64_t g0, uint64_t g1, const uint32_t* l
       // fixed start 0.25 (the mean of its start distribution) replaces the random draw.
       std::vector<double> f0(n, 0.25);
       // locus slots every lane of k_inbreed_eval_lut walks: whole batches of 8 in every segment
-      const unsigned long long walked = eval_lut && n_sel ? (eval_n_seg - 1) * eval_per_seg + (n_sel - (eval_n_seg - 1) * eval_per_seg + kEvalBatch - 1) / kEvalBatch * kEvalBatch : 0ull;
+      const unsigned long long walked = eval_lut && n_sel ? (eval_n_seg - 1) * eval_per_seg + (n_sel - (eval_n_seg - 1) * eval_per_seg + 7) / 8 * 8 : 0ull;
       try_hip(hipMemcpyAsync(d_f, f0.data(), n * sizeof(double), hipMemcpyHostToDevice, st), KGX_EHIP, "H2D(f0)");
       try_hip(hipStreamSynchronize(st), KGX_EHIP, "sync");
       for (int it = 0; it < 50 && rc == KGX_OK; ++it) {
@@ -343,12 +351,12 @@ int inbreed_shard(kgx_gt8_shard& sh, uint64_t g0, uint64_t g1, const uint32_t* l
         std::vector<BrentState> host_states;
         auto evaluate = [&]() {
           if (act_gt == gt32) { sweep(2); return; }
-#define KGX_EVAL2(GPL)                                                                                                               \
-  hipLaunchKernelGGL((k_inbreed_eval_lut<2, GPL, 4>),                                                                                \
-                     dim3(static_cast<uint32_t>(((n_act + GPL - 1) / GPL + kEvalThreads - 1) / kEvalThreads), static_cast<uint32_t>(eval_n_seg)), \
-                     dim3(kEvalThreads), 0, st, act_gt, act_dwords_per_row, act_g0, n_act, act_index,                                \
+#define KGX_EVAL2(W, B)                                                                                                              \
+  hipLaunchKernelGGL((k_inbreed_eval_lut<2, W, B>),                                                                                  \
+                     dim3(static_cast<uint32_t>(((n_act + W - 1) / W + kBlock - 1) / kBlock), static_cast<uint32_t>(eval_n_seg)),    \
+                     dim3(kBlock), 0, st, act_gt, act_dwords_per_row, act_g0, n_act, act_index,                                      \
                      n_sel, eval_per_seg, d_table, d_valid, amax, phased, act_f, d_part, d_counts)
-          if (act_gpl == 8) KGX_EVAL2(8); else KGX_EVAL2(4);
+          if (amax <= 1) KGX_EVAL2(8, 1); else if (amax <= 3) KGX_EVAL2(8, 2); else KGX_EVAL2(8, 3);
 #undef KGX_EVAL2
         };
         const bool may_compact = eval_lut && !env_int("KGX_K7_NO_COMPACT", 0);
@@ -421,7 +429,7 @@ int inbreed_shard(kgx_gt8_shard& sh, uint64_t g0, uint64_t g1, const uint32_t* l
           act_brent = new_brent;
           act_f = new_f;
           act_global = d_new_global;
-          act_gpl = env_int("KGX_K5_EVAL_GPL", 8) == 4 ? 4 : 8;          // the compacted columns start at genome 0
+          act_gpl = 8;
           n_act = n_new;
           global_of.swap(new_global);
         }

@@ -224,9 +224,9 @@ k_inbreed_sweep(const uint32_t* __restrict__ gt, uint64_t dwords_per_row, uint64
 
 // K5 evaluation passes (MODE 1: one Hall expectation step; MODE 2: the log-likelihood at F) for amax <= 7, the passes
 // HallME runs 50 times and Loglikelihood ~40 times per call.  What a cell contributes depends only on (locus, byte
-// value, F of the genome), so per batch of 8 loci the block first tabulates, in LDS, a pair (y, d) per byte value --
-// classify_cell decides every entry, so the class logic is the generic kernel's own -- and each cell is then one LDS
-// read, one fma  v = y + F*d  and a few more fp64 operations:
+// value, F of the genome), so per batch of 8 loci the block first tabulates, in LDS, a pair (y, d) for each of the
+// 128 values of (byte & 0x7F) -- classify_cell decides every entry, so the class logic is the generic kernel's own --
+// and each cell is then one LDS read, one fma  v = y + F*d  and a few more fp64 operations:
 //   MODE 2  v = the cell's probability.  hom: y = f1*f1, d = f1 - f1*f1   (F*f + (1-F)*f*f,  _calc.cpp:94-129)
 //                                        het: y = 2*f1*f2, d = -y         (2*(1-F)*f1*f2)
 //                                        unclassified: (1, 0) -> probability 1, log 0.
@@ -252,18 +252,16 @@ k_inbreed_sweep(const uint32_t* __restrict__ gt, uint64_t dwords_per_row, uint64
 //           bits of hi and says in the top bits of lo what is odd; once per batch the wave looks at the top of hi and,
 //           if any lane saw one, walks the batch's entries again and lets the odd ones adjust the lane's own
 //           (segment, genome) partial slot in memory -- a second look at 32 entries, only where such a cell is.
-// The locus's table has one 16-byte entry per BYTE VALUE (256 slots, 4 KB), so a cell's address is its byte times 16 --
-// one SDWA shift, no index arithmetic and no guard: a byte the layout does not define (an index past the alt list, an
-// unknown alt, 0xFF) lands on an entry that was written "unclassified" once, before the first batch.  Only the
-// (amax+1)^2 entries whose two allele indices are <= amax can ever be classified and are rebuilt per batch.
-// Two table buffers of 4 loci = 32 KB of LDS per workgroup of 256 threads (three or four per CU); a lane owns
-// GPL genomes (one dword or dwordx2 load per locus), the next batch's genotype words are loaded while this batch is
-// walked, its table is built by the whole block meanwhile, and its per-locus rows were staged two batches ahead.
+// Bit 7 of the byte (second allele index >= 8) is folded onto bit 3, and every entry with bit 3 set is "unclassified".
+// Entry (a1, a2) sits at slot a1 + 20*a2 of the locus's 160-slot table (a1 < 16, a2 < 8: injective), so the 16-byte
+// slots of the cells a 16-lane ds_read_b128 group meets together -- a1, a2 in 0..3 -- fall on 16 different bank quads
+// ((a1 + 4*a2) mod 16); at slot a1 + 16*a2 every a2 shared a1's banks (SQ_LDS_BANK_CONFLICT: 2.7 extra cycles a read).
+// GPL genomes per lane (4, 8 or 16: one dword / dwordx2 / dwordx4 load per locus); the whole block takes part in the
+// table build, so there is no early return.
 struct alignas(16) EvalEntry { double y, d; };
-constexpr int kEvalBatch = 4;      // loci per table buffer: 2 x 4 x 4 KB = 32 KB of LDS per workgroup
-constexpr int kEvalThreads = 256;
-constexpr int kHallBatches = 16;   // MODE 1: batches (of 4 loci) summed as one fraction before the division
-constexpr uint32_t kEvalSlots = 256;
+constexpr int kEvalBatch = 8;
+constexpr int kHallBatches = 8;    // MODE 1: batches summed as one fraction before the division
+constexpr uint32_t kEvalSlots = 160;
 constexpr uint64_t kRitlandSegment = 4088;        // MODE 3: loci per segment, below the 12-bit class counters' range
 constexpr uint32_t kOddCell = 1u << 28;           // MODE 3: in the entry's hi word: one more odd cell (a 4-bit count per batch)
 // ... and what is odd about it, in the entry's lo word (bits the 12-bit class counters never reach):
@@ -271,23 +269,26 @@ constexpr uint32_t kOddMinus = 1u << 24;          // unclassified carrier at a l
 constexpr uint32_t kOddPlus = 1u << 25;           // classified at a locus without defaults: they are added
 constexpr uint32_t kOddNoRitland = 1u << 26;      // a homozygote of an allele with f <= 0.001: classified, no Ritland term
 constexpr uint32_t kOddOutside = 1u << 27;        // a byte past the table: off wherever the locus has defaults
+// Slot of one byte value (the walk computes four at once: slots_of in the kernel).
+__host__ __device__ constexpr uint32_t eval_slot(uint32_t byte) {
+  const uint32_t folded = (byte & 0x7Fu) | ((byte >> 4) & 0x08u);
+  return folded + ((folded >> 2) & 0x1Cu);
+}
 
-// Slot of a byte value in the locus's table: the byte itself with two bits of its high nibble XORed onto bits 2..3 -- the
-// entries a 16-lane ds_read_b128 group meets together (allele indices 0..3 in either nibble) then sit on 16 different
-// bank quads; at slot = byte every second-allele index shared the first one's banks (SQ_LDS_BANK_CONFLICT: 2.7 extra
-// cycles per read).  The walk applies it to four bytes at once (swizzle_bytes).
-__host__ __device__ constexpr uint32_t eval_slot(uint32_t byte) { return byte ^ ((byte >> 2) & 0x0Cu); }
-__device__ __forceinline__ uint32_t swizzle_bytes(uint32_t w) { return w ^ ((w >> 2) & 0x0C0C0C0Cu); }
-
-// rows / flags: the batch's per-locus table rows and valid[] flags, staged in LDS two batches ahead (flag 0 past the
+// Only the (amax+1)^2 entries whose two allele indices are <= amax can ever be classified; the rest of the 160 are
+// written "unclassified" once, before the first batch, and never touched again.
+// rows / flags: the batch's 8 per-locus table rows and valid[] flags, staged in LDS two batches ahead (flag 0 past the
 // segment), so that no global-load latency sits between a batch's arithmetic and the next.
-template <int MODE>
+template <int MODE, int BITS>
 __device__ __forceinline__ void build_eval_table(EvalEntry* __restrict__ lut, const double* __restrict__ rows,
                                                  const uint8_t* __restrict__ flags, uint32_t stride, uint32_t amax, bool phased,
                                                  uint32_t* __restrict__ upper_binds, uint32_t batch_tag) {
-  const uint32_t n1 = amax + 1u, per_locus = n1 * n1;
-  for (uint32_t e = threadIdx.x; e < static_cast<uint32_t>(kEvalBatch) * per_locus; e += blockDim.x) {
-    const uint32_t i = e / per_locus, r = e - i * per_locus, a2 = r / n1, a1 = r - a2 * n1;
+  // e enumerates (locus, a2, a1) with just enough bits per allele index for amax, so that at amax <= 3 two waves
+  // build the whole batch in one step and the other two go straight on to the arithmetic
+  constexpr uint32_t bits = BITS, mask = (1u << bits) - 1u;       // BITS = 1, 2, 3 for amax <= 1, 3, 7
+  for (uint32_t e = threadIdx.x; e < (static_cast<uint32_t>(kEvalBatch) << (2u * bits)); e += kBlock) {
+    const uint32_t a1 = e & mask, a2 = (e >> bits) & mask, i = e >> (2u * bits);
+    if (a1 > amax || a2 > amax) continue;
     double y = MODE == 3 ? 0.0 : 1.0, d = 0.0;
     if (flags[i] & kLocusValid) {
       double f1 = 0.0, f2 = 0.0;
@@ -319,27 +320,14 @@ __device__ __forceinline__ void build_eval_table(EvalEntry* __restrict__ lut, co
         }
       }
     }
-    EvalEntry* slot = lut + i * kEvalSlots + eval_slot(a1 | (a2 << 4));
+    EvalEntry* slot = lut + i * kEvalSlots + (a1 + 20u * a2);
     slot->y = y;
     slot->d = d;
   }
 }
 
-// 16 * (byte B of w): the LDS byte offset of that cell's entry, one SDWA shift.
-template <int B>
-__device__ __forceinline__ uint32_t byte_times_16(uint32_t w, uint32_t four) {
-  uint32_t r;
-  if constexpr (B == 0) asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0" : "=v"(r) : "v"(four), "v"(w));
-  else if constexpr (B == 1) asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1" : "=v"(r) : "v"(four), "v"(w));
-  else if constexpr (B == 2) asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_2" : "=v"(r) : "v"(four), "v"(w));
-  else asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_3" : "=v"(r) : "v"(four), "v"(w));
-  return r;
-}
-
-// Workgroups of 256 threads (one wave per SIMD), WAVES of them per CU: 4 (<= 128 VGPRs) or 3 (<= 168) as the mode's
-// registers allow; 34 KB of LDS each.
-template <int MODE, int GPL, int WAVES>
-__global__ void __launch_bounds__(kEvalThreads) __attribute__((amdgpu_waves_per_eu(WAVES)))
+template <int MODE, int GPL, int BITS>
+__global__ void __launch_bounds__(kBlock)
 k_inbreed_eval_lut(const uint32_t* __restrict__ gt, uint64_t dwords_per_row, uint64_t g0, uint64_t n_genomes,
                    const uint32_t* __restrict__ locus_index, uint64_t n_sel, uint64_t loci_per_seg,
                    const double* __restrict__ table, const uint8_t* __restrict__ valid, uint32_t amax, int phased,
@@ -359,7 +347,6 @@ k_inbreed_eval_lut(const uint32_t* __restrict__ gt, uint64_t dwords_per_row, uin
   const uint64_t s_end = s_begin + loci_per_seg < n_sel ? s_begin + loci_per_seg : n_sel;
   const uint32_t stride = sweep_stride(amax);
   const uint64_t col = (g0 >> 2) + lane * DW;              // g0 is a multiple of GPL
-  const uint32_t four = 4u;
 
   double F[MODE == 3 ? 1 : GPL], acc[MODE == 1 ? GPL : 1], run_a[GPL], run_b[MODE == 1 ? GPL : 1];
   int expo[MODE == 2 ? GPL : 1];   // MODE 2: run_a = product;  MODE 1: run_a / run_b = N / D;  MODE 3: run_a = Ritland sum
@@ -379,7 +366,7 @@ k_inbreed_eval_lut(const uint32_t* __restrict__ gt, uint64_t dwords_per_row, uin
     }
   }
 
-  for (uint32_t e = threadIdx.x; e < 2u * kEvalBatch * kEvalSlots; e += blockDim.x) {
+  for (uint32_t e = threadIdx.x; e < 2u * kEvalBatch * kEvalSlots; e += kBlock) {
     (&lut[0][0] + e)->y = MODE == 3 ? 0.0 : 1.0;
     // MODE 3: a byte past the table is counted as nothing but is odd wherever the locus has defaults
     (&lut[0][0] + e)->d = MODE == 3 ? __builtin_bit_cast(double, (static_cast<uint64_t>(kOddCell) << 32) | kOddOutside) : 0.0;
@@ -399,72 +386,48 @@ k_inbreed_eval_lut(const uint32_t* __restrict__ gt, uint64_t dwords_per_row, uin
     if (threadIdx.x < kEvalBatch * stride) rows[rb][threadIdx.x] = staged_row;
     if (threadIdx.x < kEvalBatch) flags[rb][threadIdx.x] = staged_flag;
   };
-  // the genotype words of one batch: past the segment a word that contributes nothing (MODE 3: byte 0 of a locus whose
-  // flag is 0 -- an all-zero entry; else a byte past every table: (1, 0))
-  auto load_words = [&](uint64_t s0, uint32_t (&w)[kEvalBatch][DW]) {
+  fetch(s_begin);
+  stash(0);
+  fetch(s_begin + kEvalBatch);
+  stash(1);
+  __syncthreads();
+  build_eval_table<MODE, BITS>(lut[0], rows[0], flags[0], stride, amax, phased != 0, &upper_binds[0], 1u);
+  __syncthreads();
+  int buf = 0;
+  int batches_open = 0;            // batches since the running fraction / product was last closed
+  for (uint64_t s0 = s_begin; s0 < s_end; s0 += kEvalBatch, buf ^= 1) {
+    uint32_t w[kEvalBatch][DW];
 #pragma unroll
     for (int i = 0; i < kEvalBatch; ++i) {
       const uint64_t s = s0 + i;
 #pragma unroll
-      for (int k = 0; k < DW; ++k) w[i][k] = MODE == 3 ? 0u : 0x08080808u;
+      for (int k = 0; k < DW; ++k) w[i][k] = MODE == 3 ? 0u : 0x08080808u;  // past the segment: nothing (MODE 3: byte 0 of a locus whose flag is 0, an all-zero entry; else a byte past the table: (1, 0))
       if (active && s < s_end) {
         const uint64_t l = locus_index ? static_cast<uint64_t>(locus_index[s]) : s;
         const uint32_t* src = gt + l * dwords_per_row + col;
         if constexpr (DW == 1) {
           w[i][0] = __builtin_nontemporal_load(src);
-        } else {
+        } else if constexpr (DW == 2) {
           typedef uint32_t v2u __attribute__((ext_vector_type(2)));
           const v2u v = __builtin_nontemporal_load(reinterpret_cast<const v2u*>(src));
           w[i][0] = v.x; w[i][1] = v.y;
+        } else {
+          const kgx_v4u v = __builtin_nontemporal_load(reinterpret_cast<const kgx_v4u*>(src));
+          w[i][0] = v.x; w[i][1] = v.y; w[i][2] = v.z; w[i][3] = v.w;
         }
       }
     }
-  };
-  // (the padding words are their own swizzle: 0x08 has no high-nibble bits, 0 neither)
-  fetch(s_begin);
-  stash(0);
-  fetch(s_begin + kEvalBatch);
-  stash(1);
-  uint32_t w[kEvalBatch][DW], w_next[kEvalBatch][DW];
-  load_words(s_begin, w);
-  __syncthreads();
-  build_eval_table<MODE>(lut[0], rows[0], flags[0], stride, amax, phased != 0, &upper_binds[0], 1u);
-  __syncthreads();
-  int batches_open = 0;            // batches since the running fraction / product was last closed
-
-  // One batch, its table in lut[BUF] (a compile-time buffer: the table's LDS address folds into the read's offset).
-  auto batch = [&](auto buf_c, uint64_t s0) {
-    constexpr int BUF = decltype(buf_c)::value;
-    load_words(s0 + kEvalBatch, w_next);
     fetch(s0 + 2 * kEvalBatch);
     const uint32_t batch_tag = static_cast<uint32_t>((s0 - s_begin) / kEvalBatch) + 1u;
-    const bool clamp_above = MODE == 2 && upper_binds[BUF] == batch_tag;          // block-uniform; written before the last barrier
+    const bool clamp_above = MODE == 2 && upper_binds[buf] == batch_tag;          // block-uniform; written before the last barrier
     if (s0 + kEvalBatch < s_end)
-      build_eval_table<MODE>(lut[BUF ^ 1], rows[BUF ^ 1], flags[BUF ^ 1], stride, amax, phased != 0, &upper_binds[BUF ^ 1], batch_tag + 1u);
+      build_eval_table<MODE, BITS>(lut[buf ^ 1], rows[buf ^ 1], flags[buf ^ 1], stride, amax, phased != 0, &upper_binds[buf ^ 1], batch_tag + 1u);
     if (active) {
-      const char* __restrict__ cur = reinterpret_cast<const char*>(&lut[BUF][0]);
-      auto entry = [&](int i, uint32_t offset) {
-        return *reinterpret_cast<const EvalEntry*>(cur + i * static_cast<int>(kEvalSlots * sizeof(EvalEntry)) + offset);
-      };
-      // The cells of the batch, a locus (GPL table reads) at a time: the reads of a locus are issued together, then its
-      // arithmetic; the scheduling barrier keeps the compiler from hoisting every read of the batch to the front
-      // (32 reads x 4 registers: it spills at four waves per SIMD, and four waves hide the LDS latency anyway).
-      auto for_each_cell = [&](auto&& fn) {
-#pragma unroll
-        for (int i = 0; i < kEvalBatch; ++i) {
-          EvalEntry e[GPL];
-#pragma unroll
-          for (int k = 0; k < DW; ++k) {
-            const uint32_t slots = swizzle_bytes(w[i][k]);
-            e[4 * k + 0] = entry(i, byte_times_16<0>(slots, four));
-            e[4 * k + 1] = entry(i, byte_times_16<1>(slots, four));
-            e[4 * k + 2] = entry(i, byte_times_16<2>(slots, four));
-            e[4 * k + 3] = entry(i, byte_times_16<3>(slots, four));
-          }
-#pragma unroll
-          for (int j = 0; j < GPL; ++j) fn(j, e[j], i);
-          __builtin_amdgcn_sched_barrier(0);
-        }
+      const EvalEntry* __restrict__ cur = lut[buf];
+      // A cell's table entry: slot a1 + 20*a2 of its locus (bit 7 of the byte folded onto bit 3: "unclassified").
+      auto slots_of = [](uint32_t x) {
+        const uint32_t xf = (x & 0x7F7F7F7Fu) | ((x >> 4) & 0x08080808u);
+        return xf + ((xf >> 2) & 0x1C1C1C1Cu);                             // a1 + 16*a2 + 4*a2 per byte, < 156: no carry
       };
       if constexpr (MODE == 2) {
         // The clamp of logLikelihood (:117-121).  For -1 <= F <= 1 (the search interval) its upper bound cannot bind on a
@@ -472,39 +435,74 @@ k_inbreed_eval_lut(const uint32_t* __restrict__ gt, uint64_t dwords_per_row, uin
         // unclassified one (1, 0); on a heterozygous cell, 2*(1-F)*f1*f2 <= 4*f1*f2, only if y > 1/2.  So the batch's
         // cells are compiled twice, and the form with the fp64 min per cell runs only where build_eval_table saw such an
         // entry (one block-uniform branch per batch).
-        if (clamp_above)
-          for_each_cell([&](int j, const EvalEntry e, int) { run_a[j] *= __builtin_fmin(__builtin_fmax(__builtin_fma(F[j], e.d, e.y), 1e-10), 1.0); });
-        else
-          for_each_cell([&](int j, const EvalEntry e, int) { run_a[j] *= __builtin_fmax(__builtin_fma(F[j], e.d, e.y), 1e-10); });
-      } else if constexpr (MODE == 1) {
-        for_each_cell([&](int j, const EvalEntry e, int) {
-          const double v = __builtin_fma(F[j], e.d, e.y);
-          run_a[j] = __builtin_fma(run_a[j], v, run_b[j]);
-          run_b[j] *= v;
-        });
+        auto walk_cells = [&](auto above_c) {
+          constexpr bool kClampAbove = decltype(above_c)::value;
+#pragma unroll
+          for (int i = 0; i < kEvalBatch; ++i) {
+#pragma unroll
+            for (int k = 0; k < DW; ++k) {
+              const uint32_t slots = slots_of(w[i][k]);
+#pragma unroll
+              for (int b = 0; b < 4; ++b) {
+                const int j = 4 * k + b;
+                const EvalEntry e = cur[i * kEvalSlots + ((slots >> (8 * b)) & 0xFFu)];
+                const double floored = __builtin_fmax(__builtin_fma(F[MODE == 3 ? 0 : j], e.d, e.y), 1e-10);
+                run_a[j] *= kClampAbove ? __builtin_fmin(floored, 1.0) : floored;
+              }
+            }
+          }
+        };
+        if (clamp_above) walk_cells(std::true_type{});
+        else walk_cells(std::false_type{});
       } else {
-        for_each_cell([&](int j, const EvalEntry e, int) {
-          run_a[j] += e.y;
-          const uint64_t packed = __builtin_bit_cast(uint64_t, e.d);
-          cnt_lo[j] += static_cast<uint32_t>(packed);
-          cnt_hi[j] += static_cast<uint32_t>(packed >> 32);
-        });
+#pragma unroll
+        for (int i = 0; i < kEvalBatch; ++i) {
+#pragma unroll
+          for (int k = 0; k < DW; ++k) {
+            const uint32_t slots = slots_of(w[i][k]);
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+              const int j = 4 * k + b;
+              const EvalEntry e = cur[i * kEvalSlots + ((slots >> (8 * b)) & 0xFFu)];
+              if constexpr (MODE == 3) {
+                run_a[j] += e.y;
+                const uint64_t packed = __builtin_bit_cast(uint64_t, e.d);
+                cnt_lo[j] += static_cast<uint32_t>(packed);
+                cnt_hi[j] += static_cast<uint32_t>(packed >> 32);
+              } else {
+                const double v = __builtin_fma(F[MODE == 3 ? 0 : j], e.d, e.y);
+                run_a[j] = __builtin_fma(run_a[j], v, run_b[j]);
+                run_b[j] *= v;
+              }
+            }
+          }
+          // MODE 3: nothing in this block reads the sums, so machine sinking would carry the batch's 64 fp64 adds and 128
+          // counter adds past the odd-cell branch below and keep every entry read until then alive (319 registers, one
+          // wave per SIMD).  The empty asm reads them here: a locus's reads and adds stay together.
+          if constexpr (MODE == 3) {
+#pragma unroll
+            for (int j = 0; j < GPL; ++j) asm volatile("" : "+v"(run_a[j]), "+v"(cnt_lo[j]), "+v"(cnt_hi[j]));
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        }
+      }
+      if constexpr (MODE == 3) {
         uint32_t seen = 0;
 #pragma unroll
         for (int j = 0; j < GPL; ++j) seen |= cnt_hi[j];
         if (__any((seen >> 28) != 0u)) {                    // some lane of the wave met an odd cell in this batch
 #pragma unroll
           for (int j = 0; j < GPL; ++j) cnt_hi[j] &= kOddCell - 1u;
-          // The lanes that met one look at their 32 cells of the batch once more, this time for what is odd about them: an
-          // odd cell adjusts the lane's own (segment, genome) partial slot in memory (single writer) or the genome's
-          // Ritland count.  Rolled loops over bytes re-read from the matrix (L2 hits), entries re-read from LDS.
+          // The lanes that met one look at their cells of the batch once more, this time for what is odd about them: an odd
+          // cell adjusts the lane's own (segment, genome) partial slot in memory (single writer: the order of its adds is
+          // the program's) or the genome's Ritland count.  Rolled loops, bytes re-read from the matrix (L2 hits), the
+          // locus's row from memory as well -- not from rows[buf]: a faster wave may already have stashed the batch
+          // after next's rows there (only the table build reads those, behind the barrier).
           if ((seen >> 28) != 0u) {
 #pragma nounroll
             for (int i = 0; i < kEvalBatch; ++i) {
               const uint64_t s = s0 + i;
               if (s >= s_end) break;
-              // the locus's row from memory, not from rows[BUF]: a faster wave may already have stashed the batch after
-              // next's rows there (only the table build reads those, behind the barrier)
               const uint8_t flag = valid[s];
               const double* row = table + s * stride;
               const uint64_t l = locus_index ? static_cast<uint64_t>(locus_index[s]) : s;
@@ -513,13 +511,14 @@ k_inbreed_eval_lut(const uint32_t* __restrict__ gt, uint64_t dwords_per_row, uin
               for (int j = 0; j < GPL; ++j) {
                 const uint64_t g = lane * GPL + j;
                 if (g >= n_genomes) break;
-                const uint32_t odd = static_cast<uint32_t>(__builtin_bit_cast(uint64_t, lut[BUF][i * kEvalSlots + eval_slot(bytes[j])].d)) >> 24;
+                const uint32_t odd = static_cast<uint32_t>(__builtin_bit_cast(uint64_t, cur[i * kEvalSlots + eval_slot(bytes[j])].d)) >> 24;
                 if (odd == 0u) continue;
                 const double sign = (odd & (kOddMinus >> 24)) ? -1.0 : (odd & (kOddPlus >> 24)) ? 1.0
                                     : ((odd & (kOddOutside >> 24)) && (flag & kLocusDefault)) ? -1.0 : 0.0;
                 if (sign != 0.0) {
                   double* p = part + (seg * n_genomes + g) * kParts0;
-                  p[0] += sign * row[amax + 1]; p[1] += sign * row[amax + 2]; p[2] += sign * row[amax + 3]; p[3] += sign * row[amax + 4];
+#pragma nounroll
+                  for (uint32_t k = 0; k < 4u; ++k) unsafeAtomicAdd(p + k, sign * row[amax + 1u + k]);
                 }
                 if (odd & (kOddNoRitland >> 24)) atomicAdd(&counts[g * 6 + 5], ~0ull);       // counted with the classes, not by Ritland
               }
@@ -529,8 +528,8 @@ k_inbreed_eval_lut(const uint32_t* __restrict__ gt, uint64_t dwords_per_row, uin
       }
       // MODE 1: the fraction N/D runs on over up to kHallBatches batches before its one division -- the division is a
       // dozen fp64 instructions, a quarter of the pass when taken every 8 cells.  D is a product of denominators
-      // F + (1-F)*f1 <= 1 and shrinks; a lane whose D has fallen below 1e-100 divides at once (4 more factors would
-      // have to average 1e-50 to take it under).  The last batch of the segment always divides.
+      // F + (1-F)*f1 <= 1 and shrinks; a lane whose D has fallen below 1e-100 divides at once (8 more factors would
+      // have to average 1e-26 to take it under).  The last batch of the segment always divides.
       const bool closing = s0 + kEvalBatch >= s_end;            // block-uniform
       ++batches_open;
 #pragma unroll
@@ -548,16 +547,8 @@ k_inbreed_eval_lut(const uint32_t* __restrict__ gt, uint64_t dwords_per_row, uin
       }
       if (closing || batches_open >= kHallBatches) batches_open = 0;
     }
-    stash(BUF);          // rows[BUF] fed this batch's table one iteration ago: free for the batch after next
+    stash(buf);          // rows[buf] fed this batch's table one iteration ago: free for the batch after next
     __syncthreads();
-#pragma unroll
-    for (int i = 0; i < kEvalBatch; ++i)
-#pragma unroll
-      for (int k = 0; k < DW; ++k) w[i][k] = w_next[i][k];
-  };
-  for (uint64_t s0 = s_begin; s0 < s_end; s0 += 2 * kEvalBatch) {
-    batch(std::integral_constant<int, 0>{}, s0);
-    if (s0 + kEvalBatch < s_end) batch(std::integral_constant<int, 1>{}, s0 + kEvalBatch);
   }
 
   if (!active) return;
