@@ -155,6 +155,10 @@ int inbreed_shard(kgx_gt8_shard& sh, uint64_t g0, uint64_t g1, const uint32_t* l
   const uint64_t n_seq_blocks = (n_sel + kSeqBlock - 1) / kSeqBlock;
   const size_t o_seq_sum = plan.add(n_seq_blocks * 4 * sizeof(double)), o_seq_e = plan.add(n_seq_blocks * 4 * sizeof(int));
   const size_t o_seq_n = plan.add(n_seq_blocks * 4 * sizeof(long long)), o_seq_out = plan.add(kParts0 * sizeof(double));
+  // The table passes' entries (k_eval_entries): 64 / 256 / 1024 bytes per selected locus, only where such a pass will run.
+  const bool wave_sized = n_sel > 0 && n_sel <= 64ull * kWaveCells && !env_int("KGX_K7_NO_WAVE", 0);
+  const bool table_passes = n_sel > 0 && (ritland_lut || (eval_lut && (algorithm == 2 || algorithm == 3) && !wave_sized));
+  const size_t o_entries = plan.add(table_passes ? (n_sel << (2u * eval_bits(amax))) * sizeof(EvalEntry) : 0);
   char* arena = nullptr;
   if (int arc = scratch_reserve(dev, plan.total, &arena)) return arc;
   d_af = reinterpret_cast<double*>(arena + o_af);
@@ -175,6 +179,7 @@ int inbreed_shard(kgx_gt8_shard& sh, uint64_t g0, uint64_t g1, const uint32_t* l
   int* d_seq_e = reinterpret_cast<int*>(arena + o_seq_e);
   long long* d_seq_n = reinterpret_cast<long long*>(arena + o_seq_n);
   double* d_seq_out = reinterpret_cast<double*>(arena + o_seq_out);
+  EvalEntry* d_entries = reinterpret_cast<EvalEntry*>(arena + o_entries);
   try_hip(hipMemsetAsync(d_meta, 0, (n_tab + 8) * sizeof(uint32_t), dev.stream), KGX_EHIP, "memset(meta)");
   if (locus_index && n_sel) {
     d_index = reinterpret_cast<uint32_t*>(arena + o_index);
@@ -196,7 +201,7 @@ int inbreed_shard(kgx_gt8_shard& sh, uint64_t g0, uint64_t g1, const uint32_t* l
   // The SWAR sweeps guard against allele indexes 8..14 (past their 8-entry tables) only if the matrix holds any: looked
   // up once per content of the matrix, by one pass over its bytes (KGX_K5_ALWAYS_GUARD=1 skips the look and guards).
   bool guard = true;
-  if (rc == KGX_OK && n_sel && (swar16 || amax <= 4) && env_int("KGX_K5_ALWAYS_GUARD", 0) == 0) {
+  if (rc == KGX_OK && n_sel && (swar16 || amax <= 4 || table_passes) && env_int("KGX_K5_ALWAYS_GUARD", 0) == 0) {
     if (sh.wide_nibbles == 0) {
       unsigned int found = 0;
       try_hip(hipMemsetAsync(d_running, 0, sizeof(unsigned int), st), KGX_EHIP, "memset(scan flag)");
@@ -212,6 +217,15 @@ int inbreed_shard(kgx_gt8_shard& sh, uint64_t g0, uint64_t g1, const uint32_t* l
     }
     guard = sh.wide_nibbles != 1;
   }
+  // the table passes fold bit 7 of a byte onto bit 3 only where an index 8..14, or 7 as a real one, can occur
+  const bool eval_fold = guard || amax > 6;
+  auto tabulate = [&](int mode) {
+    if (!table_passes) return;
+    const uint32_t tab_grid = stream_grid(dev, n_sel << (2u * eval_bits(amax)), kBlock);
+    if (mode == 1) hipLaunchKernelGGL((k_eval_entries<1>), dim3(tab_grid), dim3(kBlock), 0, dev.stream, d_table, d_valid, n_sel, amax, phased, d_entries);
+    else if (mode == 2) hipLaunchKernelGGL((k_eval_entries<2>), dim3(tab_grid), dim3(kBlock), 0, dev.stream, d_table, d_valid, n_sel, amax, phased, d_entries);
+    else hipLaunchKernelGGL((k_eval_entries<3>), dim3(tab_grid), dim3(kBlock), 0, dev.stream, d_table, d_valid, n_sel, amax, phased, d_entries);
+  };
   auto sweep = [&](int mode) {
     if (n_sel == 0) return;
     if (mode == 0 && sequential_defaults) {
@@ -257,23 +271,23 @@ int inbreed_shard(kgx_gt8_shard& sh, uint64_t g0, uint64_t g1, const uint32_t* l
 #undef KGX_SWAR
       }
     } else if (eval_lut || mode == 3) {
-#define KGX_EVAL(M, W, B)                                                                                                            \
-  hipLaunchKernelGGL((k_inbreed_eval_lut<M, W, B>),                                                                                  \
+#define KGX_EVAL(M, W, FOLD)                                                                                                         \
+  hipLaunchKernelGGL((k_inbreed_eval_lut<M, W, FOLD>),                                                                               \
                      dim3(static_cast<uint32_t>(((n + W - 1) / W + kBlock - 1) / kBlock), static_cast<uint32_t>(eval_n_seg)),        \
                      dim3(kBlock), 0, st, gt32, dwords_per_row, g0, n, d_index, n_sel,                                               \
-                     eval_per_seg, d_table, d_valid, amax, phased, d_f, d_part, d_counts)
-#define KGX_EVAL_BITS(M, W)                                                                \
-  do {                                                                                     \
-    if (amax <= 1) KGX_EVAL(M, W, 1); else if (amax <= 3) KGX_EVAL(M, W, 2); else KGX_EVAL(M, W, 3); \
+                     eval_per_seg, d_entries, d_table, d_valid, amax, d_f, d_part, d_counts)
+#define KGX_EVAL_FOLD(M, W)                                                \
+  do {                                                                     \
+    if (eval_fold) KGX_EVAL(M, W, true); else KGX_EVAL(M, W, false);       \
   } while (0)
       if (mode == 1) {
-        if (eval_gpl == 8) KGX_EVAL_BITS(1, 8); else KGX_EVAL_BITS(1, 4);
+        if (eval_gpl == 8) KGX_EVAL_FOLD(1, 8); else KGX_EVAL_FOLD(1, 4);
       } else if (mode == 2) {
-        if (eval_gpl == 8) KGX_EVAL_BITS(2, 8); else KGX_EVAL_BITS(2, 4);
+        if (eval_gpl == 8) KGX_EVAL_FOLD(2, 8); else KGX_EVAL_FOLD(2, 4);
       } else {
-        if (eval_gpl == 8) KGX_EVAL_BITS(3, 8); else KGX_EVAL_BITS(3, 4);
+        if (eval_gpl == 8) KGX_EVAL_FOLD(3, 8); else KGX_EVAL_FOLD(3, 4);
       }
-#undef KGX_EVAL_BITS
+#undef KGX_EVAL_FOLD
 #undef KGX_EVAL
     } else if (mode == 1)
       hipLaunchKernelGGL((k_inbreed_sweep<1>), grid, dim3(kBlock), 0, st, gt32, dwords_per_row, g0, n, d_index, n_sel, per_seg, d_table,
@@ -287,13 +301,13 @@ int inbreed_shard(kgx_gt8_shard& sh, uint64_t g0, uint64_t g1, const uint32_t* l
     if (n_sel) hipLaunchKernelGGL((k_locus_tables<true>), dim3(stream_grid(dev, n_sel, kBlock)), dim3(kBlock), 0, st, d_af, n_sel, amax, 0.0, d_table, d_valid);
     if (rc == KGX_OK) try_hip(hipEventRecord(dev.sweep_begin, st), KGX_EHIP, "hipEventRecord");
     sweep(0);
-    if (ritland_lut) sweep(3);
+    if (ritland_lut) { tabulate(3); sweep(3); }
     if (rc == KGX_OK) try_hip(hipEventRecord(dev.sweep_end, st), KGX_EHIP, "hipEventRecord");
     if (sequential_defaults && n_sel) try_hip(hipStreamWaitEvent(st, dev.side_end, 0), KGX_EHIP, "hipStreamWaitEvent");
     hipLaunchKernelGGL(k_reduce_parts, dim3(stream_grid(dev, n * kParts0, kBlock)), dim3(kBlock), 0, st, d_part, n_seg, n * kParts0,
                        (sequential_defaults && n_sel) ? d_seq_out : nullptr, d_sums);
     // Window-sized calls: the whole iteration in one launch, a wave per genome (k_inbreed_iterate_wave).
-    const bool wave_path = (algorithm == 2 || algorithm == 3) && n_sel > 0 && n_sel <= 64ull * kWaveCells && !env_int("KGX_K7_NO_WAVE", 0);
+    const bool wave_path = (algorithm == 2 || algorithm == 3) && wave_sized;
     if (wave_path) {
       const uint32_t wave_grid = static_cast<uint32_t>((n * kWave + kBlock - 1) / kBlock);
       try_hip(hipMemsetAsync(d_running, 0, sizeof(unsigned int), st), KGX_EHIP, "memset(evaluations)");
@@ -318,6 +332,7 @@ int inbreed_shard(kgx_gt8_shard& sh, uint64_t g0, uint64_t g1, const uint32_t* l
       const unsigned long long walked = eval_lut && n_sel ? (eval_n_seg - 1) * eval_per_seg + (n_sel - (eval_n_seg - 1) * eval_per_seg + 7) / 8 * 8 : 0ull;
       try_hip(hipMemcpyAsync(d_f, f0.data(), n * sizeof(double), hipMemcpyHostToDevice, st), KGX_EHIP, "H2D(f0)");
       try_hip(hipStreamSynchronize(st), KGX_EHIP, "sync");
+      tabulate(1);
       for (int it = 0; it < 50 && rc == KGX_OK; ++it) {
         sweep(1);
         hipLaunchKernelGGL(k_reduce_parts, dim3(lin_grid), dim3(kBlock), 0, st, d_part, pass_n_seg, n, nullptr, d_eval);
@@ -328,6 +343,7 @@ int inbreed_shard(kgx_gt8_shard& sh, uint64_t g0, uint64_t g1, const uint32_t* l
       // clamped linear functions of F; Brent's method on that same clamped objective replaces nlopt's Nelder-Mead
       // (un-vendored, unpinned), to within 5e-7 in F where the reference stops at an absolute change of 1e-6.  KGX_K7_GOLDEN=1 runs the
       // plain golden-section search instead (38 evaluations, bracket 6e-8).
+      tabulate(2);
       if (!env_int("KGX_K7_GOLDEN", 0)) {
         // Start: [-1, 1] from its golden point.  KGX_K7_ESTIMATE_START=1 starts in a window around the Simple estimate
         // instead (brent_start): 11 instead of 15 evaluations on a population with F in [0, 0.1], but where the clamped
@@ -351,12 +367,12 @@ int inbreed_shard(kgx_gt8_shard& sh, uint64_t g0, uint64_t g1, const uint32_t* l
         std::vector<BrentState> host_states;
         auto evaluate = [&]() {
           if (act_gt == gt32) { sweep(2); return; }
-#define KGX_EVAL2(W, B)                                                                                                              \
-  hipLaunchKernelGGL((k_inbreed_eval_lut<2, W, B>),                                                                                  \
-                     dim3(static_cast<uint32_t>(((n_act + W - 1) / W + kBlock - 1) / kBlock), static_cast<uint32_t>(eval_n_seg)),    \
+#define KGX_EVAL2(FOLD)                                                                                                              \
+  hipLaunchKernelGGL((k_inbreed_eval_lut<2, 8, FOLD>),                                                                               \
+                     dim3(static_cast<uint32_t>(((n_act + 7) / 8 + kBlock - 1) / kBlock), static_cast<uint32_t>(eval_n_seg)),        \
                      dim3(kBlock), 0, st, act_gt, act_dwords_per_row, act_g0, n_act, act_index,                                      \
-                     n_sel, eval_per_seg, d_table, d_valid, amax, phased, act_f, d_part, d_counts)
-          if (amax <= 1) KGX_EVAL2(8, 1); else if (amax <= 3) KGX_EVAL2(8, 2); else KGX_EVAL2(8, 3);
+                     n_sel, eval_per_seg, d_entries, d_table, d_valid, amax, act_f, d_part, d_counts)
+          if (eval_fold) KGX_EVAL2(true); else KGX_EVAL2(false);
 #undef KGX_EVAL2
         };
         const bool may_compact = eval_lut && !env_int("KGX_K7_NO_COMPACT", 0);

@@ -224,9 +224,9 @@ k_inbreed_sweep(const uint32_t* __restrict__ gt, uint64_t dwords_per_row, uint64
 
 // K5 evaluation passes (MODE 1: one Hall expectation step; MODE 2: the log-likelihood at F) for amax <= 7, the passes
 // HallME runs 50 times and Loglikelihood ~40 times per call.  What a cell contributes depends only on (locus, byte
-// value, F of the genome), so per batch of 8 loci the block first tabulates, in LDS, a pair (y, d) for each of the
-// 128 values of (byte & 0x7F) -- classify_cell decides every entry, so the class logic is the generic kernel's own --
-// and each cell is then one LDS read, one fma  v = y + F*d  and a few more fp64 operations:
+// value, F of the genome): a pair (y, d) per (locus, allele index pair) is tabulated once per call (k_eval_entries --
+// classify_cell decides every entry, so the class logic is the generic kernel's own), a pass holds the entries of the
+// batch of 8 loci it is walking in LDS, and each cell is one LDS read, one fma  v = y + F*d  and a few more fp64 operations:
 //   MODE 2  v = the cell's probability.  hom: y = f1*f1, d = f1 - f1*f1   (F*f + (1-F)*f*f,  _calc.cpp:94-129)
 //                                        het: y = 2*f1*f2, d = -y         (2*(1-F)*f1*f2)
 //                                        unclassified: (1, 0) -> probability 1, log 0.
@@ -253,11 +253,16 @@ k_inbreed_sweep(const uint32_t* __restrict__ gt, uint64_t dwords_per_row, uint64
 //           if any lane saw one, walks the batch's entries again and lets the odd ones adjust the lane's own
 //           (segment, genome) partial slot in memory -- a second look at 32 entries, only where such a cell is.
 // Bit 7 of the byte (second allele index >= 8) is folded onto bit 3, and every entry with bit 3 set is "unclassified".
+// FOLD = false leaves the fold's three operations per dword out: the matrix is known to hold no allele index 8..14
+// (kgx_gt8::wide_nibbles == 1) and amax <= 6, so a second index with bit 3 set is 15 and, read without bit 7, 7 > amax --
+// an entry nobody tabulates, "unclassified" from the prefill.
 // Entry (a1, a2) sits at slot a1 + 20*a2 of the locus's 160-slot table (a1 < 16, a2 < 8: injective), so the 16-byte
 // slots of the cells a 16-lane ds_read_b128 group meets together -- a1, a2 in 0..3 -- fall on 16 different bank quads
 // ((a1 + 4*a2) mod 16); at slot a1 + 16*a2 every a2 shared a1's banks (SQ_LDS_BANK_CONFLICT: 2.7 extra cycles a read).
-// GPL genomes per lane (4, 8 or 16: one dword / dwordx2 / dwordx4 load per locus); the whole block takes part in the
-// table build, so there is no early return.
+// GPL genomes per lane (4 or 8: one dword / dwordx2 load per locus).
+#ifndef KGX_EVAL_SCHED_BARRIER
+#define KGX_EVAL_SCHED_BARRIER 1
+#endif
 struct alignas(16) EvalEntry { double y, d; };
 constexpr int kEvalBatch = 8;
 constexpr int kHallBatches = 8;    // MODE 1: batches summed as one fraction before the division
@@ -270,35 +275,43 @@ constexpr uint32_t kOddPlus = 1u << 25;           // classified at a locus witho
 constexpr uint32_t kOddNoRitland = 1u << 26;      // a homozygote of an allele with f <= 0.001: classified, no Ritland term
 constexpr uint32_t kOddOutside = 1u << 27;        // a byte past the table: off wherever the locus has defaults
 // Slot of one byte value (the walk computes four at once: slots_of in the kernel).
+template <bool FOLD>
 __host__ __device__ constexpr uint32_t eval_slot(uint32_t byte) {
-  const uint32_t folded = (byte & 0x7Fu) | ((byte >> 4) & 0x08u);
+  const uint32_t folded = FOLD ? ((byte & 0x7Fu) | ((byte >> 4) & 0x08u)) : (byte & 0x7Fu);
   return folded + ((folded >> 2) & 0x1Cu);
 }
+__host__ __device__ constexpr uint32_t eval_bits(uint32_t amax) { return amax <= 1 ? 1u : amax <= 3 ? 2u : 3u; }
 
-// Only the (amax+1)^2 entries whose two allele indices are <= amax can ever be classified; the rest of the 160 are
-// written "unclassified" once, before the first batch, and never touched again.
-// rows / flags: the batch's 8 per-locus table rows and valid[] flags, staged in LDS two batches ahead (flag 0 past the
-// segment), so that no global-load latency sits between a batch's arithmetic and the next.
-template <int MODE, int BITS>
-__device__ __forceinline__ void build_eval_table(EvalEntry* __restrict__ lut, const double* __restrict__ rows,
-                                                 const uint8_t* __restrict__ flags, uint32_t stride, uint32_t amax, bool phased,
-                                                 uint32_t* __restrict__ upper_binds, uint32_t batch_tag) {
-  // e enumerates (locus, a2, a1) with just enough bits per allele index for amax, so that at amax <= 3 two waves
-  // build the whole batch in one step and the other two go straight on to the arithmetic
-  constexpr uint32_t bits = BITS, mask = (1u << bits) - 1u;       // BITS = 1, 2, 3 for amax <= 1, 3, 7
-  for (uint32_t e = threadIdx.x; e < (static_cast<uint32_t>(kEvalBatch) << (2u * bits)); e += kBlock) {
-    const uint32_t a1 = e & mask, a2 = (e >> bits) & mask, i = e >> (2u * bits);
-    if (a1 > amax || a2 > amax) continue;
+// The entries of the selected loci, tabulated ONCE per call: modes 1 and 2 do not depend on F, so the 50 / ~35 passes of
+// a call read the same ones, and the pass itself no longer classifies anything (building them per batch inside the pass
+// was a sixth of its vector instructions, repeated by every workgroup of a segment).  (1 << 2*bits) entries per locus,
+// entry a1 | a2 << bits with bits = eval_bits(amax): 64 / 256 / 1024 bytes per locus.  classify_cell decides every entry, so the class logic is the
+// generic kernel's own.  An index pair past amax is "unclassified", like the slots the pass never refills.
+template <int MODE>
+__global__ void __launch_bounds__(kBlock)
+k_eval_entries(const double* __restrict__ table, const uint8_t* __restrict__ valid, uint64_t n_sel, uint32_t amax, int phased,
+               EvalEntry* __restrict__ entries) {
+  const uint32_t stride = sweep_stride(amax);
+  const uint32_t bits = eval_bits(amax), mask = (1u << bits) - 1u;
+  const uint64_t total = n_sel << (2u * bits);
+  for (uint64_t idx = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x; idx < total;
+       idx += static_cast<uint64_t>(gridDim.x) * blockDim.x) {
+    const uint64_t s = idx >> (2u * bits);
+    const uint32_t a1 = static_cast<uint32_t>(idx) & mask, a2 = (static_cast<uint32_t>(idx) >> bits) & mask;
     double y = MODE == 3 ? 0.0 : 1.0, d = 0.0;
-    if (flags[i] & kLocusValid) {
+    const uint8_t flag = valid[s];
+    if (a1 > amax || a2 > amax) {
+      // MODE 3: a byte past the table is counted as nothing but is odd wherever the locus has defaults
+      if constexpr (MODE == 3) d = __builtin_bit_cast(double, (static_cast<uint64_t>(kOddCell) << 32) | kOddOutside);
+    } else if (flag & kLocusValid) {
       double f1 = 0.0, f2 = 0.0;
-      const int cls = classify_cell(a1 | (a2 << 4), rows + i * stride, amax, phased, f1, f2);
+      const int cls = classify_cell(a1 | (a2 << 4), table + s * stride, amax, phased != 0, f1, f2);
       if constexpr (MODE == 3) {
         uint32_t lo = 0, hi = 0;
         if (cls == kMajorHom) lo = 1u; else if (cls == kMajorHet) lo = 1u << 12;
         else if (cls == kMinorHom) hi = 1u; else if (cls == kMinorHet) hi = 1u << 12;
         // odd: the cell's share of the class-frequency sums is not the segment default's
-        if (flags[i] & kLocusDefault) { if (cls == kClassNone && (a1 | a2) != 0u) lo |= kOddMinus; }
+        if (flag & kLocusDefault) { if (cls == kClassNone && (a1 | a2) != 0u) lo |= kOddMinus; }
         else if (cls != kClassNone) lo |= kOddPlus;
         if (cls == kMajorHom || cls == kMinorHom) {
           if (f1 > 0.001) { y = 1.0 / f1; y -= 1.0; }                  // minimum_frequency (_calc.cpp:380,396)
@@ -312,32 +325,41 @@ __device__ __forceinline__ void build_eval_table(EvalEntry* __restrict__ lut, co
         if constexpr (MODE == 2) { y = f1 * f1; d = f1 - y; }
         else { y = f1; d = 1.0 - f1; }
       } else if (cls != kClassNone) {
-        if constexpr (MODE == 2) {
-          y = 2.0 * f1 * f2; d = -y;
-          // (1-F)*y can pass 1 on [-1, 1] only if y > 1/2: two minor alleles near 1/2 each whose sum checkValidAlleleVector
-          // let through up to 1e-5 over 1.  The batch is then walked with the upper clamp (see the kernel).
-          if (y > 0.5) *upper_binds = batch_tag;
-        }
+        // MODE 2: d < 0 marks the heterozygous entries; (1-F)*y can pass 1 on [-1, 1] only if y > 1/2 (see the pass)
+        if constexpr (MODE == 2) { y = 2.0 * f1 * f2; d = -y; }
       }
     }
-    EvalEntry* slot = lut + i * kEvalSlots + (a1 + 20u * a2);
-    slot->y = y;
-    slot->d = d;
+    entries[idx].y = y;
+    entries[idx].d = d;
   }
 }
 
-template <int MODE, int GPL, int BITS>
+// 16 * (byte B of w): the LDS byte offset of a cell's entry within its locus's table, one SDWA shift.
+template <int B>
+__device__ __forceinline__ uint32_t byte_times_16(uint32_t w, uint32_t four) {
+  uint32_t r;
+  if constexpr (B == 0) asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0" : "=v"(r) : "v"(four), "v"(w));
+  else if constexpr (B == 1) asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1" : "=v"(r) : "v"(four), "v"(w));
+  else if constexpr (B == 2) asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_2" : "=v"(r) : "v"(four), "v"(w));
+  else asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_3" : "=v"(r) : "v"(four), "v"(w));
+  return r;
+}
+
+// The pass.  Per batch of 8 loci the block copies the batch's entries from `entries` into one of two LDS tables (through
+// registers, fetched two batches ahead; the genotype dwords one batch ahead), and each cell is then one LDS read and a
+// few fp64 / integer operations.  The loop is unrolled over the two tables, so a cell's LDS address is one SDWA shift
+// of its slot byte plus an immediate offset.
+template <int MODE, int GPL, bool FOLD>
 __global__ void __launch_bounds__(kBlock)
 k_inbreed_eval_lut(const uint32_t* __restrict__ gt, uint64_t dwords_per_row, uint64_t g0, uint64_t n_genomes,
                    const uint32_t* __restrict__ locus_index, uint64_t n_sel, uint64_t loci_per_seg,
-                   const double* __restrict__ table, const uint8_t* __restrict__ valid, uint32_t amax, int phased,
-                   const double* __restrict__ f_in, double* __restrict__ part, unsigned long long* __restrict__ counts) {
+                   const EvalEntry* __restrict__ entries, const double* __restrict__ table, const uint8_t* __restrict__ valid,
+                   uint32_t amax, const double* __restrict__ f_in, double* __restrict__ part,
+                   unsigned long long* __restrict__ counts) {
   constexpr int DW = GPL / 4;
   __shared__ EvalEntry lut[2][kEvalBatch * kEvalSlots];
-  __shared__ double rows[2][kEvalBatch * sweep_stride(7)];
-  __shared__ uint8_t flags[2][kEvalBatch];
   // MODE 2: upper_binds[b] == tag of the batch in lut[b]  <=>  some entry of that batch can exceed probability 1
-  // (tags are batch numbers + 1, so a word never has to be cleared between uses of its buffer)
+  // (tags are batch numbers + 1, so a word never has to be cleared between uses of its table)
   __shared__ uint32_t upper_binds[2];
   if (threadIdx.x < 2) upper_binds[threadIdx.x] = 0;
   const uint64_t lane = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x;   // genomes g0 + GPL*lane ..
@@ -347,6 +369,8 @@ k_inbreed_eval_lut(const uint32_t* __restrict__ gt, uint64_t dwords_per_row, uin
   const uint64_t s_end = s_begin + loci_per_seg < n_sel ? s_begin + loci_per_seg : n_sel;
   const uint32_t stride = sweep_stride(amax);
   const uint64_t col = (g0 >> 2) + lane * DW;              // g0 is a multiple of GPL
+  const uint32_t bits = eval_bits(amax), mask = (1u << bits) - 1u;
+  const uint32_t in_batch = static_cast<uint32_t>(kEvalBatch) << (2u * bits);              // 32, 128 or 512 entries
 
   double F[MODE == 3 ? 1 : GPL], acc[MODE == 1 ? GPL : 1], run_a[GPL], run_b[MODE == 1 ? GPL : 1];
   int expo[MODE == 2 ? GPL : 1];   // MODE 2: run_a = product;  MODE 1: run_a / run_b = N / D;  MODE 3: run_a = Ritland sum
@@ -366,125 +390,138 @@ k_inbreed_eval_lut(const uint32_t* __restrict__ gt, uint64_t dwords_per_row, uin
     }
   }
 
+  // Every slot starts "unclassified"; the batches refill the (1 << bits)^2 slots their entries have.
   for (uint32_t e = threadIdx.x; e < 2u * kEvalBatch * kEvalSlots; e += kBlock) {
     (&lut[0][0] + e)->y = MODE == 3 ? 0.0 : 1.0;
-    // MODE 3: a byte past the table is counted as nothing but is odd wherever the locus has defaults
     (&lut[0][0] + e)->d = MODE == 3 ? __builtin_bit_cast(double, (static_cast<uint64_t>(kOddCell) << 32) | kOddOutside) : 0.0;
   }
-  // stage(batch): thread t < 8*stride carries one double of the batch's contiguous table rows, t < 8 one valid[] flag
-  double staged_row = 0.0;
-  uint8_t staged_flag = 0;
+  typedef double v2d __attribute__((ext_vector_type(2)));
+  v2d staged[2];                   // entries threadIdx.x and threadIdx.x + 256 of a batch (the second at bits == 3 only)
   auto fetch = [&](uint64_t s0) {
-    staged_row = 0.0;
-    staged_flag = 0;
-    if (s0 >= s_end) return;
-    const uint64_t loci = s_end - s0 < kEvalBatch ? s_end - s0 : kEvalBatch;
-    if (threadIdx.x < loci * stride) staged_row = table[s0 * stride + threadIdx.x];
-    if (threadIdx.x < loci) staged_flag = valid[s0 + threadIdx.x];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const uint32_t idx = threadIdx.x + static_cast<uint32_t>(k) * kBlock;
+      staged[k] = v2d{MODE == 3 ? 0.0 : 1.0, 0.0};           // a locus past the segment: nothing, whatever the byte
+      if (idx < in_batch && s0 + (idx >> (2u * bits)) < s_end)
+        staged[k] = *reinterpret_cast<const v2d*>(entries + (s0 << (2u * bits)) + idx);
+    }
   };
-  auto stash = [&](int rb) {
-    if (threadIdx.x < kEvalBatch * stride) rows[rb][threadIdx.x] = staged_row;
-    if (threadIdx.x < kEvalBatch) flags[rb][threadIdx.x] = staged_flag;
+  auto stash = [&](int rb, uint32_t tag) {
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const uint32_t idx = threadIdx.x + static_cast<uint32_t>(k) * kBlock;
+      if (idx < in_batch) {
+        const uint32_t a1 = idx & mask, a2 = (idx >> bits) & mask, i = idx >> (2u * bits);
+        *reinterpret_cast<v2d*>(&lut[rb][i * kEvalSlots + a1 + 20u * a2]) = staged[k];
+        if constexpr (MODE == 2) {
+          if (staged[k].x > 0.5 && staged[k].y < 0.0) upper_binds[rb] = tag;       // (y, d): heterozygous, y > 1/2
+        }
+      }
+    }
   };
-  fetch(s_begin);
-  stash(0);
-  fetch(s_begin + kEvalBatch);
-  stash(1);
-  __syncthreads();
-  build_eval_table<MODE, BITS>(lut[0], rows[0], flags[0], stride, amax, phased != 0, &upper_binds[0], 1u);
-  __syncthreads();
-  int buf = 0;
-  int batches_open = 0;            // batches since the running fraction / product was last closed
-  for (uint64_t s0 = s_begin; s0 < s_end; s0 += kEvalBatch, buf ^= 1) {
-    uint32_t w[kEvalBatch][DW];
+  auto load_cells = [&](uint32_t (&w)[kEvalBatch][DW], uint64_t base) {
 #pragma unroll
     for (int i = 0; i < kEvalBatch; ++i) {
-      const uint64_t s = s0 + i;
+      const uint64_t s = base + i;
 #pragma unroll
-      for (int k = 0; k < DW; ++k) w[i][k] = MODE == 3 ? 0u : 0x08080808u;  // past the segment: nothing (MODE 3: byte 0 of a locus whose flag is 0, an all-zero entry; else a byte past the table: (1, 0))
+      for (int k = 0; k < DW; ++k) w[i][k] = MODE == 3 ? 0u : 0x08080808u;  // past the segment: nothing (MODE 3: byte 0 of an all-zero table; else a byte past the table: (1, 0))
       if (active && s < s_end) {
         const uint64_t l = locus_index ? static_cast<uint64_t>(locus_index[s]) : s;
         const uint32_t* src = gt + l * dwords_per_row + col;
         if constexpr (DW == 1) {
           w[i][0] = __builtin_nontemporal_load(src);
-        } else if constexpr (DW == 2) {
+        } else {
           typedef uint32_t v2u __attribute__((ext_vector_type(2)));
           const v2u v = __builtin_nontemporal_load(reinterpret_cast<const v2u*>(src));
           w[i][0] = v.x; w[i][1] = v.y;
-        } else {
-          const kgx_v4u v = __builtin_nontemporal_load(reinterpret_cast<const kgx_v4u*>(src));
-          w[i][0] = v.x; w[i][1] = v.y; w[i][2] = v.z; w[i][3] = v.w;
         }
       }
     }
-    fetch(s0 + 2 * kEvalBatch);
+  };
+  // A cell's table entry: slot a1 + 20*a2 of its locus (bit 7 of the byte folded onto bit 3: "unclassified").
+  auto slots_of = [](uint32_t x) {
+    const uint32_t xf = FOLD ? ((x & 0x7F7F7F7Fu) | ((x >> 4) & 0x08080808u)) : (x & 0x7F7F7F7Fu);
+    return xf + ((FOLD ? xf >> 2 : x >> 2) & 0x1C1C1C1Cu);               // a1 + 16*a2 + 4*a2 per byte, < 156: no carry
+  };
+  uint32_t four = 4u;
+  asm volatile("" : "+v"(four));                              // the SDWA shift takes its count from a register
+  int batches_open = 0;            // batches since the running fraction / product was last closed
+
+  // One batch: the table lut[BUF] holds its entries, w its cells.  Meanwhile the next batch's entries go from the
+  // registers into the other table, the entries of the batch after that are fetched, and the next cells are loaded.
+  auto batch = [&](auto buf_c, uint64_t s0, uint32_t (&w)[kEvalBatch][DW], uint32_t (&w_next)[kEvalBatch][DW]) {
+    constexpr int BUF = decltype(buf_c)::value;
     const uint32_t batch_tag = static_cast<uint32_t>((s0 - s_begin) / kEvalBatch) + 1u;
-    const bool clamp_above = MODE == 2 && upper_binds[buf] == batch_tag;          // block-uniform; written before the last barrier
-    if (s0 + kEvalBatch < s_end)
-      build_eval_table<MODE, BITS>(lut[buf ^ 1], rows[buf ^ 1], flags[buf ^ 1], stride, amax, phased != 0, &upper_binds[buf ^ 1], batch_tag + 1u);
+    stash(BUF ^ 1, batch_tag + 1u);
+    fetch(s0 + 2 * kEvalBatch);
+    load_cells(w_next, s0 + kEvalBatch);
+    const bool clamp_above = MODE == 2 && upper_binds[BUF] == batch_tag;          // block-uniform; written before the last barrier
     if (active) {
-      const EvalEntry* __restrict__ cur = lut[buf];
-      // A cell's table entry: slot a1 + 20*a2 of its locus (bit 7 of the byte folded onto bit 3: "unclassified").
-      auto slots_of = [](uint32_t x) {
-        const uint32_t xf = (x & 0x7F7F7F7Fu) | ((x >> 4) & 0x08080808u);
-        return xf + ((xf >> 2) & 0x1C1C1C1Cu);                             // a1 + 16*a2 + 4*a2 per byte, < 156: no carry
+      const char* cur = reinterpret_cast<const char*>(&lut[BUF][0]);
+      auto entry_at = [&](int i, uint32_t offset16) {
+        return *reinterpret_cast<const EvalEntry*>(cur + i * static_cast<int>(kEvalSlots * sizeof(EvalEntry)) + offset16);
+      };
+      // The batch's loci, one behind the other, a locus's GPL table reads issued before the arithmetic of the locus
+      // before it (two sets of entry registers): the reads' latency passes under 3*GPL fp64 operations, and the
+      // registers stay those of two loci -- left alone the compiler either waits for every read where it issues it or
+      // (machine sinking: nothing in this block reads the sums) carries all 64 reads of the batch past the batch.
+      auto read_locus = [&](int i, EvalEntry (&e)[GPL]) {
+#pragma unroll
+        for (int k = 0; k < DW; ++k) {
+          const uint32_t slots = slots_of(w[i][k]);
+          e[4 * k + 0] = entry_at(i, byte_times_16<0>(slots, four));
+          e[4 * k + 1] = entry_at(i, byte_times_16<1>(slots, four));
+          e[4 * k + 2] = entry_at(i, byte_times_16<2>(slots, four));
+          e[4 * k + 3] = entry_at(i, byte_times_16<3>(slots, four));
+        }
+      };
+      auto walk = [&](auto&& cell) {
+        EvalEntry e_a[GPL], e_b[GPL];
+        read_locus(0, e_a);
+#pragma unroll
+        for (int i = 0; i < kEvalBatch; ++i) {
+          EvalEntry (&e)[GPL] = (i & 1) ? e_b : e_a;
+          if (i + 1 < kEvalBatch) read_locus(i + 1, (i & 1) ? e_a : e_b);
+          if (KGX_EVAL_SCHED_BARRIER) __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int j = 0; j < GPL; ++j) cell(j, e[j]);
+          // the empty asm reads the sums here, so the locus's arithmetic stays here
+#pragma unroll
+          for (int j = 0; j < GPL; ++j) {
+            if constexpr (MODE == 3) asm volatile("" : "+v"(run_a[j]), "+v"(cnt_lo[j]), "+v"(cnt_hi[j]));
+            else if constexpr (MODE == 1) asm volatile("" : "+v"(run_a[j]), "+v"(run_b[j]));
+            else asm volatile("" : "+v"(run_a[j]));
+          }
+          if (KGX_EVAL_SCHED_BARRIER) __builtin_amdgcn_sched_barrier(0);
+        }
       };
       if constexpr (MODE == 2) {
         // The clamp of logLikelihood (:117-121).  For -1 <= F <= 1 (the search interval) its upper bound cannot bind on a
         // homozygous cell, F*f + (1-F)*f*f <= max(f, 2*f*f - f) <= 1 (at f = 1: y = 1, d = 0, the fma exact), nor on an
-        // unclassified one (1, 0); on a heterozygous cell, 2*(1-F)*f1*f2 <= 4*f1*f2, only if y > 1/2.  So the batch's
-        // cells are compiled twice, and the form with the fp64 min per cell runs only where build_eval_table saw such an
-        // entry (one block-uniform branch per batch).
-        auto walk_cells = [&](auto above_c) {
-          constexpr bool kClampAbove = decltype(above_c)::value;
-#pragma unroll
-          for (int i = 0; i < kEvalBatch; ++i) {
-#pragma unroll
-            for (int k = 0; k < DW; ++k) {
-              const uint32_t slots = slots_of(w[i][k]);
-#pragma unroll
-              for (int b = 0; b < 4; ++b) {
-                const int j = 4 * k + b;
-                const EvalEntry e = cur[i * kEvalSlots + ((slots >> (8 * b)) & 0xFFu)];
-                const double floored = __builtin_fmax(__builtin_fma(F[MODE == 3 ? 0 : j], e.d, e.y), 1e-10);
-                run_a[j] *= kClampAbove ? __builtin_fmin(floored, 1.0) : floored;
-              }
-            }
-          }
-        };
-        if (clamp_above) walk_cells(std::true_type{});
-        else walk_cells(std::false_type{});
-      } else {
-#pragma unroll
-        for (int i = 0; i < kEvalBatch; ++i) {
-#pragma unroll
-          for (int k = 0; k < DW; ++k) {
-            const uint32_t slots = slots_of(w[i][k]);
-#pragma unroll
-            for (int b = 0; b < 4; ++b) {
-              const int j = 4 * k + b;
-              const EvalEntry e = cur[i * kEvalSlots + ((slots >> (8 * b)) & 0xFFu)];
-              if constexpr (MODE == 3) {
-                run_a[j] += e.y;
-                const uint64_t packed = __builtin_bit_cast(uint64_t, e.d);
-                cnt_lo[j] += static_cast<uint32_t>(packed);
-                cnt_hi[j] += static_cast<uint32_t>(packed >> 32);
-              } else {
-                const double v = __builtin_fma(F[MODE == 3 ? 0 : j], e.d, e.y);
-                run_a[j] = __builtin_fma(run_a[j], v, run_b[j]);
-                run_b[j] *= v;
-              }
-            }
-          }
-          // MODE 3: nothing in this block reads the sums, so machine sinking would carry the batch's 64 fp64 adds and 128
-          // counter adds past the odd-cell branch below and keep every entry read until then alive (319 registers, one
-          // wave per SIMD).  The empty asm reads them here: a locus's reads and adds stay together.
-          if constexpr (MODE == 3) {
-#pragma unroll
-            for (int j = 0; j < GPL; ++j) asm volatile("" : "+v"(run_a[j]), "+v"(cnt_lo[j]), "+v"(cnt_hi[j]));
-            __builtin_amdgcn_sched_barrier(0);
-          }
+        // unclassified one (1, 0); on a heterozygous cell, 2*(1-F)*f1*f2 <= 4*f1*f2, only if y > 1/2: two minor alleles
+        // near 1/2 each whose sum checkValidAlleleVector let through up to 1e-5 over 1.  So the batch's cells are compiled
+        // twice, and the form with the fp64 min per cell runs only where the copy into the table saw such an entry (one
+        // block-uniform branch per batch).
+        if (clamp_above) {
+          walk([&](int j, const EvalEntry& e) {
+            run_a[j] *= __builtin_fmin(__builtin_fmax(__builtin_fma(F[MODE == 3 ? 0 : j], e.d, e.y), 1e-10), 1.0);
+          });
+        } else {
+          walk([&](int j, const EvalEntry& e) { run_a[j] *= __builtin_fmax(__builtin_fma(F[MODE == 3 ? 0 : j], e.d, e.y), 1e-10); });
         }
+      } else if constexpr (MODE == 3) {
+        walk([&](int j, const EvalEntry& e) {
+          run_a[j] += e.y;
+          const uint64_t packed = __builtin_bit_cast(uint64_t, e.d);
+          cnt_lo[j] += static_cast<uint32_t>(packed);
+          cnt_hi[j] += static_cast<uint32_t>(packed >> 32);
+        });
+      } else {
+        walk([&](int j, const EvalEntry& e) {
+          const double v = __builtin_fma(F[MODE == 3 ? 0 : j], e.d, e.y);
+          run_a[j] = __builtin_fma(run_a[j], v, run_b[j]);
+          run_b[j] *= v;
+        });
       }
       if constexpr (MODE == 3) {
         uint32_t seen = 0;
@@ -496,9 +533,9 @@ k_inbreed_eval_lut(const uint32_t* __restrict__ gt, uint64_t dwords_per_row, uin
           // The lanes that met one look at their cells of the batch once more, this time for what is odd about them: an odd
           // cell adjusts the lane's own (segment, genome) partial slot in memory (single writer: the order of its adds is
           // the program's) or the genome's Ritland count.  Rolled loops, bytes re-read from the matrix (L2 hits), the
-          // locus's row from memory as well -- not from rows[buf]: a faster wave may already have stashed the batch
-          // after next's rows there (only the table build reads those, behind the barrier).
+          // locus's class frequencies from the per-locus table in memory.
           if ((seen >> 28) != 0u) {
+            const EvalEntry* cur_entries = &lut[BUF][0];
 #pragma nounroll
             for (int i = 0; i < kEvalBatch; ++i) {
               const uint64_t s = s0 + i;
@@ -511,7 +548,7 @@ k_inbreed_eval_lut(const uint32_t* __restrict__ gt, uint64_t dwords_per_row, uin
               for (int j = 0; j < GPL; ++j) {
                 const uint64_t g = lane * GPL + j;
                 if (g >= n_genomes) break;
-                const uint32_t odd = static_cast<uint32_t>(__builtin_bit_cast(uint64_t, cur[i * kEvalSlots + eval_slot(bytes[j])].d)) >> 24;
+                const uint32_t odd = static_cast<uint32_t>(__builtin_bit_cast(uint64_t, cur_entries[i * kEvalSlots + eval_slot<FOLD>(bytes[j])].d)) >> 24;
                 if (odd == 0u) continue;
                 const double sign = (odd & (kOddMinus >> 24)) ? -1.0 : (odd & (kOddPlus >> 24)) ? 1.0
                                     : ((odd & (kOddOutside >> 24)) && (flag & kLocusDefault)) ? -1.0 : 0.0;
@@ -547,8 +584,20 @@ k_inbreed_eval_lut(const uint32_t* __restrict__ gt, uint64_t dwords_per_row, uin
       }
       if (closing || batches_open >= kHallBatches) batches_open = 0;
     }
-    stash(buf);          // rows[buf] fed this batch's table one iteration ago: free for the batch after next
-    __syncthreads();
+    __syncthreads();     // the other table is complete, and this one is free for the batch after next
+  };
+
+  __syncthreads();                                           // the prefill, before the first entries land on it
+  fetch(s_begin);
+  stash(0, 1u);
+  fetch(s_begin + kEvalBatch);
+  uint32_t w_a[kEvalBatch][DW], w_b[kEvalBatch][DW];
+  load_cells(w_a, s_begin);
+  __syncthreads();
+  for (uint64_t s0 = s_begin; s0 < s_end; s0 += 2 * kEvalBatch) {
+    batch(std::integral_constant<int, 0>{}, s0, w_a, w_b);
+    if (s0 + kEvalBatch >= s_end) break;
+    batch(std::integral_constant<int, 1>{}, s0 + kEvalBatch, w_b, w_a);
   }
 
   if (!active) return;
