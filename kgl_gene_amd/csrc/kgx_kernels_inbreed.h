@@ -234,8 +234,9 @@ k_inbreed_sweep(const uint32_t* __restrict__ gt, uint64_t dwords_per_row, uint64
 //           exponent of the running product is peeled off into an integer after every batch, and ONE log per
 //           (segment, genome) is taken at the end: sum(log p) = log(prod p).
 //   MODE 1  v = the denominator F + (1-F)*f1 of a homozygous cell: y = f1, d = 1 - f1; every other cell (1, 0), i.e.
-//           v = 1 exactly.  The terms 1/v of ALL cells of a batch are summed as one fraction N/D (N <- N*v + D,
-//           D <- D*v; one division per kHallBatches batches), so part[] holds  sum_hom 1/v + #(other cells the lane walked);
+//           v = 1 exactly.  The terms 1/v of ALL cells of a segment are summed as one fraction N/D (N <- N*v + D,
+//           D <- D*v, both rescaled by a power of two every other batch; one division per segment), so part[] holds
+//           sum_hom 1/v + #(other cells the lane walked);
 //           k_hall_update subtracts that count (it is known: loci walked - homozygous cells counted by the frequency
 //           sweep) and multiplies by F.  The reference's zero-denominator guard (_calc.cpp:272) can only fire at
 //           F = 0, where every term F/v is 0: such a genome is walked with F = 1 (v = 1 everywhere) and the
@@ -260,12 +261,14 @@ k_inbreed_sweep(const uint32_t* __restrict__ gt, uint64_t dwords_per_row, uint64
 // slots of the cells a 16-lane ds_read_b128 group meets together -- a1, a2 in 0..3 -- fall on 16 different bank quads
 // ((a1 + 4*a2) mod 16); at slot a1 + 16*a2 every a2 shared a1's banks (SQ_LDS_BANK_CONFLICT: 2.7 extra cycles a read).
 // GPL genomes per lane (4 or 8: one dword / dwordx2 load per locus).
-#ifndef KGX_EVAL_SCHED_BARRIER
-#define KGX_EVAL_SCHED_BARRIER 1
+#ifndef KGX_EVAL_DEPTH
+#define KGX_EVAL_DEPTH 1            // table reads in flight ahead of the arithmetic, in groups of four (modes 1, 2)
+#endif
+#ifndef KGX_EVAL_DEPTH3
+#define KGX_EVAL_DEPTH3 2           // ... mode 3, which has the registers for it
 #endif
 struct alignas(16) EvalEntry { double y, d; };
 constexpr int kEvalBatch = 8;
-constexpr int kHallBatches = 8;    // MODE 1: batches summed as one fraction before the division
 constexpr uint32_t kEvalSlots = 160;
 constexpr uint64_t kRitlandSegment = 4088;        // MODE 3: loci per segment, below the 12-bit class counters' range
 constexpr uint32_t kOddCell = 1u << 28;           // MODE 3: in the entry's hi word: one more odd cell (a 4-bit count per batch)
@@ -325,7 +328,6 @@ k_eval_entries(const double* __restrict__ table, const uint8_t* __restrict__ val
         if constexpr (MODE == 2) { y = f1 * f1; d = f1 - y; }
         else { y = f1; d = 1.0 - f1; }
       } else if (cls != kClassNone) {
-        // MODE 2: d < 0 marks the heterozygous entries; (1-F)*y can pass 1 on [-1, 1] only if y > 1/2 (see the pass)
         if constexpr (MODE == 2) { y = 2.0 * f1 * f2; d = -y; }
       }
     }
@@ -358,10 +360,6 @@ k_inbreed_eval_lut(const uint32_t* __restrict__ gt, uint64_t dwords_per_row, uin
                    unsigned long long* __restrict__ counts) {
   constexpr int DW = GPL / 4;
   __shared__ EvalEntry lut[2][kEvalBatch * kEvalSlots];
-  // MODE 2: upper_binds[b] == tag of the batch in lut[b]  <=>  some entry of that batch can exceed probability 1
-  // (tags are batch numbers + 1, so a word never has to be cleared between uses of its table)
-  __shared__ uint32_t upper_binds[2];
-  if (threadIdx.x < 2) upper_binds[threadIdx.x] = 0;
   const uint64_t lane = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x;   // genomes g0 + GPL*lane ..
   const bool active = lane * GPL < n_genomes;
   const uint64_t seg = blockIdx.y;
@@ -372,7 +370,7 @@ k_inbreed_eval_lut(const uint32_t* __restrict__ gt, uint64_t dwords_per_row, uin
   const uint32_t bits = eval_bits(amax), mask = (1u << bits) - 1u;
   const uint32_t in_batch = static_cast<uint32_t>(kEvalBatch) << (2u * bits);              // 32, 128 or 512 entries
 
-  double F[MODE == 3 ? 1 : GPL], acc[MODE == 1 ? GPL : 1], run_a[GPL], run_b[MODE == 1 ? GPL : 1];
+  double F[MODE == 3 ? 1 : GPL], run_a[GPL], run_b[MODE == 1 ? GPL : 1];
   int expo[MODE == 2 ? GPL : 1];   // MODE 2: run_a = product;  MODE 1: run_a / run_b = N / D;  MODE 3: run_a = Ritland sum
   uint32_t cnt_lo[MODE == 3 ? GPL : 1], cnt_hi[MODE == 3 ? GPL : 1];   // MODE 3: packed class counters (see above)
 #pragma unroll
@@ -381,7 +379,7 @@ k_inbreed_eval_lut(const uint32_t* __restrict__ gt, uint64_t dwords_per_row, uin
     if constexpr (MODE != 3) F[j] = g < n_genomes ? f_in[g] : 0.0;
     run_a[j] = MODE == 2 ? 1.0 : 0.0;
     if constexpr (MODE == 1) {
-      acc[j] = 0.0; run_b[j] = 1.0;
+      run_b[j] = 1.0;
       if (!(F[j] > 0.0)) F[j] = 1.0;                        // see above: v = 1 everywhere, k_hall_update multiplies by the real F
     } else if constexpr (MODE == 2) {
       expo[j] = 0;
@@ -396,45 +394,59 @@ k_inbreed_eval_lut(const uint32_t* __restrict__ gt, uint64_t dwords_per_row, uin
     (&lut[0][0] + e)->d = MODE == 3 ? __builtin_bit_cast(double, (static_cast<uint64_t>(kOddCell) << 32) | kOddOutside) : 0.0;
   }
   typedef double v2d __attribute__((ext_vector_type(2)));
-  v2d staged[2];                   // entries threadIdx.x and threadIdx.x + 256 of a batch (the second at bits == 3 only)
-  auto fetch = [&](uint64_t s0) {
-#pragma unroll
-    for (int k = 0; k < 2; ++k) {
-      const uint32_t idx = threadIdx.x + static_cast<uint32_t>(k) * kBlock;
-      staged[k] = v2d{MODE == 3 ? 0.0 : 1.0, 0.0};           // a locus past the segment: nothing, whatever the byte
-      if (idx < in_batch && s0 + (idx >> (2u * bits)) < s_end)
-        staged[k] = *reinterpret_cast<const v2d*>(entries + (s0 << (2u * bits)) + idx);
+  // Positions within the segment are 32-bit (the scalar unit compares those; 64-bit ones go through the vector unit).
+  const uint32_t seg_len = static_cast<uint32_t>(s_end - s_begin);
+  const EvalEntry* __restrict__ seg_entries = entries + (s_begin << (2u * bits));
+  const uint32_t* __restrict__ seg_index = locus_index ? locus_index + s_begin : nullptr;
+  // Entry threadIdx.x of a batch travels through a register pair, fetched two batches ahead; at bits == 3 a batch has
+  // 512 entries and the second of the thread goes straight from memory to the table (four-to-seven-allele loci only).
+  // With a locus index, the batch's eight row numbers travel the same way (every lane holds all eight).
+  v2d staged;
+  kgx_v4u staged_rows[2];
+  auto entry_of = [&](uint32_t r0, uint32_t idx) {
+    v2d e{MODE == 3 ? 0.0 : 1.0, 0.0};                       // a locus past the segment: nothing, whatever the byte
+    if (idx < in_batch && r0 + (idx >> (2u * bits)) < seg_len) e = *reinterpret_cast<const v2d*>(seg_entries + ((r0 << (2u * bits)) + idx));
+    return e;
+  };
+  auto fetch = [&](uint32_t r0) {
+    staged = entry_of(r0, threadIdx.x);
+    if (seg_index && r0 < seg_len) {                          // the index is padded by 8 entries (0) past its end
+      staged_rows[0] = *reinterpret_cast<const kgx_v4u*>(seg_index + r0);
+      staged_rows[1] = *reinterpret_cast<const kgx_v4u*>(seg_index + r0 + 4);
     }
   };
-  auto stash = [&](int rb, uint32_t tag) {
-#pragma unroll
-    for (int k = 0; k < 2; ++k) {
-      const uint32_t idx = threadIdx.x + static_cast<uint32_t>(k) * kBlock;
-      if (idx < in_batch) {
-        const uint32_t a1 = idx & mask, a2 = (idx >> bits) & mask, i = idx >> (2u * bits);
-        *reinterpret_cast<v2d*>(&lut[rb][i * kEvalSlots + a1 + 20u * a2]) = staged[k];
-        if constexpr (MODE == 2) {
-          if (staged[k].x > 0.5 && staged[k].y < 0.0) upper_binds[rb] = tag;       // (y, d): heterozygous, y > 1/2
-        }
-      }
+  auto put = [&](int rb, uint32_t idx, v2d e) {
+    if (idx < in_batch) {
+      const uint32_t a1 = idx & mask, a2 = (idx >> bits) & mask, i = idx >> (2u * bits);
+      *reinterpret_cast<v2d*>(&lut[rb][i * kEvalSlots + a1 + 20u * a2]) = e;
     }
   };
-  auto load_cells = [&](uint32_t (&w)[kEvalBatch][DW], uint64_t base) {
+  auto stash = [&](int rb, uint32_t r0) {                     // r0: the batch the registers hold
+    put(rb, threadIdx.x, staged);
+    if (bits == 3u) put(rb, threadIdx.x + kBlock, entry_of(r0, threadIdx.x + kBlock));
+  };
+  // The cells of the batch at r0 (whose row numbers the registers hold).  A locus past the segment reads the
+  // segment's last row (or, indexed, row 0) against a table of nothing.
+  const uint64_t row_base = seg_index ? 0ull : s_begin;
+  // The rows of the batch at r0, as scalars (out of the registers before the next fetch), relative to row_base.
+  auto take_rows = [&](uint32_t (&rows)[kEvalBatch], uint32_t r0) {
 #pragma unroll
     for (int i = 0; i < kEvalBatch; ++i) {
-      const uint64_t s = base + i;
+      const uint32_t r = r0 + i < seg_len ? r0 + i : seg_len - 1u;
+      rows[i] = seg_index ? static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(staged_rows[i / 4][i % 4]))) : r;
+    }
+  };
+  auto load_cells = [&](uint32_t (&w)[kEvalBatch][DW], uint32_t r0, const uint32_t (&rows)[kEvalBatch]) {
+    if (!active || r0 >= seg_len) return;
 #pragma unroll
-      for (int k = 0; k < DW; ++k) w[i][k] = MODE == 3 ? 0u : 0x08080808u;  // past the segment: nothing (MODE 3: byte 0 of an all-zero table; else a byte past the table: (1, 0))
-      if (active && s < s_end) {
-        const uint64_t l = locus_index ? static_cast<uint64_t>(locus_index[s]) : s;
-        const uint32_t* src = gt + l * dwords_per_row + col;
-        if constexpr (DW == 1) {
-          w[i][0] = __builtin_nontemporal_load(src);
-        } else {
-          typedef uint32_t v2u __attribute__((ext_vector_type(2)));
-          const v2u v = __builtin_nontemporal_load(reinterpret_cast<const v2u*>(src));
-          w[i][0] = v.x; w[i][1] = v.y;
-        }
+    for (int i = 0; i < kEvalBatch; ++i) {
+      const uint32_t* src = gt + (row_base + rows[i]) * dwords_per_row + col;
+      if constexpr (DW == 1) {
+        w[i][0] = __builtin_nontemporal_load(src);
+      } else {
+        typedef uint32_t v2u __attribute__((ext_vector_type(2)));
+        const v2u v = __builtin_nontemporal_load(reinterpret_cast<const v2u*>(src));
+        w[i][0] = v.x; w[i][1] = v.y;
       }
     }
   };
@@ -445,70 +457,60 @@ k_inbreed_eval_lut(const uint32_t* __restrict__ gt, uint64_t dwords_per_row, uin
   };
   uint32_t four = 4u;
   asm volatile("" : "+v"(four));                              // the SDWA shift takes its count from a register
-  int batches_open = 0;            // batches since the running fraction / product was last closed
 
   // One batch: the table lut[BUF] holds its entries, w its cells.  Meanwhile the next batch's entries go from the
   // registers into the other table, the entries of the batch after that are fetched, and the next cells are loaded.
-  auto batch = [&](auto buf_c, uint64_t s0, uint32_t (&w)[kEvalBatch][DW], uint32_t (&w_next)[kEvalBatch][DW]) {
+  auto batch = [&](auto buf_c, uint32_t r0, uint32_t (&w)[kEvalBatch][DW], uint32_t (&w_next)[kEvalBatch][DW]) {
     constexpr int BUF = decltype(buf_c)::value;
-    const uint32_t batch_tag = static_cast<uint32_t>((s0 - s_begin) / kEvalBatch) + 1u;
-    stash(BUF ^ 1, batch_tag + 1u);
-    fetch(s0 + 2 * kEvalBatch);
-    load_cells(w_next, s0 + kEvalBatch);
-    const bool clamp_above = MODE == 2 && upper_binds[BUF] == batch_tag;          // block-uniform; written before the last barrier
+    stash(BUF ^ 1, r0 + kEvalBatch);
+    uint32_t rows[kEvalBatch];
+    take_rows(rows, r0 + kEvalBatch);
+    fetch(r0 + 2 * kEvalBatch);
+    load_cells(w_next, r0 + kEvalBatch, rows);
     if (active) {
       const char* cur = reinterpret_cast<const char*>(&lut[BUF][0]);
       auto entry_at = [&](int i, uint32_t offset16) {
         return *reinterpret_cast<const EvalEntry*>(cur + i * static_cast<int>(kEvalSlots * sizeof(EvalEntry)) + offset16);
       };
-      // The batch's loci, one behind the other, a locus's GPL table reads issued before the arithmetic of the locus
-      // before it (two sets of entry registers): the reads' latency passes under 3*GPL fp64 operations, and the
-      // registers stay those of two loci -- left alone the compiler either waits for every read where it issues it or
-      // (machine sinking: nothing in this block reads the sums) carries all 64 reads of the batch past the batch.
-      auto read_locus = [&](int i, EvalEntry (&e)[GPL]) {
-#pragma unroll
-        for (int k = 0; k < DW; ++k) {
-          const uint32_t slots = slots_of(w[i][k]);
-          e[4 * k + 0] = entry_at(i, byte_times_16<0>(slots, four));
-          e[4 * k + 1] = entry_at(i, byte_times_16<1>(slots, four));
-          e[4 * k + 2] = entry_at(i, byte_times_16<2>(slots, four));
-          e[4 * k + 3] = entry_at(i, byte_times_16<3>(slots, four));
-        }
+      // The batch's cells in groups of four (one dword), a group's four table reads issued kEvalDepth groups before its
+      // arithmetic: the reads' latency passes under that of the groups before it, and the registers stay those of
+      // kEvalDepth + 1 groups -- left alone the compiler either waits for every read where it issues it or (machine
+      // sinking: nothing in this block reads the sums) carries all 64 reads of the batch past the batch.
+      constexpr int kGroups = kEvalBatch * DW, kDepth = MODE == 3 ? KGX_EVAL_DEPTH3 : KGX_EVAL_DEPTH;
+      auto read_group = [&](int q, EvalEntry (&e)[4]) {
+        const uint32_t slots = slots_of(w[q / DW][q % DW]);
+        e[0] = entry_at(q / DW, byte_times_16<0>(slots, four));
+        e[1] = entry_at(q / DW, byte_times_16<1>(slots, four));
+        e[2] = entry_at(q / DW, byte_times_16<2>(slots, four));
+        e[3] = entry_at(q / DW, byte_times_16<3>(slots, four));
       };
       auto walk = [&](auto&& cell) {
-        EvalEntry e_a[GPL], e_b[GPL];
-        read_locus(0, e_a);
+        EvalEntry e[kDepth + 1][4];
 #pragma unroll
-        for (int i = 0; i < kEvalBatch; ++i) {
-          EvalEntry (&e)[GPL] = (i & 1) ? e_b : e_a;
-          if (i + 1 < kEvalBatch) read_locus(i + 1, (i & 1) ? e_a : e_b);
-          if (KGX_EVAL_SCHED_BARRIER) __builtin_amdgcn_sched_barrier(0);
+        for (int q = 0; q < kDepth; ++q) read_group(q, e[q]);
 #pragma unroll
-          for (int j = 0; j < GPL; ++j) cell(j, e[j]);
-          // the empty asm reads the sums here, so the locus's arithmetic stays here
+        for (int q = 0; q < kGroups; ++q) {
+          if (q + kDepth < kGroups) read_group(q + kDepth, e[(q + kDepth) % (kDepth + 1)]);
+          __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-          for (int j = 0; j < GPL; ++j) {
+          for (int b = 0; b < 4; ++b) {
+            const int j = 4 * (q % DW) + b;
+            cell(j, e[q % (kDepth + 1)][b]);
+            // the empty asm reads the sums here, so the group's arithmetic stays here
             if constexpr (MODE == 3) asm volatile("" : "+v"(run_a[j]), "+v"(cnt_lo[j]), "+v"(cnt_hi[j]));
             else if constexpr (MODE == 1) asm volatile("" : "+v"(run_a[j]), "+v"(run_b[j]));
             else asm volatile("" : "+v"(run_a[j]));
           }
-          if (KGX_EVAL_SCHED_BARRIER) __builtin_amdgcn_sched_barrier(0);
+          __builtin_amdgcn_sched_barrier(0);
         }
       };
       if constexpr (MODE == 2) {
-        // The clamp of logLikelihood (:117-121).  For -1 <= F <= 1 (the search interval) its upper bound cannot bind on a
-        // homozygous cell, F*f + (1-F)*f*f <= max(f, 2*f*f - f) <= 1 (at f = 1: y = 1, d = 0, the fma exact), nor on an
-        // unclassified one (1, 0); on a heterozygous cell, 2*(1-F)*f1*f2 <= 4*f1*f2, only if y > 1/2: two minor alleles
-        // near 1/2 each whose sum checkValidAlleleVector let through up to 1e-5 over 1.  So the batch's cells are compiled
-        // twice, and the form with the fp64 min per cell runs only where the copy into the table saw such an entry (one
-        // block-uniform branch per batch).
-        if (clamp_above) {
-          walk([&](int j, const EvalEntry& e) {
-            run_a[j] *= __builtin_fmin(__builtin_fmax(__builtin_fma(F[MODE == 3 ? 0 : j], e.d, e.y), 1e-10), 1.0);
-          });
-        } else {
-          walk([&](int j, const EvalEntry& e) { run_a[j] *= __builtin_fmax(__builtin_fma(F[MODE == 3 ? 0 : j], e.d, e.y), 1e-10); });
-        }
+        // The clamp of logLikelihood (:117-121) to [1e-10, 1]: the fma's clamp bit takes the value into [0, 1] for
+        // nothing (min(max(x, 0), 1) is folded into it), the fp64 max lifts it to 1e-10.
+        walk([&](int j, const EvalEntry& e) {
+          const double p = __builtin_fmin(__builtin_fmax(__builtin_fma(F[MODE == 3 ? 0 : j], e.d, e.y), 0.0), 1.0);
+          run_a[j] *= __builtin_fmax(p, 1e-10);
+        });
       } else if constexpr (MODE == 3) {
         walk([&](int j, const EvalEntry& e) {
           run_a[j] += e.y;
@@ -538,8 +540,8 @@ k_inbreed_eval_lut(const uint32_t* __restrict__ gt, uint64_t dwords_per_row, uin
             const EvalEntry* cur_entries = &lut[BUF][0];
 #pragma nounroll
             for (int i = 0; i < kEvalBatch; ++i) {
-              const uint64_t s = s0 + i;
-              if (s >= s_end) break;
+              if (r0 + i >= seg_len) break;
+              const uint64_t s = s_begin + r0 + i;
               const uint8_t flag = valid[s];
               const double* row = table + s * stride;
               const uint64_t l = locus_index ? static_cast<uint64_t>(locus_index[s]) : s;
@@ -563,41 +565,39 @@ k_inbreed_eval_lut(const uint32_t* __restrict__ gt, uint64_t dwords_per_row, uin
           }
         }
       }
-      // MODE 1: the fraction N/D runs on over up to kHallBatches batches before its one division -- the division is a
-      // dozen fp64 instructions, a quarter of the pass when taken every 8 cells.  D is a product of denominators
-      // F + (1-F)*f1 <= 1 and shrinks; a lane whose D has fallen below 1e-100 divides at once (8 more factors would
-      // have to average 1e-26 to take it under).  The last batch of the segment always divides.
-      const bool closing = s0 + kEvalBatch >= s_end;            // block-uniform
-      ++batches_open;
+      // MODE 2: 8 factors >= 1e-10 a batch: no underflow before the exponent is peeled.
+      // MODE 1: D is a product of denominators F + (1-F)*f1 <= 1 and shrinks, so every other batch N and D are scaled by
+      // the power of two that takes D back into [1/2, 1) -- exact, and the 16 factors in between would have to average
+      // 1e-19 to take D under.  One division per (segment, genome), at the end.
 #pragma unroll
       for (int j = 0; j < GPL; ++j) {
-        if constexpr (MODE == 2) {                          // 8 factors >= 1e-10: no underflow before the exponent is peeled
+        if constexpr (MODE == 2) {
           expo[j] += __builtin_amdgcn_frexp_exp(run_a[j]);
           run_a[j] = __builtin_amdgcn_frexp_mant(run_a[j]);
-        } else if constexpr (MODE == 1) {
-          if (closing || batches_open >= kHallBatches || run_b[j] < 1e-100) {
-            acc[j] += run_a[j] / run_b[j];
-            run_a[j] = 0.0;
-            run_b[j] = 1.0;
-          }
+        } else if constexpr (MODE == 1 && BUF == 1) {
+          run_a[j] = __builtin_ldexp(run_a[j], -__builtin_amdgcn_frexp_exp(run_b[j]));
+          run_b[j] = __builtin_amdgcn_frexp_mant(run_b[j]);
         }
       }
-      if (closing || batches_open >= kHallBatches) batches_open = 0;
     }
     __syncthreads();     // the other table is complete, and this one is free for the batch after next
   };
 
   __syncthreads();                                           // the prefill, before the first entries land on it
-  fetch(s_begin);
-  stash(0, 1u);
-  fetch(s_begin + kEvalBatch);
   uint32_t w_a[kEvalBatch][DW], w_b[kEvalBatch][DW];
-  load_cells(w_a, s_begin);
+  fetch(0);
+  stash(0, 0);
+  {
+    uint32_t rows[kEvalBatch];
+    take_rows(rows, 0);
+    fetch(kEvalBatch);
+    load_cells(w_a, 0, rows);
+  }
   __syncthreads();
-  for (uint64_t s0 = s_begin; s0 < s_end; s0 += 2 * kEvalBatch) {
-    batch(std::integral_constant<int, 0>{}, s0, w_a, w_b);
-    if (s0 + kEvalBatch >= s_end) break;
-    batch(std::integral_constant<int, 1>{}, s0 + kEvalBatch, w_b, w_a);
+  for (uint32_t r0 = 0; r0 < seg_len; r0 += 2 * kEvalBatch) {
+    batch(std::integral_constant<int, 0>{}, r0, w_a, w_b);
+    if (r0 + kEvalBatch >= seg_len) break;
+    batch(std::integral_constant<int, 1>{}, r0 + kEvalBatch, w_b, w_a);
   }
 
   if (!active) return;
@@ -608,7 +608,7 @@ k_inbreed_eval_lut(const uint32_t* __restrict__ gt, uint64_t dwords_per_row, uin
     if constexpr (MODE == 2) {
       part[seg * n_genomes + g] = log(run_a[j]) + static_cast<double>(expo[j]) * 0.6931471805599453;
     } else if constexpr (MODE == 1) {
-      part[seg * n_genomes + g] = acc[j];
+      part[seg * n_genomes + g] = run_a[j] / run_b[j];
     } else {
       part[(seg * n_genomes + g) * kParts0 + 4] = run_a[j];
       const unsigned long long major_hom = cnt_lo[j] & 0xFFFu, major_het = (cnt_lo[j] >> 12) & 0xFFFu;
