@@ -79,13 +79,15 @@ int inbreed_shard(kgx_gt8_shard& sh, uint64_t g0, uint64_t g1, const uint32_t* l
   static_assert(sizeof(kgx_locus_results) == sizeof(LocusResultsDev), "LocusResults layout");
 
   const uint32_t stride = sweep_stride(amax);
-  // Frequency pass flavour: 16 genomes per lane (SWAR, 16-byte loads) when the group starts on a 16-genome boundary,
-  // otherwise 4 genomes per lane.  RitlandLocus with allele indices that fit the tables: ONE table pass that yields the
-  // class counts, the class-frequency sums and the Ritland terms together (k_inbreed_eval_lut<3>), no SWAR sweep.
-  const bool ritland_lut = algorithm == KGX_ALGO_RITLAND_LOCUS && !env_int("KGX_K5_GENERIC", 0) && !env_int("KGX_K5_NO_EVAL_LUT", 0) &&
-                           amax <= 7 && n_sel <= 65535ull * kRitlandSegment;
-  const bool swar16 = !env_int("KGX_K5_GENERIC", 0) && !env_int("KGX_K5_NO_SWAR16", 0) && amax <= 4 && (g0 & 15u) == 0 &&
-                      algorithm != KGX_ALGO_RITLAND_LOCUS;
+  // Frequency pass flavour.  With allele indices that fit the tables (amax <= 7): ONE table pass that yields the class
+  // counts and the class-frequency sums (k_inbreed_eval_lut<4>) and, for RitlandLocus, the Ritland terms with them
+  // (k_inbreed_eval_lut<3>).  KGX_K5_NO_TABLE_SWEEP=1 (not for RitlandLocus): the SWAR sweeps instead -- 16 genomes per
+  // lane (16-byte loads) when the group starts on a 16-genome boundary, otherwise 4 genomes per lane (amax <= 4).
+  const bool ritland = algorithm == KGX_ALGO_RITLAND_LOCUS;
+  const bool table_sweep = !env_int("KGX_K5_GENERIC", 0) && !env_int("KGX_K5_NO_EVAL_LUT", 0) && amax <= 7 &&
+                           n_sel <= 65535ull * kRitlandSegment && (ritland || !env_int("KGX_K5_NO_TABLE_SWEEP", 0));
+  const bool swar16 = !table_sweep && !env_int("KGX_K5_GENERIC", 0) && !env_int("KGX_K5_NO_SWAR16", 0) && amax <= 4 && (g0 & 15u) == 0 &&
+                      !ritland;
   // The evaluation passes of HallME / Loglikelihood go through the per-batch LDS tables when the allele indices fit them.
   const bool eval_lut = !env_int("KGX_K5_GENERIC", 0) && !env_int("KGX_K5_NO_EVAL_LUT", 0) && amax <= 7;
   int eval_gpl = env_int("KGX_K5_EVAL_GPL", 8);            // genomes per lane: the widest load the group's alignment allows
@@ -105,7 +107,7 @@ int inbreed_shard(kgx_gt8_shard& sh, uint64_t g0, uint64_t g1, const uint32_t* l
   // three resident per CU (registers), about eight rounds of them and never a workgroup more than that (one more, nearly
   // empty round costs an eighth of the pass).
   uint64_t eval_n_seg = n_seg, eval_per_seg = per_seg;
-  if (eval_lut || ritland_lut) {
+  if (eval_lut || table_sweep) {
     const uint64_t eval_gx = ((n + eval_gpl - 1) / eval_gpl + kBlock - 1) / kBlock;
     const uint64_t resident = static_cast<uint64_t>(dev.compute_units) * static_cast<uint64_t>(env_int("KGX_K5_EVAL_RESIDENT", 2));
     uint64_t want = resident * static_cast<uint64_t>(env_int("KGX_K5_EVAL_ROUNDS", 8)) / eval_gx;
@@ -114,9 +116,11 @@ int inbreed_shard(kgx_gt8_shard& sh, uint64_t g0, uint64_t g1, const uint32_t* l
     eval_per_seg = n_sel ? (n_sel + want - 1) / want : kEvalBatch;
     eval_per_seg = (eval_per_seg + 7) / 8 * 8;
     if (eval_per_seg < 64) eval_per_seg = 64;
-    if (algorithm == KGX_ALGO_RITLAND_LOCUS && eval_per_seg > kRitlandSegment) eval_per_seg = kRitlandSegment;
     eval_n_seg = n_sel ? (n_sel + eval_per_seg - 1) / eval_per_seg : 1;
-    if (ritland_lut) { n_seg = eval_n_seg; per_seg = eval_per_seg; }          // its one pass fills the frequency sweep's partials
+    if (table_sweep) {                                       // the frequency sweep's own cut: 12-bit class counters per segment
+      per_seg = eval_per_seg > kRitlandSegment ? kRitlandSegment : eval_per_seg;
+      n_seg = n_sel ? (n_sel + per_seg - 1) / per_seg : 1;
+    }
   }
   const uint64_t max_seg = eval_n_seg > n_seg ? eval_n_seg : n_seg;
   const uint64_t pass_n_seg = eval_lut ? eval_n_seg : n_seg;                  // segments of an estimator pass (modes 1, 2)
@@ -150,14 +154,14 @@ int inbreed_shard(kgx_gt8_shard& sh, uint64_t g0, uint64_t g1, const uint32_t* l
   const size_t o_brent = plan.add(n * sizeof(BrentState)), o_running = plan.add(sizeof(unsigned int));
   // The class-frequency sums of the defaults in the reference's own (sequential) summation order (k_seq_* kernels): from
   // the size at which a tree reduction and a sequential sum part by more than a tenth of the tolerance.
-  const bool swar_family = ritland_lut || (!env_int("KGX_K5_GENERIC", 0) && amax <= 4 && algorithm != KGX_ALGO_RITLAND_LOCUS);
+  const bool swar_family = table_sweep || (!env_int("KGX_K5_GENERIC", 0) && amax <= 4 && !ritland);
   const bool sequential_defaults = swar_family && n_sel >= static_cast<uint64_t>(env_int("KGX_K5_SEQUENTIAL_MIN", 1 << 16));
   const uint64_t n_seq_blocks = (n_sel + kSeqBlock - 1) / kSeqBlock;
   const size_t o_seq_sum = plan.add(n_seq_blocks * 4 * sizeof(double)), o_seq_e = plan.add(n_seq_blocks * 4 * sizeof(int));
   const size_t o_seq_n = plan.add(n_seq_blocks * 4 * sizeof(long long)), o_seq_out = plan.add(kParts0 * sizeof(double));
   // The table passes' entries (k_eval_entries): 64 / 256 / 1024 bytes per selected locus, only where such a pass will run.
   const bool wave_sized = n_sel > 0 && n_sel <= 64ull * kWaveCells && !env_int("KGX_K7_NO_WAVE", 0);
-  const bool table_passes = n_sel > 0 && (ritland_lut || (eval_lut && (algorithm == 2 || algorithm == 3) && !wave_sized));
+  const bool table_passes = n_sel > 0 && (table_sweep || (eval_lut && (algorithm == 2 || algorithm == 3) && !wave_sized));
   const size_t o_entries = plan.add(table_passes ? (n_sel << (2u * eval_bits(amax))) * sizeof(EvalEntry) : 0);
   char* arena = nullptr;
   if (int arc = scratch_reserve(dev, plan.total, &arena)) return arc;
@@ -224,7 +228,8 @@ int inbreed_shard(kgx_gt8_shard& sh, uint64_t g0, uint64_t g1, const uint32_t* l
     const uint32_t tab_grid = stream_grid(dev, n_sel << (2u * eval_bits(amax)), kBlock);
     if (mode == 1) hipLaunchKernelGGL((k_eval_entries<1>), dim3(tab_grid), dim3(kBlock), 0, dev.stream, d_table, d_valid, n_sel, amax, phased, d_entries);
     else if (mode == 2) hipLaunchKernelGGL((k_eval_entries<2>), dim3(tab_grid), dim3(kBlock), 0, dev.stream, d_table, d_valid, n_sel, amax, phased, d_entries);
-    else hipLaunchKernelGGL((k_eval_entries<3>), dim3(tab_grid), dim3(kBlock), 0, dev.stream, d_table, d_valid, n_sel, amax, phased, d_entries);
+    else if (mode == 3) hipLaunchKernelGGL((k_eval_entries<3>), dim3(tab_grid), dim3(kBlock), 0, dev.stream, d_table, d_valid, n_sel, amax, phased, d_entries);
+    else hipLaunchKernelGGL((k_eval_entries<4>), dim3(tab_grid), dim3(kBlock), 0, dev.stream, d_table, d_valid, n_sel, amax, phased, d_entries);
   };
   auto sweep = [&](int mode) {
     if (n_sel == 0) return;
@@ -240,8 +245,8 @@ int inbreed_shard(kgx_gt8_shard& sh, uint64_t g0, uint64_t g1, const uint32_t* l
       hipLaunchKernelGGL(k_seq_chain, dim3(1), dim3(kBlock), 0, side, d_table, d_valid, n_sel, amax, d_seq_e, d_seq_n, n_seq_blocks, d_seq_out);
       try_hip(hipEventRecord(dev.side_end, side), KGX_EHIP, "hipEventRecord");
     }
-    if (mode == 0 && ritland_lut) {
-      // segment defaults into the partials, then the one table pass (below, as mode 3) corrects and counts
+    if (mode == 0 && table_sweep) {
+      // segment defaults into the partials, then the one table pass (below, as mode 3 or 4) corrects and counts
       hipLaunchKernelGGL(k_segment_defaults, dim3(static_cast<uint32_t>(n_seg)), dim3(kWave), 0, st, d_table, d_valid, n_sel, per_seg, amax, sequential_defaults ? 1 : 0, d_segdef);
       hipLaunchKernelGGL(k_fill_defaults, dim3(stream_grid(dev, n_seg * n, kBlock)), dim3(kBlock), 0, st, d_segdef, n_seg, n, d_part);
     } else if (mode == 0) {
@@ -270,12 +275,14 @@ int inbreed_shard(kgx_gt8_shard& sh, uint64_t g0, uint64_t g1, const uint32_t* l
         else { if (guard) KGX_SWAR(false, true); else KGX_SWAR(false, false); }
 #undef KGX_SWAR
       }
-    } else if (eval_lut || mode == 3) {
+    } else if (eval_lut || mode >= 3) {
+      // the frequency sweeps (modes 3, 4) over their own segments, the estimator passes over theirs
+      const uint64_t launch_n_seg = mode >= 3 ? n_seg : eval_n_seg, launch_per_seg = mode >= 3 ? per_seg : eval_per_seg;
 #define KGX_EVAL(M, W, FOLD)                                                                                                         \
   hipLaunchKernelGGL((k_inbreed_eval_lut<M, W, FOLD>),                                                                               \
-                     dim3(static_cast<uint32_t>(((n + W - 1) / W + kBlock - 1) / kBlock), static_cast<uint32_t>(eval_n_seg)),        \
+                     dim3(static_cast<uint32_t>(((n + W - 1) / W + kBlock - 1) / kBlock), static_cast<uint32_t>(launch_n_seg)),      \
                      dim3(kBlock), 0, st, gt32, dwords_per_row, g0, n, d_index, n_sel,                                               \
-                     eval_per_seg, d_entries, d_table, d_valid, amax, d_f, d_part, d_counts)
+                     launch_per_seg, d_entries, d_table, d_valid, amax, d_f, d_part, d_counts)
 #define KGX_EVAL_FOLD(M, W)                                                \
   do {                                                                     \
     if (eval_fold) KGX_EVAL(M, W, true); else KGX_EVAL(M, W, false);       \
@@ -284,8 +291,10 @@ int inbreed_shard(kgx_gt8_shard& sh, uint64_t g0, uint64_t g1, const uint32_t* l
         if (eval_gpl == 8) KGX_EVAL_FOLD(1, 8); else KGX_EVAL_FOLD(1, 4);
       } else if (mode == 2) {
         if (eval_gpl == 8) KGX_EVAL_FOLD(2, 8); else KGX_EVAL_FOLD(2, 4);
-      } else {
+      } else if (mode == 3) {
         if (eval_gpl == 8) KGX_EVAL_FOLD(3, 8); else KGX_EVAL_FOLD(3, 4);
+      } else {
+        if (eval_gpl == 8) KGX_EVAL_FOLD(4, 8); else KGX_EVAL_FOLD(4, 4);
       }
 #undef KGX_EVAL_FOLD
 #undef KGX_EVAL
@@ -301,7 +310,7 @@ int inbreed_shard(kgx_gt8_shard& sh, uint64_t g0, uint64_t g1, const uint32_t* l
     if (n_sel) hipLaunchKernelGGL((k_locus_tables<true>), dim3(stream_grid(dev, n_sel, kBlock)), dim3(kBlock), 0, st, d_af, n_sel, amax, 0.0, d_table, d_valid);
     if (rc == KGX_OK) try_hip(hipEventRecord(dev.sweep_begin, st), KGX_EHIP, "hipEventRecord");
     sweep(0);
-    if (ritland_lut) { tabulate(3); sweep(3); }
+    if (table_sweep) { tabulate(ritland ? 3 : 4); sweep(ritland ? 3 : 4); }
     if (rc == KGX_OK) try_hip(hipEventRecord(dev.sweep_end, st), KGX_EHIP, "hipEventRecord");
     if (sequential_defaults && n_sel) try_hip(hipStreamWaitEvent(st, dev.side_end, 0), KGX_EHIP, "hipStreamWaitEvent");
     hipLaunchKernelGGL(k_reduce_parts, dim3(stream_grid(dev, n * kParts0, kBlock)), dim3(kBlock), 0, st, d_part, n_seg, n * kParts0,

@@ -293,7 +293,7 @@ __host__ __device__ constexpr uint32_t eval_bits(uint32_t amax) { return amax <=
 template <int MODE>
 __global__ void __launch_bounds__(kBlock)
 k_eval_entries(const double* __restrict__ table, const uint8_t* __restrict__ valid, uint64_t n_sel, uint32_t amax, int phased,
-               EvalEntry* __restrict__ entries) {
+               void* __restrict__ entries_out) {
   const uint32_t stride = sweep_stride(amax);
   const uint32_t bits = eval_bits(amax), mask = (1u << bits) - 1u;
   const uint64_t total = n_sel << (2u * bits);
@@ -301,15 +301,15 @@ k_eval_entries(const double* __restrict__ table, const uint8_t* __restrict__ val
        idx += static_cast<uint64_t>(gridDim.x) * blockDim.x) {
     const uint64_t s = idx >> (2u * bits);
     const uint32_t a1 = static_cast<uint32_t>(idx) & mask, a2 = (static_cast<uint32_t>(idx) >> bits) & mask;
-    double y = MODE == 3 ? 0.0 : 1.0, d = 0.0;
+    double y = (MODE == 3 || MODE == 4) ? 0.0 : 1.0, d = 0.0;
     const uint8_t flag = valid[s];
     if (a1 > amax || a2 > amax) {
-      // MODE 3: a byte past the table is counted as nothing but is odd wherever the locus has defaults
-      if constexpr (MODE == 3) d = __builtin_bit_cast(double, (static_cast<uint64_t>(kOddCell) << 32) | kOddOutside);
+      // MODE 3, 4: a byte past the table is counted as nothing but is odd wherever the locus has defaults
+      if constexpr (MODE == 3 || MODE == 4) d = __builtin_bit_cast(double, (static_cast<uint64_t>(kOddCell) << 32) | kOddOutside);
     } else if (flag & kLocusValid) {
       double f1 = 0.0, f2 = 0.0;
       const int cls = classify_cell(a1 | (a2 << 4), table + s * stride, amax, phased != 0, f1, f2);
-      if constexpr (MODE == 3) {
+      if constexpr (MODE == 3 || MODE == 4) {
         uint32_t lo = 0, hi = 0;
         if (cls == kMajorHom) lo = 1u; else if (cls == kMajorHet) lo = 1u << 12;
         else if (cls == kMinorHom) hi = 1u; else if (cls == kMinorHet) hi = 1u << 12;
@@ -331,14 +331,20 @@ k_eval_entries(const double* __restrict__ table, const uint8_t* __restrict__ val
         if constexpr (MODE == 2) { y = 2.0 * f1 * f2; d = -y; }
       }
     }
-    entries[idx].y = y;
-    entries[idx].d = d;
+    if constexpr (MODE == 4) {
+      static_cast<uint64_t*>(entries_out)[idx] = __builtin_bit_cast(uint64_t, d);      // the packed words alone
+    } else {
+      EvalEntry* entries = static_cast<EvalEntry*>(entries_out);
+      entries[idx].y = y;
+      entries[idx].d = d;
+    }
   }
 }
 
-// 16 * (byte B of w): the LDS byte offset of a cell's entry within its locus's table, one SDWA shift.
+// (byte B of w) << shift, shift = log2 of the entry size: the LDS byte offset of a cell's entry within its locus's
+// table, one SDWA shift (which takes its count from a register).
 template <int B>
-__device__ __forceinline__ uint32_t byte_times_16(uint32_t w, uint32_t four) {
+__device__ __forceinline__ uint32_t byte_shifted(uint32_t w, uint32_t four) {
   uint32_t r;
   if constexpr (B == 0) asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0" : "=v"(r) : "v"(four), "v"(w));
   else if constexpr (B == 1) asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1" : "=v"(r) : "v"(four), "v"(w));
@@ -355,11 +361,24 @@ template <int MODE, int GPL, bool FOLD>
 __global__ void __launch_bounds__(kBlock)
 k_inbreed_eval_lut(const uint32_t* __restrict__ gt, uint64_t dwords_per_row, uint64_t g0, uint64_t n_genomes,
                    const uint32_t* __restrict__ locus_index, uint64_t n_sel, uint64_t loci_per_seg,
-                   const EvalEntry* __restrict__ entries, const double* __restrict__ table, const uint8_t* __restrict__ valid,
+                   const void* __restrict__ entries_in, const double* __restrict__ table, const uint8_t* __restrict__ valid,
                    uint32_t amax, const double* __restrict__ f_in, double* __restrict__ part,
                    unsigned long long* __restrict__ counts) {
   constexpr int DW = GPL / 4;
-  __shared__ EvalEntry lut[2][kEvalBatch * kEvalSlots];
+  constexpr bool kCounts = MODE == 3 || MODE == 4;           // the one-pass frequency sweeps: packed class counters, odd cells
+  // MODE 4 is MODE 3 without the Ritland term: 8-byte entries (the packed words), half the LDS traffic.
+  using Entry = std::conditional_t<MODE == 4, uint64_t, EvalEntry>;
+  const Entry* __restrict__ entries = static_cast<const Entry*>(entries_in);
+  __shared__ Entry lut[2][kEvalBatch * kEvalSlots];
+  constexpr uint64_t kOutside = (static_cast<uint64_t>(kOddCell) << 32) | kOddOutside;
+  auto nothing = []() {                                      // the entry of a locus past the segment, whatever the byte
+    if constexpr (MODE == 4) return static_cast<uint64_t>(0);
+    else return EvalEntry{MODE == 3 ? 0.0 : 1.0, 0.0};
+  };
+  auto packed_of = [](const Entry& e) {
+    if constexpr (MODE == 4) return e;
+    else return __builtin_bit_cast(uint64_t, e.d);
+  };
   const uint64_t lane = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x;   // genomes g0 + GPL*lane ..
   const bool active = lane * GPL < n_genomes;
   const uint64_t seg = blockIdx.y;
@@ -370,14 +389,14 @@ k_inbreed_eval_lut(const uint32_t* __restrict__ gt, uint64_t dwords_per_row, uin
   const uint32_t bits = eval_bits(amax), mask = (1u << bits) - 1u;
   const uint32_t in_batch = static_cast<uint32_t>(kEvalBatch) << (2u * bits);              // 32, 128 or 512 entries
 
-  double F[MODE == 3 ? 1 : GPL], run_a[GPL], run_b[MODE == 1 ? GPL : 1];
+  double F[kCounts ? 1 : GPL], run_a[MODE == 4 ? 1 : GPL], run_b[MODE == 1 ? GPL : 1];
   int expo[MODE == 2 ? GPL : 1];   // MODE 2: run_a = product;  MODE 1: run_a / run_b = N / D;  MODE 3: run_a = Ritland sum
-  uint32_t cnt_lo[MODE == 3 ? GPL : 1], cnt_hi[MODE == 3 ? GPL : 1];   // MODE 3: packed class counters (see above)
+  uint32_t cnt_lo[kCounts ? GPL : 1], cnt_hi[kCounts ? GPL : 1];   // MODE 3, 4: packed class counters (see above)
 #pragma unroll
   for (int j = 0; j < GPL; ++j) {
     const uint64_t g = lane * GPL + j;
-    if constexpr (MODE != 3) F[j] = g < n_genomes ? f_in[g] : 0.0;
-    run_a[j] = MODE == 2 ? 1.0 : 0.0;
+    if constexpr (!kCounts) F[j] = g < n_genomes ? f_in[g] : 0.0;
+    if constexpr (MODE != 4) run_a[j] = MODE == 2 ? 1.0 : 0.0;
     if constexpr (MODE == 1) {
       run_b[j] = 1.0;
       if (!(F[j] > 0.0)) F[j] = 1.0;                        // see above: v = 1 everywhere, k_hall_update multiplies by the real F
@@ -390,22 +409,21 @@ k_inbreed_eval_lut(const uint32_t* __restrict__ gt, uint64_t dwords_per_row, uin
 
   // Every slot starts "unclassified"; the batches refill the (1 << bits)^2 slots their entries have.
   for (uint32_t e = threadIdx.x; e < 2u * kEvalBatch * kEvalSlots; e += kBlock) {
-    (&lut[0][0] + e)->y = MODE == 3 ? 0.0 : 1.0;
-    (&lut[0][0] + e)->d = MODE == 3 ? __builtin_bit_cast(double, (static_cast<uint64_t>(kOddCell) << 32) | kOddOutside) : 0.0;
+    if constexpr (MODE == 4) lut[0][e] = kOutside;
+    else lut[0][e] = EvalEntry{MODE == 3 ? 0.0 : 1.0, MODE == 3 ? __builtin_bit_cast(double, kOutside) : 0.0};
   }
-  typedef double v2d __attribute__((ext_vector_type(2)));
   // Positions within the segment are 32-bit (the scalar unit compares those; 64-bit ones go through the vector unit).
   const uint32_t seg_len = static_cast<uint32_t>(s_end - s_begin);
-  const EvalEntry* __restrict__ seg_entries = entries + (s_begin << (2u * bits));
+  const Entry* __restrict__ seg_entries = entries + (s_begin << (2u * bits));
   const uint32_t* __restrict__ seg_index = locus_index ? locus_index + s_begin : nullptr;
   // Entry threadIdx.x of a batch travels through a register pair, fetched two batches ahead; at bits == 3 a batch has
   // 512 entries and the second of the thread goes straight from memory to the table (four-to-seven-allele loci only).
   // With a locus index, the batch's eight row numbers travel the same way (every lane holds all eight).
-  v2d staged;
+  Entry staged;
   kgx_v4u staged_rows[2];
   auto entry_of = [&](uint32_t r0, uint32_t idx) {
-    v2d e{MODE == 3 ? 0.0 : 1.0, 0.0};                       // a locus past the segment: nothing, whatever the byte
-    if (idx < in_batch && r0 + (idx >> (2u * bits)) < seg_len) e = *reinterpret_cast<const v2d*>(seg_entries + ((r0 << (2u * bits)) + idx));
+    Entry e = nothing();
+    if (idx < in_batch && r0 + (idx >> (2u * bits)) < seg_len) e = seg_entries[(r0 << (2u * bits)) + idx];
     return e;
   };
   auto fetch = [&](uint32_t r0) {
@@ -415,10 +433,10 @@ k_inbreed_eval_lut(const uint32_t* __restrict__ gt, uint64_t dwords_per_row, uin
       staged_rows[1] = *reinterpret_cast<const kgx_v4u*>(seg_index + r0 + 4);
     }
   };
-  auto put = [&](int rb, uint32_t idx, v2d e) {
+  auto put = [&](int rb, uint32_t idx, Entry e) {
     if (idx < in_batch) {
       const uint32_t a1 = idx & mask, a2 = (idx >> bits) & mask, i = idx >> (2u * bits);
-      *reinterpret_cast<v2d*>(&lut[rb][i * kEvalSlots + a1 + 20u * a2]) = e;
+      lut[rb][i * kEvalSlots + a1 + 20u * a2] = e;
     }
   };
   auto stash = [&](int rb, uint32_t r0) {                     // r0: the batch the registers hold
@@ -455,7 +473,7 @@ k_inbreed_eval_lut(const uint32_t* __restrict__ gt, uint64_t dwords_per_row, uin
     const uint32_t xf = FOLD ? ((x & 0x7F7F7F7Fu) | ((x >> 4) & 0x08080808u)) : (x & 0x7F7F7F7Fu);
     return xf + ((FOLD ? xf >> 2 : x >> 2) & 0x1C1C1C1Cu);               // a1 + 16*a2 + 4*a2 per byte, < 156: no carry
   };
-  uint32_t four = 4u;
+  uint32_t four = MODE == 4 ? 3u : 4u;                        // log2 of the entry size
   asm volatile("" : "+v"(four));                              // the SDWA shift takes its count from a register
 
   // One batch: the table lut[BUF] holds its entries, w its cells.  Meanwhile the next batch's entries go from the
@@ -470,22 +488,22 @@ k_inbreed_eval_lut(const uint32_t* __restrict__ gt, uint64_t dwords_per_row, uin
     if (active) {
       const char* cur = reinterpret_cast<const char*>(&lut[BUF][0]);
       auto entry_at = [&](int i, uint32_t offset16) {
-        return *reinterpret_cast<const EvalEntry*>(cur + i * static_cast<int>(kEvalSlots * sizeof(EvalEntry)) + offset16);
+        return *reinterpret_cast<const Entry*>(cur + i * static_cast<int>(kEvalSlots * sizeof(Entry)) + offset16);
       };
       // The batch's cells in groups of four (one dword), a group's four table reads issued kEvalDepth groups before its
       // arithmetic: the reads' latency passes under that of the groups before it, and the registers stay those of
       // kEvalDepth + 1 groups -- left alone the compiler either waits for every read where it issues it or (machine
       // sinking: nothing in this block reads the sums) carries all 64 reads of the batch past the batch.
-      constexpr int kGroups = kEvalBatch * DW, kDepth = MODE == 3 ? KGX_EVAL_DEPTH3 : KGX_EVAL_DEPTH;
-      auto read_group = [&](int q, EvalEntry (&e)[4]) {
+      constexpr int kGroups = kEvalBatch * DW, kDepth = kCounts ? KGX_EVAL_DEPTH3 : KGX_EVAL_DEPTH;
+      auto read_group = [&](int q, Entry (&e)[4]) {
         const uint32_t slots = slots_of(w[q / DW][q % DW]);
-        e[0] = entry_at(q / DW, byte_times_16<0>(slots, four));
-        e[1] = entry_at(q / DW, byte_times_16<1>(slots, four));
-        e[2] = entry_at(q / DW, byte_times_16<2>(slots, four));
-        e[3] = entry_at(q / DW, byte_times_16<3>(slots, four));
+        e[0] = entry_at(q / DW, byte_shifted<0>(slots, four));
+        e[1] = entry_at(q / DW, byte_shifted<1>(slots, four));
+        e[2] = entry_at(q / DW, byte_shifted<2>(slots, four));
+        e[3] = entry_at(q / DW, byte_shifted<3>(slots, four));
       };
       auto walk = [&](auto&& cell) {
-        EvalEntry e[kDepth + 1][4];
+        Entry e[kDepth + 1][4];
 #pragma unroll
         for (int q = 0; q < kDepth; ++q) read_group(q, e[q]);
 #pragma unroll
@@ -497,7 +515,8 @@ k_inbreed_eval_lut(const uint32_t* __restrict__ gt, uint64_t dwords_per_row, uin
             const int j = 4 * (q % DW) + b;
             cell(j, e[q % (kDepth + 1)][b]);
             // the empty asm reads the sums here, so the group's arithmetic stays here
-            if constexpr (MODE == 3) asm volatile("" : "+v"(run_a[j]), "+v"(cnt_lo[j]), "+v"(cnt_hi[j]));
+            if constexpr (MODE == 4) asm volatile("" : "+v"(cnt_lo[j]), "+v"(cnt_hi[j]));
+            else if constexpr (MODE == 3) asm volatile("" : "+v"(run_a[j]), "+v"(cnt_lo[j]), "+v"(cnt_hi[j]));
             else if constexpr (MODE == 1) asm volatile("" : "+v"(run_a[j]), "+v"(run_b[j]));
             else asm volatile("" : "+v"(run_a[j]));
           }
@@ -508,24 +527,24 @@ k_inbreed_eval_lut(const uint32_t* __restrict__ gt, uint64_t dwords_per_row, uin
         // The clamp of logLikelihood (:117-121) to [1e-10, 1]: the fma's clamp bit takes the value into [0, 1] for
         // nothing (min(max(x, 0), 1) is folded into it), the fp64 max lifts it to 1e-10.
         walk([&](int j, const EvalEntry& e) {
-          const double p = __builtin_fmin(__builtin_fmax(__builtin_fma(F[MODE == 3 ? 0 : j], e.d, e.y), 0.0), 1.0);
+          const double p = __builtin_fmin(__builtin_fmax(__builtin_fma(F[kCounts ? 0 : j], e.d, e.y), 0.0), 1.0);
           run_a[j] *= __builtin_fmax(p, 1e-10);
         });
-      } else if constexpr (MODE == 3) {
-        walk([&](int j, const EvalEntry& e) {
-          run_a[j] += e.y;
-          const uint64_t packed = __builtin_bit_cast(uint64_t, e.d);
+      } else if constexpr (kCounts) {
+        walk([&](int j, const Entry& e) {
+          if constexpr (MODE == 3) run_a[j] += e.y;
+          const uint64_t packed = packed_of(e);
           cnt_lo[j] += static_cast<uint32_t>(packed);
           cnt_hi[j] += static_cast<uint32_t>(packed >> 32);
         });
       } else {
         walk([&](int j, const EvalEntry& e) {
-          const double v = __builtin_fma(F[MODE == 3 ? 0 : j], e.d, e.y);
+          const double v = __builtin_fma(F[kCounts ? 0 : j], e.d, e.y);
           run_a[j] = __builtin_fma(run_a[j], v, run_b[j]);
           run_b[j] *= v;
         });
       }
-      if constexpr (MODE == 3) {
+      if constexpr (kCounts) {
         uint32_t seen = 0;
 #pragma unroll
         for (int j = 0; j < GPL; ++j) seen |= cnt_hi[j];
@@ -537,7 +556,7 @@ k_inbreed_eval_lut(const uint32_t* __restrict__ gt, uint64_t dwords_per_row, uin
           // the program's) or the genome's Ritland count.  Rolled loops, bytes re-read from the matrix (L2 hits), the
           // locus's class frequencies from the per-locus table in memory.
           if ((seen >> 28) != 0u) {
-            const EvalEntry* cur_entries = &lut[BUF][0];
+            const Entry* cur_entries = &lut[BUF][0];
 #pragma nounroll
             for (int i = 0; i < kEvalBatch; ++i) {
               if (r0 + i >= seg_len) break;
@@ -550,7 +569,7 @@ k_inbreed_eval_lut(const uint32_t* __restrict__ gt, uint64_t dwords_per_row, uin
               for (int j = 0; j < GPL; ++j) {
                 const uint64_t g = lane * GPL + j;
                 if (g >= n_genomes) break;
-                const uint32_t odd = static_cast<uint32_t>(__builtin_bit_cast(uint64_t, cur_entries[i * kEvalSlots + eval_slot<FOLD>(bytes[j])].d)) >> 24;
+                const uint32_t odd = static_cast<uint32_t>(packed_of(cur_entries[i * kEvalSlots + eval_slot<FOLD>(bytes[j])])) >> 24;
                 if (odd == 0u) continue;
                 const double sign = (odd & (kOddMinus >> 24)) ? -1.0 : (odd & (kOddPlus >> 24)) ? 1.0
                                     : ((odd & (kOddOutside >> 24)) && (flag & kLocusDefault)) ? -1.0 : 0.0;
@@ -610,7 +629,8 @@ k_inbreed_eval_lut(const uint32_t* __restrict__ gt, uint64_t dwords_per_row, uin
     } else if constexpr (MODE == 1) {
       part[seg * n_genomes + g] = run_a[j] / run_b[j];
     } else {
-      part[(seg * n_genomes + g) * kParts0 + 4] = run_a[j];
+      // slot 4: the Ritland sum (MODE 4: none -- the slot held the segment's default, which is RitlandLocus' alone)
+      part[(seg * n_genomes + g) * kParts0 + 4] = MODE == 3 ? run_a[MODE == 4 ? 0 : j] : 0.0;
       const unsigned long long major_hom = cnt_lo[j] & 0xFFFu, major_het = (cnt_lo[j] >> 12) & 0xFFFu;
       const unsigned long long minor_hom = cnt_hi[j] & 0xFFFu, minor_het = (cnt_hi[j] >> 12) & 0xFFFu;
       const unsigned long long total = major_hom + major_het + minor_hom + minor_het;
