@@ -317,15 +317,18 @@ int inbreed_shard(kgx_gt8_shard& sh, uint64_t g0, uint64_t g1, const uint32_t* l
                        (sequential_defaults && n_sel) ? d_seq_out : nullptr, d_sums);
     // Window-sized calls: the whole iteration in one launch, a wave per genome (k_inbreed_iterate_wave).
     const bool wave_path = (algorithm == 2 || algorithm == 3) && wave_sized;
+    // Loglikelihood's search: the reference optimiser's own path (Nelder-Mead, see nm_advance) unless KGX_K7_SEARCH=brent
+    const char* search_name = std::getenv("KGX_K7_SEARCH");
+    const int search = search_name && std::strcmp(search_name, "brent") == 0 ? kSearchBrent : kSearchNelderMead;
     if (wave_path) {
       const uint32_t wave_grid = static_cast<uint32_t>((n * kWave + kBlock - 1) / kBlock);
       try_hip(hipMemsetAsync(d_running, 0, sizeof(unsigned int), st), KGX_EHIP, "memset(evaluations)");
       if (algorithm == 2)
         hipLaunchKernelGGL((k_inbreed_iterate_wave<1>), dim3(wave_grid), dim3(kBlock), 0, st, sh.d_gt, sh.pitch, g0, n, d_index, n_sel, d_table, d_valid,
-                           amax, phased, d_counts, d_sums, d_f, d_running);
+                           amax, phased, d_counts, d_sums, search, d_f, d_running);
       else
         hipLaunchKernelGGL((k_inbreed_iterate_wave<2>), dim3(wave_grid), dim3(kBlock), 0, st, sh.d_gt, sh.pitch, g0, n, d_index, n_sel, d_table, d_valid,
-                           amax, phased, d_counts, env_int("KGX_K7_ESTIMATE_START", 0) ? d_sums : nullptr, d_f, d_running);
+                           amax, phased, d_counts, env_int("KGX_K7_ESTIMATE_START", 0) ? d_sums : nullptr, search, d_f, d_running);
       if (algorithm == 3) {
         unsigned int evaluations = 0;
         try_hip(hipMemcpyAsync(&evaluations, d_running, sizeof(unsigned int), hipMemcpyDeviceToHost, st), KGX_EHIP, "D2H(evaluations)");
@@ -358,8 +361,9 @@ int inbreed_shard(kgx_gt8_shard& sh, uint64_t g0, uint64_t g1, const uint32_t* l
         // instead (brent_start): 11 instead of 15 evaluations on a population with F in [0, 0.1], but where the clamped
         // objective has several local maxima (F < 0) it may settle on another one than a search from the middle does --
         // the reference itself lands on one or another from its random starts -- so it is not the default.
-        hipLaunchKernelGGL(k_brent_init, dim3(lin_grid), dim3(kBlock), 0, st, d_counts, d_sums, n, env_int("KGX_K7_ESTIMATE_START", 0), d_brent, d_f);
-        constexpr int kMaxEvaluations = 60;        // golden section alone would need 38; Brent's safeguard keeps that bound
+        hipLaunchKernelGGL(k_brent_init, dim3(lin_grid), dim3(kBlock), 0, st, d_counts, d_sums, n, env_int("KGX_K7_ESTIMATE_START", 0), search, d_brent, d_f);
+        // Brent: golden section alone would need 38, and its safeguard keeps that bound; Nelder-Mead: the reference's own cap
+        const int kMaxEvaluations = search == kSearchNelderMead ? 500 : 60;
         // The genomes still searching.  When at most half of them are left -- and the call is big enough for it to pay --
         // their genotype columns and states are compacted (dense in the selected loci) and the remaining passes sweep
         // only those: on populations with F of both signs the last genomes need twice the evaluations of the first.
@@ -392,7 +396,7 @@ int inbreed_shard(kgx_gt8_shard& sh, uint64_t g0, uint64_t g1, const uint32_t* l
           const uint32_t act_grid = stream_grid(dev, n_act, kBlock);
           hipLaunchKernelGGL(k_reduce_parts, dim3(act_grid), dim3(kBlock), 0, st, d_part, pass_n_seg, n_act, nullptr, d_eval);
           try_hip(hipMemsetAsync(d_running, 0, sizeof(unsigned int), st), KGX_EHIP, "memset(running)");
-          hipLaunchKernelGGL(k_brent_step, dim3(act_grid), dim3(kBlock), 0, st, act_brent, d_eval, n_act, it == 0 ? 0 : 1, act_f, d_running,
+          hipLaunchKernelGGL(k_brent_step, dim3(act_grid), dim3(kBlock), 0, st, act_brent, d_eval, n_act, it == 0 ? 0 : 1, search, act_f, d_running,
                              act_global, d_f);
           unsigned int running = 0;
           try_hip(hipMemcpyAsync(&running, d_running, sizeof(unsigned int), hipMemcpyDeviceToHost, st), KGX_EHIP, "D2H(running)");
@@ -458,7 +462,7 @@ int inbreed_shard(kgx_gt8_shard& sh, uint64_t g0, uint64_t g1, const uint32_t* l
           n_act = n_new;
           global_of.swap(new_global);
         }
-        hipLaunchKernelGGL(k_brent_step, dim3(stream_grid(dev, n_act, kBlock)), dim3(kBlock), 0, st, act_brent, d_eval, n_act, 2, act_f, d_running, act_global, d_f);
+        hipLaunchKernelGGL(k_brent_step, dim3(stream_grid(dev, n_act, kBlock)), dim3(kBlock), 0, st, act_brent, d_eval, n_act, 2, search, act_f, d_running, act_global, d_f);
         try_hip(hipStreamSynchronize(st), KGX_EHIP, "sync");
       } else {
       const double inv_phi = 0.6180339887498949;

@@ -1381,12 +1381,75 @@ __device__ __forceinline__ BrentState brent_start(const unsigned long long* __re
   return s;
 }
 
+// The reference's own optimiser for this objective, step for step: nlopt's LN_NELDERMEAD in one dimension (the simplex
+// method after Nelder & Mead / Box: reflection 1, expansion 2, contraction 1/2) on [-1, 1], stopped at an absolute
+// simplex width of 1e-6 or 500 evaluations (createLogLikelihoodOptimizer, _calc.cpp:131-144), from the midpoint 0 of the
+// reference's random start interval (-0.5, 0.5] with nlopt's default first step, a quarter of the box.  The clamped
+// objective has several local maxima where F < 0 (every homozygous cell whose probability falls under the 1e-10 floor
+// stops pulling); which one a search ends on depends on its path, so the path is the reference optimiser's (as
+// restated in oracle/kgo_inbreed.cpp:neldermead1D, which this follows expression for expression): the same maximum,
+// to the rounding of the objective.  One evaluation per call; the state lives in a BrentState:
+//   a = best point, fx = its value;  b = worst point, fw = its value;  v = reflected point, fv = its value;
+//   u = the point to evaluate next;  widened = phase;  e = evaluations so far;  x = the result once done.
+enum : int { kNmFirst = 0, kNmSecond, kNmReflect, kNmExpand, kNmOutside, kNmInside };
+constexpr int kSearchBrent = 0, kSearchNelderMead = 1;
+__device__ __forceinline__ BrentState nm_start() {
+  BrentState s{};
+  s.a = 0.0;                                                  // x0
+  s.b = 0.5;                                                  // x0 + (ub - lb) / 4
+  s.x = s.u = s.a;
+  s.widened = kNmFirst;
+  return s;
+}
+__device__ __forceinline__ void nm_advance(BrentState& s, double f) {      // f: the objective (maximised) at s.u
+  auto clampx = [](double x) { return x > 1.0 ? 1.0 : (x < -1.0 ? -1.0 : x); };
+  s.e += 1.0;
+  switch (s.widened) {
+    case kNmFirst:
+      s.fx = f;
+      s.u = s.b;
+      s.widened = kNmSecond;
+      return;
+    case kNmSecond:
+      s.fw = f;
+      break;
+    case kNmReflect:
+      s.v = s.u; s.fv = f;
+      if (f > s.fx) { s.u = clampx(s.a + 2.0 * (s.a - s.b)); s.widened = kNmExpand; }
+      else if (f > s.fw) { s.u = clampx(s.a + 0.5 * (s.v - s.a)); s.widened = kNmOutside; }
+      else { s.u = s.a + 0.5 * (s.b - s.a); s.widened = kNmInside; }
+      return;
+    case kNmExpand:
+      if (f > s.fv) { s.b = s.u; s.fw = f; } else { s.b = s.v; s.fw = s.fv; }
+      break;
+    case kNmOutside:
+      if (f >= s.fv) { s.b = s.u; s.fw = f; } else { s.b = s.v; s.fw = s.fv; }
+      break;
+    default:                                                   // inside contraction == shrink in one dimension
+      s.b = s.u; s.fw = f;
+      break;
+  }
+  if (s.fw > s.fx) {                                           // a best, b worst
+    const double x = s.a, fx = s.fx;
+    s.a = s.b; s.fx = s.fw;
+    s.b = x; s.fw = fx;
+  }
+  if (fabs(s.a - s.b) < 1e-6 || s.e >= 500.0) {
+    s.x = s.a;
+    s.done = 1;
+    return;
+  }
+  s.u = clampx(s.a + (s.a - s.b));
+  s.widened = kNmReflect;
+}
+
 __global__ void __launch_bounds__(kBlock)
-k_brent_init(const unsigned long long* __restrict__ counts, const double* __restrict__ sums, uint64_t n, int use_estimate,
+k_brent_init(const unsigned long long* __restrict__ counts, const double* __restrict__ sums, uint64_t n, int use_estimate, int search,
              BrentState* __restrict__ st, double* __restrict__ f_next) {
   for (uint64_t g = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x; g < n;
        g += static_cast<uint64_t>(gridDim.x) * blockDim.x) {
-    const BrentState s = use_estimate ? brent_start(counts + g * 6, sums + g * kParts0) : brent_start(nullptr, nullptr);
+    const BrentState s = search == kSearchNelderMead ? nm_start()
+                         : use_estimate ? brent_start(counts + g * 6, sums + g * kParts0) : brent_start(nullptr, nullptr);
     st[g] = s;
     f_next[g] = s.x;
   }
@@ -1395,7 +1458,7 @@ k_brent_init(const unsigned long long* __restrict__ counts, const double* __rest
 // global_of / result (both or neither): the states are a compacted subset of the call's genomes (see kgx_inbreed);
 // a genome's coefficient goes to result[global_of[g]] when its search ends.
 __global__ void __launch_bounds__(kBlock)
-k_brent_step(BrentState* __restrict__ st, const double* __restrict__ f_eval, uint64_t n, int mode, double* __restrict__ f_next,
+k_brent_step(BrentState* __restrict__ st, const double* __restrict__ f_eval, uint64_t n, int mode, int search, double* __restrict__ f_next,
              unsigned int* __restrict__ still_running, const uint32_t* __restrict__ global_of, double* __restrict__ result) {
   for (uint64_t g = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x; g < n;
        g += static_cast<uint64_t>(gridDim.x) * blockDim.x) {
@@ -1406,7 +1469,8 @@ k_brent_step(BrentState* __restrict__ st, const double* __restrict__ f_eval, uin
       continue;
     }
     if (!s.done) {
-      brent_advance(s, -f_eval[g], mode == 0);
+      if (search == kSearchNelderMead) nm_advance(s, f_eval[g]);
+      else brent_advance(s, -f_eval[g], mode == 0);
       if (!s.done) atomicAdd(still_running, 1u);
       else if (global_of) result[global_of[g]] = s.x;
       st[g] = s;
@@ -1466,7 +1530,7 @@ __global__ void __launch_bounds__(kBlock)
 k_inbreed_iterate_wave(const uint8_t* __restrict__ gt, uint64_t pitch, uint64_t g0, uint64_t n_genomes,
                        const uint32_t* __restrict__ locus_index, uint64_t n_sel, const double* __restrict__ table,
                        const uint8_t* __restrict__ valid, uint32_t amax, int phased, const unsigned long long* __restrict__ counts,
-                       const double* __restrict__ sums, double* __restrict__ f_out, unsigned int* __restrict__ max_evaluations) {
+                       const double* __restrict__ sums, int search, double* __restrict__ f_out, unsigned int* __restrict__ max_evaluations) {
   const uint64_t g = (static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x) / kWave;
   const uint32_t lane = threadIdx.x & (kWave - 1);
   if (g >= n_genomes) return;                                 // whole waves only
@@ -1504,9 +1568,10 @@ k_inbreed_iterate_wave(const uint8_t* __restrict__ gt, uint64_t pitch, uint64_t 
     }
     if (lane == 0) f_out[g] = F;
   } else {
-    BrentState s = sums ? brent_start(counts + g * 6, sums + g * kParts0) : brent_start(nullptr, nullptr);
+    BrentState s = search == kSearchNelderMead ? nm_start()
+                   : sums ? brent_start(counts + g * 6, sums + g * kParts0) : brent_start(nullptr, nullptr);
     unsigned int evaluations = 0;
-    for (int it = 0; it < 60; ++it) {
+    for (int it = 0; it < (search == kSearchNelderMead ? 500 : 60); ++it) {
       const double F = it == 0 ? s.x : s.u;
       double log_sum = 0.0, prod = 1.0;
 #pragma unroll
@@ -1518,7 +1583,8 @@ k_inbreed_iterate_wave(const uint8_t* __restrict__ gt, uint64_t pitch, uint64_t 
         }
       }
       ++evaluations;
-      brent_advance(s, -wave_sum(log_sum), it == 0);
+      if (search == kSearchNelderMead) nm_advance(s, wave_sum(log_sum));
+      else brent_advance(s, -wave_sum(log_sum), it == 0);
       if (s.done) break;
     }
     if (lane == 0) {

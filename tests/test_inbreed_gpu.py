@@ -508,7 +508,7 @@ def test_c5_full_size_fp64_sums_vs_oracle(kgx):
 def test_iterative_estimators_at_scale_vs_oracle(kgx):
     """HallME and Loglikelihood through the multi-kernel table passes (the path C5 takes) at 1,000 genomes x 100,000 loci
     of the C5 population against the oracle run from the same fixed starts: class counts bit-exact, HallME within 1e-9,
-    Loglikelihood within 1e-5 (two maximisers of one objective, each converged to <= 1e-6)."""
+    Loglikelihood within 2e-6 (one optimiser, one start, each side converged to a simplex of 1e-6)."""
     G, L = 1000, 100_000
     m = kgx.GenotypeMatrix(G, L)
     table = m.synth_multiallelic(1111, 0, 0)
@@ -533,20 +533,21 @@ def test_iterative_estimators_at_scale_vs_oracle(kgx):
             assert err.max() <= 1e-9, (algorithm, float(err.max()), int(err.argmax()))
             continue
         # Loglikelihood.  For a genome with F < 0 the maximum of the CLAMPED objective sits on the kinks the 1e-10 floor puts
-        # into it: a homozygous cell of allele frequency f is floored for F < -f / (1 - f), flat on one side of that point
-        # and rising steeply on the other, so next to the smooth optimum lie several local maxima ~0.01 apart, one per
-        # rare-allele homozygote the genome happens to carry.  The reference's Nelder-Mead lands on one or another from its
-        # random starts (and returns 0.0 when five restarts in a row disagree); the oracle's fixed start picks one; Brent's
-        # search picks one.  So: where the objective is smooth around its maximum (F >= 0: every kink lies left of it) the
-        # two maximisers agree to 1e-5; elsewhere they agree to the spacing of those maxima, and the device's point is,
-        # under the ORACLE's objective, within a few log-units of the oracle's own (a likelihood ratio no test would call).
-        smooth = f_true[order] >= 0.0
-        assert err[smooth].max() <= 1e-5, (float(err[smooth].max()), int(np.flatnonzero(smooth)[err[smooth].argmax()]))
-        assert err.max() <= 0.03, (float(err.max()), int(err.argmax()))
+        # into it: a homozygous cell of allele frequency f is floored for F < -f / (1 - f), so next to the smooth optimum lie
+        # several local maxima ~0.01 apart, and which one a search ends on depends on its path.  The device walks the
+        # reference optimiser's own path (Nelder-Mead from the oracle's fixed start, nm_advance), so it ends on the oracle's
+        # maximum: within 2e-6 (each side stops at a simplex of 1e-6) -- except where two objective values the simplex
+        # compares differ by less than their rounding (the oracle adds ~1e5 logs one by one, the device multiplies
+        # probabilities and takes one log per segment), which may send the two paths apart once in a few thousand
+        # comparisons: at most 1% of the genomes, and those still on a maximum the oracle's own objective rates as good.
+        close = err <= 2e-6
         at_device = oa.loglikelihood_at(ref, dip, sp, 0, upper, 1, 0.0, 1.0, got["inbred_allele_sum"])
         at_oracle = oa.loglikelihood_at(ref, dip, sp, 0, upper, 1, 0.0, 1.0, freqs[:, 4])
         deficit = at_oracle - at_device
-        print(f"Loglikelihood at {G} x {L}: |dF| <= 1e-5 on {int((err <= 1e-5).sum())} of {G} genomes; device optimum better on "
-              f"{int((deficit < -1e-6).sum())}, oracle's better on {int((deficit > 1e-6).sum())} (largest deficit {float(deficit.max()):.3f} log-units)")
-        assert deficit.max() <= 5.0, (float(deficit.max()), int(deficit.argmax()))
+        print(f"Loglikelihood at {G} x {L}: |dF| <= 2e-6 on {int(close.sum())} of {G} genomes, largest {float(err.max()):.3g}; "
+              f"largest deficit under the oracle's objective {float(deficit.max()):.3g} log-units; evaluations {kgx.inbreed_last_evaluations()}")
+        smooth = f_true[order] >= 0.0
+        assert err[smooth].max() <= 2e-6, (float(err[smooth].max()), int(np.flatnonzero(smooth)[err[smooth].argmax()]))
+        assert close.sum() >= 0.99 * G, int(close.sum())
+        assert deficit[~close].max(initial=0.0) <= 1.0, (float(deficit.max()), int(deficit.argmax()))
     m.close()
