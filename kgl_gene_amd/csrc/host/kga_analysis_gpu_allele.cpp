@@ -176,10 +176,6 @@ bool kga::GpuAlleleAnalysis::sweepFlat(const gpu::FlatPopulation& flat, const st
     uint32_t n_contigs = 0;
     std::vector<ContigId_t> contig_ids;
     for (auto& [contig_id, index] : contig_index) { index = n_contigs++; contig_ids.push_back(contig_id); }
-    if (n_contigs * 4 > 254) {
-      ExecEnv::log().error("GpuAlleleAnalysis; {} contigs exceed the 63 supported by the binned by-genome sweep", n_contigs);
-      return false;
-    }
     // Offsets holding >= 2 distinct variants are adjacent rows (same "contig:g.offset" prefix in HGVS order).
     std::vector<uint32_t> first_row, n_rows, group_bin;
     std::vector<uint8_t> compound(V, 0);
@@ -194,15 +190,32 @@ bool kga::GpuAlleleAnalysis::sweepFlat(const gpu::FlatPopulation& flat, const st
       }
       v = e;
     }
-    // bin = contig*4 + is_snp*2 + compound: dosage-weighted totals per class of row
-    std::vector<uint8_t> bin_of_variant(D, 0xFF);                 // split rows take no part here
-    for (uint64_t v = 0; v < V; ++v)
-      bin_of_variant[v] = static_cast<uint8_t>(contig_index.at(flat.rows[v].contig) * 4 + (flat.rows[v].is_snp ? 2 : 0) + compound[v]);
+    // bin = contig*4 + is_snp*2 + compound: dosage-weighted totals per class of row.  One sweep holds 254 bins, 63 contigs;
+    // a population with more (an assembly with its unplaced scaffolds) is swept once per 63 of them.
+    constexpr uint32_t kContigsPerSweep = 63;
     const uint32_t n_bins = n_contigs * 4;
     std::vector<uint64_t> by_genome(G * n_bins * 4);
-    if (kgx_count_by_genome_binned(dev.handle, bin_of_variant.data(), n_bins, by_genome.data()) != KGX_OK) {
-      ExecEnv::log().error("GpuAlleleAnalysis; by-genome (contig) sweep failed: {}", kgx_last_error());
-      return false;
+    std::vector<uint8_t> bin_of_variant(D);
+    std::vector<uint64_t> sweep_counts;
+    for (uint32_t c0 = 0; c0 < n_contigs; c0 += kContigsPerSweep) {
+      const uint32_t c1 = std::min(c0 + kContigsPerSweep, n_contigs), sweep_bins = (c1 - c0) * 4;
+      std::fill(bin_of_variant.begin(), bin_of_variant.end(), static_cast<uint8_t>(0xFF));    // split rows, and the other sweeps' contigs, take no part
+      for (uint64_t v = 0; v < V; ++v) {
+        const uint32_t c = contig_index.at(flat.rows[v].contig);
+        if (c >= c0 && c < c1) bin_of_variant[v] = static_cast<uint8_t>((c - c0) * 4 + (flat.rows[v].is_snp ? 2 : 0) + compound[v]);
+      }
+      uint64_t* counts = by_genome.data();
+      if (sweep_bins != n_bins) {
+        sweep_counts.assign(G * sweep_bins * 4, 0);
+        counts = sweep_counts.data();
+      }
+      if (kgx_count_by_genome_binned(dev.handle, bin_of_variant.data(), sweep_bins, counts) != KGX_OK) {
+        ExecEnv::log().error("GpuAlleleAnalysis; by-genome (contig) sweep failed: {}", kgx_last_error());
+        return false;
+      }
+      if (sweep_bins != n_bins)
+        for (uint64_t g = 0; g < G; ++g)
+          std::copy_n(&sweep_counts[g * sweep_bins * 4], static_cast<size_t>(sweep_bins) * 4, &by_genome[(g * n_bins + c0 * 4) * 4]);
     }
     std::vector<uint64_t> compound_counts(G * n_contigs * 3);
     if (kgx_compound_offsets(dev.handle, first_row.data(), n_rows.data(), group_bin.data(), first_row.size(), n_contigs,

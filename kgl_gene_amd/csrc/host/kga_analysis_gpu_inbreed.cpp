@@ -114,6 +114,26 @@ kga::GpuReferenceContig kga::GpuInbreedAnalysis::buildReference(const Population
   return ref;
 }
 
+size_t kga::GpuReferenceContig::limitAlts() {
+  size_t lossy = 0;
+  if (max_alts <= kMaxAlts) return lossy;
+  max_alts = 0;
+  for (auto& locus : loci) {
+    if (locus.alts.size() > kMaxAlts) {
+      auto bears_frequency = [](const GpuReferenceAlt& alt) {
+        for (const double f : alt.af)
+          if (!std::isnan(f)) return true;
+        return false;
+      };
+      const auto first_without = std::stable_partition(locus.alts.begin(), locus.alts.end(), bears_frequency);
+      if (static_cast<size_t>(first_without - locus.alts.begin()) > kMaxAlts) ++lossy;
+      locus.alts.resize(kMaxAlts);
+    }
+    max_alts = std::max<uint32_t>(max_alts, static_cast<uint32_t>(locus.alts.size()));
+  }
+  return lossy;
+}
+
 void kga::GpuReferenceContig::alleleFreqRow(size_t l, int sp, double* row, uint32_t amax) const {
   const auto& alts = loci[l].alts;
   for (uint32_t j = 0; j < amax; ++j) row[j] = kNaN;
@@ -250,6 +270,18 @@ bool kga::GpuInbreedAnalysis::iterationAnalysis() {
 }
 
 bool kga::GpuInbreedAnalysis::referenceInput(GpuReferenceContig& reference) const {
+  const bool ok = referenceSource(reference);
+  if (ok && reference.max_alts > GpuReferenceContig::kMaxAlts) {
+    const uint32_t widest = reference.max_alts;
+    const size_t lossy = reference.limitAlts();
+    ExecEnv::log().warn("GpuInbreedAnalysis; a reference offset holds {} SNP alts, 14 fit the 4-bit allele index: offsets cut to their first 14 "
+                        "frequency-bearing alts, {} of them lost a frequency-bearing alt (its carriers count as carriers of an unknown alt)",
+                        widest, lossy);
+  }
+  return ok;
+}
+
+bool kga::GpuInbreedAnalysis::referenceSource(GpuReferenceContig& reference) const {
   if (unphased_population_) {
     bool ok = false;
     reference = buildReference(*unphased_population_, ok);
@@ -353,10 +385,6 @@ bool kga::GpuInbreedAnalysis::populationInbreeding(GpuParamOutput& param_output)
   }
   GpuReferenceContig reference;
   if (!referenceInput(reference)) return false;
-  if (reference.max_alts > 14) {
-    ExecEnv::log().error("GpuInbreedAnalysis; a reference offset holds {} SNP alts; at most 14 fit the 4-bit allele index", reference.max_alts);
-    return false;
-  }
   const uint32_t amax = std::max<uint32_t>(1, reference.max_alts);
   const uint64_t n_loci = reference.loci.size();
   const auto& super_pops = FrequencyDatabaseRead::superPopulations();
@@ -514,10 +542,6 @@ bool kga::GpuInbreedAnalysis::syntheticInbreeding(GpuParamOutput& param_output) 
   }
   GpuReferenceContig reference;
   if (!referenceInput(reference)) return false;
-  if (reference.max_alts > 14) {
-    ExecEnv::log().error("GpuInbreedAnalysis; a reference offset holds {} SNP alts; at most 14 fit the 4-bit allele index", reference.max_alts);
-    return false;
-  }
   const uint32_t amax = std::max<uint32_t>(1, reference.max_alts);
   const auto& super_pops = FrequencyDatabaseRead::superPopulations();
   const int all_slot = static_cast<int>(std::find(super_pops.begin(), super_pops.end(), std::string(FrequencyDatabaseRead::SUPER_POP_ALL_)) - super_pops.begin());

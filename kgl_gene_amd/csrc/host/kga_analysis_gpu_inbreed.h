@@ -81,6 +81,12 @@ class GpuReferenceContig {
   [[nodiscard]] bool validForSampling(size_t l, int sp, double& minor_sum) const;
   // RetrieveLociiVector::getLociiCount / getLociiFromTo: indices into loci.
   [[nodiscard]] std::vector<uint32_t> sampleLocii(int sp, const GpuLociiArguments& args, bool by_count) const;
+  // The device's allele index is 4 bits: 14 alts per offset.  An offset with more keeps the alts that carry a frequency
+  // for some super population first (the others can be in no AlleleFreqVector and index as "unknown alt", the same to
+  // every estimator) and is cut to 14; returns the number of offsets that lost a frequency-bearing alt that way (their
+  // carriers of such an alt then count as carriers of an unknown one).
+  static constexpr uint32_t kMaxAlts = 14;
+  size_t limitAlts();
 };
 
 class GpuInbreedAnalysis : public VirtualAnalysis {
@@ -110,7 +116,8 @@ class GpuInbreedAnalysis : public VirtualAnalysis {
   bool populationInbreeding(GpuParamOutput& param_output);
   // Either source of the two inputs: the PopulationDB objects a parser delivered, or "FileNameOnly" VCF files the
   // package flattens itself (no Variant objects).
-  bool referenceInput(GpuReferenceContig& reference) const;
+  bool referenceInput(GpuReferenceContig& reference) const;       // referenceSource + GpuReferenceContig::limitAlts
+  bool referenceSource(GpuReferenceContig& reference) const;
   bool diploidInput(const GpuReferenceContig& reference, gpu::FlatDiploid& diploid, bool& phased) const;
   [[nodiscard]] bool haveReference() const { return unphased_population_ != nullptr || !reference_vcf_.empty(); }
   [[nodiscard]] bool haveDiploid() const { return diploid_population_ != nullptr || !diploid_vcf_.empty(); }

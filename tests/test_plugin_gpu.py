@@ -243,6 +243,34 @@ def test_gpu_allele_package_reads_pf_vcf(tmp_path, kgx, quality_filter):
         assert n_rows == 4 * G                                     # every genome holds every header contig
 
 
+def test_gpu_allele_package_sweeps_more_than_63_contigs(tmp_path, kgx):
+    """One by-genome sweep holds 63 contigs' worth of bins; a population with more (here 150: three sweeps) is swept once
+    per 63 -- HeteroHomoZygous per genome x contig as the oracle has it."""
+    from . import vcf_text as vt
+
+    G, L = 23, 4000
+    ids = [f"PF{i:04d}-C" for i in range(G)]
+    contigs = [f"Pf_scaffold_{i:03d}" for i in range(150)] + ["Pf_unused"]
+    text = vt.write_vcf_pf(L, ids, rng_seed=33, contigs=contigs)
+    vcf = tmp_path / "pf.vcf"
+    vcf.write_text(text)
+    res = rio.run_driver("GPU_ALLELE", tmp_path, [f"vcf:{vcf}"], VcfFlavour="Falciparum", Pf7QualityFilter="FALSE")
+    assert res.returncode == 0, res.stderr
+    opop = oa.Population("pf")
+    opop.add_vcf_pf(text)
+    header, rows = rio.read_csv(tmp_path / "VariantStatistics.csv")
+    got = {(r[0], r[1]): [int(r[2]), int(r[3]), int(r[4]), int(r[7]), int(r[8]), int(r[6]), int(r[5])] for r in rows}
+    n_rows = 0
+    for contig in contigs:
+        want, present = opop.hethom(contig), opop.hethom_present(contig)
+        for g, genome in enumerate(sorted(ids)):
+            assert ((genome, contig) in got) == bool(present[g]), (genome, contig)
+            if present[g]:
+                assert got[(genome, contig)] == want[g].tolist(), (genome, contig)
+                n_rows += 1
+    assert n_rows == len(got) == len(contigs) * G
+
+
 @pytest.mark.parametrize("algorithm", ["Simple", "HallME"])
 def test_gpu_inbreed_package_reads_vcf_directly(tmp_path, kgx, algorithm):
     """Both INBREED inputs as "FileNameOnly" VCF files: the package flattens the Gnomad site file into its reference
@@ -292,6 +320,72 @@ def test_gpu_inbreed_package_reads_vcf_directly(tmp_path, kgx, algorithm):
             assert abs(f[4] - freqs[k, 4]) <= {"Simple": 1e-10, "HallME": 1e-9}[algorithm], (ident, g, f[4], freqs[k, 4])
             n_checked += 1
     assert n_checked == len(got) and n_checked >= 3 * (G - 10)
+
+
+def test_gpu_inbreed_package_cuts_offsets_with_more_than_14_alts(tmp_path, kgx):
+    """An offset with 16 same-length ("SNP") alts, two of them without a frequency for any super population: the 4-bit allele
+    index holds 14, so the package keeps the 14 frequency-bearing alts (the other two can be in no AlleleFreqVector and
+    index as "unknown alt"), warns, and carries on -- with the oracle's results, which knows no such limit."""
+    from . import vcf_text as vt
+
+    G, L = 41, 900
+    rec, gt = sv.multiallelic_block(G, L, rng_seed=23, indel_frac=0.0, missing_af_frac=0.0, dup_records=0)
+    rng = np.random.default_rng(5)
+    offsets, refs, alts, afs = list(rec.offsets), list(rec.refs), [list(a) for a in rec.alts], [np.array(a) for a in rec.af]
+    wide_gt = []
+    for k in range(6):                                             # six wide offsets past the block
+        # isSNP: same length, one position differs -- a 6-mer has 18 such alts; 16 of them, in a shuffled order
+        ref = "".join("ACGT"[int(i)] for i in rng.integers(0, 4, 6))
+        al = [ref[:i] + b + ref[i + 1:] for i in range(6) for b in "ACGT" if b != ref[i]]
+        al = [al[int(i)] for i in rng.permutation(len(al))[:16]]
+        p = rng.uniform(0.005, 0.05, len(al))
+        af = np.tile(p.astype(np.float32).reshape(-1, 1), (1, 6))
+        af[[2, 9], :] = np.nan                                       # two alts nobody has a frequency for
+        offsets.append(int(offsets[L - 1]) + 100 * (k + 1)); refs.append(ref); alts.append(al); afs.append(af)
+        probs = np.concatenate([[0.5], np.full(len(al), 0.5 / len(al))])
+        wide_gt.append(rng.choice(len(al) + 1, size=(G, 2), p=probs).astype(np.uint8))
+    rec = oa.Records(rec.contig, np.array(offsets, dtype=np.uint64), refs, alts, af=afs)
+    gt = np.concatenate([gt, np.stack(wide_gt)])
+    for a in rec.af:
+        a[:, 4] = a[:, 5]
+    ids = sv.genome_ids(G, prefix="HG")
+    pops = ["AFR", "AMR", "EAS", "EUR", "SAS"]
+    ped = [(g, pops[i % 5]) for i, g in enumerate(ids)]
+    ref_text = vt.write_vcf_mono(rec, "Gnomad2_1")
+    dip_text = vt.write_vcf_1000(rec, gt, ids, rng_seed=8)
+    (tmp_path / "gnomad.vcf").write_text(ref_text)
+    (tmp_path / "kg.vcf").write_text(dip_text)
+    (tmp_path / "ped.txt").write_text("".join(f"{g}\t{sp}\n" for g, sp in ped))
+    upper = int(offsets[-1]) + 10
+    params = dict(AnalysisType="false", OutputFile="inbreed", Algorithm="Simple", MinAlleleFreq=0.0, MaxAlleleFreq=1.0,
+                  LowerWindow=0, UpperWindow=upper, LociiCount=10000, SamplingDistance=1)
+    res = rio.run_driver("GPU_INBREED", tmp_path, [f"vcf:Gnomad2_1:{tmp_path / 'gnomad.vcf'}", f"vcf:Genome1000:{tmp_path / 'kg.vcf'}",
+                                                    f"ped:{tmp_path / 'ped.txt'}"], **params)
+    assert res.returncode == 0, res.stderr
+    assert "16 SNP alts" in (res.stdout + res.stderr) and " 0 of them lost" in (res.stdout + res.stderr)
+
+    ref = oa.Population("gnomad")
+    ref.add_vcf_mono(ref_text, "Gnomad2_1")
+    dip = oa.Population("kg")
+    dip.add_vcf_1000(dip_text)
+    vdb_ids = [oa.VariantDB(dip).genome_id(i) for i in range(dip.genome_count())]
+    ped_map = dict(ped)
+    sp_of = np.array([oa.SUPER_POPS.index(ped_map[g]) for g in vdb_ids], dtype=np.int32)
+    cols = oa.population_inbreeding(ref.filter_snp_pass(), dip, sp_of, "Simple", 0, upper, 1, 10000, 0.0, 1.0, seed=oa.FIXED_STARTS)
+    header, rows = rio.read_csv(tmp_path / "inbreed_detail.csv")
+    got = {(r[0], r[1]): ([int(r[2]), int(r[4]), int(r[6]), int(r[8]), int(r[10])], [float(r[3]), float(r[5]), float(r[7]), float(r[9]), float(r[11])])
+           for r in rows}
+    n_checked = 0
+    for ident, counts, freqs, present in cols:
+        for k, g in enumerate(vdb_ids):
+            if not present[k]:
+                continue
+            c, f = got[(ident, g)]
+            assert c == counts[k].tolist(), (ident, g, c, counts[k].tolist())
+            assert np.allclose(f[:4], freqs[k, :4], rtol=1e-12, atol=1e-12)
+            assert abs(f[4] - freqs[k, 4]) <= 1e-10
+            n_checked += 1
+    assert n_checked == len(got) and n_checked >= G
 
 
 @pytest.mark.parametrize("via", ["records", "vcf"])

@@ -61,18 +61,18 @@ def write_vcf_1000(rec, gt, ids, rng_seed=0, quirks=True, contig=None):
     return "\n".join(lines) + "\n"
 
 
-def write_vcf_pf(n_records, ids, rng_seed=0, quirks=True, same_af_for_repeats=True):
+def write_vcf_pf(n_records, ids, rng_seed=0, quirks=True, same_af_for_repeats=True, contigs=None):
     """Returns the text.  Several contigs (one of them the mitochondrion, one never used), multi-base alleles, repeated
     positions."""
     rng = np.random.default_rng(rng_seed)
-    contigs = ["Pf3D7_01_v3", "Pf3D7_02_v3", "Pf3D7_MIT_v3", "Pf3D7_API_v3"]
+    contigs = contigs or ["Pf3D7_01_v3", "Pf3D7_02_v3", "Pf3D7_MIT_v3", "Pf3D7_API_v3"]       # the last one is never used
     lines = ["##fileformat=VCFv4.2"] + [f"##contig=<ID={c},length=1000000>" for c in contigs] + [
         '##INFO=<ID=VQSLOD,Number=1,Type=Float,Description="x">',
         "#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\t" + "\t".join(ids)]
     bases = "ACGT"
     pos = 100
     for r in range(n_records):
-        contig = contigs[int(rng.integers(0, 3))]
+        contig = contigs[int(rng.integers(0, len(contigs) - 1))]
         if r % 9 != 4:
             pos += int(rng.integers(1, 40))                      # r % 9 == 4 repeats the previous position
         shape = rng.random()
