@@ -83,6 +83,20 @@ def k2_traffic(G, V):
     return None, "no rocprofv3 --pmc pass committed for this shape"
 
 
+def committed_traffic(label, workload):
+    """HBM bytes per launch of an aux sweep from profiles/traffic.json (scripts/summarize_round.py: the FETCH_SIZE and
+    WRITE_SIZE passes of the round's profiling run over this same workload), or None."""
+    tf = ROOT / "profiles" / "traffic.json"
+    try:
+        rec = json.loads(tf.read_text()).get(f"{label}:{workload}") if tf.exists() else None
+    except Exception:
+        rec = None
+    if rec and "hbm_bytes_per_launch" in rec:
+        return rec["hbm_bytes_per_launch"], (f"profiles/traffic.json: 2 x FETCH_SIZE + WRITE_SIZE of separate rocprofv3 --pmc passes over this "
+                                             f"workload ({rec.get('profile', 'earlier profiling run')}, kernel {rec.get('kernel')}); not measured in this run")
+    return None, "no rocprofv3 --pmc pass committed for this workload"
+
+
 def cpu_baseline(capi, pop, G, V, k2_host_sample_rows, sample_variants, seed):
     """The oracle's dense tier (the reference's summaryByVariant column walk over VariantDBGenomeData,
     single-threaded as in CalcFWS::updateVariantFWSMap) timed on this box's host cores, on the first
@@ -190,13 +204,15 @@ def aux_by_genome(capi, torch, pop, counts, G, V, dense, nv):
     wall_ms, kernel_ms = float(np.median(walls)), float(np.median(kernels))
     algorithmic = selected * ((G + 3) // 4) + 32 * G * 11
     achieved = algorithmic / (kernel_ms * 1e-3) / 1e9
+    k3_workload = f"K3 on the headline population: {G} genomes x {selected} binned variants of {V}"
+    k3_traffic, k3_traffic_source = committed_traffic("K3", k3_workload)
     record = {
         "metric": "variants·genomes/sec (by-genome sweep, 11 FWS allele-frequency bins)",
         "value": G * selected / (wall_ms * 1e-3), "unit": "variants·genomes/s", "ms_per_call": wall_ms, "calls": len(walls),
-        "config": {"workload": f"K3 on the headline population: {G} genomes x {selected} binned variants of {V}",
+        "config": {"workload": k3_workload,
                    "note": "wall per call includes the 10 MB bin-map upload, the device-side grouping and the result download"},
         "roofline": {"bound": "hbm", "kernel": "k_count_by_genome", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": None, "traffic_source": "see profiles/ (FETCH_SIZE pass of the same kernel)",
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": k3_traffic, "traffic_source": k3_traffic_source,
                      "algorithmic_bytes_per_launch": algorithmic, "kernel_ms": kernel_ms},
         "cpu_baseline": None,
     }
@@ -232,7 +248,7 @@ def aux_inbreeding(args, capi, torch, dev, cpu):
     n_sel, amax = table.shape
     sweep_bytes = int(capi.lib().kgx_gt8_sweep_bytes(G, L, amax))
     table_dev = torch.from_numpy(np.ascontiguousarray(table, dtype=np.float64)).to(dev)
-    walls, sweeps = [], []
+    walls, sweeps, kernels = [], [], []
     res = None
     for i in range(7):
         t = time.perf_counter()
@@ -240,18 +256,21 @@ def aux_inbreeding(args, capi, torch, dev, cpu):
         if i >= 2:
             walls.append((time.perf_counter() - t) * 1e3)
             sweeps.append(capi.inbreed_last_sweep_ms())
-    wall_ms, sweep_ms = float(np.median(walls)), float(np.median(sweeps))
-    achieved = sweep_bytes / (sweep_ms * 1e-3) / 1e9
+            kernels.append(capi.inbreed_last_kernel_ms())
+    wall_ms, sweep_ms, kernel_ms = float(np.median(walls)), float(np.median(sweeps)), float(np.median(kernels))
+    achieved = sweep_bytes / (kernel_ms * 1e-3) / 1e9
     label = WORKLOADS["c5"]["label"] if (G, L) == (10_000, 5_000_000) else f"custom: {G} genomes x {L} multi-allelic loci, inbreeding sweep"
+    k5_traffic, k5_traffic_source = committed_traffic("K5", label)
     record = {
         "metric": "genomes·loci/sec (inbreeding sweep + Simple)",
         "value": G * L / (wall_ms * 1e-3), "unit": "genomes·loci/s", "ms_per_call": wall_ms, "calls": len(walls), "dtype": "u8 classes, f64 sums",
         "config": {"workload": label, "genomes": G, "loci": L, "algorithm": "Simple", "layout": "gt8 allele-index bytes, locus-major",
                    "mean_F": float(res["inbred_allele_sum"].mean())},
-        "roofline": {"bound": "hbm", "kernel": "k_inbreed_sweep_swar16 (+ per-locus helper kernels)", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                     "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                     "traffic_source": "see profiles/ (FETCH_SIZE pass of the same kernel)",
-                     "algorithmic_bytes_per_launch": sweep_bytes, "kernel_ms": sweep_ms},
+        "roofline": {"bound": "hbm", "kernel": "k_inbreed_eval_lut<4> (the frequency sweep's table pass)", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                     "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": k5_traffic, "traffic_source": k5_traffic_source,
+                     "algorithmic_bytes_per_launch": sweep_bytes, "kernel_ms": kernel_ms,
+                     "kernel_ms_statistic": f"median of {len(kernels)} launches (HIP events on the launch stream)",
+                     "sweep_ms_with_locus_helpers": sweep_ms},
         "cpu_baseline": None,
     }
     if cpu:
@@ -308,17 +327,18 @@ def inbreed_workload(args, capi, dist, torch, dev, wl, L, n_gpus, rank):
         res = m.inbreed_resident(table_dev.data_ptr(), n_sel, amax, args.algorithm, phased=True)
     fence()
     t0 = time.perf_counter()
-    sweep_ms = []
+    sweep_ms, kernel_ms = [], []
     for _ in range(args.steps):
         res = m.inbreed_resident(table_dev.data_ptr(), n_sel, amax, args.algorithm, phased=True)
         sweep_ms.append(capi.inbreed_last_sweep_ms())
+        kernel_ms.append(capi.inbreed_last_kernel_ms())
     fence()
     elapsed = time.perf_counter() - t0
     if n_gpus > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    k5_ms = float(np.median(sweep_ms))
+    k5_ms = float(np.median(kernel_ms))
     achieved = sweep_bytes / (k5_ms * 1e-3) / 1e9
     if rank != 0:
         return None
@@ -332,10 +352,10 @@ def inbreed_workload(args, capi, dist, torch, dev, wl, L, n_gpus, rank):
         "config": {"workload": workload_label(args, wl, G, L), "genomes_per_gpu": G, "loci": L, "algorithm": args.algorithm,
                    "layout": "gt8 allele-index bytes, locus-major", "exchange": "none (genomes are independent)",
                    "mean_F": float(res["inbred_allele_sum"].mean()), "seed": args.seed},
-        "roofline": {"bound": "hbm", "kernel": "k_inbreed_sweep_swar16 (+ locus helpers)", "achieved": achieved, "peak": HBM_PEAK_GBS,
+        "roofline": {"bound": "hbm", "kernel": "k_inbreed_eval_lut<3|4> (the frequency sweep's table pass)", "achieved": achieved, "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                      "traffic_source": "see profiles/ (FETCH_SIZE pass of the same kernel)", "algorithmic_bytes_per_launch": sweep_bytes,
-                     "kernel_ms": k5_ms, "kernel_ms_statistic": "median"},
+                     "kernel_ms": k5_ms, "kernel_ms_statistic": "median", "sweep_ms_with_locus_helpers": float(np.median(sweep_ms))},
         "cpu_baseline": None,
     }
 

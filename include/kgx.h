@@ -242,6 +242,9 @@ int kgx_inbreed(kgx_gt8* gt, uint64_t g0, uint64_t g1, const uint32_t* locus_ind
  * still searching (at most ~3/4 of the swept bytes together); this frees them (they are re-created when needed). */
 int kgx_release_scratch(void);
 double kgx_inbreed_last_sweep_ms(void);
+/* ... and of the one kernel inside it that reads the genotype bytes (k_inbreed_eval_lut<3|4>, or the SWAR / generic
+ * sweep): the sweep without the per-locus helper kernels (tables, entries, segment defaults). */
+double kgx_inbreed_last_kernel_ms(void);
 /* Objective evaluations (= passes over the genotype bytes) the most recent KGX_ALGO_LOGLIKELIHOOD call needed. */
 int kgx_inbreed_last_evaluations(void);
 

@@ -81,6 +81,7 @@ _SIGNATURES = {
                               C.c_int, C.c_void_p]),
     "kgx_release_scratch": (C.c_int, []),
     "kgx_inbreed_last_sweep_ms": (C.c_double, []),
+    "kgx_inbreed_last_kernel_ms": (C.c_double, []),
     "kgx_inbreed_last_evaluations": (C.c_int, []),
     "kgx_gt8_synth_multiallelic": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64, C.c_void_p]),
     "kgx_synth_multiallelic_host": (C.c_int, [C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64, C.c_void_p, C.c_uint64,
@@ -450,6 +451,11 @@ class GenotypeMatrix:
 def release_scratch() -> None:
     """Free the arena kgx_inbreed keeps its per-call device buffers in."""
     check(lib().kgx_release_scratch())
+
+
+def inbreed_last_kernel_ms() -> float:
+    """HIP-event time of the kernel of the last inbreed call's frequency sweep that reads the genotype bytes."""
+    return float(lib().kgx_inbreed_last_kernel_ms())
 
 
 def inbreed_last_sweep_ms() -> float:

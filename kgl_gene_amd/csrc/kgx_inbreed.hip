@@ -309,8 +309,14 @@ int inbreed_shard(kgx_gt8_shard& sh, uint64_t g0, uint64_t g1, const uint32_t* l
   if (rc == KGX_OK) {
     if (n_sel) hipLaunchKernelGGL((k_locus_tables<true>), dim3(stream_grid(dev, n_sel, kBlock)), dim3(kBlock), 0, st, d_af, n_sel, amax, 0.0, d_table, d_valid);
     if (rc == KGX_OK) try_hip(hipEventRecord(dev.sweep_begin, st), KGX_EHIP, "hipEventRecord");
+    if (!table_sweep && rc == KGX_OK) try_hip(hipEventRecord(dev.kernel_begin, st), KGX_EHIP, "hipEventRecord");
     sweep(0);
-    if (table_sweep) { tabulate(ritland ? 3 : 4); sweep(ritland ? 3 : 4); }
+    if (table_sweep) {
+      tabulate(ritland ? 3 : 4);
+      if (rc == KGX_OK) try_hip(hipEventRecord(dev.kernel_begin, st), KGX_EHIP, "hipEventRecord");
+      sweep(ritland ? 3 : 4);
+    }
+    if (rc == KGX_OK) try_hip(hipEventRecord(dev.kernel_end, st), KGX_EHIP, "hipEventRecord");
     if (rc == KGX_OK) try_hip(hipEventRecord(dev.sweep_end, st), KGX_EHIP, "hipEventRecord");
     if (sequential_defaults && n_sel) try_hip(hipStreamWaitEvent(st, dev.side_end, 0), KGX_EHIP, "hipStreamWaitEvent");
     hipLaunchKernelGGL(k_reduce_parts, dim3(stream_grid(dev, n * kParts0, kBlock)), dim3(kBlock), 0, st, d_part, n_seg, n * kParts0,
@@ -500,6 +506,7 @@ int inbreed_shard(kgx_gt8_shard& sh, uint64_t g0, uint64_t g1, const uint32_t* l
     if (rc == KGX_OK) {
       float ms = 0.f;
       if (hipEventElapsedTime(&ms, dev.sweep_begin, dev.sweep_end) == hipSuccess) dev.last_sweep_ms = ms;
+      if (hipEventElapsedTime(&ms, dev.kernel_begin, dev.kernel_end) == hipSuccess) dev.last_kernel_ms = ms;
     }
   }
   return rc;
@@ -728,6 +735,14 @@ double kgx_inbreed_last_sweep_ms(void) {
   double worst = 0.0;
   if (rt)
     for (const auto& dev : rt->devs) worst = dev->last_sweep_ms > worst ? dev->last_sweep_ms : worst;
+  return worst;
+}
+
+double kgx_inbreed_last_kernel_ms(void) {
+  const auto rt = current_runtime();
+  double worst = 0.0;
+  if (rt)
+    for (const auto& dev : rt->devs) worst = dev->last_kernel_ms > worst ? dev->last_kernel_ms : worst;
   return worst;
 }
 

@@ -31,10 +31,11 @@ struct Device {
   char name[128] = {0};
   char arch[64] = {0};
   hipEvent_t sweep_begin = nullptr, sweep_end = nullptr;   // bracket the frequency sweep of the last kgx_inbreed call here
+  hipEvent_t kernel_begin = nullptr, kernel_end = nullptr; // ... and the one kernel of it that walks the genotype bytes
   hipEvent_t ready = nullptr;                              // cross-stream ordering (kgx_allele_count_by_locus_dev)
   hipEvent_t by_genome_begin = nullptr, by_genome_end = nullptr;   // bracket the K3 kernel of the last by-genome sweep here
   double last_by_genome_ms = 0.0;
-  double last_sweep_ms = 0.0;
+  double last_sweep_ms = 0.0, last_kernel_ms = 0.0;
   int last_evaluations = 0;                                // objective evaluations of the last Loglikelihood call here
   char* scratch = nullptr;                                 // grow-only arena for kgx_inbreed's per-call buffers
   size_t scratch_bytes = 0;

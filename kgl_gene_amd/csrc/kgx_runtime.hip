@@ -138,6 +138,8 @@ Device::~Device() {
   if (exchange_stage) (void)hipFree(exchange_stage);
   if (sweep_begin) (void)hipEventDestroy(sweep_begin);
   if (sweep_end) (void)hipEventDestroy(sweep_end);
+  if (kernel_begin) (void)hipEventDestroy(kernel_begin);
+  if (kernel_end) (void)hipEventDestroy(kernel_end);
   if (ready) (void)hipEventDestroy(ready);
   if (by_genome_begin) (void)hipEventDestroy(by_genome_begin);
   if (by_genome_end) (void)hipEventDestroy(by_genome_end);
@@ -276,6 +278,8 @@ int kgx_init(int device_count, const int* device_ids) {
     KGX_HIP(hipEventCreateWithFlags(&dev->side_end, hipEventDisableTiming));
     KGX_HIP(hipEventCreate(&dev->sweep_begin));
     KGX_HIP(hipEventCreate(&dev->sweep_end));
+    KGX_HIP(hipEventCreate(&dev->kernel_begin));
+    KGX_HIP(hipEventCreate(&dev->kernel_end));
     KGX_HIP(hipEventCreateWithFlags(&dev->ready, hipEventDisableTiming));
     KGX_HIP(hipEventCreate(&dev->by_genome_begin));
     KGX_HIP(hipEventCreate(&dev->by_genome_end));

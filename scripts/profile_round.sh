@@ -1,0 +1,23 @@
+#!/bin/bash
+# rocprofv3 evidence for one round: the default bench.py run (K2 at C3 + the aux sweeps K3 at C3 and K5 at C5) under
+# --kernel-trace --stats, then one FETCH_SIZE and one WRITE_SIZE pass of the same command (separate runs: gpurun refuses
+# mixed modes, and the two counters do not fit one pass on gfx950), then the K5/K7 table passes with SQ counters.
+#   gpurun -- 'bash scripts/profile_round.sh r02'   then   python scripts/summarize_round.py r02
+set -e
+TAG=${1:-r02}
+REPO=${GRAFT_REPO_ROOT:-/root/repo}
+OUT=$REPO/gpurun_out/prof_$TAG
+rm -rf $OUT && mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $REPO/bench.py --steps 10 --warmup 2 --no-cpu-baseline > $OUT/bench_trace.json 2> $OUT/trace.err
+echo "trace done" > $OUT/progress.txt
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -- python3 $REPO/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $OUT/bench_fetch.json 2> $OUT/fetch.err
+echo "fetch done" >> $OUT/progress.txt
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -- python3 $REPO/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $OUT/bench_write.json 2> $OUT/write.err
+echo "write done" >> $OUT/progress.txt
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/k7_trace -- python3 $REPO/scripts/bench_inbreed.py 10000 5000000 --all > $OUT/k7.txt 2> $OUT/k7.err
+echo "k7 trace done" >> $OUT/progress.txt
+rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT --kernel-trace --output-format csv -d $OUT/k7_sq -- python3 $REPO/scripts/bench_inbreed.py 10000 5000000 --all > $OUT/k7_sq.txt 2> $OUT/k7_sq.err
+echo "k7 sq done" >> $OUT/progress.txt
+cat $OUT/k7.txt
+du -sh $OUT

@@ -1,0 +1,106 @@
+"""Condense gpurun_out/prof_<tag>/ (scripts/profile_round.sh) into profiles/<tag>_*: the rocprofv3 --stats table of the
+default bench.py run, per-kernel HBM traffic from the FETCH_SIZE / WRITE_SIZE passes, and the K5/K7 table passes with
+their SQ counters.  Also refreshes profiles/traffic.json, which bench.py quotes ("traffic") when it does not measure.
+
+HBM traffic follows MI355X_MICROARCH.md (HBM / rocprofv3 section): FETCH_SIZE and WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE
+reports half the bytes of a wide coalesced >= 8-B/lane read stream, so the read side is doubled; WRITE_SIZE is exact."""
+import collections, csv, glob, json, re, sys
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent.parent
+tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
+src, dst = ROOT / "gpurun_out" / f"prof_{tag}", ROOT / "profiles"
+dst.mkdir(exist_ok=True)
+
+
+def one(pattern):
+    files = glob.glob(str(src / pattern))
+    if not files:
+        sys.exit(f"missing {pattern} under {src}")
+    return Path(files[0])
+
+
+def short(name):
+    return re.sub(r"^void ", "", name).split("(")[0].replace("kgx::", "")
+
+
+stats_file = one("trace/*/*kernel_stats.csv")
+(dst / f"{tag}_kernel_stats.csv").write_text(stats_file.read_text())
+stats = {short(r["Name"]): r for r in csv.DictReader(stats_file.open())}
+
+
+def counter(pattern, name):
+    agg = collections.defaultdict(list)
+    for r in csv.DictReader(one(pattern).open()):
+        if r["Counter_Name"] == name:
+            agg[short(r["Kernel_Name"])].append(float(r["Counter_Value"]))
+    return agg
+
+
+fetch, write = counter("pmc_fetch/*/*counter_collection.csv", "FETCH_SIZE"), counter("pmc_write/*/*counter_collection.csv", "WRITE_SIZE")
+bench = json.loads((src / "bench_trace.json").read_text().strip().splitlines()[-1])
+aux = bench.get("aux", {})
+kernels = [("K2", "k_allele_count", bench["roofline"], bench["config"]["workload"]),
+           ("K3", "k_count_by_genome", aux.get("k3_fws_bins", {}).get("roofline"), aux.get("k3_fws_bins", {}).get("config", {}).get("workload")),
+           ("K5", "k_inbreed_eval_lut<4", aux.get("c5_simple", {}).get("roofline"), aux.get("c5_simple", {}).get("config", {}).get("workload"))]
+traffic_db_path = dst / "traffic.json"
+traffic_db = json.loads(traffic_db_path.read_text()) if traffic_db_path.exists() else {}
+lines = [f"# rocprofv3 summary `{tag}` — the default `bench.py` run (N=1)", "",
+         f"Commands (on the GPU box, `scripts/profile_round.sh {tag}`):",
+         "`rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline`,",
+         "then the same command (`--steps 3 --warmup 1`) once under `--pmc FETCH_SIZE` and once under `--pmc WRITE_SIZE`.", "",
+         "| sweep | kernel | calls | avg ms (rocprofv3) | ms (HIP events, bench.py) | algorithmic bytes | GB/s (rocprofv3 avg) | of 8 TB/s | HBM read = 2 x FETCH_SIZE x 1024 | HBM write = WRITE_SIZE x 1024 | traffic / algorithmic |",
+         "|---|---|---|---|---|---|---|---|---|---|---|"]
+pmc_rows = ["kernel,counter,launches,mean_value_KiB"]
+for label, needle, roof, workload in kernels:
+    names = [k for k in stats if needle in k]
+    if not names or not roof:
+        continue
+    name = max(names, key=lambda k: float(stats[k]["TotalDurationNs"]))
+    avg_ms = float(stats[name]["AverageNs"]) / 1e6
+    alg = roof["algorithmic_bytes_per_launch"]
+    f = [v for k, vs in fetch.items() if needle in k for v in vs]
+    w = [v for k, vs in write.items() if needle in k for v in vs]
+    # the dominant launches only (K3 runs small helper-sized launches of the same kernel on warm-up shapes)
+    f = [v for v in f if v > 0.5 * max(f)] if f else f
+    w = [v for v in w if v > 0.5 * max(w)] if w else w
+    read_b = 2.0 * sum(f) / len(f) * 1024.0 if f else float("nan")
+    write_b = sum(w) / len(w) * 1024.0 if w else float("nan")
+    traffic = read_b + write_b
+    pmc_rows += [f"{name},FETCH_SIZE,{len(f)},{sum(f) / len(f) if f else 'nan'}", f"{name},WRITE_SIZE,{len(w)},{sum(w) / len(w) if w else 'nan'}"]
+    lines.append(f"| {label}: {workload} | `{name}` | {stats[name]['Calls']} | {avg_ms:.3f} | {roof['kernel_ms']:.3f} | {alg:,} | {alg / avg_ms / 1e6:,.0f} | "
+                 f"{alg / avg_ms / 1e6 / 8000:.1%} | {read_b:,.0f} | {write_b:,.0f} | {traffic / alg:.3f} |")
+    traffic_db[f"{label}:{workload}"] = {"kernel": name, "hbm_bytes_per_launch": traffic, "read_bytes": read_b, "write_bytes": write_b,
+                                         "algorithmic_bytes_per_launch": alg, "profile": f"profiles/{tag}_pmc.csv",
+                                         "correction": "read = 2 x FETCH_SIZE x 1024 (gfx950 wide-stream correction), write = WRITE_SIZE x 1024"}
+(dst / f"{tag}_pmc.csv").write_text("\n".join(pmc_rows) + "\n")
+traffic_db_path.write_text(json.dumps(traffic_db, indent=1) + "\n")
+lines += ["", f"bench.py line of the traced run: value {bench['value']:.4g} {bench['unit']}, {bench['ms_per_step']:.3f} ms/step.",
+          f"Full kernel table: `profiles/{tag}_kernel_stats.csv`; counter means: `profiles/{tag}_pmc.csv`.", ""]
+
+# ---- the table passes (K5 frequency sweep, RitlandLocus, HallME, Loglikelihood) at C5
+k7_stats = one("k7_trace/*/*kernel_stats.csv")
+(dst / f"{tag}_k7_kernel_stats.csv").write_text(k7_stats.read_text())
+k7 = {short(r["Name"]): r for r in csv.DictReader(k7_stats.open())}
+sq = collections.defaultdict(lambda: collections.defaultdict(list))
+for r in csv.DictReader(one("k7_sq/*/*counter_collection.csv").open()):
+    sq[short(r["Kernel_Name"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
+cells = 10_000 * 5_000_000
+lines += ["## The table passes at C5 (10 k genomes x 5 M loci, 50.12 GB algorithmic per pass)", "",
+          "`rocprofv3 --kernel-trace --stats -- python3 scripts/bench_inbreed.py 10000 5000000 --all`, then the same under",
+          "`--pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT`.", "",
+          "| kernel | calls | avg ms | TB/s at 50.12 GB | VALU wave-instr / launch | VALU per cell (x64 lanes / 5e10 cells) | SALU / launch | LDS instr / launch | LDS bank-conflict cycles | wait-inst / wave cycles |",
+          "|---|---|---|---|---|---|---|---|---|---|"]
+for name in sorted(k7, key=lambda k: -float(k7[k]["TotalDurationNs"])):
+    if "k_inbreed_eval_lut" not in name and "swar" not in name:
+        continue
+    avg_ms = float(k7[name]["AverageNs"]) / 1e6
+    c = {k: sum(v) / len(v) for k, v in sq.get(name, {}).items()}
+    valu = c.get("SQ_INSTS_VALU", float("nan"))
+    lines.append(f"| `{name}` | {k7[name]['Calls']} | {avg_ms:.3f} | {50.1208 / avg_ms:.2f} | {valu:.4g} | {valu * 64 / cells:.2f} | {c.get('SQ_INSTS_SALU', float('nan')):.4g} | "
+                 f"{c.get('SQ_INSTS_LDS', float('nan')):.4g} | {c.get('SQ_LDS_BANK_CONFLICT', float('nan')):.4g} | "
+                 f"{c.get('SQ_WAIT_INST_ANY', float('nan')) / c.get('SQ_WAVE_CYCLES', float('nan')):.2f} |")
+lines += ["", "(Loglikelihood's passes after the first compactions sweep fewer genomes: its average is over all its launches.)", "",
+          "`scripts/bench_inbreed.py` output of the traced run:", "", "```"] + (src / "k7.txt").read_text().strip().splitlines() + ["```", ""]
+(dst / f"{tag}_summary.md").write_text("\n".join(lines))
+print("\n".join(lines))
