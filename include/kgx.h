@@ -156,6 +156,14 @@ int kgx_count_by_genome(kgx_pop* pop, const uint8_t* variant_mask /* host [n_var
 int kgx_count_by_genome_binned(kgx_pop* pop, const uint8_t* bin_of_variant /* host [n_variants] */,
                                uint32_t n_bins, uint64_t* out /* host [n_genomes][n_bins][4] */);
 
+/* The same with the bin of every row decided ON THE DEVICE from the population's AF column (kgx_population_set_af), the
+ * P7FrequencyFilter pair of kga_analysis_PfEMP_FWS.cpp:15-38 (kgl_variant_filter_Pf7.cpp:20-66) as a per-launch
+ * predicate: row v is in bin b iff  af[v] >= bin_edges[b]  and not  af[v] >= bin_edges[b + 1]  (compared as doubles: a
+ * row whose AF passes the lower filter and fails the upper one); NaN = no value = in no bin.  Nothing but the n_bins + 1
+ * edges travels to the device per call. */
+int kgx_count_by_genome_af_bins(kgx_pop* pop, const double* bin_edges /* host [n_bins + 1] */, uint32_t n_bins,
+                                uint64_t* out /* host [n_genomes][n_bins][4] */);
+
 /* Device time (HIP events on the library streams) of the k_count_by_genome kernel of the most recent by-genome sweep
  * (the slowest shard's); 0 before the first or when no row was selected.  Algorithmic bytes of that launch:
  * selected rows x ceil(G/4) + 32 x G x n_bins. */

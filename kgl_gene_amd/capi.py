@@ -80,6 +80,7 @@ _SIGNATURES = {
     "kgx_inbreed": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint32, C.c_int,
                               C.c_int, C.c_void_p]),
     "kgx_release_scratch": (C.c_int, []),
+    "kgx_count_by_genome_af_bins": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]),
     "kgx_inbreed_last_sweep_ms": (C.c_double, []),
     "kgx_inbreed_last_kernel_ms": (C.c_double, []),
     "kgx_inbreed_last_evaluations": (C.c_int, []),
@@ -329,6 +330,15 @@ class Population:
             raise ValueError("bin_of_variant must be [n_variants]")
         out = np.zeros((self.n_genomes, n_bins, 4), dtype=np.uint64)
         check(lib().kgx_count_by_genome_binned(self._h, ptr(b), n_bins, ptr(out)))
+        return out
+
+    def count_by_genome_af_bins(self, bin_edges) -> np.ndarray:
+        """The by-genome sweep with every row's bin decided on the device from the AF column (set_af): bin b holds the rows
+        with edges[b] <= af and not edges[b + 1] <= af; NaN rows are in no bin.  [n_genomes][len(edges) - 1][4] uint64."""
+        e = np.ascontiguousarray(bin_edges, dtype=np.float64)
+        n_bins = len(e) - 1
+        out = np.zeros((self.n_genomes, n_bins, 4), dtype=np.uint64)
+        check(lib().kgx_count_by_genome_af_bins(self._h, ptr(e), n_bins, ptr(out)))
         return out
 
     def compound_offsets(self, first_row, n_rows, bins, n_bins: int) -> np.ndarray:

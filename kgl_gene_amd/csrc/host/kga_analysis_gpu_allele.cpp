@@ -1,6 +1,9 @@
 #include "kga_analysis_gpu_allele.h"
 
+#include <algorithm>
 #include <fstream>
+#include <limits>
+#include <mutex>
 #include <iterator>
 
 #include "../../../include/kgx.h"
@@ -17,6 +20,29 @@ namespace {
 struct DevicePopulation {
   kgx_pop* handle{nullptr};
   ~DevicePopulation() { if (handle) kgx_population_destroy(handle); }
+};
+
+// The flatteners' rows straight into HBM as they are packed (kgx_flatten.h: RowSink): the population is created when its
+// shape is known and every block of rows is uploaded by the thread that packed it, one upload at a time.
+struct DeviceRowSink final : kgl::analysis::gpu::RowSink {
+  DevicePopulation& dev;
+  uint64_t row_bytes{0};
+  std::mutex upload;
+  std::string error;
+  explicit DeviceRowSink(DevicePopulation& d) : dev(d) {}
+  bool begin(const kgl::analysis::gpu::FlatPopulation& meta) override {
+    row_bytes = meta.row_bytes;
+    if (meta.genomes() == 0 || meta.deviceRows() == 0) return true;
+    dev.handle = kgx_population_create(meta.genomes(), meta.deviceRows());
+    if (!dev.handle) error = std::string("kgx_population_create failed: ") + kgx_last_error();
+    return dev.handle != nullptr;
+  }
+  void rows(uint64_t first_row, uint64_t n_rows, const uint8_t* data) override {
+    std::lock_guard<std::mutex> lock(upload);
+    if (!dev.handle || !error.empty()) return;
+    if (kgx_population_load_dosage2(dev.handle, data, row_bytes, first_row, first_row + n_rows) != KGX_OK)
+      error = std::string("upload failed: ") + kgx_last_error();
+  }
 };
 
 std::string joinPath(const std::string& dir, const std::string& stem) {
@@ -92,22 +118,31 @@ bool kga::GpuAlleleAnalysis::sweepVcfFile(const std::string& file_name) {
     ExecEnv::log().error("GpuAlleleAnalysis; unknown VcfFlavour: {} (Genome1000 or Falciparum)", vcf_flavour_);
     return false;
   }
-  const bool read_ok = vcf_flavour_ == "Genome1000" ? gpu::flattenVcf1000File(file_name, flat, io_error)
-                                                    : gpu::flattenVcfPfFile(file_name, flat, io_error, 0, pf7_quality_filter_);
+  // ... and the packed rows go to the device block by block as the flattener finishes them: flat.packed stays empty
+  DevicePopulation dev;
+  DeviceRowSink sink(dev);
+  const bool read_ok = vcf_flavour_ == "Genome1000" ? gpu::flattenVcf1000File(file_name, flat, io_error, 0, size_t{64} << 20, &sink)
+                                                    : gpu::flattenVcfPfFile(file_name, flat, io_error, 0, pf7_quality_filter_, size_t{64} << 20, &sink);
   if (!read_ok) {
     ExecEnv::log().error("GpuAlleleAnalysis; {}", io_error);
     return false;
   }
-  if (vcf_flavour_ == "Genome1000") return sweepFlat(flat, file_name);
+  if (!sink.error.empty()) {
+    ExecEnv::log().error("GpuAlleleAnalysis; {}", sink.error);
+    return false;
+  }
+  if (vcf_flavour_ == "Genome1000") return sweepFlat(flat, file_name, dev.handle);
   // every genome holds every contig of the header, carrier or not (PfVCFImpl::setupPopulationStructure): zero records
   for (const auto& genome_id : flat.genome_ids) {
     auto& contig_map = variant_analysis_map_[genome_id];
     for (const auto& contig_id : flat.contig_ids) contig_map.try_emplace(contig_id);
   }
-  return sweepFlat(flat, file_name);
+  return sweepFlat(flat, file_name, dev.handle);
 }
 
-bool kga::GpuAlleleAnalysis::sweepFlat(const gpu::FlatPopulation& flat, const std::string& label) {
+// uploaded: the population already on the device (its rows arrived through a DeviceRowSink), or null: create it here and
+// upload flat.packed, a bounded block of rows at a time.
+bool kga::GpuAlleleAnalysis::sweepFlat(const gpu::FlatPopulation& flat, const std::string& label, kgx_pop* uploaded) {
   // V: the population's distinct variants; D >= V: rows on the device (the extra ones are per-bin splits, see VariantRow)
   const uint64_t G = flat.genomes(), V = flat.variants(), D = flat.deviceRows();
   ExecEnv::log().info("GpuAlleleAnalysis; population: {}, genomes: {}, distinct variants: {}, Variant objects: {}",
@@ -119,15 +154,23 @@ bool kga::GpuAlleleAnalysis::sweepFlat(const gpu::FlatPopulation& flat, const st
   }
   if (V == 0) return true;
 
-  DevicePopulation dev;
-  dev.handle = kgx_population_create(G, D);
+  DevicePopulation owned;
+  struct { kgx_pop* handle; } dev{uploaded};
   if (!dev.handle) {
-    ExecEnv::log().error("GpuAlleleAnalysis; kgx_population_create failed: {}", kgx_last_error());
-    return false;
-  }
-  if (kgx_population_load_dosage2(dev.handle, flat.packed.data(), flat.row_bytes, 0, D) != KGX_OK) {
-    ExecEnv::log().error("GpuAlleleAnalysis; upload failed: {}", kgx_last_error());
-    return false;
+    owned.handle = kgx_population_create(G, D);
+    dev.handle = owned.handle;
+    if (!dev.handle) {
+      ExecEnv::log().error("GpuAlleleAnalysis; kgx_population_create failed: {}", kgx_last_error());
+      return false;
+    }
+    const uint64_t block = std::max<uint64_t>(1, (uint64_t{256} << 20) / std::max<uint64_t>(1, flat.row_bytes));   // 256 MiB of rows per copy
+    for (uint64_t r0 = 0; r0 < D; r0 += block) {
+      const uint64_t r1 = std::min(D, r0 + block);
+      if (kgx_population_load_dosage2(dev.handle, flat.packed.data() + r0 * flat.row_bytes, flat.row_bytes, r0, r1) != KGX_OK) {
+        ExecEnv::log().error("GpuAlleleAnalysis; upload failed: {}", kgx_last_error());
+        return false;
+      }
+    }
   }
 
   // ---- K2: CalcFWS::updateVariantFWSMap -- summaryByVariant for every variant ------------------
@@ -148,11 +191,18 @@ bool kga::GpuAlleleAnalysis::sweepFlat(const gpu::FlatPopulation& flat, const st
 
   // ---- K3: CalcFWS::updateGenomeFWSMap over the 11 allele-frequency bins -----------------------
   {
-    std::vector<uint8_t> bin_of_variant(D);
-    for (uint64_t v = 0; v < D; ++v)
-      bin_of_variant[v] = flat.rows[v].fws_from_splits ? gpu::FWS_NO_BIN : gpu::fwsBinOfFrequency(flat.rows[v].info_af);
+    // The P7FrequencyFilter pair of every bin is evaluated on the device, from the AF of each row's own record; a row whose
+    // copies sit in several bins takes no part itself (no value), its split rows do.
+    std::vector<float> fws_af(D);
+    for (uint64_t v = 0; v < D; ++v) fws_af[v] = flat.rows[v].fws_from_splits ? std::numeric_limits<float>::quiet_NaN() : flat.rows[v].info_af;
+    std::vector<double> bin_edges(gpu::FWS_FREQUENCY_ARRAY_SIZE + 1);
+    for (size_t b = 0; b < gpu::FWS_FREQUENCY_ARRAY_SIZE; ++b) {
+      bin_edges[b] = gpu::fwsBinRange(b).first;
+      bin_edges[b + 1] = gpu::fwsBinRange(b).second;
+    }
     std::vector<uint64_t> by_genome(G * gpu::FWS_FREQUENCY_ARRAY_SIZE * 4);
-    if (kgx_count_by_genome_binned(dev.handle, bin_of_variant.data(), gpu::FWS_FREQUENCY_ARRAY_SIZE, by_genome.data()) != KGX_OK) {
+    if (kgx_population_set_af(dev.handle, fws_af.data()) != KGX_OK ||
+        kgx_count_by_genome_af_bins(dev.handle, bin_edges.data(), gpu::FWS_FREQUENCY_ARRAY_SIZE, by_genome.data()) != KGX_OK) {
       ExecEnv::log().error("GpuAlleleAnalysis; by-genome sweep failed: {}", kgx_last_error());
       return false;
     }

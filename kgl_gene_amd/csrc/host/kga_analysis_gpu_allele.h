@@ -20,6 +20,8 @@
 #endif
 #include "kgx_flatten.h"
 
+struct kgx_pop;                                    // include/kgx.h
+
 namespace kellerberrin::genome::analysis {
 
 #ifndef KGX_WITH_REFERENCE_HEADERS
@@ -83,7 +85,7 @@ class GpuAlleleAnalysis : public VirtualAnalysis {
  private:
   bool sweepPopulation(const PopulationDB& population);
   bool sweepVcfFile(const std::string& file_name);
-  bool sweepFlat(const gpu::FlatPopulation& flat, const std::string& label);
+  bool sweepFlat(const gpu::FlatPopulation& flat, const std::string& label, kgx_pop* uploaded = nullptr);
   bool writeVariantResults(const std::string& file_name) const;
   bool writeGenomeResults(const std::string& file_name) const;
   bool writeHetHomResults(const std::string& file_name) const;

@@ -58,6 +58,18 @@ struct FlatPopulation {
   [[nodiscard]] size_t deviceRows() const { return rows.size(); }
 };
 
+// Where a VCF flattener's finished device rows go.  Without one they are assembled in FlatPopulation::packed.  With one,
+// `packed` stays empty: the sink is first shown the population's metadata (genome ids, row metadata, row_bytes -- the
+// place of every row is settled before the first one is packed), then receives blocks of consecutive rows as they are
+// packed, possibly from several threads at once, every row exactly once.  GpuAlleleAnalysis uploads them straight to the
+// device, so the host never holds the packed population next to the parsed records it is made from.
+class RowSink {
+ public:
+  virtual ~RowSink() = default;
+  virtual bool begin(const FlatPopulation& meta) = 0;          // false: stop here (the flattener returns the metadata alone)
+  virtual void rows(uint64_t first_row, uint64_t n_rows, const uint8_t* data) = 0;      // n_rows * meta.row_bytes bytes
+};
+
 // threads == 0: the reference's default, hardware_concurrency() - 1 (kel_thread/kel_workflow_threads.h:40).
 [[nodiscard]] FlatPopulation flattenPopulation(const PopulationDB& population, size_t threads = 0);
 
@@ -77,9 +89,9 @@ struct FlatPopulation {
 // (VcfChunkReader, kgx_vcf_io.h): a piece's text is dropped once its records are parsed into 2-bit rows, so the working
 // set is the genotypes, not the text.  chunk_bytes = text per piece.  false + error on an I/O or format error.
 [[nodiscard]] bool flattenVcf1000File(const std::string& file_name, FlatPopulation& flat, std::string& error, size_t threads = 0,
-                                      size_t chunk_bytes = size_t{64} << 20);
+                                      size_t chunk_bytes = size_t{64} << 20, RowSink* sink = nullptr);
 [[nodiscard]] bool flattenVcfPfFile(const std::string& file_name, FlatPopulation& flat, std::string& error, size_t threads = 0,
-                                    bool quality_filter = false, size_t chunk_bytes = size_t{64} << 20);
+                                    bool quality_filter = false, size_t chunk_bytes = size_t{64} << 20, RowSink* sink = nullptr);
 
 // ---- the INBREED package's two inputs straight from VCF text (SURVEY.md §8f #1 for the K5 path) ------------------
 //

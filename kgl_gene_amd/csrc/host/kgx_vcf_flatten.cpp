@@ -217,7 +217,8 @@ void parallelChunks(size_t n, size_t chunk, size_t threads, Fn fn) {
   for (auto& th : pool) th.join();
 }
 
-FlatPopulation mergeRecords(const std::vector<RecordRows>& parsed, const std::vector<std::string>& samples, bool every_sample, size_t threads = 0) {
+FlatPopulation mergeRecords(const std::vector<RecordRows>& parsed, const std::vector<std::string>& samples, bool every_sample, size_t threads = 0,
+                            RowSink* sink = nullptr) {
   const size_t S = samples.size();
   if (S == 0) return FlatPopulation{};              // no #CHROM line / no sample columns: no genomes, hence no variants
   struct Key { const std::string* hgvs; uint32_t record, alt; };
@@ -258,100 +259,136 @@ FlatPopulation mergeRecords(const std::vector<RecordRows>& parsed, const std::ve
   const size_t G = flat.genome_ids.size();
   flat.row_bytes = (G + 3) / 4;
 
-  // Variants: one row per distinct HGVS, in lexicographic order; records repeating an HGVS add their copies.  Groups are
-  // independent: each is summed and packed on its own, then the rows somebody carries are kept in order.
+  // Variants: one row per distinct HGVS, in lexicographic order; records repeating an HGVS add their copies.
   std::vector<size_t> group_begin;
   for (size_t k = 0; k < keys.size(); ++k)
     if (k == 0 || *keys[k].hgvs != *keys[k - 1].hgvs) group_begin.push_back(k);
   const size_t n_groups = group_begin.size();
   group_begin.push_back(keys.size());
-  std::vector<uint8_t> group_rows(n_groups * flat.row_bytes, 0), carried(n_groups, 0);
-  std::vector<size_t> first_key(n_groups, 0);
-  struct Wide { size_t group; uint32_t genome, dosage; };
-  struct Split { size_t group; size_t key; std::vector<uint8_t> row; };   // the copies of one FWS bin of a mixed group (see VariantRow)
-  std::vector<std::vector<Split>> splits_of_chunk((n_groups + 63) / 64);
-  std::vector<std::vector<Wide>> wide_of_chunk((n_groups + 63) / 64);
-  std::vector<size_t> objects_of_chunk((n_groups + 63) / 64, 0);
-  parallelChunks(n_groups, 64, threads, [&](size_t begin, size_t end) {
-    std::vector<uint32_t> total(S);
-    for (size_t grp = begin; grp < end; ++grp) {
-      const size_t k = group_begin[grp], e = group_begin[grp + 1];
-      std::fill(total.begin(), total.end(), 0u);
-      bool any = false;
-      for (size_t m = k; m < e; ++m) {
-        const uint8_t* c = &parsed[keys[m].record].copies[static_cast<size_t>(keys[m].alt) * SB];
-        bool here = false;
-        for (size_t smp = 0; smp < S; ++smp) { const uint32_t n = copyAt(c, smp); total[smp] += n; here = here || n; }
-        // the Variant kept for an HGVS is the first one added (uniqueVariants): the first record that has a carrier
-        if (here && !any) { any = true; first_key[grp] = m; }
-      }
-      if (!any) continue;                             // a variant nobody carries never reaches the PopulationDB
-      carried[grp] = 1;
-      if (e - k > 1) {
-        // records in different FWS bins: one split row per bin, holding that bin's copies only
-        std::map<uint8_t, std::vector<size_t>> by_bin;
-        for (size_t m = k; m < e; ++m) {
-          const uint8_t* c = &parsed[keys[m].record].copies[static_cast<size_t>(keys[m].alt) * SB];
-          if (std::any_of(c, c + SB, [](uint8_t x) { return x != 0; })) by_bin[fwsBinOfFrequency(parsed[keys[m].record].rows[keys[m].alt].info_af)].push_back(m);
-        }
-        if (by_bin.size() > 1) {
-          for (const auto& [bin, members] : by_bin) {
-            if (bin == FWS_NO_BIN) continue;
-            Split split{grp, members.front(), std::vector<uint8_t>(flat.row_bytes, 0)};
-            std::fill(total.begin(), total.end(), 0u);
-            for (size_t m : members) {
-              const uint8_t* c = &parsed[keys[m].record].copies[static_cast<size_t>(keys[m].alt) * SB];
-              for (size_t smp = 0; smp < S; ++smp) total[smp] += copyAt(c, smp);
-            }
-            for (size_t g = 0; g < G; ++g) {
-              uint32_t d = 0;
-              for (uint32_t column : columns_of[g]) d += total[column];
-              split.row[g / 4] |= static_cast<uint8_t>((d > 2 ? 3u : d) << (2 * (g % 4)));
-            }
-            splits_of_chunk[begin / 64].push_back(std::move(split));
-          }
-          // restore the group's totals for the primary row below
-          std::fill(total.begin(), total.end(), 0u);
-          for (size_t m = k; m < e; ++m) {
-            const uint8_t* c = &parsed[keys[m].record].copies[static_cast<size_t>(keys[m].alt) * SB];
-            for (size_t smp = 0; smp < S; ++smp) total[smp] += copyAt(c, smp);
-          }
-          carried[grp] = 2;                             // primary row's bin counts come from its splits
-        }
-      }
-      uint8_t* row = &group_rows[grp * flat.row_bytes];
-      for (size_t g = 0; g < G; ++g) {
-        uint32_t d = 0;
-        for (uint32_t column : columns_of[g]) d += total[column];
-        objects_of_chunk[begin / 64] += d;
-        row[g / 4] |= static_cast<uint8_t>((d > 2 ? 3u : d) << (2 * (g % 4)));
-        if (d > 2) wide_of_chunk[begin / 64].push_back({grp, static_cast<uint32_t>(g), d});
-      }
+  auto copiesOf = [&](size_t m) { return &parsed[keys[m].record].copies[static_cast<size_t>(keys[m].alt) * SB]; };
+
+  // Phase A, metadata only: which groups anybody carries (a variant nobody carries never reaches the PopulationDB), the
+  // record that stands for each (the Variant kept for an HGVS is the first one added, uniqueVariants: the first record
+  // with a carrier), and the groups whose records fall in different FWS bins (one split row per bin, holding that bin's
+  // copies only).  After it every row has its place, so phase B can hand rows out as they are packed.
+  std::vector<uint8_t> has_carrier(keys.size(), 0);
+  parallelChunks(keys.size(), 4096, threads, [&](size_t begin, size_t end) {
+    for (size_t m = begin; m < end; ++m) {
+      const uint8_t* c = copiesOf(m);
+      has_carrier[m] = std::any_of(c, c + SB, [](uint8_t x) { return x != 0; }) ? 1 : 0;
     }
   });
+  struct SplitPlan { size_t group; uint8_t bin; size_t key; size_t row; };
+  std::vector<SplitPlan> split_plan;
+  std::vector<int64_t> split_begin(n_groups, -1);     // first entry of the group in split_plan
+  std::vector<uint8_t> carried(n_groups, 0);
+  std::vector<size_t> first_key(n_groups, 0);
   std::vector<uint32_t> row_of_group(n_groups, 0);
   size_t n_rows = 0;
-  for (size_t grp = 0; grp < n_groups; ++grp) if (carried[grp]) row_of_group[grp] = static_cast<uint32_t>(n_rows++);
-  flat.rows.reserve(n_rows);
-  flat.packed.resize(n_rows * flat.row_bytes);
+  auto binOfKey = [&](size_t m) { return fwsBinOfFrequency(parsed[keys[m].record].rows[keys[m].alt].info_af); };
+  for (size_t grp = 0; grp < n_groups; ++grp) {
+    const size_t k = group_begin[grp], e = group_begin[grp + 1];
+    size_t first = e;
+    for (size_t m = k; m < e; ++m)
+      if (has_carrier[m]) { first = m; break; }
+    if (first == e) continue;
+    carried[grp] = 1;
+    first_key[grp] = first;
+    row_of_group[grp] = static_cast<uint32_t>(n_rows++);
+    if (e - k > 1) {
+      std::map<uint8_t, size_t> first_of_bin;
+      for (size_t m = k; m < e; ++m)
+        if (has_carrier[m]) first_of_bin.try_emplace(binOfKey(m), m);
+      if (first_of_bin.size() > 1) {
+        carried[grp] = 2;                               // primary row's bin counts come from its splits
+        for (const auto& [bin, m] : first_of_bin) {
+          if (bin == FWS_NO_BIN) continue;
+          if (split_begin[grp] < 0) split_begin[grp] = static_cast<int64_t>(split_plan.size());
+          split_plan.push_back({grp, bin, m, 0});
+        }
+      }
+    }
+  }
+  for (size_t i = 0; i < split_plan.size(); ++i) split_plan[i].row = n_rows + i;        // split rows follow the primary rows
+  flat.rows.reserve(n_rows + split_plan.size());
   for (size_t grp = 0; grp < n_groups; ++grp) {
     if (!carried[grp]) continue;
     flat.rows.push_back(parsed[keys[first_key[grp]].record].rows[keys[first_key[grp]].alt]);
     flat.rows.back().fws_from_splits = carried[grp] == 2;
-    if (flat.row_bytes) std::memcpy(&flat.packed[static_cast<size_t>(row_of_group[grp]) * flat.row_bytes], &group_rows[grp * flat.row_bytes], flat.row_bytes);
   }
   flat.primary_rows = flat.rows.size();
-  for (size_t chunk = 0; chunk < wide_of_chunk.size(); ++chunk) {
-    flat.variant_objects += objects_of_chunk[chunk];
-    for (const Wide& w : wide_of_chunk[chunk]) flat.non_diploid.push_back({row_of_group[w.group], w.genome, w.dosage});
+  for (const SplitPlan& split : split_plan) {
+    VariantRow row = parsed[keys[split.key].record].rows[keys[split.key].alt];
+    row.split_of = row_of_group[split.group];
+    flat.rows.push_back(std::move(row));
   }
-  for (const auto& chunk : splits_of_chunk)
-    for (const Split& split : chunk) {
-      VariantRow row = parsed[keys[split.key].record].rows[keys[split.key].alt];
-      row.split_of = row_of_group[split.group];
-      flat.rows.push_back(std::move(row));
-      flat.packed.insert(flat.packed.end(), split.row.begin(), split.row.end());
+
+  // Phase B: the rows themselves, a block of groups at a time on every thread; a block's primary rows are consecutive
+  // device rows and leave for the sink at once (default: FlatPopulation::packed), so no second copy of the population
+  // is ever assembled here.
+  struct PackedSink final : RowSink {
+    FlatPopulation* flat{nullptr};
+    bool begin(const FlatPopulation& meta) override { flat->packed.assign(meta.rows.size() * meta.row_bytes, 0); return true; }
+    void rows(uint64_t first_row, uint64_t count, const uint8_t* data) override {
+      if (count && flat->row_bytes) std::memcpy(&flat->packed[first_row * flat->row_bytes], data, count * flat->row_bytes);
     }
+  } packed_sink;
+  packed_sink.flat = &flat;
+  RowSink* out = sink ? sink : &packed_sink;
+  if (!out->begin(flat)) return flat;
+  constexpr size_t kGroupsPerBlock = 1024;
+  const size_t n_blocks = (n_groups + kGroupsPerBlock - 1) / kGroupsPerBlock;
+  struct Wide { size_t group; uint32_t genome, dosage; };
+  std::vector<std::vector<Wide>> wide_of_block(n_blocks);
+  std::vector<size_t> objects_of_block(n_blocks, 0);
+  parallelChunks(n_groups, kGroupsPerBlock, threads, [&](size_t begin, size_t end) {
+    std::vector<uint32_t> total(S);
+    std::vector<uint8_t> block_rows, split_row(flat.row_bytes);
+    size_t first_row = 0, block_count = 0;
+    auto packTotals = [&](uint8_t* row, size_t grp, bool primary) {
+      for (size_t g = 0; g < G; ++g) {
+        uint32_t d = 0;
+        for (uint32_t column : columns_of[g]) d += total[column];
+        row[g / 4] |= static_cast<uint8_t>((d > 2 ? 3u : d) << (2 * (g % 4)));
+        if (primary) {
+          objects_of_block[begin / kGroupsPerBlock] += d;
+          if (d > 2) wide_of_block[begin / kGroupsPerBlock].push_back({grp, static_cast<uint32_t>(g), d});
+        }
+      }
+    };
+    for (size_t grp = begin; grp < end; ++grp) {
+      if (!carried[grp]) continue;
+      const size_t k = group_begin[grp], e = group_begin[grp + 1];
+      if (block_count == 0) first_row = row_of_group[grp];
+      if (carried[grp] == 2) {
+        for (int64_t i = split_begin[grp]; i >= 0 && static_cast<size_t>(i) < split_plan.size() && split_plan[i].group == grp; ++i) {
+          std::fill(total.begin(), total.end(), 0u);
+          for (size_t m = k; m < e; ++m) {
+            if (!has_carrier[m] || binOfKey(m) != split_plan[i].bin) continue;
+            const uint8_t* c = copiesOf(m);
+            for (size_t smp = 0; smp < S; ++smp) total[smp] += copyAt(c, smp);
+          }
+          std::fill(split_row.begin(), split_row.end(), static_cast<uint8_t>(0));
+          packTotals(split_row.data(), grp, false);
+          out->rows(split_plan[i].row, 1, split_row.data());
+        }
+      }
+      std::fill(total.begin(), total.end(), 0u);
+      for (size_t m = k; m < e; ++m) {
+        if (!has_carrier[m]) continue;
+        const uint8_t* c = copiesOf(m);
+        for (size_t smp = 0; smp < S; ++smp) total[smp] += copyAt(c, smp);
+      }
+      block_rows.resize((block_count + 1) * flat.row_bytes, 0);
+      packTotals(block_rows.data() + block_count * flat.row_bytes, grp, true);
+      ++block_count;
+    }
+    if (block_count) out->rows(first_row, block_count, block_rows.data());
+  });
+  for (size_t block = 0; block < n_blocks; ++block) {
+    flat.variant_objects += objects_of_block[block];
+    for (const Wide& w : wide_of_block[block]) flat.non_diploid.push_back({row_of_group[w.group], w.genome, w.dosage});
+  }
   return flat;
 }
 
@@ -381,7 +418,7 @@ void appendRecords(std::vector<RecordRows>& a, std::vector<RecordRows>&& b) {
 // next(text): the next run of whole lines of the file, false when there is none.  The sample names are those of the
 // first piece that holds a #CHROM line (the header precedes the records).
 template <typename NextChunk>
-FlatPopulation flattenVcf1000Chunks(NextChunk&& next, size_t threads) {
+FlatPopulation flattenVcf1000Chunks(NextChunk&& next, size_t threads, RowSink* sink = nullptr) {
   const bool trace = std::getenv("KGX_FLATTEN_TRACE") != nullptr;
   auto t_last = std::chrono::steady_clock::now();
   auto lap = [&](const char* what) {
@@ -436,7 +473,7 @@ FlatPopulation flattenVcf1000Chunks(NextChunk&& next, size_t threads) {
   lap("parse records");
   appendRecords(all_parsed, std::move(parsed));
   }
-  FlatPopulation flat = mergeRecords(all_parsed, samples, false, threads);
+  FlatPopulation flat = mergeRecords(all_parsed, samples, false, threads, sink);
   lap("merge");
   return flat;
 }
@@ -463,10 +500,10 @@ struct FilePieces {
 
 FlatPopulation flattenVcf1000(std::string_view text, size_t threads) { return flattenVcf1000Chunks(WholeText{text}, threads); }
 
-bool flattenVcf1000File(const std::string& file_name, FlatPopulation& flat, std::string& error, size_t threads, size_t chunk_bytes) {
+bool flattenVcf1000File(const std::string& file_name, FlatPopulation& flat, std::string& error, size_t threads, size_t chunk_bytes, RowSink* sink) {
   FilePieces pieces;
   if (!pieces.reader.open(file_name, error, threads, chunk_bytes)) return false;
-  flat = flattenVcf1000Chunks(pieces, threads);
+  flat = flattenVcf1000Chunks(pieces, threads, sink);
   error = pieces.error;
   return error.empty();
 }
@@ -557,7 +594,7 @@ bool passesP7VariantFilter(std::string_view info, std::string_view contig) {
 namespace {
 
 template <typename NextChunk>
-FlatPopulation flattenVcfPfChunks(NextChunk&& next, size_t threads, bool quality_filter) {
+FlatPopulation flattenVcfPfChunks(NextChunk&& next, size_t threads, bool quality_filter, RowSink* sink = nullptr) {
   std::vector<std::string> samples, contigs;
   std::vector<RecordRows> all_parsed;
   std::string_view text;
@@ -645,7 +682,7 @@ FlatPopulation flattenVcfPfChunks(NextChunk&& next, size_t threads, bool quality
   });
   appendRecords(all_parsed, std::move(parsed));
   }
-  FlatPopulation flat = mergeRecords(all_parsed, samples, true, threads);
+  FlatPopulation flat = mergeRecords(all_parsed, samples, true, threads, sink);
   flat.contig_ids = contigs;
   return flat;
 }
@@ -654,10 +691,11 @@ FlatPopulation flattenVcfPfChunks(NextChunk&& next, size_t threads, bool quality
 
 FlatPopulation flattenVcfPf(std::string_view text, size_t threads, bool quality_filter) { return flattenVcfPfChunks(WholeText{text}, threads, quality_filter); }
 
-bool flattenVcfPfFile(const std::string& file_name, FlatPopulation& flat, std::string& error, size_t threads, bool quality_filter, size_t chunk_bytes) {
+bool flattenVcfPfFile(const std::string& file_name, FlatPopulation& flat, std::string& error, size_t threads, bool quality_filter, size_t chunk_bytes,
+                      RowSink* sink) {
   FilePieces pieces;
   if (!pieces.reader.open(file_name, error, threads, chunk_bytes)) return false;
-  flat = flattenVcfPfChunks(pieces, threads, quality_filter);
+  flat = flattenVcfPfChunks(pieces, threads, quality_filter, sink);
   error = pieces.error;
   return error.empty();
 }

@@ -128,14 +128,15 @@ void launch_by_genome(const kgx_pop_shard& sh, const uint32_t* d_index, const Ge
 }
 
 // One shard's by-genome sweep; out = the shard's block [n_genomes][n_bins][4] of the caller's array.
-int count_by_genome_shard(kgx_pop_shard& sh, const uint8_t* bin_of_variant, uint32_t n_bins, uint64_t* out) {
+// bin_edges (host, n_bins + 1 doubles; bin_of_variant null then): the bins are evaluated on the device from the AF column.
+int count_by_genome_shard(kgx_pop_shard& sh, const uint8_t* bin_of_variant, uint32_t n_bins, uint64_t* out, const double* bin_edges = nullptr) {
   const uint64_t V = sh.n_variants, G = sh.n_genomes;
   if (G == 0) return KGX_OK;
   if (V > 0xFFFFFFFFull) return fail(KGX_EINVAL, "n_variants exceeds the 32-bit row index of the by-genome sweep");
   if (int rc = use_device(*sh.dev)) return rc;
   Device& dev = *sh.dev;
   const uint64_t cells = G * n_bins;
-  const bool identity = bin_of_variant == nullptr;
+  const bool identity = bin_of_variant == nullptr && bin_edges == nullptr;
   hipStream_t st = dev.stream;
 
   unsigned long long *d_acc = nullptr, *d_out = nullptr, *d_nbin = nullptr, *d_binoff = nullptr;
@@ -168,7 +169,15 @@ int count_by_genome_shard(kgx_pop_shard& sh, const uint8_t* bin_of_variant, uint
     try_hip(hipMalloc(&d_index, (V + 8) * sizeof(uint32_t)), KGX_ENOMEM, "hipMalloc(index)");      // + 8: whole 8-entry scalar fetches
     try_hip(hipMemsetAsync(d_index + V, 0, 8 * sizeof(uint32_t), st), KGX_EHIP, "memset(index pad)");
     try_hip(hipMalloc(&d_chunks, static_cast<uint64_t>(n_chunks) * n_bins * sizeof(uint32_t)), KGX_ENOMEM, "hipMalloc(chunk counts)");
-    try_hip(hipMemcpyAsync(d_bins, bin_of_variant, V, hipMemcpyHostToDevice, st), KGX_EHIP, "H2D(bins)");
+    if (bin_edges) {
+      // d_binoff is not read before k_bin_scan writes it: the edges borrow it on their way in
+      static_assert(sizeof(double) == sizeof(unsigned long long), "edge buffer");
+      try_hip(hipMemcpyAsync(d_binoff, bin_edges, (n_bins + 1) * sizeof(double), hipMemcpyHostToDevice, st), KGX_EHIP, "H2D(bin edges)");
+      if (rc == KGX_OK)
+        hipLaunchKernelGGL(k_af_bins, dim3(stream_grid(dev, V, kBlock)), dim3(kBlock), 0, st, sh.d_af, V, reinterpret_cast<const double*>(d_binoff), n_bins, d_bins);
+    } else {
+      try_hip(hipMemcpyAsync(d_bins, bin_of_variant, V, hipMemcpyHostToDevice, st), KGX_EHIP, "H2D(bins)");
+    }
     if (rc == KGX_OK) {
       hipLaunchKernelGGL(k_bin_count, dim3(n_chunks), dim3(kBlock), 0, st, d_bins, V, n_bins, d_chunks);
       hipLaunchKernelGGL(k_bin_totals, dim3(n_bins), dim3(kBlock), 0, st, d_chunks, n_chunks, d_nbin);
@@ -241,10 +250,10 @@ int count_by_genome_shard(kgx_pop_shard& sh, const uint8_t* bin_of_variant, uint
   return rc;
 }
 
-int count_by_genome_impl(kgx_pop* pop, const uint8_t* bin_of_variant, uint32_t n_bins, uint64_t* out) {
+int count_by_genome_impl(kgx_pop* pop, const uint8_t* bin_of_variant, uint32_t n_bins, uint64_t* out, const double* bin_edges = nullptr) {
   return for_each_parallel(pop->shards.size(), [&](size_t s) {
     kgx_pop_shard& sh = pop->shards[s];
-    return count_by_genome_shard(sh, bin_of_variant, n_bins, out + sh.genome_base * n_bins * 4);
+    return count_by_genome_shard(sh, bin_of_variant, n_bins, out + sh.genome_base * n_bins * 4, bin_edges);
   });
 }
 
@@ -691,6 +700,16 @@ int kgx_count_by_genome_binned(kgx_pop* pop, const uint8_t* bin_of_variant, uint
   if (!pop || !out || !bin_of_variant) return fail(KGX_EINVAL, "null population, bins or output");
   if (n_bins == 0 || n_bins > 254) return fail(KGX_EINVAL, "n_bins %u outside [1,254]", n_bins);
   const int rc = count_by_genome_impl(pop, bin_of_variant, n_bins, out);
+  (void)use_device(*pop->shards[0].dev);
+  return rc;
+}
+
+int kgx_count_by_genome_af_bins(kgx_pop* pop, const double* bin_edges, uint32_t n_bins, uint64_t* out) {
+  if (int bound = require_bound()) return bound;
+  if (!pop || !out || !bin_edges) return fail(KGX_EINVAL, "null population, bin edges or output");
+  if (n_bins == 0 || n_bins > 254) return fail(KGX_EINVAL, "n_bins %u outside [1,254]", n_bins);
+  if (!pop->has_af) return fail(KGX_ESTATE, "allele frequencies were never set (kgx_population_set_af)");
+  const int rc = count_by_genome_impl(pop, nullptr, n_bins, out, bin_edges);
   (void)use_device(*pop->shards[0].dev);
   return rc;
 }

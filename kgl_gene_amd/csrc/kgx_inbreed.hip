@@ -163,6 +163,7 @@ int inbreed_shard(kgx_gt8_shard& sh, uint64_t g0, uint64_t g1, const uint32_t* l
   const bool wave_sized = n_sel > 0 && n_sel <= 64ull * kWaveCells && !env_int("KGX_K7_NO_WAVE", 0);
   const bool table_passes = n_sel > 0 && (table_sweep || (eval_lut && (algorithm == 2 || algorithm == 3) && !wave_sized));
   const size_t o_entries = plan.add(table_passes ? (n_sel << (2u * eval_bits(amax))) * sizeof(EvalEntry) : 0);
+  const size_t o_segcnt = plan.add(table_sweep ? max_seg * n * sizeof(unsigned long long) : sizeof(unsigned long long));
   char* arena = nullptr;
   if (int arc = scratch_reserve(dev, plan.total, &arena)) return arc;
   d_af = reinterpret_cast<double*>(arena + o_af);
@@ -184,6 +185,7 @@ int inbreed_shard(kgx_gt8_shard& sh, uint64_t g0, uint64_t g1, const uint32_t* l
   long long* d_seq_n = reinterpret_cast<long long*>(arena + o_seq_n);
   double* d_seq_out = reinterpret_cast<double*>(arena + o_seq_out);
   EvalEntry* d_entries = reinterpret_cast<EvalEntry*>(arena + o_entries);
+  unsigned long long* d_segcnt = reinterpret_cast<unsigned long long*>(arena + o_segcnt);
   try_hip(hipMemsetAsync(d_meta, 0, (n_tab + 8) * sizeof(uint32_t), dev.stream), KGX_EHIP, "memset(meta)");
   if (locus_index && n_sel) {
     d_index = reinterpret_cast<uint32_t*>(arena + o_index);
@@ -282,7 +284,7 @@ int inbreed_shard(kgx_gt8_shard& sh, uint64_t g0, uint64_t g1, const uint32_t* l
   hipLaunchKernelGGL((k_inbreed_eval_lut<M, W, FOLD>),                                                                               \
                      dim3(static_cast<uint32_t>(((n + W - 1) / W + kBlock - 1) / kBlock), static_cast<uint32_t>(launch_n_seg)),      \
                      dim3(kBlock), 0, st, gt32, dwords_per_row, g0, n, d_index, n_sel,                                               \
-                     launch_per_seg, d_entries, d_table, d_valid, amax, d_f, d_part, d_counts)
+                     launch_per_seg, d_entries, d_table, d_valid, amax, d_f, d_part, d_counts, d_segcnt)
 #define KGX_EVAL_FOLD(M, W)                                                \
   do {                                                                     \
     if (eval_fold) KGX_EVAL(M, W, true); else KGX_EVAL(M, W, false);       \
@@ -315,8 +317,14 @@ int inbreed_shard(kgx_gt8_shard& sh, uint64_t g0, uint64_t g1, const uint32_t* l
       tabulate(ritland ? 3 : 4);
       if (rc == KGX_OK) try_hip(hipEventRecord(dev.kernel_begin, st), KGX_EHIP, "hipEventRecord");
       sweep(ritland ? 3 : 4);
+      if (rc == KGX_OK) try_hip(hipEventRecord(dev.kernel_end, st), KGX_EHIP, "hipEventRecord");
+      if (n_sel) {
+        const uint32_t seg_rows = n_seg < 32 ? static_cast<uint32_t>(n_seg) : 32u;
+        hipLaunchKernelGGL(k_reduce_class_counts, dim3(static_cast<uint32_t>((n + kBlock - 1) / kBlock), seg_rows), dim3(kBlock), 0, st, d_segcnt, n_seg, n, d_counts);
+      }
+    } else if (rc == KGX_OK) {
+      try_hip(hipEventRecord(dev.kernel_end, st), KGX_EHIP, "hipEventRecord");
     }
-    if (rc == KGX_OK) try_hip(hipEventRecord(dev.kernel_end, st), KGX_EHIP, "hipEventRecord");
     if (rc == KGX_OK) try_hip(hipEventRecord(dev.sweep_end, st), KGX_EHIP, "hipEventRecord");
     if (sequential_defaults && n_sel) try_hip(hipStreamWaitEvent(st, dev.side_end, 0), KGX_EHIP, "hipStreamWaitEvent");
     hipLaunchKernelGGL(k_reduce_parts, dim3(stream_grid(dev, n * kParts0, kBlock)), dim3(kBlock), 0, st, d_part, n_seg, n * kParts0,
@@ -390,7 +398,7 @@ int inbreed_shard(kgx_gt8_shard& sh, uint64_t g0, uint64_t g1, const uint32_t* l
   hipLaunchKernelGGL((k_inbreed_eval_lut<2, 8, FOLD>),                                                                               \
                      dim3(static_cast<uint32_t>(((n_act + 7) / 8 + kBlock - 1) / kBlock), static_cast<uint32_t>(eval_n_seg)),        \
                      dim3(kBlock), 0, st, act_gt, act_dwords_per_row, act_g0, n_act, act_index,                                      \
-                     n_sel, eval_per_seg, d_entries, d_table, d_valid, amax, act_f, d_part, d_counts)
+                     n_sel, eval_per_seg, d_entries, d_table, d_valid, amax, act_f, d_part, d_counts, d_segcnt)
           if (eval_fold) KGX_EVAL2(true); else KGX_EVAL2(false);
 #undef KGX_EVAL2
         };

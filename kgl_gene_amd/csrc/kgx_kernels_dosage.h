@@ -358,6 +358,24 @@ k_finish_by_genome(const unsigned long long* __restrict__ acc, const unsigned lo
 constexpr int kBinChunk = 4096;
 constexpr int kMaxBins = 256;
 
+// The bin of every row from its allele frequency, on the device: the P7FrequencyFilter pair of CalcFWS
+// (kga_analysis_PfEMP_FWS.cpp:15-38; kgl_variant_filter_Pf7.cpp:20-66: accepted iff AF >= cutoff) -- a row is in bin b
+// iff it passes the lower filter, af >= edges[b], and fails the upper one, !(af >= edges[b + 1]); the comparisons are
+// the reference's, in double.  NaN = no AF value: it passes both filters, so NOT(upper) puts it in no bin.
+__global__ void __launch_bounds__(kBlock)
+k_af_bins(const float* __restrict__ af, uint64_t n_rows, const double* __restrict__ edges, uint32_t n_bins, uint8_t* __restrict__ bin_of_row) {
+  for (uint64_t v = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x; v < n_rows; v += static_cast<uint64_t>(gridDim.x) * blockDim.x) {
+    const float f = af[v];
+    uint8_t bin = 0xFF;
+    if (f == f) {
+      const double a = static_cast<double>(f);
+      for (uint32_t b = 0; b < n_bins; ++b)
+        if (a >= edges[b] && !(a >= edges[b + 1])) { bin = static_cast<uint8_t>(b); break; }
+    }
+    bin_of_row[v] = bin;
+  }
+}
+
 __global__ void __launch_bounds__(kBlock)
 k_bin_count(const uint8_t* __restrict__ bin_of_row, uint64_t n_rows, uint32_t n_bins, uint32_t* __restrict__ chunk_counts) {
   __shared__ uint32_t cnt[kMaxBins];

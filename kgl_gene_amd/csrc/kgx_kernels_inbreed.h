@@ -363,7 +363,7 @@ k_inbreed_eval_lut(const uint32_t* __restrict__ gt, uint64_t dwords_per_row, uin
                    const uint32_t* __restrict__ locus_index, uint64_t n_sel, uint64_t loci_per_seg,
                    const void* __restrict__ entries_in, const double* __restrict__ table, const uint8_t* __restrict__ valid,
                    uint32_t amax, const double* __restrict__ f_in, double* __restrict__ part,
-                   unsigned long long* __restrict__ counts) {
+                   unsigned long long* __restrict__ counts, unsigned long long* __restrict__ seg_counts) {
   constexpr int DW = GPL / 4;
   constexpr bool kCounts = MODE == 3 || MODE == 4;           // the one-pass frequency sweeps: packed class counters, odd cells
   // MODE 4 is MODE 3 without the Ritland term: 8-byte entries (the packed words), half the LDS traffic.
@@ -631,17 +631,36 @@ k_inbreed_eval_lut(const uint32_t* __restrict__ gt, uint64_t dwords_per_row, uin
     } else {
       // slot 4: the Ritland sum (MODE 4: none -- the slot held the segment's default, which is RitlandLocus' alone)
       part[(seg * n_genomes + g) * kParts0 + 4] = MODE == 3 ? run_a[MODE == 4 ? 0 : j] : 0.0;
-      const unsigned long long major_hom = cnt_lo[j] & 0xFFFu, major_het = (cnt_lo[j] >> 12) & 0xFFFu;
-      const unsigned long long minor_hom = cnt_hi[j] & 0xFFFu, minor_het = (cnt_hi[j] >> 12) & 0xFFFu;
-      const unsigned long long total = major_hom + major_het + minor_hom + minor_het;
-      unsigned long long* c = counts + g * 6;
-      if (major_hom) atomicAdd(c + 0, major_hom);
-      if (major_het) atomicAdd(c + 1, major_het);
-      if (minor_hom) atomicAdd(c + 2, minor_hom);
-      if (minor_het) atomicAdd(c + 3, minor_het);
-      if (total) { atomicAdd(c + 4, total); atomicAdd(c + 5, total); }      // Ritland counts every classified cell but the few taken off above
+      // The segment's class counters leave as ONE packed word per (segment, genome) -- a lane's eight are 64 contiguous
+      // bytes -- and k_reduce_class_counts adds them up (six 8-byte atomics per (segment, genome) were 5 % of the sweep's
+      // HBM traffic, each a line of its own).  Ritland counts every classified cell but the few taken off above.
+      seg_counts[seg * n_genomes + g] = (static_cast<unsigned long long>(cnt_hi[j] & 0xFFFFFFu) << 32) | (cnt_lo[j] & 0xFFFFFFu);
     }
   }
+}
+
+// counts[g][0..5] += the class counters the frequency table pass (k_inbreed_eval_lut<3|4>) left per (segment, genome):
+// majorHom | majorHet << 12 in the low word, minorHom | minorHet << 12 in the high word; total and Ritland count = their sum.
+// blockIdx.y strides the segments.
+__global__ void __launch_bounds__(kBlock)
+k_reduce_class_counts(const unsigned long long* __restrict__ seg_counts, uint64_t n_seg, uint64_t n_genomes,
+                      unsigned long long* __restrict__ counts) {
+  const uint64_t g = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (g >= n_genomes) return;
+  unsigned long long major_hom = 0, major_het = 0, minor_hom = 0, minor_het = 0;
+  for (uint64_t seg = blockIdx.y; seg < n_seg; seg += gridDim.y) {
+    const unsigned long long packed = seg_counts[seg * n_genomes + g];
+    const uint32_t lo = static_cast<uint32_t>(packed), hi = static_cast<uint32_t>(packed >> 32);
+    major_hom += lo & 0xFFFu; major_het += (lo >> 12) & 0xFFFu;
+    minor_hom += hi & 0xFFFu; minor_het += (hi >> 12) & 0xFFFu;
+  }
+  const unsigned long long total = major_hom + major_het + minor_hom + minor_het;
+  unsigned long long* c = counts + g * 6;
+  if (major_hom) atomicAdd(c + 0, major_hom);
+  if (major_het) atomicAdd(c + 1, major_het);
+  if (minor_hom) atomicAdd(c + 2, minor_hom);
+  if (minor_het) atomicAdd(c + 3, minor_het);
+  if (total) { atomicAdd(c + 4, total); atomicAdd(c + 5, total); }
 }
 
 // Per-segment totals of what a genome that is reference-homozygous at EVERY locus of the segment would collect:
