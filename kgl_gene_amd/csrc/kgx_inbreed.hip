@@ -225,6 +225,15 @@ int inbreed_shard(kgx_gt8_shard& sh, uint64_t g0, uint64_t g1, const uint32_t* l
   }
   // the table passes fold bit 7 of a byte onto bit 3 only where an index 8..14, or 7 as a real one, can occur
   const bool eval_fold = guard || amax > 6;
+  // The table passes' 1-D grid.  KGX_K5_XCDS=8 deals the segments over the XCDs so that the genome chunks of a segment
+  // share an L2 (see the kernel).  Measured at C5: the frequency sweep the same to 1 %, HallME / Loglikelihood passes 4 %
+  // SLOWER than the plain order (the re-read entries come out of the memory-side cache either way, and the plain order
+  // keeps the eight XCDs on one stretch of the matrix) -- so the plain order (1) is the default.
+  const uint32_t eval_xcds = static_cast<uint32_t>(std::max(1, env_int("KGX_K5_XCDS", 1)));
+  auto eval_grid = [&](uint64_t genomes, uint64_t per_lane, uint64_t segments) {
+    const uint64_t chunks = ((genomes + per_lane - 1) / per_lane + kBlock - 1) / kBlock;
+    return static_cast<uint32_t>(chunks * ((segments + eval_xcds - 1) / eval_xcds) * eval_xcds);
+  };
   auto tabulate = [&](int mode) {
     if (!table_passes) return;
     const uint32_t tab_grid = stream_grid(dev, n_sel << (2u * eval_bits(amax)), kBlock);
@@ -281,10 +290,9 @@ int inbreed_shard(kgx_gt8_shard& sh, uint64_t g0, uint64_t g1, const uint32_t* l
       // the frequency sweeps (modes 3, 4) over their own segments, the estimator passes over theirs
       const uint64_t launch_n_seg = mode >= 3 ? n_seg : eval_n_seg, launch_per_seg = mode >= 3 ? per_seg : eval_per_seg;
 #define KGX_EVAL(M, W, FOLD)                                                                                                         \
-  hipLaunchKernelGGL((k_inbreed_eval_lut<M, W, FOLD>),                                                                               \
-                     dim3(static_cast<uint32_t>(((n + W - 1) / W + kBlock - 1) / kBlock), static_cast<uint32_t>(launch_n_seg)),      \
+  hipLaunchKernelGGL((k_inbreed_eval_lut<M, W, FOLD>), dim3(eval_grid(n, W, launch_n_seg)),                                         \
                      dim3(kBlock), 0, st, gt32, dwords_per_row, g0, n, d_index, n_sel,                                               \
-                     launch_per_seg, d_entries, d_table, d_valid, amax, d_f, d_part, d_counts, d_segcnt)
+                     launch_per_seg, d_entries, d_table, d_valid, amax, d_f, d_part, d_counts, d_segcnt, eval_xcds)
 #define KGX_EVAL_FOLD(M, W)                                                \
   do {                                                                     \
     if (eval_fold) KGX_EVAL(M, W, true); else KGX_EVAL(M, W, false);       \
@@ -395,10 +403,9 @@ int inbreed_shard(kgx_gt8_shard& sh, uint64_t g0, uint64_t g1, const uint32_t* l
         auto evaluate = [&]() {
           if (act_gt == gt32) { sweep(2); return; }
 #define KGX_EVAL2(FOLD)                                                                                                              \
-  hipLaunchKernelGGL((k_inbreed_eval_lut<2, 8, FOLD>),                                                                               \
-                     dim3(static_cast<uint32_t>(((n_act + 7) / 8 + kBlock - 1) / kBlock), static_cast<uint32_t>(eval_n_seg)),        \
+  hipLaunchKernelGGL((k_inbreed_eval_lut<2, 8, FOLD>), dim3(eval_grid(n_act, 8, eval_n_seg)),                                       \
                      dim3(kBlock), 0, st, act_gt, act_dwords_per_row, act_g0, n_act, act_index,                                      \
-                     n_sel, eval_per_seg, d_entries, d_table, d_valid, amax, act_f, d_part, d_counts, d_segcnt)
+                     n_sel, eval_per_seg, d_entries, d_table, d_valid, amax, act_f, d_part, d_counts, d_segcnt, eval_xcds)
           if (eval_fold) KGX_EVAL2(true); else KGX_EVAL2(false);
 #undef KGX_EVAL2
         };

@@ -363,7 +363,7 @@ k_inbreed_eval_lut(const uint32_t* __restrict__ gt, uint64_t dwords_per_row, uin
                    const uint32_t* __restrict__ locus_index, uint64_t n_sel, uint64_t loci_per_seg,
                    const void* __restrict__ entries_in, const double* __restrict__ table, const uint8_t* __restrict__ valid,
                    uint32_t amax, const double* __restrict__ f_in, double* __restrict__ part,
-                   unsigned long long* __restrict__ counts, unsigned long long* __restrict__ seg_counts) {
+                   unsigned long long* __restrict__ counts, unsigned long long* __restrict__ seg_counts, uint32_t xcds) {
   constexpr int DW = GPL / 4;
   constexpr bool kCounts = MODE == 3 || MODE == 4;           // the one-pass frequency sweeps: packed class counters, odd cells
   // MODE 4 is MODE 3 without the Ritland term: 8-byte entries (the packed words), half the LDS traffic.
@@ -379,9 +379,20 @@ k_inbreed_eval_lut(const uint32_t* __restrict__ gt, uint64_t dwords_per_row, uin
     if constexpr (MODE == 4) return e;
     else return __builtin_bit_cast(uint64_t, e.d);
   };
-  const uint64_t lane = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x;   // genomes g0 + GPL*lane ..
+  // Workgroup -> (genome chunk, segment); with xcds > 1, XCD-aware.  The genome chunks of one segment read the same entries (and, in
+  // MODE 3, the same per-locus rows on odd cells); the hardware deals consecutive workgroup ids round-robin over the
+  // XCDs, each with its own L2, so with the plain id every chunk of a segment would fetch them again from memory.
+  // Workgroup b = (round * n_chunks + chunk) * xcds + x works on segment round * xcds + x: XCD x takes every xcds-th
+  // segment with all its chunks (consecutive in its own queue, so they run together and share its L2), and the XCDs
+  // together still sweep neighbouring segments of the matrix at any time.  (1-D grid of xcds * n_chunks * ceil(n_seg /
+  // xcds) workgroups; in the last round some have no segment.)
+  const uint64_t n_chunks = ((n_genomes + GPL - 1) / GPL + kBlock - 1) / kBlock;
+  const uint64_t n_seg = (n_sel + loci_per_seg - 1) / loci_per_seg;
+  const uint64_t turn = blockIdx.x / xcds;
+  const uint64_t seg = (turn / n_chunks) * xcds + blockIdx.x % xcds;
+  if (seg >= n_seg) return;
+  const uint64_t lane = (turn % n_chunks) * blockDim.x + threadIdx.x;                    // genomes g0 + GPL*lane ..
   const bool active = lane * GPL < n_genomes;
-  const uint64_t seg = blockIdx.y;
   const uint64_t s_begin = seg * loci_per_seg;
   const uint64_t s_end = s_begin + loci_per_seg < n_sel ? s_begin + loci_per_seg : n_sel;
   const uint32_t stride = sweep_stride(amax);
