@@ -262,10 +262,10 @@ k_inbreed_sweep(const uint32_t* __restrict__ gt, uint64_t dwords_per_row, uint64
 // ((a1 + 4*a2) mod 16); at slot a1 + 16*a2 every a2 shared a1's banks (SQ_LDS_BANK_CONFLICT: 2.7 extra cycles a read).
 // GPL genomes per lane (4 or 8: one dword / dwordx2 load per locus).
 #ifndef KGX_EVAL_DEPTH
-#define KGX_EVAL_DEPTH 1            // table reads in flight ahead of the arithmetic, in groups of four (modes 1, 2)
+#define KGX_EVAL_DEPTH 1            // table reads in flight ahead of the arithmetic, in groups of four (mode 2: 16-byte entries, 40 registers of state)
 #endif
 #ifndef KGX_EVAL_DEPTH3
-#define KGX_EVAL_DEPTH3 2           // ... mode 3, which has the registers for it
+#define KGX_EVAL_DEPTH3 2           // ... modes 1, 3, 4, which have the registers for it
 #endif
 struct alignas(16) EvalEntry { double y, d; };
 constexpr int kEvalBatch = 8;
@@ -333,6 +333,8 @@ k_eval_entries(const double* __restrict__ table, const uint8_t* __restrict__ val
     }
     if constexpr (MODE == 4) {
       static_cast<uint64_t*>(entries_out)[idx] = __builtin_bit_cast(uint64_t, d);      // the packed words alone
+    } else if constexpr (MODE == 1) {
+      static_cast<double*>(entries_out)[idx] = y;                                     // d = 1 - y for every entry: y alone
     } else {
       EvalEntry* entries = static_cast<EvalEntry*>(entries_out);
       entries[idx].y = y;
@@ -366,17 +368,22 @@ k_inbreed_eval_lut(const uint32_t* __restrict__ gt, uint64_t dwords_per_row, uin
                    unsigned long long* __restrict__ counts, unsigned long long* __restrict__ seg_counts, uint32_t xcds) {
   constexpr int DW = GPL / 4;
   constexpr bool kCounts = MODE == 3 || MODE == 4;           // the one-pass frequency sweeps: packed class counters, odd cells
-  // MODE 4 is MODE 3 without the Ritland term: 8-byte entries (the packed words), half the LDS traffic.
-  using Entry = std::conditional_t<MODE == 4, uint64_t, EvalEntry>;
+  // MODE 4 is MODE 3 without the Ritland term: 8-byte entries (the packed words), half the LDS traffic.  MODE 1 as well:
+  // its d is 1 - y for every entry (homozygous: y = f1; anything else: y = 1), so the entry is y and the cell's
+  // denominator F + (1-F)*y is ONE fma of the genome's F and 1-F -- one rounding closer to the reference's
+  // F + ((1.0 - F) * f) (_calc.cpp:270) than y + F*(1-y) was.
+  using Entry = std::conditional_t<MODE == 4, uint64_t, std::conditional_t<MODE == 1, double, EvalEntry>>;
   const Entry* __restrict__ entries = static_cast<const Entry*>(entries_in);
   __shared__ Entry lut[2][kEvalBatch * kEvalSlots];
   constexpr uint64_t kOutside = (static_cast<uint64_t>(kOddCell) << 32) | kOddOutside;
   auto nothing = []() {                                      // the entry of a locus past the segment, whatever the byte
     if constexpr (MODE == 4) return static_cast<uint64_t>(0);
+    else if constexpr (MODE == 1) return 1.0;
     else return EvalEntry{MODE == 3 ? 0.0 : 1.0, 0.0};
   };
   auto packed_of = [](const Entry& e) {
     if constexpr (MODE == 4) return e;
+    else if constexpr (MODE == 1) return static_cast<uint64_t>(0);
     else return __builtin_bit_cast(uint64_t, e.d);
   };
   // Workgroup -> (genome chunk, segment); with xcds > 1, XCD-aware.  The genome chunks of one segment read the same entries (and, in
@@ -400,7 +407,7 @@ k_inbreed_eval_lut(const uint32_t* __restrict__ gt, uint64_t dwords_per_row, uin
   const uint32_t bits = eval_bits(amax), mask = (1u << bits) - 1u;
   const uint32_t in_batch = static_cast<uint32_t>(kEvalBatch) << (2u * bits);              // 32, 128 or 512 entries
 
-  double F[kCounts ? 1 : GPL], run_a[MODE == 4 ? 1 : GPL], run_b[MODE == 1 ? GPL : 1];
+  double F[kCounts ? 1 : GPL], one_minus_F[MODE == 1 ? GPL : 1], run_a[MODE == 4 ? 1 : GPL], run_b[MODE == 1 ? GPL : 1];
   int expo[MODE == 2 ? GPL : 1];   // MODE 2: run_a = product;  MODE 1: run_a / run_b = N / D;  MODE 3: run_a = Ritland sum
   uint32_t cnt_lo[kCounts ? GPL : 1], cnt_hi[kCounts ? GPL : 1];   // MODE 3, 4: packed class counters (see above)
 #pragma unroll
@@ -411,6 +418,7 @@ k_inbreed_eval_lut(const uint32_t* __restrict__ gt, uint64_t dwords_per_row, uin
     if constexpr (MODE == 1) {
       run_b[j] = 1.0;
       if (!(F[j] > 0.0)) F[j] = 1.0;                        // see above: v = 1 everywhere, k_hall_update multiplies by the real F
+      one_minus_F[j] = 1.0 - F[j];
     } else if constexpr (MODE == 2) {
       expo[j] = 0;
     } else {
@@ -421,6 +429,7 @@ k_inbreed_eval_lut(const uint32_t* __restrict__ gt, uint64_t dwords_per_row, uin
   // Every slot starts "unclassified"; the batches refill the (1 << bits)^2 slots their entries have.
   for (uint32_t e = threadIdx.x; e < 2u * kEvalBatch * kEvalSlots; e += kBlock) {
     if constexpr (MODE == 4) lut[0][e] = kOutside;
+    else if constexpr (MODE == 1) lut[0][e] = 1.0;
     else lut[0][e] = EvalEntry{MODE == 3 ? 0.0 : 1.0, MODE == 3 ? __builtin_bit_cast(double, kOutside) : 0.0};
   }
   // Positions within the segment are 32-bit (the scalar unit compares those; 64-bit ones go through the vector unit).
@@ -484,7 +493,7 @@ k_inbreed_eval_lut(const uint32_t* __restrict__ gt, uint64_t dwords_per_row, uin
     const uint32_t xf = FOLD ? ((x & 0x7F7F7F7Fu) | ((x >> 4) & 0x08080808u)) : (x & 0x7F7F7F7Fu);
     return xf + ((FOLD ? xf >> 2 : x >> 2) & 0x1C1C1C1Cu);               // a1 + 16*a2 + 4*a2 per byte, < 156: no carry
   };
-  uint32_t four = MODE == 4 ? 3u : 4u;                        // log2 of the entry size
+  uint32_t four = sizeof(Entry) == 8 ? 3u : 4u;               // log2 of the entry size
   asm volatile("" : "+v"(four));                              // the SDWA shift takes its count from a register
 
   // One batch: the table lut[BUF] holds its entries, w its cells.  Meanwhile the next batch's entries go from the
@@ -505,7 +514,7 @@ k_inbreed_eval_lut(const uint32_t* __restrict__ gt, uint64_t dwords_per_row, uin
       // arithmetic: the reads' latency passes under that of the groups before it, and the registers stay those of
       // kEvalDepth + 1 groups -- left alone the compiler either waits for every read where it issues it or (machine
       // sinking: nothing in this block reads the sums) carries all 64 reads of the batch past the batch.
-      constexpr int kGroups = kEvalBatch * DW, kDepth = kCounts ? KGX_EVAL_DEPTH3 : KGX_EVAL_DEPTH;
+      constexpr int kGroups = kEvalBatch * DW, kDepth = (kCounts || sizeof(Entry) == 8) ? KGX_EVAL_DEPTH3 : KGX_EVAL_DEPTH;
       auto read_group = [&](int q, Entry (&e)[4]) {
         const uint32_t slots = slots_of(w[q / DW][q % DW]);
         e[0] = entry_at(q / DW, byte_shifted<0>(slots, four));
@@ -549,8 +558,8 @@ k_inbreed_eval_lut(const uint32_t* __restrict__ gt, uint64_t dwords_per_row, uin
           cnt_hi[j] += static_cast<uint32_t>(packed >> 32);
         });
       } else {
-        walk([&](int j, const EvalEntry& e) {
-          const double v = __builtin_fma(F[kCounts ? 0 : j], e.d, e.y);
+        walk([&](int j, const Entry& y) {
+          const double v = __builtin_fma(one_minus_F[MODE == 1 ? j : 0], y, F[kCounts ? 0 : j]);
           run_a[j] = __builtin_fma(run_a[j], v, run_b[j]);
           run_b[j] *= v;
         });
