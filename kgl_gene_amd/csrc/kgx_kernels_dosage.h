@@ -158,8 +158,8 @@ struct GenomeWork {
   uint32_t bin;         // output bin
 };
 
-constexpr int kHiPlanes = 8;                 // weights 8 .. 1024
-constexpr int kBlocksPerFlush = 255;         // 255*8 + 7 < 8 * 2^kHiPlanes
+constexpr int kHiPlanes = 8;                 // weights 16 .. 2048
+constexpr int kBlocksPerFlush = 510;         // blocks of 8 rows: 510*8 + 15 < 16 * 2^kHiPlanes
 constexpr int kLdsStride = 64;               // lanes per counter row in LDS
 
 __device__ __forceinline__ void csa(uint32_t& carry, uint32_t& sum, uint32_t a, uint32_t b, uint32_t c) {
@@ -170,17 +170,18 @@ __device__ __forceinline__ void csa(uint32_t& carry, uint32_t& sum, uint32_t a, 
 
 template <int NW>
 struct SlicedCounters {
-  uint32_t ones[NW], twos[NW], fours[NW], hi[NW][kHiPlanes];
+  // bit planes of weight 1, 2, 4, 8 and 16 << p; pending = the weight-8 carry of an odd block, waiting for its partner
+  uint32_t ones[NW], twos[NW], fours[NW], eights[NW], hi[NW][kHiPlanes], pending[NW];
   __device__ __forceinline__ void clear() {
 #pragma unroll
     for (int i = 0; i < NW; ++i) {
-      ones[i] = twos[i] = fours[i] = 0;
+      ones[i] = twos[i] = fours[i] = eights[i] = pending[i] = 0;
 #pragma unroll
       for (int p = 0; p < kHiPlanes; ++p) hi[i][p] = 0;
     }
   }
-  // Fold 8 input words of stream-word i.
-  __device__ __forceinline__ void add8(int i, const uint32_t x[8]) {
+  // Fold 8 input words of stream-word i; returns the carry of weight 8.
+  __device__ __forceinline__ uint32_t add8(int i, const uint32_t x[8]) {
     uint32_t t2a, t2b, f4a, f4b, e8;
     csa(t2a, ones[i], ones[i], x[0], x[1]);
     csa(t2b, ones[i], ones[i], x[2], x[3]);
@@ -189,18 +190,25 @@ struct SlicedCounters {
     csa(t2b, ones[i], ones[i], x[6], x[7]);
     csa(f4b, twos[i], twos[i], t2a, t2b);
     csa(e8, fours[i], fours[i], f4a, f4b);
+    return e8;
+  }
+  // Two weight-8 carries (of two blocks of 8 rows) into the weight-8 plane; its carry ripples through the planes above --
+  // once per 16 rows instead of once per 8.
+  __device__ __forceinline__ void add_eights(int i, uint32_t a, uint32_t b) {
+    uint32_t c16;
+    csa(c16, eights[i], eights[i], a, b);
 #pragma unroll
     for (int p = 0; p < kHiPlanes; ++p) {
-      const uint32_t t = hi[i][p] & e8;
-      hi[i][p] ^= e8;
-      e8 = t;
+      const uint32_t t = hi[i][p] & c16;
+      hi[i][p] ^= c16;
+      c16 = t;
     }
   }
   // Integer count of bit position b of stream-word i.
   __device__ __forceinline__ uint32_t value(int i, int b) const {
-    uint32_t v = ((ones[i] >> b) & 1u) | (((twos[i] >> b) & 1u) << 1) | (((fours[i] >> b) & 1u) << 2);
+    uint32_t v = ((ones[i] >> b) & 1u) | (((twos[i] >> b) & 1u) << 1) | (((fours[i] >> b) & 1u) << 2) | (((eights[i] >> b) & 1u) << 3);
 #pragma unroll
-    for (int p = 0; p < kHiPlanes; ++p) v |= ((hi[i][p] >> b) & 1u) << (3 + p);
+    for (int p = 0; p < kHiPlanes; ++p) v |= ((hi[i][p] >> b) & 1u) << (4 + p);
     return v;
   }
 };
@@ -225,6 +233,10 @@ __device__ __forceinline__ void by_genome_pass(const kgx_v4u* __restrict__ rows,
   uint32_t seen = 0;
 
   auto flush = [&]() {
+    if (blocks & 1) {                       // an odd block's carries still wait for a partner
+#pragma unroll
+      for (int i = 0; i < NW; ++i) cnt.add_eights(i, cnt.pending[i], 0u);
+    }
 #pragma unroll
     for (int i = 0; i < NW; ++i) {
 #pragma unroll
@@ -268,6 +280,7 @@ __device__ __forceinline__ void by_genome_pass(const kgx_v4u* __restrict__ rows,
         x[j] = v;
       }
     }
+    uint32_t e8[NW];
     if constexpr (MODE == 0) {
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
@@ -275,9 +288,9 @@ __device__ __forceinline__ void by_genome_pass(const kgx_v4u* __restrict__ rows,
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
           w[j] = x[j][i];
-          seen |= w[j] & (w[j] >> 1) & 0x55555555u;
+          seen |= w[j] & (w[j] >> 1);       // code 3 = both bits of a field; the odd positions are masked out at the end
         }
-        cnt.add8(i, w);
+        e8[i] = cnt.add8(i, w);
       }
     } else {
 #pragma unroll
@@ -288,13 +301,20 @@ __device__ __forceinline__ void by_genome_pass(const kgx_v4u* __restrict__ rows,
           const uint32_t d0 = x[j][2 * i], d1 = x[j][2 * i + 1];
           w[j] = (d0 & (d0 >> 1) & 0x55555555u) | ((d1 & (d1 >> 1) & 0x55555555u) << 1);
         }
-        cnt.add8(i, w);
+        e8[i] = cnt.add8(i, w);
       }
+    }
+    if (blocks & 1) {                       // (block-uniform) the second block of a pair: both carries go up together
+#pragma unroll
+      for (int i = 0; i < NW; ++i) cnt.add_eights(i, cnt.pending[i], e8[i]);
+    } else {
+#pragma unroll
+      for (int i = 0; i < NW; ++i) cnt.pending[i] = e8[i];
     }
     if (++blocks == kBlocksPerFlush) flush();
   }
   flush();
-  saw_nondiploid |= seen;
+  saw_nondiploid |= seen & 0x55555555u;
 }
 
 template <int W>

@@ -19,6 +19,15 @@ def kgx():
     from kgl_gene_amd import capi
 
     capi.ensure_built()
+    # torch (the plumbing a few tests and bench.py use for device buffers) sets its HIP context up first, once: after
+    # tens of GB of library allocations and several device rebinds its lazy initialisation has been seen to find no device
+    try:
+        import torch
+
+        if torch.cuda.is_available():
+            torch.cuda.init()
+    except ImportError:
+        pass
     capi.lib()
     if capi.device_count() <= 0:
         pytest.fail("no HIP device visible: -m gpu tests must run on the GPU box")
