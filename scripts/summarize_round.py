@@ -17,7 +17,7 @@ def one(pattern):
     files = glob.glob(str(src / pattern))
     if not files:
         sys.exit(f"missing {pattern} under {src}")
-    return Path(files[0])
+    return Path(max(files, key=lambda f: Path(f).stat().st_mtime))      # gpurun merges into what earlier calls left: the newest
 
 
 def short(name):
