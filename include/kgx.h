@@ -86,6 +86,11 @@ kgx_pop* kgx_population_create(uint64_t n_genomes, uint64_t n_variants);
 /* Shard geometry: how many shards, and for shard i its device slot, first genome and genome count. */
 uint32_t kgx_population_shards(const kgx_pop* pop);
 int kgx_population_shard_info(const kgx_pop* pop, uint32_t shard, int* slot, uint64_t* genome_base, uint64_t* n_genomes);
+/* Change the number of variant rows: the rows held so far keep their content, new rows are zero (nobody carries them),
+ * the AF column is dropped.  Growing past what is allocated re-allocates with at least half as much again, so a
+ * population filled piece by piece (rows uploaded as a VCF is read, the final count unknown until its end) is copied a
+ * bounded number of times; shrinking only lowers the count. */
+int      kgx_population_resize(kgx_pop* pop, uint64_t n_variants);
 void     kgx_population_destroy(kgx_pop* pop);
 uint64_t kgx_population_genomes(const kgx_pop* pop);
 uint64_t kgx_population_variants(const kgx_pop* pop);
@@ -179,6 +184,11 @@ double kgx_count_by_genome_last_ms(void);
  *      Offsets with one row follow from kgx_count_by_genome_binned and are not passed here. */
 int kgx_compound_offsets(kgx_pop* pop, const uint32_t* first_row, const uint32_t* n_rows, const uint32_t* bin,
                          uint64_t n_groups, uint32_t n_bins, uint64_t* out /* host [n_genomes][n_bins][3] */);
+/* The same for groups whose rows are NOT adjacent (a population whose rows are in file order rather than HGVS order):
+ * group i is the rows member_rows[first_member[i] .. first_member[i] + n_rows[i]). */
+int kgx_compound_offsets_listed(kgx_pop* pop, const uint32_t* member_rows, uint64_t n_members, const uint32_t* first_member,
+                                const uint32_t* n_rows, const uint32_t* bin, uint64_t n_groups, uint32_t n_bins,
+                                uint64_t* out /* host [n_genomes][n_bins][3] */);
 
 /* ---- K4: VariantDBVariant::populationSummary (kgl_variant_db_variant.cpp:234-279). */
 int kgx_population_summary(kgx_pop* pop, uint64_t out[4]);

@@ -81,6 +81,7 @@ _SIGNATURES = {
                               C.c_int, C.c_void_p]),
     "kgx_release_scratch": (C.c_int, []),
     "kgx_count_by_genome_af_bins": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]),
+    "kgx_population_resize": (C.c_int, [C.c_void_p, C.c_uint64]),
     "kgx_inbreed_last_sweep_ms": (C.c_double, []),
     "kgx_inbreed_last_kernel_ms": (C.c_double, []),
     "kgx_inbreed_last_evaluations": (C.c_int, []),
@@ -91,6 +92,7 @@ _SIGNATURES = {
     "kgx_synth_loci_host": (C.c_int, [C.c_uint64, C.c_uint64, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p]),
     "kgx_gt8_synth_inbred": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint64]),
     "kgx_compound_offsets": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_void_p]),
+    "kgx_compound_offsets_listed": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_void_p]),
 }
 
 
@@ -230,6 +232,11 @@ class Population:
         self.n_genomes = int(n_genomes)
         self.n_variants = int(n_variants)
 
+    def resize(self, n_variants: int) -> None:
+        """Change the row count: rows held keep their content, new rows are empty; growing re-allocates by >= 1.5 x."""
+        check(lib().kgx_population_resize(self._h, int(n_variants)))
+        self.n_variants = int(n_variants)
+
     # -- lifetime ---------------------------------------------------------------------------
     def close(self) -> None:
         if getattr(self, "_h", None):
@@ -348,6 +355,16 @@ class Population:
         bn = np.ascontiguousarray(bins, dtype=np.uint32)
         out = np.zeros((self.n_genomes, n_bins, 3), dtype=np.uint64)
         check(lib().kgx_compound_offsets(self._h, ptr(fr), ptr(nr), ptr(bn), len(fr), n_bins, ptr(out)))
+        return out
+
+    def compound_offsets_listed(self, member_rows, first_member, n_rows, bins, n_bins: int) -> np.ndarray:
+        """compound_offsets for groups whose rows are not adjacent: group i = member_rows[first_member[i] : + n_rows[i]]."""
+        mr = np.ascontiguousarray(member_rows, dtype=np.uint32)
+        fm = np.ascontiguousarray(first_member, dtype=np.uint32)
+        nr = np.ascontiguousarray(n_rows, dtype=np.uint32)
+        bn = np.ascontiguousarray(bins, dtype=np.uint32)
+        out = np.zeros((self.n_genomes, n_bins, 3), dtype=np.uint64)
+        check(lib().kgx_compound_offsets_listed(self._h, ptr(mr), len(mr), ptr(fm), ptr(nr), ptr(bn), len(fm), n_bins, ptr(out)))
         return out
 
     def population_summary(self) -> np.ndarray:

@@ -52,6 +52,40 @@ std::string joinPath(const std::string& dir, const std::string& stem) {
 
 }  // namespace
 
+// ... and the streaming flatteners' rows while the file is still being read (kgx_flatten.h: StreamSink): the population
+// grows on the device as pieces arrive (kgx_population_resize re-allocates by half as much again when it must), a row
+// that a later record adds copies to is read back, merged on the host and written again.
+struct DeviceStreamSink final : kgl::analysis::gpu::StreamSink {
+  DevicePopulation& dev;
+  uint64_t row_bytes{0}, rows{0};
+  std::string error;
+  explicit DeviceStreamSink(DevicePopulation& d) : dev(d) {}
+  bool fail(const char* what) { error = std::string(what) + ": " + kgx_last_error(); return false; }
+  bool open(uint64_t n_genomes, uint64_t bytes_per_row) override {
+    row_bytes = bytes_per_row;
+    if (n_genomes == 0) return true;
+    dev.handle = kgx_population_create(n_genomes, 0);
+    return dev.handle ? true : fail("kgx_population_create failed");
+  }
+  bool write(uint64_t first_row, uint64_t n_rows, const uint8_t* data) override {
+    if (!dev.handle) return n_rows == 0;
+    if (first_row + n_rows > rows) {
+      rows = first_row + n_rows;
+      if (kgx_population_resize(dev.handle, rows) != KGX_OK) return fail("growing the device population failed");
+    }
+    return kgx_population_load_dosage2(dev.handle, data, row_bytes, first_row, first_row + n_rows) == KGX_OK ? true : fail("upload failed");
+  }
+  bool read(uint64_t row, uint8_t* data) override {
+    if (!dev.handle || row >= rows) return false;
+    return kgx_population_read_dosage2(dev.handle, data, row_bytes, row, row + 1) == KGX_OK ? true : fail("reading a row back failed");
+  }
+  bool close(uint64_t n_rows) override {
+    if (!dev.handle) return n_rows == 0;
+    rows = n_rows;
+    return kgx_population_resize(dev.handle, n_rows) == KGX_OK ? true : fail("setting the final row count failed");
+  }
+};
+
 bool kga::GpuAlleleAnalysis::initializeAnalysis(const std::string& work_directory, const ActiveParameterList& named_parameters,
                                                 const std::shared_ptr<const AnalysisResources>&) {
   ExecEnv::log().info("Analysis Id: {} initialized with work directory: {}", ident(), work_directory);
@@ -118,18 +152,37 @@ bool kga::GpuAlleleAnalysis::sweepVcfFile(const std::string& file_name) {
     ExecEnv::log().error("GpuAlleleAnalysis; unknown VcfFlavour: {} (Genome1000 or Falciparum)", vcf_flavour_);
     return false;
   }
-  // ... and the packed rows go to the device block by block as the flattener finishes them: flat.packed stays empty
+  // First the streaming flattener: every piece's rows go to the device while the next piece is read, the host never
+  // holds more than a piece.  A file it cannot take (a sample named twice, a sample without any variant) goes through the
+  // two-phase flattener instead, whose packed rows leave block by block once every row's place is known.
   DevicePopulation dev;
-  DeviceRowSink sink(dev);
-  const bool read_ok = vcf_flavour_ == "Genome1000" ? gpu::flattenVcf1000File(file_name, flat, io_error, 0, size_t{64} << 20, &sink)
-                                                    : gpu::flattenVcfPfFile(file_name, flat, io_error, 0, pf7_quality_filter_, size_t{64} << 20, &sink);
-  if (!read_ok) {
-    ExecEnv::log().error("GpuAlleleAnalysis; {}", io_error);
-    return false;
+  bool two_phase = false;
+  {
+    DeviceStreamSink stream(dev);
+    const bool streamed = vcf_flavour_ == "Genome1000"
+                              ? gpu::flattenVcf1000FileStreaming(file_name, stream, flat, io_error, two_phase)
+                              : gpu::flattenVcfPfFileStreaming(file_name, stream, flat, io_error, two_phase, 0, pf7_quality_filter_);
+    if (!streamed && !two_phase) {
+      ExecEnv::log().error("GpuAlleleAnalysis; {}{}", io_error, stream.error.empty() ? std::string() : " (" + stream.error + ")");
+      return false;
+    }
   }
-  if (!sink.error.empty()) {
-    ExecEnv::log().error("GpuAlleleAnalysis; {}", sink.error);
-    return false;
+  if (two_phase) {
+    ExecEnv::log().warn("GpuAlleleAnalysis; {}: flattened in two phases ({})", file_name, io_error);
+    if (dev.handle) { kgx_population_destroy(dev.handle); dev.handle = nullptr; }
+    io_error.clear();
+    flat = gpu::FlatPopulation{};
+    DeviceRowSink sink(dev);
+    const bool read_ok = vcf_flavour_ == "Genome1000" ? gpu::flattenVcf1000File(file_name, flat, io_error, 0, size_t{64} << 20, &sink)
+                                                      : gpu::flattenVcfPfFile(file_name, flat, io_error, 0, pf7_quality_filter_, size_t{64} << 20, &sink);
+    if (!read_ok) {
+      ExecEnv::log().error("GpuAlleleAnalysis; {}", io_error);
+      return false;
+    }
+    if (!sink.error.empty()) {
+      ExecEnv::log().error("GpuAlleleAnalysis; {}", sink.error);
+      return false;
+    }
   }
   if (vcf_flavour_ == "Genome1000") return sweepFlat(flat, file_name, dev.handle);
   // every genome holds every contig of the header, carrier or not (PfVCFImpl::setupPopulationStructure): zero records
@@ -226,19 +279,20 @@ bool kga::GpuAlleleAnalysis::sweepFlat(const gpu::FlatPopulation& flat, const st
     uint32_t n_contigs = 0;
     std::vector<ContigId_t> contig_ids;
     for (auto& [contig_id, index] : contig_index) { index = n_contigs++; contig_ids.push_back(contig_id); }
-    // Offsets holding >= 2 distinct variants are adjacent rows (same "contig:g.offset" prefix in HGVS order).
-    std::vector<uint32_t> first_row, n_rows, group_bin;
+    // Offsets holding >= 2 distinct variants, as lists of their rows: adjacent in a population flattened in HGVS order,
+    // anywhere in one streamed in file order (the Pf flavour's canonical variants need not start where their record does).
+    std::vector<uint32_t> member_rows, first_member, n_rows, group_bin;
     std::vector<uint8_t> compound(V, 0);
-    for (uint64_t v = 0; v < V;) {
-      uint64_t e = v + 1;
-      while (e < V && flat.rows[e].offset == flat.rows[v].offset && flat.rows[e].contig == flat.rows[v].contig) ++e;
-      if (e - v >= 2) {
-        first_row.push_back(static_cast<uint32_t>(v));
-        n_rows.push_back(static_cast<uint32_t>(e - v));
-        group_bin.push_back(contig_index.at(flat.rows[v].contig));
-        for (uint64_t r = v; r < e; ++r) compound[r] = 1;
+    {
+      std::map<std::pair<uint32_t, uint64_t>, std::vector<uint32_t>> rows_of_offset;
+      for (uint64_t v = 0; v < V; ++v) rows_of_offset[{contig_index.at(flat.rows[v].contig), flat.rows[v].offset}].push_back(static_cast<uint32_t>(v));
+      for (const auto& [key, rows] : rows_of_offset) {
+        if (rows.size() < 2) continue;
+        first_member.push_back(static_cast<uint32_t>(member_rows.size()));
+        n_rows.push_back(static_cast<uint32_t>(rows.size()));
+        group_bin.push_back(key.first);
+        for (uint32_t r : rows) { member_rows.push_back(r); compound[r] = 1; }
       }
-      v = e;
     }
     // bin = contig*4 + is_snp*2 + compound: dosage-weighted totals per class of row.  One sweep holds 254 bins, 63 contigs;
     // a population with more (an assembly with its unplaced scaffolds) is swept once per 63 of them.
@@ -268,8 +322,8 @@ bool kga::GpuAlleleAnalysis::sweepFlat(const gpu::FlatPopulation& flat, const st
           std::copy_n(&sweep_counts[g * sweep_bins * 4], static_cast<size_t>(sweep_bins) * 4, &by_genome[(g * n_bins + c0 * 4) * 4]);
     }
     std::vector<uint64_t> compound_counts(G * n_contigs * 3);
-    if (kgx_compound_offsets(dev.handle, first_row.data(), n_rows.data(), group_bin.data(), first_row.size(), n_contigs,
-                             compound_counts.data()) != KGX_OK) {
+    if (kgx_compound_offsets_listed(dev.handle, member_rows.data(), member_rows.size(), first_member.data(), n_rows.data(), group_bin.data(),
+                                    first_member.size(), n_contigs, compound_counts.data()) != KGX_OK) {
       ExecEnv::log().error("GpuAlleleAnalysis; compound offset sweep failed: {}", kgx_last_error());
       return false;
     }

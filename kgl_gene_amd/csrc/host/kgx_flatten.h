@@ -70,6 +70,21 @@ class RowSink {
   virtual void rows(uint64_t first_row, uint64_t n_rows, const uint8_t* data) = 0;      // n_rows * meta.row_bytes bytes
 };
 
+// Streaming: rows leave for the sink piece by piece WHILE the file is read, so the host holds one piece of parsed records
+// at a time instead of all of them.  The rows are then in the order the variants first appear in the file (not HGVS
+// order: nothing on the path reads it -- the CSV writers key by HGVS, the compound-offset sweep takes its groups as row
+// lists), their number is known at the end only (the sink grows), and a variant met again in a later
+// record is merged into its row at the end (the row is read back: exact, a single record puts at most two copies into a
+// cell).  Not every file can be taken this way -- see flattenVcf1000FileStreaming.
+class StreamSink {
+ public:
+  virtual ~StreamSink() = default;
+  virtual bool open(uint64_t n_genomes, uint64_t row_bytes) = 0;
+  virtual bool write(uint64_t first_row, uint64_t n_rows, const uint8_t* data) = 0;      // may extend the population
+  virtual bool read(uint64_t row, uint8_t* data) = 0;                                     // one row written earlier
+  virtual bool close(uint64_t n_rows) = 0;                                                // the final row count
+};
+
 // threads == 0: the reference's default, hardware_concurrency() - 1 (kel_thread/kel_workflow_threads.h:40).
 [[nodiscard]] FlatPopulation flattenPopulation(const PopulationDB& population, size_t threads = 0);
 
@@ -92,6 +107,15 @@ class RowSink {
                                       size_t chunk_bytes = size_t{64} << 20, RowSink* sink = nullptr);
 [[nodiscard]] bool flattenVcfPfFile(const std::string& file_name, FlatPopulation& flat, std::string& error, size_t threads = 0,
                                     bool quality_filter = false, size_t chunk_bytes = size_t{64} << 20, RowSink* sink = nullptr);
+
+// The streaming forms (StreamSink above).  flat comes back without `packed`, rows in first-appearance order.  Returns false
+// with `error` on an I/O, format or sink error -- and false with `two_phase` set (no error) for a file that has to go through
+// the two-phase flatteners above instead: a sample named twice, or a sample that carries no variant at all (Genome1000
+// flavour: it is then no genome, which changes every row's width).
+[[nodiscard]] bool flattenVcf1000FileStreaming(const std::string& file_name, StreamSink& sink, FlatPopulation& flat, std::string& error, bool& two_phase,
+                                               size_t threads = 0, size_t chunk_bytes = size_t{64} << 20);
+[[nodiscard]] bool flattenVcfPfFileStreaming(const std::string& file_name, StreamSink& sink, FlatPopulation& flat, std::string& error, bool& two_phase,
+                                             size_t threads = 0, bool quality_filter = false, size_t chunk_bytes = size_t{64} << 20);
 
 // ---- the INBREED package's two inputs straight from VCF text (SURVEY.md §8f #1 for the K5 path) ------------------
 //

@@ -1,11 +1,13 @@
 // Small extern "C" window onto the host-side flatteners so that they can be tested without a GPU (ctypes).
 // Not part of the device ABI (include/kgx.h): pure host code, no HIP calls.
+#include <algorithm>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
 
 #include <chrono>
 #include <sstream>
+#include <vector>
 
 #include "kgx_flatten.h"
 #include "kgx_variant_sort.h"
@@ -41,6 +43,82 @@ void* kgxh_flatten_vcf_file(const char* path, int flavour, int threads, int qual
     delete flat;
     return nullptr;
   }
+  return flat;
+}
+
+// The streaming flatteners (rows leave for a sink piece by piece, in first-appearance order) into memory, then put into the
+// two-phase flatteners' order (primary rows by HGVS, split rows by their primary row and bin), so that the result can be
+// compared field for field with kgxh_flatten_vcf_file's.  *two_phase = 1 (and null): the file has to take the other path.
+void* kgxh_flatten_vcf_file_streaming(const char* path, int flavour, int threads, int quality_filter, uint64_t chunk_bytes, char* error, size_t error_len,
+                                      int* two_phase) {
+  if (!path) return nullptr;
+  namespace g = kellerberrin::genome::analysis::gpu;
+  struct MemorySink final : g::StreamSink {
+    std::vector<uint8_t> packed;
+    uint64_t row_bytes{0}, rows{0};
+    bool open(uint64_t, uint64_t rb) override { row_bytes = rb; return true; }
+    bool write(uint64_t first_row, uint64_t n_rows, const uint8_t* data) override {
+      if ((first_row + n_rows) * row_bytes > packed.size()) packed.resize((first_row + n_rows) * row_bytes, 0);
+      if (n_rows * row_bytes) std::memcpy(&packed[first_row * row_bytes], data, n_rows * row_bytes);
+      return true;
+    }
+    bool read(uint64_t row, uint8_t* data) override {
+      if ((row + 1) * row_bytes > packed.size()) return false;
+      std::memcpy(data, &packed[row * row_bytes], row_bytes);
+      return true;
+    }
+    bool close(uint64_t n_rows) override { rows = n_rows; packed.resize(n_rows * row_bytes, 0); return true; }
+  } sink;
+  auto* flat = new FlatPopulation();
+  std::string err;
+  bool other_path = false;
+  const size_t piece = chunk_bytes ? static_cast<size_t>(chunk_bytes) : (size_t{64} << 20);
+  const bool ok = flavour == 0 ? g::flattenVcf1000FileStreaming(path, sink, *flat, err, other_path, threads > 0 ? threads : 0, piece)
+                               : g::flattenVcfPfFileStreaming(path, sink, *flat, err, other_path, threads > 0 ? threads : 0, quality_filter != 0, piece);
+  if (two_phase) *two_phase = other_path ? 1 : 0;
+  if (!ok) {
+    if (error && error_len) { std::strncpy(error, err.c_str(), error_len - 1); error[error_len - 1] = 0; }
+    delete flat;
+    return nullptr;
+  }
+  // canonical order
+  const size_t P = flat->primary_rows, D = flat->rows.size(), RB = flat->row_bytes;
+  std::vector<size_t> order(P);
+  for (size_t i = 0; i < P; ++i) order[i] = i;
+  std::sort(order.begin(), order.end(), [&](size_t x, size_t y) { return flat->rows[x].hgvs < flat->rows[y].hgvs; });
+  std::vector<size_t> new_of_old(P);
+  for (size_t i = 0; i < P; ++i) new_of_old[order[i]] = i;
+  std::vector<size_t> split_order;
+  for (size_t i = P; i < D; ++i) split_order.push_back(i);
+  std::stable_sort(split_order.begin(), split_order.end(), [&](size_t x, size_t y) {
+    const size_t px = new_of_old[static_cast<size_t>(flat->rows[x].split_of)], py = new_of_old[static_cast<size_t>(flat->rows[y].split_of)];
+    if (px != py) return px < py;
+    return g::fwsBinOfFrequency(flat->rows[x].info_af) < g::fwsBinOfFrequency(flat->rows[y].info_af);
+  });
+  FlatPopulation sorted;
+  sorted.genome_ids = flat->genome_ids;
+  sorted.primary_rows = P;
+  sorted.row_bytes = RB;
+  sorted.variant_objects = flat->variant_objects;
+  sorted.contig_ids = flat->contig_ids;
+  sorted.packed.resize(D * RB);
+  for (size_t i = 0; i < P; ++i) {
+    sorted.rows.push_back(flat->rows[order[i]]);
+    if (RB) std::memcpy(&sorted.packed[i * RB], &sink.packed[order[i] * RB], RB);
+  }
+  for (size_t i = 0; i < split_order.size(); ++i) {
+    sorted.rows.push_back(flat->rows[split_order[i]]);
+    sorted.rows.back().split_of = static_cast<int64_t>(new_of_old[static_cast<size_t>(flat->rows[split_order[i]].split_of)]);
+    if (RB) std::memcpy(&sorted.packed[(P + i) * RB], &sink.packed[split_order[i] * RB], RB);
+  }
+  for (auto cell : flat->non_diploid) {
+    cell.row = static_cast<uint32_t>(new_of_old[cell.row]);
+    sorted.non_diploid.push_back(cell);
+  }
+  std::sort(sorted.non_diploid.begin(), sorted.non_diploid.end(), [](const g::NonDiploidCell& x, const g::NonDiploidCell& y) {
+    return x.row != y.row ? x.row < y.row : x.genome < y.genome;
+  });
+  *flat = std::move(sorted);
   return flat;
 }
 

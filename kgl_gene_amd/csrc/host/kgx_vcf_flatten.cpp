@@ -392,6 +392,185 @@ FlatPopulation mergeRecords(const std::vector<RecordRows>& parsed, const std::ve
   return flat;
 }
 
+// The streaming counterpart of mergeRecords (kgx_flatten.h: StreamSink): consume() takes one piece's parsed records, gives
+// every variant seen for the first time the next row, packs those rows (genome order = sorted sample names) and writes
+// them out; a variant seen before is kept aside ("late") and merged into its row by finish(), exactly as mergeRecords adds
+// the copies of repeated records -- including the per-bin split rows when the records' AF fall in different FWS bins.
+class StreamMerger {
+ public:
+  StreamMerger(StreamSink& sink, bool every_sample, size_t threads) : sink_(sink), every_sample_(every_sample), threads_(threads) {}
+  bool two_phase{false};          // the file cannot be taken this way (why_ says why): not an error
+  std::string error;              // sink failure
+
+  bool consume(const std::vector<std::string>& samples, const std::vector<RecordRows>& parsed) {
+    if (!error.empty() || two_phase) return false;
+    if (!opened_) {
+      if (samples.empty()) return true;                   // no #CHROM line yet (or no sample columns at all): nothing to place
+      if (!open(samples)) return false;
+    }
+    const size_t S = column_of_sample_.size(), SB = copyRowBytes(S);
+    struct Item { uint32_t record, alt; uint64_t row; bool late; };
+    std::vector<Item> items;
+    const uint64_t first_new = meta_.size();
+    for (uint32_t r = 0; r < parsed.size(); ++r)
+      for (uint32_t a = 0; a < parsed[r].rows.size(); ++a) {
+        const uint8_t* c = &parsed[r].copies[static_cast<size_t>(a) * SB];
+        if (!std::any_of(c, c + SB, [](uint8_t x) { return x != 0; })) continue;        // a variant nobody carries never reaches the PopulationDB
+        const VariantRow& row = parsed[r].rows[a];
+        auto [found, is_new] = row_of_hgvs_.try_emplace(row.hgvs, meta_.size());
+        if (is_new) meta_.push_back(row);
+        items.push_back({r, a, found->second, !is_new});
+      }
+    const uint64_t n_new = meta_.size() - first_new;
+    std::vector<uint8_t> block(n_new * row_bytes_, 0);
+    std::vector<std::vector<uint8_t>> late_rows(items.size());
+    std::vector<size_t> objects(items.size(), 0);
+    std::vector<uint8_t> carried_here(S, 0);
+    std::mutex carried_mutex;
+    parallelChunks(items.size(), 256, threads_, [&](size_t begin, size_t end) {
+      std::vector<uint8_t> local(S, 0);
+      for (size_t k = begin; k < end; ++k) {
+        const Item& item = items[k];
+        const uint8_t* c = &parsed[item.record].copies[static_cast<size_t>(item.alt) * SB];
+        uint8_t* out;
+        if (item.late) { late_rows[k].assign(row_bytes_, 0); out = late_rows[k].data(); }
+        else out = &block[(item.row - first_new) * row_bytes_];
+        for (size_t smp = 0; smp < S; ++smp) {
+          const uint32_t d = copyAt(c, smp);
+          if (!d) continue;
+          local[smp] = 1;
+          objects[k] += d;
+          const uint32_t g = column_of_sample_[smp];
+          out[g / 4] = static_cast<uint8_t>(out[g / 4] | (d << (2 * (g % 4))));        // one sample per genome here: d <= 2, no carry
+        }
+      }
+      std::lock_guard<std::mutex> lock(carried_mutex);
+      for (size_t smp = 0; smp < S; ++smp) carried_here[smp] |= local[smp];
+    });
+    for (size_t smp = 0; smp < S; ++smp) carries_[smp] |= carried_here[smp];
+    for (size_t k = 0; k < items.size(); ++k) {
+      variant_objects_ += objects[k];
+      if (items[k].late) late_.push_back({items[k].row, parsed[items[k].record].rows[items[k].alt], std::move(late_rows[k])});
+    }
+    if (n_new && !sink_.write(first_new, n_new, block.data())) { error = "the row sink failed while taking a piece's rows"; return false; }
+    return true;
+  }
+
+  bool finish(FlatPopulation& flat) {
+    flat = FlatPopulation{};
+    if (!error.empty() || two_phase) return false;
+    if (!opened_) return sink_.open(0, 0) && sink_.close(0);            // no samples: no genomes, hence no variants
+    const size_t S = column_of_sample_.size();
+    if (!every_sample_)
+      for (size_t smp = 0; smp < S; ++smp)
+        if (!carries_[smp]) return giveUp("sample " + sample_names_[smp] + " carries no variant: it is no genome, and the rows are one column too wide");
+    flat.genome_ids = genome_ids_;
+    flat.row_bytes = row_bytes_;
+    flat.primary_rows = meta_.size();
+    // variants met again: merge into the row of their first appearance, in that row's order
+    std::stable_sort(late_.begin(), late_.end(), [](const Late& x, const Late& y) { return x.row < y.row; });
+    std::vector<uint8_t> first(row_bytes_), merged(row_bytes_), split_row(row_bytes_);
+    std::vector<uint32_t> total(genome_ids_.size());
+    std::vector<VariantRow> split_meta;
+    std::vector<std::vector<uint8_t>> split_rows;
+    auto addCodes = [&](const uint8_t* row) { for (size_t g = 0; g < total.size(); ++g) total[g] += (row[g / 4] >> (2 * (g % 4))) & 3u; };
+    auto packTotals = [&](uint8_t* row) {
+      std::fill(row, row + row_bytes_, static_cast<uint8_t>(0));
+      for (size_t g = 0; g < total.size(); ++g) row[g / 4] = static_cast<uint8_t>(row[g / 4] | ((total[g] > 2 ? 3u : total[g]) << (2 * (g % 4))));
+    };
+    for (size_t k = 0; k < late_.size();) {
+      size_t e = k;
+      while (e < late_.size() && late_[e].row == late_[k].row) ++e;
+      const uint64_t row = late_[k].row;
+      if (!sink_.read(row, first.data())) { error = "the row sink failed to give a row back"; return false; }
+      std::fill(total.begin(), total.end(), 0u);
+      addCodes(first.data());
+      for (size_t m = k; m < e; ++m) addCodes(late_[m].packed.data());
+      packTotals(merged.data());
+      for (size_t g = 0; g < total.size(); ++g)
+        if (total[g] > 2) flat.non_diploid.push_back({static_cast<uint32_t>(row), static_cast<uint32_t>(g), total[g]});
+      if (!sink_.write(row, 1, merged.data())) { error = "the row sink failed while taking a merged row"; return false; }
+      // records in different FWS bins: one split row per bin, holding that bin's copies only
+      std::map<uint8_t, std::vector<const uint8_t*>> by_bin;
+      std::map<uint8_t, const VariantRow*> first_of_bin;
+      by_bin[fwsBinOfFrequency(meta_[row].info_af)].push_back(first.data());
+      first_of_bin.try_emplace(fwsBinOfFrequency(meta_[row].info_af), &meta_[row]);
+      for (size_t m = k; m < e; ++m) {
+        const uint8_t bin = fwsBinOfFrequency(late_[m].meta.info_af);
+        by_bin[bin].push_back(late_[m].packed.data());
+        first_of_bin.try_emplace(bin, &late_[m].meta);
+      }
+      if (by_bin.size() > 1) {
+        meta_[row].fws_from_splits = true;                 // primary row's bin counts come from its splits
+        for (const auto& [bin, members] : by_bin) {
+          if (bin == FWS_NO_BIN) continue;
+          std::fill(total.begin(), total.end(), 0u);
+          for (const uint8_t* member : members) addCodes(member);
+          packTotals(split_row.data());
+          VariantRow split = *first_of_bin.at(bin);
+          split.fws_from_splits = false;
+          split.split_of = static_cast<int64_t>(row);
+          split_meta.push_back(std::move(split));
+          split_rows.push_back(split_row);
+        }
+      }
+      k = e;
+    }
+    std::sort(flat.non_diploid.begin(), flat.non_diploid.end(), [](const NonDiploidCell& x, const NonDiploidCell& y) {
+      return x.row != y.row ? x.row < y.row : x.genome < y.genome;
+    });
+    const uint64_t n_primary = meta_.size();
+    for (size_t i = 0; i < split_rows.size(); ++i)
+      if (!sink_.write(n_primary + i, 1, split_rows[i].data())) { error = "the row sink failed while taking a split row"; return false; }
+    flat.rows = std::move(meta_);
+    flat.rows.insert(flat.rows.end(), std::make_move_iterator(split_meta.begin()), std::make_move_iterator(split_meta.end()));
+    flat.variant_objects = variant_objects_;
+    if (!sink_.close(flat.rows.size())) { error = "the row sink failed to close"; return false; }
+    return true;
+  }
+
+ private:
+  struct Late { uint64_t row; VariantRow meta; std::vector<uint8_t> packed; };
+
+  bool giveUp(const std::string& why) { two_phase = true; why_ = why; return false; }
+  bool open(const std::vector<std::string>& samples) {
+    const size_t S = samples.size();
+    sample_names_ = samples;
+    std::vector<uint32_t> order(S);
+    std::iota(order.begin(), order.end(), 0u);
+    std::sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) { return samples[x] < samples[y]; });
+    column_of_sample_.assign(S, 0);
+    for (size_t rank = 0; rank < S; ++rank) {
+      if (rank && samples[order[rank]] == samples[order[rank - 1]]) return giveUp("sample " + samples[order[rank]] + " is named twice: its columns add up into one genome");
+      column_of_sample_[order[rank]] = static_cast<uint32_t>(rank);
+      genome_ids_.push_back(samples[order[rank]]);
+    }
+    carries_.assign(S, every_sample_ ? 1 : 0);
+    row_bytes_ = (S + 3) / 4;
+    opened_ = true;
+    if (!sink_.open(S, row_bytes_)) { error = "the row sink failed to open"; return false; }
+    return true;
+  }
+
+  StreamSink& sink_;
+  bool every_sample_;
+  size_t threads_;
+  bool opened_{false};
+  std::string why_;
+  std::vector<std::string> sample_names_;
+  std::vector<GenomeId_t> genome_ids_;
+  std::vector<uint32_t> column_of_sample_;
+  std::vector<uint8_t> carries_;
+  uint64_t row_bytes_{0};
+  std::unordered_map<std::string, uint64_t> row_of_hgvs_;
+  std::vector<VariantRow> meta_;
+  std::vector<Late> late_;
+  size_t variant_objects_{0};
+
+ public:
+  [[nodiscard]] const std::string& why() const { return why_; }
+};
+
 // "AF" of the INFO column: one value per alt; a size mismatch is flagged with +inf (P7FrequencyFilter errors out: in no bin).
 void readInfoAf(std::string_view info, size_t A, std::vector<float>& af, bool& af_bad_size) {
   af.assign(A, std::numeric_limits<float>::quiet_NaN());
@@ -418,7 +597,7 @@ void appendRecords(std::vector<RecordRows>& a, std::vector<RecordRows>&& b) {
 // next(text): the next run of whole lines of the file, false when there is none.  The sample names are those of the
 // first piece that holds a #CHROM line (the header precedes the records).
 template <typename NextChunk>
-FlatPopulation flattenVcf1000Chunks(NextChunk&& next, size_t threads, RowSink* sink = nullptr) {
+FlatPopulation flattenVcf1000Chunks(NextChunk&& next, size_t threads, RowSink* sink = nullptr, StreamMerger* stream = nullptr) {
   const bool trace = std::getenv("KGX_FLATTEN_TRACE") != nullptr;
   auto t_last = std::chrono::steady_clock::now();
   auto lap = [&](const char* what) {
@@ -471,7 +650,18 @@ FlatPopulation flattenVcf1000Chunks(NextChunk&& next, size_t threads, RowSink* s
     }
   });
   lap("parse records");
+  if (stream) {
+    if (!stream->consume(samples, parsed)) break;
+    lap("stream rows");
+    continue;
+  }
   appendRecords(all_parsed, std::move(parsed));
+  }
+  if (stream) {
+    FlatPopulation streamed;
+    (void)stream->finish(streamed);
+    lap("finish stream");
+    return streamed;
   }
   FlatPopulation flat = mergeRecords(all_parsed, samples, false, threads, sink);
   lap("merge");
@@ -594,7 +784,7 @@ bool passesP7VariantFilter(std::string_view info, std::string_view contig) {
 namespace {
 
 template <typename NextChunk>
-FlatPopulation flattenVcfPfChunks(NextChunk&& next, size_t threads, bool quality_filter, RowSink* sink = nullptr) {
+FlatPopulation flattenVcfPfChunks(NextChunk&& next, size_t threads, bool quality_filter, RowSink* sink = nullptr, StreamMerger* stream = nullptr) {
   std::vector<std::string> samples, contigs;
   std::vector<RecordRows> all_parsed;
   std::string_view text;
@@ -680,7 +870,17 @@ FlatPopulation flattenVcfPfChunks(NextChunk&& next, size_t threads, bool quality
       }
     }
   });
+  if (stream) {
+    if (!stream->consume(samples, parsed)) break;
+    continue;
+  }
   appendRecords(all_parsed, std::move(parsed));
+  }
+  if (stream) {
+    FlatPopulation streamed;
+    (void)stream->finish(streamed);
+    streamed.contig_ids = contigs;
+    return streamed;
   }
   FlatPopulation flat = mergeRecords(all_parsed, samples, true, threads, sink);
   flat.contig_ids = contigs;
@@ -697,6 +897,32 @@ bool flattenVcfPfFile(const std::string& file_name, FlatPopulation& flat, std::s
   if (!pieces.reader.open(file_name, error, threads, chunk_bytes)) return false;
   flat = flattenVcfPfChunks(pieces, threads, quality_filter, sink);
   error = pieces.error;
+  return error.empty();
+}
+
+bool flattenVcf1000FileStreaming(const std::string& file_name, StreamSink& sink, FlatPopulation& flat, std::string& error, bool& two_phase, size_t threads,
+                                 size_t chunk_bytes) {
+  two_phase = false;
+  FilePieces pieces;
+  if (!pieces.reader.open(file_name, error, threads, chunk_bytes)) return false;
+  StreamMerger stream(sink, false, threads);
+  flat = flattenVcf1000Chunks(pieces, threads, nullptr, &stream);
+  error = !pieces.error.empty() ? pieces.error : stream.error;
+  two_phase = error.empty() && stream.two_phase;
+  if (two_phase) error = stream.why();
+  return error.empty();
+}
+
+bool flattenVcfPfFileStreaming(const std::string& file_name, StreamSink& sink, FlatPopulation& flat, std::string& error, bool& two_phase, size_t threads,
+                               bool quality_filter, size_t chunk_bytes) {
+  two_phase = false;
+  FilePieces pieces;
+  if (!pieces.reader.open(file_name, error, threads, chunk_bytes)) return false;
+  StreamMerger stream(sink, true, threads);
+  flat = flattenVcfPfChunks(pieces, threads, quality_filter, nullptr, &stream);
+  error = !pieces.error.empty() ? pieces.error : stream.error;
+  two_phase = error.empty() && stream.two_phase;
+  if (two_phase) error = stream.why();
   return error.empty();
 }
 

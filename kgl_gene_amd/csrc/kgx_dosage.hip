@@ -257,16 +257,19 @@ int count_by_genome_impl(kgx_pop* pop, const uint8_t* bin_of_variant, uint32_t n
   });
 }
 
-int compound_offsets_shard(kgx_pop_shard& sh, const std::vector<OffsetGroup>& groups, uint32_t n_bins, uint64_t* out) {
+// row_list (may be empty): the groups' member rows; a group's first_row is then its first position in the list.
+int compound_offsets_shard(kgx_pop_shard& sh, const std::vector<OffsetGroup>& groups, const std::vector<uint32_t>& row_list, uint32_t n_bins, uint64_t* out) {
   const uint64_t G = sh.n_genomes, n_groups = groups.size();
   if (G == 0) return KGX_OK;
   if (int rc = use_device(*sh.dev)) return rc;
   const Device& dev = *sh.dev;
   const uint64_t cells = G * n_bins * 3;
   OffsetGroup* d_groups = nullptr;
+  uint32_t* d_list = nullptr;
   unsigned long long* d_acc = nullptr;
   int rc = KGX_OK;
-  if (hipMalloc(&d_groups, n_groups * sizeof(OffsetGroup)) != hipSuccess || hipMalloc(&d_acc, cells * sizeof(unsigned long long)) != hipSuccess) {
+  if (hipMalloc(&d_groups, n_groups * sizeof(OffsetGroup)) != hipSuccess || hipMalloc(&d_acc, cells * sizeof(unsigned long long)) != hipSuccess ||
+      (!row_list.empty() && hipMalloc(&d_list, row_list.size() * sizeof(uint32_t)) != hipSuccess)) {
     (void)hipGetLastError();
     rc = fail(KGX_ENOMEM, "compound_offsets: hipMalloc failed");
   }
@@ -279,12 +282,13 @@ int compound_offsets_shard(kgx_pop_shard& sh, const std::vector<OffsetGroup>& gr
     const uint64_t per_slice = (n_groups + slices - 1) / slices;
     const uint32_t gy = static_cast<uint32_t>((n_groups + per_slice - 1) / per_slice);
     if (hipMemsetAsync(d_acc, 0, cells * sizeof(unsigned long long), dev.stream) != hipSuccess ||
-        hipMemcpyAsync(d_groups, groups.data(), n_groups * sizeof(OffsetGroup), hipMemcpyHostToDevice, dev.stream) != hipSuccess) {
+        hipMemcpyAsync(d_groups, groups.data(), n_groups * sizeof(OffsetGroup), hipMemcpyHostToDevice, dev.stream) != hipSuccess ||
+        (d_list && hipMemcpyAsync(d_list, row_list.data(), row_list.size() * sizeof(uint32_t), hipMemcpyHostToDevice, dev.stream) != hipSuccess)) {
       rc = fail(KGX_EHIP, "compound_offsets: upload failed");
     } else {
       hipLaunchKernelGGL(k_compound_offsets, dim3(gx, gy), dim3(kBlock), 0, dev.stream,
                          reinterpret_cast<const uint32_t*>(sh.d_rows), sh.pitch / 4, G, d_groups, n_groups, per_slice,
-                         n_bins, d_acc);
+                         d_list, n_bins, d_acc);
       if (hipGetLastError() != hipSuccess ||
           hipMemcpyAsync(out, d_acc, cells * sizeof(unsigned long long), hipMemcpyDeviceToHost, dev.stream) != hipSuccess ||
           hipStreamSynchronize(dev.stream) != hipSuccess)
@@ -292,6 +296,7 @@ int compound_offsets_shard(kgx_pop_shard& sh, const std::vector<OffsetGroup>& gr
     }
   }
   if (d_groups) (void)hipFree(d_groups);
+  if (d_list) (void)hipFree(d_list);
   if (d_acc) (void)hipFree(d_acc);
   return rc;
 }
@@ -366,6 +371,7 @@ kgx_pop* kgx_population_create(uint64_t n_genomes, uint64_t n_variants) {
       return nullptr;
     }
     sh.d_rows = sh.d_alloc;
+    sh.capacity = n_variants;
     if (hipMemsetAsync(sh.d_rows, 0, bytes, sh.dev->stream) != hipSuccess) {
       (void)hipGetLastError();
       fail(KGX_EHIP, "hipMemset of dosage rows failed");
@@ -484,6 +490,46 @@ int kgx_population_read_dosage2(const kgx_pop* pop, uint8_t* dst, uint64_t dst_p
                              v1 - v0, hipMemcpyDeviceToHost, sh.dev->stream));
   }
   return sync_shards(pop);
+}
+
+int kgx_population_resize(kgx_pop* pop, uint64_t n_variants) {
+  if (int bound = require_bound()) return bound;
+  if (!pop) return fail(KGX_EINVAL, "null population");
+  for (auto& sh : pop->shards) {
+    if (int rc = use_device(*sh.dev)) return rc;
+    if (n_variants > sh.capacity) {
+      // grow by at least half, so that a population filled piece by piece is copied a bounded number of times
+      uint64_t capacity = sh.capacity + sh.capacity / 2;
+      if (capacity < n_variants) capacity = n_variants;
+      uint8_t* grown = nullptr;
+      if (sh.pitch * capacity) {
+        if (hipMalloc(&grown, sh.pitch * capacity) != hipSuccess) {
+          (void)hipGetLastError();
+          return fail(KGX_ENOMEM, "hipMalloc of %llu bytes for %llu dosage rows on device %d failed", (unsigned long long)(sh.pitch * capacity),
+                      (unsigned long long)capacity, sh.dev->id);
+        }
+        const uint64_t held = sh.pitch * sh.capacity;
+        if ((held && hipMemcpyAsync(grown, sh.d_rows, held, hipMemcpyDeviceToDevice, sh.dev->stream) != hipSuccess) ||
+            hipMemsetAsync(grown + held, 0, sh.pitch * capacity - held, sh.dev->stream) != hipSuccess ||
+            hipStreamSynchronize(sh.dev->stream) != hipSuccess) {
+          (void)hipGetLastError();
+          (void)hipFree(grown);
+          return fail(KGX_EHIP, "copying the dosage rows into the grown allocation failed");
+        }
+      }
+      if (sh.d_alloc) (void)hipFree(sh.d_alloc);
+      sh.d_alloc = sh.d_rows = grown;
+      sh.capacity = capacity;
+    }
+    if (n_variants != sh.n_variants) {                       // the per-variant columns follow the row count: re-created on demand
+      if (sh.d_af) { (void)hipFree(sh.d_af); sh.d_af = nullptr; }
+      if (sh.d_counts) { (void)hipFree(sh.d_counts); sh.d_counts = nullptr; }
+    }
+    sh.n_variants = n_variants;
+  }
+  if (n_variants != pop->n_variants) pop->has_af = false;
+  pop->n_variants = n_variants;
+  return use_device(*pop->shards[0].dev);
 }
 
 int kgx_population_set_af(kgx_pop* pop, const float* af) {
@@ -737,9 +783,37 @@ int kgx_compound_offsets(kgx_pop* pop, const uint32_t* first_row, const uint32_t
       return fail(KGX_EINVAL, "group %llu out of range", (unsigned long long)i);
     groups[i] = OffsetGroup{first_row[i], n_rows[i], bin[i], 0};
   }
+  const std::vector<uint32_t> no_list;
   const int rc = for_each_parallel(pop->shards.size(), [&](size_t s) {
     kgx_pop_shard& sh = pop->shards[s];
-    return compound_offsets_shard(sh, groups, n_bins, out + sh.genome_base * n_bins * 3);
+    return compound_offsets_shard(sh, groups, no_list, n_bins, out + sh.genome_base * n_bins * 3);
+  });
+  (void)use_device(*pop->shards[0].dev);
+  return rc;
+}
+
+int kgx_compound_offsets_listed(kgx_pop* pop, const uint32_t* member_rows, uint64_t n_members, const uint32_t* first_member, const uint32_t* n_rows,
+                                const uint32_t* bin, uint64_t n_groups, uint32_t n_bins, uint64_t* out) {
+  if (int bound = require_bound()) return bound;
+  if (!pop || !out || (n_groups && (!member_rows || !first_member || !n_rows || !bin))) return fail(KGX_EINVAL, "null argument");
+  if (n_bins == 0) return fail(KGX_EINVAL, "n_bins must be > 0");
+  if (n_members > 0xFFFFFFFFull) return fail(KGX_EINVAL, "more than 2^32 member rows");
+  std::memset(out, 0, pop->n_genomes * n_bins * 3 * sizeof(uint64_t));
+  if (n_groups == 0) return KGX_OK;
+  std::vector<OffsetGroup> groups(n_groups);
+  for (uint64_t i = 0; i < n_groups; ++i) {
+    if (n_rows[i] > 15) return fail(KGX_EINVAL, "group %llu has %u rows; at most 15 distinct variants per offset are supported",
+                                    (unsigned long long)i, n_rows[i]);
+    if (static_cast<uint64_t>(first_member[i]) + n_rows[i] > n_members || bin[i] >= n_bins)
+      return fail(KGX_EINVAL, "group %llu out of range", (unsigned long long)i);
+    groups[i] = OffsetGroup{first_member[i], n_rows[i], bin[i], 0};
+  }
+  const std::vector<uint32_t> row_list(member_rows, member_rows + n_members);
+  for (uint32_t row : row_list)
+    if (row >= pop->n_variants) return fail(KGX_EINVAL, "member row %u past the population's %llu rows", row, (unsigned long long)pop->n_variants);
+  const int rc = for_each_parallel(pop->shards.size(), [&](size_t s) {
+    kgx_pop_shard& sh = pop->shards[s];
+    return compound_offsets_shard(sh, groups, row_list, n_bins, out + sh.genome_base * n_bins * 3);
   });
   (void)use_device(*pop->shards[0].dev);
   return rc;

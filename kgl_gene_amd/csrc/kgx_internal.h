@@ -106,6 +106,7 @@ struct kgx_pop_shard {
   uint64_t genome_base = 0;      // first genome of the shard (a multiple of 64)
   uint64_t n_genomes = 0;
   uint64_t n_variants = 0;
+  uint64_t capacity = 0;         // rows allocated (>= n_variants; kgx_population_resize)
   uint64_t row_bytes = 0;        // ceil(n_genomes / 4): algorithmic bytes per row
   uint64_t pitch = 0;            // device row pitch, multiple of 16
   uint32_t chunks_per_row = 0;   // pitch / 16

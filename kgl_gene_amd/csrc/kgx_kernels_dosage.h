@@ -494,7 +494,7 @@ k_bin_scatter(const uint8_t* __restrict__ bin_of_row, uint64_t n_rows, uint32_t 
 // integer atomics.  Reads only the rows of compound offsets.
 // ---------------------------------------------------------------------------------------------
 struct OffsetGroup {
-  uint32_t first_row;
+  uint32_t first_row;  // first row of the group -- or, with a row list, the group's first position in that list
   uint32_t n_rows;
   uint32_t bin;        // output bin (contig index)
   uint32_t pad;
@@ -503,7 +503,7 @@ struct OffsetGroup {
 __global__ void __launch_bounds__(kBlock)
 k_compound_offsets(const uint32_t* __restrict__ rows, uint64_t dwords_per_row, uint64_t n_genomes,
                    const OffsetGroup* __restrict__ groups, uint64_t n_groups, uint64_t groups_per_slice,
-                   uint32_t n_bins, unsigned long long* __restrict__ acc) {
+                   const uint32_t* __restrict__ row_list, uint32_t n_bins, unsigned long long* __restrict__ acc) {
   const uint64_t col = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x;   // dword column = 16 genomes
   if (col * 16 >= n_genomes) return;
   const uint64_t g_begin = static_cast<uint64_t>(blockIdx.y) * groups_per_slice;
@@ -536,7 +536,8 @@ k_compound_offsets(const uint32_t* __restrict__ rows, uint64_t dwords_per_row, u
     // Field-wise sums in 2-bit fields would overflow for k > 3, so split even/odd genomes into 4-bit fields.
     uint32_t present_e = 0, present_o = 0, single_e = 0, single_o = 0, ge2 = 0;
     for (uint32_t r = 0; r < grp.n_rows; ++r) {
-      const uint32_t w = rows[(static_cast<uint64_t>(grp.first_row) + r) * dwords_per_row + col];
+      const uint64_t row = row_list ? static_cast<uint64_t>(row_list[grp.first_row + r]) : static_cast<uint64_t>(grp.first_row) + r;   // group-uniform
+      const uint32_t w = rows[row * dwords_per_row + col];
       const uint32_t lo = w & 0x55555555u, hi = (w >> 1) & 0x55555555u;
       const uint32_t present = lo | hi, single = lo & ~hi;
       present_e += present & 0x11111111u;

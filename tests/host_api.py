@@ -28,6 +28,8 @@ def lib():
         L.kgxh_flatten_vcf_pf.argtypes = [C.c_char_p, C.c_uint64, C.c_int, C.c_int]
         L.kgxh_flatten_vcf_file.restype = C.c_void_p
         L.kgxh_flatten_vcf_file.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_uint64, C.c_char_p, C.c_size_t]
+        L.kgxh_flatten_vcf_file_streaming.restype = C.c_void_p
+        L.kgxh_flatten_vcf_file_streaming.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_uint64, C.c_char_p, C.c_size_t, C.c_void_p]
         L.kgxh_flat_destroy.argtypes = [C.c_void_p]
         L.kgxh_flat_copy_splits.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         for name in ("kgxh_flat_genomes", "kgxh_flat_variants", "kgxh_flat_row_bytes", "kgxh_flat_variant_objects", "kgxh_flat_non_diploid",
@@ -80,12 +82,24 @@ def variant_sort(text: str | None, flavour: str, what: str, names=None, genome_i
     return [tuple(line.split("\t")) for line in out.split("\n") if line]
 
 
+class TwoPhaseNeeded(Exception):
+    """The streaming flattener cannot take this file (the message says why): the two-phase one has to."""
+
+
 class FlatVcf:
     def __init__(self, text: str | None, threads: int = 0, flavour: str = "Genome1000", quality_filter: bool = False, path=None,
-                 chunk_bytes: int = 0):
-        """From text, or (path=...) from a file read chunk_bytes of text at a time (kgxh_flatten_vcf_file)."""
+                 chunk_bytes: int = 0, streaming: bool = False):
+        """From text, or (path=...) from a file read chunk_bytes of text at a time (kgxh_flatten_vcf_file); streaming=True:
+        through the streaming flattener and an in-memory sink, rows put back into the two-phase order."""
         assert flavour in ("Genome1000", "Falciparum")
-        if path is not None:
+        if streaming:
+            err = C.create_string_buffer(512)
+            two_phase = C.c_int(0)
+            h = lib().kgxh_flatten_vcf_file_streaming(str(path).encode(), 0 if flavour == "Genome1000" else 1, threads, int(quality_filter),
+                                                      chunk_bytes, err, 512, C.byref(two_phase))
+            if not h:
+                raise (TwoPhaseNeeded if two_phase.value else IOError)(err.value.decode())
+        elif path is not None:
             err = C.create_string_buffer(512)
             h = lib().kgxh_flatten_vcf_file(str(path).encode(), 0 if flavour == "Genome1000" else 1, threads, int(quality_filter),
                                             chunk_bytes, err, 512)

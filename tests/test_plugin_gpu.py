@@ -127,19 +127,26 @@ def test_gpu_inbreed_package_matches_oracle_window_loop(tmp_path, kgx, algorithm
     assert len(lines) == 2 + int(np.sum(sp_of >= 0))
 
 
-def test_gpu_allele_package_reads_vcf_directly(tmp_path, kgx):
+@pytest.mark.parametrize("path", ["streamed", "two-phase"])
+def test_gpu_allele_package_reads_vcf_directly(tmp_path, kgx, path):
     """A FileNameOnly data file: the package parses the VCF itself (no Variant / PopulationDB objects) and must
-    produce what the oracle gets by parsing the same text the reference's way and running CalcFWS / HeteroHomoZygous."""
+    produce what the oracle gets by parsing the same text the reference's way and running CalcFWS / HeteroHomoZygous.
+    "streamed": rows go to the device piece by piece while the file is read (file order, repeated records merged at the
+    end); "two-phase": a sample that carries no variant is no genome, which the streaming flattener cannot know in time
+    -- the package says so and takes the two-phase flattener."""
     from . import vcf_text as vt
 
     G, L = 37, 1200
     rec, gt = sv.multiallelic_block(G, L, rng_seed=9, dup_records=2)
+    if path == "two-phase":
+        gt[:, 5, :] = 0
     ids = [f"HG{i:05d}" for i in range(G)]
-    text = vt.write_vcf_1000(rec, gt, ids, rng_seed=4)
+    text = vt.write_vcf_1000(rec, gt, ids, rng_seed=4, quirks=(path == "streamed"))
     vcf = tmp_path / "pop.vcf"
     vcf.write_text(text)
     res = rio.run_driver("GPU_ALLELE", tmp_path, [f"vcf:{vcf}"])
     assert res.returncode == 0, res.stderr
+    assert ("flattened in two phases" in res.stderr) == (path == "two-phase"), res.stderr[-2000:]
 
     opop = oa.Population("vcf")
     opop.add_vcf_1000(text)

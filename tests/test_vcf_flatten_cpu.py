@@ -267,6 +267,55 @@ def same_flat(a, b):
 
 
 @pytest.mark.parametrize("flavour", ["Genome1000", "Falciparum"])
+def test_streaming_flatten_equals_the_two_phase_one(tmp_path, flavour):
+    """The streaming flatteners hand rows to a sink piece by piece while the file is read (first-appearance order, repeated
+    records merged into their row at the end, split rows last); put back into HGVS order the population is the two-phase
+    flatteners' -- rows, split rows, non-diploid cells, Variant-object count -- whatever the piece size.  Files they cannot
+    take say so instead of guessing."""
+    if flavour == "Genome1000":
+        G, L = 37, 900
+        rec, gt = sv.multiallelic_block(G, L, rng_seed=9, dup_records=40)
+        for i in range(L, L + 40, 2):
+            rec.af[i] = rec.af[i] * np.float32(0.3)                        # half of the repeats in another FWS bin than their first record
+        by_offset = np.argsort(rec.offsets, kind="stable")                 # repeated records right behind their first, as in a sorted VCF
+        sorted_rec = oa.Records(rec.contig, rec.offsets[by_offset], [rec.refs[i] for i in by_offset], [rec.alts[i] for i in by_offset],
+                                af=[rec.af[i] for i in by_offset])
+        ids = [f"HG{i:05d}" for i in reversed(range(G))]
+        text = vt.write_vcf_1000(sorted_rec, gt[by_offset], ids, rng_seed=2)
+        unsorted_text = vt.write_vcf_1000(rec, gt, ids, rng_seed=2)
+    else:
+        text = vt.write_vcf_pf(700, [f"PF{i:04d}-C" for i in range(19)], rng_seed=5, same_af_for_repeats=False)
+    whole = ha.FlatVcf(text, 3, flavour=flavour, quality_filter=(flavour == "Falciparum"))
+    assert whole.V > 300 and whole.n_split > 0 and (whole.non_diploid > 0 or flavour == "Falciparum")
+    data = text.encode()
+    for kind, payload in {"plain": data, "bgzf": vt.bgzip(data, block=4000)}.items():
+        path = tmp_path / f"population.{kind}"
+        path.write_bytes(payload)
+        for chunk_bytes in (1, 777, 9000, 0):
+            got = ha.FlatVcf(None, 2, flavour=flavour, quality_filter=(flavour == "Falciparum"), path=path, chunk_bytes=chunk_bytes, streaming=True)
+            assert same_flat(got, whole), (kind, chunk_bytes)
+    if flavour == "Genome1000":
+        (tmp_path / "unsorted.vcf").write_text(unsorted_text)              # the repeats at the end of the file, pieces after their first record
+        assert same_flat(ha.FlatVcf(None, 2, path=tmp_path / "unsorted.vcf", chunk_bytes=5000, streaming=True), ha.FlatVcf(unsorted_text, 2))
+        lines = text.split("\n")
+        header = next(i for i, ln in enumerate(lines) if ln.startswith("#CHROM"))
+        silent = [ln if i <= header or not ln else "\t".join(ln.split("\t")[:9] + ["0|0"] + ln.split("\t")[10:]) for i, ln in enumerate(lines)]
+        (tmp_path / "silent.vcf").write_text("\n".join(silent))            # the first sample carries nothing: it is no genome
+        with pytest.raises(ha.TwoPhaseNeeded, match="carries no variant"):
+            ha.FlatVcf(None, 2, path=tmp_path / "silent.vcf", streaming=True)
+        assert ha.FlatVcf(None, 2, path=tmp_path / "silent.vcf").G == G - 1
+        twice = list(lines)
+        cols = twice[header].split("\t")
+        cols[-1] = cols[-2]
+        twice[header] = "\t".join(cols)
+        (tmp_path / "twice.vcf").write_text("\n".join(twice))
+        with pytest.raises(ha.TwoPhaseNeeded, match="named twice"):
+            ha.FlatVcf(None, 2, path=tmp_path / "twice.vcf", streaming=True)
+    (tmp_path / "empty").write_bytes(b"")
+    assert ha.FlatVcf(None, 1, flavour=flavour, path=tmp_path / "empty", streaming=True).V == 0
+
+
+@pytest.mark.parametrize("flavour", ["Genome1000", "Falciparum"])
 def test_flatten_from_file_in_pieces_equals_flatten_of_the_text(tmp_path, flavour):
     """The file entry points read a bounded piece of whole lines at a time (plain, gzip, block gzip); whatever the piece
     size -- smaller than a line, a few lines, the whole file -- the population is the one the whole text flattens to."""
