@@ -222,19 +222,21 @@ k_inbreed_sweep(const uint32_t* __restrict__ gt, uint64_t dwords_per_row, uint64
   }
 }
 
-// K5 evaluation passes (MODE 1: one Hall expectation step; MODE 2: the log-likelihood at F) for amax <= 7, the passes
-// HallME runs 50 times and Loglikelihood ~40 times per call.  What a cell contributes depends only on (locus, byte
-// value, F of the genome): a pair (y, d) per (locus, allele index pair) is tabulated once per call (k_eval_entries --
-// classify_cell decides every entry, so the class logic is the generic kernel's own), a pass holds the entries of the
-// batch of 8 loci it is walking in LDS, and each cell is one LDS read, one fma  v = y + F*d  and a few more fp64 operations:
+// The table passes, amax <= 7: the frequency sweep every estimator starts with (MODE 4; MODE 3 for RitlandLocus, with its
+// terms from the same read) and the evaluation passes (MODE 1: one Hall expectation step, run 50 times per call; MODE 2:
+// the log-likelihood at F, ~56 times).  What a cell contributes depends only on (locus, byte value, F of the genome): an
+// entry per (locus, allele index pair) is tabulated once per call (k_eval_entries -- classify_cell decides every entry,
+// so the class logic is the generic kernel's own), a pass holds the entries of the batch of 8 loci it is walking in LDS,
+// and each cell is one LDS read and two or three more operations:
 //   MODE 2  v = the cell's probability.  hom: y = f1*f1, d = f1 - f1*f1   (F*f + (1-F)*f*f,  _calc.cpp:94-129)
 //                                        het: y = 2*f1*f2, d = -y         (2*(1-F)*f1*f2)
 //                                        unclassified: (1, 0) -> probability 1, log 0.
 //           The probabilities, clamped to [1e-10, 1] as the reference clamps them, are multiplied across the batch, the
 //           exponent of the running product is peeled off into an integer after every batch, and ONE log per
 //           (segment, genome) is taken at the end: sum(log p) = log(prod p).
-//   MODE 1  v = the denominator F + (1-F)*f1 of a homozygous cell: y = f1, d = 1 - f1; every other cell (1, 0), i.e.
-//           v = 1 exactly.  The terms 1/v of ALL cells of a segment are summed as one fraction N/D (N <- N*v + D,
+//   MODE 1  v = the denominator F + (1-F)*f1 of a homozygous cell: y = f1 (8-byte entries: d = 1 - y for every entry),
+//           v = fma(1-F, y, F); every other cell y = 1, i.e. v = 1 exactly.  The terms 1/v of ALL cells of a segment are
+//           summed as one fraction N/D (N <- N*v + D,
 //           D <- D*v, both rescaled by a power of two every other batch; one division per segment), so part[] holds
 //           sum_hom 1/v + #(other cells the lane walked);
 //           k_hall_update subtracts that count (it is known: loci walked - homozygous cells counted by the frequency
@@ -253,6 +255,9 @@ k_inbreed_sweep(const uint32_t* __restrict__ gt, uint64_t dwords_per_row, uint64
 //           bits of hi and says in the top bits of lo what is odd; once per batch the wave looks at the top of hi and,
 //           if any lane saw one, walks the batch's entries again and lets the odd ones adjust the lane's own
 //           (segment, genome) partial slot in memory -- a second look at 32 entries, only where such a cell is.
+//   MODE 4  MODE 3 without the Ritland term (Simple, and the first pass of HallME / Loglikelihood): 8-byte entries, the
+//           two packed words alone.  In both, a segment's class counters leave as one packed word per (segment, genome)
+//           (k_reduce_class_counts).
 // Bit 7 of the byte (second allele index >= 8) is folded onto bit 3, and every entry with bit 3 set is "unclassified".
 // FOLD = false leaves the fold's three operations per dword out: the matrix is known to hold no allele index 8..14
 // (kgx_gt8::wide_nibbles == 1) and amax <= 6, so a second index with bit 3 set is 15 and, read without bit 7, 7 > amax --
