@@ -179,3 +179,59 @@ def test_handles_outlive_a_rebinding(kgx, rebind):
     assert np.array_equal(pop.allele_count_by_locus(), single.allele_count_by_locus())
     assert np.array_equal(pop.count_by_genome(), single.count_by_genome())
     pop.close(); single.close()
+
+
+def test_bench_exchange_calls_run_on_rccl_with_one_rank(tmp_path):
+    """What bench.py does between ranks -- torch.distributed on the nccl (= RCCL) backend bound to the device, an
+    asynchronous all_reduce(SUM) of the int32 view of the uint32 counts, work.wait() on the current stream, barrier --
+    run with a one-rank group in a child process (a box with one GPU cannot hold two RCCL ranks): the calls, dtypes and
+    stream semantics are RCCL's, only the peers are missing."""
+    import subprocess
+    import sys
+    import textwrap
+
+    script = tmp_path / "one_rank.py"
+    script.write_text(textwrap.dedent("""
+        import os, sys
+        import numpy as np
+        import torch
+        import torch.distributed as dist
+        sys.path.insert(0, os.environ["KGX_ROOT"])
+        from kgl_gene_amd import capi
+        from kgl_gene_amd.sharding import allreduce_counts_async
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", RANK="0", WORLD_SIZE="1", TORCH_NCCL_HIGH_PRIORITY="1")
+        dev = torch.device("cuda", 0)
+        torch.cuda.set_device(0)
+        dist.init_process_group(backend="nccl", device_id=dev)
+        capi.ensure_built(); capi.init(0)
+        G, V = 4000, 50_000
+        pop = capi.Population(G, V); pop.synth_biallelic(1111, 0, 0)
+        want = pop.allele_count_by_locus()
+        bufs = [torch.empty((V, 4), dtype=torch.int32, device=dev) for _ in range(2)]
+        af = torch.empty((V,), dtype=torch.float64, device=dev)
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        pending = None
+        for i in range(4):                                   # bench.py's pipeline: sweep i+1 beside the exchange of i
+            buf = bufs[i % 2]
+            pop.allele_count_by_locus_dev(buf.data_ptr(), stream)
+            work = allreduce_counts_async(buf, 2)            # world size "2": issue the collective (this group has one rank)
+            if pending is not None:
+                pending[0].wait()
+                capi.allele_frequency_dev(pending[1].data_ptr(), V, G, af.data_ptr(), stream)
+            pending = (work, buf)
+        pending[0].wait()
+        capi.allele_frequency_dev(pending[1].data_ptr(), V, G, af.data_ptr(), stream)
+        dist.barrier()
+        torch.cuda.synchronize(dev)
+        got = pending[1].cpu().numpy().view(np.uint32)
+        assert np.array_equal(got, want)
+        assert np.array_equal(af.cpu().numpy(), (want[:, 1].astype(np.float64) + 2.0 * want[:, 2]) / (2.0 * G))
+        dist.destroy_process_group()
+        print("one-rank RCCL exchange ok")
+    """))
+    import os
+    from pathlib import Path
+
+    env = dict(os.environ, KGX_ROOT=str(Path(__file__).resolve().parent.parent), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    res = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, env=env, timeout=600)
+    assert res.returncode == 0 and "one-rank RCCL exchange ok" in res.stdout, res.stderr[-3000:]
