@@ -198,7 +198,8 @@ int inbreed_shard(kgx_gt8_shard& sh, uint64_t g0, uint64_t g1, const uint32_t* l
     if (d_index) try_hip(hipMemcpyAsync(d_index, locus_index, n_sel * sizeof(uint32_t), hipMemcpyDefault, st), KGX_EHIP, "copy(index)");
   }
   try_hip(hipMemsetAsync(d_counts, 0, n * 6 * sizeof(unsigned long long), st), KGX_EHIP, "memset(counts)");
-  try_hip(hipMemsetAsync(d_part, 0, n_seg * n * kParts0 * sizeof(double), st), KGX_EHIP, "memset(partials)");
+  // (the table sweep and the 16-genome SWAR sweep pre-fill every partial with the segment defaults: k_fill_defaults)
+  if (!(n_sel && (table_sweep || swar16))) try_hip(hipMemsetAsync(d_part, 0, n_seg * n * kParts0 * sizeof(double), st), KGX_EHIP, "memset(partials)");
   try_hip(hipMemsetAsync(d_f, 0, n * sizeof(double), st), KGX_EHIP, "memset(f)");
 
   const dim3 grid(gx, static_cast<uint32_t>(n_seg));
@@ -316,6 +317,7 @@ int inbreed_shard(kgx_gt8_shard& sh, uint64_t g0, uint64_t g1, const uint32_t* l
                          d_valid, amax, phased, d_f, d_counts, d_part);
   };
   const uint32_t lin_grid = stream_grid(dev, n, kBlock);
+  auto reduce_grid = [&](uint64_t items) { return stream_grid(dev, (items + kReduceItems - 1) / kReduceItems * kBlock, kBlock); };
   if (rc == KGX_OK) {
     if (n_sel) hipLaunchKernelGGL((k_locus_tables<true>), dim3(stream_grid(dev, n_sel, kBlock)), dim3(kBlock), 0, st, d_af, n_sel, amax, 0.0, d_table, d_valid);
     if (rc == KGX_OK) try_hip(hipEventRecord(dev.sweep_begin, st), KGX_EHIP, "hipEventRecord");
@@ -335,7 +337,7 @@ int inbreed_shard(kgx_gt8_shard& sh, uint64_t g0, uint64_t g1, const uint32_t* l
     }
     if (rc == KGX_OK) try_hip(hipEventRecord(dev.sweep_end, st), KGX_EHIP, "hipEventRecord");
     if (sequential_defaults && n_sel) try_hip(hipStreamWaitEvent(st, dev.side_end, 0), KGX_EHIP, "hipStreamWaitEvent");
-    hipLaunchKernelGGL(k_reduce_parts, dim3(stream_grid(dev, n * kParts0, kBlock)), dim3(kBlock), 0, st, d_part, n_seg, n * kParts0,
+    hipLaunchKernelGGL(k_reduce_parts, dim3(reduce_grid(n * kParts0)), dim3(kBlock), 0, st, d_part, n_seg, n * kParts0,
                        (sequential_defaults && n_sel) ? d_seq_out : nullptr, d_sums);
     // Window-sized calls: the whole iteration in one launch, a wave per genome (k_inbreed_iterate_wave).
     const bool wave_path = (algorithm == 2 || algorithm == 3) && wave_sized;
@@ -369,7 +371,7 @@ int inbreed_shard(kgx_gt8_shard& sh, uint64_t g0, uint64_t g1, const uint32_t* l
       tabulate(1);
       for (int it = 0; it < 50 && rc == KGX_OK; ++it) {
         sweep(1);
-        hipLaunchKernelGGL(k_reduce_parts, dim3(lin_grid), dim3(kBlock), 0, st, d_part, pass_n_seg, n, nullptr, d_eval);
+        hipLaunchKernelGGL(k_reduce_parts, dim3(reduce_grid(n)), dim3(kBlock), 0, st, d_part, pass_n_seg, n, nullptr, d_eval);
         hipLaunchKernelGGL(k_hall_update, dim3(lin_grid), dim3(kBlock), 0, st, d_eval, d_counts, n, walked, d_f);
       }
     } else if (algorithm == 3) {
@@ -415,7 +417,7 @@ int inbreed_shard(kgx_gt8_shard& sh, uint64_t g0, uint64_t g1, const uint32_t* l
         for (int it = 0; it < kMaxEvaluations && rc == KGX_OK; ++it) {
           evaluate();
           const uint32_t act_grid = stream_grid(dev, n_act, kBlock);
-          hipLaunchKernelGGL(k_reduce_parts, dim3(act_grid), dim3(kBlock), 0, st, d_part, pass_n_seg, n_act, nullptr, d_eval);
+          hipLaunchKernelGGL(k_reduce_parts, dim3(reduce_grid(n_act)), dim3(kBlock), 0, st, d_part, pass_n_seg, n_act, nullptr, d_eval);
           try_hip(hipMemsetAsync(d_running, 0, sizeof(unsigned int), st), KGX_EHIP, "memset(running)");
           hipLaunchKernelGGL(k_brent_step, dim3(act_grid), dim3(kBlock), 0, st, act_brent, d_eval, n_act, it == 0 ? 0 : 1, search, act_f, d_running,
                              act_global, d_f);
@@ -500,7 +502,7 @@ int inbreed_shard(kgx_gt8_shard& sh, uint64_t g0, uint64_t g1, const uint32_t* l
       try_hip(hipStreamSynchronize(st), KGX_EHIP, "sync");
       for (int it = 0; it < kGoldenSteps && rc == KGX_OK; ++it) {
         sweep(2);
-        hipLaunchKernelGGL(k_reduce_parts, dim3(lin_grid), dim3(kBlock), 0, st, d_part, pass_n_seg, n, nullptr, d_eval);
+        hipLaunchKernelGGL(k_reduce_parts, dim3(reduce_grid(n)), dim3(kBlock), 0, st, d_part, pass_n_seg, n, nullptr, d_eval);
         hipLaunchKernelGGL(k_golden_step, dim3(lin_grid), dim3(kBlock), 0, st, d_golden, d_eval, n, it < 2 ? it : 2, d_f);
       }
       // coefficient = the better interior point of the final bracket

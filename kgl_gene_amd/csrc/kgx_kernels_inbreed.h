@@ -40,10 +40,17 @@ __global__ void __launch_bounds__(kBlock)
 k_locus_tables(const double* __restrict__ af_in, uint64_t n_loci, uint32_t amax, double inbreeding,
                double* __restrict__ table, uint8_t* __restrict__ valid) {
   const uint32_t stride = WIDE ? sweep_stride(amax) : amax + kTableExtra;
-  for (uint64_t l = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x; l < n_loci;
-       l += static_cast<uint64_t>(gridDim.x) * blockDim.x) {
+  // A thread's row is `stride` doubles: written straight to memory, neighbouring threads' stores are `stride` apart
+  // (0.84 ms for 5 M loci at amax = 3: 480 MB at a tenth of the bandwidth).  Rows of up to kTileStride doubles go through
+  // LDS instead and leave as whole lines.
+  constexpr uint32_t kTileStride = 16;
+  __shared__ double tile[kBlock * kTileStride];
+  const bool tiled = stride <= kTileStride;
+  for (uint64_t l0 = static_cast<uint64_t>(blockIdx.x) * blockDim.x; l0 < n_loci; l0 += static_cast<uint64_t>(gridDim.x) * blockDim.x) {
+  const uint64_t l = l0 + threadIdx.x;
+  if (l < n_loci) {
     const double* in = af_in + l * amax;
-    double* out = table + l * stride;
+    double* out = tiled ? tile + threadIdx.x * stride : table + l * stride;
     double sum_minor = 0.0;
     uint32_t n = 0;
     for (uint32_t a = 0; a < amax; ++a) {
@@ -98,6 +105,13 @@ k_locus_tables(const double* __restrict__ af_in, uint64_t n_loci, uint32_t amax,
     out[amax + 2] = major_het / sum_freqs;
     out[amax + 3] = minor_hom / sum_freqs;
     out[amax + 4] = minor_het / sum_freqs;
+  }
+  if (tiled) {                                              // block-uniform
+    __syncthreads();
+    const uint64_t rows = n_loci - l0 < blockDim.x ? n_loci - l0 : blockDim.x;
+    for (uint64_t i = threadIdx.x; i < rows * stride; i += blockDim.x) table[l0 * stride + i] = tile[i];
+    __syncthreads();
+  }
   }
 }
 
@@ -1102,16 +1116,33 @@ k_fill_defaults(const double* __restrict__ seg_def, uint64_t n_seg, uint64_t n_g
   }
 }
 
-// Sum the per-segment partials in segment order (deterministic; segments are ascending locus ranges).
+// Sum the per-segment partials (deterministic: a workgroup takes 16 neighbouring items, its 16 slices of 16 lanes each add
+// a contiguous sixteenth of the segments in ascending order, and the sixteen slice sums are added in order -- the same
+// additions whatever the launch; one thread walking all ~1000 segments of an item was 0.3 ms of latency per pass).
 // base (may be null): kParts0 values added to every genome's kParts0 sums -- the class-frequency sums of the defaults
 // when they are kept apart from the genomes' corrections (k_seq_chain).
+constexpr uint32_t kReduceItems = 16, kReduceSlices = kBlock / kReduceItems;
 __global__ void __launch_bounds__(kBlock)
 k_reduce_parts(const double* __restrict__ part, uint64_t n_seg, uint64_t n_items, const double* __restrict__ base, double* __restrict__ out) {
-  for (uint64_t i = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n_items;
-       i += static_cast<uint64_t>(gridDim.x) * blockDim.x) {
+  __shared__ double slice_sum[kReduceSlices][kReduceItems + 1];
+  const uint32_t item = threadIdx.x % kReduceItems, slice = threadIdx.x / kReduceItems;
+  const uint64_t per_slice = (n_seg + kReduceSlices - 1) / kReduceSlices;
+  const uint64_t k_begin = slice * per_slice < n_seg ? slice * per_slice : n_seg;
+  const uint64_t k_end = k_begin + per_slice < n_seg ? k_begin + per_slice : n_seg;
+  for (uint64_t i0 = static_cast<uint64_t>(blockIdx.x) * kReduceItems; i0 < n_items; i0 += static_cast<uint64_t>(gridDim.x) * kReduceItems) {
+    const uint64_t i = i0 + item;
     double s = 0.0;
-    for (uint64_t k = 0; k < n_seg; ++k) s += part[k * n_items + i];
-    out[i] = base ? base[i % kParts0] + s : s;
+    if (i < n_items)
+      for (uint64_t k = k_begin; k < k_end; ++k) s += part[k * n_items + i];
+    slice_sum[slice][item] = s;
+    __syncthreads();
+    if (slice == 0 && i < n_items) {
+      double total = 0.0;
+#pragma unroll
+      for (uint32_t k = 0; k < kReduceSlices; ++k) total += slice_sum[k][item];
+      out[i] = base ? base[i % kParts0] + total : total;
+    }
+    __syncthreads();
   }
 }
 
