@@ -122,6 +122,31 @@ void* kgxh_flatten_vcf_file_streaming(const char* path, int flavour, int threads
   return flat;
 }
 
+// The streaming flattener into a sink that only counts (scripts/bench_flatten_file.py: the flattener's own footprint and
+// time, without a packed copy anywhere on the host).  Rows read back for a merge are all-zero: use on files without
+// repeated records.  Returns the number of rows, or -1.
+int64_t kgxh_stream_flatten_count(const char* path, int flavour, int threads, uint64_t chunk_bytes, uint64_t* genomes, uint64_t* bytes_written) {
+  if (!path) return -1;
+  namespace g = kellerberrin::genome::analysis::gpu;
+  struct CountingSink final : g::StreamSink {
+    uint64_t row_bytes{0}, rows{0}, bytes{0}, genomes{0};
+    bool open(uint64_t n, uint64_t rb) override { genomes = n; row_bytes = rb; return true; }
+    bool write(uint64_t first_row, uint64_t n_rows, const uint8_t*) override { rows = std::max(rows, first_row + n_rows); bytes += n_rows * row_bytes; return true; }
+    bool read(uint64_t, uint8_t* data) override { std::memset(data, 0, row_bytes); return true; }
+    bool close(uint64_t n_rows) override { rows = n_rows; return true; }
+  } sink;
+  FlatPopulation flat;
+  std::string err;
+  bool other_path = false;
+  const size_t piece = chunk_bytes ? static_cast<size_t>(chunk_bytes) : (size_t{64} << 20);
+  const bool ok = flavour == 0 ? g::flattenVcf1000FileStreaming(path, sink, flat, err, other_path, threads > 0 ? threads : 0, piece)
+                               : g::flattenVcfPfFileStreaming(path, sink, flat, err, other_path, threads > 0 ? threads : 0, false, piece);
+  if (!ok) return -1;
+  if (genomes) *genomes = sink.genomes;
+  if (bytes_written) *bytes_written = sink.bytes;
+  return static_cast<int64_t>(sink.rows);
+}
+
 void kgxh_flat_destroy(void* h) { delete static_cast<FlatPopulation*>(h); }
 uint64_t kgxh_flat_genomes(void* h) { return h ? static_cast<FlatPopulation*>(h)->genomes() : 0; }
 uint64_t kgxh_flat_variants(void* h) { return h ? static_cast<FlatPopulation*>(h)->variants() : 0; }
