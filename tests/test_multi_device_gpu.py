@@ -37,6 +37,21 @@ def dosage_results(kgx, G, V, codes, bins, n_bins, groups):
         "k3_binned": pop.count_by_genome_binned(bins, n_bins),
         "k8": pop.compound_offsets(*groups, 3),
     }
+    # the same groups as row lists; the FWS bins decided on the device from an AF column; then the population grown by
+    # a third (rows uploaded afterwards) and swept again
+    first, count, gbin = groups
+    members = np.concatenate([np.arange(f, f + n, dtype=np.uint32) for f, n in zip(first, count)])
+    starts = np.concatenate([[0], np.cumsum(count)[:-1]]).astype(np.uint32)
+    out["k8_listed"] = pop.compound_offsets_listed(members, starts, count, gbin, 3)
+    af = (np.arange(V) % 23).astype(np.float32) / 40.0
+    af[::17] = np.nan
+    pop.set_af(af)
+    out["k3_af_bins"] = pop.count_by_genome_af_bins([0.0, 0.05, 0.10, 0.15, 0.20, 0.25, 0.30, 0.35, 0.40, 0.45, 0.5, 1.0])
+    extra = V // 3
+    pop.resize(V + extra)
+    pop.load_dosage2(kgx.pack_dosage2(codes[:extra]), V)
+    out["k2_grown"] = pop.allele_count_by_locus()
+    out["k3_grown"] = pop.count_by_genome()
     pop.close()
     return out
 
@@ -60,8 +75,10 @@ def test_sharded_dosage_sweeps_equal_the_unsharded_ones(kgx, rebind, slots, G):
     assert len(shards) == slots and sum(s["n_genomes"] for s in shards) == G
     assert all(s["genome_base"] % 64 == 0 for s in shards if s["n_genomes"])
     assert [s["genome_base"] for s in shards] == list(np.cumsum([0] + [s["n_genomes"] for s in shards[:-1]]))
-    for key in ("rows", "k2", "k4", "k3", "k3_binned", "k8"):
+    for key in ("rows", "k2", "k4", "k3", "k3_binned", "k8", "k8_listed", "k3_af_bins", "k2_grown", "k3_grown"):
         assert np.array_equal(got[key], want[key]), key
+    assert np.array_equal(want["k8_listed"], want["k8"])
+    assert np.array_equal(want["k2_grown"][:V], want["k2"]) and np.array_equal(want["k2_grown"][V:], want["k2"][:V // 3])
 
 
 def test_sharded_loaders_and_synthetic_population(kgx, rebind):
