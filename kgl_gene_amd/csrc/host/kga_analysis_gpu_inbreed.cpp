@@ -5,6 +5,7 @@
 #include <thread>
 #include <cmath>
 #include <fstream>
+#include <functional>
 #include <iomanip>
 #include <limits>
 #include <sstream>
@@ -390,68 +391,126 @@ bool kga::GpuInbreedAnalysis::populationInbreeding(GpuParamOutput& param_output)
   const auto& super_pops = FrequencyDatabaseRead::superPopulations();
   gpu::FlatDiploid diploid;
   bool phased = true;
-  if (!diploidInput(reference, diploid, phased)) return false;
 
   // Genomes with the contig and a PED record, grouped by super population; each group starts on a multiple of 16.
   struct DeviceGenome { uint64_t column; GenomeId_t id; };
   std::vector<std::vector<DeviceGenome>> by_super_pop(super_pops.size());
-  for (uint64_t column = 0; column < diploid.genome_ids.size(); ++column) {
-    const GenomeId_t& genome_id = diploid.genome_ids[column];
-    auto record_opt = genealogy_data_->getGenomeGenealogyRecord(genome_id);
-    if (!record_opt) {
-      ExecEnv::log().error("InbreedingAnalysis::populationInbreeding, Genome sample: {} does not have a PED record", genome_id);
-      continue;
-    }
-    const auto sp_it = std::find(super_pops.begin(), super_pops.end(), record_opt.value().superPopulation());
-    if (sp_it == super_pops.end()) {
-      ExecEnv::log().error("InbreedingAnalysis::populationInbreeding, Locus set not found for super population: {}", record_opt.value().superPopulation());
-      continue;
-    }
-    by_super_pop[static_cast<size_t>(sp_it - super_pops.begin())].push_back({column, genome_id});
-  }
   std::vector<uint64_t> range_begin(super_pops.size(), 0), range_end(super_pops.size(), 0);
   uint64_t device_genomes = 0;
-  for (size_t sp = 0; sp < super_pops.size(); ++sp) {
-    device_genomes = (device_genomes + 15) / 16 * 16;   // 16-genome boundary: the widest sweep kernel applies
-    range_begin[sp] = device_genomes;
-    device_genomes += by_super_pop[sp].size();
-    range_end[sp] = device_genomes;
-  }
-  if (device_genomes == 0 || n_loci == 0) return true;
-
-  // Device column order = super-population groups; the flattened input is in genome-id order.
-  const uint64_t input_genomes = diploid.genome_ids.size();
-  std::vector<int64_t> column_of(device_genomes, -1);          // -1: padding up to the next group's 16-genome boundary
-  for (size_t sp = 0; sp < super_pops.size(); ++sp)
-    for (size_t k = 0; k < by_super_pop[sp].size(); ++k) column_of[range_begin[sp] + k] = static_cast<int64_t>(by_super_pop[sp][k].column);
-  std::vector<uint8_t> bytes(n_loci * device_genomes, 0);
-  {
+  std::vector<int64_t> column_of;                               // device column -> column of the flattened input (genome-id order)
+  auto planColumns = [&](const std::vector<GenomeId_t>& genome_ids) {
+    for (auto& group : by_super_pop) group.clear();
+    for (uint64_t column = 0; column < genome_ids.size(); ++column) {
+      const GenomeId_t& genome_id = genome_ids[column];
+      auto record_opt = genealogy_data_->getGenomeGenealogyRecord(genome_id);
+      if (!record_opt) {
+        ExecEnv::log().error("InbreedingAnalysis::populationInbreeding, Genome sample: {} does not have a PED record", genome_id);
+        continue;
+      }
+      const auto sp_it = std::find(super_pops.begin(), super_pops.end(), record_opt.value().superPopulation());
+      if (sp_it == super_pops.end()) {
+        ExecEnv::log().error("InbreedingAnalysis::populationInbreeding, Locus set not found for super population: {}", record_opt.value().superPopulation());
+        continue;
+      }
+      by_super_pop[static_cast<size_t>(sp_it - super_pops.begin())].push_back({column, genome_id});
+    }
+    device_genomes = 0;
+    for (size_t sp = 0; sp < super_pops.size(); ++sp) {
+      device_genomes = (device_genomes + 15) / 16 * 16;   // 16-genome boundary: the widest sweep kernel applies
+      range_begin[sp] = device_genomes;
+      device_genomes += by_super_pop[sp].size();
+      range_end[sp] = device_genomes;
+    }
+    // Device column order = super-population groups; the flattened input is in genome-id order.
+    column_of.assign(device_genomes, -1);                        // -1: padding up to the next group's 16-genome boundary
+    for (size_t sp = 0; sp < super_pops.size(); ++sp)
+      for (size_t k = 0; k < by_super_pop[sp].size(); ++k) column_of[range_begin[sp] + k] = static_cast<int64_t>(by_super_pop[sp][k].column);
+  };
+  // rows of the flattened input (genome-id order, input_genomes wide) into device column order
+  auto permuteRows = [&](const uint8_t* in, uint64_t input_genomes, uint64_t n_rows, uint8_t* out) {
     std::atomic<uint64_t> next{0};
     auto worker = [&]() {
-      for (uint64_t begin = next.fetch_add(1024); begin < n_loci; begin = next.fetch_add(1024))
-        for (uint64_t l = begin; l < std::min<uint64_t>(n_loci, begin + 1024); ++l) {
-          const uint8_t* in = &diploid.bytes[l * input_genomes];
-          uint8_t* row = &bytes[l * device_genomes];
-          for (uint64_t g = 0; g < device_genomes; ++g)
-            if (column_of[g] >= 0) row[g] = in[column_of[g]];
+      for (uint64_t begin = next.fetch_add(1024); begin < n_rows; begin = next.fetch_add(1024))
+        for (uint64_t l = begin; l < std::min<uint64_t>(n_rows, begin + 1024); ++l) {
+          const uint8_t* from = in + l * input_genomes;
+          uint8_t* row = out + l * device_genomes;
+          for (uint64_t g = 0; g < device_genomes; ++g) row[g] = column_of[g] >= 0 ? from[column_of[g]] : 0;
         }
     };
-    const size_t n_threads = std::max<size_t>(1, std::min<size_t>(std::max(2u, std::thread::hardware_concurrency()) - 1, (n_loci + 1023) / 1024));
+    const size_t n_threads = std::max<size_t>(1, std::min<size_t>(std::max(2u, std::thread::hardware_concurrency()) - 1, (n_rows + 1023) / 1024));
     std::vector<std::thread> pool;
     for (size_t t = 1; t < n_threads; ++t) pool.emplace_back(worker);
     worker();
     for (auto& th : pool) th.join();
-  }
-  diploid.bytes.clear();
-  diploid.bytes.shrink_to_fit();
+  };
+
   DeviceMatrix dev;
-  dev.handle = kgx_gt8_create(device_genomes, n_loci);
-  if (!dev.handle || kgx_gt8_load_rows(dev.handle, bytes.data(), device_genomes, 0, n_loci) != KGX_OK) {
-    ExecEnv::log().error("GpuInbreedAnalysis; genotype upload failed: {}", kgx_last_error());
-    return false;
+  bool on_device = false;
+  if (!diploid_population_) {
+    // A population VCF file: its rows go to the device as their loci are complete (flattenVcf1000Gt8FileStreaming), the
+    // host holds a piece of the file at a time.  A file that cannot be streamed takes the two-phase flattener below.
+    struct DeviceSink final : gpu::Gt8StreamSink {
+      std::function<void(const std::vector<GenomeId_t>&)> plan;
+      std::function<void(const uint8_t*, uint64_t, uint64_t, uint8_t*)> permute;
+      DeviceMatrix* dev{nullptr};
+      const uint64_t* device_genomes{nullptr};
+      uint64_t input_genomes{0};
+      std::vector<uint8_t> block;
+      std::string error;
+      bool open(const std::vector<GenomeId_t>& genome_ids, uint64_t loci) override {
+        plan(genome_ids);
+        input_genomes = genome_ids.size();
+        if (*device_genomes == 0 || loci == 0) return true;
+        dev->handle = kgx_gt8_create(*device_genomes, loci);
+        if (!dev->handle) error = std::string("kgx_gt8_create failed: ") + kgx_last_error();
+        return dev->handle != nullptr;
+      }
+      bool write(uint64_t first_locus, uint64_t n, const uint8_t* rows) override {
+        if (!dev->handle) return true;
+        block.resize(n * *device_genomes);
+        permute(rows, input_genomes, n, block.data());
+        if (kgx_gt8_load_rows(dev->handle, block.data(), *device_genomes, first_locus, first_locus + n) == KGX_OK) return true;
+        error = std::string("genotype upload failed: ") + kgx_last_error();
+        return false;
+      }
+      bool close() override { return true; }
+    } sink;
+    sink.plan = planColumns;
+    sink.permute = permuteRows;
+    sink.dev = &dev;
+    sink.device_genomes = &device_genomes;
+    gpu::FlatReference flat;
+    flat.contig_id = reference.contig_id;
+    flat.loci = reference.loci;
+    std::string io_error;
+    bool two_phase = false;
+    if (gpu::flattenVcf1000Gt8FileStreaming(diploid_vcf_, flat, sink, diploid, io_error, two_phase)) {
+      on_device = true;
+    } else if (two_phase) {
+      ExecEnv::log().warn("GpuInbreedAnalysis; {}: flattened in two phases ({})", diploid_vcf_, io_error);
+      if (dev.handle) { kgx_gt8_destroy(dev.handle); dev.handle = nullptr; }
+      diploid = gpu::FlatDiploid{};
+    } else {
+      ExecEnv::log().error("GpuInbreedAnalysis; population VCF: {}{}", io_error, sink.error.empty() ? std::string() : " (" + sink.error + ")");
+      return false;
+    }
   }
-  bytes.clear();
-  bytes.shrink_to_fit();
+  if (!on_device) {
+    if (!diploidInput(reference, diploid, phased)) return false;
+    planColumns(diploid.genome_ids);
+  }
+  if (device_genomes == 0 || n_loci == 0) return true;
+  if (!on_device) {
+    std::vector<uint8_t> bytes(n_loci * device_genomes, 0);
+    permuteRows(diploid.bytes.data(), diploid.genome_ids.size(), n_loci, bytes.data());
+    diploid.bytes.clear();
+    diploid.bytes.shrink_to_fit();
+    dev.handle = kgx_gt8_create(device_genomes, n_loci);
+    if (!dev.handle || kgx_gt8_load_rows(dev.handle, bytes.data(), device_genomes, 0, n_loci) != KGX_OK) {
+      ExecEnv::log().error("GpuInbreedAnalysis; genotype upload failed: {}", kgx_last_error());
+      return false;
+    }
+  }
 
   // The window loop of InbreedingAnalysis::populationInbreeding (_diploid.cpp:43-75).
   const int all_slot = static_cast<int>(std::find(super_pops.begin(), super_pops.end(), std::string(FrequencyDatabaseRead::SUPER_POP_ALL_)) - super_pops.begin());

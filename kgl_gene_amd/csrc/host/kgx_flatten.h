@@ -162,6 +162,22 @@ struct FlatDiploid {
 [[nodiscard]] bool flattenVcf1000Gt8File(const std::string& file_name, const FlatReference& reference, FlatDiploid& diploid, std::string& error,
                                          size_t threads = 0, size_t chunk_bytes = size_t{64} << 20);
 
+// Streaming: the rows of the loci a piece completes leave for the sink while the next piece is read; what stays on the
+// host between pieces is the records of the one locus that may go on.  Genomes are every sample, in id order, as soon as
+// the header is read (open); rows are [genome_ids.size()] bytes each and arrive as dense runs of consecutive loci in
+// ascending order (a locus no record lands on is never written: zero).  Returns false with two_phase set (error = why) for
+// a file that has to take flattenVcf1000Gt8File instead: a sample named twice, a sample that carries nothing on the contig
+// (it is then no genome of it), records not in ascending position order.
+class Gt8StreamSink {
+ public:
+  virtual ~Gt8StreamSink() = default;
+  virtual bool open(const std::vector<GenomeId_t>& genome_ids, uint64_t n_loci) = 0;
+  virtual bool write(uint64_t first_locus, uint64_t n_loci, const uint8_t* rows) = 0;
+  virtual bool close() = 0;
+};
+[[nodiscard]] bool flattenVcf1000Gt8FileStreaming(const std::string& file_name, const FlatReference& reference, Gt8StreamSink& sink, FlatDiploid& diploid,
+                                                  std::string& error, bool& two_phase, size_t threads = 0, size_t chunk_bytes = size_t{64} << 20);
+
 // P7FrequencyFilter / CalcFWS bins on the "AF" INFO value of a row (kgl_variant_filter_Pf7.cpp:20-66,
 // kga_analysis_PfEMP_FWS.cpp:15-38,104-145): bin index 0..10, or 0xFF when the row is in no bin
 // (missing AF passes both filters and is excluded by the NOT).

@@ -258,6 +258,42 @@ void* kgxh_inbreed_inputs_file(const char* reference_text, uint64_t reference_le
   }
   return out;
 }
+// The population through the streaming flattener (rows leave as their loci are complete) into memory: the same InbreedInputs
+// as kgxh_inbreed_inputs_file's, for comparison.  *two_phase = 1 (null returned, why filled): the file has to take the other path.
+void* kgxh_inbreed_inputs_file_streaming(const char* reference_text, uint64_t reference_len, int data_source, const char* diploid_path, int threads,
+                                         uint64_t diploid_chunk_bytes, int* two_phase, char* why, size_t why_len) {
+  if (!reference_text || !diploid_path) return nullptr;
+  namespace g = kellerberrin::genome::analysis::gpu;
+  struct MemorySink final : g::Gt8StreamSink {
+    std::vector<uint8_t> bytes;
+    uint64_t genomes{0};
+    bool open(const std::vector<kellerberrin::genome::GenomeId_t>& genome_ids, uint64_t n_loci) override {
+      genomes = genome_ids.size();
+      bytes.assign(n_loci * genomes, 0);
+      return true;
+    }
+    bool write(uint64_t first_locus, uint64_t n_loci, const uint8_t* rows) override {
+      if ((first_locus + n_loci) * genomes > bytes.size()) return false;
+      if (n_loci * genomes) std::memcpy(&bytes[first_locus * genomes], rows, n_loci * genomes);
+      return true;
+    }
+    bool close() override { return true; }
+  } sink;
+  auto* out = new InbreedInputs();
+  out->reference = g::flattenReferenceVcf(std::string_view(reference_text, reference_len), static_cast<kellerberrin::genome::DataSourceEnum>(data_source));
+  std::string error;
+  bool other_path = false;
+  const bool ok = g::flattenVcf1000Gt8FileStreaming(diploid_path, out->reference, sink, out->diploid, error, other_path, threads > 0 ? threads : 0,
+                                                    diploid_chunk_bytes ? static_cast<size_t>(diploid_chunk_bytes) : (size_t{64} << 20));
+  if (two_phase) *two_phase = other_path ? 1 : 0;
+  if (!ok) {
+    if (why && why_len) { std::strncpy(why, error.c_str(), why_len - 1); why[why_len - 1] = 0; }
+    delete out;
+    return nullptr;
+  }
+  out->diploid.bytes = std::move(sink.bytes);
+  return out;
+}
 void kgxh_inbreed_inputs_destroy(void* h) { delete static_cast<InbreedInputs*>(h); }
 uint64_t kgxh_inbreed_loci(void* h) { return h ? static_cast<InbreedInputs*>(h)->reference.loci.size() : 0; }
 uint64_t kgxh_inbreed_genomes(void* h) { return h ? static_cast<InbreedInputs*>(h)->diploid.genome_ids.size() : 0; }

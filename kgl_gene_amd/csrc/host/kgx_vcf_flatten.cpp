@@ -1014,8 +1014,59 @@ bool flattenReferenceVcfFile(const std::string& file_name, DataSourceEnum data_s
 
 namespace {
 
+// One locus' row from its records (in file order): per genome the count of SNP variants so far, their codes and phases.
+struct Gt8RecordCalls {
+  int64_t locus{-1};
+  std::vector<uint8_t> code;            // [n_alt]
+  std::vector<uint8_t> calls;           // [S]: phase A alt | phase B alt << 4  (alt numbers up to 15 fit; larger ones are clipped below)
+  std::vector<std::pair<uint32_t, std::pair<uint32_t, uint32_t>>> wide;   // samples whose alt numbers need more than 4 bits
+};
+void assembleGt8Locus(const Gt8RecordCalls* const* records, size_t n_records, const std::vector<int64_t>& genome_of_sample, uint8_t* row,
+                      std::vector<uint8_t>& count, std::vector<uint8_t>& first_phase) {
+  std::fill(count.begin(), count.end(), 0);
+  auto add = [&](uint64_t g, uint8_t code, uint8_t phase) {
+    const uint8_t n = count[g];
+    if (n == 0) { row[g] = code; first_phase[g] = phase; }
+    else if (n == 1) {
+      const uint8_t c0 = row[g] & 0xF;
+      // two copies of one variant on ONE phase (a repeated record): analogous, not homozygous -> the (0, a) byte
+      if (c0 == code && code != 15 && first_phase[g] == phase) row[g] = static_cast<uint8_t>(code << 4);
+      else row[g] = static_cast<uint8_t>(c0 | (code << 4));
+    } else {
+      row[g] = 0xFF;
+    }
+    if (n < 3) count[g] = static_cast<uint8_t>(n + 1);
+  };
+  for (size_t k = 0; k < n_records; ++k) {
+    const Gt8RecordCalls& rc = *records[k];
+    const size_t A = rc.code.size();
+    // Genome1000VCFImpl::addVariants: all phase A variants of the record are added first (by alt), then phase B
+    for (uint8_t phase = 0; phase < 2; ++phase) {
+      for (size_t s = 0; s < rc.calls.size(); ++s) {
+        if (rc.calls[s] == 0 || genome_of_sample[s] < 0) continue;
+        const uint32_t alt = phase == 0 ? (rc.calls[s] & 0xFu) : (rc.calls[s] >> 4);
+        if (alt == 0 || alt > A) continue;
+        const uint8_t code = rc.code[alt - 1];
+        if (code == 0) continue;                                        // not a SNP
+        add(static_cast<uint64_t>(genome_of_sample[s]), code, phase);
+      }
+      for (const auto& [s, ab] : rc.wide) {
+        if (genome_of_sample[s] < 0) continue;
+        const uint32_t alt = phase == 0 ? ab.first : ab.second;
+        if (alt == 0 || alt > A) continue;
+        const uint8_t code = rc.code[alt - 1];
+        if (code == 0) continue;
+        add(static_cast<uint64_t>(genome_of_sample[s]), code, phase);
+      }
+    }
+  }
+}
+
+// stream (may be null): rows leave for the sink as their loci are complete (Gt8StreamSink); *two_phase is set, with the
+// reason in out.error, when the file cannot be taken that way.
 template <typename NextChunk>
-FlatDiploid flattenVcf1000Gt8Chunks(NextChunk&& next_piece, const FlatReference& reference, size_t threads) {
+FlatDiploid flattenVcf1000Gt8Chunks(NextChunk&& next_piece, const FlatReference& reference, size_t threads, Gt8StreamSink* stream = nullptr,
+                                    bool* two_phase = nullptr, std::string* stream_error = nullptr) {
   const bool trace = std::getenv("KGX_FLATTEN_TRACE") != nullptr;
   auto t_last = std::chrono::steady_clock::now();
   auto lap = [&](const char* what) {
@@ -1034,13 +1085,39 @@ FlatDiploid flattenVcf1000Gt8Chunks(NextChunk&& next_piece, const FlatReference&
   // before the sweep, _freq.cpp:436), and per sample the two alt numbers.  A record off the loci only says who holds
   // the contig (holds[]) and keeps nothing: what stays in memory between the pieces of a file is a byte per cell of
   // the result.
-  struct RecordCalls {
-    int64_t locus{-1};
-    std::vector<uint8_t> code;            // [n_alt]
-    std::vector<uint8_t> calls;           // [S]: phase A alt | phase B alt << 4  (alt numbers up to 15 fit; larger ones are clipped below)
-    std::vector<std::pair<uint32_t, std::pair<uint32_t, uint32_t>>> wide;   // samples whose alt numbers need more than 4 bits
-  };
+  using RecordCalls = Gt8RecordCalls;
   std::vector<RecordCalls> parsed;
+  // streaming state: the records of the last locus met (it may go on in the next piece), the last locus written
+  std::vector<RecordCalls> open_records;
+  int64_t last_written = -1;
+  bool stream_open = false;
+  std::vector<int64_t> stream_genome_of_sample;
+  auto giveUp = [&](const std::string& why) {
+    if (two_phase) *two_phase = true;
+    out.error = why;
+  };
+  auto streamFailed = [&](const char* what) { if (stream_error) *stream_error = what; };
+  // write the rows of the given records' loci (ascending, whole loci) as one dense block: loci without a record in between are zero rows
+  auto writeLoci = [&](const std::vector<const RecordCalls*>& records) -> bool {
+    if (records.empty()) return true;
+    const size_t G = out.genome_ids.size();
+    const int64_t first = records.front()->locus, last = records.back()->locus;
+    std::vector<uint8_t> block(static_cast<size_t>(last - first + 1) * G, 0);
+    std::vector<size_t> group_begin;                    // rows are independent: the loci are assembled on every thread
+    for (size_t k = 0; k < records.size(); ++k)
+      if (k == 0 || records[k]->locus != records[k - 1]->locus) group_begin.push_back(k);
+    group_begin.push_back(records.size());
+    parallelChunks(group_begin.size() - 1, 64, threads, [&](size_t begin, size_t end) {
+      std::vector<uint8_t> count(G), first_phase(G);
+      for (size_t grp = begin; grp < end; ++grp) {
+        const size_t k = group_begin[grp];
+        assembleGt8Locus(&records[k], group_begin[grp + 1] - k, stream_genome_of_sample, &block[static_cast<size_t>(records[k]->locus - first) * G], count, first_phase);
+      }
+    });
+    if (!stream->write(static_cast<uint64_t>(first), static_cast<uint64_t>(last - first + 1), block.data())) { streamFailed("the row sink failed while taking a piece's rows"); return false; }
+    last_written = last;
+    return true;
+  };
   std::vector<std::string> samples;
   std::vector<uint8_t> holds;             // [S] 1 if the sample carries ANY alt (SNP or not) of a record on the contig
   if (threads == 0) threads = std::max<size_t>(std::thread::hardware_concurrency(), 2) - 1;
@@ -1102,9 +1179,59 @@ FlatDiploid flattenVcf1000Gt8Chunks(NextChunk&& next_piece, const FlatReference&
     worker();
     for (auto& th : pool) th.join();
   }
+  if (stream) {
+    if (two_phase && *two_phase) break;
+    if (!stream_open && S) {
+      // genomes: every sample, in id order (whether each holds the contig is known at the end only)
+      std::vector<uint32_t> by_name(S);
+      std::iota(by_name.begin(), by_name.end(), 0u);
+      std::sort(by_name.begin(), by_name.end(), [&](uint32_t x, uint32_t y) { return samples[x] < samples[y]; });
+      stream_genome_of_sample.assign(S, -1);
+      for (size_t rank = 0; rank < S; ++rank) {
+        if (rank && samples[by_name[rank]] == samples[by_name[rank - 1]]) { giveUp("sample " + samples[by_name[rank]] + " is named twice: its columns add up into one genome"); break; }
+        stream_genome_of_sample[by_name[rank]] = static_cast<int64_t>(rank);
+        out.genome_ids.push_back(samples[by_name[rank]]);
+      }
+      if (two_phase && *two_phase) break;
+      if (!stream->open(out.genome_ids, out.n_loci)) { streamFailed("the row sink failed to open"); break; }
+      stream_open = true;
+    }
+    // the open locus' records, then this piece's, in file order; whole loci are written, the last one stays open
+    std::vector<RecordCalls> held = std::move(open_records);
+    open_records.clear();
+    std::vector<const RecordCalls*> records;
+    for (const auto& rc : held) records.push_back(&rc);
+    for (const auto& rc : piece) if (rc.locus >= 0) records.push_back(&rc);
+    bool ascending = true;
+    for (size_t k = 0; k < records.size() && ascending; ++k)
+      ascending = records[k]->locus > last_written && (k == 0 || records[k]->locus >= records[k - 1]->locus);
+    if (!ascending) { giveUp("the records of the contig are not in ascending position order"); break; }
+    size_t keep_from = records.size();
+    while (keep_from > 0 && records[keep_from - 1]->locus == records.back()->locus) --keep_from;
+    const std::vector<const RecordCalls*> complete(records.begin(), records.begin() + static_cast<std::ptrdiff_t>(keep_from));
+    if (stream_open && !writeLoci(complete)) break;
+    std::vector<RecordCalls> still_open;
+    for (size_t k = keep_from; k < records.size(); ++k) still_open.push_back(*records[k]);
+    open_records = std::move(still_open);
+    continue;
+  }
   for (auto& rc : piece) if (rc.locus >= 0) parsed.push_back(std::move(rc));      // file order kept
   }
   const size_t S = samples.size();
+  if (stream) {
+    if ((two_phase && *two_phase) || (stream_error && !stream_error->empty())) return out;
+    if (!stream_open) {                                   // no sample columns at all: nobody holds the contig
+      if (!stream->open(out.genome_ids, out.n_loci) || !stream->close()) streamFailed("the row sink failed");
+      return out;
+    }
+    std::vector<const RecordCalls*> records;
+    for (const auto& rc : open_records) records.push_back(&rc);
+    if (!writeLoci(records)) return out;
+    for (size_t smp = 0; smp < S; ++smp)
+      if (!holds[smp]) { giveUp("sample " + samples[smp] + " carries no variant on the contig: it is no genome of it, and the rows are one column too wide"); return out; }
+    if (!stream->close()) streamFailed("the row sink failed to close");
+    return out;
+  }
 
   lap("parse records");
   // genomes that hold the contig, in id order; a sample named twice is one genome
@@ -1147,45 +1274,9 @@ FlatDiploid flattenVcf1000Gt8Chunks(NextChunk&& next_piece, const FlatReference&
       while (k < end) {
         const int64_t locus = parsed[by_locus[k]].locus;
         uint8_t* row = &out.bytes[static_cast<uint64_t>(locus) * G];
-        std::fill(count.begin(), count.end(), 0);
-        auto add = [&](uint64_t g, uint8_t code, uint8_t phase, uint32_t sample) -> bool {
-          const uint8_t n = count[g];
-          if (n == 0) { row[g] = code; first_phase[g] = phase; }
-          else if (n == 1) {
-            const uint8_t c0 = row[g] & 0xF;
-            (void)sample;
-            // two copies of one variant on ONE phase (a repeated record): analogous, not homozygous -> the (0, a) byte
-            if (c0 == code && code != 15 && first_phase[g] == phase) row[g] = static_cast<uint8_t>(code << 4);
-            else row[g] = static_cast<uint8_t>(c0 | (code << 4));
-          } else {
-            row[g] = 0xFF;
-          }
-          if (n < 3) count[g] = static_cast<uint8_t>(n + 1);
-          return true;
-        };
-        for (; k < by_locus.size() && parsed[by_locus[k]].locus == locus; ++k) {
-          const RecordCalls& rc = parsed[by_locus[k]];
-          const size_t A = rc.code.size();
-          // Genome1000VCFImpl::addVariants: all phase A variants of the record are added first (by alt), then phase B
-          for (uint8_t phase = 0; phase < 2; ++phase) {
-            for (size_t s = 0; s < rc.calls.size(); ++s) {
-              if (rc.calls[s] == 0 || genome_of_sample[s] < 0) continue;
-              const uint32_t alt = phase == 0 ? (rc.calls[s] & 0xFu) : (rc.calls[s] >> 4);
-              if (alt == 0 || alt > A) continue;
-              const uint8_t code = rc.code[alt - 1];
-              if (code == 0) continue;                                        // not a SNP
-              if (!add(static_cast<uint64_t>(genome_of_sample[s]), code, phase, static_cast<uint32_t>(s))) return;
-            }
-            for (const auto& [s, ab] : rc.wide) {
-              if (genome_of_sample[s] < 0) continue;
-              const uint32_t alt = phase == 0 ? ab.first : ab.second;
-              if (alt == 0 || alt > A) continue;
-              const uint8_t code = rc.code[alt - 1];
-              if (code == 0) continue;
-              if (!add(static_cast<uint64_t>(genome_of_sample[s]), code, phase, s)) return;
-            }
-          }
-        }
+        std::vector<const RecordCalls*> records;
+        for (; k < by_locus.size() && parsed[by_locus[k]].locus == locus; ++k) records.push_back(&parsed[by_locus[k]]);
+        assembleGt8Locus(records.data(), records.size(), genome_of_sample, row, count, first_phase);
       }
     }
   };
@@ -1212,6 +1303,19 @@ bool flattenVcf1000Gt8File(const std::string& file_name, const FlatReference& re
   if (!pieces.reader.open(file_name, error, threads, chunk_bytes)) return false;
   diploid = flattenVcf1000Gt8Chunks(pieces, reference, threads);
   error = pieces.error;
+  return error.empty();
+}
+
+bool flattenVcf1000Gt8FileStreaming(const std::string& file_name, const FlatReference& reference, Gt8StreamSink& sink, FlatDiploid& diploid, std::string& error,
+                                    bool& two_phase, size_t threads, size_t chunk_bytes) {
+  two_phase = false;
+  FilePieces pieces;
+  if (!pieces.reader.open(file_name, error, threads, chunk_bytes)) return false;
+  std::string sink_error;
+  diploid = flattenVcf1000Gt8Chunks(pieces, reference, threads, &sink, &two_phase, &sink_error);
+  error = !pieces.error.empty() ? pieces.error : sink_error;
+  if (error.empty() && two_phase) { error = diploid.error; diploid.error.clear(); }
+  else two_phase = false;
   return error.empty();
 }
 

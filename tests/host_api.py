@@ -46,6 +46,8 @@ def lib():
         L.kgxh_inbreed_inputs.argtypes = [C.c_char_p, C.c_uint64, C.c_int, C.c_char_p, C.c_uint64, C.c_int]
         L.kgxh_inbreed_inputs_file.restype = C.c_void_p
         L.kgxh_inbreed_inputs_file.argtypes = [C.c_char_p, C.c_uint64, C.c_int, C.c_char_p, C.c_int, C.c_uint64]
+        L.kgxh_inbreed_inputs_file_streaming.restype = C.c_void_p
+        L.kgxh_inbreed_inputs_file_streaming.argtypes = [C.c_char_p, C.c_uint64, C.c_int, C.c_char_p, C.c_int, C.c_uint64, C.c_void_p, C.c_char_p, C.c_size_t]
         L.kgxh_inbreed_inputs_destroy.argtypes = [C.c_void_p]
         for name in ("kgxh_inbreed_loci", "kgxh_inbreed_genomes", "kgxh_inbreed_max_alts", "kgxh_inbreed_contigs"):
             getattr(L, name).restype = C.c_uint64
@@ -165,9 +167,15 @@ class InbreedInputs:
     and the population's allele-index bytes [n_loci][genomes]."""
 
     def __init__(self, reference_text: str, data_source: int, diploid_text: str | None, threads: int = 0, diploid_path=None, chunk_bytes: int = 0,
-                 reference_path=None):
+                 reference_path=None, streaming: bool = False):
         rb = reference_text.encode()
-        if diploid_path is not None:
+        if streaming:
+            why = C.create_string_buffer(512)
+            two_phase = C.c_int(0)
+            h = lib().kgxh_inbreed_inputs_file_streaming(rb, len(rb), data_source, str(diploid_path).encode(), threads, chunk_bytes, C.byref(two_phase), why, 512)
+            if not h:
+                raise (TwoPhaseNeeded if two_phase.value else IOError)(why.value.decode())
+        elif diploid_path is not None:
             # reference_path: the reference site file is read in pieces too (reference_text is then ignored)
             if reference_path is not None:
                 h = lib().kgxh_inbreed_inputs_file(str(reference_path).encode(), 0, data_source, str(diploid_path).encode(), threads, chunk_bytes)

@@ -208,6 +208,40 @@ def test_inbreed_inputs_from_vcf_match_the_scaffold_encoder(threads):
                 for chunk_bytes in (1, 2500, 0):
                     piecewise = ha.InbreedInputs(ref_text, DATA_SOURCE["Gnomad2_1"], None, 2, diploid_path=Path(tmp) / name, chunk_bytes=chunk_bytes)
                     assert piecewise.genome_ids == got.genome_ids and np.array_equal(piecewise.bytes, got.bytes), (name, chunk_bytes)
+                    # ... and streamed: rows handed to a sink as their loci are complete, one locus' records held between pieces
+                    if len(carriers) == G:
+                        streamed = ha.InbreedInputs(ref_text, DATA_SOURCE["Gnomad2_1"], None, 2, diploid_path=Path(tmp) / name, chunk_bytes=chunk_bytes,
+                                                    streaming=True)
+                        assert streamed.genome_ids == got.genome_ids and np.array_equal(streamed.bytes, got.bytes), (name, chunk_bytes)
+            assert len(carriers) == G
+            # repeated records right behind their first (a sorted file): the streamed rows are the two-phase ones; at the end of the
+            # file (positions no longer ascending), a sample without any variant, a sample named twice: the two-phase path is asked for
+            lines = dip_text.split("\n")
+            header = next(i for i, ln in enumerate(lines) if ln.startswith("#CHROM"))
+            body = [ln for ln in lines[header + 1:] if ln]
+            doubled = []
+            for k, ln in enumerate(body):
+                doubled.append(ln)
+                if k % 9 == 2:
+                    doubled.append(ln)
+            adjacent = "\n".join(lines[:header + 1] + doubled) + "\n"
+            (Path(tmp) / "adjacent.vcf").write_text(adjacent)
+            want_adjacent = ha.InbreedInputs(ref_text, DATA_SOURCE["Gnomad2_1"], adjacent, 2)
+            for chunk_bytes in (1, 3000, 0):
+                streamed = ha.InbreedInputs(ref_text, DATA_SOURCE["Gnomad2_1"], None, 2, diploid_path=Path(tmp) / "adjacent.vcf", chunk_bytes=chunk_bytes, streaming=True)
+                assert np.array_equal(streamed.bytes, want_adjacent.bytes) and not np.array_equal(streamed.bytes, got.bytes), chunk_bytes
+            (Path(tmp) / "late.vcf").write_text("\n".join(lines[:header + 1] + body + body[5:8]) + "\n")
+            with pytest.raises(ha.TwoPhaseNeeded, match="ascending"):
+                ha.InbreedInputs(ref_text, DATA_SOURCE["Gnomad2_1"], None, 2, diploid_path=Path(tmp) / "late.vcf", chunk_bytes=2000, streaming=True)
+            silent = ["\t".join(ln.split("\t")[:9] + ["0|0"] + ln.split("\t")[10:]) for ln in body]
+            (Path(tmp) / "silent.vcf").write_text("\n".join(lines[:header + 1] + silent) + "\n")
+            with pytest.raises(ha.TwoPhaseNeeded, match="carries no variant"):
+                ha.InbreedInputs(ref_text, DATA_SOURCE["Gnomad2_1"], None, 2, diploid_path=Path(tmp) / "silent.vcf", streaming=True)
+            cols = lines[header].split("\t")
+            cols[-1] = cols[-2]
+            (Path(tmp) / "twice.vcf").write_text("\n".join(lines[:header] + ["\t".join(cols)] + body) + "\n")
+            with pytest.raises(ha.TwoPhaseNeeded, match="named twice"):
+                ha.InbreedInputs(ref_text, DATA_SOURCE["Gnomad2_1"], None, 2, diploid_path=Path(tmp) / "twice.vcf", streaming=True)
             # and the reference site file in pieces as well
             (Path(tmp) / "sites.vcf.bgz").write_bytes(vt.bgzip(ref_text.encode(), block=5000))
             for chunk_bytes in (1, 4000, 0):
