@@ -59,7 +59,7 @@ void* kgxh_flatten_vcf_file_streaming(const char* path, int flavour, int threads
     bool open(uint64_t, uint64_t rb) override { row_bytes = rb; return true; }
     bool write(uint64_t first_row, uint64_t n_rows, const uint8_t* data) override {
       if ((first_row + n_rows) * row_bytes > packed.size()) packed.resize((first_row + n_rows) * row_bytes, 0);
-      if (n_rows * row_bytes) std::memcpy(&packed[first_row * row_bytes], data, n_rows * row_bytes);
+      if (n_rows && row_bytes) std::memcpy(&packed[first_row * row_bytes], data, n_rows * row_bytes);
       return true;
     }
     bool read(uint64_t row, uint8_t* data) override {
@@ -274,7 +274,7 @@ void* kgxh_inbreed_inputs_file_streaming(const char* reference_text, uint64_t re
     }
     bool write(uint64_t first_locus, uint64_t n_loci, const uint8_t* rows) override {
       if ((first_locus + n_loci) * genomes > bytes.size()) return false;
-      if (n_loci * genomes) std::memcpy(&bytes[first_locus * genomes], rows, n_loci * genomes);
+      if (n_loci && genomes) std::memcpy(&bytes[first_locus * genomes], rows, n_loci * genomes);
       return true;
     }
     bool close() override { return true; }
