@@ -133,8 +133,9 @@ int count_by_genome_shard(kgx_pop_shard& sh, const uint8_t* bin_of_variant, uint
   const uint64_t V = sh.n_variants, G = sh.n_genomes;
   if (G == 0) return KGX_OK;
   if (V > 0xFFFFFFFFull) return fail(KGX_EINVAL, "n_variants exceeds the 32-bit row index of the by-genome sweep");
-  if (int rc = use_device(*sh.dev)) return rc;
   Device& dev = *sh.dev;
+  std::lock_guard<std::mutex> device_lock(dev.mutex);          // the scratch arena and the timing events are the device's
+  if (int rc = use_device(dev)) return rc;
   const uint64_t cells = G * n_bins;
   const bool identity = bin_of_variant == nullptr && bin_edges == nullptr;
   hipStream_t st = dev.stream;
@@ -150,10 +151,24 @@ int count_by_genome_shard(kgx_pop_shard& sh, const uint8_t* bin_of_variant, uint
       rc = fail(code, "count_by_genome: %s failed: %s", what, hipGetErrorString(e));
     }
   };
-  try_hip(hipMalloc(&d_acc, (cells ? cells : 1) * 3 * sizeof(unsigned long long)), KGX_ENOMEM, "hipMalloc(acc)");
-  try_hip(hipMalloc(&d_out, (cells ? cells : 1) * 4 * sizeof(unsigned long long)), KGX_ENOMEM, "hipMalloc(out)");
-  try_hip(hipMalloc(&d_nbin, n_bins * sizeof(unsigned long long)), KGX_ENOMEM, "hipMalloc(rows_in_bin)");
-  try_hip(hipMalloc(&d_binoff, (n_bins + 1) * sizeof(unsigned long long)), KGX_ENOMEM, "hipMalloc(bin_offset)");
+  // every buffer of the call out of the device's arena; the work list's size is bounded before the bins are known:
+  // about `target` items, one more per (bin, column group) for the bins' last pieces
+  const uint32_t n_chunks = static_cast<uint32_t>((V + kBinChunk - 1) / kBinChunk);
+  const uint32_t n_cg = (sh.chunks_per_row + 63) / 64;
+  const uint64_t target = static_cast<uint64_t>(dev.compute_units) * 10u;
+  const uint64_t max_work = target + (static_cast<uint64_t>(n_bins) + 2) * n_cg + 64;
+  ScratchPlan plan;
+  const size_t o_acc = plan.add((cells ? cells : 1) * 3 * sizeof(unsigned long long)), o_out = plan.add((cells ? cells : 1) * 4 * sizeof(unsigned long long));
+  const size_t o_nbin = plan.add(n_bins * sizeof(unsigned long long)), o_binoff = plan.add((n_bins + 1) * sizeof(unsigned long long));
+  const size_t o_bins = plan.add(identity ? 0 : V), o_index = plan.add(identity ? 0 : (V + 8) * sizeof(uint32_t));
+  const size_t o_chunks = plan.add(identity ? 0 : static_cast<uint64_t>(n_chunks) * n_bins * sizeof(uint32_t)), o_work = plan.add(max_work * sizeof(GenomeWork));
+  char* arena = nullptr;
+  if (int arc = scratch_reserve(dev, plan.total, &arena)) return arc;
+  d_acc = reinterpret_cast<unsigned long long*>(arena + o_acc);
+  d_out = reinterpret_cast<unsigned long long*>(arena + o_out);
+  d_nbin = reinterpret_cast<unsigned long long*>(arena + o_nbin);
+  d_binoff = reinterpret_cast<unsigned long long*>(arena + o_binoff);
+  d_work = reinterpret_cast<GenomeWork*>(arena + o_work);
   try_hip(hipMemsetAsync(d_acc, 0, (cells ? cells : 1) * 3 * sizeof(unsigned long long), st), KGX_EHIP, "memset(acc)");
 
   // Rows grouped by bin, so that a workgroup only ever touches one bin: on the device (k_bin_count / _scan / _scatter).
@@ -164,11 +179,10 @@ int count_by_genome_shard(kgx_pop_shard& sh, const uint8_t* bin_of_variant, uint
     try_hip(hipMemcpyAsync(d_nbin, &v, sizeof(v), hipMemcpyHostToDevice, st), KGX_EHIP, "H2D(rows_in_bin)");
     try_hip(hipStreamSynchronize(st), KGX_EHIP, "sync");
   } else if (V > 0) {
-    const uint32_t n_chunks = static_cast<uint32_t>((V + kBinChunk - 1) / kBinChunk);
-    try_hip(hipMalloc(&d_bins, V), KGX_ENOMEM, "hipMalloc(bins)");
-    try_hip(hipMalloc(&d_index, (V + 8) * sizeof(uint32_t)), KGX_ENOMEM, "hipMalloc(index)");      // + 8: whole 8-entry scalar fetches
+    d_bins = reinterpret_cast<uint8_t*>(arena + o_bins);
+    d_index = reinterpret_cast<uint32_t*>(arena + o_index);                                       // + 8: whole 8-entry scalar fetches
+    d_chunks = reinterpret_cast<uint32_t*>(arena + o_chunks);
     try_hip(hipMemsetAsync(d_index + V, 0, 8 * sizeof(uint32_t), st), KGX_EHIP, "memset(index pad)");
-    try_hip(hipMalloc(&d_chunks, static_cast<uint64_t>(n_chunks) * n_bins * sizeof(uint32_t)), KGX_ENOMEM, "hipMalloc(chunk counts)");
     if (bin_edges) {
       // d_binoff is not read before k_bin_scan writes it: the edges borrow it on their way in
       static_assert(sizeof(double) == sizeof(unsigned long long), "edge buffer");
@@ -195,9 +209,7 @@ int count_by_genome_shard(kgx_pop_shard& sh, const uint8_t* bin_of_variant, uint
 
   if (rc == KGX_OK && selected > 0) {
     const int W = lanes_per_row(sh.chunks_per_row);
-    const uint32_t n_cg = (sh.chunks_per_row + 63) / 64;
     const uint64_t gran = static_cast<uint64_t>(64 / W) * (kBlock / kWave) * 8;
-    const uint64_t target = static_cast<uint64_t>(dev.compute_units) * 10u;
     uint64_t per_wg = (selected * n_cg + target - 1) / target;
     per_wg = (per_wg + gran - 1) / gran * gran;
     if (per_wg < gran * 4) per_wg = gran * 4;
@@ -212,7 +224,7 @@ int count_by_genome_shard(kgx_pop_shard& sh, const uint8_t* bin_of_variant, uint
           w.bin = b;
           work.push_back(w);
         }
-    try_hip(hipMalloc(&d_work, work.size() * sizeof(GenomeWork)), KGX_ENOMEM, "hipMalloc(work)");
+    if (rc == KGX_OK && work.size() > max_work) rc = fail(KGX_ESTATE, "count_by_genome: %zu work items exceed the %llu reserved", work.size(), (unsigned long long)max_work);
     try_hip(hipMemcpyAsync(d_work, work.data(), work.size() * sizeof(GenomeWork), hipMemcpyHostToDevice, st), KGX_EHIP, "H2D(work)");
     try_hip(hipStreamSynchronize(st), KGX_EHIP, "sync");     // `work` is pageable host memory
     if (rc == KGX_OK) {
@@ -244,9 +256,6 @@ int count_by_genome_shard(kgx_pop_shard& sh, const uint8_t* bin_of_variant, uint
     if (hipEventElapsedTime(&ms, dev.by_genome_begin, dev.by_genome_end) == hipSuccess) dev.last_by_genome_ms = ms;
     else (void)hipGetLastError();
   }
-  for (void* p : {static_cast<void*>(d_acc), static_cast<void*>(d_out), static_cast<void*>(d_nbin), static_cast<void*>(d_binoff),
-                  static_cast<void*>(d_index), static_cast<void*>(d_chunks), static_cast<void*>(d_bins), static_cast<void*>(d_work)})
-    if (p) (void)hipFree(p);
   return rc;
 }
 

@@ -39,35 +39,6 @@ void destroy_shards(kgx_gt8* h) {
   if (!h->shards.empty()) (void)use_device(*h->shards[0].dev);
 }
 
-struct ScratchPlan {
-  size_t total = 0;
-  size_t add(size_t bytes) {
-    const size_t at = total;
-    total += (bytes + 255u) & ~static_cast<size_t>(255u);
-    return at;
-  }
-};
-int scratch_reserve(Device& dev, size_t bytes, char** out) {
-  if (bytes > dev.scratch_bytes) {
-    if (dev.scratch) (void)hipFree(dev.scratch);
-    dev.scratch = nullptr;
-    dev.scratch_bytes = 0;
-    const size_t want = bytes + bytes / 8;            // headroom: windows of a contig differ a little in locus count
-    if (hipMalloc(&dev.scratch, want) != hipSuccess) {
-      (void)hipGetLastError();
-      if (hipMalloc(&dev.scratch, bytes) != hipSuccess) {
-        (void)hipGetLastError();
-        dev.scratch = nullptr;
-        return fail(KGX_ENOMEM, "hipMalloc of %llu scratch bytes failed", static_cast<unsigned long long>(bytes));
-      }
-      dev.scratch_bytes = bytes;
-    } else {
-      dev.scratch_bytes = want;
-    }
-  }
-  *out = dev.scratch;
-  return KGX_OK;
-}
 // kgx_inbreed for the genomes [g0, g1) of ONE shard (shard-local indices, g0 a multiple of 4); arguments checked by the caller.
 int inbreed_shard(kgx_gt8_shard& sh, uint64_t g0, uint64_t g1, const uint32_t* locus_index, uint64_t n_sel, const double* minor_af,
                   uint32_t amax, int phased, int algorithm, kgx_locus_results* out) {

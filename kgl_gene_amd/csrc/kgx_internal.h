@@ -67,6 +67,19 @@ void set_last_error(const std::string& message);
 int env_int(const char* name, int dflt);
 uint32_t stream_grid(const Device& dev, uint64_t work_items, uint32_t items_per_block);
 
+// Per-call device buffers come out of ONE grow-only arena per device (a window loop calls kgx_inbreed thousands of times, the
+// FWS analysis the by-genome sweep once per population: a dozen hipMalloc / hipFree pairs per call cost more than some of
+// the sweeps).  The caller holds the device's mutex; kgx_release_scratch frees the arena.
+struct ScratchPlan {
+  size_t total = 0;
+  size_t add(size_t bytes) {
+    const size_t at = total;
+    total += (bytes + 255u) & ~static_cast<size_t>(255u);
+    return at;
+  }
+};
+int scratch_reserve(Device& dev, size_t bytes, char** out);
+
 // Makes `dev` the calling thread's current HIP device.
 int use_device(const Device& dev);
 

@@ -111,6 +111,28 @@ uint32_t stream_grid(const Device& dev, uint64_t work_items, uint32_t items_per_
   return static_cast<uint32_t>(g ? g : 1);
 }
 
+int scratch_reserve(Device& dev, size_t bytes, char** out) {
+  if (bytes > dev.scratch_bytes) {
+    if (dev.scratch) (void)hipFree(dev.scratch);
+    dev.scratch = nullptr;
+    dev.scratch_bytes = 0;
+    const size_t want = bytes + bytes / 8;            // headroom: windows of a contig differ a little in locus count
+    if (hipMalloc(&dev.scratch, want) != hipSuccess) {
+      (void)hipGetLastError();
+      if (hipMalloc(&dev.scratch, bytes) != hipSuccess) {
+        (void)hipGetLastError();
+        dev.scratch = nullptr;
+        return fail(KGX_ENOMEM, "hipMalloc of %llu scratch bytes failed", static_cast<unsigned long long>(bytes));
+      }
+      dev.scratch_bytes = bytes;
+    } else {
+      dev.scratch_bytes = want;
+    }
+  }
+  *out = dev.scratch;
+  return KGX_OK;
+}
+
 int use_device(const Device& dev) {
   KGX_HIP(hipSetDevice(dev.id));
   return KGX_OK;
