@@ -23,7 +23,7 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 HIP_FLAGS = [
     "--offload-arch=gfx950",
     "-O3",
-    "-std=c++17",
+    "-std=c++20",
     "-ffp-contract=off",  # host and device fp64 must agree bit for bit (synthetic generator, K6)
     "-fPIC",
     "-Wall",

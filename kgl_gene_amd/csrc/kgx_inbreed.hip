@@ -369,7 +369,6 @@ int inbreed_shard(kgx_gt8_shard& sh, uint64_t g0, uint64_t g1, const uint32_t* l
         BrentState* act_brent = d_brent;
         double* act_f = d_f;
         uint32_t* act_global = nullptr;
-        int act_gpl = eval_gpl;
         std::vector<uint32_t> global_of(n);
         for (uint64_t g = 0; g < n; ++g) global_of[g] = static_cast<uint32_t>(g);
         std::vector<BrentState> host_states;
@@ -452,7 +451,6 @@ int inbreed_shard(kgx_gt8_shard& sh, uint64_t g0, uint64_t g1, const uint32_t* l
           act_brent = new_brent;
           act_f = new_f;
           act_global = d_new_global;
-          act_gpl = 8;
           n_act = n_new;
           global_of.swap(new_global);
         }

@@ -7,11 +7,11 @@ OUT=/tmp/kgx_san
 rm -rf $OUT && mkdir -p $OUT
 SAN="-O1 -g -fsanitize=address,undefined -fno-omit-frame-pointer -fno-sanitize-recover=undefined"
 cd $ROOT/kgl_gene_amd/csrc/host
-g++ $SAN -std=c++17 -fPIC -Wall -Wextra -Wno-unused-parameter -ffp-contract=off -pthread -shared -o $OUT/libkgx_analysis.so \
+g++ $SAN -std=c++20 -fPIC -Wall -Wextra -Wno-unused-parameter -ffp-contract=off -pthread -shared -o $OUT/libkgx_analysis.so \
     kgx_flatten.cpp kgx_vcf_flatten.cpp kgx_variant_sort.cpp kgx_vcf_io.cpp kgx_host_capi.cpp kga_analysis_gpu_allele.cpp kga_analysis_gpu_inbreed.cpp \
     -L$ROOT/kgl_gene_amd/lib -lkgx -lz -Wl,-rpath,$ROOT/kgl_gene_amd/lib
 cd $ROOT/oracle
-g++ $SAN -std=c++17 -fPIC -Wall -pthread -ffp-contract=off -shared -o $OUT/libkgo.so kgo_core.cpp kgo_analysis.cpp kgo_inbreed.cpp kgo_inbreed_dense.cpp kgo_vcf.cpp kgo_sort.cpp kgo_capi.cpp kgo_fast.cpp
+g++ $SAN -std=c++20 -fPIC -Wall -pthread -ffp-contract=off -shared -o $OUT/libkgo.so kgo_core.cpp kgo_analysis.cpp kgo_inbreed.cpp kgo_inbreed_dense.cpp kgo_vcf.cpp kgo_sort.cpp kgo_capi.cpp kgo_fast.cpp
 cd $ROOT
 export KGX_SANITIZED_HOST_LIB=$OUT/libkgx_analysis.so KGX_SANITIZED_ORACLE_LIB=$OUT/libkgo.so
 export ASAN_OPTIONS=detect_leaks=0:verify_asan_link_order=0 UBSAN_OPTIONS=print_stacktrace=1
