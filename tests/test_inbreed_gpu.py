@@ -57,17 +57,20 @@ def test_class_frequency_table_is_bit_exact(kgx):
                                             ("HallME", "passes"), ("Loglikelihood", "passes"), ("Loglikelihood", "golden"),
                                             ("Loglikelihood", "compacting"),
                                             ("Simple", "generic"), ("RitlandLocus", "generic"), ("HallME", "generic"), ("Loglikelihood", "generic"),
-                                            ("Simple", "swar4"), ("RitlandLocus", "no-table"),
-                                            ("Simple", "sequential"), ("RitlandLocus", "sequential"), ("Simple", "sequential-swar4")])
+                                            ("Simple", "swar16"), ("HallME", "swar16"), ("Simple", "swar4"), ("RitlandLocus", "no-table"),
+                                            ("Simple", "sequential"), ("RitlandLocus", "sequential"), ("Simple", "sequential-swar16"), ("Simple", "sequential-swar4")])
 def test_inbreed_window_vs_oracle(kgx, mode, algorithm, path, monkeypatch):
-    # every kernel flavour against the same oracle window: the window-sized fused iteration (default), the multi-kernel
-    # table passes, plain golden section, the generic per-cell kernels, the 4-genomes-per-lane SWAR sweep
+    # every kernel flavour against the same oracle window: the table sweep + window-sized fused iteration (default), the
+    # multi-kernel table passes, plain golden section, the generic per-cell kernels, the SWAR sweeps (16 and 4 genomes per
+    # lane: what the frequency pass falls back to without the table sweep)
     env = {"passes": {"KGX_K7_NO_WAVE": "1"},
            "compacting": {"KGX_K7_NO_WAVE": "1", "KGX_K7_COMPACT_MIN_GENOMES": "4", "KGX_K7_COMPACT_MIN_CELLS": "1"}, "golden": {"KGX_K7_NO_WAVE": "1", "KGX_K7_GOLDEN": "1"},
-           "generic": {"KGX_K5_GENERIC": "1", "KGX_K7_NO_WAVE": "1"}, "swar4": {"KGX_K5_NO_SWAR16": "1"},
+           "generic": {"KGX_K5_GENERIC": "1", "KGX_K7_NO_WAVE": "1"}, "swar16": {"KGX_K5_NO_TABLE_SWEEP": "1"},
+           "swar4": {"KGX_K5_NO_TABLE_SWEEP": "1", "KGX_K5_NO_SWAR16": "1"},
            "no-table": {"KGX_K5_NO_EVAL_LUT": "1"},
            # the class-frequency sums of the defaults in the reference's sequential order (the path every call >= 65536 loci takes)
-           "sequential": {"KGX_K5_SEQUENTIAL_MIN": "1"}, "sequential-swar4": {"KGX_K5_SEQUENTIAL_MIN": "1", "KGX_K5_NO_SWAR16": "1"}}.get(path, {})
+           "sequential": {"KGX_K5_SEQUENTIAL_MIN": "1"}, "sequential-swar16": {"KGX_K5_SEQUENTIAL_MIN": "1", "KGX_K5_NO_TABLE_SWEEP": "1"},
+           "sequential-swar4": {"KGX_K5_SEQUENTIAL_MIN": "1", "KGX_K5_NO_TABLE_SWEEP": "1", "KGX_K5_NO_SWAR16": "1"}}.get(path, {})
     for key, value in env.items():
         monkeypatch.setenv(key, value)
     G, L = 101, 1200
@@ -314,7 +317,8 @@ def test_kernel_flavours_agree_on_random_shapes(kgx, monkeypatch):
     table passes and the fused wave iteration must reproduce them."""
     rng = np.random.default_rng(2024)
     flavours = {"default": {}, "generic": {"KGX_K5_GENERIC": "1", "KGX_K7_NO_WAVE": "1"}, "passes": {"KGX_K7_NO_WAVE": "1"},
-                "swar4": {"KGX_K5_NO_SWAR16": "1"}, "sequential": {"KGX_K5_SEQUENTIAL_MIN": "1"}}
+                "swar16": {"KGX_K5_NO_TABLE_SWEEP": "1"}, "swar4": {"KGX_K5_NO_TABLE_SWEEP": "1", "KGX_K5_NO_SWAR16": "1"},
+                "sequential": {"KGX_K5_SEQUENTIAL_MIN": "1"}}
     knobs = sorted({k for env in flavours.values() for k in env})
     for trial in range(150):
         G = int(rng.choice([1, 3, 4, 5, 15, 16, 17, 63, 64, 65, 100, 257, 1000]))
