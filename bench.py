@@ -361,8 +361,10 @@ def inbreed_workload(args, capi, dist, torch, dev, wl, L, n_gpus, rank):
                    "layout": "gt8 allele-index bytes, locus-major", "exchange": "none (genomes are independent)",
                    "mean_F": float(res["inbred_allele_sum"].mean()), "seed": args.seed},
         "roofline": {"bound": "hbm", "kernel": "k_inbreed_eval_lut<3|4> (the frequency sweep's table pass)", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                     "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                     "traffic_source": "see profiles/ (FETCH_SIZE pass of the same kernel)", "algorithmic_bytes_per_launch": sweep_bytes,
+                     "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                     "traffic": committed_traffic("K5", workload_label(args, wl, G, L))[0] if args.algorithm != "RitlandLocus" and n_gpus == 1 else None,
+                     "traffic_source": (committed_traffic("K5", workload_label(args, wl, G, L))[1] if args.algorithm != "RitlandLocus" and n_gpus == 1
+                                        else "no rocprofv3 --pmc pass committed for this kernel"), "algorithmic_bytes_per_launch": sweep_bytes,
                      "kernel_ms": k5_ms, "kernel_ms_statistic": "median", "sweep_ms_with_locus_helpers": float(np.median(sweep_ms))},
         "cpu_baseline": None,
     }
