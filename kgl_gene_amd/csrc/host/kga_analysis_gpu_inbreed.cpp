@@ -398,18 +398,21 @@ bool kga::GpuInbreedAnalysis::populationInbreeding(GpuParamOutput& param_output)
   std::vector<uint64_t> range_begin(super_pops.size(), 0), range_end(super_pops.size(), 0);
   uint64_t device_genomes = 0;
   std::vector<int64_t> column_of;                               // device column -> column of the flattened input (genome-id order)
+  bool planned_before = false;                                  // a second plan (two-phase after a streaming attempt) repeats no message
   auto planColumns = [&](const std::vector<GenomeId_t>& genome_ids) {
+    const bool log_missing = !planned_before;
+    planned_before = true;
     for (auto& group : by_super_pop) group.clear();
     for (uint64_t column = 0; column < genome_ids.size(); ++column) {
       const GenomeId_t& genome_id = genome_ids[column];
       auto record_opt = genealogy_data_->getGenomeGenealogyRecord(genome_id);
       if (!record_opt) {
-        ExecEnv::log().error("InbreedingAnalysis::populationInbreeding, Genome sample: {} does not have a PED record", genome_id);
+        if (log_missing) ExecEnv::log().error("InbreedingAnalysis::populationInbreeding, Genome sample: {} does not have a PED record", genome_id);
         continue;
       }
       const auto sp_it = std::find(super_pops.begin(), super_pops.end(), record_opt.value().superPopulation());
       if (sp_it == super_pops.end()) {
-        ExecEnv::log().error("InbreedingAnalysis::populationInbreeding, Locus set not found for super population: {}", record_opt.value().superPopulation());
+        if (log_missing) ExecEnv::log().error("InbreedingAnalysis::populationInbreeding, Locus set not found for super population: {}", record_opt.value().superPopulation());
         continue;
       }
       by_super_pop[static_cast<size_t>(sp_it - super_pops.begin())].push_back({column, genome_id});
