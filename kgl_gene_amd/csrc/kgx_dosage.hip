@@ -517,7 +517,7 @@ int kgx_population_resize(kgx_pop* pop, uint64_t n_variants) {
           return fail(KGX_ENOMEM, "hipMalloc of %llu bytes for %llu dosage rows on device %d failed", (unsigned long long)(sh.pitch * capacity),
                       (unsigned long long)capacity, sh.dev->id);
         }
-        const uint64_t held = sh.pitch * sh.capacity;
+        const uint64_t held = sh.pitch * sh.n_variants;            // the rows in use; what a shrink left behind them is not carried over
         if ((held && hipMemcpyAsync(grown, sh.d_rows, held, hipMemcpyDeviceToDevice, sh.dev->stream) != hipSuccess) ||
             hipMemsetAsync(grown + held, 0, sh.pitch * capacity - held, sh.dev->stream) != hipSuccess ||
             hipStreamSynchronize(sh.dev->stream) != hipSuccess) {
@@ -529,6 +529,10 @@ int kgx_population_resize(kgx_pop* pop, uint64_t n_variants) {
       if (sh.d_alloc) (void)hipFree(sh.d_alloc);
       sh.d_alloc = sh.d_rows = grown;
       sh.capacity = capacity;
+    } else if (n_variants > sh.n_variants && sh.pitch) {
+      // within the allocation: rows a shrink left behind must read as empty again
+      KGX_HIP(hipMemsetAsync(sh.d_rows + sh.pitch * sh.n_variants, 0, sh.pitch * (n_variants - sh.n_variants), sh.dev->stream));
+      KGX_HIP(hipStreamSynchronize(sh.dev->stream));
     }
     if (n_variants != sh.n_variants) {                       // the per-variant columns follow the row count: re-created on demand
       if (sh.d_af) { (void)hipFree(sh.d_af); sh.d_af = nullptr; }

@@ -52,6 +52,10 @@ def dosage_results(kgx, G, V, codes, bins, n_bins, groups):
     pop.load_dosage2(kgx.pack_dosage2(codes[:extra]), V)
     out["k2_grown"] = pop.allele_count_by_locus()
     out["k3_grown"] = pop.count_by_genome()
+    pop.resize(V)                                            # shrink, then grow within the allocation: the rows come back empty
+    pop.resize(V + extra)
+    regrown = pop.allele_count_by_locus()
+    assert np.array_equal(regrown[:V], out["k2"]) and np.all(regrown[V:, 0] == G) and not regrown[V:, 1:].any()
     pop.close()
     return out
 
