@@ -249,16 +249,21 @@ int kgx_locus_class_frequencies(const double* minor_af, uint64_t n_loci, uint32_
  * alt is not in the locus's AlleleFreqVector; phased != 0 when the two copies of a homozygous alt carry different
  * phases (1000-Genomes style); algorithm = KGX_ALGO_*.  out[g1-g0] (host).  locus_index and minor_af may be host
  * pointers or pointers to memory of a bound device (a table kept resident between calls is then copied device to
- * device).  Genomes are independent: every shard the range touches is swept on its own device at the same time, no exchange. */
+ * device).  Genomes are independent: every shard the range touches is swept on its own device at the same time, no exchange.
+ * The reference's random restarts are fixed starts here (the midpoints of its start intervals): HallME runs its 50
+ * expectation steps from 0.25; Loglikelihood walks nlopt's 1-D Nelder-Mead from 0 with the reference's stopping rule
+ * (absolute simplex width 1e-6, at most 500 evaluations; _calc.cpp:131-144), one pass over the genotype bytes per
+ * evaluation for all genomes still searching. */
 int kgx_inbreed(kgx_gt8* gt, uint64_t g0, uint64_t g1, const uint32_t* locus_index, uint64_t n_selected,
                 const double* minor_af, uint32_t amax, int phased, int algorithm, kgx_locus_results* out);
+/* kgx_inbreed and the by-genome sweeps keep their per-call device buffers in one grow-only arena per device between calls
+ * (a window loop calls kgx_inbreed thousands of times), and a large Loglikelihood call two more buffers holding the
+ * genotype columns of the genomes still searching (at most ~3/4 of the swept bytes together); this frees them (they are
+ * re-created when needed). */
+int kgx_release_scratch(void);
 /* Device time (HIP events on the library streams) of the frequency sweep -- locus helpers + the K5 kernel, i.e. the one
  * pass over the genotype bytes that every estimator makes -- of the most recent successful kgx_inbreed call (the
  * slowest shard's); 0 before the first.  For bench.py / profiles: algorithmic bytes = kgx_gt8_sweep_bytes(). */
-/* kgx_inbreed keeps its per-call device buffers in one grow-only arena between calls (a window loop calls it
- * thousands of times), and a large Loglikelihood call two more buffers holding the genotype columns of the genomes
- * still searching (at most ~3/4 of the swept bytes together); this frees them (they are re-created when needed). */
-int kgx_release_scratch(void);
 double kgx_inbreed_last_sweep_ms(void);
 /* ... and of the one kernel inside it that reads the genotype bytes (k_inbreed_eval_lut<3|4>, or the SWAR / generic
  * sweep): the sweep without the per-locus helper kernels (tables, entries, segment defaults). */
