@@ -252,8 +252,8 @@ int kgx_locus_class_frequencies(const double* minor_af, uint64_t n_loci, uint32_
  * device).  Genomes are independent: every shard the range touches is swept on its own device at the same time, no exchange.
  * The reference's random restarts are fixed starts here (the midpoints of its start intervals): HallME runs its 50
  * expectation steps from 0.25; Loglikelihood walks nlopt's 1-D Nelder-Mead from 0 with the reference's stopping rule
- * (absolute simplex width 1e-6, at most 500 evaluations; _calc.cpp:131-144), one pass over the genotype bytes per
- * evaluation for all genomes still searching. */
+ * (absolute simplex width 1e-6, at most 500 evaluations; _calc.cpp:131-144); a pass over the genotype bytes serves two
+ * evaluations (a simplex' reflection and inside contraction) of every genome still searching. */
 int kgx_inbreed(kgx_gt8* gt, uint64_t g0, uint64_t g1, const uint32_t* locus_index, uint64_t n_selected,
                 const double* minor_af, uint32_t amax, int phased, int algorithm, kgx_locus_results* out);
 /* kgx_inbreed and the by-genome sweeps keep their per-call device buffers in one grow-only arena per device between calls

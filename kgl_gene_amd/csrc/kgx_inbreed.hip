@@ -120,7 +120,8 @@ int inbreed_shard(kgx_gt8_shard& sh, uint64_t g0, uint64_t g1, const uint32_t* l
   const size_t o_valid = plan.add(n_tab), o_meta = plan.add((n_tab + 8) * sizeof(uint32_t));
   const size_t o_part = plan.add(max_seg * n * kParts0 * sizeof(double)), o_segdef = plan.add(max_seg * kSegDefaults * sizeof(double));
   const size_t o_sums = plan.add(n * kParts0 * sizeof(double)), o_counts = plan.add(n * 6 * sizeof(unsigned long long));
-  const size_t o_f = plan.add(n * sizeof(double)), o_eval = plan.add(n * sizeof(double)), o_out = plan.add(n * sizeof(LocusResultsDev));
+  // (two planes of n values each for F and the objective: the paired Loglikelihood search evaluates two points per pass)
+  const size_t o_f = plan.add(2 * n * sizeof(double)), o_eval = plan.add(2 * n * sizeof(double)), o_out = plan.add(n * sizeof(LocusResultsDev));
   const size_t o_index = plan.add((n_sel + 8) * sizeof(uint32_t)), o_golden = plan.add(n * sizeof(GoldenState));
   const size_t o_brent = plan.add(n * sizeof(BrentState)), o_running = plan.add(sizeof(unsigned int));
   // The class-frequency sums of the defaults in the reference's own (sequential) summation order (k_seq_* kernels): from
@@ -171,7 +172,7 @@ int inbreed_shard(kgx_gt8_shard& sh, uint64_t g0, uint64_t g1, const uint32_t* l
   try_hip(hipMemsetAsync(d_counts, 0, n * 6 * sizeof(unsigned long long), st), KGX_EHIP, "memset(counts)");
   // (the table sweep and the 16-genome SWAR sweep pre-fill every partial with the segment defaults: k_fill_defaults)
   if (!(n_sel && (table_sweep || swar16))) try_hip(hipMemsetAsync(d_part, 0, n_seg * n * kParts0 * sizeof(double), st), KGX_EHIP, "memset(partials)");
-  try_hip(hipMemsetAsync(d_f, 0, n * sizeof(double), st), KGX_EHIP, "memset(f)");
+  try_hip(hipMemsetAsync(d_f, 0, 2 * n * sizeof(double), st), KGX_EHIP, "memset(f)");
 
   const dim3 grid(gx, static_cast<uint32_t>(n_seg));
   const uint32_t* gt32 = reinterpret_cast<const uint32_t*>(sh.d_gt);
@@ -214,6 +215,7 @@ int inbreed_shard(kgx_gt8_shard& sh, uint64_t g0, uint64_t g1, const uint32_t* l
     else if (mode == 3) hipLaunchKernelGGL((k_eval_entries<3>), dim3(tab_grid), dim3(kBlock), 0, dev.stream, d_table, d_valid, n_sel, amax, phased, d_entries);
     else hipLaunchKernelGGL((k_eval_entries<4>), dim3(tab_grid), dim3(kBlock), 0, dev.stream, d_table, d_valid, n_sel, amax, phased, d_entries);
   };
+  bool ll_pair = false;                                       // Loglikelihood passes with two values of F per genome (set by its driver below)
   auto sweep = [&](int mode) {
     if (n_sel == 0) return;
     if (mode == 0 && sequential_defaults) {
@@ -271,6 +273,14 @@ int inbreed_shard(kgx_gt8_shard& sh, uint64_t g0, uint64_t g1, const uint32_t* l
   } while (0)
       if (mode == 1) {
         if (eval_gpl == 8) KGX_EVAL_FOLD(1, 8); else KGX_EVAL_FOLD(1, 4);
+      } else if (mode == 2 && ll_pair) {
+#define KGX_EVAL_PAIR(W, FOLD)                                                                                                      \
+  hipLaunchKernelGGL((k_inbreed_eval_lut<2, W, FOLD, true>), dim3(eval_grid(n, W, launch_n_seg)),                                  \
+                     dim3(kBlock), 0, st, gt32, dwords_per_row, g0, n, d_index, n_sel,                                               \
+                     launch_per_seg, d_entries, d_table, d_valid, amax, d_f, d_part, d_counts, d_segcnt, eval_xcds)
+        if (eval_gpl == 8) { if (eval_fold) KGX_EVAL_PAIR(8, true); else KGX_EVAL_PAIR(8, false); }
+        else { if (eval_fold) KGX_EVAL_PAIR(4, true); else KGX_EVAL_PAIR(4, false); }
+#undef KGX_EVAL_PAIR
       } else if (mode == 2) {
         if (eval_gpl == 8) KGX_EVAL_FOLD(2, 8); else KGX_EVAL_FOLD(2, 4);
       } else if (mode == 3) {
@@ -315,6 +325,9 @@ int inbreed_shard(kgx_gt8_shard& sh, uint64_t g0, uint64_t g1, const uint32_t* l
     // Loglikelihood's search: the reference optimiser's own path (Nelder-Mead, see nm_advance) unless KGX_K7_SEARCH=brent
     const char* search_name = std::getenv("KGX_K7_SEARCH");
     const int search = search_name && std::strcmp(search_name, "brent") == 0 ? kSearchBrent : kSearchNelderMead;
+    // ... two evaluations per pass where a pass is a sweep over the matrix (the table passes): same path, half the passes
+    const int pass_search = (search == kSearchNelderMead && eval_lut && !env_int("KGX_K7_NO_PAIR", 0)) ? kSearchNelderMeadPair : search;
+    const uint64_t planes = pass_search == kSearchNelderMeadPair ? 2 : 1;
     if (wave_path) {
       const uint32_t wave_grid = static_cast<uint32_t>((n * kWave + kBlock - 1) / kBlock);
       try_hip(hipMemsetAsync(d_running, 0, sizeof(unsigned int), st), KGX_EHIP, "memset(evaluations)");
@@ -356,7 +369,8 @@ int inbreed_shard(kgx_gt8_shard& sh, uint64_t g0, uint64_t g1, const uint32_t* l
         // instead (brent_start): 11 instead of 15 evaluations on a population with F in [0, 0.1], but where the clamped
         // objective has several local maxima (F < 0) it may settle on another one than a search from the middle does --
         // the reference itself lands on one or another from its random starts -- so it is not the default.
-        hipLaunchKernelGGL(k_brent_init, dim3(lin_grid), dim3(kBlock), 0, st, d_counts, d_sums, n, env_int("KGX_K7_ESTIMATE_START", 0), search, d_brent, d_f);
+        ll_pair = planes == 2;
+        hipLaunchKernelGGL(k_brent_init, dim3(lin_grid), dim3(kBlock), 0, st, d_counts, d_sums, n, env_int("KGX_K7_ESTIMATE_START", 0), pass_search, d_brent, d_f);
         // Brent: golden section alone would need 38, and its safeguard keeps that bound; Nelder-Mead: the reference's own cap
         const int kMaxEvaluations = search == kSearchNelderMead ? 500 : 60;
         // The genomes still searching.  When at most half of them are left -- and the call is big enough for it to pay --
@@ -374,11 +388,12 @@ int inbreed_shard(kgx_gt8_shard& sh, uint64_t g0, uint64_t g1, const uint32_t* l
         std::vector<BrentState> host_states;
         auto evaluate = [&]() {
           if (act_gt == gt32) { sweep(2); return; }
-#define KGX_EVAL2(FOLD)                                                                                                              \
-  hipLaunchKernelGGL((k_inbreed_eval_lut<2, 8, FOLD>), dim3(eval_grid(n_act, 8, eval_n_seg)),                                       \
+#define KGX_EVAL2(FOLD, PAIR)                                                                                                        \
+  hipLaunchKernelGGL((k_inbreed_eval_lut<2, 8, FOLD, PAIR>), dim3(eval_grid(n_act, 8, eval_n_seg)),                                 \
                      dim3(kBlock), 0, st, act_gt, act_dwords_per_row, act_g0, n_act, act_index,                                      \
                      n_sel, eval_per_seg, d_entries, d_table, d_valid, amax, act_f, d_part, d_counts, d_segcnt, eval_xcds)
-          if (eval_fold) KGX_EVAL2(true); else KGX_EVAL2(false);
+          if (ll_pair) { if (eval_fold) KGX_EVAL2(true, true); else KGX_EVAL2(false, true); }
+          else { if (eval_fold) KGX_EVAL2(true, false); else KGX_EVAL2(false, false); }
 #undef KGX_EVAL2
         };
         const bool may_compact = eval_lut && !env_int("KGX_K7_NO_COMPACT", 0);
@@ -387,9 +402,9 @@ int inbreed_shard(kgx_gt8_shard& sh, uint64_t g0, uint64_t g1, const uint32_t* l
         for (int it = 0; it < kMaxEvaluations && rc == KGX_OK; ++it) {
           evaluate();
           const uint32_t act_grid = stream_grid(dev, n_act, kBlock);
-          hipLaunchKernelGGL(k_reduce_parts, dim3(reduce_grid(n_act)), dim3(kBlock), 0, st, d_part, pass_n_seg, n_act, nullptr, d_eval);
+          hipLaunchKernelGGL(k_reduce_parts, dim3(reduce_grid(planes * n_act)), dim3(kBlock), 0, st, d_part, pass_n_seg, planes * n_act, nullptr, d_eval);
           try_hip(hipMemsetAsync(d_running, 0, sizeof(unsigned int), st), KGX_EHIP, "memset(running)");
-          hipLaunchKernelGGL(k_brent_step, dim3(act_grid), dim3(kBlock), 0, st, act_brent, d_eval, n_act, it == 0 ? 0 : 1, search, act_f, d_running,
+          hipLaunchKernelGGL(k_brent_step, dim3(act_grid), dim3(kBlock), 0, st, act_brent, d_eval, n_act, it == 0 ? 0 : 1, pass_search, act_f, d_running,
                              act_global, d_f);
           unsigned int running = 0;
           try_hip(hipMemcpyAsync(&running, d_running, sizeof(unsigned int), hipMemcpyDeviceToHost, st), KGX_EHIP, "D2H(running)");
@@ -413,7 +428,7 @@ int inbreed_shard(kgx_gt8_shard& sh, uint64_t g0, uint64_t g1, const uint32_t* l
           // Level k lives in the library's ping-pong buffer k & 1 (what that buffer held, level k - 2, is no longer read);
           // the buffers stay allocated between calls like the scratch arena (kgx_release_scratch frees them).
           ScratchPlan level;
-          const size_t o_gt = level.add(n_sel * new_pitch), o_st = level.add(n_new * sizeof(BrentState)), o_nf = level.add(n_new * sizeof(double));
+          const size_t o_gt = level.add(n_sel * new_pitch), o_st = level.add(n_new * sizeof(BrentState)), o_nf = level.add(planes * n_new * sizeof(double));
           const size_t o_col = level.add(n_new * sizeof(uint32_t)), o_glob = level.add(n_new * sizeof(uint32_t));
           const int slot = compaction_level & 1;
           if (dev.compact_bytes[slot] < level.total) {
@@ -442,7 +457,8 @@ int inbreed_shard(kgx_gt8_shard& sh, uint64_t g0, uint64_t g1, const uint32_t* l
           const dim3 gather_grid(static_cast<uint32_t>((new_pitch / 4 + kBlock - 1) / kBlock), static_cast<uint32_t>(std::min<uint64_t>(n_sel, 8192)));
           hipLaunchKernelGGL(k_gather_columns, gather_grid, dim3(kBlock), 0, st, reinterpret_cast<const uint8_t*>(act_gt), act_dwords_per_row * 4,
                              act_g0, act_index, n_sel, new_columns, n_new, new_gt, new_pitch);
-          hipLaunchKernelGGL(k_gather_states, dim3(stream_grid(dev, n_new, kBlock)), dim3(kBlock), 0, st, act_brent, act_f, new_columns, n_new, new_brent, new_f);
+          hipLaunchKernelGGL(k_gather_states, dim3(stream_grid(dev, n_new, kBlock)), dim3(kBlock), 0, st, act_brent, act_f, n_act, static_cast<int>(planes),
+                             new_columns, n_new, new_brent, new_f);
           try_hip(hipStreamSynchronize(st), KGX_EHIP, "sync");           // columns / new_global leave scope
           act_gt = reinterpret_cast<const uint32_t*>(new_gt);
           act_dwords_per_row = new_pitch / 4;
@@ -454,7 +470,8 @@ int inbreed_shard(kgx_gt8_shard& sh, uint64_t g0, uint64_t g1, const uint32_t* l
           n_act = n_new;
           global_of.swap(new_global);
         }
-        hipLaunchKernelGGL(k_brent_step, dim3(stream_grid(dev, n_act, kBlock)), dim3(kBlock), 0, st, act_brent, d_eval, n_act, 2, search, act_f, d_running, act_global, d_f);
+        hipLaunchKernelGGL(k_brent_step, dim3(stream_grid(dev, n_act, kBlock)), dim3(kBlock), 0, st, act_brent, d_eval, n_act, 2, pass_search, act_f, d_running, act_global, d_f);
+        ll_pair = false;
         try_hip(hipStreamSynchronize(st), KGX_EHIP, "sync");
       } else {
       const double inv_phi = 0.6180339887498949;

@@ -283,6 +283,9 @@ k_inbreed_sweep(const uint32_t* __restrict__ gt, uint64_t dwords_per_row, uint64
 #ifndef KGX_EVAL_DEPTH
 #define KGX_EVAL_DEPTH 1            // table reads in flight ahead of the arithmetic, in groups of four (mode 2: 16-byte entries, 40 registers of state)
 #endif
+#ifndef KGX_EVAL_DEPTH_PAIR
+#define KGX_EVAL_DEPTH_PAIR 0       // ... mode 2 with two values of F: 80 registers of state, and 24 fp64 operations per group to wait under
+#endif
 #ifndef KGX_EVAL_DEPTH3
 #define KGX_EVAL_DEPTH3 2           // ... modes 1, 3, 4, which have the registers for it
 #endif
@@ -378,7 +381,10 @@ __device__ __forceinline__ uint32_t byte_shifted(uint32_t w, uint32_t four) {
 // registers, fetched two batches ahead; the genotype dwords one batch ahead), and each cell is then one LDS read and a
 // few fp64 / integer operations.  The loop is unrolled over the two tables, so a cell's LDS address is one SDWA shift
 // of its slot byte plus an immediate offset.
-template <int MODE, int GPL, bool FOLD>
+// PAIR (MODE 2 only): TWO values of F per genome in one pass -- f_in[g] and f_in[n_genomes + g], results in
+// part[(2 * seg + k) * n_genomes + g] -- from the same table read: the Nelder-Mead search almost always (97 % of its steps)
+// needs the reflected point and the inside-contraction point of the same simplex, both known before either is evaluated.
+template <int MODE, int GPL, bool FOLD, bool PAIR = false>
 __global__ void __launch_bounds__(kBlock)
 k_inbreed_eval_lut(const uint32_t* __restrict__ gt, uint64_t dwords_per_row, uint64_t g0, uint64_t n_genomes,
                    const uint32_t* __restrict__ locus_index, uint64_t n_sel, uint64_t loci_per_seg,
@@ -428,6 +434,9 @@ k_inbreed_eval_lut(const uint32_t* __restrict__ gt, uint64_t dwords_per_row, uin
 
   double F[kCounts ? 1 : GPL], one_minus_F[MODE == 1 ? GPL : 1], run_a[MODE == 4 ? 1 : GPL], run_b[MODE == 1 ? GPL : 1];
   int expo[MODE == 2 ? GPL : 1];   // MODE 2: run_a = product;  MODE 1: run_a / run_b = N / D;  MODE 3: run_a = Ritland sum
+  static_assert(!PAIR || MODE == 2, "two values of F per pass: the log-likelihood only");
+  double F_pair[PAIR ? GPL : 1], run_pair[PAIR ? GPL : 1];         // PAIR: the second value of F and its running product
+  int expo_pair[PAIR ? GPL : 1];
   uint32_t cnt_lo[kCounts ? GPL : 1], cnt_hi[kCounts ? GPL : 1];   // MODE 3, 4: packed class counters (see above)
 #pragma unroll
   for (int j = 0; j < GPL; ++j) {
@@ -440,6 +449,11 @@ k_inbreed_eval_lut(const uint32_t* __restrict__ gt, uint64_t dwords_per_row, uin
       one_minus_F[j] = 1.0 - F[j];
     } else if constexpr (MODE == 2) {
       expo[j] = 0;
+      if constexpr (PAIR) {
+        F_pair[j] = g < n_genomes ? f_in[n_genomes + g] : 0.0;
+        run_pair[j] = 1.0;
+        expo_pair[j] = 0;
+      }
     } else {
       cnt_lo[j] = cnt_hi[j] = 0u;
     }
@@ -533,7 +547,7 @@ k_inbreed_eval_lut(const uint32_t* __restrict__ gt, uint64_t dwords_per_row, uin
       // arithmetic: the reads' latency passes under that of the groups before it, and the registers stay those of
       // kEvalDepth + 1 groups -- left alone the compiler either waits for every read where it issues it or (machine
       // sinking: nothing in this block reads the sums) carries all 64 reads of the batch past the batch.
-      constexpr int kGroups = kEvalBatch * DW, kDepth = (kCounts || sizeof(Entry) == 8) ? KGX_EVAL_DEPTH3 : KGX_EVAL_DEPTH;
+      constexpr int kGroups = kEvalBatch * DW, kDepth = PAIR ? KGX_EVAL_DEPTH_PAIR : (kCounts || sizeof(Entry) == 8) ? KGX_EVAL_DEPTH3 : KGX_EVAL_DEPTH;
       auto read_group = [&](int q, Entry (&e)[4]) {
         const uint32_t slots = slots_of(w[q / DW][q % DW]);
         e[0] = entry_at(q / DW, byte_shifted<0>(slots, four));
@@ -557,6 +571,7 @@ k_inbreed_eval_lut(const uint32_t* __restrict__ gt, uint64_t dwords_per_row, uin
             if constexpr (MODE == 4) asm volatile("" : "+v"(cnt_lo[j]), "+v"(cnt_hi[j]));
             else if constexpr (MODE == 3) asm volatile("" : "+v"(run_a[j]), "+v"(cnt_lo[j]), "+v"(cnt_hi[j]));
             else if constexpr (MODE == 1) asm volatile("" : "+v"(run_a[j]), "+v"(run_b[j]));
+            else if constexpr (PAIR) asm volatile("" : "+v"(run_a[j]), "+v"(run_pair[j]));
             else asm volatile("" : "+v"(run_a[j]));
           }
           __builtin_amdgcn_sched_barrier(0);
@@ -568,6 +583,10 @@ k_inbreed_eval_lut(const uint32_t* __restrict__ gt, uint64_t dwords_per_row, uin
         walk([&](int j, const EvalEntry& e) {
           const double p = __builtin_fmin(__builtin_fmax(__builtin_fma(F[kCounts ? 0 : j], e.d, e.y), 0.0), 1.0);
           run_a[j] *= __builtin_fmax(p, 1e-10);
+          if constexpr (PAIR) {
+            const double q = __builtin_fmin(__builtin_fmax(__builtin_fma(F_pair[j], e.d, e.y), 0.0), 1.0);
+            run_pair[j] *= __builtin_fmax(q, 1e-10);
+          }
         });
       } else if constexpr (kCounts) {
         walk([&](int j, const Entry& e) {
@@ -632,6 +651,10 @@ k_inbreed_eval_lut(const uint32_t* __restrict__ gt, uint64_t dwords_per_row, uin
         if constexpr (MODE == 2) {
           expo[j] += __builtin_amdgcn_frexp_exp(run_a[j]);
           run_a[j] = __builtin_amdgcn_frexp_mant(run_a[j]);
+          if constexpr (PAIR) {
+            expo_pair[j] += __builtin_amdgcn_frexp_exp(run_pair[j]);
+            run_pair[j] = __builtin_amdgcn_frexp_mant(run_pair[j]);
+          }
         } else if constexpr (MODE == 1 && BUF == 1) {
           run_a[j] = __builtin_ldexp(run_a[j], -__builtin_amdgcn_frexp_exp(run_b[j]));
           run_b[j] = __builtin_amdgcn_frexp_mant(run_b[j]);
@@ -664,7 +687,8 @@ k_inbreed_eval_lut(const uint32_t* __restrict__ gt, uint64_t dwords_per_row, uin
     const uint64_t g = lane * GPL + j;
     if (g >= n_genomes) continue;
     if constexpr (MODE == 2) {
-      part[seg * n_genomes + g] = log(run_a[j]) + static_cast<double>(expo[j]) * 0.6931471805599453;
+      part[(PAIR ? 2 * seg : seg) * n_genomes + g] = log(run_a[j]) + static_cast<double>(expo[j]) * 0.6931471805599453;
+      if constexpr (PAIR) part[(2 * seg + 1) * n_genomes + g] = log(run_pair[j]) + static_cast<double>(expo_pair[j]) * 0.6931471805599453;
     } else if constexpr (MODE == 1) {
       part[seg * n_genomes + g] = run_a[j] / run_b[j];
     } else {
@@ -1518,15 +1542,71 @@ __device__ __forceinline__ void nm_advance(BrentState& s, double f) {      // f:
   s.widened = kNmReflect;
 }
 
+// The same search with TWO evaluations per step (k_inbreed_eval_lut<2, ., ., true>): the two start points together, then
+// for every simplex the reflected point AND the inside-contraction point -- both follow from the simplex alone, and in
+// one dimension 97 % of the steps end in that contraction (once the maximum is bracketed, the reflection lands beyond the
+// worse point).  When the reflection is better than the worst point after all, the expansion or the outside contraction
+// is evaluated in the next step (its twin slot repeats it).  Every comparison is made on the values the one-at-a-time
+// search would have seen, in its order: the same path, the same result, in about half the passes over the bytes.
+//   u, d = the two points to evaluate next;  e counts the evaluations the one-at-a-time search would have made.
+enum : int { kNm2Start = 0, kNm2Reflect, kNm2Expand, kNm2Outside };
+constexpr int kSearchNelderMeadPair = 2;
+__device__ __forceinline__ BrentState nm2_start() {
+  BrentState s{};
+  s.a = 0.0;
+  s.b = 0.5;
+  s.u = s.a; s.d = s.b; s.x = s.a;
+  s.widened = kNm2Start;
+  return s;
+}
+__device__ __forceinline__ void nm2_advance(BrentState& s, double f0, double f1) {     // the objective at s.u and at s.d
+  auto clampx = [](double x) { return x > 1.0 ? 1.0 : (x < -1.0 ? -1.0 : x); };
+  switch (s.widened) {
+    case kNm2Start:
+      s.fx = f0; s.fw = f1;
+      s.e = 2.0;
+      break;
+    case kNm2Reflect:
+      s.v = s.u; s.fv = f0;                                    // reflected point
+      if (f0 > s.fx) { s.u = s.d = clampx(s.a + 2.0 * (s.a - s.b)); s.widened = kNm2Expand; return; }
+      if (f0 > s.fw) { s.u = s.d = clampx(s.a + 0.5 * (s.v - s.a)); s.widened = kNm2Outside; return; }
+      s.b = s.d; s.fw = f1;                                    // inside contraction: its point was evaluated with the reflection
+      s.e += 2.0;
+      break;
+    case kNm2Expand:
+      if (f0 > s.fv) { s.b = s.u; s.fw = f0; } else { s.b = s.v; s.fw = s.fv; }
+      s.e += 2.0;
+      break;
+    default:                                                   // outside contraction
+      if (f0 >= s.fv) { s.b = s.u; s.fw = f0; } else { s.b = s.v; s.fw = s.fv; }
+      s.e += 2.0;
+      break;
+  }
+  if (s.fw > s.fx) {                                           // a best, b worst
+    const double x = s.a, fx = s.fx;
+    s.a = s.b; s.fx = s.fw;
+    s.b = x; s.fw = fx;
+  }
+  if (fabs(s.a - s.b) < 1e-6 || s.e >= 500.0) {
+    s.x = s.a;
+    s.done = 1;
+    return;
+  }
+  s.u = clampx(s.a + (s.a - s.b));
+  s.d = s.a + 0.5 * (s.b - s.a);
+  s.widened = kNm2Reflect;
+}
+
 __global__ void __launch_bounds__(kBlock)
 k_brent_init(const unsigned long long* __restrict__ counts, const double* __restrict__ sums, uint64_t n, int use_estimate, int search,
              BrentState* __restrict__ st, double* __restrict__ f_next) {
   for (uint64_t g = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x; g < n;
        g += static_cast<uint64_t>(gridDim.x) * blockDim.x) {
-    const BrentState s = search == kSearchNelderMead ? nm_start()
+    const BrentState s = search == kSearchNelderMeadPair ? nm2_start() : search == kSearchNelderMead ? nm_start()
                          : use_estimate ? brent_start(counts + g * 6, sums + g * kParts0) : brent_start(nullptr, nullptr);
     st[g] = s;
     f_next[g] = s.x;
+    if (search == kSearchNelderMeadPair) f_next[n + g] = s.d;                  // two planes of n values
   }
 }
 
@@ -1544,13 +1624,15 @@ k_brent_step(BrentState* __restrict__ st, const double* __restrict__ f_eval, uin
       continue;
     }
     if (!s.done) {
-      if (search == kSearchNelderMead) nm_advance(s, f_eval[g]);
+      if (search == kSearchNelderMeadPair) nm2_advance(s, f_eval[g], f_eval[n + g]);
+      else if (search == kSearchNelderMead) nm_advance(s, f_eval[g]);
       else brent_advance(s, -f_eval[g], mode == 0);
       if (!s.done) atomicAdd(still_running, 1u);
       else if (global_of) result[global_of[g]] = s.x;
       st[g] = s;
     }
     f_next[g] = s.done ? s.x : s.u;
+    if (search == kSearchNelderMeadPair) f_next[n + g] = s.done ? s.x : s.d;
   }
 }
 
@@ -1577,12 +1659,12 @@ k_gather_columns(const uint8_t* __restrict__ src, uint64_t src_pitch, uint64_t s
 }
 
 __global__ void __launch_bounds__(kBlock)
-k_gather_states(const BrentState* __restrict__ st, const double* __restrict__ f, const uint32_t* __restrict__ columns, uint64_t n_columns,
-                BrentState* __restrict__ st_out, double* __restrict__ f_out) {
+k_gather_states(const BrentState* __restrict__ st, const double* __restrict__ f, uint64_t n_source, int planes, const uint32_t* __restrict__ columns,
+                uint64_t n_columns, BrentState* __restrict__ st_out, double* __restrict__ f_out) {
   for (uint64_t j = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x; j < n_columns;
        j += static_cast<uint64_t>(gridDim.x) * blockDim.x) {
     st_out[j] = st[columns[j]];
-    f_out[j] = f[columns[j]];
+    for (int k = 0; k < planes; ++k) f_out[k * n_columns + j] = f[k * n_source + columns[j]];      // planes of n values (the paired search: 2)
   }
 }
 
