@@ -112,6 +112,15 @@ int kgx_population_load_dosage_u8(kgx_pop* pop, const uint8_t* src, uint64_t g0,
 /* Device → host copy of packed rows [v0,v1) with dst_pitch >= ceil(G/4) (tests). */
 int kgx_population_read_dosage2(const kgx_pop* pop, uint8_t* dst, uint64_t dst_pitch,
                                 uint64_t v0, uint64_t v1);
+/* Genome-level filter, evaluated on the device by every sweep: keep[g] != 0 = genome g takes part, NULL = all do again.
+ * Replaces the genome filters the PfEMP package applies before counting -- Pf7SampleResource::filterPassQCGenomes
+ * (kga_analytic/kga_analysis_library/kga_analysis_lib_PfFilter.cpp:124-158) and Pf7FwsResource::viewFilterFWS
+ * (kgl_genomics/kgl_parser/kgl_pf7_fws_parser.cpp:55-70), both PopulationDB::viewFilter(GenomeListFilter) -- without
+ * re-flattening or re-uploading the population.  Under a mask the results are those of the filtered PopulationDB:
+ * K2 counts over the kept genomes (referenceHomozygous = kept - carriers; a row left with no carrier -- kept,0,0,0 -- is a
+ * variant the filtered population does not hold: the reference has no entry for it, the caller skips it), K3 leaves such
+ * rows out of every kept genome's referenceHomozygous, and the genomes left out read as zero in K3 / K8 results. */
+int kgx_population_set_genome_mask(kgx_pop* pop, const uint8_t* keep /* host [n_genomes] or NULL */);
 /* Per-variant allele frequency as parsed from VCF INFO (float32, the reference's storage type,
  * kgl_parser/kgl_variant_factory_vcf_parse_info.h:27-37); NaN = missing. */
 int kgx_population_set_af(kgx_pop* pop, const float* af /* [n_variants] */);

@@ -54,6 +54,7 @@ _SIGNATURES = {
     "kgx_population_load_dosage_u8": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64]),
     "kgx_population_read_dosage2": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64]),
     "kgx_population_set_af": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "kgx_population_set_genome_mask": (C.c_int, [C.c_void_p, C.c_void_p]),
     "kgx_population_get_af": (C.c_int, [C.c_void_p, C.c_void_p]),
     "kgx_population_synth_biallelic": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64]),
     "kgx_synth_biallelic_host": (C.c_int, [C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64,
@@ -289,6 +290,16 @@ class Population:
         out = np.zeros((v1 - v0, (self.n_genomes + 3) // 4), dtype=np.uint8)
         check(lib().kgx_population_read_dosage2(self._h, ptr(out), out.shape[1], v0, v1))
         return out
+
+    def set_genome_mask(self, keep: np.ndarray | None) -> None:
+        """keep[g] != 0: genome g takes part in every sweep (the reference's genome-list filters); None lifts the mask."""
+        if keep is None:
+            check(lib().kgx_population_set_genome_mask(self._h, None))
+            return
+        k = np.ascontiguousarray(np.asarray(keep) != 0, dtype=np.uint8)
+        if k.shape != (self.n_genomes,):
+            raise ValueError("keep must be [n_genomes]")
+        check(lib().kgx_population_set_genome_mask(self._h, ptr(k)))
 
     def set_af(self, af: np.ndarray) -> None:
         a = np.ascontiguousarray(af, dtype=np.float32)

@@ -87,7 +87,7 @@ struct DeviceStreamSink final : kgl::analysis::gpu::StreamSink {
 };
 
 bool kga::GpuAlleleAnalysis::initializeAnalysis(const std::string& work_directory, const ActiveParameterList& named_parameters,
-                                                const std::shared_ptr<const AnalysisResources>&) {
+                                                const std::shared_ptr<const AnalysisResources>& resource_ptr) {
   ExecEnv::log().info("Analysis Id: {} initialized with work directory: {}", ident(), work_directory);
   work_directory_ = work_directory;
   for (const auto& [block_name, named_vector] : named_parameters.getMap()) {
@@ -99,6 +99,35 @@ bool kga::GpuAlleleAnalysis::initializeAnalysis(const std::string& work_director
       // per-record quality filter (P7VariantFilter) runs before the counting
       if (auto v = parameter_map.getString("VcfFlavour")) vcf_flavour_ = v.value().front();
       if (auto v = parameter_map.getBool("Pf7QualityFilter")) pf7_quality_filter_ = v.value();
+      // the genome-level filters of FilterPf7 (kga_analysis_lib_PfFilter.h:58-66) and the location summary's radius
+      if (auto v = parameter_map.getString("LocationFile")) location_file_ = v.value().front();
+      if (auto v = parameter_map.getBool("Pf7FilterQC")) filter_qc_ = v.value();
+      if (auto v = parameter_map.getBool("Pf7FilterFWS")) filter_fws_ = v.value();
+      if (auto v = parameter_map.getFloat("Pf7FwsThreshold")) fws_monoclonal_threshold_ = v.value().front();
+      if (auto v = parameter_map.getFloat("LocationRadiusKm")) location_radius_km_ = v.value().front();
+    }
+  }
+  // The Pf7 sample resources are optional here (PfEMPAnalysis requires them, kga_analysis_PfEMP.cpp:24-28): both or neither.
+  if (resource_ptr) {
+    const auto samples = resource_ptr->getResources(ResourceProperties::PF7SAMPLE_RESOURCE_ID_);
+    const auto fws = resource_ptr->getResources(ResourceProperties::PF7FWS_RESOURCE_ID_);
+    if (samples.size() > 1 || fws.size() > 1 || samples.size() != fws.size()) {
+      ExecEnv::log().error("GpuAlleleAnalysis::initializeAnalysis; expected one Pf7Sample and one Pf7Fws resource (or neither), found: {} and {}",
+                           samples.size(), fws.size());
+      return false;
+    }
+    if (samples.size() == 1) {
+      pf7_sample_ptr_ = std::dynamic_pointer_cast<const Pf7SampleResource>(samples.front());
+      pf7_fws_ptr_ = std::dynamic_pointer_cast<const Pf7FwsResource>(fws.front());
+      if (!pf7_sample_ptr_ || !pf7_fws_ptr_) {
+        ExecEnv::log().error("GpuAlleleAnalysis::initializeAnalysis; invalid Pf7Sample / Pf7Fws resource type");
+        return false;
+      }
+      const auto physical_distance_ptr = std::make_shared<const Pf7SampleLocation>(*pf7_sample_ptr_);
+      hetero_homo_zygous_.setResources(pf7_sample_ptr_, pf7_fws_ptr_, physical_distance_ptr);
+      ExecEnv::log().info("GpuAlleleAnalysis; Pf7 sample resources: {} samples, {} FWS values, {} locations; QC filter: {}, monoclonal FWS filter: {} (>= {})",
+                          pf7_sample_ptr_->getMap().size(), pf7_fws_ptr_->getMap().size(), physical_distance_ptr->locationMap().size(),
+                          filter_qc_ ? "on" : "off", filter_fws_ ? "on" : "off", fws_monoclonal_threshold_);
     }
   }
   std::string binding, binding_error;
@@ -138,7 +167,7 @@ bool kga::GpuAlleleAnalysis::sweepPopulation(const PopulationDB& population) {
   const gpu::FlatPopulation flat = gpu::flattenPopulation(population);
   // contigs a genome holds without any variant still get a (zero) record (heterozygous.cpp:38-41)
   for (const auto& [genome_id, genome_ptr] : population.getMap()) {
-    auto& contig_map = variant_analysis_map_[genome_id];
+    auto& contig_map = hetero_homo_zygous_.analysisMap()[genome_id];
     for (const auto& [contig_id, contig_ptr] : genome_ptr->getMap()) contig_map.try_emplace(contig_id);
   }
   return sweepFlat(flat, population.populationId());
@@ -187,7 +216,8 @@ bool kga::GpuAlleleAnalysis::sweepVcfFile(const std::string& file_name) {
   if (vcf_flavour_ == "Genome1000") return sweepFlat(flat, file_name, dev.handle);
   // every genome holds every contig of the header, carrier or not (PfVCFImpl::setupPopulationStructure): zero records
   for (const auto& genome_id : flat.genome_ids) {
-    auto& contig_map = variant_analysis_map_[genome_id];
+    if (!keepGenome(genome_id)) continue;
+    auto& contig_map = hetero_homo_zygous_.analysisMap()[genome_id];
     for (const auto& contig_id : flat.contig_ids) contig_map.try_emplace(contig_id);
   }
   return sweepFlat(flat, file_name, dev.handle);
@@ -201,9 +231,20 @@ bool kga::GpuAlleleAnalysis::sweepFlat(const gpu::FlatPopulation& flat, const st
   ExecEnv::log().info("GpuAlleleAnalysis; population: {}, genomes: {}, distinct variants: {}, Variant objects: {}",
                       label, G, V, flat.variant_objects);
   if (G == 0) return true;
-  for (const auto& genome_id : flat.genome_ids) {
-    genome_fws_map_.try_emplace(genome_id, GpuFwsFrequencyArray());
-    variant_analysis_map_.try_emplace(genome_id);
+  // FilterPf7::qualityFilter's genome part (kga_analysis_lib_PfFilter.cpp:26-58): the genomes that pass QC and are
+  // monoclonal take part, the others are absent from everything below -- a genome mask on the device population.
+  const bool masked = genomeFilterActive();
+  std::vector<uint8_t> keep(G, 1);
+  if (masked) {
+    uint64_t kept = 0;
+    for (uint64_t g = 0; g < G; ++g) kept += keep[g] = keepGenome(flat.genome_ids[g]) ? 1 : 0;
+    ExecEnv::log().info("GpuAlleleAnalysis; Pf7 genome filters (QC pass: {}, FWS >= {}: {}) keep {} of {} genomes", filter_qc_ ? "on" : "off",
+                        fws_monoclonal_threshold_, filter_fws_ ? "on" : "off", kept, G);
+  }
+  for (uint64_t g = 0; g < G; ++g) {
+    if (!keep[g]) continue;
+    genome_fws_map_.try_emplace(flat.genome_ids[g], GpuFwsFrequencyArray());
+    hetero_homo_zygous_.analysisMap().try_emplace(flat.genome_ids[g]);
   }
   if (V == 0) return true;
 
@@ -226,6 +267,11 @@ bool kga::GpuAlleleAnalysis::sweepFlat(const gpu::FlatPopulation& flat, const st
     }
   }
 
+  if (masked && kgx_population_set_genome_mask(dev.handle, keep.data()) != KGX_OK) {
+    ExecEnv::log().error("GpuAlleleAnalysis; setting the genome mask failed: {}", kgx_last_error());
+    return false;
+  }
+
   // ---- K2: CalcFWS::updateVariantFWSMap -- summaryByVariant for every variant ------------------
   std::vector<uint32_t> by_variant(D * 4);
   if (kgx_allele_count_by_locus(dev.handle, by_variant.data()) != KGX_OK) {
@@ -233,6 +279,8 @@ bool kga::GpuAlleleAnalysis::sweepFlat(const gpu::FlatPopulation& flat, const st
     return false;
   }
   for (uint64_t v = 0; v < V; ++v) {
+    // no carrier among the genomes taking part: the filtered population does not hold the variant
+    if (masked && (by_variant[v * 4 + 1] | by_variant[v * 4 + 2] | by_variant[v * 4 + 3]) == 0) continue;
     AlleleSummmary summary;
     summary.referenceHomozygous_ = by_variant[v * 4 + 0];
     summary.minorHeterozygous_ = by_variant[v * 4 + 1];
@@ -260,6 +308,7 @@ bool kga::GpuAlleleAnalysis::sweepFlat(const gpu::FlatPopulation& flat, const st
       return false;
     }
     for (uint64_t g = 0; g < G; ++g) {
+      if (!keep[g]) continue;
       auto& freq_array = genome_fws_map_[flat.genome_ids[g]];
       for (size_t b = 0; b < gpu::FWS_FREQUENCY_ARRAY_SIZE; ++b) {
         const uint64_t* c = &by_genome[(g * gpu::FWS_FREQUENCY_ARRAY_SIZE + b) * 4];
@@ -335,7 +384,8 @@ bool kga::GpuAlleleAnalysis::sweepFlat(const gpu::FlatPopulation& flat, const st
       if (flat.rows[cell.row].is_snp) extra_snp[cell.genome * n_contigs + c] += cell.dosage;
     }
     for (uint64_t g = 0; g < G; ++g) {
-      auto& contig_map = variant_analysis_map_[flat.genome_ids[g]];
+      if (!keep[g]) continue;
+      auto& contig_map = hetero_homo_zygous_.analysisMap()[flat.genome_ids[g]];
       for (uint32_t c = 0; c < n_contigs; ++c) {
         VariantAnalysisType record;
         uint64_t copies_snp = 0, copies_indel = 0;
@@ -386,20 +436,15 @@ bool kga::GpuAlleleAnalysis::finalizeAnalysis() {
   ExecEnv::log().info("Finalize Analysis called for Analysis Id: {}", ident());
   bool ok = writeVariantResults(joinPath(work_directory_, variant_file_));
   ok = writeGenomeResults(joinPath(work_directory_, genome_file_)) && ok;
-  ok = writeHetHomResults(joinPath(work_directory_, hethom_file_)) && ok;
-  return ok;
-}
-
-double kga::GpuAlleleAnalysis::wrightsInbreeding(const VariantAnalysisType& location, const VariantAnalysisType& genome) {
-  double wrights_inbreeding{0.0};
-  if (location.total_variants_ > 0 and genome.total_variants_ > 0) {
-    const double expected = static_cast<double>(location.heterozygous_minor_alleles_ + location.heterozygous_reference_minor_alleles_) /
-                            static_cast<double>(location.total_variants_);
-    const double observed = static_cast<double>(genome.heterozygous_minor_alleles_ + genome.heterozygous_reference_minor_alleles_) /
-                            static_cast<double>(genome.total_variants_);
-    wrights_inbreeding = (expected - observed) / expected;
+  if (pf7_sample_ptr_) {
+    // PfEMPAnalysis::finalizeAnalysis (kga_analysis_PfEMP.cpp:146-163)
+    const GpuLocationSummaryMap location_summary = hetero_homo_zygous_.locationSummary(location_radius_km_);
+    ok = hetero_homo_zygous_.writeSampleResults(joinPath(work_directory_, hethom_file_), location_summary) && ok;
+    ok = hetero_homo_zygous_.writeLocationResults(joinPath(work_directory_, location_file_), location_summary) && ok;
+  } else {
+    ok = hetero_homo_zygous_.writeContigResults(joinPath(work_directory_, hethom_file_)) && ok;
   }
-  return wrights_inbreeding;
+  return ok;
 }
 
 // Column layout of CalcFWS::writeVariantResults (kga_analysis_PfEMP_FWS.cpp:235-309).
@@ -448,36 +493,5 @@ bool kga::GpuAlleleAnalysis::writeGenomeResults(const std::string& file_name) co
     }
     out << '\n';
   }
-  return out.good();
-}
-
-// One line per genome x contig with the VariantAnalysisType counters and Wright's F_IS against the
-// whole-population aggregate of the contig.
-bool kga::GpuAlleleAnalysis::writeHetHomResults(const std::string& file_name) const {
-  std::ofstream out(file_name);
-  if (!out.good()) {
-    ExecEnv::log().error("GpuAlleleAnalysis::writeHetHomResults; Unable to open results file: {}", file_name);
-    return false;
-  }
-  std::map<std::string, VariantAnalysisType> aggregate;
-  for (const auto& [genome_id, contig_map] : variant_analysis_map_)
-    for (const auto& [contig_id, r] : contig_map) {
-      VariantAnalysisType& a = aggregate[contig_id];
-      a.total_variants_ += r.total_variants_;
-      a.heterozygous_reference_minor_alleles_ += r.heterozygous_reference_minor_alleles_;
-      a.homozygous_minor_alleles_ += r.homozygous_minor_alleles_;
-      a.heterozygous_minor_alleles_ += r.heterozygous_minor_alleles_;
-      a.snp_count_ += r.snp_count_;
-      a.indel_count_ += r.indel_count_;
-    }
-  out << "Genome" << CSV_DELIMITER_ << "Contig" << CSV_DELIMITER_ << "Variant Count" << CSV_DELIMITER_ << "SNP" << CSV_DELIMITER_ << "Indel"
-      << CSV_DELIMITER_ << "Hom Ref (A;A)" << CSV_DELIMITER_ << "Het Ref Minor (A;a)" << CSV_DELIMITER_ << "Hom Minor (a;a)"
-      << CSV_DELIMITER_ << "Het Diff Minor (a;b)" << CSV_DELIMITER_ << "FIS" << '\n';
-  for (const auto& [genome_id, contig_map] : variant_analysis_map_)
-    for (const auto& [contig_id, r] : contig_map)
-      out << genome_id << CSV_DELIMITER_ << contig_id << CSV_DELIMITER_ << r.total_variants_ << CSV_DELIMITER_ << r.snp_count_
-          << CSV_DELIMITER_ << r.indel_count_ << CSV_DELIMITER_ << r.homozygous_reference_alleles_ << CSV_DELIMITER_
-          << r.heterozygous_reference_minor_alleles_ << CSV_DELIMITER_ << r.homozygous_minor_alleles_ << CSV_DELIMITER_
-          << r.heterozygous_minor_alleles_ << CSV_DELIMITER_ << wrightsInbreeding(aggregate.at(contig_id), r) << '\n';
   return out.good();
 }

@@ -9,6 +9,7 @@
 #include <sstream>
 #include <vector>
 
+#include "kga_analysis_gpu_allele.h"
 #include "kgx_flatten.h"
 #include "kgx_variant_sort.h"
 #include "kgx_vcf_io.h"
@@ -217,6 +218,36 @@ char* kgxh_read_vcf_text(const char* path, uint64_t* len, int threads, char* err
   return out;
 }
 void kgxh_free(void* p) { std::free(p); }
+
+// GpuHeteroHomoZygous over counters handed in (no device): record i belongs to genomes[i] x contigs[i], counters[i] =
+// { total, snp, indel, hom_minor, het_minor, het_ref_minor, hom_ref }.  Writes the two files of the location analysis.
+// 0 = written, -1 = a resource file does not parse, -2 = a file could not be written.
+int kgxh_pfemp_location_write(const char* sample_file, const char* fws_file, uint64_t n, const char* const* genomes, const char* const* contigs,
+                              const uint64_t* counters, double radius_km, const char* statistics_csv, const char* location_csv) {
+  namespace kgl = kellerberrin::genome;
+  namespace kga = kellerberrin::genome::analysis;
+  if (!sample_file || !fws_file || !statistics_csv || !location_csv || (n && (!genomes || !contigs || !counters))) return -1;
+  kgl::ParsePf7Sample sample_parser;
+  kgl::ParsePf7Fws fws_parser;
+  if (!sample_parser.parsePf7SampleFile(sample_file) || !fws_parser.parsePf7FwsFile(fws_file)) return -1;
+  const auto samples = std::make_shared<const kgl::Pf7SampleResource>("Pf7Sample", sample_parser.getPf7SampleVector());
+  const auto fws = std::make_shared<const kgl::Pf7FwsResource>("Pf7Fws", fws_parser.getPf7FwsVector());
+  kga::GpuHeteroHomoZygous hethom;
+  hethom.setResources(samples, fws, std::make_shared<const kgl::Pf7SampleLocation>(*samples));
+  for (uint64_t i = 0; i < n; ++i) {
+    kga::VariantAnalysisType& r = hethom.analysisMap()[genomes[i]][contigs[i]];
+    const uint64_t* c = counters + i * 7;
+    r.total_variants_ = c[0];
+    r.snp_count_ = c[1];
+    r.indel_count_ = c[2];
+    r.homozygous_minor_alleles_ = c[3];
+    r.heterozygous_minor_alleles_ = c[4];
+    r.heterozygous_reference_minor_alleles_ = c[5];
+    r.homozygous_reference_alleles_ = c[6];
+  }
+  const auto summary = hethom.locationSummary(radius_km);
+  return hethom.writeSampleResults(statistics_csv, summary) && hethom.writeLocationResults(location_csv, summary) ? 0 : -2;
+}
 
 // ---- INBREED inputs from VCF text: reference site file + 1000-Genomes population --------------------------------
 struct InbreedInputs {

@@ -4,10 +4,12 @@
 // -> finalizeAnalysis on the VirtualAnalysis interface.  Used by the parity tests; in the reference tree the
 // packages are registered in the factory map instead.
 //
-//   kgx_host_driver <IDENT> <work_dir> [key=value ...] -- <records.bin | vcf:[<DataSource>:]<file.vcf> | ped:<file>> ...
+//   kgx_host_driver <IDENT> <work_dir> [key=value ...] -- <records.bin | vcf:[<DataSource>:]<file.vcf> | ped:<file>
+//                                                            | pf7sample:<file.tsv> | pf7fws:<file.tsv>> ...
 //
 // "vcf:<path>" hands the package a FilenameDataDB (the reference's "FileNameOnly" data file,
-// kgl_parser/kgl_variant_factory_parsers.cpp:65-66): the package reads the VCF itself.
+// kgl_parser/kgl_variant_factory_parsers.cpp:65-66): the package reads the VCF itself.  "pf7sample:" / "pf7fws:" load
+// the Pf7 sample and FWS resources (kgl_app/kgl_package_resource_pf.cpp) the way the runtime XML's resource entries do.
 //
 // Record file (little endian): "KGXR" u32 version=1, u32 mode (0 = phased 1000-Genomes style, 1 = unphased
 // Pf style, 2 = reference mono-genome), u32 data_source (DataSourceEnum), str population_id, str contig,
@@ -154,6 +156,7 @@ int main(int argc, char** argv) {
 
   std::vector<LoadedFile> files;
   auto genealogy = std::make_shared<kgl::HsGenomeGenealogyData>("PED");
+  std::vector<std::shared_ptr<const kgl::ResourceBase>> pf7_resources;
   for (; i < argc; ++i) {
     if (std::strncmp(argv[i], "vcf:", 4) == 0) {
       // vcf:<path>  or  vcf:<DataSource>:<path>  (the data source the runtime XML gives the file)
@@ -204,11 +207,24 @@ int main(int argc, char** argv) {
       }
       continue;
     }
+    if (std::strncmp(argv[i], "pf7sample:", 10) == 0) {
+      kgl::ParsePf7Sample parser;
+      if (!parser.parsePf7SampleFile(argv[i] + 10)) { std::cerr << "cannot read the Pf7 sample file " << (argv[i] + 10) << "\n"; return 2; }
+      pf7_resources.push_back(std::make_shared<kgl::Pf7SampleResource>("Pf7SampleDriver", parser.getPf7SampleVector()));
+      continue;
+    }
+    if (std::strncmp(argv[i], "pf7fws:", 7) == 0) {
+      kgl::ParsePf7Fws parser;
+      if (!parser.parsePf7FwsFile(argv[i] + 7)) { std::cerr << "cannot read the Pf7 FWS file " << (argv[i] + 7) << "\n"; return 2; }
+      pf7_resources.push_back(std::make_shared<kgl::Pf7FwsResource>("Pf7FwsDriver", parser.getPf7FwsVector()));
+      continue;
+    }
     files.push_back(loadRecords(argv[i]));
     for (const auto& [genome, sp] : files.back().ped) genealogy->addGenealogyRecord(kgl::HsGenealogyRecord(genome, sp));
   }
   auto resources = std::make_shared<kgl::AnalysisResources>();
   resources->addResource(genealogy);
+  for (const auto& resource : pf7_resources) resources->addResource(resource);
 
   kgl::ActiveParameterList named_parameters;
   named_parameters.addNamedParameterVector({"DriverParameters", kgl::ParameterVector{parameters}});

@@ -433,6 +433,8 @@ class AnalysisResources {
 };
 struct ResourceProperties {   // kgl_app/kgl_properties_resource.h:70
   constexpr static const char GENEALOGY_RESOURCE_ID_[] = "genomeGenealogy";
+  constexpr static const char PF7SAMPLE_RESOURCE_ID_[] = "Pf7Sample";      // :86
+  constexpr static const char PF7FWS_RESOURCE_ID_[] = "Pf7Fws";            // :90
 };
 
 // kgl_parser/kgl_hsgenealogy_parser.h:22-135 — the PED table: genome -> super population.

@@ -38,15 +38,22 @@ void launch_count(const kgx_pop_shard& sh, kgx_v4u* d_out, hipStream_t stream) {
   const uint64_t want = (waves + (kBlock / kWave) - 1) / (kBlock / kWave);
   const uint64_t cap = static_cast<uint64_t>(sh.dev->compute_units) * env_int("KGX_K2_BLOCKS_PER_CU", 32);
   const uint32_t grid = static_cast<uint32_t>(want < cap ? (want ? want : 1) : cap);
+  if (sh.d_keep) {
+    if constexpr (NT)     // the masked sweep comes in the default load flavour only
+      hipLaunchKernelGGL((k_allele_count<W, U, true, true>), dim3(grid), dim3(kBlock), 0, stream,
+                         reinterpret_cast<const kgx_v4u*>(sh.d_rows), sh.chunks_per_row, sh.n_variants, static_cast<uint32_t>(sh.n_kept), d_out,
+                         reinterpret_cast<const kgx_v4u*>(sh.d_keep));
+    return;
+  }
   hipLaunchKernelGGL((k_allele_count<W, U, NT>), dim3(grid), dim3(kBlock), 0, stream,
                      reinterpret_cast<const kgx_v4u*>(sh.d_rows), sh.chunks_per_row,
-                     sh.n_variants, static_cast<uint32_t>(sh.n_genomes), d_out);
+                     sh.n_variants, static_cast<uint32_t>(sh.n_genomes), d_out, nullptr);
 }
 
 template <int W>
 void launch_count_w(const kgx_pop_shard& sh, kgx_v4u* out, hipStream_t stream) {
   const int U = env_int("KGX_K2_U", 8);
-  const bool nt = env_int("KGX_K2_NT", 1) != 0;
+  const bool nt = sh.d_keep != nullptr || env_int("KGX_K2_NT", 1) != 0;
   if (U <= 1)      nt ? launch_count<W, 1, true>(sh, out, stream) : launch_count<W, 1, false>(sh, out, stream);
   else if (U == 2) nt ? launch_count<W, 2, true>(sh, out, stream) : launch_count<W, 2, false>(sh, out, stream);
   else if (U <= 4) nt ? launch_count<W, 4, true>(sh, out, stream) : launch_count<W, 4, false>(sh, out, stream);
@@ -137,7 +144,8 @@ int count_by_genome_shard(kgx_pop_shard& sh, const uint8_t* bin_of_variant, uint
   std::lock_guard<std::mutex> device_lock(dev.mutex);          // the scratch arena and the timing events are the device's
   if (int rc = use_device(dev)) return rc;
   const uint64_t cells = G * n_bins;
-  const bool identity = bin_of_variant == nullptr && bin_edges == nullptr;
+  const bool masked = sh.d_keep != nullptr;                   // rows without a kept carrier drop out (d_counts: K2 under the mask)
+  const bool identity = bin_of_variant == nullptr && bin_edges == nullptr && !masked;
   hipStream_t st = dev.stream;
 
   unsigned long long *d_acc = nullptr, *d_out = nullptr, *d_nbin = nullptr, *d_binoff = nullptr;
@@ -189,9 +197,13 @@ int count_by_genome_shard(kgx_pop_shard& sh, const uint8_t* bin_of_variant, uint
       try_hip(hipMemcpyAsync(d_binoff, bin_edges, (n_bins + 1) * sizeof(double), hipMemcpyHostToDevice, st), KGX_EHIP, "H2D(bin edges)");
       if (rc == KGX_OK)
         hipLaunchKernelGGL(k_af_bins, dim3(stream_grid(dev, V, kBlock)), dim3(kBlock), 0, st, sh.d_af, V, reinterpret_cast<const double*>(d_binoff), n_bins, d_bins);
-    } else {
+    } else if (bin_of_variant) {
       try_hip(hipMemcpyAsync(d_bins, bin_of_variant, V, hipMemcpyHostToDevice, st), KGX_EHIP, "H2D(bins)");
+    } else {
+      try_hip(hipMemsetAsync(d_bins, 0, V, st), KGX_EHIP, "memset(bins)");
     }
+    if (rc == KGX_OK && masked)
+      hipLaunchKernelGGL(k_drop_absent_rows, dim3(stream_grid(dev, V, kBlock)), dim3(kBlock), 0, st, static_cast<const kgx_v4u*>(sh.d_counts), V, d_bins);
     if (rc == KGX_OK) {
       hipLaunchKernelGGL(k_bin_count, dim3(n_chunks), dim3(kBlock), 0, st, d_bins, V, n_bins, d_chunks);
       hipLaunchKernelGGL(k_bin_totals, dim3(n_bins), dim3(kBlock), 0, st, d_chunks, n_chunks, d_nbin);
@@ -259,11 +271,27 @@ int count_by_genome_shard(kgx_pop_shard& sh, const uint8_t* bin_of_variant, uint
   return rc;
 }
 
+int sync_shards(const kgx_pop* pop);
+
+// The genomes a mask leaves out take no part: their blocks of a per-genome result read as zero.
+void zero_masked_genomes(const kgx_pop* pop, uint64_t* out, uint64_t words_per_genome) {
+  for (uint64_t g = 0; g < pop->keep.size(); ++g)
+    if (!pop->keep[g]) std::memset(out + g * words_per_genome, 0, words_per_genome * sizeof(uint64_t));
+}
+
 int count_by_genome_impl(kgx_pop* pop, const uint8_t* bin_of_variant, uint32_t n_bins, uint64_t* out, const double* bin_edges = nullptr) {
-  return for_each_parallel(pop->shards.size(), [&](size_t s) {
+  if (!pop->keep.empty() && !pop->counts_current && pop->n_variants) {
+    // which rows still have a carrier: the population's K2 counts under the mask, on every shard's device
+    if (int rc = sweep_and_exchange(pop, nullptr, nullptr, true)) return rc;
+    if (int rc = sync_shards(pop)) return rc;
+    pop->counts_current = true;
+  }
+  const int rc = for_each_parallel(pop->shards.size(), [&](size_t s) {
     kgx_pop_shard& sh = pop->shards[s];
     return count_by_genome_shard(sh, bin_of_variant, n_bins, out + sh.genome_base * n_bins * 4, bin_edges);
   });
+  if (rc == KGX_OK) zero_masked_genomes(pop, out, static_cast<uint64_t>(n_bins) * 4);
+  return rc;
 }
 
 // row_list (may be empty): the groups' member rows; a group's first_row is then its first position in the list.
@@ -324,6 +352,7 @@ void destroy_shards(kgx_pop* pop) {
     if (sh.d_alloc) (void)hipFree(sh.d_alloc);
     if (sh.d_af) (void)hipFree(sh.d_af);
     if (sh.d_counts) (void)hipFree(sh.d_counts);
+    if (sh.d_keep) (void)hipFree(sh.d_keep);
   }
   if (!pop->shards.empty()) (void)use_device(*pop->shards[0].dev);
 }
@@ -358,6 +387,7 @@ kgx_pop* kgx_population_create(uint64_t n_genomes, uint64_t n_variants) {
     const uint64_t want = (per + (s < extra ? 1 : 0)) * 64;
     sh.n_genomes = want < n_genomes - base ? want : n_genomes - base;
     sh.n_variants = n_variants;
+    sh.n_kept = sh.n_genomes;
     sh.row_bytes = (sh.n_genomes + 3) / 4;
     // Rows longer than half a wave-load start on a 128-byte line so that every 1 KiB wave load covers
     // whole lines (measured +6 % on 2500-byte rows); short rows stay densely packed.
@@ -425,6 +455,7 @@ int kgx_population_shard_info(const kgx_pop* pop, uint32_t shard, int* slot, uin
 }
 
 int kgx_population_load_dosage2(kgx_pop* pop, const uint8_t* src, uint64_t src_pitch, uint64_t v0, uint64_t v1) {
+  if (pop) pop->counts_current = false;
   if (int bound = require_bound()) return bound;
   if (!pop || !src) return fail(KGX_EINVAL, "null population or source");
   if (v0 > v1 || v1 > pop->n_variants) return fail(KGX_EINVAL, "variant range [%llu,%llu) outside [0,%llu)",
@@ -447,6 +478,7 @@ int kgx_population_load_dosage2(kgx_pop* pop, const uint8_t* src, uint64_t src_p
 }
 
 int kgx_population_load_dosage_u8(kgx_pop* pop, const uint8_t* src, uint64_t g0, uint64_t g1) {
+  if (pop) pop->counts_current = false;
   if (int bound = require_bound()) return bound;
   if (!pop || !src) return fail(KGX_EINVAL, "null population or source");
   if (g0 > g1 || g1 > pop->n_genomes) return fail(KGX_EINVAL, "genome range [%llu,%llu) outside [0,%llu)",
@@ -502,6 +534,7 @@ int kgx_population_read_dosage2(const kgx_pop* pop, uint8_t* dst, uint64_t dst_p
 }
 
 int kgx_population_resize(kgx_pop* pop, uint64_t n_variants) {
+  if (pop) pop->counts_current = false;
   if (int bound = require_bound()) return bound;
   if (!pop) return fail(KGX_EINVAL, "null population");
   for (auto& sh : pop->shards) {
@@ -545,6 +578,41 @@ int kgx_population_resize(kgx_pop* pop, uint64_t n_variants) {
   return use_device(*pop->shards[0].dev);
 }
 
+int kgx_population_set_genome_mask(kgx_pop* pop, const uint8_t* keep) {
+  if (int bound = require_bound()) return bound;
+  if (!pop) return fail(KGX_EINVAL, "null population");
+  pop->counts_current = false;
+  if (!keep) {
+    pop->keep.clear();
+    for (auto& sh : pop->shards) {
+      if (sh.d_keep) {
+        if (int rc = use_device(*sh.dev)) return rc;
+        KGX_HIP(hipStreamSynchronize(sh.dev->stream));
+        (void)hipFree(sh.d_keep);
+        sh.d_keep = nullptr;
+      }
+      sh.n_kept = sh.n_genomes;
+    }
+    return use_device(*pop->shards[0].dev);
+  }
+  pop->keep.assign(keep, keep + pop->n_genomes);
+  for (auto& sh : pop->shards) {
+    if (sh.n_genomes == 0) continue;
+    if (int rc = use_device(*sh.dev)) return rc;
+    std::vector<uint8_t> row(sh.pitch, 0);
+    sh.n_kept = 0;
+    for (uint64_t g = 0; g < sh.n_genomes; ++g)
+      if (keep[sh.genome_base + g]) {
+        row[g >> 2] |= static_cast<uint8_t>(3u << (2 * (g & 3u)));
+        ++sh.n_kept;
+      }
+    if (!sh.d_keep) KGX_HIP_MEM(hipMalloc(&sh.d_keep, sh.pitch));
+    KGX_HIP(hipMemcpyAsync(sh.d_keep, row.data(), sh.pitch, hipMemcpyHostToDevice, sh.dev->stream));
+    KGX_HIP(hipStreamSynchronize(sh.dev->stream));             // `row` is pageable host memory
+  }
+  return use_device(*pop->shards[0].dev);
+}
+
 int kgx_population_set_af(kgx_pop* pop, const float* af) {
   if (int bound = require_bound()) return bound;
   if (!pop || !af) return fail(KGX_EINVAL, "null population or af");
@@ -574,6 +642,7 @@ int kgx_population_get_af(const kgx_pop* pop, float* af) {
 }
 
 int kgx_population_synth_biallelic(kgx_pop* pop, uint64_t seed, uint64_t genome_base, uint64_t variant_base) {
+  if (pop) pop->counts_current = false;
   if (int bound = require_bound()) return bound;
   if (!pop) return fail(KGX_EINVAL, "null population");
   for (auto& sh : pop->shards) {
@@ -630,7 +699,9 @@ int kgx_allele_count_by_locus(kgx_pop* pop, uint32_t* out) {
   if (int rc = sweep_and_exchange(pop, nullptr, nullptr, true)) return rc;
   kgx_pop_shard& sh = pop->shards[0];
   KGX_HIP(hipMemcpyAsync(out, sh.d_counts, pop->n_variants * 16u, hipMemcpyDeviceToHost, sh.dev->stream));
-  return sync_shards(pop);
+  const int rc = sync_shards(pop);
+  pop->counts_current = rc == KGX_OK;      // every shard's d_counts now holds the population's counts
+  return rc;
 }
 
 int kgx_allele_frequency_dev(const void* d_counts, uint64_t n_variants, uint64_t total_genomes, void* d_af, void* stream) {
@@ -801,6 +872,7 @@ int kgx_compound_offsets(kgx_pop* pop, const uint32_t* first_row, const uint32_t
     kgx_pop_shard& sh = pop->shards[s];
     return compound_offsets_shard(sh, groups, no_list, n_bins, out + sh.genome_base * n_bins * 3);
   });
+  if (rc == KGX_OK) zero_masked_genomes(pop, out, static_cast<uint64_t>(n_bins) * 3);
   (void)use_device(*pop->shards[0].dev);
   return rc;
 }
@@ -828,6 +900,7 @@ int kgx_compound_offsets_listed(kgx_pop* pop, const uint32_t* member_rows, uint6
     kgx_pop_shard& sh = pop->shards[s];
     return compound_offsets_shard(sh, groups, row_list, n_bins, out + sh.genome_base * n_bins * 3);
   });
+  if (rc == KGX_OK) zero_masked_genomes(pop, out, static_cast<uint64_t>(n_bins) * 3);
   (void)use_device(*pop->shards[0].dev);
   return rc;
 }

@@ -127,6 +127,8 @@ struct kgx_pop_shard {
   uint8_t* d_rows = nullptr;     // [n_variants][pitch] dosage2
   float* d_af = nullptr;         // [n_variants] INFO allele frequency (float32, NaN = missing)
   void* d_counts = nullptr;      // [n_variants][4] u32 scratch for the host-returning entry points
+  uint8_t* d_keep = nullptr;     // [pitch] genome mask in the rows' own layout: 0b11 where the genome takes part; null = all do
+  uint64_t n_kept = 0;           // genomes of the shard taking part (n_genomes without a mask)
 };
 
 struct kgx_pop {
@@ -135,6 +137,8 @@ struct kgx_pop {
   uint64_t n_variants = 0;
   std::vector<kgx_pop_shard> shards;
   bool has_af = false;
+  std::vector<uint8_t> keep;     // kgx_population_set_genome_mask: one byte per genome, empty = no mask
+  bool counts_current = false;   // with a mask: every shard's d_counts holds the population's K2 counts under it
 };
 
 struct kgx_gt8_shard {

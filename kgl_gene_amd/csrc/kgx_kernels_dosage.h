@@ -51,10 +51,12 @@ __device__ __forceinline__ void count_chunk(const kgx_v4u x, uint32_t& a, uint32
 // row sets in flight per wave (U independent 16-B loads per lane per step).
 // out[v] = { refHom, het, minorHom, nonDiploid }.
 // ---------------------------------------------------------------------------------------------
-template <int W, int U, bool NT = true>
+// MASKED: `keep` is one row in the rows' layout, 0b11 where a genome takes part (a genome filter of the reference's
+// kind, PopulationDB::viewFilter(GenomeListFilter)); the genomes left out count as absent and n_genomes is the number kept.
+template <int W, int U, bool NT = true, bool MASKED = false>
 __global__ void __launch_bounds__(kBlock)
 k_allele_count(const kgx_v4u* __restrict__ rows, uint32_t chunks_per_row, uint64_t n_rows,
-               uint32_t n_genomes, kgx_v4u* __restrict__ out) {
+               uint32_t n_genomes, kgx_v4u* __restrict__ out, const kgx_v4u* __restrict__ keep = nullptr) {
   constexpr int kRowsPerSet = kWave / W;
   constexpr int kRowsPerIter = kRowsPerSet * U;
   const uint32_t lane = threadIdx.x & (kWave - 1);
@@ -79,6 +81,11 @@ k_allele_count(const kgx_v4u* __restrict__ rows, uint32_t chunks_per_row, uint64
       kgx_v4u x[U];
 #pragma unroll
       for (int u = 0; u < U; ++u) x[u] = NT ? __builtin_nontemporal_load(rp[u] + k) : rp[u][k];
+      if constexpr (MASKED) {
+        const kgx_v4u m = keep[k];                                  // one row for every row set: stays in cache
+#pragma unroll
+        for (int u = 0; u < U; ++u) x[u] &= m;
+      }
 #pragma unroll
       for (int u = 0; u < U; ++u) count_chunk(x[u], a[u], b[u], c[u]);
     }
@@ -108,6 +115,17 @@ k_allele_frequency(const kgx_v4u* __restrict__ counts, uint64_t n, uint64_t tota
        i += static_cast<uint64_t>(gridDim.x) * blockDim.x) {
     const kgx_v4u c = counts[i];
     af[i] = static_cast<double>(static_cast<uint64_t>(c[1]) + 2u * static_cast<uint64_t>(c[2])) / denom;
+  }
+}
+
+// Under a genome mask a variant nobody kept carries is not in the population: its row takes no part in the by-genome
+// sweep (bin 0xFF).  counts = K2's output under the same mask.
+__global__ void __launch_bounds__(kBlock)
+k_drop_absent_rows(const kgx_v4u* __restrict__ counts, uint64_t n, uint8_t* __restrict__ bin_of_variant) {
+  for (uint64_t i = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n;
+       i += static_cast<uint64_t>(gridDim.x) * blockDim.x) {
+    const kgx_v4u c = counts[i];
+    if ((c[1] | c[2] | c[3]) == 0) bin_of_variant[i] = 0xFF;
   }
 }
 

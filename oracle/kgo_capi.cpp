@@ -10,6 +10,7 @@
 
 #include "kgo_analysis.h"
 #include "kgo_inbreed.h"
+#include "kgo_pf7.h"
 #include "kgo_sort.h"
 
 using namespace kgo;
@@ -555,6 +556,44 @@ double kgo_wrights_fis(const uint64_t location[7], const uint64_t genome[7]) {
   l.total_variants_ = location[0]; l.heterozygous_minor_alleles_ = location[4]; l.heterozygous_reference_minor_alleles_ = location[5];
   g.total_variants_ = genome[0]; g.heterozygous_minor_alleles_ = genome[4]; g.heterozygous_reference_minor_alleles_ = genome[5];
   return wrightsFIS(l, g);
+}
+
+// ---- Pf7 sample resources: genome filters, location summary, F_IS ------------------------------------
+
+// FilterPf7::qualityFilter's genome part + squareContigs over the sample / FWS resource files; nullptr when a file does
+// not parse.
+kgo_pop* kgo_population_filter_pf7_genomes(kgo_pop* p, const char* sample_file, const char* fws_file, int filter_qc, int filter_fws,
+                                           double fws_threshold) {
+  if (!p || !sample_file || !fws_file) return nullptr;
+  Pf7SampleMap samples;
+  Pf7FwsMap fws;
+  if (!parsePf7SampleFile(sample_file, samples) || !parsePf7FwsFile(fws_file, fws)) return nullptr;
+  auto* out = new kgo_pop();
+  out->pop = pf7GenomeFilter(*p->pop, samples, fws, filter_qc != 0, filter_fws != 0, fws_threshold);
+  out->input_ids = p->input_ids;
+  return out;
+}
+
+// PfEMPAnalysis::finalizeAnalysis' two HeteroHomoZygous files (kga_analysis_PfEMP.cpp:146-163) for a population.
+// radius_km: PfEMPAnalysis::SAMPLE_LOCATION_RADIUS_ is 0 (kga_analysis_PfEMP.h:64).
+int kgo_pfemp_location_write(kgo_pop* p, const char* sample_file, const char* fws_file, double radius_km, const char* statistics_csv,
+                             const char* location_csv) {
+  if (!p || !sample_file || !fws_file || !statistics_csv || !location_csv) return -1;
+  Pf7SampleMap samples;
+  Pf7FwsMap fws;
+  if (!parsePf7SampleFile(sample_file, samples) || !parsePf7FwsFile(fws_file, fws)) return -2;
+  try {
+    Pf7SampleLocation distance(samples);
+    HeteroHomoZygous hethom;
+    hethom.analyzeVariantPopulation(*p->pop, fws, samples);
+    auto summary = hethom.location_summary(samples, distance, radius_km, fws);
+    hethom.UpdateSampleLocation(summary);
+    hethom.write_variant_results(statistics_csv, summary);
+    hethom.write_location_results(location_csv, summary);
+  } catch (std::exception&) {
+    return -3;   // a year that is not a number ends the reference's run
+  }
+  return 0;
 }
 
 // ---- inbreeding --------------------------------------------------------------------------------

@@ -42,6 +42,8 @@ def lib():
         L.kgxh_read_vcf_text.restype = C.c_void_p
         L.kgxh_read_vcf_text.argtypes = [C.c_char_p, C.c_void_p, C.c_int, C.c_char_p, C.c_size_t]
         L.kgxh_free.argtypes = [C.c_void_p]
+        L.kgxh_pfemp_location_write.restype = C.c_int
+        L.kgxh_pfemp_location_write.argtypes = [C.c_char_p, C.c_char_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_char_p, C.c_char_p]
         L.kgxh_inbreed_inputs.restype = C.c_void_p
         L.kgxh_inbreed_inputs.argtypes = [C.c_char_p, C.c_uint64, C.c_int, C.c_char_p, C.c_uint64, C.c_int]
         L.kgxh_inbreed_inputs_file.restype = C.c_void_p
@@ -82,6 +84,20 @@ def variant_sort(text: str | None, flavour: str, what: str, names=None, genome_i
     finally:
         lib().kgxh_free(ptr)
     return [tuple(line.split("\t")) for line in out.split("\n") if line]
+
+
+def pfemp_location_write(sample_file, fws_file, records, statistics_csv, location_csv, radius_km: float = 0.0) -> int:
+    """GpuHeteroHomoZygous' two location files from counters handed in (no device).
+    records: [(genome, contig, (total, snp, indel, hom_minor, het_minor, het_ref_minor, hom_ref)), ...]"""
+    import numpy as np
+
+    n = len(records)
+    genomes = (C.c_char_p * max(n, 1))(*[r[0].encode() for r in records])
+    contigs = (C.c_char_p * max(n, 1))(*[r[1].encode() for r in records])
+    counters = np.ascontiguousarray([r[2] for r in records], dtype=np.uint64).reshape(n, 7)
+    return int(lib().kgxh_pfemp_location_write(str(sample_file).encode(), str(fws_file).encode(), n, C.cast(genomes, C.c_void_p),
+                                               C.cast(contigs, C.c_void_p), C.c_void_p(counters.ctypes.data), float(radius_km),
+                                               str(statistics_csv).encode(), str(location_csv).encode()))
 
 
 class TwoPhaseNeeded(Exception):

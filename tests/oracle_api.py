@@ -47,6 +47,8 @@ def lib() -> C.CDLL:
         "kgo_population_add_vcf_mono": (C.c_long, [vp, C.c_char_p, u64, C.c_char_p, C.c_char_p]),
         "kgo_hethom_present": (C.c_int, [vp, C.c_char_p, vp]),
         "kgo_population_filter_p7": (vp, [vp]),
+        "kgo_population_filter_pf7_genomes": (vp, [vp, C.c_char_p, C.c_char_p, C.c_int, C.c_int, dbl]),
+        "kgo_pfemp_location_write": (C.c_int, [vp, C.c_char_p, C.c_char_p, dbl, C.c_char_p, C.c_char_p]),
         "kgo_canonical": (u64, [C.c_char_p, C.c_char_p, u64, C.c_char_p, C.c_char_p]),
         "kgo_gt_alternate_index": (C.c_int, [C.c_char_p, C.c_char_p, u64, vp]),
         "kgo_population_variant_count": (u64, [vp]),
@@ -220,6 +222,20 @@ class Population:
         p = Population(handle=lib().kgo_population_filter_p7(self._h))
         p.genome_ids = list(self.genome_ids)
         return p
+
+    def filter_pf7_genomes(self, sample_file, fws_file, filter_qc=True, filter_fws=True, fws_threshold=0.95):
+        """FilterPf7::qualityFilter's genome part (QC pass, monoclonal FWS) + squareContigs, from the two resource files."""
+        h = lib().kgo_population_filter_pf7_genomes(self._h, str(sample_file).encode(), str(fws_file).encode(), int(filter_qc), int(filter_fws),
+                                                    float(fws_threshold))
+        assert h, "the Pf7 resource files did not parse"
+        p = Population(handle=h)
+        p.genome_ids = list(self.genome_ids)
+        return p
+
+    def write_pfemp_location(self, sample_file, fws_file, statistics_csv, location_csv, radius_km=0.0):
+        """HeteroHomoZygous' VariantStatistics.csv and VariantLocation.csv for this population."""
+        return int(lib().kgo_pfemp_location_write(self._h, str(sample_file).encode(), str(fws_file).encode(), float(radius_km),
+                                                  str(statistics_csv).encode(), str(location_csv).encode()))
 
     @property
     def handle(self):

@@ -47,6 +47,22 @@ def dosage_results(kgx, G, V, codes, bins, n_bins, groups):
     af[::17] = np.nan
     pop.set_af(af)
     out["k3_af_bins"] = pop.count_by_genome_af_bins([0.0, 0.05, 0.10, 0.15, 0.20, 0.25, 0.30, 0.35, 0.40, 0.45, 0.5, 1.0])
+    # a genome mask (two genomes in three kept): a row counts as present when ANY shard holds a kept carrier of it
+    keep = (np.arange(G) % 3 != 0).astype(np.uint8)
+    pop.set_genome_mask(keep)
+    out["k2_masked"] = pop.allele_count_by_locus()
+    out["k3_masked"] = pop.count_by_genome()
+    out["k3_binned_masked"] = pop.count_by_genome_binned(bins, n_bins)
+    out["k3_af_bins_masked"] = pop.count_by_genome_af_bins([0.0, 0.05, 0.10, 0.15, 0.20, 0.25, 0.30, 0.35, 0.40, 0.45, 0.5, 1.0])
+    out["k8_masked"] = pop.compound_offsets(*groups, 3)
+    kept_codes = codes[:, keep.astype(bool)]
+    assert np.array_equal(out["k2_masked"], np.stack([(kept_codes == k).sum(1) for k in range(4)], 1).astype(np.uint32))
+    present = (kept_codes > 0).any(1) if kept_codes.shape[1] else np.zeros(V, dtype=bool)
+    want_k3 = np.stack([(codes[present] == k).sum(0) for k in range(4)], 1).astype(np.uint64)
+    want_k3[keep == 0] = 0
+    assert np.array_equal(out["k3_masked"], want_k3)
+    pop.set_genome_mask(None)
+    assert np.array_equal(pop.allele_count_by_locus(), out["k2"])
     extra = V // 3
     pop.resize(V + extra)
     pop.load_dosage2(kgx.pack_dosage2(codes[:extra]), V)
@@ -79,7 +95,8 @@ def test_sharded_dosage_sweeps_equal_the_unsharded_ones(kgx, rebind, slots, G):
     assert len(shards) == slots and sum(s["n_genomes"] for s in shards) == G
     assert all(s["genome_base"] % 64 == 0 for s in shards if s["n_genomes"])
     assert [s["genome_base"] for s in shards] == list(np.cumsum([0] + [s["n_genomes"] for s in shards[:-1]]))
-    for key in ("rows", "k2", "k4", "k3", "k3_binned", "k8", "k8_listed", "k3_af_bins", "k2_grown", "k3_grown"):
+    for key in ("rows", "k2", "k4", "k3", "k3_binned", "k8", "k8_listed", "k3_af_bins", "k2_grown", "k3_grown", "k2_masked", "k3_masked",
+                "k3_binned_masked", "k3_af_bins_masked", "k8_masked"):
         assert np.array_equal(got[key], want[key]), key
     assert np.array_equal(want["k8_listed"], want["k8"])
     assert np.array_equal(want["k2_grown"][:V], want["k2"]) and np.array_equal(want["k2_grown"][V:], want["k2"][:V // 3])

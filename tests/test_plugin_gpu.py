@@ -517,3 +517,50 @@ def test_gpu_inbreed_package_synthetic_file_layout(tmp_path, kgx):
     syn = np.array([float(r[1]) for r in rows])
     calc = np.array([float(r[2]) for r in rows])
     assert np.corrcoef(syn, calc)[0, 1] > 0.9
+
+
+@pytest.mark.parametrize("filter_qc,filter_fws,quality_filter", [(True, True, True), (True, False, False), (False, True, False)])
+def test_gpu_allele_package_with_pf7_sample_resources(tmp_path, kgx, filter_qc, filter_fws, quality_filter):
+    """The package as PfEMPAnalysis runs it (kga_analysis_PfEMP.cpp:24-26,90,105,146-163): with the Pf7 sample and FWS
+    resources only the genomes that pass QC / are monoclonal take part -- a genome mask evaluated on the device, the
+    population is flattened and uploaded whole -- and the heterozygosity results come out in the reference's layout with
+    the location summary.  FWS counts must equal the oracle's over the filtered PopulationDB, the two HeteroHomoZygous
+    files must equal the oracle's byte for byte."""
+    from . import pf7_text as pt
+    from . import vcf_text as vt
+
+    G, L = 150, 1500
+    ids = [f"PF{i:04d}-C" for i in range(G)]
+    text = vt.write_vcf_pf(L, ids, rng_seed=29)
+    vcf = tmp_path / "pf.vcf"
+    vcf.write_text(text)
+    sample_path, fws_path, records = pt.write_resources(tmp_path, ids, rng_seed=17)
+    res = rio.run_driver("GPU_ALLELE", tmp_path, [f"pf7sample:{sample_path}", f"pf7fws:{fws_path}", f"vcf:{vcf}"], VcfFlavour="Falciparum",
+                         Pf7QualityFilter="TRUE" if quality_filter else "FALSE", Pf7FilterQC="TRUE" if filter_qc else "FALSE",
+                         Pf7FilterFWS="TRUE" if filter_fws else "FALSE")
+    assert res.returncode == 0, res.stderr
+
+    opop = oa.Population("pf")
+    opop.add_vcf_pf(text)
+    if quality_filter:
+        opop = opop.filter_p7()
+    kept = opop.filter_pf7_genomes(sample_path, fws_path, filter_qc, filter_fws)
+    kept.genome_ids = list(ids)
+    kept_ids = [ids[i] for i in kept.genome_order()]
+    want_ids = sorted(g for g in ids if (not filter_qc or records[g]["qc"]) and
+                      (not filter_fws or (records[g]["fws"] is not None and records[g]["fws"] >= 0.95)))
+    assert kept_ids == want_ids and 10 < len(kept_ids) < G
+
+    variant_out, genome_out, vdb = kept.fws()
+    header, rows = rio.read_csv(tmp_path / "VariantFWS.csv")
+    assert [r[0] for r in rows] == [vdb.hgvs(i) for i in range(vdb.n_variants)]        # variants nobody kept carries are gone
+    assert np.array_equal(np.array([[int(x) for x in r[-3:]] for r in rows], dtype=np.uint64), variant_out)
+    header, rows = rio.read_csv(tmp_path / "GenomeFWS.csv")
+    assert [r[0] for r in rows] == kept_ids
+    got = np.array([[int(r[1 + 8 * b + 5 + k]) for b in range(11) for k in range(3)] for r in rows], dtype=np.uint64)
+    assert np.array_equal(got.reshape(len(rows), 11, 3), genome_out)
+
+    want_stats, want_loc = tmp_path / "oracle_stats.csv", tmp_path / "oracle_location.csv"
+    assert kept.write_pfemp_location(sample_path, fws_path, want_stats, want_loc) == 0
+    assert (tmp_path / "VariantLocation.csv").read_bytes() == want_loc.read_bytes()
+    assert (tmp_path / "VariantStatistics.csv").read_bytes() == want_stats.read_bytes()
