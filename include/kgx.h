@@ -199,6 +199,17 @@ int kgx_compound_offsets_listed(kgx_pop* pop, const uint32_t* member_rows, uint6
                                 const uint32_t* n_rows, const uint32_t* bin, uint64_t n_groups, uint32_t n_bins,
                                 uint64_t* out /* host [n_genomes][n_bins][3] */);
 
+/* The offset filters of kgl_genomics/kgl_variant_filter/kgl_variant_filter_db_offset.cpp as device-side counting predicates:
+ * out[g][b] = { HomozygousFilter (:17-58), HeterozygousFilter (:66-101), DiploidFilter (:110-129), UniqueUnphasedFilter
+ * (:137-156) } = the Variant objects PopulationDB::viewFilter(F) leaves genome g in bin b (its variantCount() there).
+ * Offsets holding >= 2 distinct variants come as row lists, as for kgx_compound_offsets_listed; every other row is an
+ * offset of its own and single_bin[row] names its bin (0xFF: not counted; required for the rows of the lists).  A cell
+ * with more than two copies of one variant (code 3) counts as "more than two" wherever the exact number does not matter
+ * -- it never does for these four filters.  Honours the genome mask. */
+int kgx_offset_filter_counts(kgx_pop* pop, const uint8_t* single_bin /* host [n_variants] */, const uint32_t* member_rows, uint64_t n_members,
+                             const uint32_t* first_member, const uint32_t* n_rows, const uint32_t* bin, uint64_t n_groups, uint32_t n_bins,
+                             uint64_t* out /* host [n_genomes][n_bins][4] */);
+
 /* ---- K4: VariantDBVariant::populationSummary (kgl_variant_db_variant.cpp:234-279). */
 int kgx_population_summary(kgx_pop* pop, uint64_t out[4]);
 

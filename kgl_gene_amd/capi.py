@@ -94,6 +94,8 @@ _SIGNATURES = {
     "kgx_gt8_synth_inbred": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint64]),
     "kgx_compound_offsets": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_void_p]),
     "kgx_compound_offsets_listed": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_void_p]),
+    "kgx_offset_filter_counts": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32,
+                                           C.c_void_p]),
 }
 
 
@@ -376,6 +378,21 @@ class Population:
         bn = np.ascontiguousarray(bins, dtype=np.uint32)
         out = np.zeros((self.n_genomes, n_bins, 3), dtype=np.uint64)
         check(lib().kgx_compound_offsets_listed(self._h, ptr(mr), len(mr), ptr(fm), ptr(nr), ptr(bn), len(fm), n_bins, ptr(out)))
+        return out
+
+    def offset_filter_counts(self, single_bin, member_rows, first_member, n_rows, bins, n_bins: int) -> np.ndarray:
+        """[n_genomes][n_bins][4] uint64: the Variant objects HomozygousFilter / HeterozygousFilter / DiploidFilter /
+        UniqueUnphasedFilter leave each genome per bin.  single_bin[row]: the bin of a row alone at its offset (0xFF for
+        the members of the listed groups and for rows not counted)."""
+        sb = np.ascontiguousarray(single_bin, dtype=np.uint8)
+        if sb.shape != (self.n_variants,):
+            raise ValueError("single_bin must be [n_variants]")
+        mr = np.ascontiguousarray(member_rows, dtype=np.uint32)
+        fm = np.ascontiguousarray(first_member, dtype=np.uint32)
+        nr = np.ascontiguousarray(n_rows, dtype=np.uint32)
+        bn = np.ascontiguousarray(bins, dtype=np.uint32)
+        out = np.zeros((self.n_genomes, n_bins, 4), dtype=np.uint64)
+        check(lib().kgx_offset_filter_counts(self._h, ptr(sb), ptr(mr), len(mr), ptr(fm), ptr(nr), ptr(bn), len(fm), n_bins, ptr(out)))
         return out
 
     def population_summary(self) -> np.ndarray:

@@ -295,12 +295,14 @@ int count_by_genome_impl(kgx_pop* pop, const uint8_t* bin_of_variant, uint32_t n
 }
 
 // row_list (may be empty): the groups' member rows; a group's first_row is then its first position in the list.
-int compound_offsets_shard(kgx_pop_shard& sh, const std::vector<OffsetGroup>& groups, const std::vector<uint32_t>& row_list, uint32_t n_bins, uint64_t* out) {
+// fields: 3 = k_compound_offsets' counters, 4 = k_offset_filters'.
+int compound_offsets_shard(kgx_pop_shard& sh, const std::vector<OffsetGroup>& groups, const std::vector<uint32_t>& row_list, uint32_t n_bins, uint64_t* out,
+                           uint32_t fields = 3) {
   const uint64_t G = sh.n_genomes, n_groups = groups.size();
   if (G == 0) return KGX_OK;
   if (int rc = use_device(*sh.dev)) return rc;
   const Device& dev = *sh.dev;
-  const uint64_t cells = G * n_bins * 3;
+  const uint64_t cells = G * n_bins * fields;
   OffsetGroup* d_groups = nullptr;
   uint32_t* d_list = nullptr;
   unsigned long long* d_acc = nullptr;
@@ -323,9 +325,14 @@ int compound_offsets_shard(kgx_pop_shard& sh, const std::vector<OffsetGroup>& gr
         (d_list && hipMemcpyAsync(d_list, row_list.data(), row_list.size() * sizeof(uint32_t), hipMemcpyHostToDevice, dev.stream) != hipSuccess)) {
       rc = fail(KGX_EHIP, "compound_offsets: upload failed");
     } else {
-      hipLaunchKernelGGL(k_compound_offsets, dim3(gx, gy), dim3(kBlock), 0, dev.stream,
-                         reinterpret_cast<const uint32_t*>(sh.d_rows), sh.pitch / 4, G, d_groups, n_groups, per_slice,
-                         d_list, n_bins, d_acc);
+      if (fields == 4)
+        hipLaunchKernelGGL(k_offset_filters, dim3(gx, gy), dim3(kBlock), 0, dev.stream,
+                           reinterpret_cast<const uint32_t*>(sh.d_rows), sh.pitch / 4, G, d_groups, n_groups, per_slice,
+                           d_list, n_bins, d_acc);
+      else
+        hipLaunchKernelGGL(k_compound_offsets, dim3(gx, gy), dim3(kBlock), 0, dev.stream,
+                           reinterpret_cast<const uint32_t*>(sh.d_rows), sh.pitch / 4, G, d_groups, n_groups, per_slice,
+                           d_list, n_bins, d_acc);
       if (hipGetLastError() != hipSuccess ||
           hipMemcpyAsync(out, d_acc, cells * sizeof(unsigned long long), hipMemcpyDeviceToHost, dev.stream) != hipSuccess ||
           hipStreamSynchronize(dev.stream) != hipSuccess)
@@ -901,6 +908,51 @@ int kgx_compound_offsets_listed(kgx_pop* pop, const uint32_t* member_rows, uint6
     return compound_offsets_shard(sh, groups, row_list, n_bins, out + sh.genome_base * n_bins * 3);
   });
   if (rc == KGX_OK) zero_masked_genomes(pop, out, static_cast<uint64_t>(n_bins) * 3);
+  (void)use_device(*pop->shards[0].dev);
+  return rc;
+}
+
+int kgx_offset_filter_counts(kgx_pop* pop, const uint8_t* single_bin, const uint32_t* member_rows, uint64_t n_members, const uint32_t* first_member,
+                             const uint32_t* n_rows, const uint32_t* bin, uint64_t n_groups, uint32_t n_bins, uint64_t* out) {
+  if (int bound = require_bound()) return bound;
+  if (!pop || !out || !single_bin || (n_groups && (!member_rows || !first_member || !n_rows || !bin))) return fail(KGX_EINVAL, "null argument");
+  if (n_bins == 0 || n_bins > 254) return fail(KGX_EINVAL, "n_bins %u outside [1,254]", n_bins);
+  if (n_members > 0xFFFFFFFFull) return fail(KGX_EINVAL, "more than 2^32 member rows");
+  const uint64_t cells = pop->n_genomes * n_bins;
+  // offsets of one row: its dosage decides, per genome -- the by-genome sweep's counters, re-read per filter
+  std::vector<uint64_t> single(cells * 4, 0);
+  if (pop->n_variants)
+    if (int rc = count_by_genome_impl(pop, single_bin, n_bins, single.data())) { (void)use_device(*pop->shards[0].dev); return rc; }
+  for (uint64_t c = 0; c < cells; ++c) {
+    const uint64_t het = single[c * 4 + 1], hom = single[c * 4 + 2], more = single[c * 4 + 3];
+    out[c * 4 + 0] = 2 * hom;                 // HomozygousFilter: the two copies of the one variant
+    out[c * 4 + 1] = het;                     // HeterozygousFilter
+    out[c * 4 + 2] = het + 2 * hom;           // DiploidFilter: nothing of an offset holding more than two
+    out[c * 4 + 3] = het + hom + more;        // UniqueUnphasedFilter
+  }
+  if (n_groups == 0) return use_device(*pop->shards[0].dev);
+  std::vector<OffsetGroup> groups(n_groups);
+  for (uint64_t i = 0; i < n_groups; ++i) {
+    if (n_rows[i] > 15) return fail(KGX_EINVAL, "group %llu has %u rows; at most 15 distinct variants per offset are supported",
+                                    (unsigned long long)i, n_rows[i]);
+    if (static_cast<uint64_t>(first_member[i]) + n_rows[i] > n_members || bin[i] >= n_bins)
+      return fail(KGX_EINVAL, "group %llu out of range", (unsigned long long)i);
+    groups[i] = OffsetGroup{first_member[i], n_rows[i], bin[i], 0};
+  }
+  const std::vector<uint32_t> row_list(member_rows, member_rows + n_members);
+  for (uint32_t row : row_list) {
+    if (row >= pop->n_variants) return fail(KGX_EINVAL, "member row %u past the population's %llu rows", row, (unsigned long long)pop->n_variants);
+    if (single_bin[row] != 0xFF) return fail(KGX_EINVAL, "row %u is a member of a group and has a bin of its own", row);
+  }
+  std::vector<uint64_t> grouped(cells * 4, 0);
+  const int rc = for_each_parallel(pop->shards.size(), [&](size_t s) {
+    kgx_pop_shard& sh = pop->shards[s];
+    return compound_offsets_shard(sh, groups, row_list, n_bins, grouped.data() + sh.genome_base * n_bins * 4, 4);
+  });
+  if (rc == KGX_OK) {
+    zero_masked_genomes(pop, grouped.data(), static_cast<uint64_t>(n_bins) * 4);
+    for (uint64_t i = 0; i < cells * 4; ++i) out[i] += grouped[i];
+  }
   (void)use_device(*pop->shards[0].dev);
   return rc;
 }

@@ -580,6 +580,82 @@ k_compound_offsets(const uint32_t* __restrict__ rows, uint64_t dwords_per_row, u
   flush(current_bin);
 }
 
+// The offset filters of kgl_genomics/kgl_variant_filter/kgl_variant_filter_db_offset.cpp as counting predicates: how many
+// Variant objects each leaves of a genome's offset, summed per (genome, bin) -- PopulationDB::viewFilter(F) followed by
+// variantCount().  At an offset a genome holds ns variants once, n2 twice, n3 more often (np = ns + n2 + n3 distinct):
+//   HomozygousFilter     (:17-58)    two objects in all, of one variant:  n3 == 0 && n2 == 1 && ns == 0  -> 2
+//   HeterozygousFilter   (:66-101)   the variants held exactly once:                                      -> ns
+//   DiploidFilter        (:110-129)  everything if at most two objects: n3 == 0 && ns + 2 n2 <= 2        -> ns + 2 n2
+//   UniqueUnphasedFilter (:137-156)  one object per distinct variant:                                     -> np
+// Same walk as k_compound_offsets (offsets holding >= 2 distinct variants; the offsets of a single row follow from the
+// by-genome sweep); acc[g][bin][4] in the order above.
+__global__ void __launch_bounds__(kBlock)
+k_offset_filters(const uint32_t* __restrict__ rows, uint64_t dwords_per_row, uint64_t n_genomes,
+                 const OffsetGroup* __restrict__ groups, uint64_t n_groups, uint64_t groups_per_slice,
+                 const uint32_t* __restrict__ row_list, uint32_t n_bins, unsigned long long* __restrict__ acc) {
+  const uint64_t col = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x;   // dword column = 16 genomes
+  if (col * 16 >= n_genomes) return;
+  const uint64_t g_begin = static_cast<uint64_t>(blockIdx.y) * groups_per_slice;
+  const uint64_t g_end = g_begin + groups_per_slice < n_groups ? g_begin + groups_per_slice : n_groups;
+  uint32_t homozygous[16], heterozygous[16], diploid[16], unique[16];
+#pragma unroll
+  for (int j = 0; j < 16; ++j) homozygous[j] = heterozygous[j] = diploid[j] = unique[j] = 0;
+  uint32_t current_bin = g_begin < g_end ? groups[g_begin].bin : 0;
+
+  auto flush = [&](uint32_t bin) {
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      const uint64_t g = col * 16 + j;
+      if (g < n_genomes) {
+        unsigned long long* a = acc + (g * n_bins + bin) * 4;
+        if (homozygous[j]) atomicAdd(a + 0, static_cast<unsigned long long>(homozygous[j]));
+        if (heterozygous[j]) atomicAdd(a + 1, static_cast<unsigned long long>(heterozygous[j]));
+        if (diploid[j]) atomicAdd(a + 2, static_cast<unsigned long long>(diploid[j]));
+        if (unique[j]) atomicAdd(a + 3, static_cast<unsigned long long>(unique[j]));
+      }
+      homozygous[j] = heterozygous[j] = diploid[j] = unique[j] = 0;
+    }
+  };
+
+  for (uint64_t gi = g_begin; gi < g_end; ++gi) {
+    const OffsetGroup grp = groups[gi];
+    if (grp.bin != current_bin) {
+      flush(current_bin);
+      current_bin = grp.bin;
+    }
+    // per-genome row counts in 4-bit fields (a group holds at most 15 rows), even and odd genomes apart
+    uint32_t present_e = 0, present_o = 0, single_e = 0, single_o = 0, twice_e = 0, twice_o = 0, more = 0;
+    for (uint32_t r = 0; r < grp.n_rows; ++r) {
+      const uint64_t row = row_list ? static_cast<uint64_t>(row_list[grp.first_row + r]) : static_cast<uint64_t>(grp.first_row) + r;   // group-uniform
+      const uint32_t w = rows[row * dwords_per_row + col];
+      const uint32_t lo = w & 0x55555555u, hi = (w >> 1) & 0x55555555u;
+      const uint32_t present = lo | hi, single = lo & ~hi, twice = hi & ~lo;
+      present_e += present & 0x11111111u;
+      present_o += (present >> 2) & 0x11111111u;
+      single_e += single & 0x11111111u;
+      single_o += (single >> 2) & 0x11111111u;
+      twice_e += twice & 0x11111111u;
+      twice_o += (twice >> 2) & 0x11111111u;
+      more |= lo & hi;
+    }
+    if ((present_e | present_o) == 0) continue;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      const int shift = 4 * (j >> 1);
+      const uint32_t np = ((j & 1) ? present_o : present_e) >> shift & 0xFu;
+      const uint32_t ns = ((j & 1) ? single_o : single_e) >> shift & 0xFu;
+      const uint32_t n2 = ((j & 1) ? twice_o : twice_e) >> shift & 0xFu;
+      const bool n3 = (more >> (2 * j)) & 1u;
+      const uint32_t objects = ns + 2 * n2;                       // exact when n3 is false
+      homozygous[j] += (!n3 && n2 == 1 && ns == 0) ? 2u : 0u;
+      heterozygous[j] += ns;
+      diploid[j] += (!n3 && objects <= 2) ? objects : 0u;
+      unique[j] += np;
+    }
+  }
+  flush(current_bin);
+}
+
 // ---------------------------------------------------------------------------------------------
 // Flattening helpers.
 // ---------------------------------------------------------------------------------------------

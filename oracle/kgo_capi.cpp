@@ -551,6 +551,28 @@ int kgo_hethom_present(kgo_pop* p, const char* contig, uint8_t* out) {
   return 0;
 }
 
+// The Variant objects each offset filter of kgl_variant_filter_db_offset.cpp leaves of one contig, per genome (genome-id
+// order): out[g][4] = { HomozygousFilter, HeterozygousFilter, DiploidFilter, UniqueUnphasedFilter } -- what
+// PopulationDB::viewFilter(F) followed by variantCount() gives for that genome and contig.
+int kgo_offset_filter_counts(kgo_pop* p, const char* contig, uint64_t* out) {
+  if (!p || !contig || !out) return -1;
+  size_t g = 0;
+  for (const auto& [genome_id, genome_ptr] : p->pop->getMap()) {
+    uint64_t* o = out + g * 4;
+    o[0] = o[1] = o[2] = o[3] = 0;
+    auto found = genome_ptr->getMap().find(contig);
+    if (found != genome_ptr->getMap().end())
+      for (const auto& [offset, offset_ptr] : found->second->getMap()) {
+        o[0] += homozygousFilter(*offset_ptr)->getVariantArray().size();
+        o[1] += heterozygousFilter(*offset_ptr)->getVariantArray().size();
+        o[2] += diploidFilter(*offset_ptr)->getVariantArray().size();
+        o[3] += uniqueUnphasedFilter(*offset_ptr)->getVariantArray().size();
+      }
+    ++g;
+  }
+  return 0;
+}
+
 double kgo_wrights_fis(const uint64_t location[7], const uint64_t genome[7]) {
   VariantAnalysisType l, g;
   l.total_variants_ = location[0]; l.heterozygous_minor_alleles_ = location[4]; l.heterozygous_reference_minor_alleles_ = location[5];

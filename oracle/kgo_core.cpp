@@ -120,6 +120,13 @@ std::unique_ptr<OffsetDB> uniqueUnphasedFilter(const OffsetDB& offset) {
   return out;
 }
 
+std::unique_ptr<OffsetDB> diploidFilter(const OffsetDB& offset) {
+  auto out = std::make_unique<OffsetDB>();
+  if (offset.getVariantArray().size() <= 2)
+    for (const auto& v : offset.getVariantArray()) out->addVariant(v);
+  return out;
+}
+
 // ---- ContigDB ----------------------------------------------------------------------------------
 
 bool ContigDB::addVariant(const VariantPtr& v) {
