@@ -242,6 +242,31 @@ def aux_by_genome(capi, torch, pop, counts, G, V, dense, nv):
     return record
 
 
+def aux_genome_mask(capi, torch, pop, counts, G, V, sweep_bytes, seed):
+    """K2 under a genome mask (kgx_population_set_genome_mask: the Pf7 QC / monoclonal genome lists of FilterPf7 as a
+    per-launch predicate instead of a re-flattened population): same rows, one cached mask row more.  Checked in-run
+    against the unmasked counts of the kept genomes' complement being absent: row sums == genomes kept."""
+    keep = np.random.default_rng(seed).random(G) < 0.7
+    pop.set_genome_mask(keep)
+    ms = pop.allele_count_timed(counts.data_ptr(), torch.cuda.current_stream().cuda_stream, 2, 10)
+    torch.cuda.synchronize()
+    rows = counts[:4096].cpu().numpy().view(np.uint32)
+    ok = bool(np.all(rows.astype(np.uint64).sum(1) == int(keep.sum())))
+    pop.set_genome_mask(None)
+    kernel_ms = float(np.median(ms))
+    achieved = sweep_bytes / (kernel_ms * 1e-3) / 1e9
+    return {
+        "metric": "variants·genomes/sec (allele-freq sweep under a genome mask)",
+        "value": int(keep.sum()) * V / (kernel_ms * 1e-3), "unit": "variants·genomes/s (genomes kept)", "ms_per_call": kernel_ms, "calls": len(ms),
+        "config": {"workload": f"K2 on the headline population with {int(keep.sum())} of {G} genomes kept",
+                   "check": "row sums == genomes kept on the first 4096 variants: " + ("ok" if ok else "MISMATCH")},
+        "roofline": {"bound": "hbm", "kernel": "k_allele_count<..., MASKED>", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": None, "algorithmic_bytes_per_launch": sweep_bytes + (G + 3) // 4,
+                     "kernel_ms": kernel_ms},
+        "cpu_baseline": None,
+    }
+
+
 def aux_inbreeding(args, capi, torch, dev, cpu):
     """C5 (BASELINE.json configs[4]) on this GPU: generateFrequencies + processSimple for every genome over every locus
     (kga_analysis_inbreed_freq.cpp:425-583, _calc.cpp:318-365) = one kgx_inbreed call; the AF table is resident in HBM.
@@ -550,6 +575,7 @@ def main():
             result["cpu_baseline"] = None
         if n_gpus == 1 and args.workload == "c3" and not args.no_aux:
             aux = {"k3_fws_bins": aux_by_genome(capi, torch, pop, counts.view(torch.int32), G, V, dense, nv)}
+            aux["k2_genome_mask"] = aux_genome_mask(capi, torch, pop, counts, G, V, sweep_bytes, args.seed)
             del dense
             pop.close()
             del bufs, counts, af

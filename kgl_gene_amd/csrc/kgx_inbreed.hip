@@ -353,10 +353,31 @@ int inbreed_shard(kgx_gt8_shard& sh, uint64_t g0, uint64_t g1, const uint32_t* l
       try_hip(hipMemcpyAsync(d_f, f0.data(), n * sizeof(double), hipMemcpyHostToDevice, st), KGX_EHIP, "H2D(f0)");
       try_hip(hipStreamSynchronize(st), KGX_EHIP, "sync");
       tabulate(1);
+      std::vector<double> trace_prev, trace_prev2, trace_now;
+      const bool trace = env_int("KGX_K7_TRACE", 0) != 0;
+      if (trace) { trace_prev = f0; trace_prev2 = f0; trace_now.resize(n); }
       for (int it = 0; it < 50 && rc == KGX_OK; ++it) {
         sweep(1);
         hipLaunchKernelGGL(k_reduce_parts, dim3(reduce_grid(n)), dim3(kBlock), 0, st, d_part, pass_n_seg, n, nullptr, d_eval);
         hipLaunchKernelGGL(k_hall_update, dim3(lin_grid), dim3(kBlock), 0, st, d_eval, d_counts, n, walked, d_f);
+        if (trace) {
+          try_hip(hipMemcpyAsync(trace_now.data(), d_f, n * sizeof(double), hipMemcpyDeviceToHost, st), KGX_EHIP, "D2H(trace)");
+          try_hip(hipStreamSynchronize(st), KGX_EHIP, "sync");
+          uint64_t changed = 0, cycling = 0;
+          double worst = 0.0;
+          for (uint64_t g = 0; g < n; ++g) {
+            if (trace_now[g] != trace_prev[g]) {
+              ++changed;
+              if (trace_now[g] == trace_prev2[g]) ++cycling;
+              const double d = std::fabs(trace_now[g] - trace_prev[g]);
+              worst = d > worst ? d : worst;
+            }
+          }
+          std::fprintf(stderr, "[kgx] HallME step %d: %llu of %llu genomes moved (%llu back to the value before), largest move %.3e\n", it + 1,
+                       (unsigned long long)changed, (unsigned long long)n, (unsigned long long)cycling, worst);
+          trace_prev2 = trace_prev;
+          trace_prev = trace_now;
+        }
       }
     } else if (algorithm == 3) {
       // processLogLikelihood (_calc.cpp:153-216): maximise over [-1,1].  The objective is a sum of logs of
