@@ -276,3 +276,35 @@ def test_bench_exchange_calls_run_on_rccl_with_one_rank(tmp_path):
     env = dict(os.environ, KGX_ROOT=str(Path(__file__).resolve().parent.parent), HSA_ENABLE_IPC_MODE_LEGACY="0")
     res = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, env=env, timeout=600)
     assert res.returncode == 0 and "one-rank RCCL exchange ok" in res.stdout, res.stderr[-3000:]
+
+
+@pytest.mark.parametrize("workload", ["c3", "c5"])
+def test_bench_two_ranks_rehearsal_on_one_device(tmp_path, workload):
+    """bench.py's N > 1 path end to end, as the driver launches it (torch.distributed.run, one process per rank), on the
+    one GPU of the test box: both ranks sweep their genome shard with the HIP kernels on device 0 and the counts are
+    exchanged through gloo (KGX_BENCH_REHEARSAL=1; RCCL refuses two ranks on one device -- its calls are covered by the
+    one-rank test above).  The line must be rank 0's only, carry both ranks' work and pass its own exchange check."""
+    import json
+    import os
+    import subprocess
+    import sys
+    from pathlib import Path
+
+    root = Path(__file__).resolve().parent.parent
+    env = dict(os.environ, KGX_BENCH_REHEARSAL="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for key in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(key, None)
+    shape = ["--genomes", "3000", "--variants", "300000"] if workload == "c3" else ["--workload", "c5", "--genomes", "1500", "--variants", "100000"]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port",
+           "29541" if workload == "c3" else "29542", str(root / "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--no-cpu-baseline", *shape]
+    res = subprocess.run(cmd, env=env, cwd=str(tmp_path), capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stderr[-3000:]
+    lines = [line for line in res.stdout.splitlines() if line.startswith("{")]
+    assert len(lines) == 1, res.stdout
+    record = json.loads(lines[0])
+    assert record["n_gpus"] == 2 and record["steps"] == 3 and record["warmup"] == 1 and record["value"] > 0
+    assert record["scaling"] == "weak" and record["vs_baseline"] is None
+    if workload == "c3":
+        assert record["config"]["total_genomes"] == 2 * record["config"]["genomes_per_gpu"] == 6000
+        assert record["config"]["exchange"].startswith("gloo rehearsal") and record["config"]["exchange_check"].endswith("ok")
+        assert abs(record["value"] - 6000 * 300000 * 3 / (record["ms_per_step"] * 3e-3)) <= 1e-6 * record["value"]
