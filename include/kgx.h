@@ -210,6 +210,16 @@ int kgx_offset_filter_counts(kgx_pop* pop, const uint8_t* single_bin /* host [n_
                              const uint32_t* first_member, const uint32_t* n_rows, const uint32_t* bin, uint64_t n_groups, uint32_t n_bins,
                              uint64_t* out /* host [n_genomes][n_bins][4] */);
 
+/* ---- Genome-major row lists: for every genome of [g0, g1) the rows it carries (dosage > 0), ascending -- the visit
+ *      GenomeDB::processAll makes of one genome, on which VariantSort::variantGenomeIndexMT builds its per-genome
+ *      identifier maps (kgl_genomics/kgl_variant_analysis/kgl_variant_sort.cpp:234-306, one pool task per genome; the
+ *      IndexMap keeps Variants with a non-empty identifier, :245-255).  A sparse transpose of the bit matrix on the device.
+ *      row_selected: host [n_variants] or NULL (every row) -- e.g. the rows whose variant bears an identifier.
+ *      begin: host [g1 - g0 + 1], begin[i] .. begin[i+1] = genome g0 + i's entries in rows; rows: host [capacity], or NULL
+ *      to size the call (begin[g1 - g0] = entries needed).  Genomes a genome mask leaves out have no entries. */
+int kgx_genome_row_lists(kgx_pop* pop, uint64_t g0, uint64_t g1, const uint8_t* row_selected /* or NULL */, uint64_t* begin,
+                         uint32_t* rows /* or NULL */, uint64_t capacity);
+
 /* ---- K4: VariantDBVariant::populationSummary (kgl_variant_db_variant.cpp:234-279). */
 int kgx_population_summary(kgx_pop* pop, uint64_t out[4]);
 

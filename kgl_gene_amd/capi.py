@@ -94,6 +94,7 @@ _SIGNATURES = {
     "kgx_gt8_synth_inbred": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint64]),
     "kgx_compound_offsets": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_void_p]),
     "kgx_compound_offsets_listed": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_void_p]),
+    "kgx_genome_row_lists": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64]),
     "kgx_offset_filter_counts": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32,
                                            C.c_void_p]),
 }
@@ -394,6 +395,18 @@ class Population:
         out = np.zeros((self.n_genomes, n_bins, 4), dtype=np.uint64)
         check(lib().kgx_offset_filter_counts(self._h, ptr(sb), ptr(mr), len(mr), ptr(fm), ptr(nr), ptr(bn), len(fm), n_bins, ptr(out)))
         return out
+
+    def genome_row_lists(self, g0: int = 0, g1: int | None = None, row_selected: np.ndarray | None = None):
+        """(begin [g1-g0+1] uint64, rows uint32): for every genome of [g0, g1) the rows it carries, ascending."""
+        g1 = self.n_genomes if g1 is None else g1
+        sel = None if row_selected is None else np.ascontiguousarray(np.asarray(row_selected) != 0, dtype=np.uint8)
+        if sel is not None and sel.shape != (self.n_variants,):
+            raise ValueError("row_selected must be [n_variants]")
+        begin = np.zeros(g1 - g0 + 1, dtype=np.uint64)
+        check(lib().kgx_genome_row_lists(self._h, g0, g1, ptr(sel) if sel is not None else None, ptr(begin), None, 0))
+        rows = np.zeros(int(begin[-1]), dtype=np.uint32)
+        check(lib().kgx_genome_row_lists(self._h, g0, g1, ptr(sel) if sel is not None else None, ptr(begin), ptr(rows), len(rows)))
+        return begin, rows
 
     def population_summary(self) -> np.ndarray:
         out = np.zeros(4, dtype=np.uint64)

@@ -345,6 +345,83 @@ int compound_offsets_shard(kgx_pop_shard& sh, const std::vector<OffsetGroup>& gr
   return rc;
 }
 
+// One shard's genome-major row lists for its genomes [g_lo, g_hi) (shard-local numbers): begin (host, g_hi - g_lo + 1
+// entries, starting at 0) and, when rows_out is given, the row numbers.
+int genome_row_lists_shard(kgx_pop_shard& sh, uint64_t g_lo, uint64_t g_hi, const uint8_t* row_selected, std::vector<unsigned long long>& begin,
+                           std::vector<uint32_t>* rows_out) {
+  const uint64_t V = sh.n_variants, n = g_hi - g_lo;
+  begin.assign(n + 1, 0);
+  if (n == 0 || V == 0) return KGX_OK;
+  if (V > 0xFFFFFFFFull) return fail(KGX_EINVAL, "n_variants exceeds the 32-bit row numbers of the row lists");
+  Device& dev = *sh.dev;
+  if (int rc = use_device(dev)) return rc;
+  hipStream_t st = dev.stream;
+  const uint64_t genomes_padded = (static_cast<uint64_t>(sh.chunks_per_row) + kListChunks - 1) / kListChunks * kListChunks * 64u;
+  const uint64_t first_group = g_lo / (64u * kListChunks), last_group = (g_hi - 1) / (64u * kListChunks);
+  const uint32_t gx = static_cast<uint32_t>((last_group - first_group + 1 + (kBlock / kWave) - 1) / (kBlock / kWave));
+  // slices of whole 64-row tiles: enough workgroups to fill the device, at most 65535
+  uint64_t slices = (static_cast<uint64_t>(dev.compute_units) * 16 + gx - 1) / gx;
+  const uint64_t tiles = (V + kWave - 1) / kWave;
+  if (slices > tiles) slices = tiles;
+  if (slices > 65535) slices = 65535;
+  const uint64_t rows_per_slice = (tiles + slices - 1) / slices * kWave;
+  slices = (V + rows_per_slice - 1) / rows_per_slice;
+  uint8_t* d_sel = nullptr;
+  uint32_t *d_counts = nullptr, *d_out = nullptr;
+  unsigned long long *d_cursors = nullptr, *d_begin = nullptr, *d_totals = nullptr;
+  int rc = KGX_OK;
+  auto try_hip = [&](hipError_t e, int code, const char* what) {
+    if (rc == KGX_OK && e != hipSuccess) {
+      (void)hipGetLastError();
+      rc = fail(code, "genome_row_lists: %s failed: %s", what, hipGetErrorString(e));
+    }
+  };
+  try_hip(hipMalloc(&d_totals, sh.n_genomes * sizeof(unsigned long long)), KGX_ENOMEM, "hipMalloc(totals)");
+  try_hip(hipMalloc(&d_counts, slices * genomes_padded * sizeof(uint32_t)), KGX_ENOMEM, "hipMalloc(counts)");
+  try_hip(hipMalloc(&d_cursors, slices * genomes_padded * sizeof(unsigned long long)), KGX_ENOMEM, "hipMalloc(cursors)");
+  try_hip(hipMalloc(&d_begin, (sh.n_genomes + 1) * sizeof(unsigned long long)), KGX_ENOMEM, "hipMalloc(begin)");
+  if (row_selected) {
+    try_hip(hipMalloc(&d_sel, V), KGX_ENOMEM, "hipMalloc(selection)");
+    try_hip(hipMemcpyAsync(d_sel, row_selected, V, hipMemcpyHostToDevice, st), KGX_EHIP, "H2D(selection)");
+  }
+  try_hip(hipMemsetAsync(d_counts, 0, slices * genomes_padded * sizeof(uint32_t), st), KGX_EHIP, "memset(counts)");
+  std::vector<unsigned long long> shard_begin(sh.n_genomes + 1, 0);
+  if (rc == KGX_OK) {
+    hipLaunchKernelGGL((k_genome_row_lists<false>), dim3(gx, static_cast<uint32_t>(slices)), dim3(kBlock), 0, st,
+                       reinterpret_cast<const kgx_v4u*>(sh.d_rows), sh.chunks_per_row, V, sh.n_genomes, g_lo, g_hi,
+                       reinterpret_cast<const kgx_v4u*>(sh.d_keep), d_sel, rows_per_slice, d_counts, genomes_padded, nullptr, nullptr);
+    const uint32_t by_genome = static_cast<uint32_t>((sh.n_genomes + kBlock - 1) / kBlock);
+    hipLaunchKernelGGL(k_row_list_totals, dim3(by_genome), dim3(kBlock), 0, st, d_counts, slices, genomes_padded, sh.n_genomes, d_totals);
+    hipLaunchKernelGGL(k_row_list_scan, dim3(1), dim3(kBlock), 0, st, d_totals, sh.n_genomes, d_begin);
+    hipLaunchKernelGGL(k_row_list_cursors, dim3(by_genome), dim3(kBlock), 0, st, d_counts, slices, genomes_padded, sh.n_genomes, d_begin, d_cursors);
+    try_hip(hipGetLastError(), KGX_EHIP, "count / offset kernels");
+    try_hip(hipMemcpyAsync(shard_begin.data(), d_begin, (sh.n_genomes + 1) * sizeof(unsigned long long), hipMemcpyDeviceToHost, st), KGX_EHIP, "D2H(begin)");
+    try_hip(hipStreamSynchronize(st), KGX_EHIP, "sync");
+  }
+  if (rc == KGX_OK) {
+    // genomes outside [g_lo, g_hi) list nothing, so the scan's values at g_lo .. g_hi are the range's own, starting at 0
+    for (uint64_t g = 0; g <= n; ++g) begin[g] = shard_begin[g_lo + g];
+    const unsigned long long total = begin[n];
+    if (rows_out) {
+      rows_out->assign(total, 0u);
+      if (total) {
+        try_hip(hipMalloc(&d_out, total * sizeof(uint32_t)), KGX_ENOMEM, "hipMalloc(rows)");
+        if (rc == KGX_OK) {
+          hipLaunchKernelGGL((k_genome_row_lists<true>), dim3(gx, static_cast<uint32_t>(slices)), dim3(kBlock), 0, st,
+                             reinterpret_cast<const kgx_v4u*>(sh.d_rows), sh.chunks_per_row, V, sh.n_genomes, g_lo, g_hi,
+                             reinterpret_cast<const kgx_v4u*>(sh.d_keep), d_sel, rows_per_slice, nullptr, genomes_padded, d_cursors, d_out);
+          try_hip(hipGetLastError(), KGX_EHIP, "fill kernel");
+          try_hip(hipMemcpyAsync(rows_out->data(), d_out, total * sizeof(uint32_t), hipMemcpyDeviceToHost, st), KGX_EHIP, "D2H(rows)");
+          try_hip(hipStreamSynchronize(st), KGX_EHIP, "sync");
+        }
+      }
+    }
+  }
+  for (void* p : {static_cast<void*>(d_sel), static_cast<void*>(d_counts), static_cast<void*>(d_cursors), static_cast<void*>(d_begin), static_cast<void*>(d_totals), static_cast<void*>(d_out)})
+    if (p) (void)hipFree(p);
+  return rc;
+}
+
 int sync_shards(const kgx_pop* pop) {
   for (const auto& sh : pop->shards) {
     if (int rc = use_device(*sh.dev)) return rc;
@@ -955,6 +1032,39 @@ int kgx_offset_filter_counts(kgx_pop* pop, const uint8_t* single_bin, const uint
   }
   (void)use_device(*pop->shards[0].dev);
   return rc;
+}
+
+int kgx_genome_row_lists(kgx_pop* pop, uint64_t g0, uint64_t g1, const uint8_t* row_selected, uint64_t* begin, uint32_t* rows, uint64_t capacity) {
+  if (int bound = require_bound()) return bound;
+  if (!pop || !begin) return fail(KGX_EINVAL, "null population or begin array");
+  if (g0 > g1 || g1 > pop->n_genomes) return fail(KGX_EINVAL, "genome range [%llu, %llu) outside the population's %llu genomes", (unsigned long long)g0,
+                                                  (unsigned long long)g1, (unsigned long long)pop->n_genomes);
+  const size_t n_shards = pop->shards.size();
+  std::vector<std::vector<unsigned long long>> shard_begin(n_shards);
+  std::vector<std::vector<uint32_t>> shard_rows(n_shards);
+  const int rc = for_each_parallel(n_shards, [&](size_t s) -> int {
+    kgx_pop_shard& sh = pop->shards[s];
+    const uint64_t lo = g0 > sh.genome_base ? g0 : sh.genome_base;
+    const uint64_t hi = g1 < sh.genome_base + sh.n_genomes ? g1 : sh.genome_base + sh.n_genomes;
+    if (lo >= hi) { shard_begin[s].assign(1, 0); return KGX_OK; }
+    return genome_row_lists_shard(sh, lo - sh.genome_base, hi - sh.genome_base, row_selected, shard_begin[s], rows ? &shard_rows[s] : nullptr);
+  });
+  (void)use_device(*pop->shards[0].dev);
+  if (rc != KGX_OK) return rc;
+  // the shards hold consecutive genome ranges: their lists follow one another
+  uint64_t at = 0, g = 0;
+  begin[0] = 0;
+  for (size_t s = 0; s < n_shards; ++s) {
+    const auto& b = shard_begin[s];
+    for (size_t i = 0; i + 1 < b.size(); ++i) begin[++g] = at + b[i + 1];
+    const uint64_t total = b.back();
+    if (rows) {
+      if (at + total > capacity) return fail(KGX_EINVAL, "row lists need %llu entries, capacity is %llu", (unsigned long long)(at + total), (unsigned long long)capacity);
+      if (total) std::memcpy(rows + at, shard_rows[s].data(), total * sizeof(uint32_t));
+    }
+    at += total;
+  }
+  return KGX_OK;
 }
 
 }  // extern "C"

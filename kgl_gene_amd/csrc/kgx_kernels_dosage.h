@@ -660,6 +660,136 @@ k_offset_filters(const uint32_t* __restrict__ rows, uint64_t dwords_per_row, uin
 }
 
 // ---------------------------------------------------------------------------------------------
+// Genome-major row lists out of the variant-major rows: for every genome the rows it carries (code != 0), ascending --
+// what GenomeDB::processAll hands a per-genome indexer (VariantSort::variantGenomeIndexMT, kgl_genomics/
+// kgl_variant_analysis/kgl_variant_sort.cpp:234-306, one pool task per genome there).  A sparse transpose of the bit
+// matrix: a wave owns four adjacent chunk columns (one 64-byte line, 256 genomes) and a slice of the rows; lane i loads
+// the line of row r0 + i, 64 ballots per chunk turn the 64 x 64 tile around (lane j ends up with the 64-row mask of its
+// genome), and the set bits become row numbers at the genome's cursor.  Two launches of the same walk: FILL = false counts
+// per (slice, genome), k_row_list_offsets turns the counts into cursors, FILL = true writes.
+// ---------------------------------------------------------------------------------------------
+constexpr int kListChunks = 4;             // chunk columns per wave: one 64-byte line of a row
+
+template <bool FILL>
+__global__ void __launch_bounds__(kBlock)
+k_genome_row_lists(const kgx_v4u* __restrict__ rows, uint32_t chunks_per_row, uint64_t n_rows, uint64_t n_genomes,
+                   uint64_t g_lo, uint64_t g_hi /* only genomes [g_lo, g_hi) are listed */,
+                   const kgx_v4u* __restrict__ keep /* the genome mask's row, or null */, const uint8_t* __restrict__ row_selected, uint64_t rows_per_slice,
+                   uint32_t* __restrict__ counts /* [slices][genomes padded to 256] */, uint64_t genomes_padded,
+                   const unsigned long long* __restrict__ cursors /* same shape: where each (slice, genome) starts */,
+                   uint32_t* __restrict__ out) {
+  const uint32_t lane = threadIdx.x & (kWave - 1);
+  const uint64_t wave = g_lo / (64u * kListChunks) + static_cast<uint64_t>(blockIdx.x) * (kBlock / kWave) + threadIdx.x / kWave;   // group of four chunk columns
+  const uint32_t c0 = static_cast<uint32_t>(wave) * kListChunks;
+  if (c0 >= chunks_per_row || static_cast<uint64_t>(c0) * 64u >= g_hi) return;
+  const uint64_t slice = blockIdx.y;
+  const uint64_t r_begin = slice * rows_per_slice;
+  const uint64_t r_end = r_begin + rows_per_slice < n_rows ? r_begin + rows_per_slice : n_rows;
+  unsigned long long cursor[kListChunks];
+  uint32_t count[kListChunks];
+  bool listed[kListChunks];                  // is this lane's genome of chunk k in the range (and kept by the mask)?
+#pragma unroll
+  for (int k = 0; k < kListChunks; ++k) {
+    count[k] = 0;
+    const uint64_t genome = (static_cast<uint64_t>(c0) + k) * 64u + lane;
+    listed[k] = genome >= g_lo && genome < g_hi;
+    if (keep != nullptr && c0 + k < chunks_per_row) {
+      const kgx_v4u m = keep[c0 + k];
+      listed[k] = listed[k] && ((m[lane >> 4] >> (2 * (lane & 15))) & 1u);
+    }
+    if constexpr (FILL) cursor[k] = cursors[slice * genomes_padded + (static_cast<uint64_t>(c0) + k) * 64u + lane];
+  }
+  for (uint64_t r0 = r_begin; r0 < r_end; r0 += kWave) {
+    const uint64_t r = r0 + lane;
+    const bool live = r < r_end && (row_selected == nullptr || row_selected[r] != 0);
+    kgx_v4u x[kListChunks];
+#pragma unroll
+    for (int k = 0; k < kListChunks; ++k) {
+      x[k] = kgx_v4u{0u, 0u, 0u, 0u};
+      if (live && c0 + k < chunks_per_row) x[k] = rows[r * chunks_per_row + c0 + k];
+    }
+#pragma unroll
+    for (int k = 0; k < kListChunks; ++k) {
+      // present: bit 2j of dword d set where genome 16 d + j of the chunk carries the row
+      uint32_t present[4];
+#pragma unroll
+      for (int d = 0; d < 4; ++d) present[d] = (x[k][d] | (x[k][d] >> 1)) & 0x55555555u;
+      unsigned long long mine = 0;
+#pragma unroll
+      for (int j = 0; j < 64; ++j) {
+        const unsigned long long carried = __ballot((present[j >> 4] >> (2 * (j & 15))) & 1u);   // the 64 rows of the tile, for genome j
+        if (lane == static_cast<uint32_t>(j)) mine = carried;
+      }
+      if (!listed[k]) mine = 0;
+      if constexpr (FILL) {
+        while (mine) {
+          const int b = __builtin_ctzll(mine);
+          mine &= mine - 1;
+          out[cursor[k]++] = static_cast<uint32_t>(r0 + b);
+        }
+      } else {
+        count[k] += static_cast<uint32_t>(__builtin_popcountll(mine));
+      }
+    }
+  }
+  if constexpr (!FILL) {
+#pragma unroll
+    for (int k = 0; k < kListChunks; ++k)
+      counts[slice * genomes_padded + (static_cast<uint64_t>(c0) + k) * 64u + lane] = count[k];
+  }
+}
+
+// counts[slice][genome] -> cursors[slice][genome] = begin[genome] + the genome's entries in earlier slices, in three small
+// steps: every genome's total (one thread each), the exclusive scan of the totals into begin[] (one workgroup; the grand
+// total lands in begin[n_genomes]), every genome's per-slice cursors.
+__global__ void __launch_bounds__(kBlock)
+k_row_list_totals(const uint32_t* __restrict__ counts, uint64_t n_slices, uint64_t genomes_padded, uint64_t n_genomes,
+                  unsigned long long* __restrict__ totals) {
+  const uint64_t g = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (g >= n_genomes) return;
+  unsigned long long total = 0;
+  for (uint64_t s = 0; s < n_slices; ++s) total += counts[s * genomes_padded + g];
+  totals[g] = total;
+}
+
+__global__ void __launch_bounds__(kBlock)
+k_row_list_scan(const unsigned long long* __restrict__ totals, uint64_t n_genomes, unsigned long long* __restrict__ begin) {
+  __shared__ unsigned long long piece[kBlock];
+  __shared__ unsigned long long carry;
+  if (threadIdx.x == 0) carry = 0;
+  __syncthreads();
+  for (uint64_t base = 0; base < n_genomes; base += kBlock) {
+    const uint64_t g = base + threadIdx.x;
+    const unsigned long long total = g < n_genomes ? totals[g] : 0ull;
+    piece[threadIdx.x] = total;
+    __syncthreads();
+    for (int off = 1; off < kBlock; off <<= 1) {                       // inclusive scan of the piece (Hillis-Steele)
+      const unsigned long long v = threadIdx.x >= static_cast<uint32_t>(off) ? piece[threadIdx.x - off] : 0ull;
+      __syncthreads();
+      piece[threadIdx.x] += v;
+      __syncthreads();
+    }
+    if (g < n_genomes) begin[g] = carry + piece[threadIdx.x] - total;
+    __syncthreads();
+    if (threadIdx.x == kBlock - 1) carry += piece[threadIdx.x];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) begin[n_genomes] = carry;
+}
+
+__global__ void __launch_bounds__(kBlock)
+k_row_list_cursors(const uint32_t* __restrict__ counts, uint64_t n_slices, uint64_t genomes_padded, uint64_t n_genomes,
+                   const unsigned long long* __restrict__ begin, unsigned long long* __restrict__ cursors) {
+  const uint64_t g = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (g >= n_genomes) return;
+  unsigned long long at = begin[g];
+  for (uint64_t s = 0; s < n_slices; ++s) {
+    cursors[s * genomes_padded + g] = at;
+    at += counts[s * genomes_padded + g];
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // Flattening helpers.
 // ---------------------------------------------------------------------------------------------
 

@@ -46,6 +46,10 @@ def dosage_results(kgx, G, V, codes, bins, n_bins, groups):
     single_bin = (np.arange(V) % 3).astype(np.uint8)
     single_bin[members] = 0xFF
     out["offset_filters"] = pop.offset_filter_counts(single_bin, members, starts, count, gbin, 3)
+    g_lo, g_hi = G // 5, G - G // 7
+    out["row_lists_begin"], out["row_lists"] = pop.genome_row_lists(g_lo, g_hi, np.arange(V) % 3 != 1)
+    selected = codes[(np.arange(V) % 3 != 1)][:, g_lo:g_hi] > 0
+    assert int(out["row_lists_begin"][-1]) == int(selected.sum()) == len(out["row_lists"])
     af = (np.arange(V) % 23).astype(np.float32) / 40.0
     af[::17] = np.nan
     pop.set_af(af)
@@ -99,7 +103,7 @@ def test_sharded_dosage_sweeps_equal_the_unsharded_ones(kgx, rebind, slots, G):
     assert all(s["genome_base"] % 64 == 0 for s in shards if s["n_genomes"])
     assert [s["genome_base"] for s in shards] == list(np.cumsum([0] + [s["n_genomes"] for s in shards[:-1]]))
     for key in ("rows", "k2", "k4", "k3", "k3_binned", "k8", "k8_listed", "k3_af_bins", "k2_grown", "k3_grown", "k2_masked", "k3_masked",
-                "k3_binned_masked", "k3_af_bins_masked", "k8_masked", "offset_filters"):
+                "k3_binned_masked", "k3_af_bins_masked", "k8_masked", "offset_filters", "row_lists_begin", "row_lists"):
         assert np.array_equal(got[key], want[key]), key
     assert np.array_equal(want["k8_listed"], want["k8"])
     assert np.array_equal(want["k2_grown"][:V], want["k2"]) and np.array_equal(want["k2_grown"][V:], want["k2"][:V // 3])
