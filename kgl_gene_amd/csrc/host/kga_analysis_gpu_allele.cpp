@@ -90,6 +90,7 @@ bool kga::GpuAlleleAnalysis::initializeAnalysis(const std::string& work_director
                                                 const std::shared_ptr<const AnalysisResources>& resource_ptr) {
   ExecEnv::log().info("Analysis Id: {} initialized with work directory: {}", ident(), work_directory);
   work_directory_ = work_directory;
+  bool quality_filter_given = false;
   for (const auto& [block_name, named_vector] : named_parameters.getMap()) {
     for (const auto& parameter_map : named_vector.second) {
       if (auto v = parameter_map.getString("VariantFile")) variant_file_ = v.value().front();
@@ -98,7 +99,7 @@ bool kga::GpuAlleleAnalysis::initializeAnalysis(const std::string& work_director
       // "FileNameOnly" VCF data files: which of the reference's parsers the text is for, and whether the PfEMP package's
       // per-record quality filter (P7VariantFilter) runs before the counting
       if (auto v = parameter_map.getString("VcfFlavour")) vcf_flavour_ = v.value().front();
-      if (auto v = parameter_map.getBool("Pf7QualityFilter")) pf7_quality_filter_ = v.value();
+      if (auto v = parameter_map.getBool("Pf7QualityFilter")) { pf7_quality_filter_ = v.value(); quality_filter_given = true; }
       // the genome-level filters of FilterPf7 (kga_analysis_lib_PfFilter.h:58-66) and the location summary's radius
       if (auto v = parameter_map.getString("LocationFile")) location_file_ = v.value().front();
       if (auto v = parameter_map.getBool("Pf7FilterQC")) filter_qc_ = v.value();
@@ -123,6 +124,8 @@ bool kga::GpuAlleleAnalysis::initializeAnalysis(const std::string& work_director
         ExecEnv::log().error("GpuAlleleAnalysis::initializeAnalysis; invalid Pf7Sample / Pf7Fws resource type");
         return false;
       }
+      // as PfEMPAnalysis: FilterPf7::qualityFilter always applies P7VariantFilter (kga_analysis_lib_PfFilter.cpp:63-67)
+      if (!quality_filter_given) pf7_quality_filter_ = true;
       const auto physical_distance_ptr = std::make_shared<const Pf7SampleLocation>(*pf7_sample_ptr_);
       hetero_homo_zygous_.setResources(pf7_sample_ptr_, pf7_fws_ptr_, physical_distance_ptr);
       ExecEnv::log().info("GpuAlleleAnalysis; Pf7 sample resources: {} samples, {} FWS values, {} locations; QC filter: {}, monoclonal FWS filter: {} (>= {})",
@@ -167,9 +170,12 @@ bool kga::GpuAlleleAnalysis::sweepPopulation(const PopulationDB& population) {
   const gpu::FlatPopulation flat = gpu::flattenPopulation(population);
   // contigs a genome holds without any variant still get a (zero) record (heterozygous.cpp:38-41)
   for (const auto& [genome_id, genome_ptr] : population.getMap()) {
+    if (!keepGenome(genome_id)) continue;                           // the genome-level Pf7 filters: absent from every result
     auto& contig_map = hetero_homo_zygous_.analysisMap()[genome_id];
     for (const auto& [contig_id, contig_ptr] : genome_ptr->getMap()) contig_map.try_emplace(contig_id);
   }
+  // A PopulationDB is counted as delivered: the per-record P7VariantFilter is the caller's viewFilter (the "FileNameOnly"
+  // entry applies it itself, Pf7QualityFilter).
   return sweepFlat(flat, population.populationId());
 }
 

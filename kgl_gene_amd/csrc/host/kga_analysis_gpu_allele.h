@@ -129,7 +129,8 @@ class GpuAlleleAnalysis : public VirtualAnalysis {
   // genomes are sharded over: kgx_device_binding.h; default device 0),
   // "VariantFile" / "GenomeFile" / "HetHomFile" / "LocationFile" (output file stems, default VariantFWS / GenomeFWS /
   // VariantStatistics / VariantLocation), "Pf7FilterQC" / "Pf7FilterFWS" / "Pf7FwsThreshold" (the genome-level filters of
-  // FilterPf7, default on / on / 0.95 once the Pf7 resources are there), "LocationRadiusKm" (default 0).
+  // FilterPf7, default on / on / 0.95 once the Pf7 resources are there), "LocationRadiusKm" (default 0); "Pf7QualityFilter"
+  // (the per-record P7VariantFilter of "FileNameOnly" Pf7 VCF files) defaults to on with the resources, off without.
   // Resources (optional, both or neither): one Pf7SampleResource and one Pf7FwsResource.  With them the package works as
   // PfEMPAnalysis does (kga_analysis_PfEMP.cpp:24-26,90,105,146-163): only genomes that pass QC and are monoclonal take part
   // (a genome mask on the device population), VariantStatistics.csv takes the reference's one-line-per-genome layout with

@@ -564,3 +564,38 @@ def test_gpu_allele_package_with_pf7_sample_resources(tmp_path, kgx, filter_qc, 
     assert kept.write_pfemp_location(sample_path, fws_path, want_stats, want_loc) == 0
     assert (tmp_path / "VariantLocation.csv").read_bytes() == want_loc.read_bytes()
     assert (tmp_path / "VariantStatistics.csv").read_bytes() == want_stats.read_bytes()
+
+
+@pytest.mark.parametrize("binding", [{}, {"DeviceList": "0,0,0"}], ids=["one-device", "three-shards"])
+def test_gpu_allele_package_population_entry_with_pf7_resources(tmp_path, kgx, binding):
+    """The same through the PopulationDB entry (Variant objects delivered by a parser, here the driver's record file):
+    compound offsets, indels and genomes holding a variant more than twice, under the genome filters, sharded or not."""
+    from . import pf7_text as pt
+
+    G, L = 153, 1500
+    mode, source = oa.Population.UNPHASED, "Falciparum"
+    rec, gt = sv.multiallelic_block(G, L, rng_seed=22)
+    ids = sv.genome_ids(G, prefix="PF")
+    path = tmp_path / "pop.bin"
+    rio.write_records(path, rec, gt, ids, mode, source, population_id="Pf7")
+    sample_path, fws_path, records = pt.write_resources(tmp_path, ids, rng_seed=31)
+    res = rio.run_driver("GPU_ALLELE", tmp_path, [f"pf7sample:{sample_path}", f"pf7fws:{fws_path}", path], **binding)
+    assert res.returncode == 0, res.stderr
+
+    opop = sv.oracle_population(rec, gt, ids, mode)
+    kept = opop.filter_pf7_genomes(sample_path, fws_path, True, True)
+    kept.genome_ids = list(ids)
+    kept_ids = [ids[i] for i in kept.genome_order()]
+    assert 10 < len(kept_ids) < G
+    variant_out, genome_out, vdb = kept.fws()
+    header, rows = rio.read_csv(tmp_path / "VariantFWS.csv")
+    assert [r[0] for r in rows] == [vdb.hgvs(i) for i in range(vdb.n_variants)]
+    assert np.array_equal(np.array([[int(x) for x in r[-3:]] for r in rows], dtype=np.uint64), variant_out)
+    header, rows = rio.read_csv(tmp_path / "GenomeFWS.csv")
+    assert [r[0] for r in rows] == kept_ids
+    got = np.array([[int(r[1 + 8 * b + 5 + k]) for b in range(11) for k in range(3)] for r in rows], dtype=np.uint64)
+    assert np.array_equal(got.reshape(len(rows), 11, 3), genome_out)
+    want_stats, want_loc = tmp_path / "oracle_stats.csv", tmp_path / "oracle_location.csv"
+    assert kept.write_pfemp_location(sample_path, fws_path, want_stats, want_loc) == 0
+    assert (tmp_path / "VariantLocation.csv").read_bytes() == want_loc.read_bytes()
+    assert (tmp_path / "VariantStatistics.csv").read_bytes() == want_stats.read_bytes()
