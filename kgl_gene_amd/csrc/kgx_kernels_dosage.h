@@ -335,11 +335,8 @@ __device__ __forceinline__ void by_genome_pass(const kgx_v4u* __restrict__ rows,
   saw_nondiploid |= seen & 0x55555555u;
 }
 
-// Four waves per SIMD (128 registers; the one-row-per-lane-group instance keeps 15 cold values in scratch): the sweep is
-// bound by loads in flight, not by issue -- 8 x 16 B per lane and wave -- and the fourth wave is worth 8 % (4.49 -> 4.19 ms
-// at C3's eleven bins beside a K2 of 4.03 -> 4.17 ms on the two boxes).
 template <int W>
-__global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 4)))
+__global__ void __launch_bounds__(kBlock)
 k_count_by_genome(const kgx_v4u* __restrict__ rows, uint32_t chunks_per_row, uint64_t n_genomes,
                   const uint32_t* __restrict__ row_index, const GenomeWork* __restrict__ work,
                   uint32_t n_bins, unsigned long long* __restrict__ acc /* [n_genomes][n_bins][3] */) {
