@@ -666,6 +666,7 @@ k_offset_filters(const uint32_t* __restrict__ rows, uint64_t dwords_per_row, uin
 // per (slice, genome), k_row_list_offsets turns the counts into cursors, FILL = true writes.
 // ---------------------------------------------------------------------------------------------
 constexpr int kListChunks = 4;             // chunk columns per wave: one 64-byte line of a row
+struct __attribute__((packed, aligned(4))) RowQuad { uint32_t a, b, c, d; };   // four list entries, dword aligned
 
 template <bool FILL>
 __global__ void __launch_bounds__(kBlock)
@@ -684,10 +685,13 @@ k_genome_row_lists(const kgx_v4u* __restrict__ rows, uint32_t chunks_per_row, ui
   const uint64_t r_end = r_begin + rows_per_slice < n_rows ? r_begin + rows_per_slice : n_rows;
   unsigned long long cursor[kListChunks];
   uint32_t count[kListChunks];
+  uint32_t queued[kListChunks][3], pending[kListChunks];     // FILL: row numbers waiting for a fourth
   bool listed[kListChunks];                  // is this lane's genome of chunk k in the range (and kept by the mask)?
 #pragma unroll
   for (int k = 0; k < kListChunks; ++k) {
     count[k] = 0;
+    pending[k] = 0;
+    queued[k][0] = queued[k][1] = queued[k][2] = 0;
     const uint64_t genome = (static_cast<uint64_t>(c0) + k) * 64u + lane;
     listed[k] = genome >= g_lo && genome < g_hi;
     if (keep != nullptr && c0 + k < chunks_per_row) {
@@ -719,17 +723,31 @@ k_genome_row_lists(const kgx_v4u* __restrict__ rows, uint32_t chunks_per_row, ui
       }
       if (!listed[k]) mine = 0;
       if constexpr (FILL) {
+        // four row numbers per store: a lane appends to its own list, so every store instruction touches 64 different
+        // lines whatever its width -- 16 bytes each instead of 4 (the lists are only dword aligned)
         while (mine) {
           const int b = __builtin_ctzll(mine);
           mine &= mine - 1;
-          out[cursor[k]++] = static_cast<uint32_t>(r0 + b);
+          const uint32_t row = static_cast<uint32_t>(r0 + b);
+          if (pending[k] == 3) {
+            *reinterpret_cast<RowQuad*>(out + cursor[k]) = RowQuad{queued[k][0], queued[k][1], queued[k][2], row};
+            cursor[k] += 4;
+            pending[k] = 0;
+          } else {
+            if (pending[k] == 0) queued[k][0] = row; else if (pending[k] == 1) queued[k][1] = row; else queued[k][2] = row;
+            ++pending[k];
+          }
         }
       } else {
         count[k] += static_cast<uint32_t>(__builtin_popcountll(mine));
       }
     }
   }
-  if constexpr (!FILL) {
+  if constexpr (FILL) {
+#pragma unroll
+    for (int k = 0; k < kListChunks; ++k)
+      for (uint32_t i = 0; i < pending[k]; ++i) out[cursor[k] + i] = i == 0 ? queued[k][0] : i == 1 ? queued[k][1] : queued[k][2];
+  } else {
 #pragma unroll
     for (int k = 0; k < kListChunks; ++k)
       counts[slice * genomes_padded + (static_cast<uint64_t>(c0) + k) * 64u + lane] = count[k];
