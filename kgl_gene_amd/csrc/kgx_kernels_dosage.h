@@ -661,12 +661,55 @@ k_offset_filters(const uint32_t* __restrict__ rows, uint64_t dwords_per_row, uin
 // what GenomeDB::processAll hands a per-genome indexer (VariantSort::variantGenomeIndexMT, kgl_genomics/
 // kgl_variant_analysis/kgl_variant_sort.cpp:234-306, one pool task per genome there).  A sparse transpose of the bit
 // matrix: a wave owns four adjacent chunk columns (one 64-byte line, 256 genomes) and a slice of the rows; lane i loads
-// the line of row r0 + i, 64 ballots per chunk turn the 64 x 64 tile around (lane j ends up with the 64-row mask of its
-// genome), and the set bits become row numbers at the genome's cursor.  Two launches of the same walk: FILL = false counts
+// the line of row r0 + i, a six-stage butterfly per chunk turns the 64 x 64 tile around (lane j ends up with the 64-row
+// mask of its genome), and the set bits become row numbers at the genome's cursor.  Two launches of the same walk: FILL = false counts
 // per (slice, genome), k_row_list_offsets turns the counts into cursors, FILL = true writes.
 // ---------------------------------------------------------------------------------------------
 constexpr int kListChunks = 4;             // chunk columns per wave: one 64-byte line of a row
 struct __attribute__((packed, aligned(4))) RowQuad { uint32_t a, b, c, d; };   // four list entries, dword aligned
+
+// One bit per genome out of the chunk's 2-bit codes: bit j set where genome j's code is not 0.
+__device__ __forceinline__ unsigned long long carried_bits(kgx_v4u x) {
+  uint32_t half[4];
+#pragma unroll
+  for (int d = 0; d < 4; ++d) {
+    uint32_t t = (x[d] | (x[d] >> 1)) & 0x55555555u;      // bit 2j: genome 16 d + j carries the row
+    t = (t | (t >> 1)) & 0x33333333u;                     // the even bits drawn together, 16 of them in the end
+    t = (t | (t >> 2)) & 0x0F0F0F0Fu;
+    t = (t | (t >> 4)) & 0x00FF00FFu;
+    half[d] = (t | (t >> 8)) & 0x0000FFFFu;
+  }
+  return static_cast<unsigned long long>(half[0] | (half[1] << 16)) | (static_cast<unsigned long long>(half[2] | (half[3] << 16)) << 32);
+}
+
+template <int S, uint32_t LOW>
+__device__ __forceinline__ void transpose_stage(uint32_t& lo, uint32_t& hi, uint32_t lane) {
+  const uint32_t other_lo = __shfl_xor(lo, S), other_hi = __shfl_xor(hi, S);
+  if (lane & static_cast<uint32_t>(S)) {
+    lo = ((other_lo >> S) & LOW) | (lo & ~LOW);
+    hi = ((other_hi >> S) & LOW) | (hi & ~LOW);
+  } else {
+    lo = (lo & LOW) | ((other_lo & LOW) << S);
+    hi = (hi & LOW) | ((other_hi & LOW) << S);
+  }
+}
+
+// 64 x 64 bit transpose across a wave: lane i comes in with row i (bit j = column j) and leaves with column i (bit j = row
+// j).  Six exchange stages, blocks of 32, 16, ... 1: at block size s the lanes i and i ^ s swap their off-diagonal s x s
+// blocks -- the lower lane gives its high-s columns for the upper lane's low-s columns.
+__device__ __forceinline__ unsigned long long transpose_tile(unsigned long long row, uint32_t lane) {
+  uint32_t lo = static_cast<uint32_t>(row), hi = static_cast<uint32_t>(row >> 32);
+  {                                                         // s = 32: whole dwords change hands
+    const uint32_t other_lo = __shfl_xor(lo, 32), other_hi = __shfl_xor(hi, 32);
+    if (lane & 32u) lo = other_hi; else hi = other_lo;
+  }
+  transpose_stage<16, 0x0000FFFFu>(lo, hi, lane);         // within each dword: columns j with (j & s) == 0 are "low"
+  transpose_stage<8, 0x00FF00FFu>(lo, hi, lane);
+  transpose_stage<4, 0x0F0F0F0Fu>(lo, hi, lane);
+  transpose_stage<2, 0x33333333u>(lo, hi, lane);
+  transpose_stage<1, 0x55555555u>(lo, hi, lane);
+  return static_cast<unsigned long long>(lo) | (static_cast<unsigned long long>(hi) << 32);
+}
 
 template <bool FILL>
 __global__ void __launch_bounds__(kBlock)
@@ -711,16 +754,8 @@ k_genome_row_lists(const kgx_v4u* __restrict__ rows, uint32_t chunks_per_row, ui
     }
 #pragma unroll
     for (int k = 0; k < kListChunks; ++k) {
-      // present: bit 2j of dword d set where genome 16 d + j of the chunk carries the row
-      uint32_t present[4];
-#pragma unroll
-      for (int d = 0; d < 4; ++d) present[d] = (x[k][d] | (x[k][d] >> 1)) & 0x55555555u;
-      unsigned long long mine = 0;
-#pragma unroll
-      for (int j = 0; j < 64; ++j) {
-        const unsigned long long carried = __ballot((present[j >> 4] >> (2 * (j & 15))) & 1u);   // the 64 rows of the tile, for genome j
-        if (lane == static_cast<uint32_t>(j)) mine = carried;
-      }
+      // the row's 64 "carried" bits (bit j: genome j of the chunk), then the 64 x 64 tile turned around across the wave
+      unsigned long long mine = transpose_tile(carried_bits(x[k]), lane);
       if (!listed[k]) mine = 0;
       if constexpr (FILL) {
         // four row numbers per store: a lane appends to its own list, so every store instruction touches 64 different
@@ -745,8 +780,11 @@ k_genome_row_lists(const kgx_v4u* __restrict__ rows, uint32_t chunks_per_row, ui
   }
   if constexpr (FILL) {
 #pragma unroll
-    for (int k = 0; k < kListChunks; ++k)
-      for (uint32_t i = 0; i < pending[k]; ++i) out[cursor[k] + i] = i == 0 ? queued[k][0] : i == 1 ? queued[k][1] : queued[k][2];
+    for (int k = 0; k < kListChunks; ++k) {
+      if (pending[k] > 0) out[cursor[k]] = queued[k][0];
+      if (pending[k] > 1) out[cursor[k] + 1] = queued[k][1];
+      if (pending[k] > 2) out[cursor[k] + 2] = queued[k][2];
+    }
   } else {
 #pragma unroll
     for (int k = 0; k < kListChunks; ++k)
