@@ -557,3 +557,21 @@ def test_iterative_estimators_at_scale_vs_oracle(kgx):
         assert close.sum() >= 0.99 * G, int(close.sum())
         assert deficit[~close].max(initial=0.0) <= 1.0, (float(deficit.max()), int(deficit.argmax()))
     m.close()
+
+
+def test_paired_loglikelihood_search_is_the_single_search(kgx, monkeypatch):
+    """Two evaluations per pass (the reflected and the inside-contraction point of a simplex, from one table read) must
+    walk the path of the one-at-a-time Nelder-Mead search: the same coefficient for every genome, bit for bit, in fewer
+    passes.  Large enough for the multi-kernel table passes and for the compaction of the genomes still searching."""
+    G, L = 4096, 40_000                      # 164 M cells: the tail of the search runs on gathered columns (>= 64 M cells left)
+    m = kgx.GenotypeMatrix(G, L)
+    table = m.synth_multiallelic(1111, 0, 0)
+    paired = m.inbreed(table, "Loglikelihood", phased=True)["inbred_allele_sum"].copy()
+    passes_paired = kgx.inbreed_last_evaluations()
+    monkeypatch.setenv("KGX_K7_NO_PAIR", "1")
+    single = m.inbreed(table, "Loglikelihood", phased=True)["inbred_allele_sum"].copy()
+    passes_single = kgx.inbreed_last_evaluations()
+    monkeypatch.delenv("KGX_K7_NO_PAIR")
+    assert np.array_equal(paired, single)
+    assert passes_paired < passes_single, (passes_paired, passes_single)
+    m.close()
