@@ -391,7 +391,9 @@ int genome_row_lists_shard(kgx_pop_shard& sh, uint64_t g_lo, uint64_t g_hi, cons
                        reinterpret_cast<const kgx_v4u*>(sh.d_rows), sh.chunks_per_row, V, sh.n_genomes, g_lo, g_hi,
                        reinterpret_cast<const kgx_v4u*>(sh.d_keep), d_sel, rows_per_slice, d_counts, genomes_padded, nullptr, nullptr);
     const uint32_t by_genome = static_cast<uint32_t>((sh.n_genomes + kBlock - 1) / kBlock);
-    hipLaunchKernelGGL(k_row_list_totals, dim3(by_genome), dim3(kBlock), 0, st, d_counts, slices, genomes_padded, sh.n_genomes, d_totals);
+    try_hip(hipMemsetAsync(d_totals, 0, sh.n_genomes * sizeof(unsigned long long), st), KGX_EHIP, "memset(totals)");
+    hipLaunchKernelGGL(k_row_list_totals, dim3(by_genome, static_cast<uint32_t>((slices + kTotalsSlices - 1) / kTotalsSlices)), dim3(kBlock), 0, st,
+                       d_counts, slices, genomes_padded, sh.n_genomes, d_totals);
     hipLaunchKernelGGL(k_row_list_scan, dim3(1), dim3(kBlock), 0, st, d_totals, sh.n_genomes, d_begin);
     hipLaunchKernelGGL(k_row_list_cursors, dim3(by_genome), dim3(kBlock), 0, st, d_counts, slices, genomes_padded, sh.n_genomes, d_begin, d_cursors);
     try_hip(hipGetLastError(), KGX_EHIP, "count / offset kernels");

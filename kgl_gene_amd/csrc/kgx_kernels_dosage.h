@@ -795,14 +795,18 @@ k_genome_row_lists(const kgx_v4u* __restrict__ rows, uint32_t chunks_per_row, ui
 // counts[slice][genome] -> cursors[slice][genome] = begin[genome] + the genome's entries in earlier slices, in three small
 // steps: every genome's total (one thread each), the exclusive scan of the totals into begin[] (one workgroup; the grand
 // total lands in begin[n_genomes]), every genome's per-slice cursors.
+constexpr int kTotalsSlices = 16;
 __global__ void __launch_bounds__(kBlock)
 k_row_list_totals(const uint32_t* __restrict__ counts, uint64_t n_slices, uint64_t genomes_padded, uint64_t n_genomes,
                   unsigned long long* __restrict__ totals) {
+  // blockIdx.y: a run of kTotalsSlices slices; totals[] starts at zero
   const uint64_t g = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
   if (g >= n_genomes) return;
+  const uint64_t s_begin = static_cast<uint64_t>(blockIdx.y) * kTotalsSlices;
+  const uint64_t s_end = s_begin + kTotalsSlices < n_slices ? s_begin + kTotalsSlices : n_slices;
   unsigned long long total = 0;
-  for (uint64_t s = 0; s < n_slices; ++s) total += counts[s * genomes_padded + g];
-  totals[g] = total;
+  for (uint64_t s = s_begin; s < s_end; ++s) total += counts[s * genomes_padded + g];
+  if (total) atomicAdd(&totals[g], total);
 }
 
 __global__ void __launch_bounds__(kBlock)
