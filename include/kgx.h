@@ -280,12 +280,22 @@ int kgx_locus_class_frequencies(const double* minor_af, uint64_t n_loci, uint32_
  * phases (1000-Genomes style); algorithm = KGX_ALGO_*.  out[g1-g0] (host).  locus_index and minor_af may be host
  * pointers or pointers to memory of a bound device (a table kept resident between calls is then copied device to
  * device).  Genomes are independent: every shard the range touches is swept on its own device at the same time, no exchange.
- * The reference's random restarts are fixed starts here (the midpoints of its start intervals): HallME runs its 50
- * expectation steps from 0.25; Loglikelihood walks nlopt's 1-D Nelder-Mead from 0 with the reference's stopping rule
- * (absolute simplex width 1e-6, at most 500 evaluations; _calc.cpp:131-144); a pass over the genotype bytes serves two
- * evaluations (a simplex' reflection and inside contraction) of every genome still searching. */
+ * start[g1-g0] (host) or NULL: where HallME / Loglikelihood start for each genome.  The reference draws its starts from
+ * std::random_device-seeded Mersenne twisters (kel_math/kel_distribution.h:25-43; _calc.cpp:163-166,180,235-237) and
+ * restarts five times, of which -- RetryCalcResult::checkTolerance compares every entry with itself (_calc.cpp:45-68) --
+ * the FIFTH alone decides the result: kgx_inbreed_reference_starts() makes exactly those draws, so passing its output is
+ * the reference's algorithm at no extra pass.  NULL: the midpoints of its start intervals (0.25 / 0.0), a deterministic
+ * mode the reference does not have.  HallME runs the reference's 50 expectation steps from the start; Loglikelihood
+ * walks nlopt's 1-D Nelder-Mead from it with the reference's stopping rule (absolute simplex width 1e-6, at most 500
+ * evaluations; _calc.cpp:131-144); a pass over the genotype bytes serves two evaluations (a simplex' reflection and
+ * inside contraction) of every genome still searching.  Ignored by Simple and RitlandLocus. */
 int kgx_inbreed(kgx_gt8* gt, uint64_t g0, uint64_t g1, const uint32_t* locus_index, uint64_t n_selected,
-                const double* minor_af, uint32_t amax, int phased, int algorithm, kgx_locus_results* out);
+                const double* minor_af, uint32_t amax, int phased, int algorithm, const double* start, kgx_locus_results* out);
+/* The start points the reference's processHallME / processLogLikelihood end up using, for n genomes: genome i owns the
+ * stream std::mt19937_64(seed + first_stream + i) -- seed 0: seeded from std::random_device, the reference's
+ * RandomEntropySource, i.e. production behaviour -- and draws std::uniform_real_distribution<>(0.5, 0) (HallME,
+ * _calc.cpp:237) or (0.5, -0.5) (Loglikelihood, :166) once per restart; out[i] = the fifth draw.  Host only, no device. */
+int kgx_inbreed_reference_starts(int algorithm, uint64_t seed, uint64_t first_stream, uint64_t n, double* out /* [n] */);
 /* kgx_inbreed and the by-genome sweeps keep their per-call device buffers in one grow-only arena per device between calls
  * (a window loop calls kgx_inbreed thousands of times), and a large Loglikelihood call two more buffers holding the
  * genotype columns of the genomes still searching (at most ~3/4 of the swept bytes together); this frees them (they are

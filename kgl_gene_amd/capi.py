@@ -79,7 +79,8 @@ _SIGNATURES = {
     "kgx_gt8_read_rows": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64]),
     "kgx_locus_class_frequencies": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint32, C.c_double, C.c_void_p, C.c_void_p]),
     "kgx_inbreed": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint32, C.c_int,
-                              C.c_int, C.c_void_p]),
+                              C.c_int, C.c_void_p, C.c_void_p]),
+    "kgx_inbreed_reference_starts": (C.c_int, [C.c_int, C.c_uint64, C.c_uint64, C.c_uint64, C.c_void_p]),
     "kgx_release_scratch": (C.c_int, []),
     "kgx_count_by_genome_af_bins": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]),
     "kgx_population_resize": (C.c_int, [C.c_void_p, C.c_uint64]),
@@ -497,23 +498,39 @@ class GenotypeMatrix:
             raise ValueError("minor_af must have one row per locus and inbreeding one value per genome")
         check(lib().kgx_gt8_synth_inbred(self._h, ptr(a), a.shape[1], ptr(f), int(seed)))
 
-    def inbreed(self, minor_af: np.ndarray, algorithm: str, phased: bool, locus_index=None, g0: int = 0, g1: int | None = None):
+    def inbreed(self, minor_af: np.ndarray, algorithm: str, phased: bool, locus_index=None, g0: int = 0, g1: int | None = None,
+                start=None):
+        """start: per-genome start points of HallME / Loglikelihood (reference_starts()), None = the interval midpoints."""
         g1 = self.n_genomes if g1 is None else g1
+        st = None if start is None else np.ascontiguousarray(start, dtype=np.float64)
+        if st is not None and st.shape != (g1 - g0,):
+            raise ValueError("start must hold one value per genome of the range")
         a = np.ascontiguousarray(minor_af, dtype=np.float64)
         n_sel, amax = a.shape if a.ndim == 2 else (0, 1)
         idx = None if locus_index is None else np.ascontiguousarray(locus_index, dtype=np.uint32)
         out = np.zeros(g1 - g0, dtype=LOCUS_RESULTS_DTYPE)
         check(lib().kgx_inbreed(self._h, g0, g1, None if idx is None else ptr(idx), n_sel, ptr(a), amax, int(bool(phased)),
-                                ALGORITHMS[algorithm], ptr(out)))
+                                ALGORITHMS[algorithm], None if st is None else ptr(st), ptr(out)))
         return out
 
-    def inbreed_resident(self, minor_af_dev: int, n_selected: int, amax: int, algorithm: str, phased: bool, g0: int = 0, g1: int | None = None):
+    def inbreed_resident(self, minor_af_dev: int, n_selected: int, amax: int, algorithm: str, phased: bool, g0: int = 0, g1: int | None = None,
+                         start=None):
         """inbreed() with the allele-frequency table already on this device: minor_af_dev is the device address of
         float64 [n_selected][amax] (e.g. a torch tensor's data_ptr())."""
         g1 = self.n_genomes if g1 is None else g1
         out = np.zeros(g1 - g0, dtype=LOCUS_RESULTS_DTYPE)
-        check(lib().kgx_inbreed(self._h, g0, g1, None, n_selected, C.c_void_p(minor_af_dev), amax, int(bool(phased)), ALGORITHMS[algorithm], ptr(out)))
+        st = None if start is None else np.ascontiguousarray(start, dtype=np.float64)
+        check(lib().kgx_inbreed(self._h, g0, g1, None, n_selected, C.c_void_p(minor_af_dev), amax, int(bool(phased)), ALGORITHMS[algorithm],
+                                None if st is None else ptr(st), ptr(out)))
         return out
+
+
+def reference_starts(algorithm: str, seed: int, n: int, first_stream: int = 0) -> np.ndarray:
+    """The start points the reference's HallME / Loglikelihood end up using for n genomes: genome i draws from
+    std::mt19937_64(seed + first_stream + i) (seed 0: std::random_device) and its fifth draw counts (kgx.h)."""
+    out = np.zeros(n, dtype=np.float64)
+    check(lib().kgx_inbreed_reference_starts(ALGORITHMS[algorithm], int(seed), int(first_stream), int(n), ptr(out)))
+    return out
 
 
 def release_scratch() -> None:

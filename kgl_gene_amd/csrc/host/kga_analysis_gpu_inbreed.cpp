@@ -192,6 +192,8 @@ bool kga::GpuInbreedAnalysis::initializeAnalysis(const std::string& work_directo
     for (const auto& parameter_map : named_vector.second)
     {
       if (auto v = parameter_map.getSize("SyntheticSeed")) synthetic_seed_ = v.value().front();
+      if (auto v = parameter_map.getSize("StartSeed")) start_seed_ = v.value().front();
+      if (auto v = parameter_map.getString("StartPoints")) start_midpoints_ = v.value().front() == "Midpoint";
     }
   for (const auto& parameter : extractParameters(named_parameters)) {
     GpuParamOutput out;
@@ -393,7 +395,7 @@ bool kga::GpuInbreedAnalysis::populationInbreeding(GpuParamOutput& param_output)
   bool phased = true;
 
   // Genomes with the contig and a PED record, grouped by super population; each group starts on a multiple of 16.
-  struct DeviceGenome { uint64_t column; GenomeId_t id; };
+  struct DeviceGenome { uint64_t column; GenomeId_t id; uint64_t stream; };   // stream: its place in processResults' fan-out
   std::vector<std::vector<DeviceGenome>> by_super_pop(super_pops.size());
   std::vector<uint64_t> range_begin(super_pops.size(), 0), range_end(super_pops.size(), 0);
   uint64_t device_genomes = 0;
@@ -403,6 +405,7 @@ bool kga::GpuInbreedAnalysis::populationInbreeding(GpuParamOutput& param_output)
     const bool log_missing = !planned_before;
     planned_before = true;
     for (auto& group : by_super_pop) group.clear();
+    uint64_t enqueued = 0;                                       // future_vector.size() at the genome's turn (_diploid.cpp:117-148)
     for (uint64_t column = 0; column < genome_ids.size(); ++column) {
       const GenomeId_t& genome_id = genome_ids[column];
       auto record_opt = genealogy_data_->getGenomeGenealogyRecord(genome_id);
@@ -415,7 +418,7 @@ bool kga::GpuInbreedAnalysis::populationInbreeding(GpuParamOutput& param_output)
         if (log_missing) ExecEnv::log().error("InbreedingAnalysis::populationInbreeding, Locus set not found for super population: {}", record_opt.value().superPopulation());
         continue;
       }
-      by_super_pop[static_cast<size_t>(sp_it - super_pops.begin())].push_back({column, genome_id});
+      by_super_pop[static_cast<size_t>(sp_it - super_pops.begin())].push_back({column, genome_id, enqueued++});
     }
     device_genomes = 0;
     for (size_t sp = 0; sp < super_pops.size(); ++sp) {
@@ -523,6 +526,7 @@ bool kga::GpuInbreedAnalysis::populationInbreeding(GpuParamOutput& param_output)
   local.upper_offset = reference.loci[locii_vector.back()].offset;
   std::vector<double> af_table;
   std::vector<kgx_locus_results> device_results;
+  std::vector<uint64_t> streams;
   while (local.upper_offset < params.locii.upper_offset && locii_vector.size() >= 100) {
     GpuResultColumn column;
     {
@@ -537,8 +541,11 @@ bool kga::GpuInbreedAnalysis::populationInbreeding(GpuParamOutput& param_output)
       af_table.assign(selected.size() * amax, kNaN);
       for (size_t s = 0; s < selected.size(); ++s) reference.alleleFreqRow(selected[s], static_cast<int>(sp), &af_table[s * amax], amax);
       device_results.assign(n, kgx_locus_results{});
+      streams.resize(n);
+      for (uint64_t k = 0; k < n; ++k) streams[k] = by_super_pop[sp][k].stream;
+      const std::vector<double> start = startPoints(algorithm, streams);
       if (kgx_inbreed(dev.handle, range_begin[sp], range_end[sp], selected.data(), selected.size(), af_table.data(), amax, phased ? 1 : 0,
-                      algorithm, device_results.data()) != KGX_OK) {
+                      algorithm, start.empty() ? nullptr : start.data(), device_results.data()) != KGX_OK) {
         ExecEnv::log().error("GpuInbreedAnalysis; inbreeding sweep failed: {}", kgx_last_error());
         return false;
       }
@@ -561,6 +568,18 @@ bool kga::GpuInbreedAnalysis::populationInbreeding(GpuParamOutput& param_output)
     local.upper_offset = reference.loci[locii_vector.back()].offset;
   }
   return true;
+}
+
+std::vector<double> kga::GpuInbreedAnalysis::startPoints(int algorithm, const std::vector<uint64_t>& streams) const {
+  std::vector<double> start;
+  if (start_midpoints_ || (algorithm != KGX_ALGO_HALL_ME && algorithm != KGX_ALGO_LOGLIKELIHOOD)) return start;
+  start.resize(streams.size());
+  for (size_t k = 0; k < streams.size(); ++k)
+    if (kgx_inbreed_reference_starts(algorithm, start_seed_, streams[k], 1, &start[k]) != KGX_OK) {
+      ExecEnv::log().error("GpuInbreedAnalysis; start points: {}", kgx_last_error());
+      return {};
+    }
+  return start;
 }
 
 // ---- synthetic self-check ------------------------------------------------------------------------------
@@ -617,6 +636,15 @@ bool kga::GpuInbreedAnalysis::syntheticInbreeding(GpuParamOutput& param_output) 
   // reference.  Here the draws are keyed by (seed, column).
   auto process = [&](uint64_t column, GpuResultsMap& results_map) -> bool {
     for (size_t sp = 0; sp < super_pops.size(); ++sp) {
+      // processResults walks the synthetic population in genome-id (std::map) order: the grid genome's place in it
+      std::vector<GenomeId_t> ids(grid.size());
+      for (size_t g = 0; g < grid.size(); ++g) ids[g] = generateSyntheticGenomeId(grid[g], super_pops[sp], g);
+      std::vector<size_t> by_id(grid.size());
+      for (size_t g = 0; g < grid.size(); ++g) by_id[g] = g;
+      std::sort(by_id.begin(), by_id.end(), [&](size_t a, size_t b) { return ids[a] < ids[b]; });
+      std::vector<uint64_t> streams(grid.size());
+      for (size_t rank = 0; rank < by_id.size(); ++rank) streams[by_id[rank]] = rank;
+      const std::vector<double> start = startPoints(algorithm, streams);
       const std::vector<uint32_t> selected = reference.sampleLocii(static_cast<int>(sp), params.locii, false);
       std::vector<double> af_table(selected.size() * amax, kNaN);
       for (size_t s = 0; s < selected.size(); ++s) reference.alleleFreqRow(selected[s], static_cast<int>(sp), &af_table[s * amax], amax);
@@ -625,14 +653,15 @@ bool kga::GpuInbreedAnalysis::syntheticInbreeding(GpuParamOutput& param_output) 
       std::vector<kgx_locus_results> device_results(grid.size());
       if (!dev.handle ||
           kgx_gt8_synth_inbred(dev.handle, af_table.data(), amax, grid.data(), synthetic_seed_ + 1000003ull * column + sp) != KGX_OK ||
-          kgx_inbreed(dev.handle, 0, grid.size(), nullptr, selected.size(), af_table.data(), amax, 1, algorithm, device_results.data()) != KGX_OK) {
+          kgx_inbreed(dev.handle, 0, grid.size(), nullptr, selected.size(), af_table.data(), amax, 1, algorithm,
+                      start.empty() ? nullptr : start.data(), device_results.data()) != KGX_OK) {
         ExecEnv::log().error("GpuInbreedAnalysis; synthetic sweep failed: {}", kgx_last_error());
         return false;
       }
       for (size_t g = 0; g < grid.size(); ++g) {
         const kgx_locus_results& d = device_results[g];
         GpuLocusResults r;
-        r.genome = generateSyntheticGenomeId(grid[g], super_pops[sp], g);
+        r.genome = ids[g];
         r.major_hetero_count = d.major_hetero_count;  r.major_hetero_freq = d.major_hetero_freq;
         r.minor_hetero_count = d.minor_hetero_count;  r.minor_hetero_freq = d.minor_hetero_freq;
         r.minor_homo_count = d.minor_homo_count;      r.minor_homo_freq = d.minor_homo_freq;

@@ -131,6 +131,17 @@ class GpuInbreedAnalysis : public VirtualAnalysis {
   // Seed of the synthetic draws (parameter "SyntheticSeed", default 1111 = DeterministicEntropySource, kel_distribution.h:60;
   // the reference itself seeds from std::random_device).
   uint64_t synthetic_seed_{1111};
+  // Entropy of the HallME / Loglikelihood start points.  The reference gives every per-genome task its own
+  // RandomEntropySource (a std::mt19937_64 seeded from std::random_device, kel_math/kel_distribution.h:25-43;
+  // _calc.cpp:163,235) -- that is the default here too (parameter "StartSeed" absent or 0).  "StartSeed" = s > 0 makes the
+  // runs repeatable: the k-th task processResults enqueues (genome-id order over the genomes with the contig, a PED record
+  // and a locus list, _diploid.cpp:117-148) owns the stream std::mt19937_64(s + k), the DeterministicEntropySource idea
+  // (kel_distribution.h:53-70) with one stream per task.  "StartPoints" = "Midpoint": no draws, the midpoints of the
+  // reference's start intervals (0.25 / 0.0) -- a deterministic mode the reference does not have.
+  uint64_t start_seed_{0};
+  bool start_midpoints_{false};
+  // The start points of n tasks, the first of which is the first_stream-th enqueued; empty = midpoints (or not iterative).
+  [[nodiscard]] std::vector<double> startPoints(int algorithm, const std::vector<uint64_t>& streams) const;
 
  private:
   bool writeResults() const;

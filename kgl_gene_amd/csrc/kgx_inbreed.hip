@@ -10,6 +10,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <new>
+#include <random>
 #include <string>
 #include <vector>
 
@@ -40,8 +41,9 @@ void destroy_shards(kgx_gt8* h) {
 }
 
 // kgx_inbreed for the genomes [g0, g1) of ONE shard (shard-local indices, g0 a multiple of 4); arguments checked by the caller.
+// start: host [g1 - g0] start points of the iterative estimators, or null (the midpoints of the reference's start intervals).
 int inbreed_shard(kgx_gt8_shard& sh, uint64_t g0, uint64_t g1, const uint32_t* locus_index, uint64_t n_sel, const double* minor_af,
-                  uint32_t amax, int phased, int algorithm, kgx_locus_results* out) {
+                  uint32_t amax, int phased, int algorithm, const double* start, kgx_locus_results* out) {
   Device& dev = *sh.dev;
   std::lock_guard<std::mutex> device_lock(dev.mutex);          // the arena, the compaction buffers and the timing events are the device's
   if (int rc = use_device(dev)) return rc;
@@ -124,6 +126,7 @@ int inbreed_shard(kgx_gt8_shard& sh, uint64_t g0, uint64_t g1, const uint32_t* l
   const size_t o_f = plan.add(2 * n * sizeof(double)), o_eval = plan.add(2 * n * sizeof(double)), o_out = plan.add(n * sizeof(LocusResultsDev));
   const size_t o_index = plan.add((n_sel + 8) * sizeof(uint32_t)), o_golden = plan.add(n * sizeof(GoldenState));
   const size_t o_brent = plan.add(n * sizeof(BrentState)), o_running = plan.add(sizeof(unsigned int));
+  const size_t o_start = plan.add(n * sizeof(double));
   // The class-frequency sums of the defaults in the reference's own (sequential) summation order (k_seq_* kernels): from
   // the size at which a tree reduction and a sequential sum part by more than a tenth of the tolerance.
   const bool swar_family = table_sweep || (!env_int("KGX_K5_GENERIC", 0) && amax <= 4 && !ritland);
@@ -152,6 +155,7 @@ int inbreed_shard(kgx_gt8_shard& sh, uint64_t g0, uint64_t g1, const uint32_t* l
   d_golden = reinterpret_cast<GoldenState*>(arena + o_golden);
   d_brent = reinterpret_cast<BrentState*>(arena + o_brent);
   d_running = reinterpret_cast<unsigned int*>(arena + o_running);
+  double* d_start = reinterpret_cast<double*>(arena + o_start);
   double* d_seq_sum = reinterpret_cast<double*>(arena + o_seq_sum);
   int* d_seq_e = reinterpret_cast<int*>(arena + o_seq_e);
   long long* d_seq_n = reinterpret_cast<long long*>(arena + o_seq_n);
@@ -173,6 +177,14 @@ int inbreed_shard(kgx_gt8_shard& sh, uint64_t g0, uint64_t g1, const uint32_t* l
   // (the table sweep and the 16-genome SWAR sweep pre-fill every partial with the segment defaults: k_fill_defaults)
   if (!(n_sel && (table_sweep || swar16))) try_hip(hipMemsetAsync(d_part, 0, n_seg * n * kParts0 * sizeof(double), st), KGX_EHIP, "memset(partials)");
   try_hip(hipMemsetAsync(d_f, 0, 2 * n * sizeof(double), st), KGX_EHIP, "memset(f)");
+  // Where the iterative estimators start (kgx.h): the caller's per-genome points -- the reference draws them, and its
+  // fifth draw alone decides the result (kgx_inbreed_reference_starts) -- or the midpoint of the reference's start interval.
+  std::vector<double> start_points;
+  if (algorithm == KGX_ALGO_HALL_ME || algorithm == KGX_ALGO_LOGLIKELIHOOD) {
+    if (start) start_points.assign(start, start + n);
+    else start_points.assign(n, algorithm == KGX_ALGO_HALL_ME ? 0.25 : 0.0);
+    try_hip(hipMemcpyAsync(d_start, start_points.data(), n * sizeof(double), hipMemcpyHostToDevice, st), KGX_EHIP, "H2D(start)");
+  }
 
   const dim3 grid(gx, static_cast<uint32_t>(n_seg));
   const uint32_t* gt32 = reinterpret_cast<const uint32_t*>(sh.d_gt);
@@ -333,10 +345,10 @@ int inbreed_shard(kgx_gt8_shard& sh, uint64_t g0, uint64_t g1, const uint32_t* l
       try_hip(hipMemsetAsync(d_running, 0, sizeof(unsigned int), st), KGX_EHIP, "memset(evaluations)");
       if (algorithm == 2)
         hipLaunchKernelGGL((k_inbreed_iterate_wave<1>), dim3(wave_grid), dim3(kBlock), 0, st, sh.d_gt, sh.pitch, g0, n, d_index, n_sel, d_table, d_valid,
-                           amax, phased, d_counts, d_sums, search, d_f, d_running);
+                           amax, phased, d_counts, d_sums, search, d_start, d_f, d_running);
       else
         hipLaunchKernelGGL((k_inbreed_iterate_wave<2>), dim3(wave_grid), dim3(kBlock), 0, st, sh.d_gt, sh.pitch, g0, n, d_index, n_sel, d_table, d_valid,
-                           amax, phased, d_counts, env_int("KGX_K7_ESTIMATE_START", 0) ? d_sums : nullptr, search, d_f, d_running);
+                           amax, phased, d_counts, env_int("KGX_K7_ESTIMATE_START", 0) ? d_sums : nullptr, search, d_start, d_f, d_running);
       if (algorithm == 3) {
         unsigned int evaluations = 0;
         try_hip(hipMemcpyAsync(&evaluations, d_running, sizeof(unsigned int), hipMemcpyDeviceToHost, st), KGX_EHIP, "D2H(evaluations)");
@@ -345,9 +357,9 @@ int inbreed_shard(kgx_gt8_shard& sh, uint64_t g0, uint64_t g1, const uint32_t* l
       }
     } else if (algorithm == 2) {
       // processHallME (_calc.cpp:225-307).  The reference restarts from U(0,0.5] and, through RetryCalcResult's
-      // self-comparison, always stops after 5 restarts of exactly 50 expectation steps, keeping the last; the
-      // fixed start 0.25 (the mean of its start distribution) replaces the random draw.
-      std::vector<double> f0(n, 0.25);
+      // self-comparison (_calc.cpp:45-68), always stops after 5 restarts of exactly 50 expectation steps, keeping the
+      // last: 50 steps from the start point handed in (the fifth draw, or 0.25 without one).
+      const std::vector<double>& f0 = start_points;
       // locus slots every lane of k_inbreed_eval_lut walks: whole batches of 8 in every segment
       const unsigned long long walked = eval_lut && n_sel ? (eval_n_seg - 1) * eval_per_seg + (n_sel - (eval_n_seg - 1) * eval_per_seg + 7) / 8 * 8 : 0ull;
       try_hip(hipMemcpyAsync(d_f, f0.data(), n * sizeof(double), hipMemcpyHostToDevice, st), KGX_EHIP, "H2D(f0)");
@@ -391,7 +403,7 @@ int inbreed_shard(kgx_gt8_shard& sh, uint64_t g0, uint64_t g1, const uint32_t* l
         // objective has several local maxima (F < 0) it may settle on another one than a search from the middle does --
         // the reference itself lands on one or another from its random starts -- so it is not the default.
         ll_pair = planes == 2;
-        hipLaunchKernelGGL(k_brent_init, dim3(lin_grid), dim3(kBlock), 0, st, d_counts, d_sums, n, env_int("KGX_K7_ESTIMATE_START", 0), pass_search, d_brent, d_f);
+        hipLaunchKernelGGL(k_brent_init, dim3(lin_grid), dim3(kBlock), 0, st, d_counts, d_sums, n, env_int("KGX_K7_ESTIMATE_START", 0), pass_search, d_start, d_brent, d_f);
         // Brent: golden section alone would need 38, and its safeguard keeps that bound; Nelder-Mead: the reference's own cap
         const int kMaxEvaluations = search == kSearchNelderMead ? 500 : 60;
         // The genomes still searching.  When at most half of them are left -- and the call is big enough for it to pay --
@@ -726,12 +738,18 @@ int kgx_locus_class_frequencies(const double* minor_af, uint64_t n_loci, uint32_
 }
 
 int kgx_inbreed(kgx_gt8* h, uint64_t g0, uint64_t g1, const uint32_t* locus_index, uint64_t n_sel, const double* minor_af,
-                uint32_t amax, int phased, int algorithm, kgx_locus_results* out) {
+                uint32_t amax, int phased, int algorithm, const double* start, kgx_locus_results* out) {
   if (int bound = require_bound()) return bound;
   if (!h || !out || (n_sel && !minor_af)) return fail(KGX_EINVAL, "null argument");
   if (g0 > g1 || g1 > h->n_genomes || (g0 & 3u)) return fail(KGX_EINVAL, "genome range must lie in the matrix and start on a multiple of 4");
   if (amax == 0 || amax > 14) return fail(KGX_EINVAL, "amax %u outside [1,14] (4-bit allele indices)", amax);
   if (algorithm < 0 || algorithm > 3) return fail(KGX_EINVAL, "unknown algorithm %d", algorithm);
+  if (start && (algorithm == KGX_ALGO_HALL_ME || algorithm == KGX_ALGO_LOGLIKELIHOOD))
+    for (uint64_t g = 0; g < g1 - g0; ++g) {
+      // HallME: the reference's draws lie in (0, 0.5]; Loglikelihood: the optimiser's box [-1, 1]
+      const bool ok = algorithm == KGX_ALGO_HALL_ME ? (start[g] > 0.0 && start[g] <= 1.0) : (start[g] >= -1.0 && start[g] <= 1.0);
+      if (!ok) return fail(KGX_EINVAL, "start[%llu] = %g outside the estimator's interval", (unsigned long long)g, start[g]);
+    }
   if (!locus_index && n_sel > h->n_loci) return fail(KGX_EINVAL, "n_sel exceeds the locus count");
   if (locus_index) {
     hipPointerAttribute_t attr;                                  // a device-resident index cannot be range-checked from here
@@ -748,10 +766,35 @@ int kgx_inbreed(kgx_gt8* h, uint64_t g0, uint64_t g1, const uint32_t* locus_inde
     const uint64_t lo = g0 > sh.genome_base ? g0 : sh.genome_base;
     const uint64_t hi = g1 < sh.genome_base + sh.n_genomes ? g1 : sh.genome_base + sh.n_genomes;
     if (lo >= hi) return KGX_OK;
-    return inbreed_shard(sh, lo - sh.genome_base, hi - sh.genome_base, locus_index, n_sel, minor_af, amax, phased, algorithm, out + (lo - g0));
+    return inbreed_shard(sh, lo - sh.genome_base, hi - sh.genome_base, locus_index, n_sel, minor_af, amax, phased, algorithm,
+                         start ? start + (lo - g0) : nullptr, out + (lo - g0));
   });
   (void)use_device(*h->shards[0].dev);
   return rc;
+}
+
+int kgx_inbreed_reference_starts(int algorithm, uint64_t seed, uint64_t first_stream, uint64_t n, double* out) {
+  if (!out && n) return fail(KGX_EINVAL, "null argument");
+  if (algorithm != KGX_ALGO_HALL_ME && algorithm != KGX_ALGO_LOGLIKELIHOOD) return fail(KGX_EINVAL, "algorithm %d draws no start points", algorithm);
+  // processHallME: UniformRealDistribution(INIT_UPPER_, 0) (_calc.cpp:237); processLogLikelihood: (INIT_UPPER_, INIT_LOWER_)
+  // (:166) = std::uniform_real_distribution<>(0.5, 0 | -0.5) on a std::mt19937_64 (kel_math/kel_distribution.h:25-43, 90-108).
+  // RetryCalcResult(FINAL_ACCURACY_, MIN_RETRIES_ = 5, MAX_RETRIES_) ends the restarts at the fifth: checkTolerance
+  // (:45-68) compares every entry with itself.  One draw per restart, so the fifth draw is the start that counts.
+  constexpr int kRestarts = 5;
+  for (uint64_t i = 0; i < n; ++i) {
+    std::mt19937_64 entropy_mt;
+    if (seed) {
+      entropy_mt.seed(seed + first_stream + i);
+    } else {
+      std::random_device rd;                                    // RandomEntropySource: generator_(rd_())
+      entropy_mt.seed(rd());
+    }
+    std::uniform_real_distribution<> initialize_distribution(0.5, algorithm == KGX_ALGO_HALL_ME ? 0.0 : -0.5);
+    double drawn = 0.0;
+    for (int restart = 0; restart < kRestarts; ++restart) drawn = initialize_distribution(entropy_mt);
+    out[i] = drawn;
+  }
+  return KGX_OK;
 }
 
 double kgx_inbreed_last_sweep_ms(void) {

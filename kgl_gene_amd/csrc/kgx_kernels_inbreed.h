@@ -1482,8 +1482,9 @@ __device__ __forceinline__ BrentState brent_start(const unsigned long long* __re
 
 // The reference's own optimiser for this objective, step for step: nlopt's LN_NELDERMEAD in one dimension (the simplex
 // method after Nelder & Mead / Box: reflection 1, expansion 2, contraction 1/2) on [-1, 1], stopped at an absolute
-// simplex width of 1e-6 or 500 evaluations (createLogLikelihoodOptimizer, _calc.cpp:131-144), from the midpoint 0 of the
-// reference's random start interval (-0.5, 0.5] with nlopt's default first step, a quarter of the box.  The clamped
+// simplex width of 1e-6 or 500 evaluations (createLogLikelihoodOptimizer, _calc.cpp:131-144), from the start point x0
+// handed in (the reference draws it from (-0.5, 0.5], _calc.cpp:166,180) with nlopt's default first step, a quarter of
+// the box, turned inward where it would leave the box.  The clamped
 // objective has several local maxima where F < 0 (every homozygous cell whose probability falls under the 1e-10 floor
 // stops pulling); which one a search ends on depends on its path, so the path is the reference optimiser's (as
 // restated in oracle/kgo_inbreed.cpp:neldermead1D, which this follows expression for expression): the same maximum,
@@ -1492,10 +1493,17 @@ __device__ __forceinline__ BrentState brent_start(const unsigned long long* __re
 //   u = the point to evaluate next;  widened = phase;  e = evaluations so far;  x = the result once done.
 enum : int { kNmFirst = 0, kNmSecond, kNmReflect, kNmExpand, kNmOutside, kNmInside };
 constexpr int kSearchBrent = 0, kSearchNelderMead = 1;
-__device__ __forceinline__ BrentState nm_start() {
+__device__ __forceinline__ void nm_first_simplex(double x0, double& xa, double& xb) {
+  auto clampx = [](double x) { return x > 1.0 ? 1.0 : (x < -1.0 ? -1.0 : x); };
+  const double step = (1.0 - -1.0) * 0.25;
+  xa = clampx(x0);
+  xb = xa + step;
+  if (xb > 1.0) xb = xa - step;
+  xb = clampx(xb);
+}
+__device__ __forceinline__ BrentState nm_start(double x0) {
   BrentState s{};
-  s.a = 0.0;                                                  // x0
-  s.b = 0.5;                                                  // x0 + (ub - lb) / 4
+  nm_first_simplex(x0, s.a, s.b);
   s.x = s.u = s.a;
   s.widened = kNmFirst;
   return s;
@@ -1551,10 +1559,9 @@ __device__ __forceinline__ void nm_advance(BrentState& s, double f) {      // f:
 //   u, d = the two points to evaluate next;  e counts the evaluations the one-at-a-time search would have made.
 enum : int { kNm2Start = 0, kNm2Reflect, kNm2Expand, kNm2Outside };
 constexpr int kSearchNelderMeadPair = 2;
-__device__ __forceinline__ BrentState nm2_start() {
+__device__ __forceinline__ BrentState nm2_start(double x0) {
   BrentState s{};
-  s.a = 0.0;
-  s.b = 0.5;
+  nm_first_simplex(x0, s.a, s.b);
   s.u = s.a; s.d = s.b; s.x = s.a;
   s.widened = kNm2Start;
   return s;
@@ -1599,10 +1606,10 @@ __device__ __forceinline__ void nm2_advance(BrentState& s, double f0, double f1)
 
 __global__ void __launch_bounds__(kBlock)
 k_brent_init(const unsigned long long* __restrict__ counts, const double* __restrict__ sums, uint64_t n, int use_estimate, int search,
-             BrentState* __restrict__ st, double* __restrict__ f_next) {
+             const double* __restrict__ start, BrentState* __restrict__ st, double* __restrict__ f_next) {
   for (uint64_t g = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x; g < n;
        g += static_cast<uint64_t>(gridDim.x) * blockDim.x) {
-    const BrentState s = search == kSearchNelderMeadPair ? nm2_start() : search == kSearchNelderMead ? nm_start()
+    const BrentState s = search == kSearchNelderMeadPair ? nm2_start(start[g]) : search == kSearchNelderMead ? nm_start(start[g])
                          : use_estimate ? brent_start(counts + g * 6, sums + g * kParts0) : brent_start(nullptr, nullptr);
     st[g] = s;
     f_next[g] = s.x;
@@ -1687,7 +1694,8 @@ __global__ void __launch_bounds__(kBlock)
 k_inbreed_iterate_wave(const uint8_t* __restrict__ gt, uint64_t pitch, uint64_t g0, uint64_t n_genomes,
                        const uint32_t* __restrict__ locus_index, uint64_t n_sel, const double* __restrict__ table,
                        const uint8_t* __restrict__ valid, uint32_t amax, int phased, const unsigned long long* __restrict__ counts,
-                       const double* __restrict__ sums, int search, double* __restrict__ f_out, unsigned int* __restrict__ max_evaluations) {
+                       const double* __restrict__ sums, int search, const double* __restrict__ start, double* __restrict__ f_out,
+                       unsigned int* __restrict__ max_evaluations) {
   const uint64_t g = (static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x) / kWave;
   const uint32_t lane = threadIdx.x & (kWave - 1);
   if (g >= n_genomes) return;                                 // whole waves only
@@ -1711,9 +1719,9 @@ k_inbreed_iterate_wave(const uint8_t* __restrict__ gt, uint64_t pitch, uint64_t 
     }
   }
   if constexpr (MODE == 1) {
-    // processHallME (_calc.cpp:255-285) from the fixed start 0.25, 50 expectation steps (see kgx_inbreed)
+    // processHallME (_calc.cpp:255-285): 50 expectation steps from the genome's start point (see kgx_inbreed)
     const double total = static_cast<double>(counts[g * 6 + 4]);
-    double F = 0.25;
+    double F = start[g];
     for (int it = 0; it < 50; ++it) {
       double sum = 0.0;
 #pragma unroll
@@ -1725,7 +1733,7 @@ k_inbreed_iterate_wave(const uint8_t* __restrict__ gt, uint64_t pitch, uint64_t 
     }
     if (lane == 0) f_out[g] = F;
   } else {
-    BrentState s = search == kSearchNelderMead ? nm_start()
+    BrentState s = search == kSearchNelderMead ? nm_start(start[g])
                    : sums ? brent_start(counts + g * 6, sums + g * kParts0) : brent_start(nullptr, nullptr);
     unsigned int evaluations = 0;
     for (int it = 0; it < (search == kSearchNelderMead ? 500 : 60); ++it) {

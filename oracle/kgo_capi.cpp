@@ -769,6 +769,17 @@ int kgo_inbreed_dense(kgo_pop* reference_all, kgo_pop* reference_snp_pass, int s
                       freqs_out, seconds);
 }
 
+// The restart start points of n per-genome tasks under processResults' seeding (task k: start_seed + k): out[k][restarts].
+int kgo_restart_draws(const char* algorithm, uint64_t start_seed, uint64_t n, uint64_t restarts, double* out) {
+  auto algo = namedAlgorithm(algorithm ? algorithm : "");
+  if (!algo || !out || start_seed == 0) return -1;
+  for (uint64_t k = 0; k < n; ++k) {
+    const auto draws = restartDraws(algo.value(), start_seed + k, restarts);
+    for (uint64_t r = 0; r < restarts; ++r) out[k * restarts + r] = draws[r];
+  }
+  return 0;
+}
+
 // The whole window loop (populationInbreeding, _diploid.cpp:18-79).
 kgo_columns* kgo_population_inbreeding(kgo_pop* reference, kgo_pop* diploid, const int32_t* super_pop_of_genome,
                                        const char* algorithm, uint64_t lower, uint64_t upper, uint64_t spacing,

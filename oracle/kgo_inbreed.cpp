@@ -323,17 +323,24 @@ static constexpr size_t MAXIMUM_ITERATIONS_ = 1000;
 static constexpr size_t MAX_RETRIES_ = 50;
 static constexpr size_t MIN_RETRIES_ = 5;
 
-// Test hook: start_seed == kFixedStarts replaces the random restart points by the midpoint of the
-// reference's start interval (HallME: 0.25 of (0,0.5]; Loglikelihood: 0.0 of (-0.5,0.5]), so that a
-// deterministic implementation can be compared value for value.  Any other seed draws as the reference does.
-static constexpr uint64_t kFixedStarts = ~0ull;
-
+// The entropy of one per-genome task.  The reference builds a RandomEntropySource (kel_math/kel_distribution.h:25-43: a
+// std::mt19937_64 seeded from std::random_device) inside every process* call: seed 0.  A non-zero seed is the reference's
+// DeterministicEntropySource (kel_distribution.h:53-70) instead -- same generator, known start -- so that a run can be
+// repeated; processResults gives the k-th task it enqueues the seed start_seed + k.  Nothing else differs.
 static std::mt19937_64 makeEntropy(uint64_t seed) {
   if (seed == 0) {
     std::random_device rd;
     return std::mt19937_64(rd());
   }
   return std::mt19937_64(seed);
+}
+
+std::vector<double> restartDraws(InbreedAlgorithm algorithm, uint64_t start_seed, size_t restarts) {
+  std::mt19937_64 entropy_mt = makeEntropy(start_seed);
+  std::uniform_real_distribution<> initialize_distribution(INIT_UPPER_, algorithm == InbreedAlgorithm::HallME ? 0.0 : INIT_LOWER_);
+  std::vector<double> draws;
+  for (size_t r = 0; r < restarts; ++r) draws.push_back(initialize_distribution(entropy_mt));
+  return draws;
 }
 
 double logLikelihood(double f, const std::vector<AlleleFreqInfo>& data) {
@@ -407,7 +414,7 @@ LocusResults processLogLikelihood(const std::string& genome_id, const ContigDB& 
   double updated_coefficient = 0.0;
   RetryCalcResult retry_results(FINAL_ACCURACY_, MIN_RETRIES_, MAX_RETRIES_);
   do {
-    const double initial_f = start_seed == kFixedStarts ? 0.0 : initialize_distribution(entropy_mt);
+    const double initial_f = initialize_distribution(entropy_mt);
     const auto& data = frequency_vector;
     updated_coefficient = neldermead1D([&data](double f) { return logLikelihood(f, data); }, initial_f, -1.0, 1.0, 1e-06, 500, nullptr);
   } while (!retry_results.checkRetry(updated_coefficient));
@@ -428,7 +435,7 @@ LocusResults processHallME(const std::string& genome_id, const ContigDB& contig,
   double inbreed_coefficient;
   RetryCalcResult retry_results(FINAL_ACCURACY_, MIN_RETRIES_, MAX_RETRIES_);
   do {
-    updated_coefficient = start_seed == kFixedStarts ? 0.25 : initialize_distribution(entropy_mt);
+    updated_coefficient = initialize_distribution(entropy_mt);
     RetryCalcResult converge_retry(FINAL_ACCURACY_, MINIMUM_ITERATIONS_, MAXIMUM_ITERATIONS_);
     do {
       inbreed_coefficient = updated_coefficient;
@@ -521,7 +528,7 @@ ResultsMap processResults(const PopulationDB& diploid_population, const std::str
     std::shared_ptr<const ContigDB> contig = contig_opt.value();
     std::shared_ptr<const ContigDB> locus_list = locus_result->second;
     const std::string gid = genome_id;
-    const uint64_t seed = params.start_seed == ~0ull ? ~0ull : (params.start_seed ? params.start_seed + future_vector.size() : 0);
+    const uint64_t seed = params.start_seed ? params.start_seed + future_vector.size() : 0;
     future_vector.push_back(thread_pool.enqueueFuture([=]() -> LocusResults {
       switch (algo) {
         case InbreedAlgorithm::RitlandLocus: return processRitlandLocus(gid, *contig, super_pop, *locus_list);

@@ -164,6 +164,9 @@ LocusResults processSimple(const std::string& genome_id, const ContigDB& contig,
 LocusResults processRitlandLocus(const std::string& genome_id, const ContigDB& contig, int super_pop, const ContigDB& locus_list);
 LocusResults processHallME(const std::string& genome_id, const ContigDB& contig, int super_pop, const ContigDB& locus_list,
                            uint64_t start_seed);
+// The start points one task draws, restart by restart, exactly as processHallME (_calc.cpp:235-246) / processLogLikelihood
+// (:163-180) construct and use their entropy source and distribution: draws[r] = the start of restart r.
+std::vector<double> restartDraws(InbreedAlgorithm algorithm, uint64_t start_seed, size_t restarts);
 LocusResults processLogLikelihood(const std::string& genome_id, const ContigDB& contig, int super_pop,
                                   const ContigDB& locus_list, uint64_t start_seed);
 double logLikelihood(double f, const std::vector<AlleleFreqInfo>& data);   // _calc.cpp:94-129

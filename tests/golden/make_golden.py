@@ -32,6 +32,9 @@ def allele_case():
                         hgvs_first=np.array([vdb.hgvs(0)]), hethom=pop.hethom(rec.contig))
 
 
+START_SEED = 20201
+
+
 def inbreed_case():
     G, L = 40, 700
     rec, gt = sv.multiallelic_block(G, L, rng_seed=3, missing_af_frac=0.03, dup_records=25)   # repeated records: same-phase pairs ((0, a) bytes) and >= 3 variants (0xFF)
@@ -48,12 +51,18 @@ def inbreed_case():
     sel = loci.sample(table, args["lower"], args["upper"], args["spacing"], args["min_af"], args["max_af"])
     out = dict(gt8=ii.encode_gt8(rec, gt, loci, phased_order=True), af_table=table, selected=sel, genome_order=dip.genome_order(),
                offsets=loci.offsets)
+    # The iterative estimators under known entropy: the k-th per-genome task draws from std::mt19937_64(START_SEED + k)
+    # (oracle/kgo_inbreed.cpp: makeEntropy, processResults); start_<algo>[k] = the fifth draw of that stream, the start of
+    # the restart that decides the result (the oracle's own draws, kgo_restart_draws).
+    out["start_seed"] = np.uint64(START_SEED)
     for algo in ("Simple", "RitlandLocus", "HallME", "Loglikelihood"):
         counts, freqs, present, _ = oa.inbreed_window(ref_f, dip, np.full(G, oa.ALL, dtype=np.int32), algo, args["lower"], args["upper"],
-                                                      args["spacing"], 1000, args["min_af"], args["max_af"], seed=oa.FIXED_STARTS)
+                                                      args["spacing"], 1000, args["min_af"], args["max_af"], seed=START_SEED)
         assert present.all()
         out[f"counts_{algo}"] = counts
         out[f"freqs_{algo}"] = freqs
+        if algo in ("HallME", "Loglikelihood"):
+            out[f"start_{algo}"] = oa.restart_draws(algo, START_SEED, G)[:, 4]      # genome-id order
     np.savez_compressed(HERE / "inbreed_40x700.npz", **out)
 
 
@@ -90,7 +99,7 @@ def vcf_cases():
     genomes = [vdb.genome_id(i) for i in range(vdb.n_genomes)]
     # the package's window loop (LociiCount 100, SamplingDistance 10) with every genome in the "ALL" super population
     cols = oa.population_inbreeding(ref.filter_snp_pass(), dip, np.full(len(genomes), oa.ALL, dtype=np.int32), "Simple", 0, 10**9, 10, 100,
-                                    0.02, 0.9, seed=oa.FIXED_STARTS)
+                                    0.02, 0.9, seed=START_SEED)
     assert len(cols) >= 2
     out.update(ref_text=np.array([ref_text]), kg_text=np.array([dip_text]), kg_genomes=np.array(genomes),
                kg_column_ident=np.array([c[0] for c in cols]), kg_counts=np.stack([c[1] for c in cols]),

@@ -17,7 +17,6 @@ import os as _os
 LIB_PATH = Path(_os.environ.get("KGX_SANITIZED_ORACLE_LIB") or ROOT / "oracle" / "_build" / "libkgo.so")
 
 SUPER_POPS = ["AFR", "AMR", "EAS", "EUR", "SAS", "ALL"]
-FIXED_STARTS = 0xFFFFFFFFFFFFFFFF   # oracle test hook: deterministic restart points (see kgo_inbreed.cpp)
 ALL = 5
 
 _lib = None
@@ -78,6 +77,7 @@ def lib() -> C.CDLL:
         "kgo_class_frequencies": (C.c_int, [vp, C.c_uint32, dbl, C.c_int, vp]),
         "kgo_sample_locii": (i64, [vp, C.c_int, C.c_int, u64, u64, u64, u64, dbl, dbl, vp, u64]),
         "kgo_inbreed_window": (C.c_int, [vp, vp, vp, C.c_char_p, u64, u64, u64, u64, dbl, dbl, u64, vp, vp, vp, vp]),
+        "kgo_restart_draws": (C.c_int, [C.c_char_p, u64, u64, u64, vp]),
         "kgo_loglikelihood_at": (C.c_int, [vp, vp, vp, u64, u64, u64, dbl, dbl, vp, vp]),
         "kgo_inbreed_dense": (C.c_int, [vp, vp, C.c_int, u64, u64, u64, dbl, dbl, vp, u64, vp, u64, C.c_int, vp, vp, vp]),
         "kgo_population_inbreeding": (vp, [vp, vp, vp, C.c_char_p, u64, u64, u64, u64, dbl, dbl, u64]),
@@ -420,6 +420,14 @@ def inbreed_window(reference: Population, diploid: Population, super_pop_of_geno
                                   count, min_af, max_af, seed, _p(counts), _p(freqs), _p(present), C.byref(sec))
     assert rc == 0
     return counts, freqs, present.astype(bool), sec.value
+
+
+def restart_draws(algorithm, seed, n, restarts=5):
+    """The start points the oracle's per-genome tasks draw under inbreed_window(seed=seed): [n][restarts], task k from
+    std::mt19937_64(seed + k); RetryCalcResult ends the restarts at the fifth, whose run is the result."""
+    out = np.zeros((n, restarts), dtype=np.float64)
+    assert lib().kgo_restart_draws(algorithm.encode(), int(seed), int(n), int(restarts), _p(out)) == 0
+    return out
 
 
 def loglikelihood_at(reference: Population, diploid: Population, super_pop_of_genome, lower, upper, spacing, min_af, max_af, f):

@@ -1,11 +1,12 @@
 """Parity of the inbreeding kernels (K5/K6/K7, through the C ABI) against the oracle's restatement of
 kga_analytic/kga_inbreed.  Integer class counts are bit-exact; fp64 sums and the Simple / RitlandLocus
 coefficients agree to 1e-12 relative (only the summation order differs).  HallME and Loglikelihood restart
-from random points in the reference; against the oracle run with the same fixed start the GPU agrees to 1e-9
-(HallME: 50 expectation steps of the same map) and 1e-5 (Loglikelihood: two different maximisers of one
-concave objective, each converged to <= 1e-6); against the oracle's random restarts the deviation is the
-reference's own run-to-run scatter and is reported, not asserted, except where the estimator has converged.
-Needs a GPU."""
+from random points in the reference (one std::mt19937_64 per genome task) and keep the fifth restart: given the
+same entropy -- oracle(seed s) hands the k-th task the stream s + k, the device gets the points
+kgx_inbreed_reference_starts draws from those streams -- the GPU agrees to 1e-9 (HallME: 50 expectation steps of
+the same map from the same point) and 2e-6 (Loglikelihood: the same simplex walk, each side stopping at a width of
+1e-6).  The deterministic mode (no start points: the interval midpoints) is checked to lie inside the envelope of
+the seeded runs.  Needs a GPU."""
 import numpy as np
 import pytest
 
@@ -17,6 +18,17 @@ pytestmark = pytest.mark.gpu
 
 REL = 1e-12
 F_BAND = 2e-4
+START_SEED = 77
+
+
+def seeded_starts(kgx, algorithm, seed, order):
+    """Start point of every device genome (caller's order) under the oracle's entropy: the k-th genome in id order --
+    processResults' fan-out order -- owns the stream seed + k (oracle/kgo_inbreed.cpp: processResults)."""
+    if algorithm not in ("HallME", "Loglikelihood"):
+        return None
+    start = np.empty(len(order), dtype=np.float64)
+    start[order] = kgx.reference_starts(algorithm, seed, len(order))
+    return start
 
 
 def build(G, L, mode, seed):
@@ -89,10 +101,10 @@ def test_inbreed_window_vs_oracle(kgx, mode, algorithm, path, monkeypatch):
         want_offsets = oa.sample_locii(ref, sp, False, lower, upper, spacing, 1000, min_af, max_af)
         assert np.array_equal(loci.offsets[sel], want_offsets)
         counts, freqs, present, _ = oa.inbreed_window(ref, dip, np.full(G, sp, dtype=np.int32), algorithm, lower, upper,
-                                                      spacing, 1000, min_af, max_af, seed=oa.FIXED_STARTS)
+                                                      spacing, 1000, min_af, max_af, seed=START_SEED)
         assert present.all()
-        got = m.inbreed(table[sel], algorithm, phased=(mode == oa.Population.PHASED), locus_index=sel)[np.argsort(order)]
-        got = got[order]
+        got = m.inbreed(table[sel], algorithm, phased=(mode == oa.Population.PHASED), locus_index=sel,
+                        start=seeded_starts(kgx, algorithm, START_SEED, order))[order]
         # oracle columns: major_het, minor_het, minor_hom, major_hom, total
         for k, name in enumerate(["major_hetero_count", "minor_hetero_count", "minor_homo_count", "major_homo_count", "total_allele_count"]):
             assert np.array_equal(got[name], counts[:, k]), name
@@ -102,13 +114,52 @@ def test_inbreed_window_vs_oracle(kgx, mode, algorithm, path, monkeypatch):
             assert np.allclose(got["inbred_allele_sum"], freqs[:, 4], rtol=1e-10, atol=1e-12)
         elif algorithm == "HallME":
             assert np.abs(got["inbred_allele_sum"] - freqs[:, 4]).max() <= 1e-9
+        elif path == "golden":
+            # another search (golden section over [-1, 1], no start point): the same maximum within the reference's band
+            assert np.abs(got["inbred_allele_sum"] - freqs[:, 4]).max() <= F_BAND
         else:
-            assert np.abs(got["inbred_allele_sum"] - freqs[:, 4]).max() <= 1e-5
-            # and the reference's random restarts land on the same maximum within its own convergence band
-            _, fr, _, _ = oa.inbreed_window(ref, dip, np.full(G, sp, dtype=np.int32), algorithm, lower, upper, spacing, 1000,
-                                            min_af, max_af, seed=77)
-            assert np.abs(got["inbred_allele_sum"] - fr[:, 4]).max() <= F_BAND
+            assert np.abs(got["inbred_allele_sum"] - freqs[:, 4]).max() <= 2e-6
         assert counts[:, 1].sum() > 0 and counts[:, 2].sum() + counts[:, 1].sum() > 0
+    m.close()
+
+
+def test_midpoint_starts_lie_inside_the_envelope_of_seeded_runs(kgx):
+    """kgx_inbreed without start points runs from the midpoints of the reference's start intervals -- a mode the
+    reference does not have.  What it returns must lie inside what the reference's own behaviour spans: the min-max
+    envelope, per genome, of 16 oracle runs with different entropy.  (HallME's 50-step map is monotone in its start, so
+    the midpoint run lies between a run started below 0.25 and one started above; Loglikelihood ends on one of the
+    local maxima the seeded runs end on.)  The envelope's width -- the reference's run-to-run scatter -- is printed."""
+    G, L = 101, 1200
+    rec, gt, ids, ref, dip = build(G, L, oa.Population.PHASED, seed=5)
+    loci = ii.ReferenceLoci(rec)
+    amax = max(len(a) for a in loci.alts)
+    m = kgx.GenotypeMatrix(G, len(loci.offsets))
+    m.load_rows(ii.encode_gt8(rec, gt, loci, phased_order=True))
+    order = dip.genome_order()
+    lower, upper, spacing, min_af, max_af = 200, 40_000, 60, 0.02, 0.9
+    table = loci.af_table(oa.ALL, amax)
+    sel = loci.sample(table, lower, upper, spacing, min_af, max_af)
+    sp = np.full(G, oa.ALL, dtype=np.int32)
+    for algorithm, slack in (("HallME", 1e-9), ("Loglikelihood", 2e-6)):
+        runs = np.stack([oa.inbreed_window(ref, dip, sp, algorithm, lower, upper, spacing, 1000, min_af, max_af, seed=1000 + 977 * k)[1][:, 4]
+                         for k in range(16)])
+        lo, hi = runs.min(axis=0), runs.max(axis=0)
+        mid = m.inbreed(table[sel], algorithm, phased=True, locus_index=sel)[order]["inbred_allele_sum"]
+        print(f"{algorithm}: envelope of 16 seeded oracle runs up to {float((hi - lo).max()):.3g} wide (median {float(np.median(hi - lo)):.3g})")
+        outside = (mid < lo - slack) | (mid > hi + slack)
+        assert not outside.any(), (algorithm, np.flatnonzero(outside).tolist(), mid[outside].tolist(), lo[outside].tolist(), hi[outside].tolist())
+    m.close()
+
+
+def test_start_points_are_range_checked(kgx):
+    m = kgx.GenotypeMatrix(8, 16)
+    m.load_rows(np.zeros((16, 8), dtype=np.uint8))
+    af = np.full((16, 1), 0.2)
+    with pytest.raises(Exception):
+        m.inbreed(af, "HallME", phased=True, start=np.full(8, 0.0))          # the reference's draws lie in (0, 0.5]
+    with pytest.raises(Exception):
+        m.inbreed(af, "Loglikelihood", phased=True, start=np.full(8, 1.5))   # outside the optimiser's box
+    m.inbreed(af, "Simple", phased=True, start=np.full(8, 9.0))              # ignored by the closed-form estimators
     m.close()
 
 
@@ -513,8 +564,9 @@ def test_c5_full_size_fp64_sums_vs_oracle(kgx):
 
 def test_iterative_estimators_at_scale_vs_oracle(kgx):
     """HallME and Loglikelihood through the multi-kernel table passes (the path C5 takes) at 1,000 genomes x 100,000 loci
-    of the C5 population against the oracle run from the same fixed starts: class counts bit-exact, HallME within 1e-9,
-    Loglikelihood within 2e-6 (one optimiser, one start, each side converged to a simplex of 1e-6)."""
+    of the C5 population against the oracle under the same entropy (seeded per-genome streams, the fifth draw starts the
+    run that counts): class counts bit-exact, HallME within 1e-9, Loglikelihood within 2e-6 (one optimiser, one start,
+    each side converged to a simplex of 1e-6)."""
     G, L = 1000, 100_000
     m = kgx.GenotypeMatrix(G, L)
     table = m.synth_multiallelic(1111, 0, 0)
@@ -529,9 +581,9 @@ def test_iterative_estimators_at_scale_vs_oracle(kgx):
     sp = np.full(G, oa.ALL, dtype=np.int32)
     f_true = ((np.arange(G) % 101) - 50) / 100.0
     for algorithm in ("HallME", "Loglikelihood"):
-        counts, freqs, present, _ = oa.inbreed_window(ref, dip, sp, algorithm, 0, upper, 1, 10**9, 0.0, 1.0, seed=oa.FIXED_STARTS)
+        counts, freqs, present, _ = oa.inbreed_window(ref, dip, sp, algorithm, 0, upper, 1, 10**9, 0.0, 1.0, seed=START_SEED)
         assert present.all()
-        got = m.inbreed(table, algorithm, phased=True)[order]
+        got = m.inbreed(table, algorithm, phased=True, start=seeded_starts(kgx, algorithm, START_SEED, order))[order]
         assert np.array_equal(got["total_allele_count"], counts[:, 4])
         assert np.array_equal(got["minor_homo_count"], counts[:, 2]) and np.array_equal(got["major_homo_count"], counts[:, 3])
         err = np.abs(got["inbred_allele_sum"] - freqs[:, 4])
@@ -541,7 +593,7 @@ def test_iterative_estimators_at_scale_vs_oracle(kgx):
         # Loglikelihood.  For a genome with F < 0 the maximum of the CLAMPED objective sits on the kinks the 1e-10 floor puts
         # into it: a homozygous cell of allele frequency f is floored for F < -f / (1 - f), so next to the smooth optimum lie
         # several local maxima ~0.01 apart, and which one a search ends on depends on its path.  The device walks the
-        # reference optimiser's own path (Nelder-Mead from the oracle's fixed start, nm_advance), so it ends on the oracle's
+        # reference optimiser's own path (Nelder-Mead from the oracle's own start point, nm_advance), so it ends on the oracle's
         # maximum: within 2e-6 (each side stops at a simplex of 1e-6) -- except where two objective values the simplex
         # compares differ by less than their rounding (the oracle adds ~1e5 logs one by one, the device multiplies
         # probabilities and takes one log per segment), which may send the two paths apart once in a few thousand

@@ -269,15 +269,87 @@ def test_locus_sampling_spacing_and_af_window():
     assert oa.sample_locii(ref_f, oa.ALL, False, 0, 700, 1, 1000, 0.2, 0.5).tolist() == [100, 200, 300]
 
 
-def test_retry_quirk_gives_exactly_five_restarts_of_fifty_em_steps():
-    # With checkTolerance comparing each entry with itself, HallME = 50 EM steps from the 5th random start.
+def mt19937_64(seed):
+    """std::mt19937_64 as the C++ standard defines it ([rand.predef]: w 64, n 312, m 156, r 31, a 0xb5026f5aa96619e9,
+    u 29, d 0x5555555555555555, s 17, b 0x71d67fffeda60000, t 37, c 0xfff7eeee00000000, l 43, f 6364136223846793005)."""
+    mask = (1 << 64) - 1
+    mt = [seed & mask]
+    for i in range(1, 312):
+        mt.append((6364136223846793005 * (mt[-1] ^ (mt[-1] >> 62)) + i) & mask)
+    index = 312
+    while True:
+        if index == 312:
+            for i in range(312):
+                x = (mt[i] & 0xFFFFFFFF80000000) | (mt[(i + 1) % 312] & 0x7FFFFFFF)
+                mt[i] = mt[(i + 156) % 312] ^ (x >> 1) ^ (0xB5026F5AA96619E9 if x & 1 else 0)
+            index = 0
+        y = mt[index]
+        index += 1
+        y ^= (y >> 29) & 0x5555555555555555
+        y ^= (y << 17) & 0x71D67FFFEDA60000
+        y ^= (y << 37) & 0xFFF7EEEE00000000
+        y ^= y >> 43
+        yield y & mask
+
+
+def uniform_real(bits, a, b):
+    """libstdc++'s std::uniform_real_distribution<double>(a, b) on one 64-bit draw: generate_canonical<double, 53> =
+    double(x) / 2^64 (below 1 by construction), then u * (b - a) + a."""
+    u = float(bits) / 18446744073709551616.0
+    if u >= 1.0:
+        u = float(np.nextafter(1.0, 0.0))
+    return u * (b - a) + a
+
+
+def test_mersenne_twister_known_answer():
+    gen = mt19937_64(5489)                       # [rand.predef]: the 10000th invocation of a default-constructed mt19937_64
+    for _ in range(9999):
+        next(gen)
+    assert next(gen) == 9981545732273789042
+
+
+def test_restart_entropy_is_the_standard_twister_and_the_reference_distributions():
+    # processHallME draws UniformRealDistribution(INIT_UPPER_, 0), processLogLikelihood (INIT_UPPER_, INIT_LOWER_)
+    # (_calc.cpp:237,166) from a std::mt19937_64, once per restart; task k owns the seed start_seed + k.
+    for seed in (11, 20201):
+        for algorithm, lower in (("HallME", 0.0), ("Loglikelihood", -0.5)):
+            draws = oa.restart_draws(algorithm, seed, 3, restarts=6)
+            for k in range(3):
+                gen = mt19937_64(seed + k)
+                assert draws[k].tolist() == [uniform_real(next(gen), 0.5, lower) for _ in range(6)]
+
+
+def test_retry_quirk_keeps_the_fifth_restart_of_fifty_em_steps():
+    # RetryCalcResult::checkTolerance compares every entry with itself (_calc.cpp:45-68), so the outer loop ends when five
+    # restarts are in (MIN_RETRIES_) and the inner one after exactly MINIMUM_ITERATIONS_ = 50 expectation steps: HallME is
+    # 50 steps of F <- (1/N) sum_hom F / (F + (1 - F) p) (_calc.cpp:255-285) from the FIFTH draw of the task's twister.
     ref, dip, *_ = reference_and_diploid()
     ref_f = ref.filter_snp_pass()
     sp = np.full(8, oa.ALL, dtype=np.int32)
-    _, fa, _, _ = oa.inbreed_window(ref_f, dip, sp, "HallME", 0, 10_000, 1, 1000, 0.0, 1.0, seed=11)
-    _, fb, _, _ = oa.inbreed_window(ref_f, dip, sp, "HallME", 0, 10_000, 1, 1000, 0.0, 1.0, seed=11)
+    seed = 11
+    _, fa, _, _ = oa.inbreed_window(ref_f, dip, sp, "HallME", 0, 10_000, 1, 1000, 0.0, 1.0, seed=seed)
+    _, fb, _, _ = oa.inbreed_window(ref_f, dip, sp, "HallME", 0, 10_000, 1, 1000, 0.0, 1.0, seed=seed)
     assert np.array_equal(fa, fb)
-    assert np.all(np.isfinite(fa[:, 4]))
+    # genome 4 (see test_ritland_closed_form): five classified loci, all homozygous, allele frequencies ps
+    f32 = lambda *x: float(sum(np.float32(v).astype(np.float64) for v in x))
+    ps = [1.0 - f32(0.30), 1.0 - f32(0.10, 0.20), 1.0 - f32(0.25), 1.0 - f32(0.15), f32(0.40)]
+    for g in range(4, 8):                                     # genomes 4..7 hold the same genotypes, each its own stream
+        gen = mt19937_64(seed + g)
+        starts = [uniform_real(next(gen), 0.5, 0.0) for _ in range(5)]
+        by_start = []
+        for start in starts:
+            F = start
+            for _ in range(50):
+                total = 0.0
+                for p in ps:
+                    denominator = F + ((1.0 - F) * p)
+                    if denominator != 0:
+                        total += F / denominator
+                F = total / 5.0
+            by_start.append(F)
+        assert fa[g, 4] == by_start[4], (g, fa[g, 4], by_start)
+        assert all(abs(fa[g, 4] - other) > 1e-12 for other in by_start[:4])   # not any of the first four
+    assert len({fa[g, 4] for g in range(4, 8)}) == 4           # one stream per task
 
 
 @pytest.mark.parametrize("algorithm,slope_lo", [("Simple", 0.8), ("Loglikelihood", 0.8), ("HallME", 0.3)])

@@ -10,6 +10,9 @@ from . import synth_vcf as sv
 
 pytestmark = pytest.mark.gpu
 
+# "StartSeed" of GPU_INBREED = the oracle's start_seed: the k-th per-genome task owns std::mt19937_64(seed + k)
+START_SEED = 4242
+
 
 # Device bindings of the package (kgx_device_binding.h): the default single device; "Devices=0" = every visible device
 # (one on the test box); "DeviceList=0,0,0" = three genome shards, here on one device -- the single-process multi-GPU
@@ -88,7 +91,7 @@ def test_gpu_inbreed_package_matches_oracle_window_loop(tmp_path, kgx, algorithm
     rio.write_records(ref_path, rec, None, ["Reference"], oa.Population.REFERENCE, "Gnomad2_1", population_id="Gnomad")
     rio.write_records(dip_path, rec, gt, ids, mode, source, population_id="Diploid", ped=ped)
     params = dict(AnalysisType="false", OutputFile="inbreed", Algorithm=algorithm, MinAlleleFreq=0.02, MaxAlleleFreq=0.9,
-                  LowerWindow=0, UpperWindow=60000, LociiCount=150, SamplingDistance=40)
+                  LowerWindow=0, UpperWindow=60000, LociiCount=150, SamplingDistance=40, StartSeed=START_SEED)
     res = rio.run_driver("GPU_INBREED", tmp_path, [ref_path, dip_path], **params, **binding)
     assert res.returncode == 0, res.stderr
 
@@ -99,7 +102,7 @@ def test_gpu_inbreed_package_matches_oracle_window_loop(tmp_path, kgx, algorithm
     ped_map = dict(ped)
     sorted_ids = sorted(ids)
     sp_of = np.array([oa.SUPER_POPS.index(ped_map[g]) if g in ped_map else -1 for g in sorted_ids], dtype=np.int32)
-    cols = oa.population_inbreeding(ref.filter_snp_pass(), dip, sp_of, algorithm, 0, 60000, 40, 150, 0.02, 0.9, seed=oa.FIXED_STARTS)
+    cols = oa.population_inbreeding(ref.filter_snp_pass(), dip, sp_of, algorithm, 0, 60000, 40, 150, 0.02, 0.9, seed=START_SEED)
     assert len(cols) >= 3
 
     header, rows = rio.read_csv(tmp_path / "inbreed_detail.csv")
@@ -115,7 +118,7 @@ def test_gpu_inbreed_package_matches_oracle_window_loop(tmp_path, kgx, algorithm
             c, f = got[(ident, g)]
             assert c == counts[k].tolist(), (ident, g)                       # major_het, minor_het, minor_hom, major_hom, total
             assert np.allclose(f[:4], freqs[k, :4], rtol=1e-12, atol=1e-12)
-            tol = {"Simple": 1e-10, "RitlandLocus": 1e-10, "HallME": 1e-9, "Loglikelihood": 1e-5}[algorithm]
+            tol = {"Simple": 1e-10, "RitlandLocus": 1e-10, "HallME": 1e-9, "Loglikelihood": 2e-6}[algorithm]
             assert abs(f[4] - freqs[k, 4]) <= tol, (ident, g, f[4], freqs[k, 4])
             n_checked += 1
     assert n_checked == len(got) and n_checked >= 3 * (G - 21)
@@ -298,7 +301,7 @@ def test_gpu_inbreed_package_reads_vcf_directly(tmp_path, kgx, algorithm):
     (tmp_path / "kg.vcf").write_text(dip_text)
     (tmp_path / "ped.txt").write_text("".join(f"{g}\t{sp}\n" for g, sp in ped))
     params = dict(AnalysisType="false", OutputFile="inbreed", Algorithm=algorithm, MinAlleleFreq=0.02, MaxAlleleFreq=0.9,
-                  LowerWindow=0, UpperWindow=60000, LociiCount=150, SamplingDistance=40)
+                  LowerWindow=0, UpperWindow=60000, LociiCount=150, SamplingDistance=40, StartSeed=START_SEED)
     res = rio.run_driver("GPU_INBREED", tmp_path, [f"vcf:Gnomad2_1:{tmp_path / 'gnomad.vcf'}", f"vcf:Genome1000:{tmp_path / 'kg.vcf'}",
                                                     f"ped:{tmp_path / 'ped.txt'}"], **params)
     assert res.returncode == 0, res.stderr
@@ -310,7 +313,7 @@ def test_gpu_inbreed_package_reads_vcf_directly(tmp_path, kgx, algorithm):
     vdb_ids = [oa.VariantDB(dip).genome_id(i) for i in range(dip.genome_count())]
     ped_map = dict(ped)
     sp_of = np.array([oa.SUPER_POPS.index(ped_map[g]) if g in ped_map else -1 for g in vdb_ids], dtype=np.int32)
-    cols = oa.population_inbreeding(ref.filter_snp_pass(), dip, sp_of, algorithm, 0, 60000, 40, 150, 0.02, 0.9, seed=oa.FIXED_STARTS)
+    cols = oa.population_inbreeding(ref.filter_snp_pass(), dip, sp_of, algorithm, 0, 60000, 40, 150, 0.02, 0.9, seed=START_SEED)
     assert len(cols) >= 3
     header, rows = rio.read_csv(tmp_path / "inbreed_detail.csv")
     got = {(r[0], r[1]): ([int(r[2]), int(r[4]), int(r[6]), int(r[8]), int(r[10])], [float(r[3]), float(r[5]), float(r[7]), float(r[9]), float(r[11])])
@@ -378,7 +381,7 @@ def test_gpu_inbreed_package_cuts_offsets_with_more_than_14_alts(tmp_path, kgx):
     vdb_ids = [oa.VariantDB(dip).genome_id(i) for i in range(dip.genome_count())]
     ped_map = dict(ped)
     sp_of = np.array([oa.SUPER_POPS.index(ped_map[g]) for g in vdb_ids], dtype=np.int32)
-    cols = oa.population_inbreeding(ref.filter_snp_pass(), dip, sp_of, "Simple", 0, upper, 1, 10000, 0.0, 1.0, seed=oa.FIXED_STARTS)
+    cols = oa.population_inbreeding(ref.filter_snp_pass(), dip, sp_of, "Simple", 0, upper, 1, 10000, 0.0, 1.0, seed=START_SEED)
     header, rows = rio.read_csv(tmp_path / "inbreed_detail.csv")
     got = {(r[0], r[1]): ([int(r[2]), int(r[4]), int(r[6]), int(r[8]), int(r[10])], [float(r[3]), float(r[5]), float(r[7]), float(r[9]), float(r[11])])
            for r in rows}
@@ -465,7 +468,7 @@ def test_gpu_inbreed_package_writes_the_reference_ped_file(tmp_path, kgx, algori
     rio.write_records(ref_path, rec, None, ["Reference"], oa.Population.REFERENCE, "Gnomad2_1", population_id="Gnomad")
     rio.write_records(dip_path, rec, gt, ids, oa.Population.PHASED, "Genome1000", population_id="Diploid")
     params = dict(AnalysisType="false", OutputFile="inbreed", Algorithm=algorithm, MinAlleleFreq=0.02, MaxAlleleFreq=0.9,
-                  LowerWindow=0, UpperWindow=60000, LociiCount=150, SamplingDistance=40)
+                  LowerWindow=0, UpperWindow=60000, LociiCount=150, SamplingDistance=40, StartSeed=START_SEED)
     res = rio.run_driver("GPU_INBREED", tmp_path, [f"ped:{ped_path}", ref_path, dip_path], **params)
     assert res.returncode == 0, res.stderr
 
@@ -476,7 +479,7 @@ def test_gpu_inbreed_package_writes_the_reference_ped_file(tmp_path, kgx, algori
     sp_of_genome = {row[0]: oa.SUPER_POPS.index(row[3]) for row in ped_rows}
     sp_of = np.array([sp_of_genome.get(g, -1) for g in sorted(ids)], dtype=np.int32)
     want_path = tmp_path / "oracle_inbreed.csv"
-    cols = oa.population_inbreeding(ref.filter_snp_pass(), dip, sp_of, algorithm, 0, 60000, 40, 150, 0.02, 0.9, seed=oa.FIXED_STARTS,
+    cols = oa.population_inbreeding(ref.filter_snp_pass(), dip, sp_of, algorithm, 0, 60000, 40, 150, 0.02, 0.9, seed=START_SEED,
                                     ped_file=(want_path, "DriverParameters", ped_rows))
     assert len(cols) >= 3
     got_text, want_text = (tmp_path / "inbreed.csv").read_text(), want_path.read_text()
