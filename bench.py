@@ -54,6 +54,8 @@ def parse_args():
     ap.add_argument("--cpu-sample-variants", type=int, default=300_000)      # x 10k genomes = 3e9 cells: ~12 s of the port
     ap.add_argument("--aux-genomes", type=int, default=10_000, help="genomes of the aux C5 population")
     ap.add_argument("--aux-loci", type=int, default=5_000_000, help="loci of the aux C5 population")
+    ap.add_argument("--c4-genomes", type=int, default=0,
+                    help="total genomes of the strong-scaled aux job of an N > 1 run (default: C4's 100,000 when the headline shape is C3's)")
     ap.add_argument("--algorithm", choices=["Simple", "RitlandLocus", "HallME", "Loglikelihood"], default="Simple",
                     help="estimator of the c5 workload")
     return ap.parse_args()
@@ -454,71 +456,108 @@ def main():
     else:
         shards = replicate_genomes(args.genomes or wl.get("genomes_per_gpu", 10_000), n_gpus)
         scaling = "weak"
-    total_genomes = sum(s.n_genomes for s in shards)
-    G = shards[rank].n_genomes
-    genome_base = shards[rank].genome_base
 
-    pop = capi.Population(G, V)
-    t0 = time.perf_counter()
-    pop.synth_biallelic(args.seed, genome_base, 0)
-    capi.synchronize()
-    t_synth = time.perf_counter() - t0
+    def sweep_job(shards, keep_population):
+        """The timed region over one population cut into `shards` (one per rank): W warm-up + K steps, each the K2 sweep of
+        this rank's rows, the one exchange of the path (all-reduce of the [V][4] counts, beside the next batch's sweep) and
+        the AF epilogue; barrier + synchronize on both sides, MAX over ranks.  Then the dominant kernel alone (HIP events).
+        Returns a dict; the population and the last batch's counts stay alive when keep_population."""
+        total_genomes = sum(s.n_genomes for s in shards)
+        G = shards[rank].n_genomes
+        pop = capi.Population(G, V)
+        t0 = time.perf_counter()
+        pop.synth_biallelic(args.seed, shards[rank].genome_base, 0)
+        capi.synchronize()
+        t_synth = time.perf_counter() - t0
 
-    # uint32 bit patterns in int32 tensors; sums < 2^31.  With N > 1 two buffers alternate: the all-reduce of batch i
-    # (RCCL's own stream, over xGMI) runs beside the sweep of batch i+1, and batch i's AF epilogue follows its sums.
-    bufs = [torch.empty((V, 4), dtype=torch.int32, device=dev) for _ in range(2 if n_gpus > 1 else 1)]
-    counts = bufs[0]
-    af = torch.empty((V,), dtype=torch.float64, device=dev)
-    stream = torch.cuda.current_stream(dev).cuda_stream
-    pending = []                                                       # at most one (work, buffer) in flight
-    issued = [0]
+        # uint32 bit patterns in int32 tensors; sums < 2^31.  With N > 1 two buffers alternate: the all-reduce of batch i
+        # (RCCL's own stream, over xGMI) runs beside the sweep of batch i+1, and batch i's AF epilogue follows its sums.
+        bufs = [torch.empty((V, 4), dtype=torch.int32, device=dev) for _ in range(2 if n_gpus > 1 else 1)]
+        af = torch.empty((V,), dtype=torch.float64, device=dev)
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        pending = []                                                       # at most one (work, buffer) in flight
+        issued = [0]
 
-    def finish():
-        while pending:
-            work, buf = pending.pop(0)
-            if work is not None:
-                work.wait()                                            # the current stream waits; the host does not
-            capi.allele_frequency_dev(buf.data_ptr(), V, total_genomes, af.data_ptr(), stream)
+        def finish():
+            while pending:
+                work, buf = pending.pop(0)
+                if work is not None:
+                    work.wait()                                            # the current stream waits; the host does not
+                capi.allele_frequency_dev(buf.data_ptr(), V, total_genomes, af.data_ptr(), stream)
 
-    def step():
-        buf = bufs[issued[0] % len(bufs)]
-        issued[0] += 1
-        pop.allele_count_by_locus_dev(buf.data_ptr(), stream)
-        work = allreduce_counts_async(buf, n_gpus)                     # the one exchange step of the path
-        finish()                                                       # the batch before this one
-        pending.append((work, buf))
-        if n_gpus == 1:
-            finish()
+        def step():
+            buf = bufs[issued[0] % len(bufs)]
+            issued[0] += 1
+            pop.allele_count_by_locus_dev(buf.data_ptr(), stream)
+            work = allreduce_counts_async(buf, n_gpus)                     # the one exchange step of the path
+            finish()                                                       # the batch before this one
+            pending.append((work, buf))
+            if n_gpus == 1:
+                finish()
 
-    def fence():
-        finish()                                                       # every batch's sums and AF are inside the timed region
+        def fence():
+            finish()                                                       # every batch's sums and AF are inside the timed region
+            if n_gpus > 1:
+                dist.barrier()
+            torch.cuda.synchronize(dev)
+
+        for _ in range(args.warmup):
+            step()
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        fence()
+        elapsed = time.perf_counter() - t0
+        counts = bufs[(issued[0] - 1) % len(bufs)]                        # the last batch's (summed) counts
+        # Exchange self-check outside the timed region, on the device, over EVERY variant and on every rank: the four summed
+        # counts of a row cover every genome of every rank exactly once; and the AF epilogue read those sums.
+        row_ok = counts.sum(dim=1, dtype=torch.int64) == total_genomes
+        # (divided by a TENSOR: torch turns a division by a Python scalar into a multiplication by its reciprocal on the
+        # device, which rounds differently from the IEEE division the epilogue and the reference make)
+        want_af = (counts[:, 1].to(torch.float64) + 2.0 * counts[:, 2].to(torch.float64)) / torch.full((), 2.0 * total_genomes, dtype=torch.float64, device=dev)
+        checks = torch.stack([row_ok.all(), (af == want_af).all()]).to(torch.int32)
+        del row_ok, want_af
         if n_gpus > 1:
-            dist.barrier()
-        torch.cuda.synchronize(dev)
+            dist.all_reduce(checks, op=dist.ReduceOp.MIN)                  # every rank must agree
+            t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+        exchange_ok, af_ok = (bool(x) for x in checks.tolist())
 
-    for _ in range(args.warmup):
-        step()
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    fence()
-    elapsed = time.perf_counter() - t0
-    counts = bufs[(issued[0] - 1) % len(bufs)]                        # the last batch's (summed) counts
-    # exchange self-check outside the timed region: every variant's four summed counts cover every genome once
-    head = counts[: min(V, 4096)].to(torch.int64).sum(dim=1)
-    exchange_ok = bool((head == total_genomes).all().item())
-    if n_gpus > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        # Dominant kernel (K2) timed alone with HIP events on the launch stream: the median launch.
+        scratch = torch.empty((V, 4), dtype=torch.int32, device=dev)
+        ms = pop.allele_count_timed(scratch.data_ptr(), stream, 2, max(args.steps, 10))
+        del scratch
+        job = dict(total_genomes=total_genomes, G=G, elapsed=elapsed, exchange_ok=exchange_ok, af_ok=af_ok, ms=ms, t_synth=t_synth,
+                   sweep_bytes=pop.sweep_bytes)                           # V*ceil(G/4) + 16*V (SURVEY.md §8d)
+        if keep_population:
+            job.update(pop=pop, counts=counts, bufs=bufs, af=af)
+        else:
+            pop.close()
+            del bufs, af, counts
+            torch.cuda.empty_cache()
+        return job
 
-    # Dominant kernel (K2) timed alone with HIP events on the launch stream: the median launch.
-    scratch = torch.empty((V, 4), dtype=torch.int32, device=dev)
-    ms = pop.allele_count_timed(scratch.data_ptr(), stream, 2, max(args.steps, 10))
-    del scratch
+    def exchange_description():
+        if n_gpus == 1:
+            return "none (1 GPU)"
+        if rehearsal:
+            return "gloo rehearsal on one device"
+        return "RCCL all-reduce(sum,u32) of [V][4] counts, overlapped with the next batch's sweep"
+
+    def distributed_config():
+        """What the exchange actually ran on, as torch.distributed and the library report it."""
+        return {"world_size": dist.get_world_size() if n_gpus > 1 else 1,
+                "backend": dist.get_backend() if n_gpus > 1 else "none (single process)",
+                "kgx_exchange_kind": capi.exchange_kind(),             # inside this process: one device per rank, so "none"
+                "kgx_bound_devices": capi.bound_devices()}
+
+    job = sweep_job(shards, keep_population=True)
+    total_genomes, G, elapsed, ms = job["total_genomes"], job["G"], job["elapsed"], job["ms"]
+    pop, counts, bufs, af = job["pop"], job["counts"], job["bufs"], job["af"]
+    exchange_ok, t_synth, sweep_bytes = job["exchange_ok"], job["t_synth"], job["sweep_bytes"]
     k2_ms = float(np.median(ms))
-    sweep_bytes = pop.sweep_bytes                                     # V*ceil(G/4) + 16*V
     achieved = sweep_bytes / (k2_ms * 1e-3) / 1e9
 
     result = None
@@ -547,8 +586,12 @@ def main():
                 "total_genomes": total_genomes,
                 "variants": V,
                 "layout": "2-bit dosage rows, variant-major",
-                "exchange": ("gloo rehearsal on one device" if rehearsal else "RCCL all-reduce(sum,u32) of [V][4] counts, overlapped with the next batch's sweep") if n_gpus > 1 else "none (1 GPU)",
-                "exchange_check": "row sums == total genomes on the first 4096 variants: " + ("ok" if exchange_ok else "MISMATCH"),
+                "exchange": exchange_description(),
+                "exchange_check": f"row sums == total genomes on all {V} variants, on every rank: " + ("ok" if exchange_ok else "MISMATCH")
+                                  + "; AF epilogue == (het + 2 hom) / 2G on all of them: " + ("ok" if job["af_ok"] else "MISMATCH"),
+                "distributed": distributed_config(),
+                "scaling_series": ("weak: " + str(G) + " genomes per GPU at every N; this line is its N = " + str(n_gpus) + " point"
+                                   if scaling == "weak" else "strong: " + str(total_genomes) + " genomes split over the ranks"),
                 "seed": args.seed,
                 "synth_seconds": round(t_synth, 3),
             },
@@ -578,12 +621,40 @@ def main():
             aux["k2_genome_mask"] = aux_genome_mask(capi, torch, pop, counts, G, V, sweep_bytes, args.seed)
             del dense
             pop.close()
-            del bufs, counts, af
+            job.pop("bufs"); job.pop("counts"); job.pop("af")
+            bufs = counts = af = None
             torch.cuda.empty_cache()
             aux["c5_simple"] = aux_inbreeding(args, capi, torch, dev, not args.no_cpu_baseline)
             result["aux"] = aux
 
     pop.close()
+    job = pop = counts = bufs = af = None
+    torch.cuda.empty_cache()
+    # With several ranks the weak-scaled C3 line also carries north_star's own multi-GPU configuration, BASELINE.json
+    # configs[3]: 100,000 genomes x 10M SNPs split over the ranks (12,500 per rank at N = 8), the same step -- sweep, ONE
+    # all-reduce of the per-variant counts, AF epilogue -- timed the same way.  (Every rank takes part: the job is collective.)
+    c4 = WORKLOADS["c4"]
+    c4_total = args.c4_genomes or (c4["total_genomes"] if not args.genomes and V == c4["variants"] else 0)
+    if n_gpus > 1 and args.workload == "c3" and not args.no_aux and c4_total and (c4_total // n_gpus + 63) // 64 * 16 * V <= 200e9:
+        c4_shards = shard_genomes(c4_total, n_gpus)
+        cjob = sweep_job(c4_shards, keep_population=False)
+        if rank == 0:
+            c_ms = float(np.median(cjob["ms"]))
+            c_achieved = cjob["sweep_bytes"] / (c_ms * 1e-3) / 1e9
+            result.setdefault("aux", {})["c4_strong"] = {
+                "metric": "variants·genomes/sec (allele-freq sweep)", "value": cjob["total_genomes"] * V * args.steps / cjob["elapsed"],
+                "unit": "variants·genomes/s", "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
+                "ms_per_step": cjob["elapsed"] / args.steps * 1e3, "scaling": "strong", "dtype": "u32", "data": "synthetic",
+                "config": {"workload": c4["label"] if (c4_total, V) == (c4["total_genomes"], c4["variants"]) else
+                                       f"custom: {c4_total} genomes x {V} biallelic SNPs sharded over the ranks",
+                           "genomes_per_gpu": cjob["G"], "total_genomes": cjob["total_genomes"], "variants": V,
+                           "exchange": exchange_description(),
+                           "exchange_check": f"row sums == total genomes on all {V} variants, on every rank: " + ("ok" if cjob["exchange_ok"] else "MISMATCH")
+                                             + "; AF epilogue: " + ("ok" if cjob["af_ok"] else "MISMATCH"),
+                           "distributed": distributed_config(), "synth_seconds": round(cjob["t_synth"], 3)},
+                "roofline": {"bound": "hbm", "kernel": "k_allele_count (rank 0's shard)", "achieved": c_achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                             "frac": c_achieved / HBM_PEAK_GBS, "traffic": None, "algorithmic_bytes_per_launch": cjob["sweep_bytes"], "kernel_ms": c_ms},
+            }
     if n_gpus > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -118,6 +118,34 @@ def ensure_built() -> None:
         _build.build_host()
 
 
+def _one_hip_runtime() -> None:
+    """Keep ONE HIP runtime in this process.  The PyTorch-ROCm wheel bundles its own libamdhip64.so / libhsa-runtime64.so
+    (found through an RPATH of $ORIGIN, by the file name `libamdhip64.so`), libkgx.so links the system's
+    /opt/rocm/lib/libamdhip64.so.7.  Both have the SONAME libamdhip64.so.7: when torch is loaded first, libkgx's
+    dependency resolves to the copy already mapped -- one runtime; when libkgx is loaded first, torch's request by file
+    name matches neither the mapped library's name nor its SONAME and maps the bundled copy as well -- two HIP and two HSA
+    runtimes in one process, the second of which cannot take the device the first one holds (torch then reports no GPU).
+    So a Python process that uses both (bench.py, a few tests: torch is their plumbing for device buffers and RCCL) must
+    load torch first; this does it whenever torch is installed and not loaded yet.  A C++ host (the reference binary with
+    the GPU packages, kgx_host_driver) has no torch and runs on the system runtime alone."""
+    import importlib.util
+    import sys
+
+    if "torch" not in sys.modules and importlib.util.find_spec("torch") is not None:
+        import torch  # noqa: F401
+
+
+def hip_runtimes_mapped() -> list[str]:
+    """The libamdhip64 files mapped into this process (more than one = the state _one_hip_runtime prevents)."""
+    found = set()
+    with open("/proc/self/maps") as maps:
+        for line in maps:
+            path = line.rsplit(" ", 1)[-1].strip()
+            if "libamdhip64" in path:
+                found.add(path)
+    return sorted(found)
+
+
 def lib() -> C.CDLL:
     """Load libkgx.so (once).  Raises if the HIP extension has not been built."""
     global _lib
@@ -128,6 +156,7 @@ def lib() -> C.CDLL:
             f"{LIB_PATH} is missing: build the HIP extension first "
             f"(python -m kgl_gene_amd.build, or __graft_entry__.build()). There is no CPU fallback."
         )
+    _one_hip_runtime()
     handle = C.CDLL(str(LIB_PATH))
     for name, (restype, argtypes) in _SIGNATURES.items():
         fn = getattr(handle, name)  # AttributeError here = header/library mismatch: fail loudly

@@ -10,6 +10,7 @@
 #ifndef KGX_DEVICE_BINDING_H
 #define KGX_DEVICE_BINDING_H
 
+#include <charconv>
 #include <sstream>
 #include <string>
 #include <vector>
@@ -34,8 +35,16 @@ inline bool bindDevices(const ParameterList& named_parameters, std::string& desc
             ordinals.clear();
             std::stringstream list(v.value().front());
             std::string item;
-            while (std::getline(list, item, ','))
-              if (!item.empty()) ordinals.push_back(std::stoi(item));
+            while (std::getline(list, item, ',')) {
+              if (item.empty()) continue;
+              int ordinal = 0;
+              const auto [end, errc] = std::from_chars(item.data(), item.data() + item.size(), ordinal);
+              if (errc != std::errc() || end != item.data() + item.size() || ordinal < 0) {
+                error = "DeviceList entry '" + item + "' is not a device ordinal";
+                return false;
+              }
+              ordinals.push_back(ordinal);
+            }
             decided = !ordinals.empty();
           }
         } else if (pass == 1) {

@@ -390,8 +390,10 @@ int genome_row_lists_shard(kgx_pop_shard& sh, uint64_t g_lo, uint64_t g_hi, cons
     hipLaunchKernelGGL((k_genome_row_lists<false>), dim3(gx, static_cast<uint32_t>(slices)), dim3(kBlock), 0, st,
                        reinterpret_cast<const kgx_v4u*>(sh.d_rows), sh.chunks_per_row, V, sh.n_genomes, g_lo, g_hi,
                        reinterpret_cast<const kgx_v4u*>(sh.d_keep), d_sel, rows_per_slice, d_counts, genomes_padded, nullptr, nullptr);
-    const uint32_t by_genome = static_cast<uint32_t>((sh.n_genomes + kBlock - 1) / kBlock);
     try_hip(hipMemsetAsync(d_totals, 0, sh.n_genomes * sizeof(unsigned long long), st), KGX_EHIP, "memset(totals)");
+  }
+  if (rc == KGX_OK) {                                       // only over cleared totals
+    const uint32_t by_genome = static_cast<uint32_t>((sh.n_genomes + kBlock - 1) / kBlock);
     hipLaunchKernelGGL(k_row_list_totals, dim3(by_genome, static_cast<uint32_t>((slices + kTotalsSlices - 1) / kTotalsSlices)), dim3(kBlock), 0, st,
                        d_counts, slices, genomes_padded, sh.n_genomes, d_totals);
     hipLaunchKernelGGL(k_row_list_scan, dim3(1), dim3(kBlock), 0, st, d_totals, sh.n_genomes, d_begin);
@@ -466,6 +468,13 @@ kgx_pop* kgx_population_create(uint64_t n_genomes, uint64_t n_variants) {
   const uint64_t n_slots = rt->devs.size();
   const uint64_t units = (n_genomes + 63) / 64, per = units / n_slots, extra = units % n_slots;
   uint64_t base = 0;
+  try {
+    pop->shards.reserve(n_slots);
+  } catch (const std::exception&) {
+    delete pop;
+    fail(KGX_ENOMEM, "host allocation failed");
+    return nullptr;
+  }
   for (uint64_t s = 0; s < n_slots; ++s) {
     kgx_pop_shard sh;
     sh.dev = rt->devs[s].get();
@@ -531,403 +540,463 @@ uint64_t kgx_population_sweep_bytes(const kgx_pop* pop) {
 }
 uint32_t kgx_population_shards(const kgx_pop* pop) { return pop ? static_cast<uint32_t>(pop->shards.size()) : 0; }
 int kgx_population_shard_info(const kgx_pop* pop, uint32_t shard, int* slot, uint64_t* genome_base, uint64_t* n_genomes) {
-  if (int bound = require_bound()) return bound;
-  if (!pop || shard >= pop->shards.size()) return fail(KGX_EINVAL, "no such shard");
-  const auto& sh = pop->shards[shard];
-  if (slot) *slot = sh.dev->slot;
-  if (genome_base) *genome_base = sh.genome_base;
-  if (n_genomes) *n_genomes = sh.n_genomes;
-  return KGX_OK;
+  return guarded([&]() -> int {
+    if (int bound = require_bound()) return bound;
+    if (!pop || shard >= pop->shards.size()) return fail(KGX_EINVAL, "no such shard");
+    const auto& sh = pop->shards[shard];
+    if (slot) *slot = sh.dev->slot;
+    if (genome_base) *genome_base = sh.genome_base;
+    if (n_genomes) *n_genomes = sh.n_genomes;
+    return KGX_OK;
+  });
 }
 
 int kgx_population_load_dosage2(kgx_pop* pop, const uint8_t* src, uint64_t src_pitch, uint64_t v0, uint64_t v1) {
-  if (pop) pop->counts_current = false;
-  if (int bound = require_bound()) return bound;
-  if (!pop || !src) return fail(KGX_EINVAL, "null population or source");
-  if (v0 > v1 || v1 > pop->n_variants) return fail(KGX_EINVAL, "variant range [%llu,%llu) outside [0,%llu)",
-      (unsigned long long)v0, (unsigned long long)v1, (unsigned long long)pop->n_variants);
-  if (src_pitch < (pop->n_genomes + 3) / 4) return fail(KGX_EINVAL, "src_pitch %llu < row bytes %llu",
-      (unsigned long long)src_pitch, (unsigned long long)((pop->n_genomes + 3) / 4));
-  if (v0 == v1) return KGX_OK;
-  for (auto& sh : pop->shards) {
-    if (sh.n_genomes == 0) continue;
-    if (int rc = use_device(*sh.dev)) return rc;
-    // a shard starts on a 64-genome boundary: its bytes of a source row are whole bytes from genome_base / 4 on
-    KGX_HIP(hipMemcpy2DAsync(sh.d_rows + v0 * sh.pitch, sh.pitch, src + sh.genome_base / 4, src_pitch, sh.row_bytes,
-                             v1 - v0, hipMemcpyHostToDevice, sh.dev->stream));
-    const uint64_t touched = (v1 - v0) * (sh.pitch - sh.row_bytes + 1);
-    hipLaunchKernelGGL(k_mask_row_tail, dim3(stream_grid(*sh.dev, touched, kBlock)), dim3(kBlock), 0, sh.dev->stream,
-                       sh.d_rows, sh.pitch, sh.n_genomes, v0, v1);
-    KGX_HIP(hipGetLastError());
-  }
-  return sync_shards(pop);
+  return guarded([&]() -> int {
+    if (pop) pop->counts_current = false;
+    if (int bound = require_bound()) return bound;
+    if (!pop || !src) return fail(KGX_EINVAL, "null population or source");
+    if (v0 > v1 || v1 > pop->n_variants) return fail(KGX_EINVAL, "variant range [%llu,%llu) outside [0,%llu)",
+        (unsigned long long)v0, (unsigned long long)v1, (unsigned long long)pop->n_variants);
+    if (src_pitch < (pop->n_genomes + 3) / 4) return fail(KGX_EINVAL, "src_pitch %llu < row bytes %llu",
+        (unsigned long long)src_pitch, (unsigned long long)((pop->n_genomes + 3) / 4));
+    if (v0 == v1) return KGX_OK;
+    for (auto& sh : pop->shards) {
+      if (sh.n_genomes == 0) continue;
+      if (int rc = use_device(*sh.dev)) return rc;
+      // a shard starts on a 64-genome boundary: its bytes of a source row are whole bytes from genome_base / 4 on
+      KGX_HIP(hipMemcpy2DAsync(sh.d_rows + v0 * sh.pitch, sh.pitch, src + sh.genome_base / 4, src_pitch, sh.row_bytes,
+                               v1 - v0, hipMemcpyHostToDevice, sh.dev->stream));
+      const uint64_t touched = (v1 - v0) * (sh.pitch - sh.row_bytes + 1);
+      hipLaunchKernelGGL(k_mask_row_tail, dim3(stream_grid(*sh.dev, touched, kBlock)), dim3(kBlock), 0, sh.dev->stream,
+                         sh.d_rows, sh.pitch, sh.n_genomes, v0, v1);
+      KGX_HIP(hipGetLastError());
+    }
+    return sync_shards(pop);
+  });
 }
 
 int kgx_population_load_dosage_u8(kgx_pop* pop, const uint8_t* src, uint64_t g0, uint64_t g1) {
-  if (pop) pop->counts_current = false;
-  if (int bound = require_bound()) return bound;
-  if (!pop || !src) return fail(KGX_EINVAL, "null population or source");
-  if (g0 > g1 || g1 > pop->n_genomes) return fail(KGX_EINVAL, "genome range [%llu,%llu) outside [0,%llu)",
-      (unsigned long long)g0, (unsigned long long)g1, (unsigned long long)pop->n_genomes);
-  if (g0 & 3u) return fail(KGX_EINVAL, "g0 must be a multiple of 4 (whole packed bytes)");
-  if ((g1 & 3u) && g1 != pop->n_genomes) return fail(KGX_EINVAL, "g1 must be a multiple of 4 or n_genomes");
-  if (g0 == g1 || pop->n_variants == 0) return KGX_OK;
-  const uint64_t V = pop->n_variants;
-  return for_each_parallel(pop->shards.size(), [&](size_t s) -> int {
-    kgx_pop_shard& sh = pop->shards[s];
-    const uint64_t lo = g0 > sh.genome_base ? g0 : sh.genome_base;
-    const uint64_t hi = g1 < sh.genome_base + sh.n_genomes ? g1 : sh.genome_base + sh.n_genomes;
-    if (lo >= hi) return KGX_OK;
-    if (int rc = use_device(*sh.dev)) return rc;
-    // Stage in slabs of genomes so the staging buffer stays bounded (<= 1 GiB).
-    uint64_t slab = (1ull << 30) / V;
-    slab = slab / 4 * 4;
-    if (slab < 4) slab = 4;
-    uint8_t* d_stage = nullptr;
-    const uint64_t max_rows = (hi - lo) < slab ? (hi - lo) : slab;
-    KGX_HIP_MEM(hipMalloc(&d_stage, max_rows * V));
-    int rc = KGX_OK;
-    for (uint64_t g = lo; g < hi && rc == KGX_OK; g += slab) {
-      const uint64_t n = (hi - g) < slab ? (hi - g) : slab;
-      if (hipMemcpyAsync(d_stage, src + (g - g0) * V, n * V, hipMemcpyHostToDevice, sh.dev->stream) != hipSuccess) {
-        rc = fail(KGX_EHIP, "H2D copy of dosage rows failed");
-        break;
+  return guarded([&]() -> int {
+    if (pop) pop->counts_current = false;
+    if (int bound = require_bound()) return bound;
+    if (!pop || !src) return fail(KGX_EINVAL, "null population or source");
+    if (g0 > g1 || g1 > pop->n_genomes) return fail(KGX_EINVAL, "genome range [%llu,%llu) outside [0,%llu)",
+        (unsigned long long)g0, (unsigned long long)g1, (unsigned long long)pop->n_genomes);
+    if (g0 & 3u) return fail(KGX_EINVAL, "g0 must be a multiple of 4 (whole packed bytes)");
+    if ((g1 & 3u) && g1 != pop->n_genomes) return fail(KGX_EINVAL, "g1 must be a multiple of 4 or n_genomes");
+    if (g0 == g1 || pop->n_variants == 0) return KGX_OK;
+    const uint64_t V = pop->n_variants;
+    return for_each_parallel(pop->shards.size(), [&](size_t s) -> int {
+      kgx_pop_shard& sh = pop->shards[s];
+      const uint64_t lo = g0 > sh.genome_base ? g0 : sh.genome_base;
+      const uint64_t hi = g1 < sh.genome_base + sh.n_genomes ? g1 : sh.genome_base + sh.n_genomes;
+      if (lo >= hi) return KGX_OK;
+      if (int rc = use_device(*sh.dev)) return rc;
+      // Stage in slabs of genomes so the staging buffer stays bounded (<= 1 GiB).
+      uint64_t slab = (1ull << 30) / V;
+      slab = slab / 4 * 4;
+      if (slab < 4) slab = 4;
+      uint8_t* d_stage = nullptr;
+      const uint64_t max_rows = (hi - lo) < slab ? (hi - lo) : slab;
+      KGX_HIP_MEM(hipMalloc(&d_stage, max_rows * V));
+      int rc = KGX_OK;
+      for (uint64_t g = lo; g < hi && rc == KGX_OK; g += slab) {
+        const uint64_t n = (hi - g) < slab ? (hi - g) : slab;
+        if (hipMemcpyAsync(d_stage, src + (g - g0) * V, n * V, hipMemcpyHostToDevice, sh.dev->stream) != hipSuccess) {
+          rc = fail(KGX_EHIP, "H2D copy of dosage rows failed");
+          break;
+        }
+        const uint64_t work = (n + 3) / 4 * V;
+        hipLaunchKernelGGL(k_pack_dosage_u8, dim3(stream_grid(*sh.dev, work, kBlock)), dim3(kBlock), 0, sh.dev->stream,
+                           d_stage, n, V, g - sh.genome_base, sh.d_rows, sh.pitch);
+        if (hipGetLastError() != hipSuccess || hipStreamSynchronize(sh.dev->stream) != hipSuccess)
+          rc = fail(KGX_EHIP, "dosage pack kernel failed");
       }
-      const uint64_t work = (n + 3) / 4 * V;
-      hipLaunchKernelGGL(k_pack_dosage_u8, dim3(stream_grid(*sh.dev, work, kBlock)), dim3(kBlock), 0, sh.dev->stream,
-                         d_stage, n, V, g - sh.genome_base, sh.d_rows, sh.pitch);
-      if (hipGetLastError() != hipSuccess || hipStreamSynchronize(sh.dev->stream) != hipSuccess)
-        rc = fail(KGX_EHIP, "dosage pack kernel failed");
-    }
-    (void)hipFree(d_stage);
-    return rc;
+      (void)hipFree(d_stage);
+      return rc;
+    });
   });
 }
 
 int kgx_population_read_dosage2(const kgx_pop* pop, uint8_t* dst, uint64_t dst_pitch, uint64_t v0, uint64_t v1) {
-  if (int bound = require_bound()) return bound;
-  if (!pop || !dst) return fail(KGX_EINVAL, "null population or destination");
-  if (v0 > v1 || v1 > pop->n_variants) return fail(KGX_EINVAL, "variant range out of bounds");
-  if (dst_pitch < (pop->n_genomes + 3) / 4) return fail(KGX_EINVAL, "dst_pitch too small");
-  if (v0 == v1) return KGX_OK;
-  for (const auto& sh : pop->shards) {
-    if (sh.n_genomes == 0) continue;
-    if (int rc = use_device(*sh.dev)) return rc;
-    KGX_HIP(hipMemcpy2DAsync(dst + sh.genome_base / 4, dst_pitch, sh.d_rows + v0 * sh.pitch, sh.pitch, sh.row_bytes,
-                             v1 - v0, hipMemcpyDeviceToHost, sh.dev->stream));
-  }
-  return sync_shards(pop);
+  return guarded([&]() -> int {
+    if (int bound = require_bound()) return bound;
+    if (!pop || !dst) return fail(KGX_EINVAL, "null population or destination");
+    if (v0 > v1 || v1 > pop->n_variants) return fail(KGX_EINVAL, "variant range out of bounds");
+    if (dst_pitch < (pop->n_genomes + 3) / 4) return fail(KGX_EINVAL, "dst_pitch too small");
+    if (v0 == v1) return KGX_OK;
+    for (const auto& sh : pop->shards) {
+      if (sh.n_genomes == 0) continue;
+      if (int rc = use_device(*sh.dev)) return rc;
+      KGX_HIP(hipMemcpy2DAsync(dst + sh.genome_base / 4, dst_pitch, sh.d_rows + v0 * sh.pitch, sh.pitch, sh.row_bytes,
+                               v1 - v0, hipMemcpyDeviceToHost, sh.dev->stream));
+    }
+    return sync_shards(pop);
+  });
 }
 
 int kgx_population_resize(kgx_pop* pop, uint64_t n_variants) {
-  if (pop) pop->counts_current = false;
-  if (int bound = require_bound()) return bound;
-  if (!pop) return fail(KGX_EINVAL, "null population");
-  for (auto& sh : pop->shards) {
-    if (int rc = use_device(*sh.dev)) return rc;
-    if (n_variants > sh.capacity) {
-      // grow by at least half, so that a population filled piece by piece is copied a bounded number of times
-      uint64_t capacity = sh.capacity + sh.capacity / 2;
-      if (capacity < n_variants) capacity = n_variants;
-      uint8_t* grown = nullptr;
-      if (sh.pitch * capacity) {
-        if (hipMalloc(&grown, sh.pitch * capacity) != hipSuccess) {
-          (void)hipGetLastError();
-          return fail(KGX_ENOMEM, "hipMalloc of %llu bytes for %llu dosage rows on device %d failed", (unsigned long long)(sh.pitch * capacity),
+  return guarded([&]() -> int {
+    if (pop) pop->counts_current = false;
+    if (int bound = require_bound()) return bound;
+    if (!pop) return fail(KGX_EINVAL, "null population");
+    // Two phases, so that a failure leaves every shard as it was: first every allocation, copy and fill that can fail
+    // (into blocks the shards do not own yet), then the pointers and the row count of all shards together.
+    struct Grown { uint8_t* block = nullptr; uint64_t capacity = 0; };
+    std::vector<Grown> grown(pop->shards.size());
+    int rc = KGX_OK;
+    for (size_t s = 0; s < pop->shards.size() && rc == KGX_OK; ++s) {
+      kgx_pop_shard& sh = pop->shards[s];
+      if ((rc = use_device(*sh.dev)) != KGX_OK) break;
+      if (n_variants > sh.capacity) {
+        // grow by at least half, so that a population filled piece by piece is copied a bounded number of times
+        uint64_t capacity = sh.capacity + sh.capacity / 2;
+        if (capacity < n_variants) capacity = n_variants;
+        grown[s].capacity = capacity;
+        if (sh.pitch * capacity) {
+          if (hipMalloc(&grown[s].block, sh.pitch * capacity) != hipSuccess) {
+            (void)hipGetLastError();
+            grown[s].block = nullptr;
+            rc = fail(KGX_ENOMEM, "hipMalloc of %llu bytes for %llu dosage rows on device %d failed", (unsigned long long)(sh.pitch * capacity),
                       (unsigned long long)capacity, sh.dev->id);
+            break;
+          }
+          const uint64_t held = sh.pitch * sh.n_variants;            // the rows in use; what a shrink left behind them is not carried over
+          if ((held && hipMemcpyAsync(grown[s].block, sh.d_rows, held, hipMemcpyDeviceToDevice, sh.dev->stream) != hipSuccess) ||
+              hipMemsetAsync(grown[s].block + held, 0, sh.pitch * capacity - held, sh.dev->stream) != hipSuccess ||
+              hipStreamSynchronize(sh.dev->stream) != hipSuccess) {
+            (void)hipGetLastError();
+            rc = fail(KGX_EHIP, "copying the dosage rows into the grown allocation failed");
+          }
         }
-        const uint64_t held = sh.pitch * sh.n_variants;            // the rows in use; what a shrink left behind them is not carried over
-        if ((held && hipMemcpyAsync(grown, sh.d_rows, held, hipMemcpyDeviceToDevice, sh.dev->stream) != hipSuccess) ||
-            hipMemsetAsync(grown + held, 0, sh.pitch * capacity - held, sh.dev->stream) != hipSuccess ||
+      } else if (n_variants > sh.n_variants && sh.pitch) {
+        // within the allocation: rows a shrink left behind must read as empty again (rows past n_variants: nobody reads them yet)
+        if (hipMemsetAsync(sh.d_rows + sh.pitch * sh.n_variants, 0, sh.pitch * (n_variants - sh.n_variants), sh.dev->stream) != hipSuccess ||
             hipStreamSynchronize(sh.dev->stream) != hipSuccess) {
           (void)hipGetLastError();
-          (void)hipFree(grown);
-          return fail(KGX_EHIP, "copying the dosage rows into the grown allocation failed");
+          rc = fail(KGX_EHIP, "clearing the rows behind the population failed");
         }
       }
-      if (sh.d_alloc) (void)hipFree(sh.d_alloc);
-      sh.d_alloc = sh.d_rows = grown;
-      sh.capacity = capacity;
-    } else if (n_variants > sh.n_variants && sh.pitch) {
-      // within the allocation: rows a shrink left behind must read as empty again
-      KGX_HIP(hipMemsetAsync(sh.d_rows + sh.pitch * sh.n_variants, 0, sh.pitch * (n_variants - sh.n_variants), sh.dev->stream));
-      KGX_HIP(hipStreamSynchronize(sh.dev->stream));
     }
-    if (n_variants != sh.n_variants) {                       // the per-variant columns follow the row count: re-created on demand
-      if (sh.d_af) { (void)hipFree(sh.d_af); sh.d_af = nullptr; }
-      if (sh.d_counts) { (void)hipFree(sh.d_counts); sh.d_counts = nullptr; }
+    if (rc != KGX_OK) {
+      for (size_t s = 0; s < pop->shards.size(); ++s)
+        if (grown[s].block && use_device(*pop->shards[s].dev) == KGX_OK) (void)hipFree(grown[s].block);
+      (void)use_device(*pop->shards[0].dev);
+      return rc;
     }
-    sh.n_variants = n_variants;
-  }
-  if (n_variants != pop->n_variants) pop->has_af = false;
-  pop->n_variants = n_variants;
-  return use_device(*pop->shards[0].dev);
+    for (size_t s = 0; s < pop->shards.size(); ++s) {
+      kgx_pop_shard& sh = pop->shards[s];
+      (void)use_device(*sh.dev);
+      if (grown[s].capacity) {
+        if (sh.d_alloc) (void)hipFree(sh.d_alloc);
+        sh.d_alloc = sh.d_rows = grown[s].block;
+        sh.capacity = grown[s].capacity;
+      }
+      if (n_variants != sh.n_variants) {                       // the per-variant columns follow the row count: re-created on demand
+        if (sh.d_af) { (void)hipFree(sh.d_af); sh.d_af = nullptr; }
+        if (sh.d_counts) { (void)hipFree(sh.d_counts); sh.d_counts = nullptr; }
+      }
+      sh.n_variants = n_variants;
+    }
+    if (n_variants != pop->n_variants) pop->has_af = false;
+    pop->n_variants = n_variants;
+    return use_device(*pop->shards[0].dev);
+  });
 }
 
 int kgx_population_set_genome_mask(kgx_pop* pop, const uint8_t* keep) {
-  if (int bound = require_bound()) return bound;
-  if (!pop) return fail(KGX_EINVAL, "null population");
-  pop->counts_current = false;
-  if (!keep) {
-    pop->keep.clear();
-    for (auto& sh : pop->shards) {
-      if (sh.d_keep) {
-        if (int rc = use_device(*sh.dev)) return rc;
-        KGX_HIP(hipStreamSynchronize(sh.dev->stream));
-        (void)hipFree(sh.d_keep);
-        sh.d_keep = nullptr;
+  return guarded([&]() -> int {
+    if (int bound = require_bound()) return bound;
+    if (!pop) return fail(KGX_EINVAL, "null population");
+    pop->counts_current = false;
+    if (!keep) {
+      pop->keep.clear();
+      for (auto& sh : pop->shards) {
+        if (sh.d_keep) {
+          if (int rc = use_device(*sh.dev)) return rc;
+          KGX_HIP(hipStreamSynchronize(sh.dev->stream));
+          (void)hipFree(sh.d_keep);
+          sh.d_keep = nullptr;
+        }
+        sh.n_kept = sh.n_genomes;
       }
-      sh.n_kept = sh.n_genomes;
+      return use_device(*pop->shards[0].dev);
+    }
+    pop->keep.assign(keep, keep + pop->n_genomes);
+    for (auto& sh : pop->shards) {
+      if (sh.n_genomes == 0) continue;
+      if (int rc = use_device(*sh.dev)) return rc;
+      std::vector<uint8_t> row(sh.pitch, 0);
+      sh.n_kept = 0;
+      for (uint64_t g = 0; g < sh.n_genomes; ++g)
+        if (keep[sh.genome_base + g]) {
+          row[g >> 2] |= static_cast<uint8_t>(3u << (2 * (g & 3u)));
+          ++sh.n_kept;
+        }
+      if (!sh.d_keep) KGX_HIP_MEM(hipMalloc(&sh.d_keep, sh.pitch));
+      KGX_HIP(hipMemcpyAsync(sh.d_keep, row.data(), sh.pitch, hipMemcpyHostToDevice, sh.dev->stream));
+      KGX_HIP(hipStreamSynchronize(sh.dev->stream));             // `row` is pageable host memory
     }
     return use_device(*pop->shards[0].dev);
-  }
-  pop->keep.assign(keep, keep + pop->n_genomes);
-  for (auto& sh : pop->shards) {
-    if (sh.n_genomes == 0) continue;
-    if (int rc = use_device(*sh.dev)) return rc;
-    std::vector<uint8_t> row(sh.pitch, 0);
-    sh.n_kept = 0;
-    for (uint64_t g = 0; g < sh.n_genomes; ++g)
-      if (keep[sh.genome_base + g]) {
-        row[g >> 2] |= static_cast<uint8_t>(3u << (2 * (g & 3u)));
-        ++sh.n_kept;
-      }
-    if (!sh.d_keep) KGX_HIP_MEM(hipMalloc(&sh.d_keep, sh.pitch));
-    KGX_HIP(hipMemcpyAsync(sh.d_keep, row.data(), sh.pitch, hipMemcpyHostToDevice, sh.dev->stream));
-    KGX_HIP(hipStreamSynchronize(sh.dev->stream));             // `row` is pageable host memory
-  }
-  return use_device(*pop->shards[0].dev);
+  });
 }
 
 int kgx_population_set_af(kgx_pop* pop, const float* af) {
-  if (int bound = require_bound()) return bound;
-  if (!pop || !af) return fail(KGX_EINVAL, "null population or af");
-  for (auto& sh : pop->shards) {                         // per-variant columns are replicated on every shard
-    if (int rc = ensure_af(sh)) return rc;
-    if (pop->n_variants) {
-      if (int rc = use_device(*sh.dev)) return rc;
-      KGX_HIP(hipMemcpyAsync(sh.d_af, af, pop->n_variants * sizeof(float), hipMemcpyHostToDevice, sh.dev->stream));
+  return guarded([&]() -> int {
+    if (int bound = require_bound()) return bound;
+    if (!pop || !af) return fail(KGX_EINVAL, "null population or af");
+    for (auto& sh : pop->shards) {                         // per-variant columns are replicated on every shard
+      if (int rc = ensure_af(sh)) return rc;
+      if (pop->n_variants) {
+        if (int rc = use_device(*sh.dev)) return rc;
+        KGX_HIP(hipMemcpyAsync(sh.d_af, af, pop->n_variants * sizeof(float), hipMemcpyHostToDevice, sh.dev->stream));
+      }
     }
-  }
-  if (int rc = sync_shards(pop)) return rc;
-  pop->has_af = true;
-  return KGX_OK;
+    if (int rc = sync_shards(pop)) return rc;
+    pop->has_af = true;
+    return KGX_OK;
+  });
 }
 
 int kgx_population_get_af(const kgx_pop* pop, float* af) {
-  if (int bound = require_bound()) return bound;
-  if (!pop || !af) return fail(KGX_EINVAL, "null population or af");
-  if (!pop->has_af) return fail(KGX_ESTATE, "allele frequencies were never set");
-  if (pop->n_variants) {
-    const auto& sh = pop->shards[0];
-    if (int rc = use_device(*sh.dev)) return rc;
-    KGX_HIP(hipMemcpyAsync(af, sh.d_af, pop->n_variants * sizeof(float), hipMemcpyDeviceToHost, sh.dev->stream));
-    KGX_HIP(hipStreamSynchronize(sh.dev->stream));
-  }
-  return KGX_OK;
+  return guarded([&]() -> int {
+    if (int bound = require_bound()) return bound;
+    if (!pop || !af) return fail(KGX_EINVAL, "null population or af");
+    if (!pop->has_af) return fail(KGX_ESTATE, "allele frequencies were never set");
+    if (pop->n_variants) {
+      const auto& sh = pop->shards[0];
+      if (int rc = use_device(*sh.dev)) return rc;
+      KGX_HIP(hipMemcpyAsync(af, sh.d_af, pop->n_variants * sizeof(float), hipMemcpyDeviceToHost, sh.dev->stream));
+      KGX_HIP(hipStreamSynchronize(sh.dev->stream));
+    }
+    return KGX_OK;
+  });
 }
 
 int kgx_population_synth_biallelic(kgx_pop* pop, uint64_t seed, uint64_t genome_base, uint64_t variant_base) {
-  if (pop) pop->counts_current = false;
-  if (int bound = require_bound()) return bound;
-  if (!pop) return fail(KGX_EINVAL, "null population");
-  for (auto& sh : pop->shards) {
-    if (int rc = ensure_af(sh)) return rc;
-    if (pop->n_variants == 0) continue;
-    if (int rc = use_device(*sh.dev)) return rc;
-    // a slot beyond the data still gets the allele-frequency column: one chunk per row writes it
-    const uint64_t chunks = pop->n_variants * (sh.chunks_per_row ? sh.chunks_per_row : 1);
-    if (sh.chunks_per_row == 0) {
-      std::vector<float> af(pop->n_variants);
-      for (uint64_t v = 0; v < pop->n_variants; ++v) af[v] = kgx_synth_af(seed, variant_base + v);
-      KGX_HIP(hipMemcpyAsync(sh.d_af, af.data(), af.size() * sizeof(float), hipMemcpyHostToDevice, sh.dev->stream));
-      KGX_HIP(hipStreamSynchronize(sh.dev->stream));
-      continue;
+  return guarded([&]() -> int {
+    if (pop) pop->counts_current = false;
+    if (int bound = require_bound()) return bound;
+    if (!pop) return fail(KGX_EINVAL, "null population");
+    for (auto& sh : pop->shards) {
+      if (int rc = ensure_af(sh)) return rc;
+      if (pop->n_variants == 0) continue;
+      if (int rc = use_device(*sh.dev)) return rc;
+      // a slot beyond the data still gets the allele-frequency column: one chunk per row writes it
+      const uint64_t chunks = pop->n_variants * (sh.chunks_per_row ? sh.chunks_per_row : 1);
+      if (sh.chunks_per_row == 0) {
+        std::vector<float> af(pop->n_variants);
+        for (uint64_t v = 0; v < pop->n_variants; ++v) af[v] = kgx_synth_af(seed, variant_base + v);
+        KGX_HIP(hipMemcpyAsync(sh.d_af, af.data(), af.size() * sizeof(float), hipMemcpyHostToDevice, sh.dev->stream));
+        KGX_HIP(hipStreamSynchronize(sh.dev->stream));
+        continue;
+      }
+      hipLaunchKernelGGL(k_synth_biallelic, dim3(stream_grid(*sh.dev, chunks, kBlock)), dim3(kBlock), 0, sh.dev->stream,
+                         reinterpret_cast<kgx_v4u*>(sh.d_rows), sh.chunks_per_row, pop->n_variants,
+                         sh.n_genomes, seed, genome_base + sh.genome_base, variant_base, sh.d_af);
+      KGX_HIP(hipGetLastError());
     }
-    hipLaunchKernelGGL(k_synth_biallelic, dim3(stream_grid(*sh.dev, chunks, kBlock)), dim3(kBlock), 0, sh.dev->stream,
-                       reinterpret_cast<kgx_v4u*>(sh.d_rows), sh.chunks_per_row, pop->n_variants,
-                       sh.n_genomes, seed, genome_base + sh.genome_base, variant_base, sh.d_af);
-    KGX_HIP(hipGetLastError());
-  }
-  if (int rc = sync_shards(pop)) return rc;
-  pop->has_af = true;
-  return KGX_OK;
+    if (int rc = sync_shards(pop)) return rc;
+    pop->has_af = true;
+    return KGX_OK;
+  });
 }
 
 int kgx_synth_biallelic_host(uint64_t seed, uint64_t genome_base, uint64_t n_genomes, uint64_t v0,
                              uint64_t v1, uint8_t* dst, uint64_t dst_pitch, float* af_out) {
-  if (!dst) return fail(KGX_EINVAL, "null destination");
-  const uint64_t row_bytes = (n_genomes + 3) / 4;
-  if (v0 > v1 || dst_pitch < row_bytes) return fail(KGX_EINVAL, "bad range or pitch");
-  for (uint64_t v = v0; v < v1; ++v) {
-    const float af = kgx_synth_af(seed, v);
-    if (af_out) af_out[v - v0] = af;
-    const double p = static_cast<double>(af);
-    uint8_t* row = dst + (v - v0) * dst_pitch;
-    std::memset(row, 0, dst_pitch);
-    for (uint64_t g = 0; g < n_genomes; ++g)
-      row[g >> 2] |= static_cast<uint8_t>(kgx_synth_dosage(seed, v, genome_base + g, p) << (2 * (g & 3u)));
-  }
-  return KGX_OK;
+  return guarded([&]() -> int {
+    if (!dst) return fail(KGX_EINVAL, "null destination");
+    const uint64_t row_bytes = (n_genomes + 3) / 4;
+    if (v0 > v1 || dst_pitch < row_bytes) return fail(KGX_EINVAL, "bad range or pitch");
+    for (uint64_t v = v0; v < v1; ++v) {
+      const float af = kgx_synth_af(seed, v);
+      if (af_out) af_out[v - v0] = af;
+      const double p = static_cast<double>(af);
+      uint8_t* row = dst + (v - v0) * dst_pitch;
+      std::memset(row, 0, dst_pitch);
+      for (uint64_t g = 0; g < n_genomes; ++g)
+        row[g >> 2] |= static_cast<uint8_t>(kgx_synth_dosage(seed, v, genome_base + g, p) << (2 * (g & 3u)));
+    }
+    return KGX_OK;
+  });
 }
 
 int kgx_allele_count_by_locus_dev(kgx_pop* pop, void* d_out, void* stream) {
-  if (int bound = require_bound()) return bound;
-  if (!pop || !d_out) return fail(KGX_EINVAL, "null population or output");
-  if (pop->n_variants == 0) return KGX_OK;
-  return sweep_and_exchange(pop, d_out, static_cast<hipStream_t>(stream), false);
+  return guarded([&]() -> int {
+    if (int bound = require_bound()) return bound;
+    if (!pop || !d_out) return fail(KGX_EINVAL, "null population or output");
+    if (pop->n_variants == 0) return KGX_OK;
+    return sweep_and_exchange(pop, d_out, static_cast<hipStream_t>(stream), false);
+  });
 }
 
 int kgx_allele_count_by_locus(kgx_pop* pop, uint32_t* out) {
-  if (int bound = require_bound()) return bound;
-  if (!pop || !out) return fail(KGX_EINVAL, "null population or output");
-  if (pop->n_variants == 0) return KGX_OK;
-  if (int rc = sweep_and_exchange(pop, nullptr, nullptr, true)) return rc;
-  kgx_pop_shard& sh = pop->shards[0];
-  KGX_HIP(hipMemcpyAsync(out, sh.d_counts, pop->n_variants * 16u, hipMemcpyDeviceToHost, sh.dev->stream));
-  const int rc = sync_shards(pop);
-  pop->counts_current = rc == KGX_OK;      // every shard's d_counts now holds the population's counts
-  return rc;
+  return guarded([&]() -> int {
+    if (int bound = require_bound()) return bound;
+    if (!pop || !out) return fail(KGX_EINVAL, "null population or output");
+    if (pop->n_variants == 0) return KGX_OK;
+    if (int rc = sweep_and_exchange(pop, nullptr, nullptr, true)) return rc;
+    kgx_pop_shard& sh = pop->shards[0];
+    KGX_HIP(hipMemcpyAsync(out, sh.d_counts, pop->n_variants * 16u, hipMemcpyDeviceToHost, sh.dev->stream));
+    const int rc = sync_shards(pop);
+    pop->counts_current = rc == KGX_OK;      // every shard's d_counts now holds the population's counts
+    return rc;
+  });
 }
 
 int kgx_allele_frequency_dev(const void* d_counts, uint64_t n_variants, uint64_t total_genomes, void* d_af, void* stream) {
-  std::shared_ptr<Runtime> rt;
-  if (int rc = require_runtime(rt)) return rc;
-  if (!d_counts || !d_af) return fail(KGX_EINVAL, "null device pointer");
-  if (total_genomes == 0) return fail(KGX_EINVAL, "total_genomes must be > 0");
-  if (n_variants == 0) return KGX_OK;
-  // the buffers say which device this runs on (a caller's tensors on the first slot's device, normally)
-  hipPointerAttribute_t attr;
-  const Device* dev = rt->devs[0].get();
-  if (hipPointerGetAttributes(&attr, d_counts) == hipSuccess) {
-    for (const auto& d : rt->devs)
-      if (d->id == attr.device) { dev = d.get(); break; }
-  } else {
-    (void)hipGetLastError();
-  }
-  if (int rc = use_device(*dev)) return rc;
-  hipStream_t s = static_cast<hipStream_t>(stream);
-  hipLaunchKernelGGL(k_allele_frequency, dim3(stream_grid(*dev, n_variants, kBlock)), dim3(kBlock), 0, s,
-                     static_cast<const kgx_v4u*>(d_counts), n_variants, total_genomes, static_cast<double*>(d_af));
-  KGX_HIP(hipGetLastError());
-  return KGX_OK;
+  return guarded([&]() -> int {
+    std::shared_ptr<Runtime> rt;
+    if (int rc = require_runtime(rt)) return rc;
+    if (!d_counts || !d_af) return fail(KGX_EINVAL, "null device pointer");
+    if (total_genomes == 0) return fail(KGX_EINVAL, "total_genomes must be > 0");
+    if (n_variants == 0) return KGX_OK;
+    // the buffers say which device this runs on (a caller's tensors on the first slot's device, normally)
+    hipPointerAttribute_t attr;
+    const Device* dev = rt->devs[0].get();
+    if (hipPointerGetAttributes(&attr, d_counts) == hipSuccess) {
+      for (const auto& d : rt->devs)
+        if (d->id == attr.device) { dev = d.get(); break; }
+    } else {
+      (void)hipGetLastError();
+    }
+    if (int rc = use_device(*dev)) return rc;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    hipLaunchKernelGGL(k_allele_frequency, dim3(stream_grid(*dev, n_variants, kBlock)), dim3(kBlock), 0, s,
+                       static_cast<const kgx_v4u*>(d_counts), n_variants, total_genomes, static_cast<double*>(d_af));
+    KGX_HIP(hipGetLastError());
+    return KGX_OK;
+  });
 }
 
 int kgx_allele_count_timed(kgx_pop* pop, void* d_out, void* stream, int warmup, int iters, float* ms_each) {
-  if (int bound = require_bound()) return bound;
-  if (!pop || !d_out || !ms_each || iters <= 0 || warmup < 0) return fail(KGX_EINVAL, "bad arguments");
-  const size_t n = pop->shards.size();
-  std::vector<void*> buffers(n);
-  std::vector<hipStream_t> streams(n);
-  for (size_t s = 0; s < n; ++s) {
-    kgx_pop_shard& sh = pop->shards[s];
-    if (s == 0) { buffers[s] = d_out; streams[s] = static_cast<hipStream_t>(stream); continue; }
-    if (int rc = ensure_counts(sh)) return rc;
-    buffers[s] = sh.d_counts;
-    streams[s] = sh.dev->stream;
-  }
-  for (int i = 0; i < warmup; ++i)
-    for (size_t s = 0; s < n; ++s)
-      if (int rc = launch_allele_count(pop->shards[s], buffers[s], streams[s])) return rc;
-  std::vector<hipEvent_t> ev(2 * static_cast<size_t>(iters) * n, nullptr);
-  int rc = KGX_OK;
-  for (size_t s = 0; s < n && rc == KGX_OK; ++s) {
-    rc = use_device(*pop->shards[s].dev);
-    for (int i = 0; i < 2 * iters && rc == KGX_OK; ++i)
-      if (hipEventCreate(&ev[s * 2 * iters + i]) != hipSuccess) rc = fail(KGX_EHIP, "hipEventCreate failed");
-  }
-  for (int i = 0; i < iters && rc == KGX_OK; ++i)
+  return guarded([&]() -> int {
+    if (int bound = require_bound()) return bound;
+    if (!pop || !d_out || !ms_each || iters <= 0 || warmup < 0) return fail(KGX_EINVAL, "bad arguments");
+    pop->counts_current = false;             // the shards' d_counts take LOCAL counts below (no exchange)
+    const size_t n = pop->shards.size();
+    std::vector<void*> buffers(n);
+    std::vector<hipStream_t> streams(n);
+    for (size_t s = 0; s < n; ++s) {
+      kgx_pop_shard& sh = pop->shards[s];
+      if (s == 0) { buffers[s] = d_out; streams[s] = static_cast<hipStream_t>(stream); continue; }
+      if (int rc = ensure_counts(sh)) return rc;
+      buffers[s] = sh.d_counts;
+      streams[s] = sh.dev->stream;
+    }
+    for (int i = 0; i < warmup; ++i)
+      for (size_t s = 0; s < n; ++s)
+        if (int rc = launch_allele_count(pop->shards[s], buffers[s], streams[s])) return rc;
+    std::vector<hipEvent_t> ev(2 * static_cast<size_t>(iters) * n, nullptr);
+    int rc = KGX_OK;
     for (size_t s = 0; s < n && rc == KGX_OK; ++s) {
       rc = use_device(*pop->shards[s].dev);
-      hipEvent_t* e = &ev[s * 2 * iters + 2 * i];
-      if (rc == KGX_OK && hipEventRecord(e[0], streams[s]) != hipSuccess) rc = fail(KGX_EHIP, "hipEventRecord failed");
-      if (rc == KGX_OK) rc = launch_allele_count(pop->shards[s], buffers[s], streams[s]);
-      if (rc == KGX_OK && hipEventRecord(e[1], streams[s]) != hipSuccess) rc = fail(KGX_EHIP, "hipEventRecord failed");
+      for (int i = 0; i < 2 * iters && rc == KGX_OK; ++i)
+        if (hipEventCreate(&ev[s * 2 * iters + i]) != hipSuccess) rc = fail(KGX_EHIP, "hipEventCreate failed");
     }
-  for (size_t s = 0; s < n && rc == KGX_OK; ++s) {
-    rc = use_device(*pop->shards[s].dev);
-    if (rc == KGX_OK && hipStreamSynchronize(streams[s]) != hipSuccess) rc = fail(KGX_EHIP, "stream synchronize failed");
-  }
-  for (int i = 0; i < iters && rc == KGX_OK; ++i) {
-    float worst = 0.f;
+    for (int i = 0; i < iters && rc == KGX_OK; ++i)
+      for (size_t s = 0; s < n && rc == KGX_OK; ++s) {
+        rc = use_device(*pop->shards[s].dev);
+        hipEvent_t* e = &ev[s * 2 * iters + 2 * i];
+        if (rc == KGX_OK && hipEventRecord(e[0], streams[s]) != hipSuccess) rc = fail(KGX_EHIP, "hipEventRecord failed");
+        if (rc == KGX_OK) rc = launch_allele_count(pop->shards[s], buffers[s], streams[s]);
+        if (rc == KGX_OK && hipEventRecord(e[1], streams[s]) != hipSuccess) rc = fail(KGX_EHIP, "hipEventRecord failed");
+      }
     for (size_t s = 0; s < n && rc == KGX_OK; ++s) {
-      float ms = 0.f;
-      if (hipEventElapsedTime(&ms, ev[s * 2 * iters + 2 * i], ev[s * 2 * iters + 2 * i + 1]) != hipSuccess)
-        rc = fail(KGX_EHIP, "hipEventElapsedTime failed");
-      worst = ms > worst ? ms : worst;
+      rc = use_device(*pop->shards[s].dev);
+      if (rc == KGX_OK && hipStreamSynchronize(streams[s]) != hipSuccess) rc = fail(KGX_EHIP, "stream synchronize failed");
     }
-    ms_each[i] = worst;
-  }
-  for (auto& e : ev)
-    if (e) (void)hipEventDestroy(e);
-  (void)use_device(*pop->shards[0].dev);
-  return rc;
+    for (int i = 0; i < iters && rc == KGX_OK; ++i) {
+      float worst = 0.f;
+      for (size_t s = 0; s < n && rc == KGX_OK; ++s) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, ev[s * 2 * iters + 2 * i], ev[s * 2 * iters + 2 * i + 1]) != hipSuccess)
+          rc = fail(KGX_EHIP, "hipEventElapsedTime failed");
+        worst = ms > worst ? ms : worst;
+      }
+      ms_each[i] = worst;
+    }
+    for (auto& e : ev)
+      if (e) (void)hipEventDestroy(e);
+    (void)use_device(*pop->shards[0].dev);
+    return rc;
+  });
 }
 
 int kgx_population_summary(kgx_pop* pop, uint64_t out[4]) {
-  if (int bound = require_bound()) return bound;
-  if (!pop || !out) return fail(KGX_EINVAL, "null population or output");
-  out[0] = out[1] = out[2] = out[3] = 0;
-  if (pop->n_variants == 0) return KGX_OK;
-  std::vector<unsigned long long> totals(pop->shards.size() * 4, 0);
-  const int rc = for_each_parallel(pop->shards.size(), [&](size_t s) -> int {
-    kgx_pop_shard& sh = pop->shards[s];
-    if (sh.n_genomes == 0) return KGX_OK;
-    if (int e = ensure_counts(sh)) return e;
-    if (int e = launch_allele_count(sh, sh.d_counts, sh.dev->stream)) return e;
-    unsigned long long* d_total = nullptr;
-    KGX_HIP_MEM(hipMalloc(&d_total, 4 * sizeof(unsigned long long)));
-    int r = KGX_OK;
-    if (hipMemsetAsync(d_total, 0, 4 * sizeof(unsigned long long), sh.dev->stream) != hipSuccess) r = fail(KGX_EHIP, "memset failed");
-    if (r == KGX_OK) {
-      hipLaunchKernelGGL(k_sum_counts, dim3(stream_grid(*sh.dev, sh.n_variants, kBlock)), dim3(kBlock), 0, sh.dev->stream,
-                         static_cast<const kgx_v4u*>(sh.d_counts), sh.n_variants, d_total);
-      if (hipGetLastError() != hipSuccess ||
-          hipMemcpyAsync(&totals[s * 4], d_total, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost, sh.dev->stream) != hipSuccess ||
-          hipStreamSynchronize(sh.dev->stream) != hipSuccess)
-        r = fail(KGX_EHIP, "population summary reduction failed");
-    }
-    (void)hipFree(d_total);
-    return r;
+  return guarded([&]() -> int {
+    if (int bound = require_bound()) return bound;
+    if (!pop || !out) return fail(KGX_EINVAL, "null population or output");
+    out[0] = out[1] = out[2] = out[3] = 0;
+    if (pop->n_variants == 0) return KGX_OK;
+    pop->counts_current = false;             // every shard's d_counts takes its LOCAL counts below: k_drop_absent_rows must not read them
+    std::vector<unsigned long long> totals(pop->shards.size() * 4, 0);
+    const int rc = for_each_parallel(pop->shards.size(), [&](size_t s) -> int {
+      kgx_pop_shard& sh = pop->shards[s];
+      if (sh.n_genomes == 0) return KGX_OK;
+      if (int e = ensure_counts(sh)) return e;
+      if (int e = launch_allele_count(sh, sh.d_counts, sh.dev->stream)) return e;
+      unsigned long long* d_total = nullptr;
+      KGX_HIP_MEM(hipMalloc(&d_total, 4 * sizeof(unsigned long long)));
+      int r = KGX_OK;
+      if (hipMemsetAsync(d_total, 0, 4 * sizeof(unsigned long long), sh.dev->stream) != hipSuccess) r = fail(KGX_EHIP, "memset failed");
+      if (r == KGX_OK) {
+        hipLaunchKernelGGL(k_sum_counts, dim3(stream_grid(*sh.dev, sh.n_variants, kBlock)), dim3(kBlock), 0, sh.dev->stream,
+                           static_cast<const kgx_v4u*>(sh.d_counts), sh.n_variants, d_total);
+        if (hipGetLastError() != hipSuccess ||
+            hipMemcpyAsync(&totals[s * 4], d_total, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost, sh.dev->stream) != hipSuccess ||
+            hipStreamSynchronize(sh.dev->stream) != hipSuccess)
+          r = fail(KGX_EHIP, "population summary reduction failed");
+      }
+      (void)hipFree(d_total);
+      return r;
+    });
+    if (rc != KGX_OK) return rc;
+    for (size_t s = 0; s < pop->shards.size(); ++s)
+      for (int j = 0; j < 4; ++j) out[j] += totals[s * 4 + j];
+    return use_device(*pop->shards[0].dev);
   });
-  if (rc != KGX_OK) return rc;
-  for (size_t s = 0; s < pop->shards.size(); ++s)
-    for (int j = 0; j < 4; ++j) out[j] += totals[s * 4 + j];
-  return use_device(*pop->shards[0].dev);
 }
 
 int kgx_count_by_genome(kgx_pop* pop, const uint8_t* variant_mask, uint64_t* out) {
-  if (int bound = require_bound()) return bound;
-  if (!pop || !out) return fail(KGX_EINVAL, "null population or output");
-  int rc;
-  if (!variant_mask) {
-    rc = count_by_genome_impl(pop, nullptr, 1, out);
-  } else {
-    std::vector<uint8_t> bins(pop->n_variants);
-    for (uint64_t v = 0; v < pop->n_variants; ++v) bins[v] = variant_mask[v] ? 0 : 0xFF;
-    rc = count_by_genome_impl(pop, bins.data(), 1, out);
-  }
-  (void)use_device(*pop->shards[0].dev);
-  return rc;
+  return guarded([&]() -> int {
+    if (int bound = require_bound()) return bound;
+    if (!pop || !out) return fail(KGX_EINVAL, "null population or output");
+    int rc;
+    if (!variant_mask) {
+      rc = count_by_genome_impl(pop, nullptr, 1, out);
+    } else {
+      std::vector<uint8_t> bins(pop->n_variants);
+      for (uint64_t v = 0; v < pop->n_variants; ++v) bins[v] = variant_mask[v] ? 0 : 0xFF;
+      rc = count_by_genome_impl(pop, bins.data(), 1, out);
+    }
+    (void)use_device(*pop->shards[0].dev);
+    return rc;
+  });
 }
 
 int kgx_count_by_genome_binned(kgx_pop* pop, const uint8_t* bin_of_variant, uint32_t n_bins, uint64_t* out) {
-  if (int bound = require_bound()) return bound;
-  if (!pop || !out || !bin_of_variant) return fail(KGX_EINVAL, "null population, bins or output");
-  if (n_bins == 0 || n_bins > 254) return fail(KGX_EINVAL, "n_bins %u outside [1,254]", n_bins);
-  const int rc = count_by_genome_impl(pop, bin_of_variant, n_bins, out);
-  (void)use_device(*pop->shards[0].dev);
-  return rc;
+  return guarded([&]() -> int {
+    if (int bound = require_bound()) return bound;
+    if (!pop || !out || !bin_of_variant) return fail(KGX_EINVAL, "null population, bins or output");
+    if (n_bins == 0 || n_bins > 254) return fail(KGX_EINVAL, "n_bins %u outside [1,254]", n_bins);
+    const int rc = count_by_genome_impl(pop, bin_of_variant, n_bins, out);
+    (void)use_device(*pop->shards[0].dev);
+    return rc;
+  });
 }
 
 int kgx_count_by_genome_af_bins(kgx_pop* pop, const double* bin_edges, uint32_t n_bins, uint64_t* out) {
-  if (int bound = require_bound()) return bound;
-  if (!pop || !out || !bin_edges) return fail(KGX_EINVAL, "null population, bin edges or output");
-  if (n_bins == 0 || n_bins > 254) return fail(KGX_EINVAL, "n_bins %u outside [1,254]", n_bins);
-  if (!pop->has_af) return fail(KGX_ESTATE, "allele frequencies were never set (kgx_population_set_af)");
-  const int rc = count_by_genome_impl(pop, nullptr, n_bins, out, bin_edges);
-  (void)use_device(*pop->shards[0].dev);
-  return rc;
+  return guarded([&]() -> int {
+    if (int bound = require_bound()) return bound;
+    if (!pop || !out || !bin_edges) return fail(KGX_EINVAL, "null population, bin edges or output");
+    if (n_bins == 0 || n_bins > 254) return fail(KGX_EINVAL, "n_bins %u outside [1,254]", n_bins);
+    if (!pop->has_af) return fail(KGX_ESTATE, "allele frequencies were never set (kgx_population_set_af)");
+    const int rc = count_by_genome_impl(pop, nullptr, n_bins, out, bin_edges);
+    (void)use_device(*pop->shards[0].dev);
+    return rc;
+  });
 }
 
 double kgx_count_by_genome_last_ms(void) {
@@ -940,133 +1009,141 @@ double kgx_count_by_genome_last_ms(void) {
 
 int kgx_compound_offsets(kgx_pop* pop, const uint32_t* first_row, const uint32_t* n_rows, const uint32_t* bin,
                          uint64_t n_groups, uint32_t n_bins, uint64_t* out) {
-  if (int bound = require_bound()) return bound;
-  if (!pop || !out || (n_groups && (!first_row || !n_rows || !bin))) return fail(KGX_EINVAL, "null argument");
-  if (n_bins == 0) return fail(KGX_EINVAL, "n_bins must be > 0");
-  std::memset(out, 0, pop->n_genomes * n_bins * 3 * sizeof(uint64_t));
-  if (n_groups == 0) return KGX_OK;
-  std::vector<OffsetGroup> groups(n_groups);
-  for (uint64_t i = 0; i < n_groups; ++i) {
-    if (n_rows[i] > 15) return fail(KGX_EINVAL, "group %llu has %u rows; at most 15 distinct variants per offset are supported",
-                                    (unsigned long long)i, n_rows[i]);
-    if (static_cast<uint64_t>(first_row[i]) + n_rows[i] > pop->n_variants || bin[i] >= n_bins)
-      return fail(KGX_EINVAL, "group %llu out of range", (unsigned long long)i);
-    groups[i] = OffsetGroup{first_row[i], n_rows[i], bin[i], 0};
-  }
-  const std::vector<uint32_t> no_list;
-  const int rc = for_each_parallel(pop->shards.size(), [&](size_t s) {
-    kgx_pop_shard& sh = pop->shards[s];
-    return compound_offsets_shard(sh, groups, no_list, n_bins, out + sh.genome_base * n_bins * 3);
+  return guarded([&]() -> int {
+    if (int bound = require_bound()) return bound;
+    if (!pop || !out || (n_groups && (!first_row || !n_rows || !bin))) return fail(KGX_EINVAL, "null argument");
+    if (n_bins == 0) return fail(KGX_EINVAL, "n_bins must be > 0");
+    std::memset(out, 0, pop->n_genomes * n_bins * 3 * sizeof(uint64_t));
+    if (n_groups == 0) return KGX_OK;
+    std::vector<OffsetGroup> groups(n_groups);
+    for (uint64_t i = 0; i < n_groups; ++i) {
+      if (n_rows[i] > 15) return fail(KGX_EINVAL, "group %llu has %u rows; at most 15 distinct variants per offset are supported",
+                                      (unsigned long long)i, n_rows[i]);
+      if (static_cast<uint64_t>(first_row[i]) + n_rows[i] > pop->n_variants || bin[i] >= n_bins)
+        return fail(KGX_EINVAL, "group %llu out of range", (unsigned long long)i);
+      groups[i] = OffsetGroup{first_row[i], n_rows[i], bin[i], 0};
+    }
+    const std::vector<uint32_t> no_list;
+    const int rc = for_each_parallel(pop->shards.size(), [&](size_t s) {
+      kgx_pop_shard& sh = pop->shards[s];
+      return compound_offsets_shard(sh, groups, no_list, n_bins, out + sh.genome_base * n_bins * 3);
+    });
+    if (rc == KGX_OK) zero_masked_genomes(pop, out, static_cast<uint64_t>(n_bins) * 3);
+    (void)use_device(*pop->shards[0].dev);
+    return rc;
   });
-  if (rc == KGX_OK) zero_masked_genomes(pop, out, static_cast<uint64_t>(n_bins) * 3);
-  (void)use_device(*pop->shards[0].dev);
-  return rc;
 }
 
 int kgx_compound_offsets_listed(kgx_pop* pop, const uint32_t* member_rows, uint64_t n_members, const uint32_t* first_member, const uint32_t* n_rows,
                                 const uint32_t* bin, uint64_t n_groups, uint32_t n_bins, uint64_t* out) {
-  if (int bound = require_bound()) return bound;
-  if (!pop || !out || (n_groups && (!member_rows || !first_member || !n_rows || !bin))) return fail(KGX_EINVAL, "null argument");
-  if (n_bins == 0) return fail(KGX_EINVAL, "n_bins must be > 0");
-  if (n_members > 0xFFFFFFFFull) return fail(KGX_EINVAL, "more than 2^32 member rows");
-  std::memset(out, 0, pop->n_genomes * n_bins * 3 * sizeof(uint64_t));
-  if (n_groups == 0) return KGX_OK;
-  std::vector<OffsetGroup> groups(n_groups);
-  for (uint64_t i = 0; i < n_groups; ++i) {
-    if (n_rows[i] > 15) return fail(KGX_EINVAL, "group %llu has %u rows; at most 15 distinct variants per offset are supported",
-                                    (unsigned long long)i, n_rows[i]);
-    if (static_cast<uint64_t>(first_member[i]) + n_rows[i] > n_members || bin[i] >= n_bins)
-      return fail(KGX_EINVAL, "group %llu out of range", (unsigned long long)i);
-    groups[i] = OffsetGroup{first_member[i], n_rows[i], bin[i], 0};
-  }
-  const std::vector<uint32_t> row_list(member_rows, member_rows + n_members);
-  for (uint32_t row : row_list)
-    if (row >= pop->n_variants) return fail(KGX_EINVAL, "member row %u past the population's %llu rows", row, (unsigned long long)pop->n_variants);
-  const int rc = for_each_parallel(pop->shards.size(), [&](size_t s) {
-    kgx_pop_shard& sh = pop->shards[s];
-    return compound_offsets_shard(sh, groups, row_list, n_bins, out + sh.genome_base * n_bins * 3);
+  return guarded([&]() -> int {
+    if (int bound = require_bound()) return bound;
+    if (!pop || !out || (n_groups && (!member_rows || !first_member || !n_rows || !bin))) return fail(KGX_EINVAL, "null argument");
+    if (n_bins == 0) return fail(KGX_EINVAL, "n_bins must be > 0");
+    if (n_members > 0xFFFFFFFFull) return fail(KGX_EINVAL, "more than 2^32 member rows");
+    std::memset(out, 0, pop->n_genomes * n_bins * 3 * sizeof(uint64_t));
+    if (n_groups == 0) return KGX_OK;
+    std::vector<OffsetGroup> groups(n_groups);
+    for (uint64_t i = 0; i < n_groups; ++i) {
+      if (n_rows[i] > 15) return fail(KGX_EINVAL, "group %llu has %u rows; at most 15 distinct variants per offset are supported",
+                                      (unsigned long long)i, n_rows[i]);
+      if (static_cast<uint64_t>(first_member[i]) + n_rows[i] > n_members || bin[i] >= n_bins)
+        return fail(KGX_EINVAL, "group %llu out of range", (unsigned long long)i);
+      groups[i] = OffsetGroup{first_member[i], n_rows[i], bin[i], 0};
+    }
+    const std::vector<uint32_t> row_list(member_rows, member_rows + n_members);
+    for (uint32_t row : row_list)
+      if (row >= pop->n_variants) return fail(KGX_EINVAL, "member row %u past the population's %llu rows", row, (unsigned long long)pop->n_variants);
+    const int rc = for_each_parallel(pop->shards.size(), [&](size_t s) {
+      kgx_pop_shard& sh = pop->shards[s];
+      return compound_offsets_shard(sh, groups, row_list, n_bins, out + sh.genome_base * n_bins * 3);
+    });
+    if (rc == KGX_OK) zero_masked_genomes(pop, out, static_cast<uint64_t>(n_bins) * 3);
+    (void)use_device(*pop->shards[0].dev);
+    return rc;
   });
-  if (rc == KGX_OK) zero_masked_genomes(pop, out, static_cast<uint64_t>(n_bins) * 3);
-  (void)use_device(*pop->shards[0].dev);
-  return rc;
 }
 
 int kgx_offset_filter_counts(kgx_pop* pop, const uint8_t* single_bin, const uint32_t* member_rows, uint64_t n_members, const uint32_t* first_member,
                              const uint32_t* n_rows, const uint32_t* bin, uint64_t n_groups, uint32_t n_bins, uint64_t* out) {
-  if (int bound = require_bound()) return bound;
-  if (!pop || !out || !single_bin || (n_groups && (!member_rows || !first_member || !n_rows || !bin))) return fail(KGX_EINVAL, "null argument");
-  if (n_bins == 0 || n_bins > 254) return fail(KGX_EINVAL, "n_bins %u outside [1,254]", n_bins);
-  if (n_members > 0xFFFFFFFFull) return fail(KGX_EINVAL, "more than 2^32 member rows");
-  const uint64_t cells = pop->n_genomes * n_bins;
-  // offsets of one row: its dosage decides, per genome -- the by-genome sweep's counters, re-read per filter
-  std::vector<uint64_t> single(cells * 4, 0);
-  if (pop->n_variants)
-    if (int rc = count_by_genome_impl(pop, single_bin, n_bins, single.data())) { (void)use_device(*pop->shards[0].dev); return rc; }
-  for (uint64_t c = 0; c < cells; ++c) {
-    const uint64_t het = single[c * 4 + 1], hom = single[c * 4 + 2], more = single[c * 4 + 3];
-    out[c * 4 + 0] = 2 * hom;                 // HomozygousFilter: the two copies of the one variant
-    out[c * 4 + 1] = het;                     // HeterozygousFilter
-    out[c * 4 + 2] = het + 2 * hom;           // DiploidFilter: nothing of an offset holding more than two
-    out[c * 4 + 3] = het + hom + more;        // UniqueUnphasedFilter
-  }
-  if (n_groups == 0) return use_device(*pop->shards[0].dev);
-  std::vector<OffsetGroup> groups(n_groups);
-  for (uint64_t i = 0; i < n_groups; ++i) {
-    if (n_rows[i] > 15) return fail(KGX_EINVAL, "group %llu has %u rows; at most 15 distinct variants per offset are supported",
-                                    (unsigned long long)i, n_rows[i]);
-    if (static_cast<uint64_t>(first_member[i]) + n_rows[i] > n_members || bin[i] >= n_bins)
-      return fail(KGX_EINVAL, "group %llu out of range", (unsigned long long)i);
-    groups[i] = OffsetGroup{first_member[i], n_rows[i], bin[i], 0};
-  }
-  const std::vector<uint32_t> row_list(member_rows, member_rows + n_members);
-  for (uint32_t row : row_list) {
-    if (row >= pop->n_variants) return fail(KGX_EINVAL, "member row %u past the population's %llu rows", row, (unsigned long long)pop->n_variants);
-    if (single_bin[row] != 0xFF) return fail(KGX_EINVAL, "row %u is a member of a group and has a bin of its own", row);
-  }
-  std::vector<uint64_t> grouped(cells * 4, 0);
-  const int rc = for_each_parallel(pop->shards.size(), [&](size_t s) {
-    kgx_pop_shard& sh = pop->shards[s];
-    return compound_offsets_shard(sh, groups, row_list, n_bins, grouped.data() + sh.genome_base * n_bins * 4, 4);
+  return guarded([&]() -> int {
+    if (int bound = require_bound()) return bound;
+    if (!pop || !out || !single_bin || (n_groups && (!member_rows || !first_member || !n_rows || !bin))) return fail(KGX_EINVAL, "null argument");
+    if (n_bins == 0 || n_bins > 254) return fail(KGX_EINVAL, "n_bins %u outside [1,254]", n_bins);
+    if (n_members > 0xFFFFFFFFull) return fail(KGX_EINVAL, "more than 2^32 member rows");
+    const uint64_t cells = pop->n_genomes * n_bins;
+    // offsets of one row: its dosage decides, per genome -- the by-genome sweep's counters, re-read per filter
+    std::vector<uint64_t> single(cells * 4, 0);
+    if (pop->n_variants)
+      if (int rc = count_by_genome_impl(pop, single_bin, n_bins, single.data())) { (void)use_device(*pop->shards[0].dev); return rc; }
+    for (uint64_t c = 0; c < cells; ++c) {
+      const uint64_t het = single[c * 4 + 1], hom = single[c * 4 + 2], more = single[c * 4 + 3];
+      out[c * 4 + 0] = 2 * hom;                 // HomozygousFilter: the two copies of the one variant
+      out[c * 4 + 1] = het;                     // HeterozygousFilter
+      out[c * 4 + 2] = het + 2 * hom;           // DiploidFilter: nothing of an offset holding more than two
+      out[c * 4 + 3] = het + hom + more;        // UniqueUnphasedFilter
+    }
+    if (n_groups == 0) return use_device(*pop->shards[0].dev);
+    std::vector<OffsetGroup> groups(n_groups);
+    for (uint64_t i = 0; i < n_groups; ++i) {
+      if (n_rows[i] > 15) return fail(KGX_EINVAL, "group %llu has %u rows; at most 15 distinct variants per offset are supported",
+                                      (unsigned long long)i, n_rows[i]);
+      if (static_cast<uint64_t>(first_member[i]) + n_rows[i] > n_members || bin[i] >= n_bins)
+        return fail(KGX_EINVAL, "group %llu out of range", (unsigned long long)i);
+      groups[i] = OffsetGroup{first_member[i], n_rows[i], bin[i], 0};
+    }
+    const std::vector<uint32_t> row_list(member_rows, member_rows + n_members);
+    for (uint32_t row : row_list) {
+      if (row >= pop->n_variants) return fail(KGX_EINVAL, "member row %u past the population's %llu rows", row, (unsigned long long)pop->n_variants);
+      if (single_bin[row] != 0xFF) return fail(KGX_EINVAL, "row %u is a member of a group and has a bin of its own", row);
+    }
+    std::vector<uint64_t> grouped(cells * 4, 0);
+    const int rc = for_each_parallel(pop->shards.size(), [&](size_t s) {
+      kgx_pop_shard& sh = pop->shards[s];
+      return compound_offsets_shard(sh, groups, row_list, n_bins, grouped.data() + sh.genome_base * n_bins * 4, 4);
+    });
+    if (rc == KGX_OK) {
+      zero_masked_genomes(pop, grouped.data(), static_cast<uint64_t>(n_bins) * 4);
+      for (uint64_t i = 0; i < cells * 4; ++i) out[i] += grouped[i];
+    }
+    (void)use_device(*pop->shards[0].dev);
+    return rc;
   });
-  if (rc == KGX_OK) {
-    zero_masked_genomes(pop, grouped.data(), static_cast<uint64_t>(n_bins) * 4);
-    for (uint64_t i = 0; i < cells * 4; ++i) out[i] += grouped[i];
-  }
-  (void)use_device(*pop->shards[0].dev);
-  return rc;
 }
 
 int kgx_genome_row_lists(kgx_pop* pop, uint64_t g0, uint64_t g1, const uint8_t* row_selected, uint64_t* begin, uint32_t* rows, uint64_t capacity) {
-  if (int bound = require_bound()) return bound;
-  if (!pop || !begin) return fail(KGX_EINVAL, "null population or begin array");
-  if (g0 > g1 || g1 > pop->n_genomes) return fail(KGX_EINVAL, "genome range [%llu, %llu) outside the population's %llu genomes", (unsigned long long)g0,
-                                                  (unsigned long long)g1, (unsigned long long)pop->n_genomes);
-  const size_t n_shards = pop->shards.size();
-  std::vector<std::vector<unsigned long long>> shard_begin(n_shards);
-  std::vector<std::vector<uint32_t>> shard_rows(n_shards);
-  const int rc = for_each_parallel(n_shards, [&](size_t s) -> int {
-    kgx_pop_shard& sh = pop->shards[s];
-    const uint64_t lo = g0 > sh.genome_base ? g0 : sh.genome_base;
-    const uint64_t hi = g1 < sh.genome_base + sh.n_genomes ? g1 : sh.genome_base + sh.n_genomes;
-    if (lo >= hi) { shard_begin[s].assign(1, 0); return KGX_OK; }
-    return genome_row_lists_shard(sh, lo - sh.genome_base, hi - sh.genome_base, row_selected, shard_begin[s], rows ? &shard_rows[s] : nullptr);
-  });
-  (void)use_device(*pop->shards[0].dev);
-  if (rc != KGX_OK) return rc;
-  // the shards hold consecutive genome ranges: their lists follow one another
-  uint64_t at = 0, g = 0;
-  begin[0] = 0;
-  for (size_t s = 0; s < n_shards; ++s) {
-    const auto& b = shard_begin[s];
-    for (size_t i = 0; i + 1 < b.size(); ++i) begin[++g] = at + b[i + 1];
-    const uint64_t total = b.back();
-    if (rows) {
-      if (at + total > capacity) return fail(KGX_EINVAL, "row lists need %llu entries, capacity is %llu", (unsigned long long)(at + total), (unsigned long long)capacity);
-      if (total) std::memcpy(rows + at, shard_rows[s].data(), total * sizeof(uint32_t));
+  return guarded([&]() -> int {
+    if (int bound = require_bound()) return bound;
+    if (!pop || !begin) return fail(KGX_EINVAL, "null population or begin array");
+    if (g0 > g1 || g1 > pop->n_genomes) return fail(KGX_EINVAL, "genome range [%llu, %llu) outside the population's %llu genomes", (unsigned long long)g0,
+                                                    (unsigned long long)g1, (unsigned long long)pop->n_genomes);
+    const size_t n_shards = pop->shards.size();
+    std::vector<std::vector<unsigned long long>> shard_begin(n_shards);
+    std::vector<std::vector<uint32_t>> shard_rows(n_shards);
+    const int rc = for_each_parallel(n_shards, [&](size_t s) -> int {
+      kgx_pop_shard& sh = pop->shards[s];
+      const uint64_t lo = g0 > sh.genome_base ? g0 : sh.genome_base;
+      const uint64_t hi = g1 < sh.genome_base + sh.n_genomes ? g1 : sh.genome_base + sh.n_genomes;
+      if (lo >= hi) { shard_begin[s].assign(1, 0); return KGX_OK; }
+      return genome_row_lists_shard(sh, lo - sh.genome_base, hi - sh.genome_base, row_selected, shard_begin[s], rows ? &shard_rows[s] : nullptr);
+    });
+    (void)use_device(*pop->shards[0].dev);
+    if (rc != KGX_OK) return rc;
+    // the shards hold consecutive genome ranges: their lists follow one another
+    uint64_t at = 0, g = 0;
+    begin[0] = 0;
+    for (size_t s = 0; s < n_shards; ++s) {
+      const auto& b = shard_begin[s];
+      for (size_t i = 0; i + 1 < b.size(); ++i) begin[++g] = at + b[i + 1];
+      const uint64_t total = b.back();
+      if (rows) {
+        if (at + total > capacity) return fail(KGX_EINVAL, "row lists need %llu entries, capacity is %llu", (unsigned long long)(at + total), (unsigned long long)capacity);
+        if (total) std::memcpy(rows + at, shard_rows[s].data(), total * sizeof(uint32_t));
+      }
+      at += total;
     }
-    at += total;
-  }
-  return KGX_OK;
+    return KGX_OK;
+  });
 }
 
 }  // extern "C"

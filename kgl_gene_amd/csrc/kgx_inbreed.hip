@@ -570,6 +570,13 @@ kgx_gt8* kgx_gt8_create(uint64_t n_genomes, uint64_t n_loci) {
   const uint64_t n_slots = rt->devs.size();
   const uint64_t units = (n_genomes + 127) / 128, per = units / n_slots, extra = units % n_slots;
   uint64_t base = 0;
+  try {
+    h->shards.reserve(n_slots);
+  } catch (const std::exception&) {
+    delete h;
+    fail(KGX_ENOMEM, "host allocation failed");
+    return nullptr;
+  }
   for (uint64_t s = 0; s < n_slots; ++s) {
     kgx_gt8_shard sh;
     sh.dev = rt->devs[s].get();
@@ -621,180 +628,194 @@ uint64_t kgx_gt8_sweep_bytes(uint64_t n_genomes, uint64_t n_selected, uint32_t a
 }
 uint32_t kgx_gt8_shards(const kgx_gt8* h) { return h ? static_cast<uint32_t>(h->shards.size()) : 0; }
 int kgx_gt8_shard_info(const kgx_gt8* h, uint32_t shard, int* slot, uint64_t* genome_base, uint64_t* n_genomes) {
-  if (int bound = require_bound()) return bound;
-  if (!h || shard >= h->shards.size()) return fail(KGX_EINVAL, "no such shard");
-  const auto& sh = h->shards[shard];
-  if (slot) *slot = sh.dev->slot;
-  if (genome_base) *genome_base = sh.genome_base;
-  if (n_genomes) *n_genomes = sh.n_genomes;
-  return KGX_OK;
+  return guarded([&]() -> int {
+    if (int bound = require_bound()) return bound;
+    if (!h || shard >= h->shards.size()) return fail(KGX_EINVAL, "no such shard");
+    const auto& sh = h->shards[shard];
+    if (slot) *slot = sh.dev->slot;
+    if (genome_base) *genome_base = sh.genome_base;
+    if (n_genomes) *n_genomes = sh.n_genomes;
+    return KGX_OK;
+  });
 }
 
 int kgx_gt8_load(kgx_gt8* h, const uint8_t* src, uint64_t g0, uint64_t g1) {
-  if (int bound = require_bound()) return bound;
-  if (!h || !src) return fail(KGX_EINVAL, "null handle or source");
-  if (g0 > g1 || g1 > h->n_genomes) return fail(KGX_EINVAL, "genome range out of bounds");
-  if (g0 == g1 || h->n_loci == 0) return KGX_OK;
-  const uint64_t L = h->n_loci;
-  const int rc = for_each_parallel(h->shards.size(), [&](size_t s) -> int {
-    kgx_gt8_shard& sh = h->shards[s];
-    const uint64_t lo = g0 > sh.genome_base ? g0 : sh.genome_base;
-    const uint64_t hi = g1 < sh.genome_base + sh.n_genomes ? g1 : sh.genome_base + sh.n_genomes;
-    if (lo >= hi) return KGX_OK;
-    if (int e = use_device(*sh.dev)) return e;
-    sh.wide_nibbles = 0;              // the bytes change: look again (kgx_inbreed)
-    uint64_t slab = (1ull << 30) / L;
-    if (slab < 1) slab = 1;
-    const uint64_t max_rows = (hi - lo) < slab ? (hi - lo) : slab;
-    uint8_t* d_stage = nullptr;
-    KGX_HIP_MEM(hipMalloc(&d_stage, max_rows * L));
-    int r = KGX_OK;
-    for (uint64_t g = lo; g < hi && r == KGX_OK; g += slab) {
-      const uint64_t n = (hi - g) < slab ? (hi - g) : slab;
-      if (hipMemcpyAsync(d_stage, src + (g - g0) * L, n * L, hipMemcpyHostToDevice, sh.dev->stream) != hipSuccess) {
-        r = fail(KGX_EHIP, "H2D copy of genotype bytes failed");
-        break;
+  return guarded([&]() -> int {
+    if (int bound = require_bound()) return bound;
+    if (!h || !src) return fail(KGX_EINVAL, "null handle or source");
+    if (g0 > g1 || g1 > h->n_genomes) return fail(KGX_EINVAL, "genome range out of bounds");
+    if (g0 == g1 || h->n_loci == 0) return KGX_OK;
+    const uint64_t L = h->n_loci;
+    const int rc = for_each_parallel(h->shards.size(), [&](size_t s) -> int {
+      kgx_gt8_shard& sh = h->shards[s];
+      const uint64_t lo = g0 > sh.genome_base ? g0 : sh.genome_base;
+      const uint64_t hi = g1 < sh.genome_base + sh.n_genomes ? g1 : sh.genome_base + sh.n_genomes;
+      if (lo >= hi) return KGX_OK;
+      if (int e = use_device(*sh.dev)) return e;
+      sh.wide_nibbles = 0;              // the bytes change: look again (kgx_inbreed)
+      uint64_t slab = (1ull << 30) / L;
+      if (slab < 1) slab = 1;
+      const uint64_t max_rows = (hi - lo) < slab ? (hi - lo) : slab;
+      uint8_t* d_stage = nullptr;
+      KGX_HIP_MEM(hipMalloc(&d_stage, max_rows * L));
+      int r = KGX_OK;
+      for (uint64_t g = lo; g < hi && r == KGX_OK; g += slab) {
+        const uint64_t n = (hi - g) < slab ? (hi - g) : slab;
+        if (hipMemcpyAsync(d_stage, src + (g - g0) * L, n * L, hipMemcpyHostToDevice, sh.dev->stream) != hipSuccess) {
+          r = fail(KGX_EHIP, "H2D copy of genotype bytes failed");
+          break;
+        }
+        hipLaunchKernelGGL(k_gt8_transpose, dim3(stream_grid(*sh.dev, n * L, kBlock)), dim3(kBlock), 0, sh.dev->stream, d_stage, n, L,
+                           g - sh.genome_base, sh.d_gt, sh.pitch);
+        if (hipGetLastError() != hipSuccess || hipStreamSynchronize(sh.dev->stream) != hipSuccess)
+          r = fail(KGX_EHIP, "genotype transpose kernel failed");
       }
-      hipLaunchKernelGGL(k_gt8_transpose, dim3(stream_grid(*sh.dev, n * L, kBlock)), dim3(kBlock), 0, sh.dev->stream, d_stage, n, L,
-                         g - sh.genome_base, sh.d_gt, sh.pitch);
-      if (hipGetLastError() != hipSuccess || hipStreamSynchronize(sh.dev->stream) != hipSuccess)
-        r = fail(KGX_EHIP, "genotype transpose kernel failed");
-    }
-    (void)hipFree(d_stage);
-    return r;
+      (void)hipFree(d_stage);
+      return r;
+    });
+    (void)use_device(*h->shards[0].dev);
+    return rc;
   });
-  (void)use_device(*h->shards[0].dev);
-  return rc;
 }
 
 int kgx_gt8_load_rows(kgx_gt8* h, const uint8_t* src, uint64_t src_pitch, uint64_t l0, uint64_t l1) {
-  if (int bound = require_bound()) return bound;
-  if (!h || !src) return fail(KGX_EINVAL, "null handle or source");
-  if (l0 > l1 || l1 > h->n_loci || src_pitch < h->n_genomes) return fail(KGX_EINVAL, "bad locus range or pitch");
-  if (l0 == l1) return KGX_OK;
-  for (auto& sh : h->shards) {
-    if (sh.n_genomes == 0) continue;
-    if (int rc = use_device(*sh.dev)) return rc;
-    sh.wide_nibbles = 0;
-    KGX_HIP(hipMemcpy2DAsync(sh.d_gt + l0 * sh.pitch, sh.pitch, src + sh.genome_base, src_pitch, sh.n_genomes, l1 - l0,
-                             hipMemcpyHostToDevice, sh.dev->stream));
-  }
-  return sync_shards(h);
+  return guarded([&]() -> int {
+    if (int bound = require_bound()) return bound;
+    if (!h || !src) return fail(KGX_EINVAL, "null handle or source");
+    if (l0 > l1 || l1 > h->n_loci || src_pitch < h->n_genomes) return fail(KGX_EINVAL, "bad locus range or pitch");
+    if (l0 == l1) return KGX_OK;
+    for (auto& sh : h->shards) {
+      if (sh.n_genomes == 0) continue;
+      if (int rc = use_device(*sh.dev)) return rc;
+      sh.wide_nibbles = 0;
+      KGX_HIP(hipMemcpy2DAsync(sh.d_gt + l0 * sh.pitch, sh.pitch, src + sh.genome_base, src_pitch, sh.n_genomes, l1 - l0,
+                               hipMemcpyHostToDevice, sh.dev->stream));
+    }
+    return sync_shards(h);
+  });
 }
 
 int kgx_gt8_read_rows(const kgx_gt8* h, uint8_t* dst, uint64_t dst_pitch, uint64_t l0, uint64_t l1) {
-  if (int bound = require_bound()) return bound;
-  if (!h || !dst) return fail(KGX_EINVAL, "null handle or destination");
-  if (l0 > l1 || l1 > h->n_loci || dst_pitch < h->n_genomes) return fail(KGX_EINVAL, "bad locus range or pitch");
-  if (l0 == l1) return KGX_OK;
-  for (const auto& sh : h->shards) {
-    if (sh.n_genomes == 0) continue;
-    if (int rc = use_device(*sh.dev)) return rc;
-    KGX_HIP(hipMemcpy2DAsync(dst + sh.genome_base, dst_pitch, sh.d_gt + l0 * sh.pitch, sh.pitch, sh.n_genomes, l1 - l0,
-                             hipMemcpyDeviceToHost, sh.dev->stream));
-  }
-  return sync_shards(h);
+  return guarded([&]() -> int {
+    if (int bound = require_bound()) return bound;
+    if (!h || !dst) return fail(KGX_EINVAL, "null handle or destination");
+    if (l0 > l1 || l1 > h->n_loci || dst_pitch < h->n_genomes) return fail(KGX_EINVAL, "bad locus range or pitch");
+    if (l0 == l1) return KGX_OK;
+    for (const auto& sh : h->shards) {
+      if (sh.n_genomes == 0) continue;
+      if (int rc = use_device(*sh.dev)) return rc;
+      KGX_HIP(hipMemcpy2DAsync(dst + sh.genome_base, dst_pitch, sh.d_gt + l0 * sh.pitch, sh.pitch, sh.n_genomes, l1 - l0,
+                               hipMemcpyDeviceToHost, sh.dev->stream));
+    }
+    return sync_shards(h);
+  });
 }
 
 int kgx_locus_class_frequencies(const double* minor_af, uint64_t n_loci, uint32_t amax, double inbreeding, double* out, uint8_t* valid) {
-  std::shared_ptr<Runtime> rt;
-  if (int rc = require_runtime(rt)) return rc;
-  if (!minor_af || !out || amax == 0 || amax > 14) return fail(KGX_EINVAL, "bad arguments (amax must be 1..14)");
-  if (n_loci == 0) return KGX_OK;
-  Device& dev = *rt->devs[0];
-  if (int rc = use_device(dev)) return rc;
-  const uint32_t stride = amax + kTableExtra;
-  double *d_in = nullptr, *d_table = nullptr;
-  uint8_t* d_valid = nullptr;
-  int rc = KGX_OK;
-  if (hipMalloc(&d_in, n_loci * amax * sizeof(double)) != hipSuccess || hipMalloc(&d_table, n_loci * stride * sizeof(double)) != hipSuccess ||
-      hipMalloc(&d_valid, n_loci) != hipSuccess) {
-    (void)hipGetLastError();
-    rc = fail(KGX_ENOMEM, "locus_class_frequencies: hipMalloc failed");
-  }
-  if (rc == KGX_OK) {
-    std::vector<double> table(n_loci * stride);
-    std::vector<uint8_t> v(n_loci);
-    if (hipMemcpyAsync(d_in, minor_af, n_loci * amax * sizeof(double), hipMemcpyHostToDevice, dev.stream) != hipSuccess) rc = fail(KGX_EHIP, "H2D failed");
-    if (rc == KGX_OK) {
-      hipLaunchKernelGGL((k_locus_tables<false>), dim3(stream_grid(dev, n_loci, kBlock)), dim3(kBlock), 0, dev.stream, d_in, n_loci, amax, inbreeding, d_table, d_valid);
-      if (hipGetLastError() != hipSuccess ||
-          hipMemcpyAsync(table.data(), d_table, table.size() * sizeof(double), hipMemcpyDeviceToHost, dev.stream) != hipSuccess ||
-          hipMemcpyAsync(v.data(), d_valid, n_loci, hipMemcpyDeviceToHost, dev.stream) != hipSuccess ||
-          hipStreamSynchronize(dev.stream) != hipSuccess)
-        rc = fail(KGX_EHIP, "locus table kernel failed");
+  return guarded([&]() -> int {
+    std::shared_ptr<Runtime> rt;
+    if (int rc = require_runtime(rt)) return rc;
+    if (!minor_af || !out || amax == 0 || amax > 14) return fail(KGX_EINVAL, "bad arguments (amax must be 1..14)");
+    if (n_loci == 0) return KGX_OK;
+    Device& dev = *rt->devs[0];
+    if (int rc = use_device(dev)) return rc;
+    const uint32_t stride = amax + kTableExtra;
+    double *d_in = nullptr, *d_table = nullptr;
+    uint8_t* d_valid = nullptr;
+    int rc = KGX_OK;
+    if (hipMalloc(&d_in, n_loci * amax * sizeof(double)) != hipSuccess || hipMalloc(&d_table, n_loci * stride * sizeof(double)) != hipSuccess ||
+        hipMalloc(&d_valid, n_loci) != hipSuccess) {
+      (void)hipGetLastError();
+      rc = fail(KGX_ENOMEM, "locus_class_frequencies: hipMalloc failed");
     }
     if (rc == KGX_OK) {
-      for (uint64_t l = 0; l < n_loci; ++l) {
-        for (int k = 0; k < 5; ++k) out[l * 5 + k] = table[l * stride + amax + k];
-        if (valid) valid[l] = v[l] ? 1 : 0;
+      std::vector<double> table(n_loci * stride);
+      std::vector<uint8_t> v(n_loci);
+      if (hipMemcpyAsync(d_in, minor_af, n_loci * amax * sizeof(double), hipMemcpyHostToDevice, dev.stream) != hipSuccess) rc = fail(KGX_EHIP, "H2D failed");
+      if (rc == KGX_OK) {
+        hipLaunchKernelGGL((k_locus_tables<false>), dim3(stream_grid(dev, n_loci, kBlock)), dim3(kBlock), 0, dev.stream, d_in, n_loci, amax, inbreeding, d_table, d_valid);
+        if (hipGetLastError() != hipSuccess ||
+            hipMemcpyAsync(table.data(), d_table, table.size() * sizeof(double), hipMemcpyDeviceToHost, dev.stream) != hipSuccess ||
+            hipMemcpyAsync(v.data(), d_valid, n_loci, hipMemcpyDeviceToHost, dev.stream) != hipSuccess ||
+            hipStreamSynchronize(dev.stream) != hipSuccess)
+          rc = fail(KGX_EHIP, "locus table kernel failed");
+      }
+      if (rc == KGX_OK) {
+        for (uint64_t l = 0; l < n_loci; ++l) {
+          for (int k = 0; k < 5; ++k) out[l * 5 + k] = table[l * stride + amax + k];
+          if (valid) valid[l] = v[l] ? 1 : 0;
+        }
       }
     }
-  }
-  if (d_in) (void)hipFree(d_in);
-  if (d_table) (void)hipFree(d_table);
-  if (d_valid) (void)hipFree(d_valid);
-  return rc;
+    if (d_in) (void)hipFree(d_in);
+    if (d_table) (void)hipFree(d_table);
+    if (d_valid) (void)hipFree(d_valid);
+    return rc;
+  });
 }
 
 int kgx_inbreed(kgx_gt8* h, uint64_t g0, uint64_t g1, const uint32_t* locus_index, uint64_t n_sel, const double* minor_af,
                 uint32_t amax, int phased, int algorithm, const double* start, kgx_locus_results* out) {
-  if (int bound = require_bound()) return bound;
-  if (!h || !out || (n_sel && !minor_af)) return fail(KGX_EINVAL, "null argument");
-  if (g0 > g1 || g1 > h->n_genomes || (g0 & 3u)) return fail(KGX_EINVAL, "genome range must lie in the matrix and start on a multiple of 4");
-  if (amax == 0 || amax > 14) return fail(KGX_EINVAL, "amax %u outside [1,14] (4-bit allele indices)", amax);
-  if (algorithm < 0 || algorithm > 3) return fail(KGX_EINVAL, "unknown algorithm %d", algorithm);
-  if (start && (algorithm == KGX_ALGO_HALL_ME || algorithm == KGX_ALGO_LOGLIKELIHOOD))
-    for (uint64_t g = 0; g < g1 - g0; ++g) {
-      // HallME: the reference's draws lie in (0, 0.5]; Loglikelihood: the optimiser's box [-1, 1]
-      const bool ok = algorithm == KGX_ALGO_HALL_ME ? (start[g] > 0.0 && start[g] <= 1.0) : (start[g] >= -1.0 && start[g] <= 1.0);
-      if (!ok) return fail(KGX_EINVAL, "start[%llu] = %g outside the estimator's interval", (unsigned long long)g, start[g]);
+  return guarded([&]() -> int {
+    if (int bound = require_bound()) return bound;
+    if (!h || !out || (n_sel && !minor_af)) return fail(KGX_EINVAL, "null argument");
+    if (g0 > g1 || g1 > h->n_genomes || (g0 & 3u)) return fail(KGX_EINVAL, "genome range must lie in the matrix and start on a multiple of 4");
+    if (amax == 0 || amax > 14) return fail(KGX_EINVAL, "amax %u outside [1,14] (4-bit allele indices)", amax);
+    if (algorithm < 0 || algorithm > 3) return fail(KGX_EINVAL, "unknown algorithm %d", algorithm);
+    if (start && (algorithm == KGX_ALGO_HALL_ME || algorithm == KGX_ALGO_LOGLIKELIHOOD))
+      for (uint64_t g = 0; g < g1 - g0; ++g) {
+        // HallME: the reference's draws lie in (0, 0.5]; Loglikelihood: the optimiser's box [-1, 1]
+        const bool ok = algorithm == KGX_ALGO_HALL_ME ? (start[g] > 0.0 && start[g] <= 1.0) : (start[g] >= -1.0 && start[g] <= 1.0);
+        if (!ok) return fail(KGX_EINVAL, "start[%llu] = %g outside the estimator's interval", (unsigned long long)g, start[g]);
+      }
+    if (!locus_index && n_sel > h->n_loci) return fail(KGX_EINVAL, "n_sel exceeds the locus count");
+    if (locus_index) {
+      hipPointerAttribute_t attr;                                  // a device-resident index cannot be range-checked from here
+      const bool on_device = hipPointerGetAttributes(&attr, locus_index) == hipSuccess && attr.type == hipMemoryTypeDevice;
+      if (!on_device) {
+        (void)hipGetLastError();
+        for (uint64_t i = 0; i < n_sel; ++i)
+          if (locus_index[i] >= h->n_loci) return fail(KGX_EINVAL, "locus_index[%llu] out of range", (unsigned long long)i);
+      }
     }
-  if (!locus_index && n_sel > h->n_loci) return fail(KGX_EINVAL, "n_sel exceeds the locus count");
-  if (locus_index) {
-    hipPointerAttribute_t attr;                                  // a device-resident index cannot be range-checked from here
-    const bool on_device = hipPointerGetAttributes(&attr, locus_index) == hipSuccess && attr.type == hipMemoryTypeDevice;
-    if (!on_device) {
-      (void)hipGetLastError();
-      for (uint64_t i = 0; i < n_sel; ++i)
-        if (locus_index[i] >= h->n_loci) return fail(KGX_EINVAL, "locus_index[%llu] out of range", (unsigned long long)i);
-    }
-  }
-  if (g0 == g1) return KGX_OK;
-  const int rc = for_each_parallel(h->shards.size(), [&](size_t s) -> int {
-    kgx_gt8_shard& sh = h->shards[s];
-    const uint64_t lo = g0 > sh.genome_base ? g0 : sh.genome_base;
-    const uint64_t hi = g1 < sh.genome_base + sh.n_genomes ? g1 : sh.genome_base + sh.n_genomes;
-    if (lo >= hi) return KGX_OK;
-    return inbreed_shard(sh, lo - sh.genome_base, hi - sh.genome_base, locus_index, n_sel, minor_af, amax, phased, algorithm,
-                         start ? start + (lo - g0) : nullptr, out + (lo - g0));
+    if (g0 == g1) return KGX_OK;
+    const int rc = for_each_parallel(h->shards.size(), [&](size_t s) -> int {
+      kgx_gt8_shard& sh = h->shards[s];
+      const uint64_t lo = g0 > sh.genome_base ? g0 : sh.genome_base;
+      const uint64_t hi = g1 < sh.genome_base + sh.n_genomes ? g1 : sh.genome_base + sh.n_genomes;
+      if (lo >= hi) return KGX_OK;
+      return inbreed_shard(sh, lo - sh.genome_base, hi - sh.genome_base, locus_index, n_sel, minor_af, amax, phased, algorithm,
+                           start ? start + (lo - g0) : nullptr, out + (lo - g0));
+    });
+    (void)use_device(*h->shards[0].dev);
+    return rc;
   });
-  (void)use_device(*h->shards[0].dev);
-  return rc;
 }
 
 int kgx_inbreed_reference_starts(int algorithm, uint64_t seed, uint64_t first_stream, uint64_t n, double* out) {
-  if (!out && n) return fail(KGX_EINVAL, "null argument");
-  if (algorithm != KGX_ALGO_HALL_ME && algorithm != KGX_ALGO_LOGLIKELIHOOD) return fail(KGX_EINVAL, "algorithm %d draws no start points", algorithm);
-  // processHallME: UniformRealDistribution(INIT_UPPER_, 0) (_calc.cpp:237); processLogLikelihood: (INIT_UPPER_, INIT_LOWER_)
-  // (:166) = std::uniform_real_distribution<>(0.5, 0 | -0.5) on a std::mt19937_64 (kel_math/kel_distribution.h:25-43, 90-108).
-  // RetryCalcResult(FINAL_ACCURACY_, MIN_RETRIES_ = 5, MAX_RETRIES_) ends the restarts at the fifth: checkTolerance
-  // (:45-68) compares every entry with itself.  One draw per restart, so the fifth draw is the start that counts.
-  constexpr int kRestarts = 5;
-  for (uint64_t i = 0; i < n; ++i) {
-    std::mt19937_64 entropy_mt;
-    if (seed) {
-      entropy_mt.seed(seed + first_stream + i);
-    } else {
-      std::random_device rd;                                    // RandomEntropySource: generator_(rd_())
-      entropy_mt.seed(rd());
+  return guarded([&]() -> int {
+    if (!out && n) return fail(KGX_EINVAL, "null argument");
+    if (algorithm != KGX_ALGO_HALL_ME && algorithm != KGX_ALGO_LOGLIKELIHOOD) return fail(KGX_EINVAL, "algorithm %d draws no start points", algorithm);
+    // processHallME: UniformRealDistribution(INIT_UPPER_, 0) (_calc.cpp:237); processLogLikelihood: (INIT_UPPER_, INIT_LOWER_)
+    // (:166) = std::uniform_real_distribution<>(0.5, 0 | -0.5) on a std::mt19937_64 (kel_math/kel_distribution.h:25-43, 90-108).
+    // RetryCalcResult(FINAL_ACCURACY_, MIN_RETRIES_ = 5, MAX_RETRIES_) ends the restarts at the fifth: checkTolerance
+    // (:45-68) compares every entry with itself.  One draw per restart, so the fifth draw is the start that counts.
+    constexpr int kRestarts = 5;
+    for (uint64_t i = 0; i < n; ++i) {
+      std::mt19937_64 entropy_mt;
+      if (seed) {
+        entropy_mt.seed(seed + first_stream + i);
+      } else {
+        std::random_device rd;                                    // RandomEntropySource: generator_(rd_())
+        entropy_mt.seed(rd());
+      }
+      std::uniform_real_distribution<> initialize_distribution(0.5, algorithm == KGX_ALGO_HALL_ME ? 0.0 : -0.5);
+      double drawn = 0.0;
+      for (int restart = 0; restart < kRestarts; ++restart) drawn = initialize_distribution(entropy_mt);
+      out[i] = drawn;
     }
-    std::uniform_real_distribution<> initialize_distribution(0.5, algorithm == KGX_ALGO_HALL_ME ? 0.0 : -0.5);
-    double drawn = 0.0;
-    for (int restart = 0; restart < kRestarts; ++restart) drawn = initialize_distribution(entropy_mt);
-    out[i] = drawn;
-  }
-  return KGX_OK;
+    return KGX_OK;
+  });
 }
 
 double kgx_inbreed_last_sweep_ms(void) {
@@ -822,106 +843,116 @@ int kgx_inbreed_last_evaluations(void) {
 }
 
 int kgx_gt8_synth_multiallelic(kgx_gt8* h, uint64_t seed, uint64_t genome_base, uint64_t locus_base, double* af_table) {
-  if (int bound = require_bound()) return bound;
-  if (!h) return fail(KGX_EINVAL, "null handle");
-  if (h->n_loci == 0) return KGX_OK;
-  const int rc = for_each_parallel(h->shards.size(), [&](size_t s) -> int {
-    kgx_gt8_shard& sh = h->shards[s];
-    if (sh.n_genomes == 0) return KGX_OK;
-    if (int e = use_device(*sh.dev)) return e;
-    sh.wide_nibbles = 0;
-    const bool want_table = af_table && s == 0;               // the table does not depend on the genomes: the first shard writes it
-    double* d_table = nullptr;
-    if (want_table) KGX_HIP_MEM(hipMalloc(&d_table, sh.n_loci * KGX_SYNTH_MAX_ALTS * sizeof(double)));
-    const uint64_t work = sh.n_loci * ((sh.n_genomes + 3) / 4);
-    hipLaunchKernelGGL(k_synth_gt8, dim3(stream_grid(*sh.dev, work, kBlock)), dim3(kBlock), 0, sh.dev->stream,
-                       reinterpret_cast<uint32_t*>(sh.d_gt), sh.pitch / 4, sh.n_loci, sh.n_genomes, seed, genome_base + sh.genome_base, locus_base, d_table);
-    int r = KGX_OK;
-    if (hipGetLastError() != hipSuccess) r = fail(KGX_EHIP, "synthetic genotype kernel launch failed");
-    if (r == KGX_OK && want_table &&
-        hipMemcpyAsync(af_table, d_table, sh.n_loci * KGX_SYNTH_MAX_ALTS * sizeof(double), hipMemcpyDeviceToHost, sh.dev->stream) != hipSuccess)
-      r = fail(KGX_EHIP, "D2H of the allele-frequency table failed");
-    if (r == KGX_OK && hipStreamSynchronize(sh.dev->stream) != hipSuccess) r = fail(KGX_EHIP, "synthetic genotype kernel failed");
-    if (d_table) (void)hipFree(d_table);
-    return r;
+  return guarded([&]() -> int {
+    if (int bound = require_bound()) return bound;
+    if (!h) return fail(KGX_EINVAL, "null handle");
+    if (h->n_loci == 0) return KGX_OK;
+    const int rc = for_each_parallel(h->shards.size(), [&](size_t s) -> int {
+      kgx_gt8_shard& sh = h->shards[s];
+      if (sh.n_genomes == 0) return KGX_OK;
+      if (int e = use_device(*sh.dev)) return e;
+      sh.wide_nibbles = 0;
+      const bool want_table = af_table && s == 0;               // the table does not depend on the genomes: the first shard writes it
+      double* d_table = nullptr;
+      if (want_table) KGX_HIP_MEM(hipMalloc(&d_table, sh.n_loci * KGX_SYNTH_MAX_ALTS * sizeof(double)));
+      const uint64_t work = sh.n_loci * ((sh.n_genomes + 3) / 4);
+      hipLaunchKernelGGL(k_synth_gt8, dim3(stream_grid(*sh.dev, work, kBlock)), dim3(kBlock), 0, sh.dev->stream,
+                         reinterpret_cast<uint32_t*>(sh.d_gt), sh.pitch / 4, sh.n_loci, sh.n_genomes, seed, genome_base + sh.genome_base, locus_base, d_table);
+      int r = KGX_OK;
+      if (hipGetLastError() != hipSuccess) r = fail(KGX_EHIP, "synthetic genotype kernel launch failed");
+      if (r == KGX_OK && want_table &&
+          hipMemcpyAsync(af_table, d_table, sh.n_loci * KGX_SYNTH_MAX_ALTS * sizeof(double), hipMemcpyDeviceToHost, sh.dev->stream) != hipSuccess)
+        r = fail(KGX_EHIP, "D2H of the allele-frequency table failed");
+      if (r == KGX_OK && hipStreamSynchronize(sh.dev->stream) != hipSuccess) r = fail(KGX_EHIP, "synthetic genotype kernel failed");
+      if (d_table) (void)hipFree(d_table);
+      return r;
+    });
+    (void)use_device(*h->shards[0].dev);
+    return rc;
   });
-  (void)use_device(*h->shards[0].dev);
-  return rc;
 }
 
 int kgx_synth_multiallelic_host(uint64_t seed, uint64_t genome_base, uint64_t n_genomes, uint64_t l0, uint64_t l1, uint8_t* gt8,
                                 uint64_t pitch, double* af_table, uint8_t* alleles) {
-  if (l0 > l1 || (gt8 && pitch < n_genomes)) return fail(KGX_EINVAL, "bad range or pitch");
-  for (uint64_t l = l0; l < l1; ++l) {
-    const kgx_synth_locus loc = kgx_synth_make_locus(seed, l);
-    if (af_table) {
-      double* row = af_table + (l - l0) * KGX_SYNTH_MAX_ALTS;
-      for (int a = 0; a < KGX_SYNTH_MAX_ALTS; ++a) row[a] = std::nan("");
-      for (int a = 0; a < loc.n_alt; ++a)
-        if (!loc.is_indel[a]) row[loc.snp_index[a] - 1] = static_cast<double>(loc.af[a]);
-    }
-    for (uint64_t g = 0; g < n_genomes; ++g) {
-      int a1, a2;
-      kgx_synth_multi_genotype(seed, l, genome_base + g, loc, a1, a2);
-      if (gt8) gt8[(l - l0) * pitch + g] = static_cast<uint8_t>(kgx_synth_gt8_byte(loc, a1, a2));
-      if (alleles) {
-        alleles[((l - l0) * n_genomes + g) * 2 + 0] = static_cast<uint8_t>(a1);
-        alleles[((l - l0) * n_genomes + g) * 2 + 1] = static_cast<uint8_t>(a2);
+  return guarded([&]() -> int {
+    if (l0 > l1 || (gt8 && pitch < n_genomes)) return fail(KGX_EINVAL, "bad range or pitch");
+    for (uint64_t l = l0; l < l1; ++l) {
+      const kgx_synth_locus loc = kgx_synth_make_locus(seed, l);
+      if (af_table) {
+        double* row = af_table + (l - l0) * KGX_SYNTH_MAX_ALTS;
+        for (int a = 0; a < KGX_SYNTH_MAX_ALTS; ++a) row[a] = std::nan("");
+        for (int a = 0; a < loc.n_alt; ++a)
+          if (!loc.is_indel[a]) row[loc.snp_index[a] - 1] = static_cast<double>(loc.af[a]);
+      }
+      for (uint64_t g = 0; g < n_genomes; ++g) {
+        int a1, a2;
+        kgx_synth_multi_genotype(seed, l, genome_base + g, loc, a1, a2);
+        if (gt8) gt8[(l - l0) * pitch + g] = static_cast<uint8_t>(kgx_synth_gt8_byte(loc, a1, a2));
+        if (alleles) {
+          alleles[((l - l0) * n_genomes + g) * 2 + 0] = static_cast<uint8_t>(a1);
+          alleles[((l - l0) * n_genomes + g) * 2 + 1] = static_cast<uint8_t>(a2);
+        }
       }
     }
-  }
-  return KGX_OK;
+    return KGX_OK;
+  });
 }
 
 int kgx_synth_locus_host(uint64_t seed, uint64_t l, int* n_alt, float af[3], int is_indel[3]) {
-  if (!n_alt || !af || !is_indel) return fail(KGX_EINVAL, "null argument");
-  const kgx_synth_locus loc = kgx_synth_make_locus(seed, l);
-  *n_alt = loc.n_alt;
-  for (int a = 0; a < KGX_SYNTH_MAX_ALTS; ++a) { af[a] = loc.af[a]; is_indel[a] = loc.is_indel[a]; }
-  return KGX_OK;
+  return guarded([&]() -> int {
+    if (!n_alt || !af || !is_indel) return fail(KGX_EINVAL, "null argument");
+    const kgx_synth_locus loc = kgx_synth_make_locus(seed, l);
+    *n_alt = loc.n_alt;
+    for (int a = 0; a < KGX_SYNTH_MAX_ALTS; ++a) { af[a] = loc.af[a]; is_indel[a] = loc.is_indel[a]; }
+    return KGX_OK;
+  });
 }
 
 int kgx_synth_loci_host(uint64_t seed, uint64_t l0, uint64_t l1, uint8_t* n_alt, float* af, uint8_t* is_indel) {
-  if (!n_alt || !af || !is_indel || l0 > l1) return fail(KGX_EINVAL, "bad argument");
-  for (uint64_t l = l0; l < l1; ++l) {
-    const kgx_synth_locus loc = kgx_synth_make_locus(seed, l);
-    n_alt[l - l0] = static_cast<uint8_t>(loc.n_alt);
-    for (int a = 0; a < KGX_SYNTH_MAX_ALTS; ++a) {
-      af[(l - l0) * KGX_SYNTH_MAX_ALTS + a] = loc.af[a];
-      is_indel[(l - l0) * KGX_SYNTH_MAX_ALTS + a] = static_cast<uint8_t>(loc.is_indel[a]);
+  return guarded([&]() -> int {
+    if (!n_alt || !af || !is_indel || l0 > l1) return fail(KGX_EINVAL, "bad argument");
+    for (uint64_t l = l0; l < l1; ++l) {
+      const kgx_synth_locus loc = kgx_synth_make_locus(seed, l);
+      n_alt[l - l0] = static_cast<uint8_t>(loc.n_alt);
+      for (int a = 0; a < KGX_SYNTH_MAX_ALTS; ++a) {
+        af[(l - l0) * KGX_SYNTH_MAX_ALTS + a] = loc.af[a];
+        is_indel[(l - l0) * KGX_SYNTH_MAX_ALTS + a] = static_cast<uint8_t>(loc.is_indel[a]);
+      }
     }
-  }
-  return KGX_OK;
+    return KGX_OK;
+  });
 }
 
 int kgx_gt8_synth_inbred(kgx_gt8* h, const double* minor_af, uint32_t amax, const double* inbreeding, uint64_t seed) {
-  if (int bound = require_bound()) return bound;
-  if (!h || !minor_af || !inbreeding) return fail(KGX_EINVAL, "null argument");
-  if (amax == 0 || amax > 14) return fail(KGX_EINVAL, "amax %u outside [1,14]", amax);
-  if (h->n_loci == 0) return KGX_OK;
-  const int rc = for_each_parallel(h->shards.size(), [&](size_t s) -> int {
-    kgx_gt8_shard& sh = h->shards[s];
-    if (sh.n_genomes == 0) return KGX_OK;
-    if (int e = use_device(*sh.dev)) return e;
-    sh.wide_nibbles = 0;
-    double *d_table = nullptr, *d_f = nullptr;
-    KGX_HIP_MEM(hipMalloc(&d_table, sh.n_loci * amax * sizeof(double)));
-    if (hipMalloc(&d_f, sh.n_genomes * sizeof(double)) != hipSuccess) { (void)hipGetLastError(); (void)hipFree(d_table); return fail(KGX_ENOMEM, "hipMalloc failed"); }
-    int r = KGX_OK;
-    if (hipMemcpyAsync(d_table, minor_af, sh.n_loci * amax * sizeof(double), hipMemcpyHostToDevice, sh.dev->stream) != hipSuccess ||
-        hipMemcpyAsync(d_f, inbreeding + sh.genome_base, sh.n_genomes * sizeof(double), hipMemcpyHostToDevice, sh.dev->stream) != hipSuccess)
-      r = fail(KGX_EHIP, "H2D of the allele-frequency table failed");
-    if (r == KGX_OK) {
-      hipLaunchKernelGGL(k_synth_inbred, dim3(stream_grid(*sh.dev, sh.n_loci * sh.n_genomes, kBlock)), dim3(kBlock), 0, sh.dev->stream, sh.d_gt,
-                         sh.pitch, sh.n_loci, sh.n_genomes, d_table, amax, d_f, seed, sh.genome_base);
-      if (hipGetLastError() != hipSuccess || hipStreamSynchronize(sh.dev->stream) != hipSuccess) r = fail(KGX_EHIP, "synthetic inbred genome kernel failed");
-    }
-    (void)hipFree(d_table);
-    (void)hipFree(d_f);
-    return r;
+  return guarded([&]() -> int {
+    if (int bound = require_bound()) return bound;
+    if (!h || !minor_af || !inbreeding) return fail(KGX_EINVAL, "null argument");
+    if (amax == 0 || amax > 14) return fail(KGX_EINVAL, "amax %u outside [1,14]", amax);
+    if (h->n_loci == 0) return KGX_OK;
+    const int rc = for_each_parallel(h->shards.size(), [&](size_t s) -> int {
+      kgx_gt8_shard& sh = h->shards[s];
+      if (sh.n_genomes == 0) return KGX_OK;
+      if (int e = use_device(*sh.dev)) return e;
+      sh.wide_nibbles = 0;
+      double *d_table = nullptr, *d_f = nullptr;
+      KGX_HIP_MEM(hipMalloc(&d_table, sh.n_loci * amax * sizeof(double)));
+      if (hipMalloc(&d_f, sh.n_genomes * sizeof(double)) != hipSuccess) { (void)hipGetLastError(); (void)hipFree(d_table); return fail(KGX_ENOMEM, "hipMalloc failed"); }
+      int r = KGX_OK;
+      if (hipMemcpyAsync(d_table, minor_af, sh.n_loci * amax * sizeof(double), hipMemcpyHostToDevice, sh.dev->stream) != hipSuccess ||
+          hipMemcpyAsync(d_f, inbreeding + sh.genome_base, sh.n_genomes * sizeof(double), hipMemcpyHostToDevice, sh.dev->stream) != hipSuccess)
+        r = fail(KGX_EHIP, "H2D of the allele-frequency table failed");
+      if (r == KGX_OK) {
+        hipLaunchKernelGGL(k_synth_inbred, dim3(stream_grid(*sh.dev, sh.n_loci * sh.n_genomes, kBlock)), dim3(kBlock), 0, sh.dev->stream, sh.d_gt,
+                           sh.pitch, sh.n_loci, sh.n_genomes, d_table, amax, d_f, seed, sh.genome_base);
+        if (hipGetLastError() != hipSuccess || hipStreamSynchronize(sh.dev->stream) != hipSuccess) r = fail(KGX_EHIP, "synthetic inbred genome kernel failed");
+      }
+      (void)hipFree(d_table);
+      (void)hipFree(d_f);
+      return r;
+    });
+    (void)use_device(*h->shards[0].dev);
+    return rc;
   });
-  (void)use_device(*h->shards[0].dev);
-  return rc;
 }
 
 }  // extern "C"

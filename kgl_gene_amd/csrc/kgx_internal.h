@@ -11,6 +11,8 @@
 
 #include <memory>
 #include <mutex>
+#include <new>
+#include <stdexcept>
 #include <string>
 #include <thread>
 #include <vector>
@@ -83,19 +85,33 @@ int scratch_reserve(Device& dev, size_t bytes, char** out);
 // Makes `dev` the calling thread's current HIP device.
 int use_device(const Device& dev);
 
+// No exception crosses the C ABI (or leaves a worker thread): host containers sized from caller or device values may throw.
+template <typename Fn>
+int guarded(Fn&& fn) noexcept {
+  try {
+    return fn();
+  } catch (const std::bad_alloc&) {
+    return fail(KGX_ENOMEM, "host allocation failed");
+  } catch (const std::length_error&) {
+    return fail(KGX_ENOMEM, "host allocation failed (size beyond the container's limit)");
+  } catch (const std::exception& e) {
+    return fail(KGX_ESTATE, "unexpected exception: %s", e.what());
+  }
+}
+
 // Run fn(i) for i in [0, n): inline when n == 1, otherwise one host thread per item (each shard drives its own device
 // and blocks on its own stream).  Returns the first non-zero code; the failing worker's message becomes this thread's.
 template <typename Fn>
 int for_each_parallel(size_t n, Fn&& fn) {
   if (n == 0) return KGX_OK;
-  if (n == 1) return fn(static_cast<size_t>(0));
+  if (n == 1) return guarded([&]() -> int { return fn(static_cast<size_t>(0)); });
   std::vector<int> codes(n, KGX_OK);
   std::vector<std::string> messages(n);
   std::vector<std::thread> workers;
   workers.reserve(n);
   for (size_t i = 0; i < n; ++i)
     workers.emplace_back([&, i]() {
-      codes[i] = fn(i);
+      codes[i] = guarded([&]() -> int { return fn(i); });         // an exception leaving a thread would end the process
       if (codes[i] != KGX_OK) messages[i] = last_error();
     });
   for (auto& w : workers) w.join();

@@ -248,92 +248,94 @@ int kgx_device_count(void) {
 }
 
 int kgx_init(int device_count, const int* device_ids) {
-  const int visible = kgx_device_count();
-  if (visible <= 0) return fail(KGX_ENODEVICE, "no HIP device visible (there is no CPU fallback)");
-  if (device_count < 0 || device_count > 64) return fail(KGX_EINVAL, "device_count %d outside [0,64]", device_count);
-  std::vector<int> ids;
-  if (device_count == 0) {
-    for (int d = 0; d < visible; ++d) ids.push_back(d);
-  } else {
-    for (int i = 0; i < device_count; ++i) ids.push_back(device_ids ? device_ids[i] : i);
-  }
-  bool distinct = true;
-  for (size_t i = 0; i < ids.size(); ++i) {
-    if (ids[i] < 0 || ids[i] >= visible) return fail(KGX_EINVAL, "device %d out of range [0,%d)", ids[i], visible);
-    for (size_t j = 0; j < i; ++j) distinct = distinct && ids[j] != ids[i];
-  }
-  const char* forced = std::getenv("KGX_EXCHANGE");            // "peer" | "rccl": tests and bring-up; default by the binding
-  Exchange exchange = ids.size() == 1 ? Exchange::None : (distinct ? Exchange::Rccl : Exchange::Peer);
-  if (forced && std::strcmp(forced, "peer") == 0 && ids.size() > 1) exchange = Exchange::Peer;
-  if (forced && std::strcmp(forced, "rccl") == 0) {
-    if (!distinct) return fail(KGX_EINVAL, "KGX_EXCHANGE=rccl: RCCL cannot span a binding that lists a device twice");
-    exchange = Exchange::Rccl;                                 // also with ONE slot: the all-reduce then runs over one rank
-  }
-  {
-    std::lock_guard<std::mutex> lock(g_binding_mutex);
-    const auto& now = binding();
-    if (now && now->exchange == exchange && now->devs.size() == ids.size()) {
-      bool same = true;
-      for (size_t i = 0; i < ids.size(); ++i) same = same && now->devs[i]->id == ids[i];
-      if (same) return hipSetDevice(ids[0]) == hipSuccess ? KGX_OK : fail(KGX_EHIP, "hipSetDevice(%d) failed", ids[0]);
+  return guarded([&]() -> int {
+    const int visible = kgx_device_count();
+    if (visible <= 0) return fail(KGX_ENODEVICE, "no HIP device visible (there is no CPU fallback)");
+    if (device_count < 0 || device_count > 64) return fail(KGX_EINVAL, "device_count %d outside [0,64]", device_count);
+    std::vector<int> ids;
+    if (device_count == 0) {
+      for (int d = 0; d < visible; ++d) ids.push_back(d);
+    } else {
+      for (int i = 0; i < device_count; ++i) ids.push_back(device_ids ? device_ids[i] : i);
     }
-  }
+    bool distinct = true;
+    for (size_t i = 0; i < ids.size(); ++i) {
+      if (ids[i] < 0 || ids[i] >= visible) return fail(KGX_EINVAL, "device %d out of range [0,%d)", ids[i], visible);
+      for (size_t j = 0; j < i; ++j) distinct = distinct && ids[j] != ids[i];
+    }
+    const char* forced = std::getenv("KGX_EXCHANGE");            // "peer" | "rccl": tests and bring-up; default by the binding
+    Exchange exchange = ids.size() == 1 ? Exchange::None : (distinct ? Exchange::Rccl : Exchange::Peer);
+    if (forced && std::strcmp(forced, "peer") == 0 && ids.size() > 1) exchange = Exchange::Peer;
+    if (forced && std::strcmp(forced, "rccl") == 0) {
+      if (!distinct) return fail(KGX_EINVAL, "KGX_EXCHANGE=rccl: RCCL cannot span a binding that lists a device twice");
+      exchange = Exchange::Rccl;                                 // also with ONE slot: the all-reduce then runs over one rank
+    }
+    {
+      std::lock_guard<std::mutex> lock(g_binding_mutex);
+      const auto& now = binding();
+      if (now && now->exchange == exchange && now->devs.size() == ids.size()) {
+        bool same = true;
+        for (size_t i = 0; i < ids.size(); ++i) same = same && now->devs[i]->id == ids[i];
+        if (same) return hipSetDevice(ids[0]) == hipSuccess ? KGX_OK : fail(KGX_EHIP, "hipSetDevice(%d) failed", ids[0]);
+      }
+    }
 
-  auto rt = std::make_shared<Runtime>();
-  rt->exchange = exchange;
-  for (size_t s = 0; s < ids.size(); ++s) {
-    KGX_HIP(hipSetDevice(ids[s]));
-    hipDeviceProp_t prop;
-    KGX_HIP(hipGetDeviceProperties(&prop, ids[s]));
-    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
-      return fail(KGX_ENODEVICE, "device %d is %s; this library is built for gfx950 only", ids[s], prop.gcnArchName);
-    auto dev = std::make_unique<Device>();
-    dev->slot = static_cast<int>(s);
-    dev->id = ids[s];
-    dev->compute_units = prop.multiProcessorCount;
-    dev->hbm_bytes = prop.totalGlobalMem;
-    std::snprintf(dev->name, sizeof(dev->name), "%s", prop.name);
-    std::snprintf(dev->arch, sizeof(dev->arch), "%s", prop.gcnArchName);
-    KGX_HIP(hipStreamCreateWithFlags(&dev->stream, hipStreamNonBlocking));
-    KGX_HIP(hipStreamCreateWithFlags(&dev->side_stream, hipStreamNonBlocking));
-    KGX_HIP(hipEventCreateWithFlags(&dev->side_begin, hipEventDisableTiming));
-    KGX_HIP(hipEventCreateWithFlags(&dev->side_end, hipEventDisableTiming));
-    KGX_HIP(hipEventCreate(&dev->sweep_begin));
-    KGX_HIP(hipEventCreate(&dev->sweep_end));
-    KGX_HIP(hipEventCreate(&dev->kernel_begin));
-    KGX_HIP(hipEventCreate(&dev->kernel_end));
-    KGX_HIP(hipEventCreateWithFlags(&dev->ready, hipEventDisableTiming));
-    KGX_HIP(hipEventCreate(&dev->by_genome_begin));
-    KGX_HIP(hipEventCreate(&dev->by_genome_end));
-    rt->devs.push_back(std::move(dev));
-  }
-  if (ids.size() > 1 && distinct) {
-    // direct loads / copies between the shards' devices (tables kept on one device, the peer exchange)
-    for (size_t a = 0; a < ids.size(); ++a) {
-      KGX_HIP(hipSetDevice(ids[a]));
-      for (size_t b = 0; b < ids.size(); ++b) {
-        if (a == b) continue;
-        int can = 0;
-        if (hipDeviceCanAccessPeer(&can, ids[a], ids[b]) == hipSuccess && can) {
-          const hipError_t e = hipDeviceEnablePeerAccess(ids[b], 0);
-          if (e != hipSuccess) (void)hipGetLastError();            // already enabled is fine
-        } else {
-          (void)hipGetLastError();
+    auto rt = std::make_shared<Runtime>();
+    rt->exchange = exchange;
+    for (size_t s = 0; s < ids.size(); ++s) {
+      KGX_HIP(hipSetDevice(ids[s]));
+      hipDeviceProp_t prop;
+      KGX_HIP(hipGetDeviceProperties(&prop, ids[s]));
+      if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(KGX_ENODEVICE, "device %d is %s; this library is built for gfx950 only", ids[s], prop.gcnArchName);
+      auto dev = std::make_unique<Device>();
+      dev->slot = static_cast<int>(s);
+      dev->id = ids[s];
+      dev->compute_units = prop.multiProcessorCount;
+      dev->hbm_bytes = prop.totalGlobalMem;
+      std::snprintf(dev->name, sizeof(dev->name), "%s", prop.name);
+      std::snprintf(dev->arch, sizeof(dev->arch), "%s", prop.gcnArchName);
+      KGX_HIP(hipStreamCreateWithFlags(&dev->stream, hipStreamNonBlocking));
+      KGX_HIP(hipStreamCreateWithFlags(&dev->side_stream, hipStreamNonBlocking));
+      KGX_HIP(hipEventCreateWithFlags(&dev->side_begin, hipEventDisableTiming));
+      KGX_HIP(hipEventCreateWithFlags(&dev->side_end, hipEventDisableTiming));
+      KGX_HIP(hipEventCreate(&dev->sweep_begin));
+      KGX_HIP(hipEventCreate(&dev->sweep_end));
+      KGX_HIP(hipEventCreate(&dev->kernel_begin));
+      KGX_HIP(hipEventCreate(&dev->kernel_end));
+      KGX_HIP(hipEventCreateWithFlags(&dev->ready, hipEventDisableTiming));
+      KGX_HIP(hipEventCreate(&dev->by_genome_begin));
+      KGX_HIP(hipEventCreate(&dev->by_genome_end));
+      rt->devs.push_back(std::move(dev));
+    }
+    if (ids.size() > 1 && distinct) {
+      // direct loads / copies between the shards' devices (tables kept on one device, the peer exchange)
+      for (size_t a = 0; a < ids.size(); ++a) {
+        KGX_HIP(hipSetDevice(ids[a]));
+        for (size_t b = 0; b < ids.size(); ++b) {
+          if (a == b) continue;
+          int can = 0;
+          if (hipDeviceCanAccessPeer(&can, ids[a], ids[b]) == hipSuccess && can) {
+            const hipError_t e = hipDeviceEnablePeerAccess(ids[b], 0);
+            if (e != hipSuccess) (void)hipGetLastError();            // already enabled is fine
+          } else {
+            (void)hipGetLastError();
+          }
         }
       }
     }
-  }
-  if (exchange == Exchange::Rccl) {
-    if (int rc = load_rccl()) return rc;
-    std::vector<ncclComm_t> comms(ids.size(), nullptr);
-    const ncclResult_t rc = g_rccl.CommInitAll(comms.data(), static_cast<int>(ids.size()), ids.data());
-    if (rc != ncclSuccess) return fail(KGX_EHIP, "ncclCommInitAll over %zu devices failed: %s", ids.size(), g_rccl.GetErrorString(rc));
-    for (ncclComm_t c : comms) rt->comms.push_back(c);
-  }
-  KGX_HIP(hipSetDevice(ids[0]));
-  std::lock_guard<std::mutex> lock(g_binding_mutex);
-  binding() = std::move(rt);
-  return KGX_OK;
+    if (exchange == Exchange::Rccl) {
+      if (int rc = load_rccl()) return rc;
+      std::vector<ncclComm_t> comms(ids.size(), nullptr);
+      const ncclResult_t rc = g_rccl.CommInitAll(comms.data(), static_cast<int>(ids.size()), ids.data());
+      if (rc != ncclSuccess) return fail(KGX_EHIP, "ncclCommInitAll over %zu devices failed: %s", ids.size(), g_rccl.GetErrorString(rc));
+      for (ncclComm_t c : comms) rt->comms.push_back(c);
+    }
+    KGX_HIP(hipSetDevice(ids[0]));
+    std::lock_guard<std::mutex> lock(g_binding_mutex);
+    binding() = std::move(rt);
+    return KGX_OK;
+  });
 }
 
 int kgx_bound_devices(void) {
@@ -348,15 +350,17 @@ const char* kgx_exchange_kind(void) {
 }
 
 int kgx_device_info(int slot, char* name, size_t name_len, char* arch, size_t arch_len, int* compute_units, uint64_t* hbm_bytes) {
-  if (int rc = require_bound()) return rc;
-  const auto rt = current_runtime();
-  if (slot < 0 || static_cast<size_t>(slot) >= rt->devs.size()) return fail(KGX_EINVAL, "slot %d outside [0,%zu)", slot, rt->devs.size());
-  const Device& dev = *rt->devs[static_cast<size_t>(slot)];
-  if (name && name_len) std::snprintf(name, name_len, "%s", dev.name);
-  if (arch && arch_len) std::snprintf(arch, arch_len, "%s", dev.arch);
-  if (compute_units) *compute_units = dev.compute_units;
-  if (hbm_bytes) *hbm_bytes = dev.hbm_bytes;
-  return KGX_OK;
+  return guarded([&]() -> int {
+    if (int rc = require_bound()) return rc;
+    const auto rt = current_runtime();
+    if (slot < 0 || static_cast<size_t>(slot) >= rt->devs.size()) return fail(KGX_EINVAL, "slot %d outside [0,%zu)", slot, rt->devs.size());
+    const Device& dev = *rt->devs[static_cast<size_t>(slot)];
+    if (name && name_len) std::snprintf(name, name_len, "%s", dev.name);
+    if (arch && arch_len) std::snprintf(arch, arch_len, "%s", dev.arch);
+    if (compute_units) *compute_units = dev.compute_units;
+    if (hbm_bytes) *hbm_bytes = dev.hbm_bytes;
+    return KGX_OK;
+  });
 }
 
 void* kgx_stream(int slot) {
@@ -366,35 +370,39 @@ void* kgx_stream(int slot) {
 }
 
 int kgx_synchronize(void) {
-  if (int rc = require_bound()) return rc;
-  const auto rt = current_runtime();
-  for (const auto& dev : rt->devs) {
-    if (int rc = use_device(*dev)) return rc;
-    KGX_HIP(hipStreamSynchronize(dev->stream));
-    KGX_HIP(hipDeviceSynchronize());
-  }
-  return use_device(*rt->devs[0]);
+  return guarded([&]() -> int {
+    if (int rc = require_bound()) return rc;
+    const auto rt = current_runtime();
+    for (const auto& dev : rt->devs) {
+      if (int rc = use_device(*dev)) return rc;
+      KGX_HIP(hipStreamSynchronize(dev->stream));
+      KGX_HIP(hipDeviceSynchronize());
+    }
+    return use_device(*rt->devs[0]);
+  });
 }
 
 int kgx_release_scratch(void) {
-  const auto rt = current_runtime();
-  if (!rt) return KGX_OK;
-  for (const auto& dev : rt->devs) {
-    std::lock_guard<std::mutex> lock(dev->mutex);
-    if (use_device(*dev) != KGX_OK) continue;
-    if (dev->scratch) {
-      if (dev->stream) (void)hipStreamSynchronize(dev->stream);
-      (void)hipFree(dev->scratch);
+  return guarded([&]() -> int {
+    const auto rt = current_runtime();
+    if (!rt) return KGX_OK;
+    for (const auto& dev : rt->devs) {
+      std::lock_guard<std::mutex> lock(dev->mutex);
+      if (use_device(*dev) != KGX_OK) continue;
+      if (dev->scratch) {
+        if (dev->stream) (void)hipStreamSynchronize(dev->stream);
+        (void)hipFree(dev->scratch);
+      }
+      dev->scratch = nullptr;
+      dev->scratch_bytes = 0;
+      for (int k = 0; k < 2; ++k) {
+        if (dev->compact[k]) (void)hipFree(dev->compact[k]);
+        dev->compact[k] = nullptr;
+        dev->compact_bytes[k] = 0;
+      }
     }
-    dev->scratch = nullptr;
-    dev->scratch_bytes = 0;
-    for (int k = 0; k < 2; ++k) {
-      if (dev->compact[k]) (void)hipFree(dev->compact[k]);
-      dev->compact[k] = nullptr;
-      dev->compact_bytes[k] = 0;
-    }
-  }
-  return use_device(*rt->devs[0]);
+    return use_device(*rt->devs[0]);
+  });
 }
 
 }  // extern "C"

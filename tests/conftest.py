@@ -19,16 +19,11 @@ def kgx():
     from kgl_gene_amd import capi
 
     capi.ensure_built()
-    # torch (the plumbing a few tests and bench.py use for device buffers) sets its HIP context up first, once: after
-    # tens of GB of library allocations and several device rebinds its lazy initialisation has been seen to find no device
-    try:
-        import torch
-
-        if torch.cuda.is_available():
-            torch.cuda.init()
-    except ImportError:
-        pass
+    # capi.lib() loads torch (plumbing of a few tests) BEFORE libkgx.so, so that the process holds one HIP runtime: with
+    # libkgx.so first the torch wheel's bundled libamdhip64 is mapped beside the system's and torch finds no device
+    # (capi._one_hip_runtime; tests/test_capi_cpu.py::test_one_hip_runtime_whatever_the_import_order).
     capi.lib()
+    assert len(capi.hip_runtimes_mapped()) == 1, capi.hip_runtimes_mapped()
     if capi.device_count() <= 0:
         pytest.fail("no HIP device visible: -m gpu tests must run on the GPU box")
     capi.init(0)

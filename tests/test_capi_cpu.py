@@ -79,3 +79,33 @@ def test_fws_bin_edges():
     assert fws_bin_of_variant(af, carried=np.zeros(len(af), bool)).tolist() == [NO_BIN] * len(af)
     # float32(0.1) = 0.100000001490116 >= 0.1 -> bin 2, exactly as the reference's widened compare
     assert np.float64(np.float32(0.1)) >= 0.1
+
+
+def test_one_hip_runtime_whatever_the_import_order():
+    """The cause behind an old workaround in conftest.py ("torch initialised first"): the torch wheel bundles its own
+    libamdhip64 / libhsa-runtime64, libkgx.so links the system's.  Loaded torch-first the loader reuses the mapped copy
+    (same SONAME); loaded libkgx-first, torch maps its bundled copy as well and the process holds two HIP runtimes, the
+    second of which finds no device.  capi.lib() therefore loads torch first.  Checked in fresh interpreters."""
+    import sys
+    import textwrap
+
+    probe = textwrap.dedent("""
+        import ctypes, sys
+        sys.path.insert(0, {root!r})
+        from kgl_gene_amd import capi
+        {body}
+        print(len(capi.hip_runtimes_mapped()), *capi.hip_runtimes_mapped())
+    """)
+    root = str(capi.ROOT) if hasattr(capi, "ROOT") else str(capi.LIB_PATH.parent.parent.parent)
+    cases = {
+        "capi then torch": "capi.lib(); import torch",
+        "torch then capi": "import torch; capi.lib()",
+        # what the old order did: libkgx.so by itself first, torch afterwards -> two runtimes
+        "raw libkgx then torch": "ctypes.CDLL(str(capi.LIB_PATH)); import torch",
+    }
+    counts = {}
+    for name, body in cases.items():
+        out = subprocess.run([sys.executable, "-c", probe.format(root=root, body=body)], capture_output=True, text=True, check=True).stdout
+        counts[name] = int(out.split()[0])
+    assert counts["capi then torch"] == 1 and counts["torch then capi"] == 1, counts
+    assert counts["raw libkgx then torch"] == 2, counts          # the hazard is real on this image: the guard is what removes it

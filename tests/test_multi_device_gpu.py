@@ -68,6 +68,14 @@ def dosage_results(kgx, G, V, codes, bins, n_bins, groups):
     want_k3 = np.stack([(codes[present] == k).sum(0) for k in range(4)], 1).astype(np.uint64)
     want_k3[keep == 0] = 0
     assert np.array_equal(out["k3_masked"], want_k3)
+    # the population summary leaves each shard's LOCAL counts in the buffer the by-genome sweep reads the population's
+    # counts from (which rows still have a kept carrier): the sweep after it must count afresh, not trust that buffer
+    out["offset_filters_masked"] = pop.offset_filter_counts(single_bin, members, starts, count, gbin, 3)
+    assert np.array_equal(pop.allele_count_by_locus(), out["k2_masked"])
+    out["k4_masked"] = pop.population_summary()
+    assert np.array_equal(out["k4_masked"], out["k2_masked"].sum(0).astype(np.uint64))
+    assert np.array_equal(pop.count_by_genome(), want_k3)
+    assert np.array_equal(pop.offset_filter_counts(single_bin, members, starts, count, gbin, 3), out["offset_filters_masked"])
     pop.set_genome_mask(None)
     assert np.array_equal(pop.allele_count_by_locus(), out["k2"])
     extra = V // 3
@@ -103,10 +111,47 @@ def test_sharded_dosage_sweeps_equal_the_unsharded_ones(kgx, rebind, slots, G):
     assert all(s["genome_base"] % 64 == 0 for s in shards if s["n_genomes"])
     assert [s["genome_base"] for s in shards] == list(np.cumsum([0] + [s["n_genomes"] for s in shards[:-1]]))
     for key in ("rows", "k2", "k4", "k3", "k3_binned", "k8", "k8_listed", "k3_af_bins", "k2_grown", "k3_grown", "k2_masked", "k3_masked",
-                "k3_binned_masked", "k3_af_bins_masked", "k8_masked", "offset_filters", "row_lists_begin", "row_lists"):
+                "k3_binned_masked", "k3_af_bins_masked", "k8_masked", "k4_masked", "offset_filters_masked", "offset_filters", "row_lists_begin", "row_lists"):
         assert np.array_equal(got[key], want[key]), key
     assert np.array_equal(want["k8_listed"], want["k8"])
     assert np.array_equal(want["k2_grown"][:V], want["k2"]) and np.array_equal(want["k2_grown"][V:], want["k2"][:V // 3])
+
+
+def test_two_distinct_devices_exchange_over_rccl(kgx, rebind):
+    """kgx_init(2, {0, 1}): two real devices, communicators from ncclCommInitAll over both, the K2 counts summed by a grouped
+    in-place ncclAllReduce from one thread on the two slots' streams (Exchange::Rccl with n > 1) -- what a multi-GPU node
+    runs.  K2/K3/K4/K8, the masked sweeps, the row lists and the inbreeding sweeps against the unsharded results.  Skipped
+    on a one-GPU box (the test boxes so far): the multi-rank RCCL path is then NOT verified on hardware."""
+    if kgx.device_count() < 2:
+        pytest.skip("needs two visible MI355X devices")
+    rng = np.random.default_rng(11)
+    G, V = 4099, 1500
+    codes = rng.choice(4, size=(V, G), p=[0.6, 0.25, 0.13, 0.02]).astype(np.uint8)
+    bins = rng.integers(0, 11, V).astype(np.uint8)
+    first = np.arange(0, V - 3, 7, dtype=np.uint32)
+    groups = (first, np.full(len(first), 3, dtype=np.uint32), (first % 3).astype(np.uint32))
+    want = dosage_results(kgx, G, V, codes, bins, 11, groups)
+    one = kgx.GenotypeMatrix(700, 3000)
+    table = one.synth_multiallelic(1111, 0, 0)
+    want_inbreed = {a: one.inbreed(table, a, phased=True) for a in ("Simple", "HallME", "Loglikelihood")}
+    one.close()
+    rebind([0, 1])
+    assert kgx.bound_devices() == 2 and kgx.exchange_kind() == "rccl"
+    got = dosage_results(kgx, G, V, codes, bins, 11, groups)
+    assert len(got["shards"]) == 2 and {s["slot"] for s in got["shards"]} == {0, 1}
+    for key in want:
+        if key != "shards":
+            assert np.array_equal(got[key], want[key]), key
+    many = kgx.GenotypeMatrix(700, 3000)
+    many.synth_multiallelic(1111, 0, 0)
+    for algorithm, wanted in want_inbreed.items():
+        result = many.inbreed(table, algorithm, phased=True)
+        for name in wanted.dtype.names:
+            if name.endswith("_count"):
+                assert np.array_equal(result[name], wanted[name]), (algorithm, name)
+            else:
+                assert np.allclose(result[name], wanted[name], rtol=1e-11, atol=1e-11), (algorithm, name)
+    many.close()
 
 
 def test_sharded_loaders_and_synthetic_population(kgx, rebind):
@@ -298,7 +343,7 @@ def test_bench_two_ranks_rehearsal_on_one_device(tmp_path, workload):
     env = dict(os.environ, KGX_BENCH_REHEARSAL="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
     for key in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT"):
         env.pop(key, None)
-    shape = ["--genomes", "3000", "--variants", "300000"] if workload == "c3" else ["--workload", "c5", "--genomes", "1500", "--variants", "100000"]
+    shape = ["--genomes", "3000", "--variants", "300000", "--c4-genomes", "5001"] if workload == "c3" else ["--workload", "c5", "--genomes", "1500", "--variants", "100000"]
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port",
            "29541" if workload == "c3" else "29542", str(root / "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--no-cpu-baseline", *shape]
     res = subprocess.run(cmd, env=env, cwd=str(tmp_path), capture_output=True, text=True, timeout=600)
@@ -310,5 +355,12 @@ def test_bench_two_ranks_rehearsal_on_one_device(tmp_path, workload):
     assert record["scaling"] == "weak" and record["vs_baseline"] is None
     if workload == "c3":
         assert record["config"]["total_genomes"] == 2 * record["config"]["genomes_per_gpu"] == 6000
-        assert record["config"]["exchange"].startswith("gloo rehearsal") and record["config"]["exchange_check"].endswith("ok")
+        assert record["config"]["exchange"].startswith("gloo rehearsal") and "MISMATCH" not in record["config"]["exchange_check"]
+        assert "all 300000 variants" in record["config"]["exchange_check"]
+        assert record["config"]["distributed"] == {"world_size": 2, "backend": "gloo", "kgx_exchange_kind": "none", "kgx_bound_devices": 1}
+        # ... and north_star's strong-scaled job beside it: one population split over the ranks, the same step
+        strong = record["aux"]["c4_strong"]
+        assert strong["scaling"] == "strong" and strong["n_gpus"] == 2 and strong["config"]["total_genomes"] == 5001
+        assert strong["config"]["genomes_per_gpu"] in (2500, 2501, 2504) and "MISMATCH" not in strong["config"]["exchange_check"]
+        assert abs(strong["value"] - 5001 * 300000 * 3 / (strong["ms_per_step"] * 3e-3)) <= 1e-6 * strong["value"]
         assert abs(record["value"] - 6000 * 300000 * 3 / (record["ms_per_step"] * 3e-3)) <= 1e-6 * record["value"]

@@ -70,6 +70,10 @@ def test_gpu_allele_package_disables_itself_on_bad_device(tmp_path, kgx):
     rio.write_records(path, rec, gt, sv.genome_ids(4), oa.Population.UNPHASED, "Falciparum")
     res = rio.run_driver("GPU_ALLELE", tmp_path, [path], Device=99)
     assert res.returncode == 1 and "initializeAnalysis failed" in res.stderr
+    # a malformed device list disables the package the same way (no exception out of initializeAnalysis)
+    for bad in ("0,a", "x", "0,-1", "99999999999999999999"):
+        res = rio.run_driver("GPU_ALLELE", tmp_path, [path], DeviceList=bad)
+        assert res.returncode == 1 and "initializeAnalysis failed" in res.stderr, (bad, res.returncode, res.stderr[-300:])
 
 
 @pytest.mark.parametrize("algorithm,mode,source,binding", [("Simple", oa.Population.PHASED, "Genome1000", {}),
