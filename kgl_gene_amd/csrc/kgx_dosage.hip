@@ -126,12 +126,48 @@ int sweep_and_exchange(kgx_pop* pop, void* d_out0, hipStream_t stream0, bool own
 
 // ---- K3 host glue -----------------------------------------------------------------------------
 
+struct ByGenomeShape { uint32_t n_cg, cg_width; };
+
+// The chunk columns of a row cut into column groups of at most 64 chunks (a lane owns one), whole 128-byte lines each
+// and as equal as that allows: 160 chunks (10,000 genomes) = 56 + 56 + 48 rather than 64 + 64 + 32.
+ByGenomeShape by_genome_shape(uint32_t chunks_per_row) {
+  ByGenomeShape shape;
+  shape.n_cg = (chunks_per_row + 63) / 64;
+  if (shape.n_cg <= 1) { shape.n_cg = 1; shape.cg_width = 64; return shape; }
+  const uint32_t lines = (chunks_per_row + 7) / 8;
+  shape.cg_width = (lines + shape.n_cg - 1) / shape.n_cg * 8;
+  return shape;
+}
+
 template <int W>
-void launch_by_genome(const kgx_pop_shard& sh, const uint32_t* d_index, const GenomeWork* d_work,
-                      uint32_t n_work, uint32_t n_bins, unsigned long long* d_acc) {
+int launch_by_genome(const kgx_pop_shard& sh, ByGenomeShape shape, const uint32_t* d_index, const GenomeWork* d_work, uint32_t n_work,
+                     const unsigned long long* d_binoff, uint32_t n_bins, uint32_t* d_acc, int* resident_per_cu) {
+  if (resident_per_cu) {                                     // how many of these workgroups a CU holds at once (registers, LDS)
+    int blocks = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, k_count_by_genome<W>, kBlock, 0) != hipSuccess || blocks <= 0) {
+      (void)hipGetLastError();
+      blocks = 3;
+    }
+    *resident_per_cu = blocks;
+    return KGX_OK;
+  }
   hipLaunchKernelGGL((k_count_by_genome<W>), dim3(n_work), dim3(kBlock), 0, sh.dev->stream,
-                     reinterpret_cast<const kgx_v4u*>(sh.d_rows), sh.chunks_per_row, sh.n_genomes,
-                     d_index, d_work, n_bins, d_acc);
+                     reinterpret_cast<const kgx_v4u*>(sh.d_rows), sh.chunks_per_row, shape.cg_width,
+                     d_index, d_work, d_binoff, n_bins, shape.n_cg, d_acc);
+  return KGX_OK;
+}
+
+template <typename... Args>
+int dispatch_by_genome(int W, Args... args) {
+  switch (W) {
+    case 1:  return launch_by_genome<1>(args...);
+    case 2:  return launch_by_genome<2>(args...);
+    case 4:  return launch_by_genome<4>(args...);
+    case 8:  return launch_by_genome<8>(args...);
+    case 16: return launch_by_genome<16>(args...);
+    case 32: return launch_by_genome<32>(args...);
+    default: return launch_by_genome<64>(args...);
+  }
 }
 
 // One shard's by-genome sweep; out = the shard's block [n_genomes][n_bins][4] of the caller's array.
@@ -148,8 +184,8 @@ int count_by_genome_shard(kgx_pop_shard& sh, const uint8_t* bin_of_variant, uint
   const bool identity = bin_of_variant == nullptr && bin_edges == nullptr && !masked;
   hipStream_t st = dev.stream;
 
-  unsigned long long *d_acc = nullptr, *d_out = nullptr, *d_nbin = nullptr, *d_binoff = nullptr;
-  uint32_t *d_index = nullptr, *d_chunks = nullptr;
+  unsigned long long *d_out = nullptr, *d_nbin = nullptr, *d_binoff = nullptr;
+  uint32_t *d_index = nullptr, *d_chunks = nullptr, *d_acc = nullptr;
   uint8_t* d_bins = nullptr;
   GenomeWork* d_work = nullptr;
   int rc = KGX_OK;
@@ -162,22 +198,31 @@ int count_by_genome_shard(kgx_pop_shard& sh, const uint8_t* bin_of_variant, uint
   // every buffer of the call out of the device's arena; the work list's size is bounded before the bins are known:
   // about `target` items, one more per (bin, column group) for the bins' last pieces
   const uint32_t n_chunks = static_cast<uint32_t>((V + kBinChunk - 1) / kBinChunk);
-  const uint32_t n_cg = (sh.chunks_per_row + 63) / 64;
-  const uint64_t target = static_cast<uint64_t>(dev.compute_units) * 10u;
-  const uint64_t max_work = target + (static_cast<uint64_t>(n_bins) + 2) * n_cg + 64;
+  const ByGenomeShape shape = by_genome_shape(sh.chunks_per_row);
+  const uint32_t n_cg = shape.n_cg;
+  const int W = lanes_per_row(sh.chunks_per_row);
+  // Work items: equal stretches of the bin-grouped row list, one column group each, KGX_K3_ROUNDS (default 1) per workgroup
+  // the device holds at once -- every item runs from the start of the kernel to its end, none is left for a thin last round.
+  int resident_per_cu = 0;
+  (void)dispatch_by_genome(W, sh, shape, static_cast<const uint32_t*>(nullptr), static_cast<const GenomeWork*>(nullptr), 0u,
+                           static_cast<const unsigned long long*>(nullptr), n_bins, static_cast<uint32_t*>(nullptr), &resident_per_cu);
+  const int rounds = std::max(1, env_int("KGX_K3_ROUNDS", 1));
+  const uint64_t target = static_cast<uint64_t>(dev.compute_units) * static_cast<uint64_t>(resident_per_cu) * static_cast<uint64_t>(rounds);
+  const uint64_t max_work = target + 2ull * n_cg + 64;
+  const uint64_t acc_words = static_cast<uint64_t>(n_bins) * n_cg * kAccCounters * kLdsStride;
   ScratchPlan plan;
-  const size_t o_acc = plan.add((cells ? cells : 1) * 3 * sizeof(unsigned long long)), o_out = plan.add((cells ? cells : 1) * 4 * sizeof(unsigned long long));
+  const size_t o_acc = plan.add(acc_words * sizeof(uint32_t)), o_out = plan.add((cells ? cells : 1) * 4 * sizeof(unsigned long long));
   const size_t o_nbin = plan.add(n_bins * sizeof(unsigned long long)), o_binoff = plan.add((n_bins + 1) * sizeof(unsigned long long));
   const size_t o_bins = plan.add(identity ? 0 : V), o_index = plan.add(identity ? 0 : (V + 8) * sizeof(uint32_t));
   const size_t o_chunks = plan.add(identity ? 0 : static_cast<uint64_t>(n_chunks) * n_bins * sizeof(uint32_t)), o_work = plan.add(max_work * sizeof(GenomeWork));
   char* arena = nullptr;
   if (int arc = scratch_reserve(dev, plan.total, &arena)) return arc;
-  d_acc = reinterpret_cast<unsigned long long*>(arena + o_acc);
+  d_acc = reinterpret_cast<uint32_t*>(arena + o_acc);
   d_out = reinterpret_cast<unsigned long long*>(arena + o_out);
   d_nbin = reinterpret_cast<unsigned long long*>(arena + o_nbin);
   d_binoff = reinterpret_cast<unsigned long long*>(arena + o_binoff);
   d_work = reinterpret_cast<GenomeWork*>(arena + o_work);
-  try_hip(hipMemsetAsync(d_acc, 0, (cells ? cells : 1) * 3 * sizeof(unsigned long long), st), KGX_EHIP, "memset(acc)");
+  try_hip(hipMemsetAsync(d_acc, 0, acc_words * sizeof(uint32_t), st), KGX_EHIP, "memset(acc)");
 
   // Rows grouped by bin, so that a workgroup only ever touches one bin: on the device (k_bin_count / _scan / _scatter).
   std::vector<unsigned long long> bin_offset(n_bins + 1, 0);
@@ -185,6 +230,7 @@ int count_by_genome_shard(kgx_pop_shard& sh, const uint8_t* bin_of_variant, uint
     bin_offset[1] = V;
     const unsigned long long v = V;
     try_hip(hipMemcpyAsync(d_nbin, &v, sizeof(v), hipMemcpyHostToDevice, st), KGX_EHIP, "H2D(rows_in_bin)");
+    try_hip(hipMemcpyAsync(d_binoff, bin_offset.data(), 2 * sizeof(unsigned long long), hipMemcpyHostToDevice, st), KGX_EHIP, "H2D(bin offsets)");
     try_hip(hipStreamSynchronize(st), KGX_EHIP, "sync");
   } else if (V > 0) {
     d_bins = reinterpret_cast<uint8_t*>(arena + o_bins);
@@ -220,44 +266,37 @@ int count_by_genome_shard(kgx_pop_shard& sh, const uint8_t* bin_of_variant, uint
   bool timed = false;
 
   if (rc == KGX_OK && selected > 0) {
-    const int W = lanes_per_row(sh.chunks_per_row);
     const uint64_t gran = static_cast<uint64_t>(64 / W) * (kBlock / kWave) * 8;
-    uint64_t per_wg = (selected * n_cg + target - 1) / target;
+    uint64_t pieces = target / n_cg;                          // stretches of the row list; each becomes n_cg items
+    if (pieces < 1) pieces = 1;
+    uint64_t per_wg = (selected + pieces - 1) / pieces;
     per_wg = (per_wg + gran - 1) / gran * gran;
     if (per_wg < gran * 4) per_wg = gran * 4;
     std::vector<GenomeWork> work;
-    for (uint32_t b = 0; b < n_bins; ++b)
-      for (uint64_t p = bin_offset[b]; p < bin_offset[b + 1]; p += per_wg)
-        for (uint32_t cg = 0; cg < n_cg; ++cg) {
-          GenomeWork w;
-          w.begin = p;
-          w.end = (p + per_wg < bin_offset[b + 1]) ? p + per_wg : bin_offset[b + 1];
-          w.col_group = cg;
-          w.bin = b;
-          work.push_back(w);
-        }
+    for (uint64_t p = 0; p < selected; p += per_wg)
+      for (uint32_t cg = 0; cg < n_cg; ++cg) {                // neighbours in the launch order read the same rows
+        GenomeWork w;
+        w.begin = p;
+        w.end = p + per_wg < selected ? p + per_wg : selected;
+        w.col_group = cg;
+        w.pad = 0;
+        work.push_back(w);
+      }
     if (rc == KGX_OK && work.size() > max_work) rc = fail(KGX_ESTATE, "count_by_genome: %zu work items exceed the %llu reserved", work.size(), (unsigned long long)max_work);
     try_hip(hipMemcpyAsync(d_work, work.data(), work.size() * sizeof(GenomeWork), hipMemcpyHostToDevice, st), KGX_EHIP, "H2D(work)");
     try_hip(hipStreamSynchronize(st), KGX_EHIP, "sync");     // `work` is pageable host memory
     if (rc == KGX_OK) {
       const uint32_t n_work = static_cast<uint32_t>(work.size());
       try_hip(hipEventRecord(dev.by_genome_begin, st), KGX_EHIP, "hipEventRecord");
-      switch (W) {
-        case 1:  launch_by_genome<1>(sh, d_index, d_work, n_work, n_bins, d_acc); break;
-        case 2:  launch_by_genome<2>(sh, d_index, d_work, n_work, n_bins, d_acc); break;
-        case 4:  launch_by_genome<4>(sh, d_index, d_work, n_work, n_bins, d_acc); break;
-        case 8:  launch_by_genome<8>(sh, d_index, d_work, n_work, n_bins, d_acc); break;
-        case 16: launch_by_genome<16>(sh, d_index, d_work, n_work, n_bins, d_acc); break;
-        case 32: launch_by_genome<32>(sh, d_index, d_work, n_work, n_bins, d_acc); break;
-        default: launch_by_genome<64>(sh, d_index, d_work, n_work, n_bins, d_acc); break;
-      }
+      (void)dispatch_by_genome(W, sh, shape, static_cast<const uint32_t*>(d_index), static_cast<const GenomeWork*>(d_work), n_work,
+                               static_cast<const unsigned long long*>(d_binoff), n_bins, d_acc, static_cast<int*>(nullptr));
       try_hip(hipGetLastError(), KGX_EHIP, "k_count_by_genome launch");
       try_hip(hipEventRecord(dev.by_genome_end, st), KGX_EHIP, "hipEventRecord");
       timed = rc == KGX_OK;
     }
   }
   if (rc == KGX_OK && cells > 0) {
-    hipLaunchKernelGGL(k_finish_by_genome, dim3(stream_grid(dev, cells, kBlock)), dim3(kBlock), 0, st, d_acc, d_nbin, G, n_bins, d_out);
+    hipLaunchKernelGGL(k_finish_by_genome, dim3(stream_grid(dev, cells, kBlock)), dim3(kBlock), 0, st, d_acc, d_nbin, G, n_bins, n_cg, shape.cg_width, d_out);
     try_hip(hipGetLastError(), KGX_EHIP, "k_finish_by_genome launch");
     try_hip(hipMemcpyAsync(out, d_out, cells * 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost, st), KGX_EHIP, "D2H(out)");
     try_hip(hipStreamSynchronize(st), KGX_EHIP, "stream synchronize");

@@ -164,17 +164,23 @@ k_sum_counts(const kgx_v4u* __restrict__ counts, uint64_t n, unsigned long long*
 // rows ("positional popcount").  Streams are counted bit-sliced: a carry-save adder tree folds 8
 // rows into weight-1/2/4 planes and ripples one weight-8 carry word into HI planes, ~6 VALU ops per
 // input word instead of one add per genome.  Planes are unpacked into per-workgroup LDS counters
-// every 255 blocks, and LDS goes to HBM with integer atomics once per workgroup: exact in any order.
+// every 510 blocks, and LDS goes to the accumulators with integer atomics once per (workgroup, bin): exact in any order.
 //
-// Accumulates raw stream counts acc[g][bin] = { #(code&1), #(code&2), #(code==3) }; k_finish_by_genome
-// turns them into the reference's { refHom, het, minorHom, nonDiploid }.
+// The accumulators keep the LDS image's own layout -- acc[bin][column group][counter][lane], uint32 (a count is at most
+// the number of rows, < 2^32) -- so a wave's 64 atomics fall on 256 consecutive bytes instead of 64 lines 17 KB apart
+// (genome-major uint64 accumulators: 500 MB of write traffic per C3 sweep for 3.5 MB of results).  A work item is a
+// stretch of the bin-grouped row list for one column group and may run across bin boundaries (it flushes at each), so
+// the list is cut into equal stretches, about one per resident workgroup, whatever the bins' sizes.
+// Raw stream counts { #(code&1), #(code&2), #(code==3) }; k_finish_by_genome turns them into the reference's
+// { refHom, het, minorHom, nonDiploid } per genome and bin.
 // ---------------------------------------------------------------------------------------------
 struct GenomeWork {
-  uint64_t begin;       // first position in the selected-row list
+  uint64_t begin;       // first position in the selected-row list (rows grouped by bin)
   uint64_t end;         // one past the last position
-  uint32_t col_group;   // 64-chunk column group (genomes [4096*col_group, ...))
-  uint32_t bin;         // output bin
+  uint32_t col_group;   // chunk columns [col_group * cg_width, +cg_width)
+  uint32_t pad;
 };
+constexpr int kAccCounters = 192;            // per (bin, column group): 128 stream counters + 64 non-diploid ones, x kLdsStride lanes
 
 constexpr int kHiPlanes = 8;                 // weights 16 .. 2048
 constexpr int kBlocksPerFlush = 510;         // blocks of 8 rows: 510*8 + 15 < 16 * 2^kHiPlanes
@@ -235,15 +241,15 @@ struct SlicedCounters {
 // MODE 1: two words of (code==3) indicators: word0 = t(dw0) | t(dw1)<<1, word1 = t(dw2) | t(dw3)<<1.
 template <int W, int MODE>
 __device__ __forceinline__ void by_genome_pass(const kgx_v4u* __restrict__ rows, uint32_t chunks_per_row,
-                                               const uint32_t* __restrict__ row_index,
+                                               const uint32_t* __restrict__ row_index, uint32_t cg_width,
                                                const GenomeWork wk, uint32_t* lds, uint32_t& saw_nondiploid) {
   constexpr int NW = MODE == 0 ? 4 : 2;
   constexpr int kRowSlots = (kWave / W) * (kBlock / kWave);   // rows visited per step by the workgroup
   const uint32_t lane = threadIdx.x & (kWave - 1);
   const uint32_t sub = lane & (W - 1);
   const uint32_t slot = (threadIdx.x / kWave) * (kWave / W) + lane / W;
-  const uint32_t col = wk.col_group * 64u + sub;
-  const bool col_ok = col < chunks_per_row;
+  const uint32_t col = wk.col_group * cg_width + sub;
+  const bool col_ok = sub < cg_width && col < chunks_per_row;
 
   SlicedCounters<NW> cnt;
   cnt.clear();
@@ -337,51 +343,66 @@ __device__ __forceinline__ void by_genome_pass(const kgx_v4u* __restrict__ rows,
 
 template <int W>
 __global__ void __launch_bounds__(kBlock)
-k_count_by_genome(const kgx_v4u* __restrict__ rows, uint32_t chunks_per_row, uint64_t n_genomes,
+k_count_by_genome(const kgx_v4u* __restrict__ rows, uint32_t chunks_per_row, uint32_t cg_width,
                   const uint32_t* __restrict__ row_index, const GenomeWork* __restrict__ work,
-                  uint32_t n_bins, unsigned long long* __restrict__ acc /* [n_genomes][n_bins][3] */) {
+                  const unsigned long long* __restrict__ bin_offset /* [n_bins + 1] */, uint32_t n_bins, uint32_t n_cg,
+                  uint32_t* __restrict__ acc /* [n_bins][n_cg][kAccCounters][kLdsStride] */) {
   __shared__ uint32_t lds[128 * kLdsStride];
-  const GenomeWork wk = work[blockIdx.x];
-  for (int i = threadIdx.x; i < 128 * kLdsStride; i += kBlock) lds[i] = 0;
-  __syncthreads();
+  const GenomeWork item = work[blockIdx.x];
+  uint32_t bin = 0;
+  for (uint64_t p = item.begin; p < item.end;) {
+    while (bin + 1 < n_bins && bin_offset[bin + 1] <= p) ++bin;            // the bin of position p (empty bins skipped)
+    const uint64_t stop = item.end < bin_offset[bin + 1] ? item.end : bin_offset[bin + 1];
+    GenomeWork wk = item;
+    wk.begin = p;
+    wk.end = stop;
+    p = stop;
+    uint32_t* mine = acc + (static_cast<uint64_t>(bin) * n_cg + wk.col_group) * (kAccCounters * kLdsStride);
 
-  uint32_t seen = 0;
-  by_genome_pass<W, 0>(rows, chunks_per_row, row_index, wk, lds, seen);
-  __syncthreads();
-  // LDS counter (i*32+b, sub): genome = (col_group*64 + sub)*64 + i*16 + b/2, stream = b&1.
-  for (int idx = threadIdx.x; idx < 128 * kLdsStride; idx += kBlock) {
-    const uint32_t v = lds[idx];
-    const uint32_t sub = idx % kLdsStride, ib = idx / kLdsStride;
-    const uint64_t g = (static_cast<uint64_t>(wk.col_group) * 64u + sub) * 64u + (ib / 32) * 16u + (ib % 32) / 2;
-    if (v && g < n_genomes) atomicAdd(&acc[(g * n_bins + wk.bin) * 3 + (ib & 1u)], static_cast<unsigned long long>(v));
-  }
-  // Non-diploid codes are exceptional: count them in a second pass only if this workgroup saw one.
-  if (__syncthreads_or(seen != 0)) {
-    for (int i = threadIdx.x; i < 64 * kLdsStride; i += kBlock) lds[i] = 0;
+    for (int i = threadIdx.x; i < 128 * kLdsStride; i += kBlock) lds[i] = 0;
     __syncthreads();
-    uint32_t unused = 0;
-    by_genome_pass<W, 1>(rows, chunks_per_row, row_index, wk, lds, unused);
+    uint32_t seen = 0;
+    by_genome_pass<W, 0>(rows, chunks_per_row, row_index, cg_width, wk, lds, seen);
     __syncthreads();
-    // LDS counter (i*32+b, sub): chunk dword = 2*i + (b&1), genome within dword = b/2.
-    for (int idx = threadIdx.x; idx < 64 * kLdsStride; idx += kBlock) {
+    // LDS counter (i*32+b, sub): genome = (col_group * cg_width + sub)*64 + i*16 + b/2, stream = b&1 (k_finish_by_genome)
+    for (int idx = threadIdx.x; idx < 128 * kLdsStride; idx += kBlock) {
       const uint32_t v = lds[idx];
-      const uint32_t sub = idx % kLdsStride, ib = idx / kLdsStride;
-      const uint32_t dw = 2u * (ib / 32) + (ib & 1u);
-      const uint64_t g = (static_cast<uint64_t>(wk.col_group) * 64u + sub) * 64u + dw * 16u + (ib % 32) / 2;
-      if (v && g < n_genomes) atomicAdd(&acc[(g * n_bins + wk.bin) * 3 + 2], static_cast<unsigned long long>(v));
+      if (v) atomicAdd(&mine[idx], v);
     }
+    // Non-diploid codes are exceptional: count them in a second pass only if this workgroup saw one.
+    if (__syncthreads_or(seen != 0)) {
+      for (int i = threadIdx.x; i < 64 * kLdsStride; i += kBlock) lds[i] = 0;
+      __syncthreads();
+      uint32_t unused = 0;
+      by_genome_pass<W, 1>(rows, chunks_per_row, row_index, cg_width, wk, lds, unused);
+      __syncthreads();
+      // LDS counter (i*32+b, sub): chunk dword = 2*i + (b&1), genome within dword = b/2.
+      for (int idx = threadIdx.x; idx < 64 * kLdsStride; idx += kBlock) {
+        const uint32_t v = lds[idx];
+        if (v) atomicAdd(&mine[128 * kLdsStride + idx], v);
+      }
+    }
+    __syncthreads();                                                        // the LDS counters are cleared for the next bin
   }
 }
 
 // acc {a,b,c} -> { refHom = n_rows(bin) - a - b + c, het = a - c, minorHom = b - c, nonDiploid = c }.
 __global__ void __launch_bounds__(kBlock)
-k_finish_by_genome(const unsigned long long* __restrict__ acc, const unsigned long long* __restrict__ rows_in_bin,
-                   uint64_t n_genomes, uint32_t n_bins, unsigned long long* __restrict__ out) {
+k_finish_by_genome(const uint32_t* __restrict__ acc, const unsigned long long* __restrict__ rows_in_bin,
+                   uint64_t n_genomes, uint32_t n_bins, uint32_t n_cg, uint32_t cg_width, unsigned long long* __restrict__ out) {
   const uint64_t total = n_genomes * n_bins;
   for (uint64_t i = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < total;
        i += static_cast<uint64_t>(gridDim.x) * blockDim.x) {
-    const unsigned long long a = acc[i * 3], b = acc[i * 3 + 1], c = acc[i * 3 + 2];
-    const unsigned long long n = rows_in_bin[i % n_bins];
+    const uint64_t g = i / n_bins;
+    const uint32_t bin = static_cast<uint32_t>(i % n_bins);
+    const uint32_t chunk = static_cast<uint32_t>(g / 64), j = static_cast<uint32_t>(g % 64);   // the genome's 16-byte chunk, its place in it
+    const uint32_t cg = chunk / cg_width, sub = chunk % cg_width;
+    const uint32_t dw = j / 16, jj = j % 16;                               // the chunk's dword, the 2-bit field in it
+    const uint32_t* mine = acc + (static_cast<uint64_t>(bin) * n_cg + cg) * (kAccCounters * kLdsStride);
+    const unsigned long long a = mine[(dw * 32 + 2 * jj) * kLdsStride + sub];
+    const unsigned long long b = mine[(dw * 32 + 2 * jj + 1) * kLdsStride + sub];
+    const unsigned long long c = mine[(128 + (dw / 2) * 32 + 2 * jj + (dw & 1u)) * kLdsStride + sub];
+    const unsigned long long n = rows_in_bin[bin];
     out[i * 4 + 0] = n - a - b + c;
     out[i * 4 + 1] = a - c;
     out[i * 4 + 2] = b - c;
