@@ -399,7 +399,17 @@ k_inbreed_eval_lut(const uint32_t* __restrict__ gt, uint64_t dwords_per_row, uin
   // F + ((1.0 - F) * f) (_calc.cpp:270) than y + F*(1-y) was.
   using Entry = std::conditional_t<MODE == 4, uint64_t, std::conditional_t<MODE == 1, double, EvalEntry>>;
   const Entry* __restrict__ entries = static_cast<const Entry*>(entries_in);
-  __shared__ Entry lut[2][kEvalBatch * kEvalSlots];
+  // Where the entries are 8 bytes (modes 1, 4) a locus's table has a slot for EVERY byte value, entry (a1, a2) at slot
+  // a1 | a2 << 4 = the cell's byte itself: a cell's LDS address is its byte times 8, one SDWA shift and nothing else (the
+  // four slot-number operations per dword are gone: 5.6 -> 4.6 vector instructions per cell in the HallME step, which
+  // they bound), and a byte no entry was tabulated for -- bit 3 or bit 7 set: an allele index past the table -- meets the
+  // prefill, so there is nothing to fold either.  A ds_read_b64's bank is (2 * slot) mod 64: bytes 32 apart share one
+  // (the same first allele under second alleles two apart -- a rare pair of cells in one 32-lane group).  With 16-byte
+  // entries a 256-slot table would be 4 KB a locus (two workgroups a CU) and neighbouring second alleles would share
+  // banks: those modes keep the 160-slot table at a1 + 20 * a2.
+  constexpr bool kDirect = sizeof(Entry) == 8;
+  constexpr uint32_t kSlots = kDirect ? 256u : kEvalSlots;
+  __shared__ Entry lut[2][kEvalBatch * kSlots];
   constexpr uint64_t kOutside = (static_cast<uint64_t>(kOddCell) << 32) | kOddOutside;
   auto nothing = []() {                                      // the entry of a locus past the segment, whatever the byte
     if constexpr (MODE == 4) return static_cast<uint64_t>(0);
@@ -460,7 +470,7 @@ k_inbreed_eval_lut(const uint32_t* __restrict__ gt, uint64_t dwords_per_row, uin
   }
 
   // Every slot starts "unclassified"; the batches refill the (1 << bits)^2 slots their entries have.
-  for (uint32_t e = threadIdx.x; e < 2u * kEvalBatch * kEvalSlots; e += kBlock) {
+  for (uint32_t e = threadIdx.x; e < 2u * kEvalBatch * kSlots; e += kBlock) {
     if constexpr (MODE == 4) lut[0][e] = kOutside;
     else if constexpr (MODE == 1) lut[0][e] = 1.0;
     else lut[0][e] = EvalEntry{MODE == 3 ? 0.0 : 1.0, MODE == 3 ? __builtin_bit_cast(double, kOutside) : 0.0};
@@ -469,56 +479,60 @@ k_inbreed_eval_lut(const uint32_t* __restrict__ gt, uint64_t dwords_per_row, uin
   const uint32_t seg_len = static_cast<uint32_t>(s_end - s_begin);
   const Entry* __restrict__ seg_entries = entries + (s_begin << (2u * bits));
   const uint32_t* __restrict__ seg_index = locus_index ? locus_index + s_begin : nullptr;
-  // Entry threadIdx.x of a batch travels through a register pair, fetched two batches ahead; at bits == 3 a batch has
-  // 512 entries and the second of the thread goes straight from memory to the table (four-to-seven-allele loci only).
-  // With a locus index, the batch's eight row numbers travel the same way (every lane holds all eight).
-  Entry staged;
-  kgx_v4u staged_rows[2];
+  // Entry threadIdx.x of a batch travels through a register pair: fetched at the start of the batch before its own, put
+  // into the other table at that batch's end.  At bits == 3 a batch has 512 entries and the second of the thread goes
+  // straight from memory to the table (four-to-seven-allele loci only).  The load is unconditional (a thread without an
+  // entry reads the segment's first and drops it): no branch between the fetch and the put, see `batch`.
+  Entry staged;                                               // as loaded: has_entry() says whether it is the thread's own
+  auto has_entry = [&](uint32_t r0, uint32_t idx) { return idx < in_batch && r0 + (idx >> (2u * bits)) < seg_len; };
+  auto load_entry = [&](uint32_t r0, uint32_t idx) { return seg_entries[has_entry(r0, idx) ? (r0 << (2u * bits)) + idx : 0u]; };
   auto entry_of = [&](uint32_t r0, uint32_t idx) {
-    Entry e = nothing();
-    if (idx < in_batch && r0 + (idx >> (2u * bits)) < seg_len) e = seg_entries[(r0 << (2u * bits)) + idx];
-    return e;
+    const Entry e = load_entry(r0, idx);
+    return has_entry(r0, idx) ? e : nothing();
   };
-  auto fetch = [&](uint32_t r0) {
-    staged = entry_of(r0, threadIdx.x);
-    if (seg_index && r0 < seg_len) {                          // the index is padded by 8 entries (0) past its end
-      staged_rows[0] = *reinterpret_cast<const kgx_v4u*>(seg_index + r0);
-      staged_rows[1] = *reinterpret_cast<const kgx_v4u*>(seg_index + r0 + 4);
-    }
-  };
+  auto fetch = [&](uint32_t r0) { staged = load_entry(r0, threadIdx.x); };
   auto put = [&](int rb, uint32_t idx, Entry e) {
     if (idx < in_batch) {
       const uint32_t a1 = idx & mask, a2 = (idx >> bits) & mask, i = idx >> (2u * bits);
-      lut[rb][i * kEvalSlots + a1 + 20u * a2] = e;
+      lut[rb][i * kSlots + (kDirect ? (a1 | (a2 << 4)) : a1 + 20u * a2)] = e;
     }
   };
   auto stash = [&](int rb, uint32_t r0) {                     // r0: the batch the registers hold
-    put(rb, threadIdx.x, staged);
+    put(rb, threadIdx.x, has_entry(r0, threadIdx.x) ? staged : nothing());
     if (bits == 3u) put(rb, threadIdx.x + kBlock, entry_of(r0, threadIdx.x + kBlock));
   };
-  // The cells of the batch at r0 (whose row numbers the registers hold).  A locus past the segment reads the
-  // segment's last row (or, indexed, row 0) against a table of nothing.
+  // The cells of the batch at r0.  A locus past the segment reads the segment's last row (or, indexed, one of its first
+  // eight) against a table of nothing; a lane past the genomes reads the first lane's columns and stores nothing.
   const uint64_t row_base = seg_index ? 0ull : s_begin;
-  // The rows of the batch at r0, as scalars (out of the registers before the next fetch), relative to row_base.
+  const uint64_t col_read = active ? col : (g0 >> 2);
+  // The rows of the batch at r0 as scalars, relative to row_base.  With a locus index: its eight entries by ONE scalar
+  // load, waited for on the spot -- on the scalar memory counter, so that no wait on the vector memory counter stands
+  // between the row loads in flight and their use (the index is padded by 8 entries past its end; a batch past the
+  // segment takes the segment's first eight).
+  typedef uint32_t v8u __attribute__((ext_vector_type(8)));
   auto take_rows = [&](uint32_t (&rows)[kEvalBatch], uint32_t r0) {
+    if (seg_index) {
+      const uint32_t* at = seg_index + (r0 < seg_len ? r0 : 0u);
+      v8u loaded;
+      asm volatile("s_load_dwordx8 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(loaded) : "s"(at) : "memory");
 #pragma unroll
-    for (int i = 0; i < kEvalBatch; ++i) {
-      const uint32_t r = r0 + i < seg_len ? r0 + i : seg_len - 1u;
-      rows[i] = seg_index ? static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(staged_rows[i / 4][i % 4]))) : r;
+      for (int i = 0; i < kEvalBatch; ++i) rows[i] = loaded[i];
+    } else {
+#pragma unroll
+      for (int i = 0; i < kEvalBatch; ++i) rows[i] = r0 + i < seg_len ? r0 + i : seg_len - 1u;
     }
   };
-  auto load_cells = [&](uint32_t (&w)[kEvalBatch][DW], uint32_t r0, const uint32_t (&rows)[kEvalBatch]) {
-    if (!active || r0 >= seg_len) return;
-#pragma unroll
-    for (int i = 0; i < kEvalBatch; ++i) {
-      const uint32_t* src = gt + (row_base + rows[i]) * dwords_per_row + col;
-      if constexpr (DW == 1) {
-        w[i][0] = __builtin_nontemporal_load(src);
-      } else {
-        typedef uint32_t v2u __attribute__((ext_vector_type(2)));
-        const v2u v = __builtin_nontemporal_load(reinterpret_cast<const v2u*>(src));
-        w[i][0] = v.x; w[i][1] = v.y;
-      }
+  auto load_row = [&](uint32_t (&wi)[DW], uint32_t row) {
+#if defined(KGX_EXP_NOLOAD)
+    if (row != 0xFFFFFFFFu) return;                             // experiment: the pass without its HBM reads
+#endif
+    const uint32_t* src = gt + (row_base + row) * dwords_per_row + col_read;
+    if constexpr (DW == 1) {
+      wi[0] = __builtin_nontemporal_load(src);
+    } else {
+      typedef uint32_t v2u __attribute__((ext_vector_type(2)));
+      const v2u v = __builtin_nontemporal_load(reinterpret_cast<const v2u*>(src));
+      wi[0] = v.x; wi[1] = v.y;
     }
   };
   // A cell's table entry: slot a1 + 20*a2 of its locus (bit 7 of the byte folded onto bit 3: "unclassified").
@@ -529,19 +543,26 @@ k_inbreed_eval_lut(const uint32_t* __restrict__ gt, uint64_t dwords_per_row, uin
   uint32_t four = sizeof(Entry) == 8 ? 3u : 4u;               // log2 of the entry size
   asm volatile("" : "+v"(four));                              // the SDWA shift takes its count from a register
 
-  // One batch: the table lut[BUF] holds its entries, w its cells.  Meanwhile the next batch's entries go from the
-  // registers into the other table, the entries of the batch after that are fetched, and the next cells are loaded.
-  auto batch = [&](auto buf_c, uint32_t r0, uint32_t (&w)[kEvalBatch][DW], uint32_t (&w_next)[kEvalBatch][DW]) {
+  // One batch: the table lut[BUF] holds its entries, w its cells.  The next batch's entries are fetched at its start and
+  // put into the other table at its end.  The cells are loaded TWO batches ahead and in place: as soon as the last table
+  // read of a locus' cells has its addresses, the same registers take the load of that locus' row two batches on (the other
+  // register set holds the batch in between), so a wave keeps up to sixteen row loads in flight, spread over the batch.
+  // Nothing in the batch waits for ALL vector loads: between the entry's fetch (the oldest load in flight when it is
+  // needed) and its put lies straight-line code -- no branch, every lane loads (see col_read) -- so the compiler's counter
+  // bookkeeping holds (s_waitcnt vmcnt(8) where it used to drain the queue with vmcnt(0) once per batch).  Measured at C5:
+  // no change in the passes' time -- they run against the socket's 1400 W cap at ~1.7 GHz (profiles/r03_power_cap.md), so
+  // neither load latency nor issue slots are what is short -- but the structure is what a sweep that is NOT power-bound
+  // needs, and it costs nothing.  (A row past the segment is read for nothing: 16 rows per segment of thousands.)
+  auto batch = [&](auto buf_c, uint32_t r0, uint32_t (&w)[kEvalBatch][DW]) {
     constexpr int BUF = decltype(buf_c)::value;
-    stash(BUF ^ 1, r0 + kEvalBatch);
+    fetch(r0 + kEvalBatch);
     uint32_t rows[kEvalBatch];
-    take_rows(rows, r0 + kEvalBatch);
-    fetch(r0 + 2 * kEvalBatch);
-    load_cells(w_next, r0 + kEvalBatch, rows);
-    if (active) {
+    take_rows(rows, r0 + 2 * kEvalBatch);
+    {
+      auto reload = [&](int i) { load_row(w[i], rows[i]); };   // locus i of the batch two on, into the registers locus i just left
       const char* cur = reinterpret_cast<const char*>(&lut[BUF][0]);
       auto entry_at = [&](int i, uint32_t offset16) {
-        return *reinterpret_cast<const Entry*>(cur + i * static_cast<int>(kEvalSlots * sizeof(Entry)) + offset16);
+        return *reinterpret_cast<const Entry*>(cur + i * static_cast<int>(kSlots * sizeof(Entry)) + offset16);
       };
       // The batch's cells in groups of four (one dword), a group's four table reads issued kEvalDepth groups before its
       // arithmetic: the reads' latency passes under that of the groups before it, and the registers stay those of
@@ -549,7 +570,7 @@ k_inbreed_eval_lut(const uint32_t* __restrict__ gt, uint64_t dwords_per_row, uin
       // sinking: nothing in this block reads the sums) carries all 64 reads of the batch past the batch.
       constexpr int kGroups = kEvalBatch * DW, kDepth = PAIR ? KGX_EVAL_DEPTH_PAIR : (kCounts || sizeof(Entry) == 8) ? KGX_EVAL_DEPTH3 : KGX_EVAL_DEPTH;
       auto read_group = [&](int q, Entry (&e)[4]) {
-        const uint32_t slots = slots_of(w[q / DW][q % DW]);
+        const uint32_t slots = kDirect ? w[q / DW][q % DW] : slots_of(w[q / DW][q % DW]);
         e[0] = entry_at(q / DW, byte_shifted<0>(slots, four));
         e[1] = entry_at(q / DW, byte_shifted<1>(slots, four));
         e[2] = entry_at(q / DW, byte_shifted<2>(slots, four));
@@ -558,10 +579,16 @@ k_inbreed_eval_lut(const uint32_t* __restrict__ gt, uint64_t dwords_per_row, uin
       auto walk = [&](auto&& cell) {
         Entry e[kDepth + 1][4];
 #pragma unroll
-        for (int q = 0; q < kDepth; ++q) read_group(q, e[q]);
+        for (int q = 0; q < kDepth; ++q) {
+          read_group(q, e[q]);
+          if (q % DW == DW - 1) reload(q / DW);
+        }
 #pragma unroll
         for (int q = 0; q < kGroups; ++q) {
-          if (q + kDepth < kGroups) read_group(q + kDepth, e[(q + kDepth) % (kDepth + 1)]);
+          if (q + kDepth < kGroups) {
+            read_group(q + kDepth, e[(q + kDepth) % (kDepth + 1)]);
+            if ((q + kDepth) % DW == DW - 1) reload((q + kDepth) / DW);
+          }
           __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
           for (int b = 0; b < 4; ++b) {
@@ -597,15 +624,20 @@ k_inbreed_eval_lut(const uint32_t* __restrict__ gt, uint64_t dwords_per_row, uin
         });
       } else {
         walk([&](int j, const Entry& y) {
+#if defined(KGX_EXP_NOMATH)
+          run_a[j] += y;                                          // experiment: the pass without its fp64 work
+#else
           const double v = __builtin_fma(one_minus_F[MODE == 1 ? j : 0], y, F[kCounts ? 0 : j]);
           run_a[j] = __builtin_fma(run_a[j], v, run_b[j]);
           run_b[j] *= v;
+#endif
         });
       }
       if constexpr (kCounts) {
         uint32_t seen = 0;
 #pragma unroll
         for (int j = 0; j < GPL; ++j) seen |= cnt_hi[j];
+        if (!active) seen = 0u;                               // a lane past the genomes walks the first lane's cells for nothing
         if (__any((seen >> 28) != 0u)) {                    // some lane of the wave met an odd cell in this batch
 #pragma unroll
           for (int j = 0; j < GPL; ++j) cnt_hi[j] &= kOddCell - 1u;
@@ -627,7 +659,7 @@ k_inbreed_eval_lut(const uint32_t* __restrict__ gt, uint64_t dwords_per_row, uin
               for (int j = 0; j < GPL; ++j) {
                 const uint64_t g = lane * GPL + j;
                 if (g >= n_genomes) break;
-                const uint32_t odd = static_cast<uint32_t>(packed_of(cur_entries[i * kEvalSlots + eval_slot<FOLD>(bytes[j])])) >> 24;
+                const uint32_t odd = static_cast<uint32_t>(packed_of(cur_entries[i * kSlots + (kDirect ? static_cast<uint32_t>(bytes[j]) : eval_slot<FOLD>(bytes[j]))])) >> 24;
                 if (odd == 0u) continue;
                 const double sign = (odd & (kOddMinus >> 24)) ? -1.0 : (odd & (kOddPlus >> 24)) ? 1.0
                                     : ((odd & (kOddOutside >> 24)) && (flag & kLocusDefault)) ? -1.0 : 0.0;
@@ -661,6 +693,7 @@ k_inbreed_eval_lut(const uint32_t* __restrict__ gt, uint64_t dwords_per_row, uin
         }
       }
     }
+    stash(BUF ^ 1, r0 + kEvalBatch);                         // the other table was last read in the batch before this one
     __syncthreads();     // the other table is complete, and this one is free for the batch after next
   };
 
@@ -671,14 +704,17 @@ k_inbreed_eval_lut(const uint32_t* __restrict__ gt, uint64_t dwords_per_row, uin
   {
     uint32_t rows[kEvalBatch];
     take_rows(rows, 0);
-    fetch(kEvalBatch);
-    load_cells(w_a, 0, rows);
+#pragma unroll
+    for (int i = 0; i < kEvalBatch; ++i) load_row(w_a[i], rows[i]);
+    take_rows(rows, kEvalBatch);
+#pragma unroll
+    for (int i = 0; i < kEvalBatch; ++i) load_row(w_b[i], rows[i]);
   }
   __syncthreads();
   for (uint32_t r0 = 0; r0 < seg_len; r0 += 2 * kEvalBatch) {
-    batch(std::integral_constant<int, 0>{}, r0, w_a, w_b);
+    batch(std::integral_constant<int, 0>{}, r0, w_a);
     if (r0 + kEvalBatch >= seg_len) break;
-    batch(std::integral_constant<int, 1>{}, r0 + kEvalBatch, w_b, w_a);
+    batch(std::integral_constant<int, 1>{}, r0 + kEvalBatch, w_b);
   }
 
   if (!active) return;
