@@ -339,6 +339,137 @@ def aux_inbreeding(args, capi, torch, dev, cpu):
     return record
 
 
+def aux_k1_flatten(args, capi):
+    """K1 as its own phase (SURVEY.md 8d "build-D"): VariantDBVariant::createVariantDB (kgl_variant_db_variant.cpp:11-123)
+    turns the PopulationDB a parser delivered into the dense dosage matrix.  CPU leg: the oracle's createVariantDB on the
+    reference's pool (hw - 1 threads, one task per genome).  Product: the GPU_ALLELE package, driven through its
+    VirtualAnalysis surface (kgx_host_driver) over the SAME 1000 x 20,000 records, flattens the PopulationDB into 2-bit rows
+    on the host and uploads them; it logs both times.  Parity: the package's VariantFWS.csv rows (summaryByVariant of every
+    variant, HGVS order) against the oracle's, bit for bit."""
+    import re
+    import subprocess
+    import tempfile
+
+    from tests import oracle_api as oa
+    from tests import records_io as rio
+
+    G, V = 1000, 20_000
+    rows, af = capi.synth_biallelic_host(args.seed, 0, G, 0, V)
+    codes = capi.unpack_dosage2(rows, G)
+    rng = np.random.default_rng(7)
+    offsets = np.cumsum(rng.integers(1, 51, V)).astype(np.uint64)
+    ref_code = rng.integers(0, 4, V).astype(np.uint8)
+    alt_code = ((ref_code + rng.integers(1, 4, V)) % 4).astype(np.uint8)
+    gt = np.zeros((V, G, 2), dtype=np.uint8)
+    het_phase = rng.integers(0, 2, (V, G)).astype(np.uint8)
+    gt[..., 0] = np.where(codes == 2, 1, np.where((codes == 1) & (het_phase == 0), 1, 0))
+    gt[..., 1] = np.where(codes == 2, 1, np.where((codes == 1) & (het_phase == 1), 1, 0))
+    ids = [f"HG{i:06d}" for i in range(G)]
+    opop = oa.Population("synthetic")
+    opop.add_genomes(ids)
+    opop.add_records_coded("chr1", offsets, ref_code, np.ones(V, dtype=np.uint8), alt_code, np.repeat(af[:, None], 6, axis=1), gt, oa.Population.PHASED)
+    vdb = oa.VariantDB(opop)                                       # createVariantDB, timed inside the oracle
+    want = vdb.summary_by_variant()
+    threads = int(oa.lib().kgo_pool_threads(G))
+    bases = "ACGT"
+    rec = oa.Records("chr1", offsets, [bases[c] for c in ref_code], [[bases[c]] for c in alt_code], af=[np.repeat(a, 6)[None, :] for a in af])
+    with tempfile.TemporaryDirectory() as tmp:
+        path = Path(tmp) / "population.bin"
+        rio.write_records(path, rec, gt, ids, oa.Population.PHASED, "Genome1000", population_id="synthetic")
+        if not rio.DRIVER.exists():
+            from kgl_gene_amd import build as kbuild
+            kbuild.build_host()
+        t0 = time.perf_counter()
+        res = subprocess.run([str(rio.DRIVER), "GPU_ALLELE", tmp, "--", str(path)], capture_output=True, text=True)
+        process_seconds = time.perf_counter() - t0
+        log = res.stdout + res.stderr
+        m = re.search(r"K1 \(createVariantDB's work\): flatten ([0-9.eE+-]+) s, device rows created and uploaded ([0-9.eE+-]+) s, (\d+) genomes x (\d+) rows", log)
+        if res.returncode != 0 or not m:
+            return {"error": f"kgx_host_driver GPU_ALLELE failed (rc {res.returncode}): {log[-400:]}"}
+        flatten_s, upload_s = float(m.group(1)), float(m.group(2))
+        header, rows_csv = rio.read_csv(Path(tmp) / "VariantFWS.csv")
+        got = np.array([[int(x) for x in r[-3:]] for r in rows_csv], dtype=np.uint64)
+        hgvs_ok = [r[0] for r in rows_csv] == [vdb.hgvs(i) for i in range(vdb.n_variants)]
+        ok = bool(hgvs_ok and got.shape == want.shape and np.array_equal(got, want))
+    cells = G * V
+    return {
+        "metric": "variants·genomes/sec (K1: PopulationDB -> dosage rows resident for the sweeps)",
+        "value": cells / (flatten_s + upload_s), "unit": "variants·genomes/s", "seconds": {"flatten_host": flatten_s, "create_and_upload": upload_s},
+        "config": {"workload": f"{G} genomes x {V} variants of the headline's synthetic population as a PopulationDB ({int(opop.variant_count())} Variant objects)",
+                   "boundary": "GPU_ALLELE through kgx_host_driver (VirtualAnalysis::fileReadAnalysis); the PopulationDB itself is the parser's output, untimed on both sides",
+                   "whole_process_seconds": round(process_seconds, 3), "rows_on_device": int(m.group(4))},
+        "cpu_baseline": {"value": cells / vdb.build_seconds, "unit": "variants·genomes/s", "cores": threads, "kind": "port",
+                         "sample": f"the same PopulationDB through the oracle's createVariantDB ({vdb.build_seconds:.3f} s on {threads} pool threads = "
+                                   f"hardware_concurrency() - 1 capped by the genome count); parity: the package's VariantFWS.csv == summaryByVariant of every "
+                                   f"variant in HGVS order: {'bit-exact' if ok else 'MISMATCH'}",
+                         "parity_ok": ok},
+    }
+
+
+def aux_window_calls(args, capi):
+    """The regime the INBREED package runs in (kga_analysis_inbreed_diploid.cpp:98-166 per window; defaults LociiCount 1000):
+    one kgx_inbreed call per window and super population -- here 1000 sampled loci x 2504 genomes, indexed out of a resident
+    20,000-locus matrix, all four estimators, the iterative ones from seeded reference start points.  calls/s from 200 calls
+    each; CPU leg: the oracle's getLocusList + processResults over the same window (hw - 1 pool threads), parity per estimator."""
+    from tests import oracle_api as oa
+    from tests import synth_vcf as sv
+
+    G, L, step, seed = 2504, 20_000, 20, 4242
+    m = capi.GenotypeMatrix(G, L)
+    table = m.synth_multiallelic(args.seed, 0, 0)
+    index = np.arange(0, L, step, dtype=np.uint32)
+    sub = np.ascontiguousarray(table[index])
+    d = sv.synth_multiallelic_coded(G, 0, L, seed=args.seed)
+    first_alt = np.concatenate([[0], np.cumsum(d["n_alts"])]).astype(np.int64)
+    keep = np.concatenate([np.arange(first_alt[l], first_alt[l + 1]) for l in index])
+    ref = oa.Population("gnomad")
+    ref.add_genomes(["Reference"])
+    ref.add_records_coded("chr1", d["offsets"][index], d["ref_code"][index], d["n_alts"][index], d["alt_code"][keep], d["af_flat"][keep], None, oa.Population.REFERENCE)
+    dip = oa.Population("diploid")
+    dip.add_genomes(sv.genome_ids(G))
+    dip.add_records_coded("chr1", d["offsets"][index], d["ref_code"][index], d["n_alts"][index], d["alt_code"][keep], d["af_flat"][keep],
+                          np.ascontiguousarray(d["alleles"][index]), oa.Population.PHASED)
+    ref_f = ref.filter_snp_pass()
+    order = dip.genome_order()
+    upper = int(d["offsets"][index[-1]]) + 1
+    sp = np.full(G, oa.ALL, dtype=np.int32)
+    threads = int(oa.lib().kgo_pool_threads(G))
+    for _ in range(100):                                            # clocks up
+        m.inbreed(sub, "Simple", phased=True, locus_index=index)
+    out = {"metric": "kgx_inbreed calls/sec at window size", "unit": "calls/s",
+           "config": {"workload": f"{len(index)} sampled loci (every {step}th of {L}) x {G} genomes per call", "start_points": f"kgx_inbreed_reference_starts(seed {seed})"},
+           "algorithms": {}}
+    names = ["major_hetero_count", "minor_hetero_count", "minor_homo_count", "major_homo_count", "total_allele_count"]
+    tolerance = {"Simple": 1e-10, "RitlandLocus": 1e-10, "HallME": 1e-9, "Loglikelihood": 2e-6}
+    for algorithm in ("Simple", "RitlandLocus", "HallME", "Loglikelihood"):
+        start = None
+        if algorithm in ("HallME", "Loglikelihood"):
+            start = np.empty(G)
+            start[order] = capi.reference_starts(algorithm, seed, G)
+        got = m.inbreed(sub, algorithm, phased=True, locus_index=index, start=start)
+        reps = 200
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            m.inbreed(sub, algorithm, phased=True, locus_index=index, start=start)
+        per_call = (time.perf_counter() - t0) / reps
+        counts, freqs, present, seconds = oa.inbreed_window(ref_f, dip, sp, algorithm, 0, upper, 1, 10**9, 0.0, 1.0, seed=seed)
+        got = got[order]
+        f_err = float(np.abs(got["inbred_allele_sum"] - freqs[:, 4]).max())
+        ok = bool(present.all()) and all(np.array_equal(got[name], counts[:, k]) for k, name in enumerate(names)) and f_err <= tolerance[algorithm]
+        out["algorithms"][algorithm] = {
+            "value": 1.0 / per_call, "ms_per_call": per_call * 1e3, "genomes_loci_per_s": G * len(index) / per_call,
+            "cpu_baseline": {"value": 1.0 / seconds, "unit": "calls/s", "cores": threads, "kind": "port",
+                             "sample": f"the same window through the oracle's getLocusList x 6 + processResults ({seconds:.3f} s, {threads} pool threads); "
+                                       f"class counts {'bit-exact' if ok else 'MISMATCH or F off'}, |dF| max {f_err:.1e} (bound {tolerance[algorithm]:g})",
+                             "parity_ok": ok}}
+        if algorithm == "Loglikelihood":
+            out["algorithms"][algorithm]["evaluations"] = capi.inbreed_last_evaluations()
+    out["value"] = out["algorithms"]["Simple"]["value"]
+    m.close()
+    capi.release_scratch()
+    return out
+
+
 def inbreed_workload(args, capi, dist, torch, dev, wl, L, n_gpus, rank):
     """C5: every rank sweeps its own genomes (no collective: per-genome results only need that genome's bytes and the
     per-locus tables).  A step = one kgx_inbreed call = the frequency sweep + the estimator's passes.  The boundary
@@ -625,6 +756,9 @@ def main():
             bufs = counts = af = None
             torch.cuda.empty_cache()
             aux["c5_simple"] = aux_inbreeding(args, capi, torch, dev, not args.no_cpu_baseline)
+            if not args.no_cpu_baseline:                      # both are comparisons with the CPU path on the same input
+                aux["k1_flatten"] = aux_k1_flatten(args, capi)
+                aux["window_calls"] = aux_window_calls(args, capi)
             result["aux"] = aux
 
     pop.close()

@@ -291,10 +291,12 @@ int kgx_locus_class_frequencies(const double* minor_af, uint64_t n_loci, uint32_
  * inside contraction) of every genome still searching.  Ignored by Simple and RitlandLocus. */
 int kgx_inbreed(kgx_gt8* gt, uint64_t g0, uint64_t g1, const uint32_t* locus_index, uint64_t n_selected,
                 const double* minor_af, uint32_t amax, int phased, int algorithm, const double* start, kgx_locus_results* out);
-/* The start points the reference's processHallME / processLogLikelihood end up using, for n genomes: genome i owns the
- * stream std::mt19937_64(seed + first_stream + i) -- seed 0: seeded from std::random_device, the reference's
- * RandomEntropySource, i.e. production behaviour -- and draws std::uniform_real_distribution<>(0.5, 0) (HallME,
- * _calc.cpp:237) or (0.5, -0.5) (Loglikelihood, :166) once per restart; out[i] = the fifth draw.  Host only, no device. */
+/* The start points the reference's processHallME / processLogLikelihood end up using, for n genomes.  seed > 0: genome i
+ * owns the stream std::mt19937_64(seed + first_stream + i) and draws std::uniform_real_distribution<>(0.5, 0) (HallME,
+ * _calc.cpp:237) or (0.5, -0.5) (Loglikelihood, :166) once per restart; out[i] = the fifth draw.  seed 0: fresh entropy
+ * from std::random_device, the reference's RandomEntropySource, i.e. production behaviour -- the same five draws per
+ * genome, all genomes of the call from one twister seeded from the random device (the draws are independent uniforms
+ * either way; seeding a twister per genome would cost more than a window-sized sweep).  Host only, no device. */
 int kgx_inbreed_reference_starts(int algorithm, uint64_t seed, uint64_t first_stream, uint64_t n, double* out /* [n] */);
 /* kgx_inbreed and the by-genome sweeps keep their per-call device buffers in one grow-only arena per device between calls
  * (a window loop calls kgx_inbreed thousands of times), and a large Loglikelihood call two more buffers holding the

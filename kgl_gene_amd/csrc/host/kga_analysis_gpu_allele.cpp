@@ -1,5 +1,6 @@
 #include "kga_analysis_gpu_allele.h"
 
+#include <chrono>
 #include <algorithm>
 #include <fstream>
 #include <limits>
@@ -167,7 +168,11 @@ bool kga::GpuAlleleAnalysis::fileReadAnalysis(std::shared_ptr<const DataDB> data
 }
 
 bool kga::GpuAlleleAnalysis::sweepPopulation(const PopulationDB& population) {
+  // K1: what VariantDBVariant::createVariantDB does for the CPU path (kgl_variant_db_variant.cpp:11-123: variant index,
+  // genome index, one dosage row per genome) -- here the variant-major 2-bit rows, then their upload (sweepFlat)
+  const auto flatten_begin = std::chrono::steady_clock::now();
   const gpu::FlatPopulation flat = gpu::flattenPopulation(population);
+  k1_flatten_seconds_ = std::chrono::duration<double>(std::chrono::steady_clock::now() - flatten_begin).count();
   // contigs a genome holds without any variant still get a (zero) record (heterozygous.cpp:38-41)
   for (const auto& [genome_id, genome_ptr] : population.getMap()) {
     if (!keepGenome(genome_id)) continue;                           // the genome-level Pf7 filters: absent from every result
@@ -257,6 +262,7 @@ bool kga::GpuAlleleAnalysis::sweepFlat(const gpu::FlatPopulation& flat, const st
   DevicePopulation owned;
   struct { kgx_pop* handle; } dev{uploaded};
   if (!dev.handle) {
+    const auto upload_begin = std::chrono::steady_clock::now();
     owned.handle = kgx_population_create(G, D);
     dev.handle = owned.handle;
     if (!dev.handle) {
@@ -271,6 +277,10 @@ bool kga::GpuAlleleAnalysis::sweepFlat(const gpu::FlatPopulation& flat, const st
         return false;
       }
     }
+    (void)kgx_synchronize();
+    const double upload_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - upload_begin).count();
+    ExecEnv::log().info("GpuAlleleAnalysis; K1 (createVariantDB's work): flatten {} s, device rows created and uploaded {} s, {} genomes x {} rows",
+                        k1_flatten_seconds_, upload_seconds, G, D);
   }
 
   if (masked && kgx_population_set_genome_mask(dev.handle, keep.data()) != KGX_OK) {

@@ -174,6 +174,7 @@ class GpuAlleleAnalysis : public VirtualAnalysis {
   double fws_monoclonal_threshold_{Pf7FwsResource::MONOCLONAL_FWS_THRESHOLD};
   double location_radius_km_{0.0};                             // PfEMPAnalysis::SAMPLE_LOCATION_RADIUS_ (kga_analysis_PfEMP.h:64)
   bool device_ready_{false};
+  double k1_flatten_seconds_{0.0};            // the last PopulationDB -> 2-bit rows flattening (logged with the upload time)
   GpuGenomeFWSMap genome_fws_map_;
   GpuVariantFWSMap variant_fws_map_;
   GpuHeteroHomoZygous hetero_homo_zygous_;

@@ -574,11 +574,28 @@ std::vector<double> kga::GpuInbreedAnalysis::startPoints(int algorithm, const st
   std::vector<double> start;
   if (start_midpoints_ || (algorithm != KGX_ALGO_HALL_ME && algorithm != KGX_ALGO_LOGLIKELIHOOD)) return start;
   start.resize(streams.size());
-  for (size_t k = 0; k < streams.size(); ++k)
-    if (kgx_inbreed_reference_starts(algorithm, start_seed_, streams[k], 1, &start[k]) != KGX_OK) {
+  if (start_seed_ == 0) {                                  // fresh entropy for every task of every window, as in the reference
+    if (!streams.empty() && kgx_inbreed_reference_starts(algorithm, 0, 0, streams.size(), start.data()) != KGX_OK) {
       ExecEnv::log().error("GpuInbreedAnalysis; start points: {}", kgx_last_error());
       return {};
     }
+    return start;
+  }
+  // Seeded: the k-th task of every window owns the same stream, so its start is drawn once (seeding a twister per genome
+  // per window would cost more than the window's sweep).
+  std::vector<double>& known = seeded_starts_[algorithm == KGX_ALGO_HALL_ME ? 0 : 1];
+  uint64_t needed = 0;
+  for (const uint64_t stream : streams) needed = std::max(needed, stream + 1);
+  if (needed > known.size()) {
+    const uint64_t have = known.size();
+    known.resize(needed);
+    if (kgx_inbreed_reference_starts(algorithm, start_seed_, have, needed - have, known.data() + have) != KGX_OK) {
+      ExecEnv::log().error("GpuInbreedAnalysis; start points: {}", kgx_last_error());
+      known.resize(have);
+      return {};
+    }
+  }
+  for (size_t k = 0; k < streams.size(); ++k) start[k] = known[streams[k]];
   return start;
 }
 

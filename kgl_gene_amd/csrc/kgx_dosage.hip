@@ -1056,8 +1056,6 @@ int kgx_compound_offsets(kgx_pop* pop, const uint32_t* first_row, const uint32_t
     if (n_groups == 0) return KGX_OK;
     std::vector<OffsetGroup> groups(n_groups);
     for (uint64_t i = 0; i < n_groups; ++i) {
-      if (n_rows[i] > 15) return fail(KGX_EINVAL, "group %llu has %u rows; at most 15 distinct variants per offset are supported",
-                                      (unsigned long long)i, n_rows[i]);
       if (static_cast<uint64_t>(first_row[i]) + n_rows[i] > pop->n_variants || bin[i] >= n_bins)
         return fail(KGX_EINVAL, "group %llu out of range", (unsigned long long)i);
       groups[i] = OffsetGroup{first_row[i], n_rows[i], bin[i], 0};
@@ -1084,8 +1082,6 @@ int kgx_compound_offsets_listed(kgx_pop* pop, const uint32_t* member_rows, uint6
     if (n_groups == 0) return KGX_OK;
     std::vector<OffsetGroup> groups(n_groups);
     for (uint64_t i = 0; i < n_groups; ++i) {
-      if (n_rows[i] > 15) return fail(KGX_EINVAL, "group %llu has %u rows; at most 15 distinct variants per offset are supported",
-                                      (unsigned long long)i, n_rows[i]);
       if (static_cast<uint64_t>(first_member[i]) + n_rows[i] > n_members || bin[i] >= n_bins)
         return fail(KGX_EINVAL, "group %llu out of range", (unsigned long long)i);
       groups[i] = OffsetGroup{first_member[i], n_rows[i], bin[i], 0};
@@ -1125,8 +1121,6 @@ int kgx_offset_filter_counts(kgx_pop* pop, const uint8_t* single_bin, const uint
     if (n_groups == 0) return use_device(*pop->shards[0].dev);
     std::vector<OffsetGroup> groups(n_groups);
     for (uint64_t i = 0; i < n_groups; ++i) {
-      if (n_rows[i] > 15) return fail(KGX_EINVAL, "group %llu has %u rows; at most 15 distinct variants per offset are supported",
-                                      (unsigned long long)i, n_rows[i]);
       if (static_cast<uint64_t>(first_member[i]) + n_rows[i] > n_members || bin[i] >= n_bins)
         return fail(KGX_EINVAL, "group %llu out of range", (unsigned long long)i);
       groups[i] = OffsetGroup{first_member[i], n_rows[i], bin[i], 0};

@@ -801,15 +801,24 @@ int kgx_inbreed_reference_starts(int algorithm, uint64_t seed, uint64_t first_st
     // RetryCalcResult(FINAL_ACCURACY_, MIN_RETRIES_ = 5, MAX_RETRIES_) ends the restarts at the fifth: checkTolerance
     // (:45-68) compares every entry with itself.  One draw per restart, so the fifth draw is the start that counts.
     constexpr int kRestarts = 5;
-    for (uint64_t i = 0; i < n; ++i) {
-      std::mt19937_64 entropy_mt;
-      if (seed) {
-        entropy_mt.seed(seed + first_stream + i);
-      } else {
-        std::random_device rd;                                    // RandomEntropySource: generator_(rd_())
-        entropy_mt.seed(rd());
+    const double lower = algorithm == KGX_ALGO_HALL_ME ? 0.0 : -0.5;
+    if (seed == 0) {
+      // RandomEntropySource: the reference seeds one twister per genome task from std::random_device.  Independent uniform
+      // draws are independent uniform draws whichever freshly seeded twister makes them, so ONE is seeded here per call
+      // (seeding 2,504 of them costs more than a window-sized sweep) and every genome takes its five draws from it.
+      std::random_device rd;
+      std::mt19937_64 entropy_mt(rd());
+      std::uniform_real_distribution<> initialize_distribution(0.5, lower);
+      for (uint64_t i = 0; i < n; ++i) {
+        double drawn = 0.0;
+        for (int restart = 0; restart < kRestarts; ++restart) drawn = initialize_distribution(entropy_mt);
+        out[i] = drawn;
       }
-      std::uniform_real_distribution<> initialize_distribution(0.5, algorithm == KGX_ALGO_HALL_ME ? 0.0 : -0.5);
+      return KGX_OK;
+    }
+    for (uint64_t i = 0; i < n; ++i) {
+      std::mt19937_64 entropy_mt(seed + first_stream + i);
+      std::uniform_real_distribution<> initialize_distribution(0.5, lower);
       double drawn = 0.0;
       for (int restart = 0; restart < kRestarts; ++restart) drawn = initialize_distribution(entropy_mt);
       out[i] = drawn;

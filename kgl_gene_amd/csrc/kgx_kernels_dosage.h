@@ -572,8 +572,16 @@ k_compound_offsets(const uint32_t* __restrict__ rows, uint64_t dwords_per_row, u
       flush(current_bin);
       current_bin = grp.bin;
     }
-    // Field-wise sums in 2-bit fields would overflow for k > 3, so split even/odd genomes into 4-bit fields.
+    // Field-wise sums in 2-bit fields would overflow for k > 3, so split even/odd genomes into 4-bit fields: good for 15
+    // rows.  A wider group (the reference has no cap: kga_analysis_PfEMP_heterozygous.cpp:61-105) is walked 15 rows at a
+    // time, the fields drained into per-genome counts in between.
     uint32_t present_e = 0, present_o = 0, single_e = 0, single_o = 0, ge2 = 0;
+    const bool wide = grp.n_rows > 15;
+    uint32_t np_wide[16], ns_wide[16];
+    if (wide) {
+#pragma unroll
+      for (int j = 0; j < 16; ++j) np_wide[j] = ns_wide[j] = 0;
+    }
     for (uint32_t r = 0; r < grp.n_rows; ++r) {
       const uint64_t row = row_list ? static_cast<uint64_t>(row_list[grp.first_row + r]) : static_cast<uint64_t>(grp.first_row) + r;   // group-uniform
       const uint32_t w = rows[row * dwords_per_row + col];
@@ -584,13 +592,21 @@ k_compound_offsets(const uint32_t* __restrict__ rows, uint64_t dwords_per_row, u
       single_e += single & 0x11111111u;
       single_o += (single >> 2) & 0x11111111u;
       ge2 |= hi;
+      if (wide && (r % 15 == 14 || r + 1 == grp.n_rows)) {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+          np_wide[j] += ((j & 1) ? present_o : present_e) >> (4 * (j >> 1)) & 0xFu;
+          ns_wide[j] += ((j & 1) ? single_o : single_e) >> (4 * (j >> 1)) & 0xFu;
+        }
+        present_e = present_o = single_e = single_o = 0;
+      }
     }
-    if ((present_e | present_o) == 0) continue;
+    if (!wide && (present_e | present_o) == 0) continue;
 #pragma unroll
     for (int j = 0; j < 16; ++j) {
       // genome j of the dword sits in bits 2j..2j+1: even j -> nibble j/2 of *_e, odd j -> nibble j/2 of *_o
-      const uint32_t np = ((j & 1) ? present_o : present_e) >> (4 * (j >> 1)) & 0xFu;
-      const uint32_t ns = ((j & 1) ? single_o : single_e) >> (4 * (j >> 1)) & 0xFu;
+      const uint32_t np = wide ? np_wide[j] : ((j & 1) ? present_o : present_e) >> (4 * (j >> 1)) & 0xFu;
+      const uint32_t ns = wide ? ns_wide[j] : ((j & 1) ? single_o : single_e) >> (4 * (j >> 1)) & 0xFu;
       const uint32_t two = (ge2 >> (2 * j)) & 1u;
       const bool n_ge2 = two || np >= 2;
       het_ref[j] += (!n_ge2 && np == 1) ? 1u : 0u;
@@ -644,8 +660,15 @@ k_offset_filters(const uint32_t* __restrict__ rows, uint64_t dwords_per_row, uin
       flush(current_bin);
       current_bin = grp.bin;
     }
-    // per-genome row counts in 4-bit fields (a group holds at most 15 rows), even and odd genomes apart
+    // per-genome row counts in 4-bit fields, even and odd genomes apart: good for 15 rows; a wider group is walked 15 rows
+    // at a time, the fields drained into per-genome counts in between (as in k_compound_offsets)
     uint32_t present_e = 0, present_o = 0, single_e = 0, single_o = 0, twice_e = 0, twice_o = 0, more = 0;
+    const bool wide = grp.n_rows > 15;
+    uint32_t np_wide[16], ns_wide[16], n2_wide[16];
+    if (wide) {
+#pragma unroll
+      for (int j = 0; j < 16; ++j) np_wide[j] = ns_wide[j] = n2_wide[j] = 0;
+    }
     for (uint32_t r = 0; r < grp.n_rows; ++r) {
       const uint64_t row = row_list ? static_cast<uint64_t>(row_list[grp.first_row + r]) : static_cast<uint64_t>(grp.first_row) + r;   // group-uniform
       const uint32_t w = rows[row * dwords_per_row + col];
@@ -658,14 +681,24 @@ k_offset_filters(const uint32_t* __restrict__ rows, uint64_t dwords_per_row, uin
       twice_e += twice & 0x11111111u;
       twice_o += (twice >> 2) & 0x11111111u;
       more |= lo & hi;
+      if (wide && (r % 15 == 14 || r + 1 == grp.n_rows)) {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+          const int shift = 4 * (j >> 1);
+          np_wide[j] += ((j & 1) ? present_o : present_e) >> shift & 0xFu;
+          ns_wide[j] += ((j & 1) ? single_o : single_e) >> shift & 0xFu;
+          n2_wide[j] += ((j & 1) ? twice_o : twice_e) >> shift & 0xFu;
+        }
+        present_e = present_o = single_e = single_o = twice_e = twice_o = 0;
+      }
     }
-    if ((present_e | present_o) == 0) continue;
+    if (!wide && (present_e | present_o) == 0) continue;
 #pragma unroll
     for (int j = 0; j < 16; ++j) {
       const int shift = 4 * (j >> 1);
-      const uint32_t np = ((j & 1) ? present_o : present_e) >> shift & 0xFu;
-      const uint32_t ns = ((j & 1) ? single_o : single_e) >> shift & 0xFu;
-      const uint32_t n2 = ((j & 1) ? twice_o : twice_e) >> shift & 0xFu;
+      const uint32_t np = wide ? np_wide[j] : ((j & 1) ? present_o : present_e) >> shift & 0xFu;
+      const uint32_t ns = wide ? ns_wide[j] : ((j & 1) ? single_o : single_e) >> shift & 0xFu;
+      const uint32_t n2 = wide ? n2_wide[j] : ((j & 1) ? twice_o : twice_e) >> shift & 0xFu;
       const bool n3 = (more >> (2 * j)) & 1u;
       const uint32_t objects = ns + 2 * n2;                       // exact when n3 is false
       homozygous[j] += (!n3 && n2 == 1 && ns == 0) ? 2u : 0u;

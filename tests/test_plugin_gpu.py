@@ -606,3 +606,85 @@ def test_gpu_allele_package_population_entry_with_pf7_resources(tmp_path, kgx, b
     assert kept.write_pfemp_location(sample_path, fws_path, want_stats, want_loc) == 0
     assert (tmp_path / "VariantLocation.csv").read_bytes() == want_loc.read_bytes()
     assert (tmp_path / "VariantStatistics.csv").read_bytes() == want_stats.read_bytes()
+
+
+def _wide_offset_population(G, rng_seed=61):
+    """A Pf7-style unphased population on one contig in which three offsets hold 28 distinct variants each (four records of
+    seven alts at the same position) among ordinary one- and two-alt offsets: what HeteroHomoZygous::updateVariantAnalysisType
+    (kga_analysis_PfEMP_heterozygous.cpp:61-105) walks without any cap on the variants of an offset."""
+    rng = np.random.default_rng(rng_seed)
+    offsets, refs, alts = [], [], []
+    tails = ["C", "G", "T", "CA", "CC", "CG", "CT", "GA", "GC", "GG", "GT", "TA", "TC", "TG", "TT", "CAA", "CAC", "CAG", "CAT", "CCA", "CCC",
+             "CCG", "CCT", "CGA", "CGC", "CGG", "CGT", "CTA"]
+    position = 100
+    for block in range(40):
+        position += int(rng.integers(5, 60))
+        if block % 13 == 5:                                   # a wide offset: 4 records x 7 alts, all distinct
+            for r in range(4):
+                offsets.append(position); refs.append("A"); alts.append(["A" + t for t in tails[7 * r:7 * r + 7]])
+        elif block % 3 == 0:
+            offsets.append(position); refs.append("A"); alts.append(["C", "AT"])
+        else:
+            offsets.append(position); refs.append("G"); alts.append(["T"])
+    n = len(refs)
+    af = [np.tile(np.float32(rng.uniform(0.01, 0.6)), (len(a), 6)) for a in alts]
+    rec = oa.Records("Pf3D7_02_v3", offsets, refs, alts, af=af)
+    gt = np.zeros((n, G, 2), dtype=np.uint8)
+    for r in range(n):
+        k = len(alts[r])
+        carried = rng.random((G, 2)) < (0.45 if k == 7 else 0.3)
+        gt[r] = np.where(carried, rng.integers(1, k + 1, (G, 2)), 0)
+    return rec, gt
+
+
+def test_offsets_holding_more_than_15_distinct_variants(tmp_path, kgx):
+    """No cap on the variants of an offset (the 4-bit field sums of k_compound_offsets / k_offset_filters used to fail the call
+    above 15): the package's VariantStatistics.csv counters against the oracle's updateVariantAnalysisType, and the four
+    offset filters through the C ABI against the oracle's OffsetDB filters, on offsets holding 28 distinct variants."""
+    G = 97
+    rec, gt = _wide_offset_population(G)
+    ids = sv.genome_ids(G, prefix="PF")
+    path = tmp_path / "pop.bin"
+    rio.write_records(path, rec, gt, ids, oa.Population.UNPHASED, "Falciparum", population_id="Pf7")
+    res = rio.run_driver("GPU_ALLELE", tmp_path, [path])
+    assert res.returncode == 0, res.stderr
+    opop = sv.oracle_population(rec, gt, ids, oa.Population.UNPHASED)
+    header, rows = rio.read_csv(tmp_path / "VariantStatistics.csv")
+    want = opop.hethom(rec.contig)     # total,snp,indel,hom_minor,het_minor,het_ref_minor,hom_ref
+    got = np.array([[int(r[2]), int(r[3]), int(r[4]), int(r[7]), int(r[8]), int(r[6]), int(r[5])] for r in rows], dtype=np.uint64)
+    assert [r[0] for r in rows] == sorted(ids)
+    assert np.array_equal(got, want)
+    assert want[:, 3].sum() > 0 and want[:, 4].sum() > 0      # compound offsets were exercised
+
+    # the same population through the C ABI: rows in HGVS order from the oracle's dosage matrix, groups by offset
+    vdb = oa.VariantDB(opop)
+    dosage = vdb.dosage()                                      # [G][V], oracle genome order
+    hgvs = [vdb.hgvs(i) for i in range(vdb.n_variants)]
+    import re
+
+    offset_of = [int(re.match(r".*:g\.(\d+)", h).group(1)) for h in hgvs]
+    by_offset = {}
+    for row, offset in enumerate(offset_of):
+        by_offset.setdefault(offset, []).append(row)
+    assert max(len(v) for v in by_offset.values()) == 28
+    single_bin = np.full(len(hgvs), 0xFF, dtype=np.uint8)
+    members, first, count = [], [], []
+    for offset, rows_of in by_offset.items():
+        if len(rows_of) == 1:
+            single_bin[rows_of[0]] = 0
+        else:
+            first.append(len(members)); count.append(len(rows_of)); members.extend(rows_of)
+    pop = kgx.Population(G, len(hgvs))
+    pop.load_dosage_u8(dosage)
+    got_f = pop.offset_filter_counts(single_bin, members, first, count, [0] * len(first), 1)
+    assert np.array_equal(got_f[:, 0, :], opop.offset_filter_counts(rec.contig))
+    # and the compound-offset counters on their own: adjacent rows (HGVS order keeps an offset's rows together) and as lists
+    adjacent = all(rows_of == list(range(rows_of[0], rows_of[0] + len(rows_of))) for rows_of in by_offset.values())
+    listed = pop.compound_offsets_listed(members, first, count, [0] * len(first), 1)
+    if adjacent:
+        starts = [members[f] for f in first]
+        assert np.array_equal(pop.compound_offsets(starts, count, [0] * len(first), 1), listed)
+    single = pop.count_by_genome((single_bin == 0).astype(np.uint8))       # offsets of one variant: exactly one copy = het ref minor
+    assert np.array_equal(listed[:, 0, 0] + single[:, 1], want[:, 5])     # het_ref_minor
+    assert np.array_equal(listed[:, 0, 1] + single[:, 2] + single[:, 3], want[:, 3])   # hom_minor: distinct variants where >= 2 copies
+    pop.close()
