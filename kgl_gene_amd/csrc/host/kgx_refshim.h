@@ -153,8 +153,12 @@ class VariantEvidence {
   [[nodiscard]] bool passFilter() const { return pass_filter_; }
   [[nodiscard]] DataSourceEnum dataSource() const { return data_source_; }
   [[nodiscard]] size_t vcfRecordCount() const { return vcf_record_count_; }
-  [[nodiscard]] const std::shared_ptr<const InfoRecord>& infoRecord() const { return info_; }
  private:
+  // the INFO payload behind FrequencyDatabaseRead::infoFloatField / InfoEvidenceAnalysis::getTypedInfoData (the
+  // reference keeps a DataMemoryBlock here, kgl_variant_evidence.h:140-152): theirs alone, no package reads it
+  friend class FrequencyDatabaseRead;
+  friend class InfoEvidenceAnalysis;
+  [[nodiscard]] const std::shared_ptr<const InfoRecord>& infoRecord() const { return info_; }
   size_t vcf_record_count_;
   DataSourceEnum data_source_;
   bool pass_filter_;
@@ -214,12 +218,12 @@ class OffsetDB {   // kgl_variant_db_offset.h:24-55
   OffsetDBArray variant_vector_;
 };
 
-using OffsetMap = std::map<ContigOffset_t, std::unique_ptr<OffsetDB>>;
+using OffsetDBMap = std::map<ContigOffset_t, std::unique_ptr<OffsetDB>>;   // kgl_variant_db_contig.h:21
 class ContigDB {   // kgl_variant_db_contig.h:24-90
  public:
   explicit ContigDB(ContigId_t id) : contig_id_(std::move(id)) {}
   [[nodiscard]] const ContigId_t& contigId() const { return contig_id_; }
-  [[nodiscard]] const OffsetMap& getMap() const { return contig_offset_map_; }
+  [[nodiscard]] const OffsetDBMap& getMap() const { return contig_offset_map_; }
   bool addVariant(const std::shared_ptr<const Variant>& v) {
     auto it = contig_offset_map_.find(v->offset());
     if (it == contig_offset_map_.end()) it = contig_offset_map_.try_emplace(v->offset(), std::make_unique<OffsetDB>()).first;
@@ -228,7 +232,7 @@ class ContigDB {   // kgl_variant_db_contig.h:24-90
   }
  private:
   ContigId_t contig_id_;
-  OffsetMap contig_offset_map_;
+  OffsetDBMap contig_offset_map_;
 };
 
 using ContigDBMap = std::map<ContigId_t, std::shared_ptr<ContigDB>>;
@@ -287,7 +291,10 @@ class FrequencyDatabaseRead {
     static const std::vector<std::string> pops{SUPER_POP_AFR_, SUPER_POP_AMR_, SUPER_POP_EAS_, SUPER_POP_EUR_, SUPER_POP_SAS_, SUPER_POP_ALL_};
     return pops;
   }
-  // Field-name table of kgl_variant_db_freq.h:84-96.
+  [[nodiscard]] static std::optional<double> infoFloatField(const Variant& variant, const std::string& field);   // freq.cpp:72-122
+  [[nodiscard]] static std::optional<double> superPopFrequency(const Variant& variant, const std::string& super_population);
+ private:
+  // Field-name table of kgl_variant_db_freq.h:84-96 and its lookup (:126-128): private in the reference as well.
   [[nodiscard]] static std::optional<std::string> lookupVariantSuperPopField(DataSourceEnum src, const std::string& sp) {
     static const std::map<std::string, std::vector<std::string>> table{
         {"AFR", {"AF_afr", "AF_afr", "AF_afr", "gnomad_AF_afr", "AFR_AF"}}, {"AMR", {"AF_amr", "AF_amr", "AF_amr", "gnomad_AF_amr", "AMR_AF"}},
@@ -304,27 +311,27 @@ class FrequencyDatabaseRead {
       default: return std::nullopt;
     }
   }
-  [[nodiscard]] static std::optional<double> infoFloatField(const Variant& variant, const std::string& field) {   // freq.cpp:72-122
-    const auto& info = variant.evidence().infoRecord();
-    if (!info) return std::nullopt;
-    auto it = info->float_fields.find(field);
-    if (it == info->float_fields.end()) return std::nullopt;
-    const std::vector<float>& vec = it->second;
-    float f;
-    if (vec.size() == 1) f = vec.front();
-    else if (vec.empty()) return std::nullopt;
-    else if (variant.evidence().altVariantCount() == vec.size() && variant.evidence().altVariantIndex() < vec.size())
-      f = vec[variant.evidence().altVariantIndex()];
-    else return std::nullopt;
-    if (std::isnan(f)) return std::nullopt;
-    return static_cast<double>(f);
-  }
-  [[nodiscard]] static std::optional<double> superPopFrequency(const Variant& variant, const std::string& super_population) {
-    auto field = lookupVariantSuperPopField(variant.evidence().dataSource(), super_population);
-    if (!field) return 0.0;   // freq.cpp:18-23: warn and return 0.0
-    return infoFloatField(variant, field.value());
-  }
 };
+inline std::optional<double> FrequencyDatabaseRead::infoFloatField(const Variant& variant, const std::string& field) {   // freq.cpp:72-122
+  const auto& info = variant.evidence().infoRecord();
+  if (!info) return std::nullopt;
+  auto it = info->float_fields.find(field);
+  if (it == info->float_fields.end()) return std::nullopt;
+  const std::vector<float>& vec = it->second;
+  float f;
+  if (vec.size() == 1) f = vec.front();
+  else if (vec.empty()) return std::nullopt;
+  else if (variant.evidence().altVariantCount() == vec.size() && variant.evidence().altVariantIndex() < vec.size())
+    f = vec[variant.evidence().altVariantIndex()];
+  else return std::nullopt;
+  if (std::isnan(f)) return std::nullopt;
+  return static_cast<double>(f);
+}
+inline std::optional<double> FrequencyDatabaseRead::superPopFrequency(const Variant& variant, const std::string& super_population) {
+  auto field = lookupVariantSuperPopField(variant.evidence().dataSource(), super_population);
+  if (!field) return 0.0;   // freq.cpp:18-23: warn and return 0.0
+  return infoFloatField(variant, field.value());
+}
 
 // kgl_evidence/kgl_variant_factory_vcf_evidence_analysis.h: typed INFO read, as used by P7FrequencyFilter.
 class InfoEvidenceAnalysis {
@@ -476,7 +483,7 @@ class HsGenealogyRecord {
 class HsGenomeGenealogyData : public ResourceBase {
  public:
   explicit HsGenomeGenealogyData(std::string ident) : ResourceBase(ResourceProperties::GENEALOGY_RESOURCE_ID_, std::move(ident)) {}
-  void addGenealogyRecord(const HsGenealogyRecord& r) { map_.insert_or_assign(r.individualId(), r); }
+  bool addGenealogyRecord(const HsGenealogyRecord& r) { return map_.try_emplace(r.individualId(), r).second; }   // kgl_hsgenealogy_parser.cpp: false on a repeated individual
   [[nodiscard]] std::optional<HsGenealogyRecord> getGenomeGenealogyRecord(const std::string& genome) const {
     auto it = map_.find(genome);
     if (it == map_.end()) return std::nullopt;

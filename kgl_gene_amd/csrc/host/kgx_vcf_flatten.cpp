@@ -950,11 +950,34 @@ double infoFrequency(std::string_view info, std::string_view field, size_t alt_i
 
 namespace {
 
+// The INFO field that holds a super population's allele frequency in a data source's VCF: the rows of
+// FrequencyDatabaseRead::field_text_map_AF_ (kgl_variant_db/kgl_variant_db_freq.h:84-96; private there, as is its lookup,
+// :126-128 -- superPopFrequency reads through them from a Variant, which this flattener never builds).  Empty: no such field.
+std::string superPopInfoField(DataSourceEnum data_source, const std::string& super_population) {
+  struct FieldText { const char* super_population; const char* gnomad_2_1; const char* gnomad_ex_2_1; const char* gnomad_3_1; const char* gnomadgenome_3_1; const char* genome_1000; };
+  static const FieldText table[] = {
+      {"AFR", "AF_afr", "AF_afr", "AF_afr", "gnomad_AF_afr", "AFR_AF"}, {"AMR", "AF_amr", "AF_amr", "AF_amr", "gnomad_AF_amr", "AMR_AF"},
+      {"EAS", "AF_eas", "AF_eas", "AF_eas", "gnomad_AF_eas", "EAS_AF"}, {"EUR", "AF_nfe", "AF_nfe", "AF_nfe", "gnomad_AF_nfe", "EUR_AF"},
+      {"SAS", "AF", "AF_sas", "AF_sas", "gnomad_AF_sas", "SAS_AF"},     {"ALL", "AF", "AF", "AF", "gnomad_AF", "AF"}};
+  for (const FieldText& row : table) {
+    if (super_population != row.super_population) continue;
+    switch (data_source) {                                     // lookupVariantSuperPopField's switch (kgl_variant_db_freq.cpp:33-69)
+      case DataSourceEnum::Gnomad2_1: return row.gnomad_2_1;
+      case DataSourceEnum::GnomadExomes2_1: return row.gnomad_ex_2_1;
+      case DataSourceEnum::Gnomad3_1: case DataSourceEnum::GnomadExomes3_1: case DataSourceEnum::Gnomad3_0: return row.gnomad_3_1;
+      case DataSourceEnum::GnomadGenome3_1: return row.gnomadgenome_3_1;
+      case DataSourceEnum::Genome1000: return row.genome_1000;
+      default: return {};
+    }
+  }
+  return {};
+}
+
 template <typename NextChunk>
 FlatReference flattenReferenceChunks(NextChunk&& next_piece, DataSourceEnum data_source) {
   const auto& super_pops = FrequencyDatabaseRead::superPopulations();
   std::vector<std::string> fields;
-  for (const auto& sp : super_pops) fields.push_back(FrequencyDatabaseRead::lookupVariantSuperPopField(data_source, sp).value_or(std::string()));
+  for (const auto& sp : super_pops) fields.push_back(superPopInfoField(data_source, sp));
   FlatReference out;
   std::map<ContigOffset_t, ReferenceLocusRow> by_offset;
   std::vector<std::string> contigs_seen;
