@@ -8,7 +8,7 @@ import collections, csv, glob, json, re, sys
 from pathlib import Path
 
 ROOT = Path(__file__).resolve().parent.parent
-tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
 src, dst = ROOT / "gpurun_out" / f"prof_{tag}", ROOT / "profiles"
 dst.mkdir(exist_ok=True)
 
@@ -102,5 +102,16 @@ for name in sorted(k7, key=lambda k: -float(k7[k]["TotalDurationNs"])):
                  f"{c.get('SQ_WAIT_INST_ANY', float('nan')) / c.get('SQ_WAVE_CYCLES', float('nan')):.2f} |")
 lines += ["", "(Loglikelihood's passes after the first compactions sweep fewer genomes: its average is over all its launches.)", "",
           "`scripts/bench_inbreed.py` output of the traced run:", "", "```"] + (src / "k7.txt").read_text().strip().splitlines() + ["```", ""]
+# ---- window-sized calls (what the INBREED package issues): the whole HallME / Loglikelihood iteration in one launch
+window_files = glob.glob(str(src / "window_trace/*/*kernel_stats.csv"))
+if window_files:
+    window_stats = Path(max(window_files, key=lambda f: Path(f).stat().st_mtime))
+    (dst / f"{tag}_window_kernel_stats.csv").write_text(window_stats.read_text())
+    lines += ["## Window-sized calls: 1000 sampled loci x 512 genomes (`scripts/bench_inbreed_window.py 1000`)", "",
+              "`rocprofv3 --kernel-trace --stats -- python3 scripts/bench_inbreed_window.py 1000`: 100 timed calls per estimator after 200 warm-up calls.", "",
+              "| kernel | calls | avg us | share of the traced GPU time |", "|---|---|---|---|"]
+    for r in sorted(csv.DictReader(window_stats.open()), key=lambda r: -float(r["TotalDurationNs"]))[:8]:
+        lines.append(f"| `{short(r['Name'])}` | {r['Calls']} | {float(r['AverageNs']) / 1e3:.1f} | {float(r['Percentage']):.1f} % |")
+    lines += ["", "```"] + (src / "window.txt").read_text().strip().splitlines() + ["```", ""]
 (dst / f"{tag}_summary.md").write_text("\n".join(lines))
 print("\n".join(lines))
