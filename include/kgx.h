@@ -210,6 +210,16 @@ int kgx_offset_filter_counts(kgx_pop* pop, const uint8_t* single_bin /* host [n_
                              const uint32_t* first_member, const uint32_t* n_rows, const uint32_t* bin, uint64_t n_groups, uint32_t n_bins,
                              uint64_t* out /* host [n_genomes][n_bins][4] */);
 
+/* UniquePhasedFilter (kgl_variant_filter_db_offset.cpp:160-...): one Variant object per distinct (HGVS, phase) of an offset.
+ * Phase is not in the 2-bit rows; it comes as a PHASE PLANE beside them -- one bit per (variant row, genome), variant-major,
+ * genome g in bit g % 8 of byte g / 8 of its row: set where the genome's copies of the variant sit on BOTH phases (a|a
+ * homozygote; never for unphased data, where every copy carries VariantPhase::UNPHASED).  The filter then leaves, per
+ * genome and bin, (variants carried) + (plane bits set): out[g][b].  bin_of_variant: host [n_variants], 0xFF = row not
+ * counted; NULL with n_bins == 1: every row.  Honours the genome mask.  The plane is optional (half the size of the rows);
+ * kgx_population_resize carries it along. */
+int kgx_population_load_phase_plane(kgx_pop* pop, const uint8_t* src, uint64_t src_pitch /* >= ceil(n_genomes / 8) */, uint64_t v0, uint64_t v1);
+int kgx_unique_phased_counts(kgx_pop* pop, const uint8_t* bin_of_variant, uint32_t n_bins, uint64_t* out /* host [n_genomes][n_bins] */);
+
 /* ---- Genome-major row lists: for every genome of [g0, g1) the rows it carries (dosage > 0), ascending -- the visit
  *      GenomeDB::processAll makes of one genome, on which VariantSort::variantGenomeIndexMT builds its per-genome
  *      identifier maps (kgl_genomics/kgl_variant_analysis/kgl_variant_sort.cpp:234-306, one pool task per genome; the

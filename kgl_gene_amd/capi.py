@@ -96,6 +96,8 @@ _SIGNATURES = {
     "kgx_compound_offsets": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_void_p]),
     "kgx_compound_offsets_listed": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_void_p]),
     "kgx_genome_row_lists": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64]),
+    "kgx_population_load_phase_plane": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64]),
+    "kgx_unique_phased_counts": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]),
     "kgx_offset_filter_counts": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32,
                                            C.c_void_p]),
 }
@@ -437,6 +439,18 @@ class Population:
         rows = np.zeros(int(begin[-1]), dtype=np.uint32)
         check(lib().kgx_genome_row_lists(self._h, g0, g1, ptr(sel) if sel is not None else None, ptr(begin), ptr(rows), len(rows)))
         return begin, rows
+
+    def load_phase_plane(self, both_phases: np.ndarray, v0: int = 0) -> None:
+        """both_phases: [rows][n_genomes] booleans -- the genome's copies of the row's variant sit on both phases."""
+        bits = np.packbits(np.ascontiguousarray(both_phases, dtype=np.uint8), axis=1, bitorder="little")
+        check(lib().kgx_population_load_phase_plane(self._h, ptr(bits), bits.shape[1], v0, v0 + bits.shape[0]))
+
+    def unique_phased_counts(self, bin_of_variant=None, n_bins: int = 1) -> np.ndarray:
+        """[n_genomes][n_bins]: the Variant objects UniquePhasedFilter leaves (one per distinct HGVS and phase)."""
+        out = np.zeros((self.n_genomes, n_bins), dtype=np.uint64)
+        b = None if bin_of_variant is None else np.ascontiguousarray(bin_of_variant, dtype=np.uint8)
+        check(lib().kgx_unique_phased_counts(self._h, None if b is None else ptr(b), n_bins, ptr(out)))
+        return out
 
     def population_summary(self) -> np.ndarray:
         out = np.zeros(4, dtype=np.uint64)

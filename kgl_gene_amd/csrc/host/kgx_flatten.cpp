@@ -148,30 +148,56 @@ FlatPopulation flattenPopulation(const PopulationDB& population, size_t threads)
   // Dosage = number of Variant objects with that HGVS in the genome (kgl_variant_db_variant.cpp:103).
   // Workers own whole bytes (4 consecutive genomes), so no two threads touch the same byte.
   const std::vector<std::shared_ptr<const GenomeDB>>& genomes = genome_ptrs;
-  const size_t quads = (G + 3) / 4;
-  threads = std::max<size_t>(1, std::min(threads, quads));
+  // The phase plane beside the rows (UniquePhasedFilter counts one object per distinct HGVS AND phase,
+  // kgl_variant_filter_db_offset.cpp:160-181): one bit per cell, set where the genome's copies of the variant carry more than
+  // one distinct phase (a|a in phased data; never in unphased data).  Workers own whole plane bytes = 8 consecutive genomes
+  // = two bytes of every packed row, so no two threads touch the same byte of either.
+  flat.phase_row_bytes = (G + 7) / 8;
+  flat.phase_plane.assign(V * flat.phase_row_bytes, 0);
+  const size_t octets = (G + 7) / 8;
+  threads = std::max<size_t>(1, std::min(threads, octets));
   std::vector<std::vector<NonDiploidCell>> overflow(threads);
+  std::vector<uint8_t> any_two_phases(threads, 0);
+  auto phase_bit = [](VariantPhase phase) -> uint8_t {
+    switch (phase) {
+      case VariantPhase::DIPLOID_PHASE_A: return 1;
+      case VariantPhase::DIPLOID_PHASE_B: return 2;
+      case VariantPhase::UNPHASED: return 4;
+      default: return 8;                                          // HAPLOID_PHASED
+    }
+  };
   auto worker = [&](size_t t) {
     std::vector<uint32_t> touched;
     std::vector<uint16_t> count(V, 0);
-    for (size_t q = t; q < quads; q += threads) {
-      for (size_t j = 0; j < 4 && q * 4 + j < G; ++j) {
-        const size_t g = q * 4 + j;
+    std::vector<uint8_t> phases(V, 0);
+    for (size_t o = t; o < octets; o += threads) {
+      for (size_t j = 0; j < 8 && o * 8 + j < G; ++j) {
+        const size_t g = o * 8 + j;
         touched.clear();
         for (const auto& [contig_id, contig_ptr] : genomes[g]->getMap())
           for (const auto& [offset, offset_ptr] : contig_ptr->getMap())
             for (const auto& variant_ptr : offset_ptr->getVariantArray()) {
               const uint32_t r = row_of.at(variant_ptr.get());
               if (count[r]++ == 0) touched.push_back(r);
+              phases[r] |= phase_bit(variant_ptr->phaseId());
               if (!split_row_of.empty()) {
                 auto split = split_row_of.find(variant_ptr.get());
-                if (split != split_row_of.end() && count[split->second]++ == 0) touched.push_back(split->second);
+                if (split != split_row_of.end()) {
+                  if (count[split->second]++ == 0) touched.push_back(split->second);
+                  phases[split->second] |= phase_bit(variant_ptr->phaseId());
+                }
               }
             }
         for (uint32_t r : touched) {
           const uint32_t d = count[r];
+          const uint8_t seen_phases = phases[r];
           count[r] = 0;
-          flat.packed[static_cast<size_t>(r) * flat.row_bytes + q] |= static_cast<uint8_t>((d > 2 ? 3u : d) << (2 * j));
+          phases[r] = 0;
+          flat.packed[static_cast<size_t>(r) * flat.row_bytes + o * 2 + j / 4] |= static_cast<uint8_t>((d > 2 ? 3u : d) << (2 * (j % 4)));
+          if (seen_phases & (seen_phases - 1)) {                  // more than one distinct phase among the copies
+            flat.phase_plane[static_cast<size_t>(r) * flat.phase_row_bytes + o] |= static_cast<uint8_t>(1u << j);
+            any_two_phases[t] = 1;
+          }
           if (d > 2 && r < flat.primary_rows) overflow[t].push_back({r, static_cast<uint32_t>(g), d});
         }
       }
@@ -182,6 +208,9 @@ FlatPopulation flattenPopulation(const PopulationDB& population, size_t threads)
   worker(0);
   for (auto& th : pool) th.join();
   for (auto& o : overflow) flat.non_diploid.insert(flat.non_diploid.end(), o.begin(), o.end());
+  bool two_phases = false;
+  for (const uint8_t flag : any_two_phases) two_phases = two_phases || flag;
+  if (!two_phases) { flat.phase_plane.clear(); flat.phase_plane.shrink_to_fit(); }    // unphased data: no plane
   std::sort(flat.non_diploid.begin(), flat.non_diploid.end(), [](const NonDiploidCell& a, const NonDiploidCell& b) {
     return a.row != b.row ? a.row < b.row : a.genome < b.genome;
   });

@@ -50,6 +50,11 @@ struct FlatPopulation {
   uint64_t row_bytes{0};                   // ceil(G/4)
   std::vector<uint8_t> packed;             // [rows][row_bytes] 2-bit dosage codes, genome g in bits 2*(g%4) of byte g/4
   std::vector<NonDiploidCell> non_diploid;
+  // [rows][phase_row_bytes] one bit per cell, genome g in bit g%8 of byte g/8: the genome's copies of the variant carry more
+  // than one distinct phase (what UniquePhasedFilter counts beyond UniqueUnphasedFilter; kgx_population_load_phase_plane).
+  // Empty where no cell does (unphased data).  flattenPopulation fills it; the VCF flatteners do not.
+  std::vector<uint8_t> phase_plane;
+  uint64_t phase_row_bytes{0};
   size_t variant_objects{0};               // Variant visits (= PopulationDB::variantCount())
   std::vector<ContigId_t> contig_ids;      // contigs EVERY genome holds, carrier or not (Pf flavour: the ##contig header lines)
 

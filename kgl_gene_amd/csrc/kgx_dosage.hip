@@ -139,21 +139,29 @@ ByGenomeShape by_genome_shape(uint32_t chunks_per_row) {
   return shape;
 }
 
+// The rows a by-genome sweep walks: the shard's 2-bit dosage rows, or its 1-bit phase plane.
+struct ByGenomeRows { const uint8_t* rows; uint32_t chunks_per_row; bool plane; };
+
 template <int W>
-int launch_by_genome(const kgx_pop_shard& sh, ByGenomeShape shape, const uint32_t* d_index, const GenomeWork* d_work, uint32_t n_work,
+int launch_by_genome(const kgx_pop_shard& sh, ByGenomeRows source, ByGenomeShape shape, const uint32_t* d_index, const GenomeWork* d_work, uint32_t n_work,
                      const unsigned long long* d_binoff, uint32_t n_bins, uint32_t* d_acc, int* resident_per_cu) {
   if (resident_per_cu) {                                     // how many of these workgroups a CU holds at once (registers, LDS)
     int blocks = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, k_count_by_genome<W>, kBlock, 0) != hipSuccess || blocks <= 0) {
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, k_count_by_genome<W, false>, kBlock, 0) != hipSuccess || blocks <= 0) {
       (void)hipGetLastError();
       blocks = 3;
     }
     *resident_per_cu = blocks;
     return KGX_OK;
   }
-  hipLaunchKernelGGL((k_count_by_genome<W>), dim3(n_work), dim3(kBlock), 0, sh.dev->stream,
-                     reinterpret_cast<const kgx_v4u*>(sh.d_rows), sh.chunks_per_row, shape.cg_width,
-                     d_index, d_work, d_binoff, n_bins, shape.n_cg, d_acc);
+  if (source.plane)
+    hipLaunchKernelGGL((k_count_by_genome<W, true>), dim3(n_work), dim3(kBlock), 0, sh.dev->stream,
+                       reinterpret_cast<const kgx_v4u*>(source.rows), source.chunks_per_row, shape.cg_width,
+                       d_index, d_work, d_binoff, n_bins, shape.n_cg, d_acc);
+  else
+    hipLaunchKernelGGL((k_count_by_genome<W, false>), dim3(n_work), dim3(kBlock), 0, sh.dev->stream,
+                       reinterpret_cast<const kgx_v4u*>(source.rows), source.chunks_per_row, shape.cg_width,
+                       d_index, d_work, d_binoff, n_bins, shape.n_cg, d_acc);
   return KGX_OK;
 }
 
@@ -172,7 +180,9 @@ int dispatch_by_genome(int W, Args... args) {
 
 // One shard's by-genome sweep; out = the shard's block [n_genomes][n_bins][4] of the caller's array.
 // bin_edges (host, n_bins + 1 doubles; bin_of_variant null then): the bins are evaluated on the device from the AF column.
-int count_by_genome_shard(kgx_pop_shard& sh, const uint8_t* bin_of_variant, uint32_t n_bins, uint64_t* out, const double* bin_edges = nullptr) {
+// plane: the sweep walks the shard's phase plane instead of its dosage rows; out = [n_genomes][n_bins] set-bit counts.
+int count_by_genome_shard(kgx_pop_shard& sh, const uint8_t* bin_of_variant, uint32_t n_bins, uint64_t* out, const double* bin_edges = nullptr,
+                          bool plane = false) {
   const uint64_t V = sh.n_variants, G = sh.n_genomes;
   if (G == 0) return KGX_OK;
   if (V > 0xFFFFFFFFull) return fail(KGX_EINVAL, "n_variants exceeds the 32-bit row index of the by-genome sweep");
@@ -183,6 +193,9 @@ int count_by_genome_shard(kgx_pop_shard& sh, const uint8_t* bin_of_variant, uint
   const bool masked = sh.d_keep != nullptr;                   // rows without a kept carrier drop out (d_counts: K2 under the mask)
   const bool identity = bin_of_variant == nullptr && bin_edges == nullptr && !masked;
   hipStream_t st = dev.stream;
+  if (plane && !sh.d_phase) return fail(KGX_ESTATE, "no phase plane was loaded (kgx_population_load_phase_plane)");
+  const ByGenomeRows source = plane ? ByGenomeRows{sh.d_phase, static_cast<uint32_t>(sh.phase_pitch / 16), true}
+                                    : ByGenomeRows{sh.d_rows, sh.chunks_per_row, false};
 
   unsigned long long *d_out = nullptr, *d_nbin = nullptr, *d_binoff = nullptr;
   uint32_t *d_index = nullptr, *d_chunks = nullptr, *d_acc = nullptr;
@@ -198,13 +211,13 @@ int count_by_genome_shard(kgx_pop_shard& sh, const uint8_t* bin_of_variant, uint
   // every buffer of the call out of the device's arena; the work list's size is bounded before the bins are known:
   // about `target` items, one more per (bin, column group) for the bins' last pieces
   const uint32_t n_chunks = static_cast<uint32_t>((V + kBinChunk - 1) / kBinChunk);
-  const ByGenomeShape shape = by_genome_shape(sh.chunks_per_row);
+  const ByGenomeShape shape = by_genome_shape(source.chunks_per_row);
   const uint32_t n_cg = shape.n_cg;
-  const int W = lanes_per_row(sh.chunks_per_row);
+  const int W = lanes_per_row(source.chunks_per_row);
   // Work items: equal stretches of the bin-grouped row list, one column group each, KGX_K3_ROUNDS (default 1) per workgroup
   // the device holds at once -- every item runs from the start of the kernel to its end, none is left for a thin last round.
   int resident_per_cu = 0;
-  (void)dispatch_by_genome(W, sh, shape, static_cast<const uint32_t*>(nullptr), static_cast<const GenomeWork*>(nullptr), 0u,
+  (void)dispatch_by_genome(W, sh, source, shape, static_cast<const uint32_t*>(nullptr), static_cast<const GenomeWork*>(nullptr), 0u,
                            static_cast<const unsigned long long*>(nullptr), n_bins, static_cast<uint32_t*>(nullptr), &resident_per_cu);
   const int rounds = std::max(1, env_int("KGX_K3_ROUNDS", 1));
   const uint64_t target = static_cast<uint64_t>(dev.compute_units) * static_cast<uint64_t>(resident_per_cu) * static_cast<uint64_t>(rounds);
@@ -288,7 +301,7 @@ int count_by_genome_shard(kgx_pop_shard& sh, const uint8_t* bin_of_variant, uint
     if (rc == KGX_OK) {
       const uint32_t n_work = static_cast<uint32_t>(work.size());
       try_hip(hipEventRecord(dev.by_genome_begin, st), KGX_EHIP, "hipEventRecord");
-      (void)dispatch_by_genome(W, sh, shape, static_cast<const uint32_t*>(d_index), static_cast<const GenomeWork*>(d_work), n_work,
+      (void)dispatch_by_genome(W, sh, source, shape, static_cast<const uint32_t*>(d_index), static_cast<const GenomeWork*>(d_work), n_work,
                                static_cast<const unsigned long long*>(d_binoff), n_bins, d_acc, static_cast<int*>(nullptr));
       try_hip(hipGetLastError(), KGX_EHIP, "k_count_by_genome launch");
       try_hip(hipEventRecord(dev.by_genome_end, st), KGX_EHIP, "hipEventRecord");
@@ -296,9 +309,10 @@ int count_by_genome_shard(kgx_pop_shard& sh, const uint8_t* bin_of_variant, uint
     }
   }
   if (rc == KGX_OK && cells > 0) {
-    hipLaunchKernelGGL(k_finish_by_genome, dim3(stream_grid(dev, cells, kBlock)), dim3(kBlock), 0, st, d_acc, d_nbin, G, n_bins, n_cg, shape.cg_width, d_out);
+    if (plane) hipLaunchKernelGGL(k_finish_plane_by_genome, dim3(stream_grid(dev, cells, kBlock)), dim3(kBlock), 0, st, d_acc, G, n_bins, n_cg, shape.cg_width, d_out);
+    else hipLaunchKernelGGL(k_finish_by_genome, dim3(stream_grid(dev, cells, kBlock)), dim3(kBlock), 0, st, d_acc, d_nbin, G, n_bins, n_cg, shape.cg_width, d_out);
     try_hip(hipGetLastError(), KGX_EHIP, "k_finish_by_genome launch");
-    try_hip(hipMemcpyAsync(out, d_out, cells * 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost, st), KGX_EHIP, "D2H(out)");
+    try_hip(hipMemcpyAsync(out, d_out, cells * (plane ? 1 : 4) * sizeof(unsigned long long), hipMemcpyDeviceToHost, st), KGX_EHIP, "D2H(out)");
     try_hip(hipStreamSynchronize(st), KGX_EHIP, "stream synchronize");
   }
   dev.last_by_genome_ms = 0.0;
@@ -318,7 +332,8 @@ void zero_masked_genomes(const kgx_pop* pop, uint64_t* out, uint64_t words_per_g
     if (!pop->keep[g]) std::memset(out + g * words_per_genome, 0, words_per_genome * sizeof(uint64_t));
 }
 
-int count_by_genome_impl(kgx_pop* pop, const uint8_t* bin_of_variant, uint32_t n_bins, uint64_t* out, const double* bin_edges = nullptr) {
+int count_by_genome_impl(kgx_pop* pop, const uint8_t* bin_of_variant, uint32_t n_bins, uint64_t* out, const double* bin_edges = nullptr,
+                         bool plane = false) {
   if (!pop->keep.empty() && !pop->counts_current && pop->n_variants) {
     // which rows still have a carrier: the population's K2 counts under the mask, on every shard's device
     if (int rc = sweep_and_exchange(pop, nullptr, nullptr, true)) return rc;
@@ -327,9 +342,9 @@ int count_by_genome_impl(kgx_pop* pop, const uint8_t* bin_of_variant, uint32_t n
   }
   const int rc = for_each_parallel(pop->shards.size(), [&](size_t s) {
     kgx_pop_shard& sh = pop->shards[s];
-    return count_by_genome_shard(sh, bin_of_variant, n_bins, out + sh.genome_base * n_bins * 4, bin_edges);
+    return count_by_genome_shard(sh, bin_of_variant, n_bins, out + sh.genome_base * n_bins * (plane ? 1 : 4), bin_edges, plane);
   });
-  if (rc == KGX_OK) zero_masked_genomes(pop, out, static_cast<uint64_t>(n_bins) * 4);
+  if (rc == KGX_OK) zero_masked_genomes(pop, out, static_cast<uint64_t>(n_bins) * (plane ? 1 : 4));
   return rc;
 }
 
@@ -480,6 +495,7 @@ void destroy_shards(kgx_pop* pop) {
     if (sh.d_af) (void)hipFree(sh.d_af);
     if (sh.d_counts) (void)hipFree(sh.d_counts);
     if (sh.d_keep) (void)hipFree(sh.d_keep);
+    if (sh.d_phase) (void)hipFree(sh.d_phase);
   }
   if (!pop->shards.empty()) (void)use_device(*pop->shards[0].dev);
 }
@@ -675,6 +691,48 @@ int kgx_population_read_dosage2(const kgx_pop* pop, uint8_t* dst, uint64_t dst_p
   });
 }
 
+int kgx_population_load_phase_plane(kgx_pop* pop, const uint8_t* src, uint64_t src_pitch, uint64_t v0, uint64_t v1) {
+  return guarded([&]() -> int {
+    if (int bound = require_bound()) return bound;
+    if (!pop || !src) return fail(KGX_EINVAL, "null population or source");
+    if (v0 > v1 || v1 > pop->n_variants) return fail(KGX_EINVAL, "variant range out of bounds");
+    if (src_pitch < (pop->n_genomes + 7) / 8) return fail(KGX_EINVAL, "src_pitch too small for one bit per genome");
+    for (auto& sh : pop->shards) {
+      if (sh.n_genomes == 0) continue;
+      if (int rc = use_device(*sh.dev)) return rc;
+      if (!sh.d_phase) {                                       // on first use: as many rows as the dosage rows have room for
+        sh.phase_pitch = ((sh.n_genomes + 7) / 8 + 15) / 16 * 16;
+        const uint64_t bytes = sh.phase_pitch * (sh.capacity ? sh.capacity : 1);
+        KGX_HIP_MEM(hipMalloc(&sh.d_phase, bytes));
+        KGX_HIP(hipMemsetAsync(sh.d_phase, 0, bytes, sh.dev->stream));
+      }
+      if (v0 == v1) continue;
+      // genome_base is a multiple of 64: the shard's bits start on a byte of the source row
+      KGX_HIP(hipMemcpy2DAsync(sh.d_phase + v0 * sh.phase_pitch, sh.phase_pitch, src + sh.genome_base / 8, src_pitch, (sh.n_genomes + 7) / 8, v1 - v0,
+                               hipMemcpyHostToDevice, sh.dev->stream));
+      // (every shard but the last holds whole 64-genome units: no byte is shared between shards)
+    }
+    return sync_shards(pop);
+  });
+}
+
+int kgx_unique_phased_counts(kgx_pop* pop, const uint8_t* bin_of_variant, uint32_t n_bins, uint64_t* out) {
+  return guarded([&]() -> int {
+    if (int bound = require_bound()) return bound;
+    if (!pop || !out) return fail(KGX_EINVAL, "null population or output");
+    if (n_bins == 0 || n_bins > 254) return fail(KGX_EINVAL, "n_bins %u outside [1,254]", n_bins);
+    // UniquePhasedFilter keeps one Variant object per distinct (HGVS, phase): a variant a genome carries counts once, and
+    // once more where its copies sit on both phases (the plane's bit)
+    std::vector<uint64_t> present(pop->n_genomes * n_bins * 4), both(pop->n_genomes * n_bins);
+    int rc = count_by_genome_impl(pop, bin_of_variant, n_bins, present.data());
+    if (rc == KGX_OK) rc = count_by_genome_impl(pop, bin_of_variant, n_bins, both.data(), nullptr, true);
+    (void)use_device(*pop->shards[0].dev);
+    if (rc != KGX_OK) return rc;
+    for (uint64_t i = 0; i < pop->n_genomes * n_bins; ++i) out[i] = present[i * 4 + 1] + present[i * 4 + 2] + present[i * 4 + 3] + both[i];
+    return KGX_OK;
+  });
+}
+
 int kgx_population_resize(kgx_pop* pop, uint64_t n_variants) {
   return guarded([&]() -> int {
     if (pop) pop->counts_current = false;
@@ -682,7 +740,7 @@ int kgx_population_resize(kgx_pop* pop, uint64_t n_variants) {
     if (!pop) return fail(KGX_EINVAL, "null population");
     // Two phases, so that a failure leaves every shard as it was: first every allocation, copy and fill that can fail
     // (into blocks the shards do not own yet), then the pointers and the row count of all shards together.
-    struct Grown { uint8_t* block = nullptr; uint64_t capacity = 0; };
+    struct Grown { uint8_t* block = nullptr; uint64_t capacity = 0; uint8_t* plane = nullptr; };
     std::vector<Grown> grown(pop->shards.size());
     int rc = KGX_OK;
     for (size_t s = 0; s < pop->shards.size() && rc == KGX_OK; ++s) {
@@ -708,6 +766,19 @@ int kgx_population_resize(kgx_pop* pop, uint64_t n_variants) {
             (void)hipGetLastError();
             rc = fail(KGX_EHIP, "copying the dosage rows into the grown allocation failed");
           }
+          if (rc == KGX_OK && sh.d_phase) {                       // a loaded phase plane grows with the rows
+            const uint64_t held_plane = sh.phase_pitch * sh.n_variants;
+            if (hipMalloc(&grown[s].plane, sh.phase_pitch * capacity) != hipSuccess) {
+              (void)hipGetLastError();
+              grown[s].plane = nullptr;
+              rc = fail(KGX_ENOMEM, "hipMalloc of the grown phase plane on device %d failed", sh.dev->id);
+            } else if ((held_plane && hipMemcpyAsync(grown[s].plane, sh.d_phase, held_plane, hipMemcpyDeviceToDevice, sh.dev->stream) != hipSuccess) ||
+                       hipMemsetAsync(grown[s].plane + held_plane, 0, sh.phase_pitch * capacity - held_plane, sh.dev->stream) != hipSuccess ||
+                       hipStreamSynchronize(sh.dev->stream) != hipSuccess) {
+              (void)hipGetLastError();
+              rc = fail(KGX_EHIP, "copying the phase plane into the grown allocation failed");
+            }
+          }
         }
       } else if (n_variants > sh.n_variants && sh.pitch) {
         // within the allocation: rows a shrink left behind must read as empty again (rows past n_variants: nobody reads them yet)
@@ -716,11 +787,20 @@ int kgx_population_resize(kgx_pop* pop, uint64_t n_variants) {
           (void)hipGetLastError();
           rc = fail(KGX_EHIP, "clearing the rows behind the population failed");
         }
+        if (rc == KGX_OK && sh.d_phase &&
+            (hipMemsetAsync(sh.d_phase + sh.phase_pitch * sh.n_variants, 0, sh.phase_pitch * (n_variants - sh.n_variants), sh.dev->stream) != hipSuccess ||
+             hipStreamSynchronize(sh.dev->stream) != hipSuccess)) {
+          (void)hipGetLastError();
+          rc = fail(KGX_EHIP, "clearing the phase plane behind the population failed");
+        }
       }
     }
     if (rc != KGX_OK) {
       for (size_t s = 0; s < pop->shards.size(); ++s)
-        if (grown[s].block && use_device(*pop->shards[s].dev) == KGX_OK) (void)hipFree(grown[s].block);
+        if ((grown[s].block || grown[s].plane) && use_device(*pop->shards[s].dev) == KGX_OK) {
+          if (grown[s].block) (void)hipFree(grown[s].block);
+          if (grown[s].plane) (void)hipFree(grown[s].plane);
+        }
       (void)use_device(*pop->shards[0].dev);
       return rc;
     }
@@ -731,6 +811,10 @@ int kgx_population_resize(kgx_pop* pop, uint64_t n_variants) {
         if (sh.d_alloc) (void)hipFree(sh.d_alloc);
         sh.d_alloc = sh.d_rows = grown[s].block;
         sh.capacity = grown[s].capacity;
+        if (grown[s].plane) {
+          (void)hipFree(sh.d_phase);
+          sh.d_phase = grown[s].plane;
+        }
       }
       if (n_variants != sh.n_variants) {                       // the per-variant columns follow the row count: re-created on demand
         if (sh.d_af) { (void)hipFree(sh.d_af); sh.d_af = nullptr; }

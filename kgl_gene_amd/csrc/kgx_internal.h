@@ -145,6 +145,10 @@ struct kgx_pop_shard {
   void* d_counts = nullptr;      // [n_variants][4] u32 scratch for the host-returning entry points
   uint8_t* d_keep = nullptr;     // [pitch] genome mask in the rows' own layout: 0b11 where the genome takes part; null = all do
   uint64_t n_kept = 0;           // genomes of the shard taking part (n_genomes without a mask)
+  // phase plane (kgx_population_load_phase_plane): one bit per (row, genome of the shard), rows of phase_pitch bytes
+  // (a multiple of 16: 128-genome chunks), capacity rows like d_rows; null until a plane is loaded
+  uint8_t* d_phase = nullptr;
+  uint64_t phase_pitch = 0;
 };
 
 struct kgx_pop {

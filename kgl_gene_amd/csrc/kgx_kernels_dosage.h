@@ -341,7 +341,9 @@ __device__ __forceinline__ void by_genome_pass(const kgx_v4u* __restrict__ rows,
   saw_nondiploid |= seen & 0x55555555u;
 }
 
-template <int W>
+// PLANE: the rows are a 1-bit-per-genome matrix (the phase plane): every bit is a stream of its own, there is no
+// "non-diploid" second pass.
+template <int W, bool PLANE = false>
 __global__ void __launch_bounds__(kBlock)
 k_count_by_genome(const kgx_v4u* __restrict__ rows, uint32_t chunks_per_row, uint32_t cg_width,
                   const uint32_t* __restrict__ row_index, const GenomeWork* __restrict__ work,
@@ -370,7 +372,7 @@ k_count_by_genome(const kgx_v4u* __restrict__ rows, uint32_t chunks_per_row, uin
       if (v) atomicAdd(&mine[idx], v);
     }
     // Non-diploid codes are exceptional: count them in a second pass only if this workgroup saw one.
-    if (__syncthreads_or(seen != 0)) {
+    if (!PLANE && __syncthreads_or(seen != 0)) {
       for (int i = threadIdx.x; i < 64 * kLdsStride; i += kBlock) lds[i] = 0;
       __syncthreads();
       uint32_t unused = 0;
@@ -407,6 +409,24 @@ k_finish_by_genome(const uint32_t* __restrict__ acc, const unsigned long long* _
     out[i * 4 + 1] = a - c;
     out[i * 4 + 2] = b - c;
     out[i * 4 + 3] = c;
+  }
+}
+
+// The same accumulators read as a 1-bit-per-genome matrix (the phase plane): k_count_by_genome counts every bit position of
+// a 16-byte chunk over the rows, whatever the bits mean -- here bit p of a chunk is genome 128 * chunk + p, counter
+// (p / 32) * 32 + p % 32 = p of the chunk's lane.  out[g][bin] += the count.
+__global__ void __launch_bounds__(kBlock)
+k_finish_plane_by_genome(const uint32_t* __restrict__ acc, uint64_t n_genomes, uint32_t n_bins, uint32_t n_cg, uint32_t cg_width,
+                         unsigned long long* __restrict__ out) {
+  const uint64_t total = n_genomes * n_bins;
+  for (uint64_t i = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < total;
+       i += static_cast<uint64_t>(gridDim.x) * blockDim.x) {
+    const uint64_t g = i / n_bins;
+    const uint32_t bin = static_cast<uint32_t>(i % n_bins);
+    const uint32_t chunk = static_cast<uint32_t>(g / 128), p = static_cast<uint32_t>(g % 128);
+    const uint32_t cg = chunk / cg_width, sub = chunk % cg_width;
+    const uint32_t* mine = acc + (static_cast<uint64_t>(bin) * n_cg + cg) * (kAccCounters * kLdsStride);
+    out[i] = mine[p * kLdsStride + sub];
   }
 }
 

@@ -573,6 +573,20 @@ int kgo_offset_filter_counts(kgo_pop* p, const char* contig, uint64_t* out) {
   return 0;
 }
 
+// UniquePhasedFilter the same way: out[g] = the Variant objects it leaves of the genome's contig.
+int kgo_unique_phased_counts(kgo_pop* p, const char* contig, uint64_t* out) {
+  if (!p || !contig || !out) return -1;
+  size_t g = 0;
+  for (const auto& [genome_id, genome_ptr] : p->pop->getMap()) {
+    out[g] = 0;
+    auto found = genome_ptr->getMap().find(contig);
+    if (found != genome_ptr->getMap().end())
+      for (const auto& [offset, offset_ptr] : found->second->getMap()) out[g] += uniquePhasedFilter(*offset_ptr)->getVariantArray().size();
+    ++g;
+  }
+  return 0;
+}
+
 double kgo_wrights_fis(const uint64_t location[7], const uint64_t genome[7]) {
   VariantAnalysisType l, g;
   l.total_variants_ = location[0]; l.heterozygous_minor_alleles_ = location[4]; l.heterozygous_reference_minor_alleles_ = location[5];

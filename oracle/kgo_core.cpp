@@ -120,6 +120,20 @@ std::unique_ptr<OffsetDB> uniqueUnphasedFilter(const OffsetDB& offset) {
   return out;
 }
 
+// kgl_variant_filter_db_offset.cpp:160-181: unique variants including phase
+std::unique_ptr<OffsetDB> uniquePhasedFilter(const OffsetDB& offset) {
+  std::unordered_set<std::string> hashed;
+  auto out = std::make_unique<OffsetDB>();
+  for (const auto& v : offset.getVariantArray()) {
+    auto h = v->HGVS_Phase();
+    if (!hashed.count(h)) {
+      hashed.insert(h);
+      out->addVariant(v);
+    }
+  }
+  return out;
+}
+
 std::unique_ptr<OffsetDB> diploidFilter(const OffsetDB& offset) {
   auto out = std::make_unique<OffsetDB>();
   if (offset.getVariantArray().size() <= 2)

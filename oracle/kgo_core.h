@@ -129,6 +129,7 @@ using OffsetFilter = std::function<std::unique_ptr<OffsetDB>(const OffsetDB&)>;
 std::unique_ptr<OffsetDB> homozygousFilter(const OffsetDB& offset);
 std::unique_ptr<OffsetDB> heterozygousFilter(const OffsetDB& offset);
 std::unique_ptr<OffsetDB> uniqueUnphasedFilter(const OffsetDB& offset);
+std::unique_ptr<OffsetDB> uniquePhasedFilter(const OffsetDB& offset);      // kgl_variant_filter_db_offset.cpp:160-181
 std::unique_ptr<OffsetDB> diploidFilter(const OffsetDB& offset);          // kgl_variant_filter_db_offset.cpp:110-129
 
 class ContigDB {

@@ -73,6 +73,7 @@ def lib() -> C.CDLL:
         "kgo_fws": (C.c_int, [vp, vp, vp]),
         "kgo_hethom": (C.c_int, [vp, C.c_char_p, vp]),
         "kgo_offset_filter_counts": (C.c_int, [vp, C.c_char_p, vp]),
+        "kgo_unique_phased_counts": (C.c_int, [vp, C.c_char_p, vp]),
         "kgo_wrights_fis": (dbl, [vp, vp]),
         "kgo_class_frequencies": (C.c_int, [vp, C.c_uint32, dbl, C.c_int, vp]),
         "kgo_sample_locii": (i64, [vp, C.c_int, C.c_int, u64, u64, u64, u64, dbl, dbl, vp, u64]),
@@ -279,6 +280,12 @@ class Population:
         """[genomes][4]: Variant objects HomozygousFilter / HeterozygousFilter / DiploidFilter / UniqueUnphasedFilter leave."""
         out = np.zeros((self.genome_count(), 4), dtype=np.uint64)
         assert lib().kgo_offset_filter_counts(self._h, contig.encode(), _p(out)) == 0
+        return out
+
+    def unique_phased_counts(self, contig):
+        """[genomes]: the Variant objects UniquePhasedFilter (one per distinct HGVS and phase) leaves of the contig."""
+        out = np.zeros(self.genome_count(), dtype=np.uint64)
+        assert lib().kgo_unique_phased_counts(self._h, contig.encode(), _p(out)) == 0
         return out
 
     def hethom_present(self, contig):

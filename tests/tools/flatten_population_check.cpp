@@ -3,6 +3,7 @@
 // identical.  Built and run by tests/tools/sanitize_host.sh under ASan/UBSan and under TSan (the flattener's discovery
 // walk and its packing loop are both multi-threaded); no GPU, no oracle.
 #include <cstdio>
+#include <map>
 #include <random>
 
 #include "kgx_flatten.h"
@@ -45,9 +46,23 @@ int main() {
   }
   const gpu::FlatPopulation one = gpu::flattenPopulation(*population, 1);
   int failures = 0;
+  {
+    // the phase plane against a direct count: a cell's bit is set exactly where the genome holds the row's variant on both phases
+    size_t set_bits = 0, expected = 0;
+    for (const uint8_t byte : one.phase_plane) set_bits += static_cast<size_t>(__builtin_popcount(byte));
+    for (const auto& [genome_id, genome_ptr] : population->getMap())
+      for (const auto& [contig_id, contig_ptr] : genome_ptr->getMap())
+        for (const auto& [offset, offset_ptr] : contig_ptr->getMap()) {
+          std::map<std::string, unsigned> phases_of;
+          for (const auto& v : offset_ptr->getVariantArray()) phases_of[v->HGVS()] |= v->phaseId() == kgl::VariantPhase::DIPLOID_PHASE_A ? 1u : 2u;
+          for (const auto& [hgvs, mask] : phases_of) expected += mask == 3u ? 1 : 0;
+        }
+    std::printf("phase plane: %zu cells on both phases, %zu expected\n", set_bits, expected);
+    failures += (set_bits == expected && expected > 0) ? 0 : 1;
+  }
   for (const size_t threads : {2u, 7u, 64u}) {
     const gpu::FlatPopulation many = gpu::flattenPopulation(*population, threads);
-    bool same = many.packed == one.packed && many.genome_ids == one.genome_ids && many.rows.size() == one.rows.size() &&
+    bool same = many.packed == one.packed && many.phase_plane == one.phase_plane && many.genome_ids == one.genome_ids && many.rows.size() == one.rows.size() &&
                 many.variant_objects == one.variant_objects && many.non_diploid.size() == one.non_diploid.size() && many.primary_rows == one.primary_rows;
     for (size_t r = 0; same && r < one.rows.size(); ++r)
       same = many.rows[r].hgvs == one.rows[r].hgvs && many.rows[r].variant == one.rows[r].variant && many.rows[r].split_of == one.rows[r].split_of &&
