@@ -1,7 +1,10 @@
 #include "kgx_flatten.h"
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
 #include <limits>
 #include <map>
 #include <thread>
@@ -39,6 +42,14 @@ static float infoAF(const Variant& variant) {
 FlatPopulation flattenPopulation(const PopulationDB& population, size_t threads) {
   FlatPopulation flat;
   if (threads == 0) threads = std::max<size_t>(std::thread::hardware_concurrency(), 2) - 1;
+  const bool trace = std::getenv("KGX_FLATTEN_TRACE") != nullptr;
+  auto t_last = std::chrono::steady_clock::now();
+  auto lap = [&](const char* what) {
+    if (!trace) return;
+    const auto now = std::chrono::steady_clock::now();
+    std::fprintf(stderr, "kgx flattenPopulation: %s %.3f s\n", what, std::chrono::duration<double>(now - t_last).count());
+    t_last = now;
+  };
 
   // Row index: distinct HGVS in std::map order, first Variant seen kept (PopulationDB::uniqueVariants,
   // kgl_variant_db_population.cpp:133-161).  Shared Variant objects (one per record/alt/phase in the
@@ -54,20 +65,32 @@ FlatPopulation flattenPopulation(const PopulationDB& population, size_t threads)
     // The walk over every Variant pointer of every genome (1e7 visits for 1000 genomes x 20,000 variants) in parallel:
     // each worker takes a contiguous run of genomes and notes, per distinct object, where the serial walk would have met it
     // first -- (genome, visit within the genome) -- so that the merge below keeps exactly the object the serial order keeps.
-    struct FirstSeen { uint64_t position; std::shared_ptr<const Variant> variant; };
+    // (the object's shared_ptr is noted by address: copying it here would bump one reference count per sighting from every
+    // thread at once -- 255 threads x 40,000 shared objects on the GPU box)
+    struct FirstSeen { uint64_t position; const std::shared_ptr<const Variant>* variant; };
     const size_t n_genomes = genome_ptrs.size();
-    const size_t walkers = std::max<size_t>(1, std::min(threads, n_genomes));
+    // (at most 32 walkers: every one of them meets every shared object again, and their findings are merged one after the other)
+    const size_t walkers = std::max<size_t>(1, std::min<size_t>(std::min(threads, n_genomes), 32));
     std::vector<std::unordered_map<const Variant*, FirstSeen>> found(walkers);
     std::vector<uint64_t> visits(walkers, 0);
     auto walk = [&](size_t t) {
       const size_t g_begin = n_genomes * t / walkers, g_end = n_genomes * (t + 1) / walkers;
       auto& mine = found[t];
+      // most visits meet an object met before (one object per record, alt and phase serves every genome): a direct-mapped
+      // cache of the last pointers seen answers those without touching the hash map
+      constexpr size_t kCache = size_t{1} << 16;
+      std::vector<const Variant*> recent(kCache, nullptr);
       for (size_t g = g_begin; g < g_end; ++g) {
         uint64_t visit = 0;
         for (const auto& [contig_id, contig_ptr] : genome_ptrs[g]->getMap())
           for (const auto& [offset, offset_ptr] : contig_ptr->getMap())
             for (const auto& variant_ptr : offset_ptr->getVariantArray()) {
-              mine.try_emplace(variant_ptr.get(), FirstSeen{(static_cast<uint64_t>(g) << 32) | visit, variant_ptr});
+              const Variant* object = variant_ptr.get();
+              const Variant*& slot = recent[(reinterpret_cast<uintptr_t>(object) >> 4) & (kCache - 1)];
+              if (slot != object) {
+                slot = object;
+                mine.try_emplace(object, FirstSeen{(static_cast<uint64_t>(g) << 32) | visit, &variant_ptr});
+              }
               ++visit;
             }
         visits[t] += visit;
@@ -90,10 +113,11 @@ FlatPopulation flattenPopulation(const PopulationDB& population, size_t threads)
     for (const auto& [ptr, first] : all) in_order.push_back(&first);
     std::sort(in_order.begin(), in_order.end(), [](const FirstSeen* a, const FirstSeen* b) { return a->position < b->position; });
     for (const FirstSeen* first : in_order) {
-      auto it = unique.try_emplace(first->variant->HGVS(), first->variant).first;
-      seen.emplace(first->variant.get(), &it->first);
+      auto it = unique.try_emplace((*first->variant)->HGVS(), *first->variant).first;
+      seen.emplace(first->variant->get(), &it->first);
     }
   }
+  lap("distinct variants found");
   std::unordered_map<const Variant*, uint32_t> row_of;
   row_of.reserve(seen.size());
   {
@@ -140,6 +164,7 @@ FlatPopulation flattenPopulation(const PopulationDB& population, size_t threads)
     }
   }
 
+  lap("rows indexed");
   const size_t G = flat.genome_ids.size();
   const size_t V = flat.rows.size();
   flat.row_bytes = (G + 3) / 4;
@@ -207,6 +232,7 @@ FlatPopulation flattenPopulation(const PopulationDB& population, size_t threads)
   for (size_t t = 1; t < threads; ++t) pool.emplace_back(worker, t);
   worker(0);
   for (auto& th : pool) th.join();
+  lap("rows packed");
   for (auto& o : overflow) flat.non_diploid.insert(flat.non_diploid.end(), o.begin(), o.end());
   bool two_phases = false;
   for (const uint8_t flag : any_two_phases) two_phases = two_phases || flag;
