@@ -380,7 +380,8 @@ def aux_k1_flatten(args, capi):
             from kgl_gene_amd import build as kbuild
             kbuild.build_host()
         t0 = time.perf_counter()
-        res = subprocess.run([str(rio.DRIVER), "GPU_ALLELE", tmp, "--", str(path)], capture_output=True, text=True)
+        res = subprocess.run([str(rio.DRIVER), "GPU_ALLELE", tmp, "--", str(path)], capture_output=True, text=True,
+                             env=dict(os.environ, KGX_FLATTEN_TRACE="1"))
         process_seconds = time.perf_counter() - t0
         log = res.stdout + res.stderr
         m = re.search(r"K1 \(createVariantDB's work\): flatten ([0-9.eE+-]+) s, device rows created and uploaded ([0-9.eE+-]+) s, (\d+) genomes x (\d+) rows", log)
@@ -397,7 +398,8 @@ def aux_k1_flatten(args, capi):
         "value": cells / (flatten_s + upload_s), "unit": "variants·genomes/s", "seconds": {"flatten_host": flatten_s, "create_and_upload": upload_s},
         "config": {"workload": f"{G} genomes x {V} variants of the headline's synthetic population as a PopulationDB ({int(opop.variant_count())} Variant objects)",
                    "boundary": "GPU_ALLELE through kgx_host_driver (VirtualAnalysis::fileReadAnalysis); the PopulationDB itself is the parser's output, untimed on both sides",
-                   "whole_process_seconds": round(process_seconds, 3), "rows_on_device": int(m.group(4))},
+                   "whole_process_seconds": round(process_seconds, 3), "rows_on_device": int(m.group(4)),
+                   "flatten_phases_s": {what.strip(): float(sec) for what, sec in re.findall(r"kgx flattenPopulation: (.*?) ([0-9.]+) s", log)}},
         "cpu_baseline": {"value": cells / vdb.build_seconds, "unit": "variants·genomes/s", "cores": threads, "kind": "port",
                          "sample": f"the same PopulationDB through the oracle's createVariantDB ({vdb.build_seconds:.3f} s on {threads} pool threads = "
                                    f"hardware_concurrency() - 1 capped by the genome count); parity: the package's VariantFWS.csv == summaryByVariant of every "
