@@ -1126,7 +1126,7 @@ double kgx_count_by_genome_last_ms(void) {
   const auto rt = current_runtime();
   double worst = 0.0;
   if (rt)
-    for (const auto& dev : rt->devs) worst = dev->last_by_genome_ms > worst ? dev->last_by_genome_ms : worst;
+    for (const auto& dev : rt->devs) { const double ms = dev->last_by_genome_ms.load(); worst = ms > worst ? ms : worst; }
   return worst;
 }
 

@@ -831,7 +831,7 @@ double kgx_inbreed_last_sweep_ms(void) {
   const auto rt = current_runtime();
   double worst = 0.0;
   if (rt)
-    for (const auto& dev : rt->devs) worst = dev->last_sweep_ms > worst ? dev->last_sweep_ms : worst;
+    for (const auto& dev : rt->devs) { const double ms = dev->last_sweep_ms.load(); worst = ms > worst ? ms : worst; }
   return worst;
 }
 
@@ -839,7 +839,7 @@ double kgx_inbreed_last_kernel_ms(void) {
   const auto rt = current_runtime();
   double worst = 0.0;
   if (rt)
-    for (const auto& dev : rt->devs) worst = dev->last_kernel_ms > worst ? dev->last_kernel_ms : worst;
+    for (const auto& dev : rt->devs) { const double ms = dev->last_kernel_ms.load(); worst = ms > worst ? ms : worst; }
   return worst;
 }
 
@@ -847,7 +847,7 @@ int kgx_inbreed_last_evaluations(void) {
   const auto rt = current_runtime();
   int most = 0;
   if (rt)
-    for (const auto& dev : rt->devs) most = dev->last_evaluations > most ? dev->last_evaluations : most;
+    for (const auto& dev : rt->devs) { const int n = dev->last_evaluations.load(); most = n > most ? n : most; }
   return most;
 }
 

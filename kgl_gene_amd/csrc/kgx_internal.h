@@ -9,6 +9,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <atomic>
 #include <memory>
 #include <mutex>
 #include <new>
@@ -36,9 +37,10 @@ struct Device {
   hipEvent_t kernel_begin = nullptr, kernel_end = nullptr; // ... and the one kernel of it that walks the genotype bytes
   hipEvent_t ready = nullptr;                              // cross-stream ordering (kgx_allele_count_by_locus_dev)
   hipEvent_t by_genome_begin = nullptr, by_genome_end = nullptr;   // bracket the K3 kernel of the last by-genome sweep here
-  double last_by_genome_ms = 0.0;
-  double last_sweep_ms = 0.0, last_kernel_ms = 0.0;
-  int last_evaluations = 0;                                // objective evaluations of the last Loglikelihood call here
+  // what the kgx_*_last_* getters report: written by the call that owns `mutex`, read by any thread without it
+  std::atomic<double> last_by_genome_ms{0.0};
+  std::atomic<double> last_sweep_ms{0.0}, last_kernel_ms{0.0};
+  std::atomic<int> last_evaluations{0};                    // objective evaluations of the last Loglikelihood call here
   char* scratch = nullptr;                                 // grow-only arena for kgx_inbreed's per-call buffers
   size_t scratch_bytes = 0;
   char* compact[2] = {nullptr, nullptr};                   // ping-pong buffers of the Loglikelihood search's compaction levels
