@@ -208,8 +208,8 @@ int count_by_genome_shard(kgx_pop_shard& sh, const uint8_t* bin_of_variant, uint
       rc = fail(code, "count_by_genome: %s failed: %s", what, hipGetErrorString(e));
     }
   };
-  // every buffer of the call out of the device's arena; the work list's size is bounded before the bins are known:
-  // about `target` items, one more per (bin, column group) for the bins' last pieces
+  // every buffer of the call out of the device's arena; the work list's size is known before the bins are: about `target`
+  // equal stretches of the row list (they may cross bin boundaries), one item per column group each
   const uint32_t n_chunks = static_cast<uint32_t>((V + kBinChunk - 1) / kBinChunk);
   const ByGenomeShape shape = by_genome_shape(source.chunks_per_row);
   const uint32_t n_cg = shape.n_cg;
