@@ -688,3 +688,39 @@ def test_offsets_holding_more_than_15_distinct_variants(tmp_path, kgx):
     assert np.array_equal(listed[:, 0, 0] + single[:, 1], want[:, 5])     # het_ref_minor
     assert np.array_equal(listed[:, 0, 1] + single[:, 2] + single[:, 3], want[:, 3])   # hom_minor: distinct variants where >= 2 copies
     pop.close()
+
+
+def test_gpu_inbreed_package_entropy_modes(tmp_path, kgx):
+    """The three entropy modes of GPU_INBREED's iterative estimators: no StartSeed = fresh std::random_device entropy per
+    window, the reference's behaviour (two runs differ in HallME's coefficients, not in the class counts); StartSeed =
+    repeatable; StartPoints=Midpoint = deterministic without draws."""
+    G, L = 61, 1500
+    rec, gt = sv.multiallelic_block(G, L, rng_seed=47, missing_af_frac=0.02, dup_records=10)
+    for a in rec.af:
+        a[:, 4] = a[:, 5]
+    ids = sv.genome_ids(G, prefix="NA")
+    ped = [(g, "EUR") for g in ids]
+    ref_path, dip_path = tmp_path / "gnomad.bin", tmp_path / "diploid.bin"
+    rio.write_records(ref_path, rec, None, ["Reference"], oa.Population.REFERENCE, "Gnomad2_1", population_id="Gnomad")
+    rio.write_records(dip_path, rec, gt, ids, oa.Population.PHASED, "Genome1000", population_id="Diploid", ped=ped)
+    params = dict(AnalysisType="false", OutputFile="inbreed", Algorithm="HallME", MinAlleleFreq=0.02, MaxAlleleFreq=0.9,
+                  LowerWindow=0, UpperWindow=60000, LociiCount=150, SamplingDistance=40)
+
+    def run(**extra):
+        res = rio.run_driver("GPU_INBREED", tmp_path, [ref_path, dip_path], **params, **extra)
+        assert res.returncode == 0, res.stderr
+        header, rows = rio.read_csv(tmp_path / "inbreed_detail.csv")
+        counts = [[int(r[k]) for k in (2, 4, 6, 8, 10)] for r in rows]
+        return counts, np.array([float(r[11]) for r in rows])
+
+    counts_a, f_a = run()
+    counts_b, f_b = run()
+    assert counts_a == counts_b and np.all(np.isfinite(f_a)) and np.all(np.isfinite(f_b))
+    assert not np.array_equal(f_a, f_b)                               # fresh entropy: HallME has not converged, the start shows
+    assert np.abs(f_a - f_b).max() < 0.2
+    _, f_c = run(StartSeed=5)
+    _, f_d = run(StartSeed=5)
+    assert np.array_equal(f_c, f_d)
+    _, f_e = run(StartPoints="Midpoint")
+    _, f_f = run(StartPoints="Midpoint")
+    assert np.array_equal(f_e, f_f) and not np.array_equal(f_e, f_c)
