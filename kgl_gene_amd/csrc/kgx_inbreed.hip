@@ -162,7 +162,8 @@ int inbreed_shard(kgx_gt8_shard& sh, uint64_t g0, uint64_t g1, const uint32_t* l
   double* d_seq_out = reinterpret_cast<double*>(arena + o_seq_out);
   EvalEntry* d_entries = reinterpret_cast<EvalEntry*>(arena + o_entries);
   unsigned long long* d_segcnt = reinterpret_cast<unsigned long long*>(arena + o_segcnt);
-  try_hip(hipMemsetAsync(d_meta, 0, (n_tab + 8) * sizeof(uint32_t), dev.stream), KGX_EHIP, "memset(meta)");
+  // (the per-locus bit masks are the SWAR sweeps' alone: k_locus_bits)
+  if (!table_sweep) try_hip(hipMemsetAsync(d_meta, 0, (n_tab + 8) * sizeof(uint32_t), dev.stream), KGX_EHIP, "memset(meta)");
   if (locus_index && n_sel) {
     d_index = reinterpret_cast<uint32_t*>(arena + o_index);
     try_hip(hipMemsetAsync(d_index, 0, (n_sel + 8) * sizeof(uint32_t), dev.stream), KGX_EHIP, "memset(index)");
