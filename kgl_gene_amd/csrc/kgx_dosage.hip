@@ -721,6 +721,7 @@ int kgx_unique_phased_counts(kgx_pop* pop, const uint8_t* bin_of_variant, uint32
     if (int bound = require_bound()) return bound;
     if (!pop || !out) return fail(KGX_EINVAL, "null population or output");
     if (n_bins == 0 || n_bins > 254) return fail(KGX_EINVAL, "n_bins %u outside [1,254]", n_bins);
+    if (!bin_of_variant && n_bins != 1) return fail(KGX_EINVAL, "without bin_of_variant every row is counted in ONE bin: n_bins must be 1");
     // UniquePhasedFilter keeps one Variant object per distinct (HGVS, phase): a variant a genome carries counts once, and
     // once more where its copies sit on both phases (the plane's bit)
     std::vector<uint64_t> present(pop->n_genomes * n_bins * 4), both(pop->n_genomes * n_bins);
