@@ -315,7 +315,9 @@ int kgx_inbreed_reference_starts(int algorithm, uint64_t seed, uint64_t first_st
 int kgx_release_scratch(void);
 /* Device time (HIP events on the library streams) of the frequency sweep -- locus helpers + the K5 kernel, i.e. the one
  * pass over the genotype bytes that every estimator makes -- of the most recent successful kgx_inbreed call (the
- * slowest shard's); 0 before the first.  For bench.py / profiles: algorithmic bytes = kgx_gt8_sweep_bytes(). */
+ * slowest shard's); 0 before the first, and 0 after a call over fewer than 2^24 cells (selected loci x genomes of a
+ * shard): those are not timed, four event records cost such a call more than its sweep takes (KGX_TIME_SMALL_CALLS=1
+ * times them all the same).  For bench.py / profiles: algorithmic bytes = kgx_gt8_sweep_bytes(). */
 double kgx_inbreed_last_sweep_ms(void);
 /* ... and of the one kernel inside it that reads the genotype bytes (k_inbreed_eval_lut<3|4>, or the SWAR / generic
  * sweep): the sweep without the per-locus helper kernels (tables, entries, segment defaults). */

@@ -121,11 +121,16 @@ int inbreed_shard(kgx_gt8_shard& sh, uint64_t g0, uint64_t g1, const uint32_t* l
   const size_t o_af = plan.add(n_tab * amax * sizeof(double)), o_table = plan.add(n_tab * stride * sizeof(double));
   const size_t o_valid = plan.add(n_tab), o_meta = plan.add((n_tab + 8) * sizeof(uint32_t));
   const size_t o_part = plan.add(max_seg * n * kParts0 * sizeof(double)), o_segdef = plan.add(max_seg * kSegDefaults * sizeof(double));
-  const size_t o_sums = plan.add(n * kParts0 * sizeof(double)), o_counts = plan.add(n * 6 * sizeof(unsigned long long));
+  const size_t o_sums = plan.add(n * kParts0 * sizeof(double));
+  // counts | F | the flag/counter word | locus index, adjacent: one memset clears them all (a window-sized call is bound
+  // by its API calls, not by its kernels)
   // (two planes of n values each for F and the objective: the paired Loglikelihood search evaluates two points per pass)
-  const size_t o_f = plan.add(2 * n * sizeof(double)), o_eval = plan.add(2 * n * sizeof(double)), o_out = plan.add(n * sizeof(LocusResultsDev));
-  const size_t o_index = plan.add((n_sel + 8) * sizeof(uint32_t)), o_golden = plan.add(n * sizeof(GoldenState));
-  const size_t o_brent = plan.add(n * sizeof(BrentState)), o_running = plan.add(sizeof(unsigned int));
+  const size_t o_counts = plan.add(n * 6 * sizeof(unsigned long long)), o_f = plan.add(2 * n * sizeof(double));
+  const size_t o_running = plan.add(sizeof(unsigned int));
+  const size_t o_index = plan.add((n_sel + 8) * sizeof(uint32_t)), o_cleared_end = plan.total;
+  const size_t o_eval = plan.add(2 * n * sizeof(double)), o_out = plan.add(n * sizeof(LocusResultsDev));
+  const size_t o_golden = plan.add(n * sizeof(GoldenState));
+  const size_t o_brent = plan.add(n * sizeof(BrentState));
   const size_t o_start = plan.add(n * sizeof(double));
   // The class-frequency sums of the defaults in the reference's own (sequential) summation order (k_seq_* kernels): from
   // the size at which a tree reduction and a sequential sum part by more than a tenth of the tolerance.
@@ -164,20 +169,17 @@ int inbreed_shard(kgx_gt8_shard& sh, uint64_t g0, uint64_t g1, const uint32_t* l
   unsigned long long* d_segcnt = reinterpret_cast<unsigned long long*>(arena + o_segcnt);
   // (the per-locus bit masks are the SWAR sweeps' alone: k_locus_bits)
   if (!table_sweep) try_hip(hipMemsetAsync(d_meta, 0, (n_tab + 8) * sizeof(uint32_t), dev.stream), KGX_EHIP, "memset(meta)");
-  if (locus_index && n_sel) {
-    d_index = reinterpret_cast<uint32_t*>(arena + o_index);
-    try_hip(hipMemsetAsync(d_index, 0, (n_sel + 8) * sizeof(uint32_t), dev.stream), KGX_EHIP, "memset(index)");
-  }
+  if (locus_index && n_sel) d_index = reinterpret_cast<uint32_t*>(arena + o_index);
   hipStream_t st = dev.stream;
+  // counts, F and (if the call has one: its 8 entries of padding stay 0) the locus index
+  try_hip(hipMemsetAsync(arena + o_counts, 0, (d_index ? o_cleared_end : o_index) - o_counts, st), KGX_EHIP, "memset(counts, f, index)");
   if (rc == KGX_OK && n_sel) {
     // hipMemcpyDefault: the caller's tables may live on the host or already on this device (kgx.h)
     try_hip(hipMemcpyAsync(d_af, minor_af, n_sel * amax * sizeof(double), hipMemcpyDefault, st), KGX_EHIP, "copy(af)");
     if (d_index) try_hip(hipMemcpyAsync(d_index, locus_index, n_sel * sizeof(uint32_t), hipMemcpyDefault, st), KGX_EHIP, "copy(index)");
   }
-  try_hip(hipMemsetAsync(d_counts, 0, n * 6 * sizeof(unsigned long long), st), KGX_EHIP, "memset(counts)");
   // (the table sweep and the 16-genome SWAR sweep pre-fill every partial with the segment defaults: k_fill_defaults)
   if (!(n_sel && (table_sweep || swar16))) try_hip(hipMemsetAsync(d_part, 0, n_seg * n * kParts0 * sizeof(double), st), KGX_EHIP, "memset(partials)");
-  try_hip(hipMemsetAsync(d_f, 0, 2 * n * sizeof(double), st), KGX_EHIP, "memset(f)");
   // Where the iterative estimators start (kgx.h): the caller's per-genome points -- the reference draws them, and its
   // fifth draw alone decides the result (kgx_inbreed_reference_starts) -- or the midpoint of the reference's start interval.
   std::vector<double> start_points;
@@ -196,7 +198,6 @@ int inbreed_shard(kgx_gt8_shard& sh, uint64_t g0, uint64_t g1, const uint32_t* l
   if (rc == KGX_OK && n_sel && (swar16 || amax <= 4 || table_passes) && env_int("KGX_K5_ALWAYS_GUARD", 0) == 0) {
     if (sh.wide_nibbles == 0) {
       unsigned int found = 0;
-      try_hip(hipMemsetAsync(d_running, 0, sizeof(unsigned int), st), KGX_EHIP, "memset(scan flag)");
       const uint64_t n_chunks = sh.n_loci * (sh.pitch / 16);
       if (rc == KGX_OK) {
         hipLaunchKernelGGL(k_scan_wide_nibbles, dim3(stream_grid(dev, n_chunks, kBlock)), dim3(kBlock), 0, st, reinterpret_cast<const kgx_v4u*>(sh.d_gt),
@@ -204,6 +205,7 @@ int inbreed_shard(kgx_gt8_shard& sh, uint64_t g0, uint64_t g1, const uint32_t* l
         try_hip(hipGetLastError(), KGX_EHIP, "k_scan_wide_nibbles launch");
         try_hip(hipMemcpyAsync(&found, d_running, sizeof(found), hipMemcpyDeviceToHost, st), KGX_EHIP, "D2H(scan flag)");
         try_hip(hipStreamSynchronize(st), KGX_EHIP, "sync");
+        if (found) try_hip(hipMemsetAsync(d_running, 0, sizeof(unsigned int), st), KGX_EHIP, "memset(scan flag)");   // cleared again for the search
       }
       if (rc == KGX_OK) sh.wide_nibbles = found ? 2 : 1;
     }
@@ -314,27 +316,30 @@ int inbreed_shard(kgx_gt8_shard& sh, uint64_t g0, uint64_t g1, const uint32_t* l
   auto reduce_grid = [&](uint64_t items) { return stream_grid(dev, (items + kReduceItems - 1) / kReduceItems * kBlock, kBlock); };
   if (rc == KGX_OK) {
     if (n_sel) hipLaunchKernelGGL((k_locus_tables<true>), dim3(stream_grid(dev, n_sel, kBlock)), dim3(kBlock), 0, st, d_af, n_sel, amax, 0.0, d_table, d_valid);
-    if (rc == KGX_OK) try_hip(hipEventRecord(dev.sweep_begin, st), KGX_EHIP, "hipEventRecord");
-    if (!table_sweep && rc == KGX_OK) try_hip(hipEventRecord(dev.kernel_begin, st), KGX_EHIP, "hipEventRecord");
+    // Timed from 2^24 cells up (kgx.h): below, the four event records cost the call more than its sweep takes.
+    const bool timed = n_sel * n >= (1ull << 24) || env_int("KGX_TIME_SMALL_CALLS", 0);
+    if (timed && rc == KGX_OK) try_hip(hipEventRecord(dev.sweep_begin, st), KGX_EHIP, "hipEventRecord");
+    if (timed && !table_sweep && rc == KGX_OK) try_hip(hipEventRecord(dev.kernel_begin, st), KGX_EHIP, "hipEventRecord");
     sweep(0);
     if (table_sweep) {
       tabulate(ritland ? 3 : 4);
-      if (rc == KGX_OK) try_hip(hipEventRecord(dev.kernel_begin, st), KGX_EHIP, "hipEventRecord");
+      if (timed && rc == KGX_OK) try_hip(hipEventRecord(dev.kernel_begin, st), KGX_EHIP, "hipEventRecord");
       sweep(ritland ? 3 : 4);
-      if (rc == KGX_OK) try_hip(hipEventRecord(dev.kernel_end, st), KGX_EHIP, "hipEventRecord");
+      if (timed && rc == KGX_OK) try_hip(hipEventRecord(dev.kernel_end, st), KGX_EHIP, "hipEventRecord");
       if (n_sel) {
         const uint32_t seg_rows = n_seg < 32 ? static_cast<uint32_t>(n_seg) : 32u;
         hipLaunchKernelGGL(k_reduce_class_counts, dim3(static_cast<uint32_t>((n + kBlock - 1) / kBlock), seg_rows), dim3(kBlock), 0, st, d_segcnt, n_seg, n, d_counts);
       }
-    } else if (rc == KGX_OK) {
+    } else if (timed && rc == KGX_OK) {
       try_hip(hipEventRecord(dev.kernel_end, st), KGX_EHIP, "hipEventRecord");
     }
-    if (rc == KGX_OK) try_hip(hipEventRecord(dev.sweep_end, st), KGX_EHIP, "hipEventRecord");
+    if (timed && rc == KGX_OK) try_hip(hipEventRecord(dev.sweep_end, st), KGX_EHIP, "hipEventRecord");
     if (sequential_defaults && n_sel) try_hip(hipStreamWaitEvent(st, dev.side_end, 0), KGX_EHIP, "hipStreamWaitEvent");
     hipLaunchKernelGGL(k_reduce_parts, dim3(reduce_grid(n * kParts0)), dim3(kBlock), 0, st, d_part, n_seg, n * kParts0,
                        (sequential_defaults && n_sel) ? d_seq_out : nullptr, d_sums);
     // Window-sized calls: the whole iteration in one launch, a wave per genome (k_inbreed_iterate_wave).
     const bool wave_path = (algorithm == 2 || algorithm == 3) && wave_sized;
+    bool wave_evaluations = false;
     // Loglikelihood's search: the reference optimiser's own path (Nelder-Mead, see nm_advance) unless KGX_K7_SEARCH=brent
     const char* search_name = std::getenv("KGX_K7_SEARCH");
     const int search = search_name && std::strcmp(search_name, "brent") == 0 ? kSearchBrent : kSearchNelderMead;
@@ -343,19 +348,13 @@ int inbreed_shard(kgx_gt8_shard& sh, uint64_t g0, uint64_t g1, const uint32_t* l
     const uint64_t planes = pass_search == kSearchNelderMeadPair ? 2 : 1;
     if (wave_path) {
       const uint32_t wave_grid = static_cast<uint32_t>((n * kWave + kBlock - 1) / kBlock);
-      try_hip(hipMemsetAsync(d_running, 0, sizeof(unsigned int), st), KGX_EHIP, "memset(evaluations)");
       if (algorithm == 2)
         hipLaunchKernelGGL((k_inbreed_iterate_wave<1>), dim3(wave_grid), dim3(kBlock), 0, st, sh.d_gt, sh.pitch, g0, n, d_index, n_sel, d_table, d_valid,
                            amax, phased, d_counts, d_sums, search, d_start, d_f, d_running);
       else
         hipLaunchKernelGGL((k_inbreed_iterate_wave<2>), dim3(wave_grid), dim3(kBlock), 0, st, sh.d_gt, sh.pitch, g0, n, d_index, n_sel, d_table, d_valid,
                            amax, phased, d_counts, env_int("KGX_K7_ESTIMATE_START", 0) ? d_sums : nullptr, search, d_start, d_f, d_running);
-      if (algorithm == 3) {
-        unsigned int evaluations = 0;
-        try_hip(hipMemcpyAsync(&evaluations, d_running, sizeof(unsigned int), hipMemcpyDeviceToHost, st), KGX_EHIP, "D2H(evaluations)");
-        try_hip(hipStreamSynchronize(st), KGX_EHIP, "sync");
-        dev.last_evaluations = static_cast<int>(evaluations);
-      }
+      wave_evaluations = algorithm == 3;          // its count (d_running, cleared with the counts) comes back with the results
     } else if (algorithm == 2) {
       // processHallME (_calc.cpp:225-307).  The reference restarts from U(0,0.5] and, through RetryCalcResult's
       // self-comparison (_calc.cpp:45-68), always stops after 5 restarts of exactly 50 expectation steps, keeping the
@@ -539,11 +538,16 @@ int inbreed_shard(kgx_gt8_shard& sh, uint64_t g0, uint64_t g1, const uint32_t* l
     hipLaunchKernelGGL(k_finish_inbreed, dim3(lin_grid), dim3(kBlock), 0, st, d_counts, d_sums, n, algorithm, d_f, d_out);
     try_hip(hipGetLastError(), KGX_EHIP, "kernel launch");
     try_hip(hipMemcpyAsync(out, d_out, n * sizeof(LocusResultsDev), hipMemcpyDeviceToHost, st), KGX_EHIP, "D2H(out)");
+    unsigned int evaluations = 0;
+    if (wave_evaluations) try_hip(hipMemcpyAsync(&evaluations, d_running, sizeof(unsigned int), hipMemcpyDeviceToHost, st), KGX_EHIP, "D2H(evaluations)");
     try_hip(hipStreamSynchronize(st), KGX_EHIP, "stream synchronize");
-    if (rc == KGX_OK) {
+    if (wave_evaluations && rc == KGX_OK) dev.last_evaluations = static_cast<int>(evaluations);
+    if (rc == KGX_OK && timed) {
       float ms = 0.f;
       if (hipEventElapsedTime(&ms, dev.sweep_begin, dev.sweep_end) == hipSuccess) dev.last_sweep_ms = ms;
       if (hipEventElapsedTime(&ms, dev.kernel_begin, dev.kernel_end) == hipSuccess) dev.last_kernel_ms = ms;
+    } else if (rc == KGX_OK) {
+      dev.last_sweep_ms = dev.last_kernel_ms = 0.0;
     }
   }
   return rc;
