@@ -348,12 +348,14 @@ int inbreed_shard(kgx_gt8_shard& sh, uint64_t g0, uint64_t g1, const uint32_t* l
     const uint64_t planes = pass_search == kSearchNelderMeadPair ? 2 : 1;
     if (wave_path) {
       const uint32_t wave_grid = static_cast<uint32_t>((n * kWave + kBlock - 1) / kBlock);
-      if (algorithm == 2)
-        hipLaunchKernelGGL((k_inbreed_iterate_wave<1>), dim3(wave_grid), dim3(kBlock), 0, st, sh.d_gt, sh.pitch, g0, n, d_index, n_sel, d_table, d_valid,
-                           amax, phased, d_counts, d_sums, search, d_start, d_f, d_running);
-      else
-        hipLaunchKernelGGL((k_inbreed_iterate_wave<2>), dim3(wave_grid), dim3(kBlock), 0, st, sh.d_gt, sh.pitch, g0, n, d_index, n_sel, d_table, d_valid,
-                           amax, phased, d_counts, env_int("KGX_K7_ESTIMATE_START", 0) ? d_sums : nullptr, search, d_start, d_f, d_running);
+      const double* estimate = algorithm == 2 ? d_sums : env_int("KGX_K7_ESTIMATE_START", 0) ? d_sums : nullptr;
+#define KGX_WAVE(MODE, CELLS)                                                                                                      \
+  hipLaunchKernelGGL((k_inbreed_iterate_wave<MODE, CELLS>), dim3(wave_grid), dim3(kBlock), 0, st, sh.d_gt, sh.pitch, g0, n, d_index, n_sel, \
+                     d_table, d_valid, amax, phased, d_counts, estimate, search, d_start, d_f, d_running)
+      // the smallest per-lane cell count that holds the selection (see the kernel)
+      if (algorithm == 2) { if (n_sel <= 64 * 8) KGX_WAVE(1, 8); else if (n_sel <= 64 * 16) KGX_WAVE(1, 16); else KGX_WAVE(1, kWaveCells); }
+      else { if (n_sel <= 64 * 8) KGX_WAVE(2, 8); else if (n_sel <= 64 * 16) KGX_WAVE(2, 16); else KGX_WAVE(2, kWaveCells); }
+#undef KGX_WAVE
       wave_evaluations = algorithm == 3;          // its count (d_running, cleared with the counts) comes back with the results
     } else if (algorithm == 2) {
       // processHallME (_calc.cpp:225-307).  The reference restarts from U(0,0.5] and, through RetryCalcResult's

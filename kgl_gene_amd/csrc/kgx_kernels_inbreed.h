@@ -1716,7 +1716,10 @@ k_gather_states(const BrentState* __restrict__ st, const double* __restrict__ f,
 // keeps what each of its cells contributes in registers (as k_inbreed_eval_lut tabulates it: y, d with the cell's
 // probability or denominator y + F*d); a pass is a few fp64 operations per cell and a butterfly reduction over the
 // wave (every lane ends with the bitwise-same sum, so the search's control flow is wave-uniform); no block or grid
-// synchronisation, no partials in memory.  n_sel <= 64 * kWaveCells.
+// synchronisation, no partials in memory.  n_sel <= 64 * kWaveCells; CELLS (8, 16 or kWaveCells: the host picks the
+// smallest that holds n_sel / 64) bounds the unrolled per-lane loops -- a wave is alone on its SIMD at these sizes, so a
+// pass costs the latency of its dependent instructions, and a cell past the selection would cost as much as a real one
+// (it contributes +0.0 / a factor 1.0: leaving it out gives the bitwise-same sums).
 constexpr int kWaveCells = 32;
 
 __device__ __forceinline__ double wave_sum(double v) {
@@ -1725,7 +1728,7 @@ __device__ __forceinline__ double wave_sum(double v) {
   return v;
 }
 
-template <int MODE>
+template <int MODE, int CELLS>
 __global__ void __launch_bounds__(kBlock)
 k_inbreed_iterate_wave(const uint8_t* __restrict__ gt, uint64_t pitch, uint64_t g0, uint64_t n_genomes,
                        const uint32_t* __restrict__ locus_index, uint64_t n_sel, const double* __restrict__ table,
@@ -1736,9 +1739,9 @@ k_inbreed_iterate_wave(const uint8_t* __restrict__ gt, uint64_t pitch, uint64_t 
   const uint32_t lane = threadIdx.x & (kWave - 1);
   if (g >= n_genomes) return;                                 // whole waves only
   const uint32_t stride = sweep_stride(amax);
-  double y[kWaveCells], d[kWaveCells];
+  double y[CELLS], d[CELLS];
 #pragma unroll
-  for (int c = 0; c < kWaveCells; ++c) {
+  for (int c = 0; c < CELLS; ++c) {
     y[c] = MODE == 2 ? 1.0 : 0.0;                             // contributes nothing
     d[c] = 0.0;
     const uint64_t s = static_cast<uint64_t>(c) * kWave + lane;
@@ -1759,11 +1762,13 @@ k_inbreed_iterate_wave(const uint8_t* __restrict__ gt, uint64_t pitch, uint64_t 
     const double total = static_cast<double>(counts[g * 6 + 4]);
     double F = start[g];
     for (int it = 0; it < 50; ++it) {
+      // (selects, not branches: the quotients of different cells are independent and overlap; the sum keeps its order)
       double sum = 0.0;
 #pragma unroll
-      for (int c = 0; c < kWaveCells; ++c) {
+      for (int c = 0; c < CELLS; ++c) {
         const double denominator = F + ((1.0 - F) * y[c]);
-        if (d[c] != 0.0 && denominator != 0) sum += F / denominator;
+        const double quotient = F / denominator;
+        sum += (d[c] != 0.0 && denominator != 0) ? quotient : 0.0;
       }
       F = wave_sum(sum) / total;
     }
@@ -1776,9 +1781,9 @@ k_inbreed_iterate_wave(const uint8_t* __restrict__ gt, uint64_t pitch, uint64_t 
       const double F = it == 0 ? s.x : s.u;
       double log_sum = 0.0, prod = 1.0;
 #pragma unroll
-      for (int c = 0; c < kWaveCells; ++c) {
+      for (int c = 0; c < CELLS; ++c) {
         prod *= __builtin_fmin(__builtin_fmax(__builtin_fma(F, d[c], y[c]), 1e-10), 1.0);
-        if ((c & 15) == 15) {                                 // 16 factors >= 1e-10 cannot underflow
+        if ((c & 15) == 15 || c == CELLS - 1) {               // 16 factors >= 1e-10 cannot underflow
           log_sum += log(prod);
           prod = 1.0;
         }
