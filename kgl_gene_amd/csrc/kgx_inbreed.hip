@@ -140,7 +140,7 @@ int inbreed_shard(kgx_gt8_shard& sh, uint64_t g0, uint64_t g1, const uint32_t* l
   const size_t o_seq_sum = plan.add(n_seq_blocks * 4 * sizeof(double)), o_seq_e = plan.add(n_seq_blocks * 4 * sizeof(int));
   const size_t o_seq_n = plan.add(n_seq_blocks * 4 * sizeof(long long)), o_seq_out = plan.add(kParts0 * sizeof(double));
   // The table passes' entries (k_eval_entries): 64 / 256 / 1024 bytes per selected locus, only where such a pass will run.
-  const bool wave_sized = n_sel > 0 && n_sel <= 64ull * kWaveCells && !env_int("KGX_K7_NO_WAVE", 0);
+  const bool wave_sized = n_sel > 0 && n_sel <= static_cast<uint64_t>(kBlock) * kGenomeCells && !env_int("KGX_K7_NO_WAVE", 0);
   const bool table_passes = n_sel > 0 && (table_sweep || (eval_lut && (algorithm == 2 || algorithm == 3) && !wave_sized));
   const size_t o_entries = plan.add(table_passes ? (n_sel << (2u * eval_bits(amax))) * sizeof(EvalEntry) : 0);
   const size_t o_segcnt = plan.add(table_sweep ? max_seg * n * sizeof(unsigned long long) : sizeof(unsigned long long));
@@ -337,7 +337,7 @@ int inbreed_shard(kgx_gt8_shard& sh, uint64_t g0, uint64_t g1, const uint32_t* l
     if (sequential_defaults && n_sel) try_hip(hipStreamWaitEvent(st, dev.side_end, 0), KGX_EHIP, "hipStreamWaitEvent");
     hipLaunchKernelGGL(k_reduce_parts, dim3(reduce_grid(n * kParts0)), dim3(kBlock), 0, st, d_part, n_seg, n * kParts0,
                        (sequential_defaults && n_sel) ? d_seq_out : nullptr, d_sums);
-    // Window-sized calls: the whole iteration in one launch, a wave per genome (k_inbreed_iterate_wave).
+    // Window-sized calls: the whole iteration in one launch, a block per genome (k_inbreed_iterate_genome).
     const bool wave_path = (algorithm == 2 || algorithm == 3) && wave_sized;
     bool wave_evaluations = false;
     // Loglikelihood's search: the reference optimiser's own path (Nelder-Mead, see nm_advance) unless KGX_K7_SEARCH=brent
@@ -347,14 +347,14 @@ int inbreed_shard(kgx_gt8_shard& sh, uint64_t g0, uint64_t g1, const uint32_t* l
     const int pass_search = (search == kSearchNelderMead && eval_lut && !env_int("KGX_K7_NO_PAIR", 0)) ? kSearchNelderMeadPair : search;
     const uint64_t planes = pass_search == kSearchNelderMeadPair ? 2 : 1;
     if (wave_path) {
-      const uint32_t wave_grid = static_cast<uint32_t>((n * kWave + kBlock - 1) / kBlock);
+      const uint32_t wave_grid = static_cast<uint32_t>(n);      // a block per genome
       const double* estimate = algorithm == 2 ? d_sums : env_int("KGX_K7_ESTIMATE_START", 0) ? d_sums : nullptr;
 #define KGX_WAVE(MODE, CELLS)                                                                                                      \
-  hipLaunchKernelGGL((k_inbreed_iterate_wave<MODE, CELLS>), dim3(wave_grid), dim3(kBlock), 0, st, sh.d_gt, sh.pitch, g0, n, d_index, n_sel, \
+  hipLaunchKernelGGL((k_inbreed_iterate_genome<MODE, CELLS>), dim3(wave_grid), dim3(kBlock), 0, st, sh.d_gt, sh.pitch, g0, n, d_index, n_sel, \
                      d_table, d_valid, amax, phased, d_counts, estimate, search, d_start, d_f, d_running)
       // the smallest per-lane cell count that holds the selection (see the kernel)
-      if (algorithm == 2) { if (n_sel <= 64 * 8) KGX_WAVE(1, 8); else if (n_sel <= 64 * 16) KGX_WAVE(1, 16); else KGX_WAVE(1, kWaveCells); }
-      else { if (n_sel <= 64 * 8) KGX_WAVE(2, 8); else if (n_sel <= 64 * 16) KGX_WAVE(2, 16); else KGX_WAVE(2, kWaveCells); }
+      if (algorithm == 2) { if (n_sel <= kBlock * 2) KGX_WAVE(1, 2); else if (n_sel <= kBlock * 4) KGX_WAVE(1, 4); else KGX_WAVE(1, kGenomeCells); }
+      else { if (n_sel <= kBlock * 2) KGX_WAVE(2, 2); else if (n_sel <= kBlock * 4) KGX_WAVE(2, 4); else KGX_WAVE(2, kGenomeCells); }
 #undef KGX_WAVE
       wave_evaluations = algorithm == 3;          // its count (d_running, cleared with the counts) comes back with the results
     } else if (algorithm == 2) {

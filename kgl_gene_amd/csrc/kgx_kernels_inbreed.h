@@ -1712,39 +1712,67 @@ k_gather_states(const BrentState* __restrict__ st, const double* __restrict__ f,
 }
 
 // Window-sized calls (what the INBREED package issues: ~1000 sampled loci x one super population): the whole iteration
-// of HallME (MODE 1) or Loglikelihood (MODE 2) in ONE launch.  A wave owns a genome; lane i owns loci i, i+64, ... and
-// keeps what each of its cells contributes in registers (as k_inbreed_eval_lut tabulates it: y, d with the cell's
-// probability or denominator y + F*d); a pass is a few fp64 operations per cell and a butterfly reduction over the
-// wave (every lane ends with the bitwise-same sum, so the search's control flow is wave-uniform); no block or grid
-// synchronisation, no partials in memory.  n_sel <= 64 * kWaveCells; CELLS (8, 16 or kWaveCells: the host picks the
-// smallest that holds n_sel / 64) bounds the unrolled per-lane loops -- a wave is alone on its SIMD at these sizes, so a
-// pass costs the latency of its dependent instructions, and a cell past the selection would cost as much as a real one
-// (it contributes +0.0 / a factor 1.0: leaving it out gives the bitwise-same sums).
-constexpr int kWaveCells = 32;
+// of HallME (MODE 1) or Loglikelihood (MODE 2) in ONE launch.  A block (4 waves) owns a genome; thread t owns loci t,
+// t+256, ... and keeps what each of its cells contributes in registers (as k_inbreed_eval_lut tabulates it: y, d with
+// the cell's probability or denominator y + F*d).  A pass is a few fp64 operations per cell, a DPP reduction over each
+// row of 16 lanes (row_sum16) and the sixteen row sums added as a fixed tree out of LDS: every thread ends with the
+// bitwise-same sum, so the search's control flow is block-uniform.  One barrier per pass (the LDS slots alternate), no grid synchronisation, no
+// partials in memory.  n_sel <= kBlock * kGenomeCells; CELLS (2, 4 or kGenomeCells: the host picks the smallest that
+// holds n_sel / kBlock) bounds the unrolled per-thread loops -- a few hundred genomes put one or two waves on a SIMD,
+// so a pass costs the latency of its dependent instructions, and a cell past the selection would cost as much as a
+// real one (it contributes +0.0 / a factor 1.0: leaving it out gives the bitwise-same sums).
+constexpr int kGenomeCells = 8;
 
-__device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-  for (int offset = 32; offset >= 1; offset >>= 1) v += __shfl_xor(v, offset, kWave);
+// A double moved between the lanes of a row of 16 by a DPP control (two v_mov_b32_dpp: a few cycles, where the
+// ds_bpermute pair behind __shfl_xor takes an LDS round trip -- and the passes here are nothing but such latencies).
+template <int CTRL>
+__device__ __forceinline__ double dpp_move(double v) {
+  const unsigned long long bits = static_cast<unsigned long long>(__double_as_longlong(v));
+  const unsigned int lo = static_cast<unsigned int>(__builtin_amdgcn_update_dpp(0, static_cast<int>(bits), CTRL, 0xf, 0xf, false));
+  const unsigned int hi = static_cast<unsigned int>(__builtin_amdgcn_update_dpp(0, static_cast<int>(bits >> 32), CTRL, 0xf, 0xf, false));
+  return __longlong_as_double(static_cast<long long>((static_cast<unsigned long long>(hi) << 32) | lo));
+}
+
+// The sum over each row of 16 lanes, the bitwise-same value in all 16: every step pairs lanes symmetrically (a with b
+// and b with a), and a + b == b + a.  All lanes of the wave must be active.
+__device__ __forceinline__ double row_sum16(double v) {
+  v += dpp_move<0xB1>(v);                                      // quad_perm [1,0,3,2]: lane ^ 1
+  v += dpp_move<0x4E>(v);                                      // quad_perm [2,3,0,1]: lane ^ 2
+  v += dpp_move<0x141>(v);                                     // row_half_mirror: 7 - lane within each 8 (the other quad)
+  v += dpp_move<0x140>(v);                                     // row_mirror: 15 - lane (the other half)
   return v;
 }
 
 template <int MODE, int CELLS>
 __global__ void __launch_bounds__(kBlock)
-k_inbreed_iterate_wave(const uint8_t* __restrict__ gt, uint64_t pitch, uint64_t g0, uint64_t n_genomes,
-                       const uint32_t* __restrict__ locus_index, uint64_t n_sel, const double* __restrict__ table,
-                       const uint8_t* __restrict__ valid, uint32_t amax, int phased, const unsigned long long* __restrict__ counts,
-                       const double* __restrict__ sums, int search, const double* __restrict__ start, double* __restrict__ f_out,
-                       unsigned int* __restrict__ max_evaluations) {
-  const uint64_t g = (static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x) / kWave;
-  const uint32_t lane = threadIdx.x & (kWave - 1);
-  if (g >= n_genomes) return;                                 // whole waves only
+k_inbreed_iterate_genome(const uint8_t* __restrict__ gt, uint64_t pitch, uint64_t g0, uint64_t n_genomes,
+                         const uint32_t* __restrict__ locus_index, uint64_t n_sel, const double* __restrict__ table,
+                         const uint8_t* __restrict__ valid, uint32_t amax, int phased, const unsigned long long* __restrict__ counts,
+                         const double* __restrict__ sums, int search, const double* __restrict__ start, double* __restrict__ f_out,
+                         unsigned int* __restrict__ max_evaluations) {
+  constexpr int kRows = kBlock / 16;
+  static_assert(kRows == 16, "block_sum adds sixteen row sums");
+  __shared__ double row_part[2][kRows];
+  const uint64_t g = blockIdx.x;                              // grid = n_genomes blocks
+  if (g >= n_genomes) return;                                 // (whole blocks only)
+  // the sum over the block of one value per thread, the same bits in every thread; `pass` alternates the LDS slots
+  auto block_sum = [&](double v, int pass) {
+    v = row_sum16(v);
+    if ((threadIdx.x & 15) == 0) row_part[pass & 1][threadIdx.x >> 4] = v;
+    __syncthreads();
+    const double* p = row_part[pass & 1];
+    double t[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) t[i] = p[2 * i] + p[2 * i + 1];
+    return ((t[0] + t[1]) + (t[2] + t[3])) + ((t[4] + t[5]) + (t[6] + t[7]));
+  };
   const uint32_t stride = sweep_stride(amax);
   double y[CELLS], d[CELLS];
 #pragma unroll
   for (int c = 0; c < CELLS; ++c) {
     y[c] = MODE == 2 ? 1.0 : 0.0;                             // contributes nothing
     d[c] = 0.0;
-    const uint64_t s = static_cast<uint64_t>(c) * kWave + lane;
+    const uint64_t s = static_cast<uint64_t>(c) * kBlock + threadIdx.x;
     if (s < n_sel && (valid[s] & kLocusValid)) {
       const uint64_t l = locus_index ? static_cast<uint64_t>(locus_index[s]) : s;
       double f1 = 0.0, f2 = 0.0;
@@ -1762,7 +1790,7 @@ k_inbreed_iterate_wave(const uint8_t* __restrict__ gt, uint64_t pitch, uint64_t 
     const double total = static_cast<double>(counts[g * 6 + 4]);
     double F = start[g];
     for (int it = 0; it < 50; ++it) {
-      // (selects, not branches: the quotients of different cells are independent and overlap; the sum keeps its order)
+      // (selects, not branches: the quotients of different cells are independent and overlap)
       double sum = 0.0;
 #pragma unroll
       for (int c = 0; c < CELLS; ++c) {
@@ -1770,30 +1798,25 @@ k_inbreed_iterate_wave(const uint8_t* __restrict__ gt, uint64_t pitch, uint64_t 
         const double quotient = F / denominator;
         sum += (d[c] != 0.0 && denominator != 0) ? quotient : 0.0;
       }
-      F = wave_sum(sum) / total;
+      F = block_sum(sum, it) / total;
     }
-    if (lane == 0) f_out[g] = F;
+    if (threadIdx.x == 0) f_out[g] = F;
   } else {
     BrentState s = search == kSearchNelderMead ? nm_start(start[g])
                    : sums ? brent_start(counts + g * 6, sums + g * kParts0) : brent_start(nullptr, nullptr);
     unsigned int evaluations = 0;
     for (int it = 0; it < (search == kSearchNelderMead ? 500 : 60); ++it) {
       const double F = it == 0 ? s.x : s.u;
-      double log_sum = 0.0, prod = 1.0;
+      double prod = 1.0;                                      // CELLS <= 8 factors >= 1e-10 cannot underflow
 #pragma unroll
-      for (int c = 0; c < CELLS; ++c) {
-        prod *= __builtin_fmin(__builtin_fmax(__builtin_fma(F, d[c], y[c]), 1e-10), 1.0);
-        if ((c & 15) == 15 || c == CELLS - 1) {               // 16 factors >= 1e-10 cannot underflow
-          log_sum += log(prod);
-          prod = 1.0;
-        }
-      }
+      for (int c = 0; c < CELLS; ++c) prod *= __builtin_fmin(__builtin_fmax(__builtin_fma(F, d[c], y[c]), 1e-10), 1.0);
+      const double log_sum = block_sum(log(prod), it);
       ++evaluations;
-      if (search == kSearchNelderMead) nm_advance(s, wave_sum(log_sum));
-      else brent_advance(s, -wave_sum(log_sum), it == 0);
-      if (s.done) break;
+      if (search == kSearchNelderMead) nm_advance(s, log_sum);
+      else brent_advance(s, -log_sum, it == 0);
+      if (s.done) break;                                      // block-uniform: every thread holds the same state
     }
-    if (lane == 0) {
+    if (threadIdx.x == 0) {
       f_out[g] = s.x;
       atomicMax(max_evaluations, evaluations);
     }
