@@ -19,7 +19,7 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/k7_trace -- python3
 echo "k7 trace done" >> $OUT/progress.txt
 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT --kernel-trace --output-format csv -d $OUT/k7_sq -- python3 $REPO/scripts/bench_inbreed.py 10000 5000000 --all > $OUT/k7_sq.txt 2> $OUT/k7_sq.err
 echo "k7 sq done" >> $OUT/progress.txt
-# the regime the INBREED package runs in: window-sized calls, the whole iteration inside k_inbreed_iterate_wave
+# the regime the INBREED package runs in: window-sized calls, the whole iteration inside k_inbreed_iterate_genome
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/window_trace -- python3 $REPO/scripts/bench_inbreed_window.py 1000 > $OUT/window.txt 2> $OUT/window.err
 echo "window trace done" >> $OUT/progress.txt
 cat $OUT/k7.txt $OUT/window.txt
