@@ -140,7 +140,7 @@ int inbreed_shard(kgx_gt8_shard& sh, uint64_t g0, uint64_t g1, const uint32_t* l
   const size_t o_seq_sum = plan.add(n_seq_blocks * 4 * sizeof(double)), o_seq_e = plan.add(n_seq_blocks * 4 * sizeof(int));
   const size_t o_seq_n = plan.add(n_seq_blocks * 4 * sizeof(long long)), o_seq_out = plan.add(kParts0 * sizeof(double));
   // The table passes' entries (k_eval_entries): 64 / 256 / 1024 bytes per selected locus, only where such a pass will run.
-  const bool wave_sized = n_sel > 0 && n_sel <= static_cast<uint64_t>(kBlock) * kGenomeCells && !env_int("KGX_K7_NO_WAVE", 0);
+  const bool wave_sized = n_sel > 0 && n_sel <= static_cast<uint64_t>(kGenomeLoci) && !env_int("KGX_K7_NO_WAVE", 0);
   const bool table_passes = n_sel > 0 && (table_sweep || (eval_lut && (algorithm == 2 || algorithm == 3) && !wave_sized));
   const size_t o_entries = plan.add(table_passes ? (n_sel << (2u * eval_bits(amax))) * sizeof(EvalEntry) : 0);
   const size_t o_segcnt = plan.add(table_sweep ? max_seg * n * sizeof(unsigned long long) : sizeof(unsigned long long));
@@ -337,7 +337,7 @@ int inbreed_shard(kgx_gt8_shard& sh, uint64_t g0, uint64_t g1, const uint32_t* l
     if (sequential_defaults && n_sel) try_hip(hipStreamWaitEvent(st, dev.side_end, 0), KGX_EHIP, "hipStreamWaitEvent");
     hipLaunchKernelGGL(k_reduce_parts, dim3(reduce_grid(n * kParts0)), dim3(kBlock), 0, st, d_part, n_seg, n * kParts0,
                        (sequential_defaults && n_sel) ? d_seq_out : nullptr, d_sums);
-    // Window-sized calls: the whole iteration in one launch, a block per genome (k_inbreed_iterate_genome).
+    // Window-sized calls: the whole iteration in one launch, a block or a wave per genome (k_inbreed_iterate_genome).
     const bool wave_path = (algorithm == 2 || algorithm == 3) && wave_sized;
     bool wave_evaluations = false;
     // Loglikelihood's search: the reference optimiser's own path (Nelder-Mead, see nm_advance) unless KGX_K7_SEARCH=brent
@@ -347,14 +347,27 @@ int inbreed_shard(kgx_gt8_shard& sh, uint64_t g0, uint64_t g1, const uint32_t* l
     const int pass_search = (search == kSearchNelderMead && eval_lut && !env_int("KGX_K7_NO_PAIR", 0)) ? kSearchNelderMeadPair : search;
     const uint64_t planes = pass_search == kSearchNelderMeadPair ? 2 : 1;
     if (wave_path) {
-      const uint32_t wave_grid = static_cast<uint32_t>(n);      // a block per genome
+      // A block per genome while that leaves SIMDs idle or with a wave or two (latency-bound: four waves share a
+      // genome's cells); a wave per genome from KGX_K7_WAVE_GENOMES genomes (throughput-bound: a block would repeat the
+      // log, the search step and the reduction in all four waves).  Measured at 1000 loci (scripts/exp_window_threads.sh,
+      // ms per call, block / wave): HallME 0.127 / 0.162 at 256 genomes, 0.144 / 0.154 at 512, 0.173 / 0.170 at 1024,
+      // 0.335 / 0.259 at 2504; Loglikelihood 0.150 / 0.161, 0.170 / 0.157, 0.207 / 0.176, 0.315 / 0.231.
+      const bool per_wave = n >= static_cast<uint64_t>(std::max(1, env_int("KGX_K7_WAVE_GENOMES", algorithm == 2 ? 1024 : 512)));
+      const uint32_t wave_grid = static_cast<uint32_t>(per_wave ? (n + kBlock / kWave - 1) / (kBlock / kWave) : n);
       const double* estimate = algorithm == 2 ? d_sums : env_int("KGX_K7_ESTIMATE_START", 0) ? d_sums : nullptr;
-#define KGX_WAVE(MODE, CELLS)                                                                                                      \
-  hipLaunchKernelGGL((k_inbreed_iterate_genome<MODE, CELLS>), dim3(wave_grid), dim3(kBlock), 0, st, sh.d_gt, sh.pitch, g0, n, d_index, n_sel, \
-                     d_table, d_valid, amax, phased, d_counts, estimate, search, d_start, d_f, d_running)
-      // the smallest per-lane cell count that holds the selection (see the kernel)
-      if (algorithm == 2) { if (n_sel <= kBlock * 2) KGX_WAVE(1, 2); else if (n_sel <= kBlock * 4) KGX_WAVE(1, 4); else KGX_WAVE(1, kGenomeCells); }
-      else { if (n_sel <= kBlock * 2) KGX_WAVE(2, 2); else if (n_sel <= kBlock * 4) KGX_WAVE(2, 4); else KGX_WAVE(2, kGenomeCells); }
+#define KGX_WAVE(MODE, CELLS, THREADS)                                                                                             \
+  hipLaunchKernelGGL((k_inbreed_iterate_genome<MODE, CELLS, THREADS>), dim3(wave_grid), dim3(kBlock), 0, st, sh.d_gt, sh.pitch, g0, n, d_index, \
+                     n_sel, d_table, d_valid, amax, phased, d_counts, estimate, search, d_start, d_f, d_running)
+      // the smallest per-thread cell count that holds the selection (see the kernel)
+#define KGX_WAVE_CELLS(MODE, THREADS)                                                                        \
+  do {                                                                                                       \
+    if (n_sel <= THREADS * (kGenomeLoci / THREADS / 4)) KGX_WAVE(MODE, kGenomeLoci / THREADS / 4, THREADS);  \
+    else if (n_sel <= THREADS * (kGenomeLoci / THREADS / 2)) KGX_WAVE(MODE, kGenomeLoci / THREADS / 2, THREADS); \
+    else KGX_WAVE(MODE, kGenomeLoci / THREADS, THREADS);                                                     \
+  } while (0)
+      if (algorithm == 2) { if (per_wave) KGX_WAVE_CELLS(1, kWave); else KGX_WAVE_CELLS(1, kBlock); }
+      else { if (per_wave) KGX_WAVE_CELLS(2, kWave); else KGX_WAVE_CELLS(2, kBlock); }
+#undef KGX_WAVE_CELLS
 #undef KGX_WAVE
       wave_evaluations = algorithm == 3;          // its count (d_running, cleared with the counts) comes back with the results
     } else if (algorithm == 2) {

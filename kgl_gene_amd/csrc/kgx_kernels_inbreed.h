@@ -1712,16 +1712,18 @@ k_gather_states(const BrentState* __restrict__ st, const double* __restrict__ f,
 }
 
 // Window-sized calls (what the INBREED package issues: ~1000 sampled loci x one super population): the whole iteration
-// of HallME (MODE 1) or Loglikelihood (MODE 2) in ONE launch.  A block (4 waves) owns a genome; thread t owns loci t,
-// t+256, ... and keeps what each of its cells contributes in registers (as k_inbreed_eval_lut tabulates it: y, d with
-// the cell's probability or denominator y + F*d).  A pass is a few fp64 operations per cell, a DPP reduction over each
-// row of 16 lanes (row_sum16) and the sixteen row sums added as a fixed tree out of LDS: every thread ends with the
-// bitwise-same sum, so the search's control flow is block-uniform.  One barrier per pass (the LDS slots alternate), no grid synchronisation, no
-// partials in memory.  n_sel <= kBlock * kGenomeCells; CELLS (2, 4 or kGenomeCells: the host picks the smallest that
-// holds n_sel / kBlock) bounds the unrolled per-thread loops -- a few hundred genomes put one or two waves on a SIMD,
-// so a pass costs the latency of its dependent instructions, and a cell past the selection would cost as much as a
-// real one (it contributes +0.0 / a factor 1.0: leaving it out gives the bitwise-same sums).
-constexpr int kGenomeCells = 8;
+// of HallME (MODE 1) or Loglikelihood (MODE 2) in ONE launch.  THREADS threads own a genome -- a block (256), or a
+// wave (64) where the call has genomes enough to fill the SIMDs with one wave each; thread t owns loci t, t+THREADS,
+// ... and keeps what each of its cells contributes in registers (as k_inbreed_eval_lut tabulates it: y, d with the
+// cell's probability or denominator y + F*d).  A pass is a few fp64 operations per cell, a DPP reduction over each row
+// of 16 lanes (row_sum16) and the row sums added as a fixed tree -- the wave's four read with v_readlane, the block's
+// sixteen out of LDS (one barrier per pass, the slots alternate): every thread of the genome ends with the
+// bitwise-same sum, so the search's control flow is uniform over them.  No grid synchronisation, no partials in
+// memory.  n_sel <= kGenomeLoci; CELLS (the host picks the smallest of three that holds n_sel / THREADS) bounds the
+// unrolled per-thread loops: with one or two waves on a SIMD a pass costs the latency of its dependent instructions,
+// and a cell past the selection would cost as much as a real one (it contributes +0.0 / a factor 1.0: leaving it out
+// gives the bitwise-same sums).
+constexpr int kGenomeLoci = 2048;
 
 // A double moved between the lanes of a row of 16 by a DPP control (two v_mov_b32_dpp: a few cycles, where the
 // ds_bpermute pair behind __shfl_xor takes an LDS round trip -- and the passes here are nothing but such latencies).
@@ -1743,28 +1745,40 @@ __device__ __forceinline__ double row_sum16(double v) {
   return v;
 }
 
-template <int MODE, int CELLS>
+__device__ __forceinline__ double read_lane(double v, int lane) {
+  const unsigned long long bits = static_cast<unsigned long long>(__double_as_longlong(v));
+  const unsigned int lo = static_cast<unsigned int>(__builtin_amdgcn_readlane(static_cast<int>(bits), lane));
+  const unsigned int hi = static_cast<unsigned int>(__builtin_amdgcn_readlane(static_cast<int>(bits >> 32), lane));
+  return __longlong_as_double(static_cast<long long>((static_cast<unsigned long long>(hi) << 32) | lo));
+}
+
+template <int MODE, int CELLS, int THREADS>
 __global__ void __launch_bounds__(kBlock)
 k_inbreed_iterate_genome(const uint8_t* __restrict__ gt, uint64_t pitch, uint64_t g0, uint64_t n_genomes,
                          const uint32_t* __restrict__ locus_index, uint64_t n_sel, const double* __restrict__ table,
                          const uint8_t* __restrict__ valid, uint32_t amax, int phased, const unsigned long long* __restrict__ counts,
                          const double* __restrict__ sums, int search, const double* __restrict__ start, double* __restrict__ f_out,
                          unsigned int* __restrict__ max_evaluations) {
-  constexpr int kRows = kBlock / 16;
-  static_assert(kRows == 16, "block_sum adds sixteen row sums");
-  __shared__ double row_part[2][kRows];
-  const uint64_t g = blockIdx.x;                              // grid = n_genomes blocks
-  if (g >= n_genomes) return;                                 // (whole blocks only)
-  // the sum over the block of one value per thread, the same bits in every thread; `pass` alternates the LDS slots
+  static_assert(THREADS == kWave || (THREADS == kBlock && kBlock == 256), "a wave or a block of sixteen rows per genome");
+  static_assert(CELLS * THREADS <= kGenomeLoci, "cells past the largest selection");
+  __shared__ double row_part[2][16];
+  const uint32_t t = threadIdx.x % THREADS;
+  const uint64_t g = static_cast<uint64_t>(blockIdx.x) * (kBlock / THREADS) + threadIdx.x / THREADS;
+  if (g >= n_genomes) return;                                 // whole waves / whole blocks only: no barrier is left waiting
+  // the sum over the genome's threads of one value each, the same bits in every thread; `pass` alternates the LDS slots
   auto block_sum = [&](double v, int pass) {
     v = row_sum16(v);
-    if ((threadIdx.x & 15) == 0) row_part[pass & 1][threadIdx.x >> 4] = v;
-    __syncthreads();
-    const double* p = row_part[pass & 1];
-    double t[8];
+    if constexpr (THREADS == kWave) {
+      return (read_lane(v, 0) + read_lane(v, 16)) + (read_lane(v, 32) + read_lane(v, 48));
+    } else {
+      if ((threadIdx.x & 15) == 0) row_part[pass & 1][threadIdx.x >> 4] = v;
+      __syncthreads();
+      const double* p = row_part[pass & 1];
+      double pair[8];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) t[i] = p[2 * i] + p[2 * i + 1];
-    return ((t[0] + t[1]) + (t[2] + t[3])) + ((t[4] + t[5]) + (t[6] + t[7]));
+      for (int i = 0; i < 8; ++i) pair[i] = p[2 * i] + p[2 * i + 1];
+      return ((pair[0] + pair[1]) + (pair[2] + pair[3])) + ((pair[4] + pair[5]) + (pair[6] + pair[7]));
+    }
   };
   const uint32_t stride = sweep_stride(amax);
   double y[CELLS], d[CELLS];
@@ -1772,7 +1786,7 @@ k_inbreed_iterate_genome(const uint8_t* __restrict__ gt, uint64_t pitch, uint64_
   for (int c = 0; c < CELLS; ++c) {
     y[c] = MODE == 2 ? 1.0 : 0.0;                             // contributes nothing
     d[c] = 0.0;
-    const uint64_t s = static_cast<uint64_t>(c) * kBlock + threadIdx.x;
+    const uint64_t s = static_cast<uint64_t>(c) * THREADS + t;
     if (s < n_sel && (valid[s] & kLocusValid)) {
       const uint64_t l = locus_index ? static_cast<uint64_t>(locus_index[s]) : s;
       double f1 = 0.0, f2 = 0.0;
@@ -1800,23 +1814,29 @@ k_inbreed_iterate_genome(const uint8_t* __restrict__ gt, uint64_t pitch, uint64_
       }
       F = block_sum(sum, it) / total;
     }
-    if (threadIdx.x == 0) f_out[g] = F;
+    if (t == 0) f_out[g] = F;
   } else {
     BrentState s = search == kSearchNelderMead ? nm_start(start[g])
                    : sums ? brent_start(counts + g * 6, sums + g * kParts0) : brent_start(nullptr, nullptr);
     unsigned int evaluations = 0;
     for (int it = 0; it < (search == kSearchNelderMead ? 500 : 60); ++it) {
       const double F = it == 0 ? s.x : s.u;
-      double prod = 1.0;                                      // CELLS <= 8 factors >= 1e-10 cannot underflow
+      double logs = 0.0, prod = 1.0;
 #pragma unroll
-      for (int c = 0; c < CELLS; ++c) prod *= __builtin_fmin(__builtin_fmax(__builtin_fma(F, d[c], y[c]), 1e-10), 1.0);
-      const double log_sum = block_sum(log(prod), it);
+      for (int c = 0; c < CELLS; ++c) {
+        prod *= __builtin_fmin(__builtin_fmax(__builtin_fma(F, d[c], y[c]), 1e-10), 1.0);
+        if ((c & 15) == 15 || c == CELLS - 1) {               // 16 factors >= 1e-10 cannot underflow
+          logs += log(prod);
+          prod = 1.0;
+        }
+      }
+      const double log_sum = block_sum(logs, it);
       ++evaluations;
       if (search == kSearchNelderMead) nm_advance(s, log_sum);
       else brent_advance(s, -log_sum, it == 0);
-      if (s.done) break;                                      // block-uniform: every thread holds the same state
+      if (s.done) break;                                      // uniform over the genome's threads: all hold the same state
     }
-    if (threadIdx.x == 0) {
+    if (t == 0) {
       f_out[g] = s.x;
       atomicMax(max_evaluations, evaluations);
     }

@@ -7,7 +7,8 @@ from kgl_gene_amd import capi
 
 capi.init(0)
 G, L = 2512, 200_000
-n_sel, g0, g1 = int(sys.argv[1]) if len(sys.argv) > 1 else 1000, 512, 1024
+n_sel = int(sys.argv[1]) if len(sys.argv) > 1 else 1000
+g0, g1 = (0, int(sys.argv[2])) if len(sys.argv) > 2 else (512, 1024)        # [genomes: the first N] (default: 512 in the middle)
 m = capi.GenotypeMatrix(G, L)
 table = m.synth_multiallelic(1111, 0, 0)
 index = np.sort(np.random.default_rng(1).choice(L, n_sel, replace=False)).astype(np.uint32)

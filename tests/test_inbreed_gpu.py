@@ -630,10 +630,11 @@ def test_paired_loglikelihood_search_is_the_single_search(kgx, monkeypatch):
 
 
 def test_window_iteration_kernel_at_its_cell_count_edges(kgx, monkeypatch):
-    """k_inbreed_iterate_genome<MODE, CELLS> (a block per genome, 2 / 4 / 8 loci per thread) at the selection sizes where
-    the host switches instantiation -- and one past the largest, where the multi-kernel passes take over -- against those
-    passes on the same selections of the C5 population: the counts bit for bit, HallME to 1e-12 (only the order of the
-    sums differs), Loglikelihood to 2e-6 on genomes with F >= 0 (one optimiser, one start, simplex of 1e-6)."""
+    """k_inbreed_iterate_genome<MODE, CELLS, THREADS> -- a block per genome (2 / 4 / 8 loci per thread) and a wave per
+    genome (8 / 16 / 32) -- at the selection sizes where the host switches instantiation, and one past the largest, where
+    the multi-kernel passes take over -- against those passes on the same selections of the C5 population: the counts bit
+    for bit, HallME to 1e-12 (only the order of the sums differs), Loglikelihood to 2e-6 on genomes with F >= 0 (one
+    optimiser, one start, simplex of 1e-6)."""
     G, L = 300, 4096
     m = kgx.GenotypeMatrix(G, L)
     table = m.synth_multiallelic(1111, 0, 0)
@@ -644,21 +645,24 @@ def test_window_iteration_kernel_at_its_cell_count_edges(kgx, monkeypatch):
         sub = np.ascontiguousarray(table[index])
         for algorithm in ("HallME", "Loglikelihood"):
             start = kgx.reference_starts(algorithm, START_SEED, G)
-            monkeypatch.delenv("KGX_K7_NO_WAVE", raising=False)
-            fused = {k: v.copy() for k, v in _fields(m.inbreed(sub, algorithm, phased=True, locus_index=index, start=start)).items()}
             monkeypatch.setenv("KGX_K7_NO_WAVE", "1")
-            passes = _fields(m.inbreed(sub, algorithm, phased=True, locus_index=index, start=start))
+            passes = {k: v.copy() for k, v in _fields(m.inbreed(sub, algorithm, phased=True, locus_index=index, start=start)).items()}
             monkeypatch.delenv("KGX_K7_NO_WAVE")
-            for name in ("major_hetero_count", "minor_hetero_count", "minor_homo_count", "major_homo_count", "total_allele_count"):
-                assert np.array_equal(fused[name], passes[name]), (n_sel, algorithm, name)
-            a, b = fused["inbred_allele_sum"], passes["inbred_allele_sum"]
-            both = np.isfinite(a) & np.isfinite(b)
-            assert np.array_equal(np.isfinite(a), np.isfinite(b)), (n_sel, algorithm)
-            if algorithm == "HallME":
-                assert np.abs(a[both] - b[both]).max(initial=0.0) <= 1e-12, (n_sel, float(np.abs(a[both] - b[both]).max()))
-            elif n_sel >= 255:            # (a handful of loci: a flat objective, several maxima)
-                smooth = both & (f_true >= 0.0)
-                assert np.abs(a[smooth] - b[smooth]).max(initial=0.0) <= 2e-6, (n_sel, float(np.abs(a[smooth] - b[smooth]).max()))
+            for wave_from in ("1", "1000000"):              # a wave per genome / a block per genome
+                monkeypatch.setenv("KGX_K7_WAVE_GENOMES", wave_from)
+                fused = _fields(m.inbreed(sub, algorithm, phased=True, locus_index=index, start=start))
+                monkeypatch.delenv("KGX_K7_WAVE_GENOMES")
+                ctx = (n_sel, algorithm, wave_from)
+                for name in ("major_hetero_count", "minor_hetero_count", "minor_homo_count", "major_homo_count", "total_allele_count"):
+                    assert np.array_equal(fused[name], passes[name]), ctx + (name,)
+                a, b = fused["inbred_allele_sum"], passes["inbred_allele_sum"]
+                both = np.isfinite(a) & np.isfinite(b)
+                assert np.array_equal(np.isfinite(a), np.isfinite(b)), ctx
+                if algorithm == "HallME":
+                    assert np.abs(a[both] - b[both]).max(initial=0.0) <= 1e-12, ctx + (float(np.abs(a[both] - b[both]).max()),)
+                elif n_sel >= 255:            # (a handful of loci: a flat objective, several maxima)
+                    smooth = both & (f_true >= 0.0)
+                    assert np.abs(a[smooth] - b[smooth]).max(initial=0.0) <= 2e-6, ctx + (float(np.abs(a[smooth] - b[smooth]).max()),)
     m.close()
 
 
