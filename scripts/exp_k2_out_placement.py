@@ -7,6 +7,8 @@ import torch
 sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
 from kgl_gene_amd import capi
 
+if len(sys.argv) > 1:                     # another build of the library (an experiment variant)
+    capi.LIB_PATH = Path(sys.argv[1]).resolve()
 capi.init(0)
 dev = torch.device("cuda:0")
 G, V = 10_000, 10_000_000
