@@ -15,6 +15,8 @@
 #include <vector>
 
 #include "kgx_kernels_inbreed.h"
+#include "kgx_kernels_hall.h"
+#include <hipcub/hipcub.hpp>
 #include "kgx_internal.h"
 
 namespace kgx {
@@ -144,6 +146,25 @@ int inbreed_shard(kgx_gt8_shard& sh, uint64_t g0, uint64_t g1, const uint32_t* l
   const bool table_passes = n_sel > 0 && (table_sweep || (eval_lut && (algorithm == 2 || algorithm == 3) && !wave_sized));
   const size_t o_entries = plan.add(table_passes ? (n_sel << (2u * eval_bits(amax))) * sizeof(EvalEntry) : 0);
   const size_t o_segcnt = plan.add(table_sweep ? max_seg * n * sizeof(unsigned long long) : sizeof(unsigned long long));
+  // HallME over a large call: per-genome moments of the homozygous cells' frequencies instead of 50 passes (kgx_kernels_hall.h)
+  const bool hall_moments = algorithm == KGX_ALGO_HALL_ME && n_sel > 0 && !wave_sized && eval_lut && !env_int("KGX_K7_HALL_PASSES", 0);
+  const uint64_t hall_items = hall_moments ? n_sel / kHallItemLoci + kHallBins + 1 : 0;
+  size_t hall_sort_bytes = 0;
+  if (hall_moments) {
+    // (a size query: no device work)
+    if (hipcub::DeviceRadixSort::SortPairs(nullptr, hall_sort_bytes, static_cast<const uint32_t*>(nullptr), static_cast<uint32_t*>(nullptr),
+                                           static_cast<const uint32_t*>(nullptr), static_cast<uint32_t*>(nullptr), static_cast<int>(n_sel), 0, 12,
+                                           dev.stream) != hipSuccess)
+      return fail(KGX_EHIP, "kgx_inbreed: radix sort size query failed");
+  }
+  const size_t o_hall_keys = plan.add(hall_moments ? 4 * n_sel * sizeof(uint32_t) : 0);            // keys, slots, sorted keys, sorted slots
+  const size_t o_hall_records = plan.add(hall_moments ? n_sel * sizeof(HallRecord) : 0);
+  // bin_begin | bin_end | item_base | bin_used | used | n_items, n_used, unsupported: small words, cleared together where needed
+  const size_t o_hall_words = plan.add(hall_moments ? (5 * (kHallBins + 1) + 4) * sizeof(uint32_t) : 0);
+  const size_t o_hall_items = plan.add(hall_items * sizeof(HallItem));
+  const size_t o_hall_sort = plan.add(hall_sort_bytes);
+  const size_t o_hall_moments = plan.add(hall_items * kHallMoments * n * sizeof(double));
+  const size_t o_hall_bins = plan.add(hall_moments ? static_cast<size_t>(kHallBins) * kHallMoments * n * sizeof(double) : 0);
   char* arena = nullptr;
   if (int arc = scratch_reserve(dev, plan.total, &arena)) return arc;
   d_af = reinterpret_cast<double*>(arena + o_af);
@@ -374,6 +395,52 @@ int inbreed_shard(kgx_gt8_shard& sh, uint64_t g0, uint64_t g1, const uint32_t* l
       // processHallME (_calc.cpp:225-307).  The reference restarts from U(0,0.5] and, through RetryCalcResult's
       // self-comparison (_calc.cpp:45-68), always stops after 5 restarts of exactly 50 expectation steps, keeping the
       // last: 50 steps from the start point handed in (the fifth draw, or 0.25 without one).
+      bool by_moments = false;
+      if (hall_moments && rc == KGX_OK) {
+        // HallME on per-genome moments (kgx_kernels_hall.h): one pass over the bytes per class of homozygous cell, then
+        // the 50 steps on ~10^3 numbers a genome.
+        uint32_t* h_keys = reinterpret_cast<uint32_t*>(arena + o_hall_keys);
+        uint32_t *h_slots = h_keys + n_sel, *h_sorted_keys = h_keys + 2 * n_sel, *h_sorted_slots = h_keys + 3 * n_sel;
+        HallRecord* h_records = reinterpret_cast<HallRecord*>(arena + o_hall_records);
+        uint32_t* h_bin_begin = reinterpret_cast<uint32_t*>(arena + o_hall_words);
+        uint32_t *h_bin_end = h_bin_begin + (kHallBins + 1), *h_item_base = h_bin_begin + 2 * (kHallBins + 1);
+        uint32_t *h_bin_used = h_bin_begin + 3 * (kHallBins + 1), *h_used = h_bin_begin + 4 * (kHallBins + 1);
+        uint32_t* h_counters = h_bin_begin + 5 * (kHallBins + 1);            // n_items, n_used, unsupported
+        HallItem* h_items = reinterpret_cast<HallItem*>(arena + o_hall_items);
+        double* h_moments = reinterpret_cast<double*>(arena + o_hall_moments);
+        double* h_bins = reinterpret_cast<double*>(arena + o_hall_bins);
+        const uint32_t classes = 1u + (phased ? amax : 0u);                   // byte 0x00, and a | a << 4 of a phased population (classify_cell)
+        const uint32_t hall_chunks = static_cast<uint32_t>(((n + eval_gpl - 1) / eval_gpl + kBlock - 1) / kBlock);
+        try_hip(hipMemsetAsync(arena + o_hall_words, 0, (5 * (kHallBins + 1) + 4) * sizeof(uint32_t), st), KGX_EHIP, "memset(hall words)");
+        try_hip(hipMemsetAsync(h_bins, 0, static_cast<size_t>(kHallBins) * kHallMoments * n * sizeof(double), st), KGX_EHIP, "memset(hall bins)");
+        for (uint32_t k = 0; k < classes && rc == KGX_OK; ++k) {
+          if (k) try_hip(hipMemsetAsync(h_bin_begin, 0, 2 * (kHallBins + 1) * sizeof(uint32_t), st), KGX_EHIP, "memset(hall stretches)");
+          hipLaunchKernelGGL(k_hall_keys, dim3(stream_grid(dev, n_sel, kBlock)), dim3(kBlock), 0, st, d_table, d_valid, n_sel, amax, phased, k, h_keys,
+                             h_slots, h_counters + 2);
+          size_t sort_bytes = hall_sort_bytes;
+          try_hip(hipcub::DeviceRadixSort::SortPairs(arena + o_hall_sort, sort_bytes, h_keys, h_sorted_keys, h_slots, h_sorted_slots,
+                                                     static_cast<int>(n_sel), 0, 12, st), KGX_EHIP, "radix sort");
+          hipLaunchKernelGGL(k_hall_records, dim3(stream_grid(dev, n_sel, kBlock)), dim3(kBlock), 0, st, h_sorted_keys, h_sorted_slots, n_sel, d_table,
+                             amax, k, d_index, h_records, h_bin_begin, h_bin_end);
+          hipLaunchKernelGGL(k_hall_items, dim3(1), dim3(kBlock), 0, st, h_bin_begin, h_bin_end, h_item_base, h_items, h_counters);
+          const dim3 sweep_grid(static_cast<uint32_t>(hall_items * hall_chunks));
+          const uint32_t code = k | (k << 4);
+          if (eval_gpl == 8)
+            hipLaunchKernelGGL((k_hall_sweep<8>), sweep_grid, dim3(kBlock), 0, st, gt32, dwords_per_row, g0, n, h_records, h_items, h_counters, hall_chunks, code, h_moments);
+          else
+            hipLaunchKernelGGL((k_hall_sweep<4>), sweep_grid, dim3(kBlock), 0, st, gt32, dwords_per_row, g0, n, h_records, h_items, h_counters, hall_chunks, code, h_moments);
+          hipLaunchKernelGGL(k_hall_merge, dim3(8, kHallBins), dim3(kBlock), 0, st, h_moments, h_item_base, n, h_bins, h_bin_used);
+          try_hip(hipGetLastError(), KGX_EHIP, "hall moments launch");
+        }
+        hipLaunchKernelGGL(k_hall_used_bins, dim3(1), dim3(kBlock), 0, st, h_bin_used, h_used, h_counters + 1);
+        hipLaunchKernelGGL(k_hall_iterate, dim3(static_cast<uint32_t>(n)), dim3(kBlock), 0, st, h_bins, h_used, h_counters + 1, d_counts, n, d_start, d_f);
+        try_hip(hipGetLastError(), KGX_EHIP, "hall iterate launch");
+        uint32_t unsupported = 0;
+        try_hip(hipMemcpyAsync(&unsupported, h_counters + 2, sizeof(uint32_t), hipMemcpyDeviceToHost, st), KGX_EHIP, "D2H(hall flag)");
+        try_hip(hipStreamSynchronize(st), KGX_EHIP, "sync");
+        by_moments = rc == KGX_OK && unsupported == 0;      // a frequency outside the bins (below 2^-20, above 1): the 50 passes below
+      }
+      if (!by_moments) {
       const std::vector<double>& f0 = start_points;
       // locus slots every lane of k_inbreed_eval_lut walks: whole batches of 8 in every segment
       const unsigned long long walked = eval_lut && n_sel ? (eval_n_seg - 1) * eval_per_seg + (n_sel - (eval_n_seg - 1) * eval_per_seg + 7) / 8 * 8 : 0ull;
@@ -405,6 +472,7 @@ int inbreed_shard(kgx_gt8_shard& sh, uint64_t g0, uint64_t g1, const uint32_t* l
           trace_prev2 = trace_prev;
           trace_prev = trace_now;
         }
+      }
       }
     } else if (algorithm == 3) {
       // processLogLikelihood (_calc.cpp:153-216): maximise over [-1,1].  The objective is a sum of logs of

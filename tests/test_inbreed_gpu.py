@@ -668,3 +668,48 @@ def test_window_iteration_kernel_at_its_cell_count_edges(kgx, monkeypatch):
 
 def _fields(result):
     return {name: np.asarray(result[name]) for name in result.dtype.names}
+
+
+@pytest.mark.gpu
+def test_hallme_by_moments_is_the_fifty_passes(kgx, monkeypatch):
+    """HallME over a call too large for the one-launch iteration: the per-genome moments of the homozygous cells'
+    frequencies (kgx_kernels_hall.h; one pass over the bytes per class of homozygous cell, then 50 steps on the moments)
+    against the 50 passes over the bytes (KGX_K7_HALL_PASSES=1) -- phased (1 + amax classes) and unphased (the major
+    allele alone), dense and indexed, a genome range off the lane width, both lane widths of the pass: |dF| <= 1e-10
+    (the expansion is cut below 1e-12 of a term; 50 steps carry it), everything else bit for bit."""
+    G, L = 777, 30_000
+    m = kgx.GenotypeMatrix(G, L)
+    table = m.synth_multiallelic(1111, 0, 0)
+    rng = np.random.default_rng(5)
+    index = np.sort(rng.choice(L, 17_001, replace=False)).astype(np.uint32)
+    for phased in (True, False):
+        for sel, g0, g1 in ((None, 0, G), (index, 0, G), (index, 8, 700), (None, 4, 401)):
+            sub = table if sel is None else np.ascontiguousarray(table[sel])
+            start = kgx.reference_starts("HallME", START_SEED, g1 - g0)
+            monkeypatch.setenv("KGX_K7_HALL_PASSES", "1")
+            passes = {k: v.copy() for k, v in _fields(m.inbreed(sub, "HallME", phased=phased, locus_index=sel, g0=g0, g1=g1, start=start)).items()}
+            monkeypatch.delenv("KGX_K7_HALL_PASSES")
+            moments = _fields(m.inbreed(sub, "HallME", phased=phased, locus_index=sel, g0=g0, g1=g1, start=start))
+            ctx = (phased, None if sel is None else len(sel), g0, g1)
+            for name in passes:
+                if name != "inbred_allele_sum":
+                    assert np.array_equal(moments[name], passes[name]), ctx + (name,)
+            a, b = moments["inbred_allele_sum"], passes["inbred_allele_sum"]
+            assert np.array_equal(np.isfinite(a), np.isfinite(b)), ctx
+            err = np.abs(a - b)[np.isfinite(b)]
+            assert err.max(initial=0.0) <= 1e-10, ctx + (float(err.max()),)
+            if phased:
+                assert np.abs(b[np.isfinite(b)]).max() > 0.05, ctx      # (not a comparison of zeros; unphased, HallME runs to ~0)
+    # frequencies the bins do not reach (below 2^-20): the call takes the passes, silently and with their result
+    odd = table[:5000].copy()
+    odd[7, 0] = 1e-9
+    want = None
+    for env in ("1", None):
+        if env:
+            monkeypatch.setenv("KGX_K7_HALL_PASSES", env)
+        got = m.inbreed(odd, "HallME", phased=True, locus_index=np.arange(5000, dtype=np.uint32), start=kgx.reference_starts("HallME", START_SEED, G))["inbred_allele_sum"].copy()
+        if env:
+            monkeypatch.delenv("KGX_K7_HALL_PASSES")
+            want = got
+    assert np.array_equal(got, want)
+    m.close()
