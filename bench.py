@@ -334,6 +334,45 @@ def aux_inbreeding(args, capi, torch, dev, cpu):
                       f"store itself is the parser's output and is not timed; parity vs GPU on the slice: class counts "
                       f"{'bit-exact' if ok else 'MISMATCH'}, |dF| max {f_err:.1e}",
             "parity_ok": ok}
+    # HallME over the same population (kgx_kernels_hall.h: per-genome moments, one pass over the bytes per class of
+    # homozygous cell instead of processHallME's 50): calls from seeded reference start points.
+    hall_seed = 4242
+    hall_start = capi.reference_starts("HallME", hall_seed, G)
+    hall_walls = []
+    hall = None
+    for i in range(4):
+        t = time.perf_counter()
+        hall = m.inbreed_resident(table_dev.data_ptr(), n_sel, amax, "HallME", phased=True, start=hall_start)
+        if i >= 1:
+            hall_walls.append((time.perf_counter() - t) * 1e3)
+    hall_ms = float(np.median(hall_walls))
+    classes = 1 + amax
+    record["hallme"] = {
+        "metric": "genomes·loci/sec (inbreeding sweep + HallME)", "value": G * L / (hall_ms * 1e-3), "unit": "genomes·loci/s",
+        "ms_per_call": hall_ms, "calls": len(hall_walls),
+        "config": {"workload": label, "algorithm": "HallME", "start_points": f"kgx_inbreed_reference_starts(seed {hall_seed})",
+                   "passes_over_the_bytes": f"1 frequency sweep + {classes} moment passes (classes of homozygous cell) instead of 1 + 50",
+                   "mean_F": float(hall["inbred_allele_sum"].mean())},
+        "roofline": {"bound": "hbm", "kernel": "k_hall_sweep<8> (one class's moment pass)", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": None, "traffic": None, "algorithmic_bytes_per_launch": sweep_bytes,
+                     "note": "not timed alone in this run: profiles/r03_hall_kernel_stats.csv holds its rocprofv3 average"},
+        "cpu_baseline": None,
+    }
+    if cpu:
+        counts, freqs, present, seconds = oa.inbreed_window(ref.filter_snp_pass(), dip, np.full(Gs, oa.ALL, dtype=np.int32), "HallME", 0,
+                                                            int(d["offsets"][-1]) + 1, 1, 10**9, 0.0, 1.0, seed=hall_seed)
+        order = dip.genome_order()
+        slice_start = np.empty(Gs, dtype=np.float64)
+        slice_start[order] = capi.reference_starts("HallME", hall_seed, Gs)       # the k-th genome in id order owns stream seed + k
+        got = m.inbreed(np.ascontiguousarray(table[:Ls]), "HallME", phased=True, locus_index=np.arange(Ls, dtype=np.uint32), g0=0, g1=Gs,
+                        start=slice_start)[order]
+        f_err = float(np.abs(got["inbred_allele_sum"] - freqs[:, 4]).max())
+        ok = bool(present.all()) and np.array_equal(got["total_allele_count"], counts[:, 4]) and f_err <= 1e-9
+        record["hallme"]["cpu_baseline"] = {
+            "value": Gs * Ls / seconds, "unit": "genomes·loci/s", "cores": threads, "kind": "port",
+            "sample": f"the Simple leg's slice ({Gs * Ls:.3g} cells, {seconds:.1f} s): oracle processResults with processHallME (5 restarts of 50 "
+                      f"steps, the fifth decides; {threads} pool threads), same seeded entropy; parity vs GPU on the slice: |dF| max {f_err:.1e} (bound 1e-9)",
+            "parity_ok": ok}
     m.close()
     capi.release_scratch()
     return record

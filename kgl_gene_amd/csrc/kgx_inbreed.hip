@@ -411,6 +411,8 @@ int inbreed_shard(kgx_gt8_shard& sh, uint64_t g0, uint64_t g1, const uint32_t* l
         double* h_bins = reinterpret_cast<double*>(arena + o_hall_bins);
         const uint32_t classes = 1u + (phased ? amax : 0u);                   // byte 0x00, and a | a << 4 of a phased population (classify_cell)
         const uint32_t hall_chunks = static_cast<uint32_t>(((n + eval_gpl - 1) / eval_gpl + kBlock - 1) / kBlock);
+        // (a bin's workgroups: enough of them for the few bins that hold most loci -- the major allele's -- to fill the chip)
+        const uint32_t hall_merge_blocks = static_cast<uint32_t>(std::min<uint64_t>(64, (kHallMoments * n + kBlock - 1) / kBlock));
         try_hip(hipMemsetAsync(arena + o_hall_words, 0, (5 * (kHallBins + 1) + 4) * sizeof(uint32_t), st), KGX_EHIP, "memset(hall words)");
         try_hip(hipMemsetAsync(h_bins, 0, static_cast<size_t>(kHallBins) * kHallMoments * n * sizeof(double), st), KGX_EHIP, "memset(hall bins)");
         for (uint32_t k = 0; k < classes && rc == KGX_OK; ++k) {
@@ -429,7 +431,7 @@ int inbreed_shard(kgx_gt8_shard& sh, uint64_t g0, uint64_t g1, const uint32_t* l
             hipLaunchKernelGGL((k_hall_sweep<8>), sweep_grid, dim3(kBlock), 0, st, gt32, dwords_per_row, g0, n, h_records, h_items, h_counters, hall_chunks, code, h_moments);
           else
             hipLaunchKernelGGL((k_hall_sweep<4>), sweep_grid, dim3(kBlock), 0, st, gt32, dwords_per_row, g0, n, h_records, h_items, h_counters, hall_chunks, code, h_moments);
-          hipLaunchKernelGGL(k_hall_merge, dim3(8, kHallBins), dim3(kBlock), 0, st, h_moments, h_item_base, n, h_bins, h_bin_used);
+          hipLaunchKernelGGL(k_hall_merge, dim3(hall_merge_blocks, kHallBins), dim3(kBlock), 0, st, h_moments, h_item_base, n, h_bins, h_bin_used);
           try_hip(hipGetLastError(), KGX_EHIP, "hall moments launch");
         }
         hipLaunchKernelGGL(k_hall_used_bins, dim3(1), dim3(kBlock), 0, st, h_bin_used, h_used, h_counters + 1);

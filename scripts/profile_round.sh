@@ -24,3 +24,7 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/window_trace -- pyt
 echo "window trace done" >> $OUT/progress.txt
 cat $OUT/k7.txt $OUT/window.txt
 du -sh $OUT
+# HallME over a large call on per-genome moments (kgx_kernels_hall.h) against the 50 passes, C5
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/hall_trace -- python3 $REPO/scripts/bench_hall.py > $OUT/hall.txt 2> $OUT/hall.err
+echo "hall trace done" >> $OUT/progress.txt
+cat $OUT/hall.txt
