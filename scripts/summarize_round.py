@@ -113,5 +113,18 @@ if window_files:
     for r in sorted(csv.DictReader(window_stats.open()), key=lambda r: -float(r["TotalDurationNs"]))[:8]:
         lines.append(f"| `{short(r['Name'])}` | {r['Calls']} | {float(r['AverageNs']) / 1e3:.1f} | {float(r['Percentage']):.1f} % |")
     lines += ["", "```"] + (src / "window.txt").read_text().strip().splitlines() + ["```", ""]
+# ---- HallME over a large call: per-genome moments (kgx_kernels_hall.h) against the 50 passes
+hall_files = glob.glob(str(src / "hall_trace/*/*kernel_stats.csv"))
+if hall_files:
+    hall_stats = Path(max(hall_files, key=lambda f: Path(f).stat().st_mtime))
+    (dst / f"{tag}_hall_kernel_stats.csv").write_text(hall_stats.read_text())
+    lines += ["## HallME at C5 on per-genome moments (`scripts/bench_hall.py`: 4 calls by moments, then 4 by the 50 passes)", "",
+              "`rocprofv3 --kernel-trace --stats -- python3 scripts/bench_hall.py`; `k_hall_sweep` runs once per class of homozygous cell "
+              "(4 at C5: two over every locus, two over the loci that have a second / third alt), so its average is over unequal passes.", "",
+              "| kernel | calls | avg ms |", "|---|---|---|"]
+    for r in csv.DictReader(hall_stats.open()):
+        if "k_hall" in r["Name"] or "rocprim" in r["Name"] or "eval_lut<1" in r["Name"]:
+            lines.append(f"| `{short(r['Name'])[:90]}` | {r['Calls']} | {float(r['AverageNs']) / 1e6:.3f} |")
+    lines += ["", "```"] + [l for l in (src / "hall.txt").read_text().strip().splitlines() if "amdgpu.ids" not in l] + ["```", ""]
 (dst / f"{tag}_summary.md").write_text("\n".join(lines))
 print("\n".join(lines))

@@ -66,7 +66,7 @@ def test_class_frequency_table_is_bit_exact(kgx):
 
 @pytest.mark.parametrize("mode", [oa.Population.PHASED, oa.Population.UNPHASED])
 @pytest.mark.parametrize("algorithm,path", [("Simple", "default"), ("RitlandLocus", "default"), ("HallME", "default"), ("Loglikelihood", "default"),
-                                            ("HallME", "passes"), ("Loglikelihood", "passes"), ("Loglikelihood", "golden"),
+                                            ("HallME", "passes"), ("HallME", "fifty-passes"), ("Loglikelihood", "passes"), ("Loglikelihood", "golden"),
                                             ("Loglikelihood", "compacting"),
                                             ("Simple", "generic"), ("RitlandLocus", "generic"), ("HallME", "generic"), ("Loglikelihood", "generic"),
                                             ("Simple", "swar16"), ("HallME", "swar16"), ("Simple", "swar4"), ("RitlandLocus", "no-table"),
@@ -75,7 +75,8 @@ def test_inbreed_window_vs_oracle(kgx, mode, algorithm, path, monkeypatch):
     # every kernel flavour against the same oracle window: the table sweep + window-sized fused iteration (default), the
     # multi-kernel table passes, plain golden section, the generic per-cell kernels, the SWAR sweeps (16 and 4 genomes per
     # lane: what the frequency pass falls back to without the table sweep)
-    env = {"passes": {"KGX_K7_NO_WAVE": "1"},
+    # ("passes": HallME on per-genome moments, Loglikelihood by its table passes; "fifty-passes": HallME's 50 table passes)
+    env = {"passes": {"KGX_K7_NO_WAVE": "1"}, "fifty-passes": {"KGX_K7_NO_WAVE": "1", "KGX_K7_HALL_PASSES": "1"},
            "compacting": {"KGX_K7_NO_WAVE": "1", "KGX_K7_COMPACT_MIN_GENOMES": "4", "KGX_K7_COMPACT_MIN_CELLS": "1"}, "golden": {"KGX_K7_NO_WAVE": "1", "KGX_K7_GOLDEN": "1"},
            "generic": {"KGX_K5_GENERIC": "1", "KGX_K7_NO_WAVE": "1"}, "swar16": {"KGX_K5_NO_TABLE_SWEEP": "1"},
            "swar4": {"KGX_K5_NO_TABLE_SWEEP": "1", "KGX_K5_NO_SWAR16": "1"},
@@ -365,11 +366,13 @@ def test_kernel_flavours_agree_on_random_shapes(kgx, monkeypatch):
     """Differential fuzz: random shapes (genome counts off every lane width, sub-ranges, indexed and dense loci, 1..14
     alleles, every byte value incl. the (0, a) pair, 0xFF and unknown alts, loci without defaults, missing AFs) through
     every kernel flavour -- the generic per-cell kernels are the ones pinned to the oracle above; the SWAR sweeps, the
-    table passes and the fused wave iteration must reproduce them."""
+    table passes, HallME's moments ("passes": any call size with the one-launch iteration off) and the one-launch iteration
+    must reproduce them."""
     import os
 
     rng = np.random.default_rng(int(os.environ.get("KGX_FUZZ_SEED", "2024")))      # other seeds / more trials: a longer hunt, by hand
     flavours = {"default": {}, "generic": {"KGX_K5_GENERIC": "1", "KGX_K7_NO_WAVE": "1"}, "passes": {"KGX_K7_NO_WAVE": "1"},
+                "fifty-passes": {"KGX_K7_NO_WAVE": "1", "KGX_K7_HALL_PASSES": "1"},
                 "swar16": {"KGX_K5_NO_TABLE_SWEEP": "1"}, "swar4": {"KGX_K5_NO_TABLE_SWEEP": "1", "KGX_K5_NO_SWAR16": "1"},
                 "sequential": {"KGX_K5_SEQUENTIAL_MIN": "1"}}
     knobs = sorted({k for env in flavours.values() for k in env})
