@@ -5,6 +5,8 @@ import numpy as np
 sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
 from kgl_gene_amd import capi
 
+if os.environ.get("KGX_EXP_LIB"):          # another build of the library (an experiment variant)
+    capi.LIB_PATH = Path(os.environ["KGX_EXP_LIB"]).resolve()
 capi.init(0)
 G, L = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (10_000, 5_000_000)
 m = capi.GenotypeMatrix(G, L)
