@@ -102,40 +102,49 @@ k_hall_records(const uint32_t* __restrict__ sorted_keys, const uint32_t* __restr
 }
 
 // One workgroup: every bin's stretch cut into items of at most kHallItemLoci loci, slots dealt in bin order.
-// item_base[bin] .. item_base[bin + 1] are the bin's items; *n_items their number.
+// item_base[bin] .. item_base[bin + 1] are the bin's items; *n_items their number.  Thread t owns the bins
+// t * kHallBinsPerThread ..: its own running count, then one pass of thread 0 over the 256 thread totals.
 __global__ void __launch_bounds__(kBlock)
 k_hall_items(const uint32_t* __restrict__ bin_begin, const uint32_t* __restrict__ bin_end, uint32_t* __restrict__ item_base,
              HallItem* __restrict__ items, uint32_t* __restrict__ n_items) {
-  __shared__ uint32_t count[kHallBins + 1];
-  for (uint32_t b = threadIdx.x; b < kHallBins; b += blockDim.x) {
-    const uint32_t loci = bin_end[b] - bin_begin[b];
-    count[b] = (loci + kHallItemLoci - 1) / kHallItemLoci;
+  __shared__ uint32_t thread_base[kBlock + 1];
+  const uint32_t first_bin = threadIdx.x * kHallBinsPerThread;
+  uint32_t begin[kHallBinsPerThread], loci[kHallBinsPerThread], count[kHallBinsPerThread];
+  uint32_t mine = 0;
+#pragma unroll
+  for (int i = 0; i < kHallBinsPerThread; ++i) {
+    const uint32_t b = first_bin + i;
+    begin[i] = b < kHallBins ? bin_begin[b] : 0u;
+    loci[i] = b < kHallBins ? bin_end[b] - begin[i] : 0u;
+    count[i] = (loci[i] + kHallItemLoci - 1) / kHallItemLoci;
+    mine += count[i];
+  }
+  thread_base[threadIdx.x + 1] = mine;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    thread_base[0] = 0;
+    for (uint32_t t = 1; t <= kBlock; ++t) thread_base[t] += thread_base[t - 1];
+    *n_items = thread_base[kBlock];
+    item_base[kHallBins] = thread_base[kBlock];
   }
   __syncthreads();
-  if (threadIdx.x == 0) {                                                  // 2562 additions: not worth a parallel scan
-    uint32_t running = 0;
-    for (uint32_t b = 0; b < kHallBins; ++b) {
-      const uint32_t c = count[b];
-      count[b] = running;
-      running += c;
-    }
-    count[kHallBins] = running;
-    *n_items = running;
-  }
-  __syncthreads();
-  for (uint32_t b = threadIdx.x; b <= kHallBins; b += blockDim.x) item_base[b] = count[b];
-  for (uint32_t b = threadIdx.x; b < kHallBins; b += blockDim.x) {
-    const uint32_t first = count[b], n = count[b + 1] - first;
-    const uint32_t begin = bin_begin[b], loci = bin_end[b] - begin;
+  uint32_t first = thread_base[threadIdx.x];
+#pragma unroll
+  for (int i = 0; i < kHallBinsPerThread; ++i) {
+    const uint32_t b = first_bin + i;
+    if (b >= kHallBins) break;
+    item_base[b] = first;
+    const uint32_t n = count[i];
     for (uint32_t q = 0; q < n; ++q) {
       HallItem it;
       // equal shares of the stretch (whole loci): item q takes [q * loci / n, (q + 1) * loci / n)
-      it.begin = begin + static_cast<uint32_t>(static_cast<uint64_t>(q) * loci / n);
-      it.end = begin + static_cast<uint32_t>(static_cast<uint64_t>(q + 1) * loci / n);
+      it.begin = begin[i] + static_cast<uint32_t>(static_cast<uint64_t>(q) * loci[i] / n);
+      it.end = begin[i] + static_cast<uint32_t>(static_cast<uint64_t>(q + 1) * loci[i] / n);
       it.bin = b;
       it.pad = 0u;
       items[first + q] = it;
     }
+    first += n;
   }
 }
 
@@ -237,14 +246,29 @@ k_hall_merge(const double* __restrict__ moments, const uint32_t* __restrict__ it
   }
 }
 
-// One workgroup: the bins that hold anything, in bin order.
+// One workgroup: the bins that hold anything, in bin order (thread t: the bins t * kHallBinsPerThread ..).
 __global__ void __launch_bounds__(kBlock)
 k_hall_used_bins(const uint32_t* __restrict__ bin_used, uint32_t* __restrict__ used, uint32_t* __restrict__ n_used) {
-  if (threadIdx.x != 0) return;
-  uint32_t n = 0;
-  for (uint32_t b = 0; b < kHallBins; ++b)
-    if (bin_used[b]) used[n++] = b;
-  *n_used = n;
+  __shared__ uint32_t thread_base[kBlock + 1];
+  const uint32_t first_bin = threadIdx.x * kHallBinsPerThread;
+  uint32_t flags = 0, mine = 0;
+#pragma unroll
+  for (int i = 0; i < kHallBinsPerThread; ++i) {
+    const uint32_t b = first_bin + i;
+    if (b < kHallBins && bin_used[b]) { flags |= 1u << i; ++mine; }
+  }
+  thread_base[threadIdx.x + 1] = mine;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    thread_base[0] = 0;
+    for (uint32_t t = 1; t <= kBlock; ++t) thread_base[t] += thread_base[t - 1];
+    *n_used = thread_base[kBlock];
+  }
+  __syncthreads();
+  uint32_t at = thread_base[threadIdx.x];
+#pragma unroll
+  for (int i = 0; i < kHallBinsPerThread; ++i)
+    if (flags & (1u << i)) used[at++] = first_bin + i;
 }
 
 // processHallME's 50 steps (_calc.cpp:255-285) on the moments: a workgroup per genome, thread t holds the bins used[t],
