@@ -147,7 +147,9 @@ int inbreed_shard(kgx_gt8_shard& sh, uint64_t g0, uint64_t g1, const uint32_t* l
   const size_t o_entries = plan.add(table_passes ? (n_sel << (2u * eval_bits(amax))) * sizeof(EvalEntry) : 0);
   const size_t o_segcnt = plan.add(table_sweep ? max_seg * n * sizeof(unsigned long long) : sizeof(unsigned long long));
   // HallME over a large call: per-genome moments of the homozygous cells' frequencies instead of 50 passes (kgx_kernels_hall.h)
-  const bool hall_moments = algorithm == KGX_ALGO_HALL_ME && n_sel > 0 && n_sel < (1ull << 31) && !wave_sized && eval_lut &&
+  // (any amax: the class passes compare bytes, no table; the generic / no-table flavours keep the passes they are there to test)
+  const bool hall_moments = algorithm == KGX_ALGO_HALL_ME && n_sel > 0 && n_sel < (1ull << 31) && !wave_sized &&
+                            !env_int("KGX_K5_GENERIC", 0) && !env_int("KGX_K5_NO_EVAL_LUT", 0) &&
                             !env_int("KGX_K7_HALL_PASSES", 0);                 // (the radix sort counts its items in an int)
   const uint64_t hall_items = hall_moments ? n_sel / kHallItemLoci + kHallBins + 1 : 0;
   size_t hall_sort_bytes = 0;
