@@ -296,7 +296,7 @@ int kgx_locus_class_frequencies(const double* minor_af, uint64_t n_loci, uint32_
  * the FIFTH alone decides the result: kgx_inbreed_reference_starts() makes exactly those draws, so passing its output is
  * the reference's algorithm at no extra pass.  NULL: the midpoints of its start intervals (0.25 / 0.0), a deterministic
  * mode the reference does not have.  HallME runs the reference's 50 expectation steps from the start -- over a selection
- * of more than 2048 loci on per-genome moments of the homozygous cells' allele frequencies (one pass over the genotype
+ * of more than 8192 loci (up to there the whole iteration is one kernel launch) on per-genome moments of the homozygous cells' allele frequencies (one pass over the genotype
  * bytes per class of homozygous cell, then the 50 steps on those numbers: the step's sum is expanded about the centre of
  * each frequency bin and cut below 1e-12 of a term, measured 6e-16 of F from the 50 passes; KGX_K7_HALL_PASSES=1 or a
  * frequency outside [2^-20, 1] u {0} makes the 50 passes over the bytes instead); Loglikelihood

@@ -376,21 +376,29 @@ int inbreed_shard(kgx_gt8_shard& sh, uint64_t g0, uint64_t g1, const uint32_t* l
       // log, the search step and the reduction in all four waves).  Measured at 1000 loci (scripts/exp_window_threads.sh,
       // ms per call, block / wave): HallME 0.127 / 0.162 at 256 genomes, 0.144 / 0.154 at 512, 0.173 / 0.170 at 1024,
       // 0.335 / 0.259 at 2504; Loglikelihood 0.150 / 0.161, 0.170 / 0.157, 0.207 / 0.176, 0.315 / 0.231.
-      const bool per_wave = n >= static_cast<uint64_t>(std::max(1, env_int("KGX_K7_WAVE_GENOMES", algorithm == 2 ? 1024 : 512)));
+      const bool per_wave = n_sel <= static_cast<uint64_t>(kGenomeWaveLoci) &&      // (a lane holds at most 32 cells)
+                            n >= static_cast<uint64_t>(std::max(1, env_int("KGX_K7_WAVE_GENOMES", algorithm == 2 ? 1024 : 512)));
       const uint32_t wave_grid = static_cast<uint32_t>(per_wave ? (n + kBlock / kWave - 1) / (kBlock / kWave) : n);
       const double* estimate = algorithm == 2 ? d_sums : env_int("KGX_K7_ESTIMATE_START", 0) ? d_sums : nullptr;
 #define KGX_WAVE(MODE, CELLS, THREADS)                                                                                             \
   hipLaunchKernelGGL((k_inbreed_iterate_genome<MODE, CELLS, THREADS>), dim3(wave_grid), dim3(kBlock), 0, st, sh.d_gt, sh.pitch, g0, n, d_index, \
                      n_sel, d_table, d_valid, amax, phased, d_counts, estimate, search, d_start, d_f, d_running)
       // the smallest per-thread cell count that holds the selection (see the kernel)
-#define KGX_WAVE_CELLS(MODE, THREADS)                                                                        \
-  do {                                                                                                       \
-    if (n_sel <= THREADS * (kGenomeLoci / THREADS / 4)) KGX_WAVE(MODE, kGenomeLoci / THREADS / 4, THREADS);  \
-    else if (n_sel <= THREADS * (kGenomeLoci / THREADS / 2)) KGX_WAVE(MODE, kGenomeLoci / THREADS / 2, THREADS); \
-    else KGX_WAVE(MODE, kGenomeLoci / THREADS, THREADS);                                                     \
+#define KGX_WAVE_CELLS(MODE)                                                                                  \
+  do {                                                                                                        \
+    if (per_wave) {                                                                                           \
+      if (n_sel <= kWave * 8) KGX_WAVE(MODE, 8, kWave);                                                       \
+      else if (n_sel <= kWave * 16) KGX_WAVE(MODE, 16, kWave);                                                \
+      else KGX_WAVE(MODE, 32, kWave);                                                                         \
+    } else {                                                                                                  \
+      if (n_sel <= kBlock * 2) KGX_WAVE(MODE, 2, kBlock);                                                     \
+      else if (n_sel <= kBlock * 4) KGX_WAVE(MODE, 4, kBlock);                                                \
+      else if (n_sel <= kBlock * 8) KGX_WAVE(MODE, 8, kBlock);                                                \
+      else if (n_sel <= kBlock * 16) KGX_WAVE(MODE, 16, kBlock);                                              \
+      else KGX_WAVE(MODE, 32, kBlock);                                                                        \
+    }                                                                                                         \
   } while (0)
-      if (algorithm == 2) { if (per_wave) KGX_WAVE_CELLS(1, kWave); else KGX_WAVE_CELLS(1, kBlock); }
-      else { if (per_wave) KGX_WAVE_CELLS(2, kWave); else KGX_WAVE_CELLS(2, kBlock); }
+      if (algorithm == 2) KGX_WAVE_CELLS(1); else KGX_WAVE_CELLS(2);
 #undef KGX_WAVE_CELLS
 #undef KGX_WAVE
       wave_evaluations = algorithm == 3;          // its count (d_running, cleared with the counts) comes back with the results

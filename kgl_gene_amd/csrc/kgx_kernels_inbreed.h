@@ -1719,11 +1719,12 @@ k_gather_states(const BrentState* __restrict__ st, const double* __restrict__ f,
 // of 16 lanes (row_sum16) and the row sums added as a fixed tree -- the wave's four read with v_readlane, the block's
 // sixteen out of LDS (one barrier per pass, the slots alternate): every thread of the genome ends with the
 // bitwise-same sum, so the search's control flow is uniform over them.  No grid synchronisation, no partials in
-// memory.  n_sel <= kGenomeLoci; CELLS (the host picks the smallest of three that holds n_sel / THREADS) bounds the
+// memory.  n_sel <= kGenomeLoci; CELLS (the host picks the smallest power of two that holds n_sel / THREADS) bounds the
 // unrolled per-thread loops: with one or two waves on a SIMD a pass costs the latency of its dependent instructions,
 // and a cell past the selection would cost as much as a real one (it contributes +0.0 / a factor 1.0: leaving it out
 // gives the bitwise-same sums).
-constexpr int kGenomeLoci = 2048;
+constexpr int kGenomeLoci = 8192;                        // a block per genome: 32 cells per thread; a wave per genome: up to kGenomeWaveLoci
+constexpr int kGenomeWaveLoci = 2048;
 
 // A double moved between the lanes of a row of 16 by a DPP control (two v_mov_b32_dpp: a few cycles, where the
 // ds_bpermute pair behind __shfl_xor takes an LDS round trip -- and the passes here are nothing but such latencies).

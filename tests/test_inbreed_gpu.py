@@ -633,24 +633,27 @@ def test_paired_loglikelihood_search_is_the_single_search(kgx, monkeypatch):
 
 
 def test_window_iteration_kernel_at_its_cell_count_edges(kgx, monkeypatch):
-    """k_inbreed_iterate_genome<MODE, CELLS, THREADS> -- a block per genome (2 / 4 / 8 loci per thread) and a wave per
+    """k_inbreed_iterate_genome<MODE, CELLS, THREADS> -- a block per genome (2 .. 32 loci per thread) and a wave per
     genome (8 / 16 / 32) -- at the selection sizes where the host switches instantiation, and one past the largest, where
-    the multi-kernel passes take over -- against those passes on the same selections of the C5 population: the counts bit
+    the multi-kernel passes (HallME: the moments) take over -- against those passes on the same selections of the C5 population: the counts bit
     for bit, HallME to 1e-12 (only the order of the sums differs), Loglikelihood to 2e-6 on genomes with F >= 0 (one
     optimiser, one start, simplex of 1e-6)."""
-    G, L = 300, 4096
+    G, L = 300, 9000
     m = kgx.GenotypeMatrix(G, L)
     table = m.synth_multiallelic(1111, 0, 0)
     f_true = ((np.arange(G) % 101) - 50) / 100.0
     rng = np.random.default_rng(99)
-    for n_sel in (1, 255, 256, 257, 511, 512, 513, 1023, 1024, 1025, 2047, 2048, 2049):
+    # (past 2048 loci a wave's lane would hold more than 32 cells: a block per genome whatever the genome count, to 8192)
+    for n_sel in (1, 255, 256, 257, 511, 512, 513, 1023, 1024, 1025, 2047, 2048, 2049, 4095, 4096, 4097, 8191, 8192, 8193):
         index = np.sort(rng.choice(L, n_sel, replace=False)).astype(np.uint32)
         sub = np.ascontiguousarray(table[index])
         for algorithm in ("HallME", "Loglikelihood"):
             start = kgx.reference_starts(algorithm, START_SEED, G)
             monkeypatch.setenv("KGX_K7_NO_WAVE", "1")
+            monkeypatch.setenv("KGX_K7_HALL_PASSES", "1")       # (HallME: the 50 table passes themselves)
             passes = {k: v.copy() for k, v in _fields(m.inbreed(sub, algorithm, phased=True, locus_index=index, start=start)).items()}
             monkeypatch.delenv("KGX_K7_NO_WAVE")
+            monkeypatch.delenv("KGX_K7_HALL_PASSES")
             for wave_from in ("1", "1000000"):              # a wave per genome / a block per genome
                 monkeypatch.setenv("KGX_K7_WAVE_GENOMES", wave_from)
                 fused = _fields(m.inbreed(sub, algorithm, phased=True, locus_index=index, start=start))
