@@ -148,9 +148,20 @@ int inbreed_shard(kgx_gt8_shard& sh, uint64_t g0, uint64_t g1, const uint32_t* l
   const size_t o_segcnt = plan.add(table_sweep ? max_seg * n * sizeof(unsigned long long) : sizeof(unsigned long long));
   // HallME over a large call: per-genome moments of the homozygous cells' frequencies instead of 50 passes (kgx_kernels_hall.h)
   // (any amax: the class passes compare bytes, no table; the generic / no-table flavours keep the passes they are there to test)
-  const bool hall_moments = algorithm == KGX_ALGO_HALL_ME && n_sel > 0 && n_sel < (1ull << 31) && !wave_sized &&
+  const bool hall_candidate = algorithm == KGX_ALGO_HALL_ME && n_sel > 0 && n_sel < (1ull << 31) && !wave_sized &&
                             !env_int("KGX_K5_GENERIC", 0) && !env_int("KGX_K5_NO_EVAL_LUT", 0) &&
                             !env_int("KGX_K7_HALL_PASSES", 0);                 // (the radix sort counts its items in an int)
+  bool hall_moments = hall_candidate;
+  if (hall_moments) {
+    // the moments' buffers (40 B per item and genome, 100 KB of bins per genome) must leave the device room to breathe:
+    // past half of what is free (counting the arena this call may regrow) the 50 passes, which need none of it, are made
+    const uint64_t items = n_sel / kHallItemLoci + kHallBins + 1;
+    const uint64_t extra = items * kHallMoments * n * sizeof(double) + static_cast<uint64_t>(kHallBins) * kHallMoments * n * sizeof(double) +
+                           n_sel * (4 * sizeof(uint32_t) + sizeof(HallRecord));
+    size_t free_bytes = 0, total_bytes = 0;
+    if (hipMemGetInfo(&free_bytes, &total_bytes) != hipSuccess) { (void)hipGetLastError(); free_bytes = 0; }
+    if (extra > (static_cast<uint64_t>(free_bytes) + dev.scratch_bytes) / 2) hall_moments = false;
+  }
   const uint64_t hall_items = hall_moments ? n_sel / kHallItemLoci + kHallBins + 1 : 0;
   size_t hall_sort_bytes = 0;
   if (hall_moments) {
