@@ -1,4 +1,4 @@
-// HallME over a large call without 50 passes over the genotype bytes (kgx_inbreed.hip: hall_by_moments).
+// HallME over a large call without 50 passes over the genotype bytes (driven from kgx_inbreed.hip: inbreed_shard, `hall_moments`).
 //
 // processHallME's step (_calc.cpp:255-285) is  F <- F * S(F) / N  with  S(F) = sum over the genome's homozygous cells of
 // 1 / (F + (1-F)*y),  y = the frequency of the cell's allele at its locus (classify_cell: f1).  The cells enter S only
