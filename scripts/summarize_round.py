@@ -73,8 +73,25 @@ for label, needle, roof, workload in kernels:
     traffic_db[f"{label}:{workload}"] = {"kernel": name, "hbm_bytes_per_launch": traffic, "read_bytes": read_b, "write_bytes": write_b,
                                          "algorithmic_bytes_per_launch": alg, "profile": f"profiles/{tag}_pmc.csv",
                                          "correction": "read = 2 x FETCH_SIZE x 1024 (gfx950 wide-stream correction), write = WRITE_SIZE x 1024"}
+# the moment passes of HallME in the same run (aux.c5_simple.hallme): the full classes (every locus) alone
+hall_f = [v for k, vs in fetch.items() if "k_hall_sweep" in k for v in vs]
+hall_w = [v for k, vs in write.items() if "k_hall_sweep" in k for v in vs]
+hall_note = []
+if hall_f and hall_w:
+    hall_f = [v for v in hall_f if v > 0.9 * max(hall_f)]
+    hall_w = [v for v in hall_w if v > 0.9 * max(hall_w)]
+    hall_name = max((k for k in stats if "k_hall_sweep" in k), key=lambda k: float(stats[k]["TotalDurationNs"]), default="k_hall_sweep")
+    pmc_rows += [f"{hall_name} (full classes),FETCH_SIZE,{len(hall_f)},{sum(hall_f) / len(hall_f)}",
+                 f"{hall_name} (full classes),WRITE_SIZE,{len(hall_w)},{sum(hall_w) / len(hall_w)}"]
+    c5 = aux.get("c5_simple", {}).get("roofline", {}).get("algorithmic_bytes_per_launch")
+    if c5:
+        hall_note = ["", f"`{hall_name}` (HallME's moment pass, the two classes that cover every locus): HBM read 2 x FETCH_SIZE x 1024 = "
+                         f"{2.0 * sum(hall_f) / len(hall_f) * 1024.0:,.0f} B, write {sum(hall_w) / len(hall_w) * 1024.0:,.0f} B (the items' moments) "
+                         f"against {c5:,} algorithmic bytes of genotype rows: "
+                         f"{(2.0 * sum(hall_f) / len(hall_f) + sum(hall_w) / len(hall_w)) * 1024.0 / c5:.3f} x."]
 (dst / f"{tag}_pmc.csv").write_text("\n".join(pmc_rows) + "\n")
 traffic_db_path.write_text(json.dumps(traffic_db, indent=1) + "\n")
+lines += hall_note
 lines += ["", f"bench.py line of the traced run: value {bench['value']:.4g} {bench['unit']}, {bench['ms_per_step']:.3f} ms/step.",
           f"Full kernel table: `profiles/{tag}_kernel_stats.csv`; counter means: `profiles/{tag}_pmc.csv`.", ""]
 
