@@ -173,9 +173,9 @@ k_hall_sweep(const uint32_t* __restrict__ gt, uint64_t dwords_per_row, uint64_t 
 #pragma unroll
     for (int j = 0; j < GPL; ++j) {
       const bool hit = ((w[j / 4] >> (8 * (j % 4))) & 0xFFu) == match;
-      // adds under the lanes' mask, not multiplications by 0 / 1: the socket sits on its power cap during these passes
-      // (profiles/r03_power_cap.md), and an instruction costs what its ACTIVE lanes cost -- the alt classes' cells are few
-      // (measured at C5: the major class 11.3 -> 10.6 ms, alt 1 11.8 -> 9.8 ms)
+      // adds under the lanes' mask, not multiplications by 0 / 1: an instruction costs what its ACTIVE lanes cost, and the
+      // alt classes' cells are few (measured at C5: the major class 11.3 -> 10.6 ms, alt 1 11.8 -> 9.8 ms; the call then runs
+      // at ~1060 W and 2.28 GHz, under the 1400 W cap the table passes sit on: profiles/r03_power_cap.md)
       if (hit) {
         count[j] += 1u;
         m1[j] += d1;
