@@ -109,10 +109,20 @@ lines += ["## The table passes at C5 (10 k genomes x 5 M loci, 50.12 GB algorith
           "| kernel | calls | avg ms | TB/s at 50.12 GB | VALU wave-instr / launch | VALU per cell (x64 lanes / 5e10 cells) | SALU / launch | LDS instr / launch | LDS bank-conflict cycles | wait-inst / wave cycles |",
           "|---|---|---|---|---|---|---|---|---|---|"]
 for name in sorted(k7, key=lambda k: -float(k7[k]["TotalDurationNs"])):
-    if "k_inbreed_eval_lut" not in name and "swar" not in name:
+    if "k_inbreed_eval_lut" not in name and "swar" not in name and "k_hall_sweep" not in name:
         continue
     avg_ms = float(k7[name]["AverageNs"]) / 1e6
     c = {k: sum(v) / len(v) for k, v in sq.get(name, {}).items()}
+    if "k_hall_sweep" in name:
+        # HallME's moment passes: the classes that cover every locus alone (the largest launches), not the average over all four
+        full = {k: [x for x in v if x >= 0.9 * max(v)] for k, v in sq.get(name, {}).items() if v}
+        c = {k: sum(v) / len(v) for k, v in full.items()}
+        name_shown = name + " (full classes: counters; avg ms over all four classes)"
+        valu = c.get("SQ_INSTS_VALU", float("nan"))
+        lines.append(f"| `{name_shown}` | {k7[name]['Calls']} | {avg_ms:.3f} | - | {valu:.4g} | {valu * 64 / cells:.2f} | {c.get('SQ_INSTS_SALU', float('nan')):.4g} | "
+                     f"{c.get('SQ_INSTS_LDS', float('nan')):.4g} | {c.get('SQ_LDS_BANK_CONFLICT', float('nan')):.4g} | "
+                     f"{c.get('SQ_WAIT_INST_ANY', float('nan')) / c.get('SQ_WAVE_CYCLES', float('nan')):.2f} |")
+        continue
     valu = c.get("SQ_INSTS_VALU", float("nan"))
     lines.append(f"| `{name}` | {k7[name]['Calls']} | {avg_ms:.3f} | {50.1208 / avg_ms:.2f} | {valu:.4g} | {valu * 64 / cells:.2f} | {c.get('SQ_INSTS_SALU', float('nan')):.4g} | "
                  f"{c.get('SQ_INSTS_LDS', float('nan')):.4g} | {c.get('SQ_LDS_BANK_CONFLICT', float('nan')):.4g} | "
