@@ -326,8 +326,26 @@ double kgx_inbreed_last_sweep_ms(void);
 /* ... and of the one kernel inside it that reads the genotype bytes (k_inbreed_eval_lut<3|4>, or the SWAR / generic
  * sweep): the sweep without the per-locus helper kernels (tables, entries, segment defaults). */
 double kgx_inbreed_last_kernel_ms(void);
-/* Objective evaluations (= passes over the genotype bytes) the most recent KGX_ALGO_LOGLIKELIHOOD call needed. */
+/* Objective evaluations the most recent KGX_ALGO_LOGLIKELIHOOD call needed (the most any genome made; where the call
+ * made passes over the genotype bytes, the passes). */
 int kgx_inbreed_last_evaluations(void);
+/* What the most recent successful kgx_inbreed call ran on -- so that a test of one path cannot quietly exercise another. */
+#define KGX_PATH_NONE                       0
+#define KGX_PATH_FREQUENCY_SWEEP            1   /* Simple, RitlandLocus: the one sweep every estimator starts with            */
+#define KGX_PATH_ONE_LAUNCH                 2   /* HallME / Loglikelihood, <= 8192 loci: the whole iteration in one launch     */
+#define KGX_PATH_HALL_MOMENTS               3   /* HallME on per-genome moments (one pass per class of homozygous cell)        */
+#define KGX_PATH_HALL_PASSES                4   /* HallME by 50 passes over the bytes                                          */
+#define KGX_PATH_LOGLIK_MOMENTS             5   /* Loglikelihood on the same moments + the exact walk next to the floor        */
+#define KGX_PATH_LOGLIK_MOMENTS_AND_PASSES  6   /* ... and passes for the genomes the statistics could not serve               */
+#define KGX_PATH_LOGLIK_PASSES              7   /* Loglikelihood by passes over the bytes (two evaluations per pass)           */
+int kgx_inbreed_last_path(void);
+/* A diagnostic (tests, scripts): the log-likelihood logLikelihood(F) (kga_analysis_inbreed_calc.cpp:94-129) of genomes
+ * [g0,g1) at the points at[g1-g0] (each in [-1, 1]) over the selection kgx_inbreed would be given -- by_passes == 0: from the
+ * per-genome moments and the exact walk next to the floor, as a large Loglikelihood call evaluates it (KGX_ESTATE when
+ * such a call would not run on them; NaN for a genome it would hand to the passes); by_passes != 0: by one table pass over
+ * the genotype bytes.  value[g1-g0] (host). */
+int kgx_inbreed_objective(kgx_gt8* gt, uint64_t g0, uint64_t g1, const uint32_t* locus_index, uint64_t n_selected,
+                          const double* minor_af, uint32_t amax, int phased, const double* at, int by_passes, double* value);
 
 /* Synthetic multi-allelic SNP+indel population (BASELINE.json configs[4]) written straight into
  * the matrix: 1/2/3 alts (70/20/10 %), 15 % of alts are indels, AFs rescaled to sum <= 0.6, genotypes drawn from

@@ -87,6 +87,9 @@ _SIGNATURES = {
     "kgx_inbreed_last_sweep_ms": (C.c_double, []),
     "kgx_inbreed_last_kernel_ms": (C.c_double, []),
     "kgx_inbreed_last_evaluations": (C.c_int, []),
+    "kgx_inbreed_last_path": (C.c_int, []),
+    "kgx_inbreed_objective": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint32, C.c_int,
+                                        C.c_void_p, C.c_int, C.c_void_p]),
     "kgx_gt8_synth_multiallelic": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64, C.c_void_p]),
     "kgx_synth_multiallelic_host": (C.c_int, [C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64, C.c_void_p, C.c_uint64,
                                               C.c_void_p, C.c_void_p]),
@@ -556,6 +559,22 @@ class GenotypeMatrix:
                                 ALGORITHMS[algorithm], None if st is None else ptr(st), ptr(out)))
         return out
 
+    def inbreed_objective(self, minor_af: np.ndarray, at, phased: bool, locus_index=None, g0: int = 0, g1: int | None = None,
+                          by_passes: bool = False) -> np.ndarray:
+        """The log-likelihood of each genome of the range at its point at[g] (kgx_inbreed_objective: a diagnostic) -- from the
+        moments a large Loglikelihood call runs on, or (by_passes) from one table pass over the genotype bytes."""
+        g1 = self.n_genomes if g1 is None else g1
+        points = np.ascontiguousarray(at, dtype=np.float64)
+        if points.shape != (g1 - g0,):
+            raise ValueError("at must hold one value per genome of the range")
+        a = np.ascontiguousarray(minor_af, dtype=np.float64)
+        n_sel, amax = a.shape
+        idx = None if locus_index is None else np.ascontiguousarray(locus_index, dtype=np.uint32)
+        out = np.zeros(g1 - g0, dtype=np.float64)
+        check(lib().kgx_inbreed_objective(self._h, g0, g1, None if idx is None else ptr(idx), n_sel, ptr(a), amax, int(bool(phased)),
+                                          ptr(points), int(bool(by_passes)), ptr(out)))
+        return out
+
     def inbreed_resident(self, minor_af_dev: int, n_selected: int, amax: int, algorithm: str, phased: bool, g0: int = 0, g1: int | None = None,
                          start=None):
         """inbreed() with the allele-frequency table already on this device: minor_af_dev is the device address of
@@ -589,6 +608,15 @@ def inbreed_last_kernel_ms() -> float:
 def inbreed_last_sweep_ms() -> float:
     """Device time of the frequency sweep of the most recent GenotypeMatrix.inbreed call (HIP events)."""
     return float(lib().kgx_inbreed_last_sweep_ms())
+
+
+PATHS = {0: "none", 1: "frequency sweep", 2: "one launch", 3: "hall moments", 4: "hall passes", 5: "loglik moments",
+         6: "loglik moments + passes", 7: "loglik passes"}
+
+
+def inbreed_last_path() -> str:
+    """What the most recent inbreed call ran on (kgx.h: KGX_PATH_*)."""
+    return PATHS[int(lib().kgx_inbreed_last_path())]
 
 
 def inbreed_last_evaluations() -> int:

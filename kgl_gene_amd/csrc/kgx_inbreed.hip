@@ -16,6 +16,7 @@
 
 #include "kgx_kernels_inbreed.h"
 #include "kgx_kernels_hall.h"
+#include "kgx_kernels_loglik.h"
 #include <hipcub/hipcub.hpp>
 #include "kgx_internal.h"
 
@@ -44,8 +45,11 @@ void destroy_shards(kgx_gt8* h) {
 
 // kgx_inbreed for the genomes [g0, g1) of ONE shard (shard-local indices, g0 a multiple of 4); arguments checked by the caller.
 // start: host [g1 - g0] start points of the iterative estimators, or null (the midpoints of the reference's start intervals).
+// objective_method != 0 (kgx_inbreed_objective, a diagnostic): no search -- objective_out[g] = the log-likelihood of genome g at
+// start[g], from the moments (1) or from a table pass (2); `out` is not written.
 int inbreed_shard(kgx_gt8_shard& sh, uint64_t g0, uint64_t g1, const uint32_t* locus_index, uint64_t n_sel, const double* minor_af,
-                  uint32_t amax, int phased, int algorithm, const double* start, kgx_locus_results* out) {
+                  uint32_t amax, int phased, int algorithm, const double* start, kgx_locus_results* out, int objective_method = 0,
+                  double* objective_out = nullptr) {
   Device& dev = *sh.dev;
   std::lock_guard<std::mutex> device_lock(dev.mutex);          // the arena, the compaction buffers and the timing events are the device's
   if (int rc = use_device(dev)) return rc;
@@ -133,7 +137,7 @@ int inbreed_shard(kgx_gt8_shard& sh, uint64_t g0, uint64_t g1, const uint32_t* l
   const size_t o_eval = plan.add(2 * n * sizeof(double)), o_out = plan.add(n * sizeof(LocusResultsDev));
   const size_t o_golden = plan.add(n * sizeof(GoldenState));
   const size_t o_brent = plan.add(n * sizeof(BrentState));
-  const size_t o_start = plan.add(n * sizeof(double));
+  const size_t o_start = plan.add(n * sizeof(double)), o_keep = plan.add(n * sizeof(double));
   // The class-frequency sums of the defaults in the reference's own (sequential) summation order (k_seq_* kernels): from
   // the size at which a tree reduction and a sequential sum part by more than a tenth of the tolerance.
   const bool swar_family = table_sweep || (!env_int("KGX_K5_GENERIC", 0) && amax <= 4 && !ritland);
@@ -142,43 +146,66 @@ int inbreed_shard(kgx_gt8_shard& sh, uint64_t g0, uint64_t g1, const uint32_t* l
   const size_t o_seq_sum = plan.add(n_seq_blocks * 4 * sizeof(double)), o_seq_e = plan.add(n_seq_blocks * 4 * sizeof(int));
   const size_t o_seq_n = plan.add(n_seq_blocks * 4 * sizeof(long long)), o_seq_out = plan.add(kParts0 * sizeof(double));
   // The table passes' entries (k_eval_entries): 64 / 256 / 1024 bytes per selected locus, only where such a pass will run.
-  const bool wave_sized = n_sel > 0 && n_sel <= static_cast<uint64_t>(kGenomeLoci) && !env_int("KGX_K7_NO_WAVE", 0);
+  const bool wave_sized = n_sel > 0 && n_sel <= static_cast<uint64_t>(kGenomeLoci) && !env_int("KGX_K7_NO_WAVE", 0) && objective_method == 0;
   const bool table_passes = n_sel > 0 && (table_sweep || (eval_lut && (algorithm == 2 || algorithm == 3) && !wave_sized));
   const size_t o_entries = plan.add(table_passes ? (n_sel << (2u * eval_bits(amax))) * sizeof(EvalEntry) : 0);
   const size_t o_segcnt = plan.add(table_sweep ? max_seg * n * sizeof(unsigned long long) : sizeof(unsigned long long));
-  // HallME over a large call: per-genome moments of the homozygous cells' frequencies instead of 50 passes (kgx_kernels_hall.h)
-  // (any amax: the class passes compare bytes, no table; the generic / no-table flavours keep the passes they are there to test)
-  const bool hall_candidate = algorithm == KGX_ALGO_HALL_ME && n_sel > 0 && n_sel < (1ull << 31) && !wave_sized &&
-                            !env_int("KGX_K5_GENERIC", 0) && !env_int("KGX_K5_NO_EVAL_LUT", 0) &&
-                            !env_int("KGX_K7_HALL_PASSES", 0);                 // (the radix sort counts its items in an int)
-  bool hall_moments = hall_candidate;
-  if (hall_moments) {
-    // the moments' buffers (40 B per item and genome, 100 KB of bins per genome) must leave the device room to breathe:
-    // past half of what is free (counting the arena this call may regrow) the 50 passes, which need none of it, are made
-    const uint64_t items = n_sel / kHallItemLoci + kHallBins + 1;
-    const uint64_t extra = items * kHallMoments * n * sizeof(double) + static_cast<uint64_t>(kHallBins) * kHallMoments * n * sizeof(double) +
-                           n_sel * (4 * sizeof(uint32_t) + sizeof(HallRecord));
+  // HallME and Loglikelihood over a large call: per-genome moments of the homozygous cells' frequencies instead of 50 / 38
+  // passes (kgx_kernels_hall.h, kgx_kernels_loglik.h)
+  // (any amax for HallME: the class passes compare bytes, no table; the generic / no-table flavours keep the passes they are there to test)
+  const bool no_tables = env_int("KGX_K5_GENERIC", 0) || env_int("KGX_K5_NO_EVAL_LUT", 0);
+  const char* search_name = std::getenv("KGX_K7_SEARCH");
+  const int search = search_name && std::strcmp(search_name, "brent") == 0 ? kSearchBrent : kSearchNelderMead;
+  const bool hall_candidate = algorithm == KGX_ALGO_HALL_ME && n_sel > 0 && n_sel < (1ull << 31) && !wave_sized && !no_tables &&
+                              !env_int("KGX_K7_HALL_PASSES", 0);                 // (the radix sort counts its items in an int)
+  // Loglikelihood: the reference optimiser's path alone, a phased population (unphased: every alt homozygote is a heterozygous
+  // cell that can meet the upper bound -- every genome would be handed to the passes), the frequency sweep as a table pass
+  // (it carries the heterozygous cells' term), positions in 28 bits
+  const bool loglik_candidate = algorithm == KGX_ALGO_LOGLIKELIHOOD && n_sel > 0 && n_sel < (1ull << 28) && !wave_sized && !no_tables &&
+                                table_sweep && phased && (g0 & 7u) == 0 && search == kSearchNelderMead && !env_int("KGX_K7_GOLDEN", 0) &&
+                                !env_int("KGX_K7_ESTIMATE_START", 0) && !env_int("KGX_K7_LL_PASSES", 0);
+  const uint32_t hall_classes = 1u + (phased ? amax : 0u);                  // byte 0x00, and a | a << 4 of a phased population (classify_cell)
+  const uint64_t hall_items = (hall_candidate || loglik_candidate) ? n_sel / kHallItemLoci + kHallBins + 1 : 0;    // per class, at most
+  const uint64_t hall_blocks = (hall_candidate || loglik_candidate) ? n_sel / kHallBlockLoci + hall_items : 0;      // per class, at most: blocks of 64 slots
+  const uint64_t words_per_block = (n + 7) / 8 * 8;                          // one word per genome, whole lanes of 8
+  bool hall_moments = hall_candidate, loglik_moments = loglik_candidate;
+  if (hall_moments || loglik_moments) {
+    // the moments' buffers (40 B per item and genome, 100 KB of bins per genome; Loglikelihood: a bit per homozygous-capable
+    // cell of the bins its floor can reach) must leave the device room to breathe: past half of what is free (counting what
+    // this call may regrow) the passes, which need none of it, are made
+    const uint64_t extra = hall_items * kHallMoments * n * sizeof(double) + static_cast<uint64_t>(kHallBins) * kHallMoments * n * sizeof(double) +
+                           hall_classes * (hall_blocks + 1) * kHallBlockLoci * sizeof(HallRecord) + n_sel * (sizeof(HallRecord) + 4 * sizeof(uint32_t)) +
+                           (loglik_candidate ? hall_classes * hall_blocks * words_per_block * sizeof(unsigned long long) : 0);
     size_t free_bytes = 0, total_bytes = 0;
     if (hipMemGetInfo(&free_bytes, &total_bytes) != hipSuccess) { (void)hipGetLastError(); free_bytes = 0; }
-    if (extra > (static_cast<uint64_t>(free_bytes) + dev.scratch_bytes) / 2) hall_moments = false;
+    if (extra + plan.total > (static_cast<uint64_t>(free_bytes) + dev.scratch_bytes + dev.words_bytes) / 2) hall_moments = loglik_moments = false;
   }
-  const uint64_t hall_items = hall_moments ? n_sel / kHallItemLoci + kHallBins + 1 : 0;
+  const bool by_moments_planned = hall_moments || loglik_moments;
   size_t hall_sort_bytes = 0;
-  if (hall_moments) {
+  if (by_moments_planned) {
     // (a size query: no device work)
     if (hipcub::DeviceRadixSort::SortPairs(nullptr, hall_sort_bytes, static_cast<const uint32_t*>(nullptr), static_cast<uint32_t*>(nullptr),
                                            static_cast<const uint32_t*>(nullptr), static_cast<uint32_t*>(nullptr), static_cast<int>(n_sel), 0, 12,
                                            dev.stream) != hipSuccess)
       return fail(KGX_EHIP, "kgx_inbreed: radix sort size query failed");
   }
-  const size_t o_hall_keys = plan.add(hall_moments ? 4 * n_sel * sizeof(uint32_t) : 0);            // keys, slots, sorted keys, sorted slots
-  const size_t o_hall_records = plan.add(hall_moments ? n_sel * sizeof(HallRecord) : 0);
-  // bin_begin | bin_end | item_base | bin_used | used | n_items, n_used, unsupported: small words, cleared together where needed
-  const size_t o_hall_words = plan.add(hall_moments ? (5 * (kHallBins + 1) + 4) * sizeof(uint32_t) : 0);
-  const size_t o_hall_items = plan.add(hall_items * sizeof(HallItem));
+  const uint64_t plan_classes = by_moments_planned ? hall_classes : 0, plan_items = by_moments_planned ? hall_items : 0;
+  const size_t o_hall_keys = plan.add(by_moments_planned ? 4 * n_sel * sizeof(uint32_t) : 0);            // keys, slots, sorted keys, sorted slots
+  const size_t o_hall_records = plan.add(by_moments_planned ? n_sel * sizeof(HallRecord) : 0);            // a class's loci in bin order, as sorted
+  const size_t o_hall_padded = plan.add(plan_classes * (hall_blocks + 1) * kHallBlockLoci * sizeof(HallRecord));   // per class: the same in blocks (+ a block of slack)
+  // per class: bin_begin | bin_end | item_base | bin_block (kHallBins + 1 words each); then, for all: bin_used | used; then the counters:
+  // per class n_items, n_blocks, n_blocks of the bins a band can reach, 0; for all n_used, unsupported, handed over, 0
+  constexpr size_t kHallClassWords = 4 * (kHallBins + 1);                   // (and bin_block: the first block of each bin)
+  const size_t hall_word_count = plan_classes * kHallClassWords + 2 * (kHallBins + 1) + (plan_classes + 1) * 4;
+  const size_t o_hall_words = plan.add(by_moments_planned ? hall_word_count * sizeof(uint32_t) : 0);
+  const size_t o_hall_items = plan.add(plan_classes * plan_items * sizeof(HallItem));
+  const size_t o_hall_item_blocks = plan.add(plan_classes * (plan_items + 1) * sizeof(uint32_t));
+  const size_t o_hall_ys = plan.add(loglik_moments ? plan_classes * (hall_blocks + 1) * kHallBlockLoci * sizeof(double) : 0);   // per class: every slot's frequency
   const size_t o_hall_sort = plan.add(hall_sort_bytes);
-  const size_t o_hall_moments = plan.add(hall_items * kHallMoments * n * sizeof(double));
-  const size_t o_hall_bins = plan.add(hall_moments ? static_cast<size_t>(kHallBins) * kHallMoments * n * sizeof(double) : 0);
+  const size_t o_hall_moments = plan.add(plan_items * kHallMoments * n * sizeof(double));
+  const size_t o_hall_bins = plan.add(by_moments_planned ? static_cast<size_t>(kHallBins) * kHallMoments * n * sizeof(double) : 0);
+  const size_t o_needs_passes = plan.add(loglik_moments ? n * sizeof(uint32_t) : 0);
+  const size_t o_smallest_het = plan.add(sizeof(unsigned long long));
   char* arena = nullptr;
   if (int arc = scratch_reserve(dev, plan.total, &arena)) return arc;
   d_af = reinterpret_cast<double*>(arena + o_af);
@@ -201,6 +228,7 @@ int inbreed_shard(kgx_gt8_shard& sh, uint64_t g0, uint64_t g1, const uint32_t* l
   long long* d_seq_n = reinterpret_cast<long long*>(arena + o_seq_n);
   double* d_seq_out = reinterpret_cast<double*>(arena + o_seq_out);
   EvalEntry* d_entries = reinterpret_cast<EvalEntry*>(arena + o_entries);
+  unsigned long long* d_smallest_het = reinterpret_cast<unsigned long long*>(arena + o_smallest_het);
   unsigned long long* d_segcnt = reinterpret_cast<unsigned long long*>(arena + o_segcnt);
   // (the per-locus bit masks are the SWAR sweeps' alone: k_locus_bits)
   if (!table_sweep) try_hip(hipMemsetAsync(d_meta, 0, (n_tab + 8) * sizeof(uint32_t), dev.stream), KGX_EHIP, "memset(meta)");
@@ -260,10 +288,11 @@ int inbreed_shard(kgx_gt8_shard& sh, uint64_t g0, uint64_t g1, const uint32_t* l
   auto tabulate = [&](int mode) {
     if (!table_passes) return;
     const uint32_t tab_grid = stream_grid(dev, n_sel << (2u * eval_bits(amax)), kBlock);
-    if (mode == 1) hipLaunchKernelGGL((k_eval_entries<1>), dim3(tab_grid), dim3(kBlock), 0, dev.stream, d_table, d_valid, n_sel, amax, phased, d_entries);
-    else if (mode == 2) hipLaunchKernelGGL((k_eval_entries<2>), dim3(tab_grid), dim3(kBlock), 0, dev.stream, d_table, d_valid, n_sel, amax, phased, d_entries);
-    else if (mode == 3) hipLaunchKernelGGL((k_eval_entries<3>), dim3(tab_grid), dim3(kBlock), 0, dev.stream, d_table, d_valid, n_sel, amax, phased, d_entries);
-    else hipLaunchKernelGGL((k_eval_entries<4>), dim3(tab_grid), dim3(kBlock), 0, dev.stream, d_table, d_valid, n_sel, amax, phased, d_entries);
+    if (mode == 1) hipLaunchKernelGGL((k_eval_entries<1>), dim3(tab_grid), dim3(kBlock), 0, dev.stream, d_table, d_valid, n_sel, amax, phased, d_entries, nullptr);
+    else if (mode == 2) hipLaunchKernelGGL((k_eval_entries<2>), dim3(tab_grid), dim3(kBlock), 0, dev.stream, d_table, d_valid, n_sel, amax, phased, d_entries, nullptr);
+    else if (mode == 3) hipLaunchKernelGGL((k_eval_entries<3>), dim3(tab_grid), dim3(kBlock), 0, dev.stream, d_table, d_valid, n_sel, amax, phased, d_entries, nullptr);
+    else if (mode == 5) hipLaunchKernelGGL((k_eval_entries<5>), dim3(tab_grid), dim3(kBlock), 0, dev.stream, d_table, d_valid, n_sel, amax, phased, d_entries, d_smallest_het);
+    else hipLaunchKernelGGL((k_eval_entries<4>), dim3(tab_grid), dim3(kBlock), 0, dev.stream, d_table, d_valid, n_sel, amax, phased, d_entries, nullptr);
   };
   bool ll_pair = false;                                       // Loglikelihood passes with two values of F per genome (set by its driver below)
   auto sweep = [&](int mode) {
@@ -357,9 +386,14 @@ int inbreed_shard(kgx_gt8_shard& sh, uint64_t g0, uint64_t g1, const uint32_t* l
     if (timed && !table_sweep && rc == KGX_OK) try_hip(hipEventRecord(dev.kernel_begin, st), KGX_EHIP, "hipEventRecord");
     sweep(0);
     if (table_sweep) {
-      tabulate(ritland ? 3 : 4);
+      // (Loglikelihood by moments: the same pass as RitlandLocus', its fp64 term the heterozygous cells' log 2*f1*f2 -- k_eval_entries<5>)
+      if (loglik_moments) {
+        static const double one = 1.0;                         // the smallest such product of the call, from 1 down
+        try_hip(hipMemcpyAsync(d_smallest_het, &one, sizeof(one), hipMemcpyHostToDevice, st), KGX_EHIP, "H2D(smallest het)");
+      }
+      tabulate(ritland ? 3 : loglik_moments ? 5 : 4);
       if (timed && rc == KGX_OK) try_hip(hipEventRecord(dev.kernel_begin, st), KGX_EHIP, "hipEventRecord");
-      sweep(ritland ? 3 : 4);
+      sweep(ritland || loglik_moments ? 3 : 4);
       if (timed && rc == KGX_OK) try_hip(hipEventRecord(dev.kernel_end, st), KGX_EHIP, "hipEventRecord");
       if (n_sel) {
         const uint32_t seg_rows = n_seg < 32 ? static_cast<uint32_t>(n_seg) : 32u;
@@ -372,22 +406,129 @@ int inbreed_shard(kgx_gt8_shard& sh, uint64_t g0, uint64_t g1, const uint32_t* l
     if (sequential_defaults && n_sel) try_hip(hipStreamWaitEvent(st, dev.side_end, 0), KGX_EHIP, "hipStreamWaitEvent");
     hipLaunchKernelGGL(k_reduce_parts, dim3(reduce_grid(n * kParts0)), dim3(kBlock), 0, st, d_part, n_seg, n * kParts0,
                        (sequential_defaults && n_sel) ? d_seq_out : nullptr, d_sums);
+    dev.last_path = KGX_PATH_FREQUENCY_SWEEP;   // (Simple, RitlandLocus: nothing more; the iterative estimators say below what ran)
     // Window-sized calls: the whole iteration in one launch, a block or a wave per genome (k_inbreed_iterate_genome).
     const bool wave_path = (algorithm == 2 || algorithm == 3) && wave_sized;
     bool wave_evaluations = false;
     // Loglikelihood's search: the reference optimiser's own path (Nelder-Mead, see nm_advance) unless KGX_K7_SEARCH=brent
-    const char* search_name = std::getenv("KGX_K7_SEARCH");
-    const int search = search_name && std::strcmp(search_name, "brent") == 0 ? kSearchBrent : kSearchNelderMead;
     // ... two evaluations per pass where a pass is a sweep over the matrix (the table passes): same path, half the passes
     const int pass_search = (search == kSearchNelderMead && eval_lut && !env_int("KGX_K7_NO_PAIR", 0)) ? kSearchNelderMeadPair : search;
     const uint64_t planes = pass_search == kSearchNelderMeadPair ? 2 : 1;
+    // The moments both estimators run on over a large call (kgx_kernels_hall.h): per class of homozygous cell the selected loci in
+    // bin order (keys, radix sort, records, items) -- first for every class, so that what the host must know comes back in ONE
+    // read before any pass over the bytes: a frequency without a bin (below 2^-20, above 1: `false`, the caller makes the
+    // passes instead and has lost a millisecond, not the class passes), the items of each class (the passes' grids) and, with
+    // `emit` (Loglikelihood), the blocks whose hits the passes leave as bits -- then one pass over the bytes per class and the
+    // merge of its items into the bins.
+    uint32_t* const h_words = reinterpret_cast<uint32_t*>(arena + o_hall_words);
+    uint32_t* const h_bin_used = h_words + plan_classes * kHallClassWords;
+    uint32_t* const h_used = h_bin_used + (kHallBins + 1);
+    uint32_t* const h_counters = h_used + (kHallBins + 1);                       // [class][4]: n_items, n_blocks; then n_used, unsupported, handed over
+    uint32_t* const h_totals = h_counters + plan_classes * 4;
+    double* const h_bins = reinterpret_cast<double*>(arena + o_hall_bins);
+    std::vector<uint32_t> class_items(plan_classes, 0u), class_blocks(plan_classes, 0u);
+    LoglikClasses loglik_classes{};
+    auto class_words = [&](uint32_t k) { return h_words + k * kHallClassWords; };
+    auto gather_moments = [&](bool emit) -> bool {
+      uint32_t* h_keys = reinterpret_cast<uint32_t*>(arena + o_hall_keys);
+      uint32_t *h_slots = h_keys + n_sel, *h_sorted_keys = h_keys + 2 * n_sel, *h_sorted_slots = h_keys + 3 * n_sel;
+      double* h_moments = reinterpret_cast<double*>(arena + o_hall_moments);
+      const uint32_t hall_chunks = static_cast<uint32_t>(((n + eval_gpl - 1) / eval_gpl + kBlock - 1) / kBlock);
+      // (a bin's workgroups: enough of them for the few bins that hold most loci -- the major allele's -- to fill the chip)
+      const uint32_t hall_merge_blocks = static_cast<uint32_t>(std::min<uint64_t>(64, (kHallMoments * n + kBlock - 1) / kBlock));
+      // the bins an exact walk can reach (kgx_kernels_loglik.h): those starting below kLoglikReach
+      const uint32_t block_bins = emit ? hall_key_host(kLoglikReach) + 1u : 0u;
+      HallRecord* const h_records = reinterpret_cast<HallRecord*>(arena + o_hall_records);
+      const size_t padded_records = static_cast<size_t>(hall_blocks + 1) * kHallBlockLoci;
+      auto padded_of = [&](uint32_t k) { return reinterpret_cast<HallRecord*>(arena + o_hall_padded) + static_cast<uint64_t>(k) * padded_records; };
+      auto ys_of = [&](uint32_t k) { return emit ? reinterpret_cast<double*>(arena + o_hall_ys) + static_cast<uint64_t>(k) * padded_records : nullptr; };
+      auto items_of = [&](uint32_t k) { return reinterpret_cast<HallItem*>(arena + o_hall_items) + static_cast<uint64_t>(k) * hall_items; };
+      auto item_blocks_of = [&](uint32_t k) { return reinterpret_cast<uint32_t*>(arena + o_hall_item_blocks) + static_cast<uint64_t>(k) * (hall_items + 1); };
+      try_hip(hipMemsetAsync(h_words, 0, hall_word_count * sizeof(uint32_t), st), KGX_EHIP, "memset(hall words)");
+      // (a pass reads up to two batches past an item's slots -- the next item's, or, behind the last one, this: row 0, matching nothing)
+      try_hip(hipMemsetAsync(arena + o_hall_padded, 0, hall_classes * padded_records * sizeof(HallRecord), st), KGX_EHIP, "memset(hall blocks)");
+      try_hip(hipMemsetAsync(h_bins, 0, static_cast<size_t>(kHallBins) * kHallMoments * n * sizeof(double), st), KGX_EHIP, "memset(hall bins)");
+      for (uint32_t k = 0; k < hall_classes && rc == KGX_OK; ++k) {
+        uint32_t *bin_begin = class_words(k), *bin_end = bin_begin + (kHallBins + 1), *item_base = bin_begin + 2 * (kHallBins + 1);
+        hipLaunchKernelGGL(k_hall_keys, dim3(stream_grid(dev, n_sel, kBlock)), dim3(kBlock), 0, st, d_table, d_valid, n_sel, amax, phased, k, h_keys,
+                           h_slots, h_totals + 1);
+        size_t sort_bytes = hall_sort_bytes;
+        try_hip(hipcub::DeviceRadixSort::SortPairs(arena + o_hall_sort, sort_bytes, h_keys, h_sorted_keys, h_slots, h_sorted_slots,
+                                                   static_cast<int>(n_sel), 0, 12, st), KGX_EHIP, "radix sort");
+        hipLaunchKernelGGL(k_hall_records, dim3(stream_grid(dev, n_sel, kBlock)), dim3(kBlock), 0, st, h_sorted_keys, h_sorted_slots, n_sel, d_table,
+                           amax, k, d_index, h_records, bin_begin, bin_end);
+        hipLaunchKernelGGL(k_hall_items, dim3(1), dim3(kBlock), 0, st, bin_begin, bin_end, item_base, items_of(k), h_counters + 4 * k, block_bins,
+                           item_blocks_of(k), h_counters + 4 * k + 1);
+        hipLaunchKernelGGL(k_hall_pad, dim3(static_cast<uint32_t>(std::min<uint64_t>(hall_items, 65535))), dim3(kBlock), 0, st, h_records, items_of(k),
+                           h_counters + 4 * k, item_blocks_of(k), padded_of(k), ys_of(k));
+        if (emit) hipLaunchKernelGGL(k_hall_bin_blocks, dim3((kHallBins + kBlock) / kBlock), dim3(kBlock), 0, st, item_base, item_blocks_of(k), item_base + (kHallBins + 1));
+        try_hip(hipGetLastError(), KGX_EHIP, "hall order launch");
+      }
+      std::vector<uint32_t> counters((hall_classes + 1) * 4, 0u);
+      try_hip(hipMemcpyAsync(counters.data(), h_counters, counters.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, st), KGX_EHIP, "D2H(hall counters)");
+      try_hip(hipStreamSynchronize(st), KGX_EHIP, "sync");
+      if (rc != KGX_OK || counters[hall_classes * 4 + 1] != 0u) return false;
+      uint64_t all_blocks = 0;
+      for (uint32_t k = 0; k < hall_classes; ++k) {
+        class_items[k] = counters[4 * k];
+        class_blocks[k] = counters[4 * k + 2];                                  // the blocks whose hits are kept
+        all_blocks += class_blocks[k];
+      }
+      unsigned long long* words = nullptr;
+      if (emit) {
+        // the hits' words: [block][genome], the classes' blocks one after the other; kept between calls like the arena
+        const size_t want = (all_blocks ? all_blocks : 1) * words_per_block * sizeof(unsigned long long);
+        if (dev.words_bytes < want) {
+          if (dev.words) (void)hipFree(dev.words);
+          dev.words = nullptr;
+          dev.words_bytes = 0;
+          size_t free_bytes = 0, total_bytes = 0;
+          if (hipMemGetInfo(&free_bytes, &total_bytes) != hipSuccess || free_bytes < want + (4ull << 30) || hipMalloc(&dev.words, want) != hipSuccess) {
+            (void)hipGetLastError();
+            dev.words = nullptr;
+            return false;                                                       // no room: the passes
+          }
+          dev.words_bytes = want;
+        }
+        words = reinterpret_cast<unsigned long long*>(dev.words);
+      }
+      uint64_t block_base = 0;
+      for (uint32_t k = 0; k < hall_classes && rc == KGX_OK; ++k) {
+        uint32_t* item_base = class_words(k) + 2 * (kHallBins + 1);
+        unsigned long long* class_out = emit ? words + block_base * words_per_block : nullptr;
+        if (emit) {
+          loglik_classes.of[k] = LoglikClass{ys_of(k), item_base + (kHallBins + 1), class_out};
+          block_base += class_blocks[k];
+        }
+        if (class_items[k] == 0u) continue;                                     // no locus has a homozygote of this class
+        const dim3 sweep_grid(class_items[k] * hall_chunks);
+        const uint32_t code = k | (k << 4);
+#define KGX_HALL_SWEEP(GPL, EMIT)                                                                                                      \
+  hipLaunchKernelGGL((k_hall_sweep<GPL, EMIT>), sweep_grid, dim3(kBlock), 0, st, gt32, dwords_per_row, g0, n, padded_of(k), items_of(k), \
+                     h_counters + 4 * k, hall_chunks, code, h_moments, item_blocks_of(k), block_bins, words_per_block, class_out)
+        if (eval_gpl == 8) { if (emit) KGX_HALL_SWEEP(8, true); else KGX_HALL_SWEEP(8, false); }
+        else KGX_HALL_SWEEP(4, false);                                          // (the hits' words are a lane of eight genomes': loglik_candidate)
+#undef KGX_HALL_SWEEP
+        hipLaunchKernelGGL(k_hall_merge, dim3(hall_merge_blocks, kHallBins), dim3(kBlock), 0, st, h_moments, item_base, n, h_bins, h_bin_used);
+        try_hip(hipGetLastError(), KGX_EHIP, "hall moments launch");
+      }
+      loglik_classes.n = emit ? hall_classes : 0u;
+      loglik_classes.block_bins = block_bins;
+      hipLaunchKernelGGL(k_hall_used_bins, dim3(1), dim3(kBlock), 0, st, h_bin_used, h_used, h_totals);
+      try_hip(hipGetLastError(), KGX_EHIP, "hall bins launch");
+      return rc == KGX_OK;
+    };
     if (wave_path) {
       // A block per genome while that leaves SIMDs idle or with a wave or two (latency-bound: four waves share a
       // genome's cells); a wave per genome from KGX_K7_WAVE_GENOMES genomes (throughput-bound: a block would repeat the
       // log, the search step and the reduction in all four waves).  Measured at 1000 loci (scripts/exp_window_threads.sh,
       // ms per call, block / wave): HallME 0.127 / 0.162 at 256 genomes, 0.144 / 0.154 at 512, 0.173 / 0.170 at 1024,
       // 0.335 / 0.259 at 2504; Loglikelihood 0.150 / 0.161, 0.170 / 0.157, 0.207 / 0.176, 0.315 / 0.231.
-      const bool per_wave = n_sel <= static_cast<uint64_t>(kGenomeWaveLoci) &&      // (a lane holds at most 32 cells)
+      // ... and only up to KGX_K7_WAVE_LOCI selected loci (default 1024: 16 cells per lane): with 32 cells per lane the
+      // kernel holds 218 registers -- two waves per SIMD, each walking 32 dependent cells per pass -- and a 2000-locus call
+      // took 2.7 ms at 2504 genomes where the block per genome takes 4 x the loci in a quarter of that.
+      const uint64_t wave_loci = static_cast<uint64_t>(std::min(kGenomeWaveLoci, std::max(1, env_int("KGX_K7_WAVE_LOCI", 1024))));
+      const bool per_wave = n_sel <= wave_loci &&
                             n >= static_cast<uint64_t>(std::max(1, env_int("KGX_K7_WAVE_GENOMES", algorithm == 2 ? 1024 : 512)));
       const uint32_t wave_grid = static_cast<uint32_t>(per_wave ? (n + kBlock / kWave - 1) / (kBlock / kWave) : n);
       const double* estimate = algorithm == 2 ? d_sums : env_int("KGX_K7_ESTIMATE_START", 0) ? d_sums : nullptr;
@@ -413,57 +554,21 @@ int inbreed_shard(kgx_gt8_shard& sh, uint64_t g0, uint64_t g1, const uint32_t* l
 #undef KGX_WAVE_CELLS
 #undef KGX_WAVE
       wave_evaluations = algorithm == 3;          // its count (d_running, cleared with the counts) comes back with the results
+      dev.last_path = KGX_PATH_ONE_LAUNCH;
     } else if (algorithm == 2) {
       // processHallME (_calc.cpp:225-307).  The reference restarts from U(0,0.5] and, through RetryCalcResult's
       // self-comparison (_calc.cpp:45-68), always stops after 5 restarts of exactly 50 expectation steps, keeping the
       // last: 50 steps from the start point handed in (the fifth draw, or 0.25 without one).
       bool by_moments = false;
-      if (hall_moments && rc == KGX_OK) {
+      if (hall_moments && rc == KGX_OK && gather_moments(false)) {
         // HallME on per-genome moments (kgx_kernels_hall.h): one pass over the bytes per class of homozygous cell, then
         // the 50 steps on ~10^3 numbers a genome.
-        uint32_t* h_keys = reinterpret_cast<uint32_t*>(arena + o_hall_keys);
-        uint32_t *h_slots = h_keys + n_sel, *h_sorted_keys = h_keys + 2 * n_sel, *h_sorted_slots = h_keys + 3 * n_sel;
-        HallRecord* h_records = reinterpret_cast<HallRecord*>(arena + o_hall_records);
-        uint32_t* h_bin_begin = reinterpret_cast<uint32_t*>(arena + o_hall_words);
-        uint32_t *h_bin_end = h_bin_begin + (kHallBins + 1), *h_item_base = h_bin_begin + 2 * (kHallBins + 1);
-        uint32_t *h_bin_used = h_bin_begin + 3 * (kHallBins + 1), *h_used = h_bin_begin + 4 * (kHallBins + 1);
-        uint32_t* h_counters = h_bin_begin + 5 * (kHallBins + 1);            // n_items, n_used, unsupported
-        HallItem* h_items = reinterpret_cast<HallItem*>(arena + o_hall_items);
-        double* h_moments = reinterpret_cast<double*>(arena + o_hall_moments);
-        double* h_bins = reinterpret_cast<double*>(arena + o_hall_bins);
-        const uint32_t classes = 1u + (phased ? amax : 0u);                   // byte 0x00, and a | a << 4 of a phased population (classify_cell)
-        const uint32_t hall_chunks = static_cast<uint32_t>(((n + eval_gpl - 1) / eval_gpl + kBlock - 1) / kBlock);
-        // (a bin's workgroups: enough of them for the few bins that hold most loci -- the major allele's -- to fill the chip)
-        const uint32_t hall_merge_blocks = static_cast<uint32_t>(std::min<uint64_t>(64, (kHallMoments * n + kBlock - 1) / kBlock));
-        try_hip(hipMemsetAsync(arena + o_hall_words, 0, (5 * (kHallBins + 1) + 4) * sizeof(uint32_t), st), KGX_EHIP, "memset(hall words)");
-        try_hip(hipMemsetAsync(h_bins, 0, static_cast<size_t>(kHallBins) * kHallMoments * n * sizeof(double), st), KGX_EHIP, "memset(hall bins)");
-        for (uint32_t k = 0; k < classes && rc == KGX_OK; ++k) {
-          if (k) try_hip(hipMemsetAsync(h_bin_begin, 0, 2 * (kHallBins + 1) * sizeof(uint32_t), st), KGX_EHIP, "memset(hall stretches)");
-          hipLaunchKernelGGL(k_hall_keys, dim3(stream_grid(dev, n_sel, kBlock)), dim3(kBlock), 0, st, d_table, d_valid, n_sel, amax, phased, k, h_keys,
-                             h_slots, h_counters + 2);
-          size_t sort_bytes = hall_sort_bytes;
-          try_hip(hipcub::DeviceRadixSort::SortPairs(arena + o_hall_sort, sort_bytes, h_keys, h_sorted_keys, h_slots, h_sorted_slots,
-                                                     static_cast<int>(n_sel), 0, 12, st), KGX_EHIP, "radix sort");
-          hipLaunchKernelGGL(k_hall_records, dim3(stream_grid(dev, n_sel, kBlock)), dim3(kBlock), 0, st, h_sorted_keys, h_sorted_slots, n_sel, d_table,
-                             amax, k, d_index, h_records, h_bin_begin, h_bin_end);
-          hipLaunchKernelGGL(k_hall_items, dim3(1), dim3(kBlock), 0, st, h_bin_begin, h_bin_end, h_item_base, h_items, h_counters);
-          const dim3 sweep_grid(static_cast<uint32_t>(hall_items * hall_chunks));
-          const uint32_t code = k | (k << 4);
-          if (eval_gpl == 8)
-            hipLaunchKernelGGL((k_hall_sweep<8>), sweep_grid, dim3(kBlock), 0, st, gt32, dwords_per_row, g0, n, h_records, h_items, h_counters, hall_chunks, code, h_moments);
-          else
-            hipLaunchKernelGGL((k_hall_sweep<4>), sweep_grid, dim3(kBlock), 0, st, gt32, dwords_per_row, g0, n, h_records, h_items, h_counters, hall_chunks, code, h_moments);
-          hipLaunchKernelGGL(k_hall_merge, dim3(hall_merge_blocks, kHallBins), dim3(kBlock), 0, st, h_moments, h_item_base, n, h_bins, h_bin_used);
-          try_hip(hipGetLastError(), KGX_EHIP, "hall moments launch");
-        }
-        hipLaunchKernelGGL(k_hall_used_bins, dim3(1), dim3(kBlock), 0, st, h_bin_used, h_used, h_counters + 1);
-        hipLaunchKernelGGL(k_hall_iterate, dim3(static_cast<uint32_t>(n)), dim3(kBlock), 0, st, h_bins, h_used, h_counters + 1, d_counts, n, d_start, d_f);
+        hipLaunchKernelGGL(k_hall_iterate, dim3(static_cast<uint32_t>(n)), dim3(kBlock), 0, st, h_bins, h_used, h_totals, d_counts, n, d_start, d_f);
         try_hip(hipGetLastError(), KGX_EHIP, "hall iterate launch");
-        uint32_t unsupported = 0;
-        try_hip(hipMemcpyAsync(&unsupported, h_counters + 2, sizeof(uint32_t), hipMemcpyDeviceToHost, st), KGX_EHIP, "D2H(hall flag)");
-        try_hip(hipStreamSynchronize(st), KGX_EHIP, "sync");
-        by_moments = rc == KGX_OK && unsupported == 0;      // a frequency outside the bins (below 2^-20, above 1): the 50 passes below
+        by_moments = rc == KGX_OK;
+        if (by_moments) dev.last_path = KGX_PATH_HALL_MOMENTS;
       }
+      if (!by_moments && rc == KGX_OK) dev.last_path = KGX_PATH_HALL_PASSES;
       if (!by_moments) {
       const std::vector<double>& f0 = start_points;
       // locus slots every lane of k_inbreed_eval_lut walks: whole batches of 8 in every segment
@@ -499,18 +604,77 @@ int inbreed_shard(kgx_gt8_shard& sh, uint64_t g0, uint64_t g1, const uint32_t* l
       }
       }
     } else if (algorithm == 3) {
-      // processLogLikelihood (_calc.cpp:153-216): maximise over [-1,1].  The objective is a sum of logs of
-      // clamped linear functions of F; Brent's method on that same clamped objective replaces nlopt's Nelder-Mead
-      // (un-vendored, unpinned), to within 5e-7 in F where the reference stops at an absolute change of 1e-6.  KGX_K7_GOLDEN=1 runs the
-      // plain golden-section search instead (38 evaluations, bracket 6e-8).
-      tabulate(2);
-      if (!env_int("KGX_K7_GOLDEN", 0)) {
+      // processLogLikelihood (_calc.cpp:153-216): maximise over [-1,1] on the reference optimiser's own path (nm_advance).
+      // Over a large call the objective comes from per-genome statistics (kgx_kernels_loglik.h) and the whole search of a
+      // genome runs in one workgroup; the passes over the bytes (below) serve what the statistics cannot (a frequency outside
+      // the bins; a genome with a heterozygous cell that can meet either bound), the other searches (KGX_K7_SEARCH=brent,
+      // KGX_K7_GOLDEN=1), amax > 7, unphased populations, and the comparison (KGX_K7_LL_PASSES=1).
+      bool by_moments = false;
+      std::vector<uint32_t> handed_over;                              // genomes the statistics could not serve
+      uint32_t* d_needs_passes = reinterpret_cast<uint32_t*>(arena + o_needs_passes);
+      double* d_keep = reinterpret_cast<double*>(arena + o_keep);
+      if (objective_method == 1 && !loglik_moments)
+        rc = fail(KGX_ESTATE, "kgx_inbreed_objective: this call would not run on the moments (selection size, amax, phase, memory or a switch)");
+      if (loglik_moments && objective_method != 2 && rc == KGX_OK && gather_moments(true)) {
+        uint32_t n_used = 0;                                        // (the search keeps the genome's bins in LDS: as much of it as they need)
+        try_hip(hipMemcpyAsync(&n_used, h_totals, sizeof(uint32_t), hipMemcpyDeviceToHost, st), KGX_EHIP, "D2H(used bins)");
+        try_hip(hipStreamSynchronize(st), KGX_EHIP, "sync");
+        hipLaunchKernelGGL(k_loglik_search, dim3(static_cast<uint32_t>(n)), dim3(kBlock), loglik_search_lds(n_used), st, h_bins, h_used, h_totals, d_counts, d_sums,
+                           d_smallest_het, n, words_per_block, loglik_classes, d_start, objective_method == 1 ? 1 : 0, d_f, d_needs_passes, h_totals + 2, d_running);
+        try_hip(hipGetLastError(), KGX_EHIP, "loglik search launch");
+        uint32_t handed = 0;
+        unsigned int evaluations = 0;
+        try_hip(hipMemcpyAsync(&handed, h_totals + 2, sizeof(uint32_t), hipMemcpyDeviceToHost, st), KGX_EHIP, "D2H(handed over)");
+        try_hip(hipMemcpyAsync(&evaluations, d_running, sizeof(unsigned int), hipMemcpyDeviceToHost, st), KGX_EHIP, "D2H(evaluations)");
+        try_hip(hipStreamSynchronize(st), KGX_EHIP, "sync");
+        by_moments = rc == KGX_OK;
+        if (by_moments) {
+          dev.last_evaluations = static_cast<int>(evaluations);
+          dev.last_path = KGX_PATH_LOGLIK_MOMENTS;
+        }
+        if (by_moments && handed) {
+          std::vector<uint32_t> flags(n);
+          try_hip(hipMemcpyAsync(flags.data(), d_needs_passes, n * sizeof(uint32_t), hipMemcpyDeviceToHost, st), KGX_EHIP, "D2H(needs passes)");
+          try_hip(hipMemcpyAsync(d_keep, d_f, n * sizeof(double), hipMemcpyDeviceToDevice, st), KGX_EHIP, "copy(kept results)");
+          try_hip(hipMemsetAsync(d_running, 0, sizeof(unsigned int), st), KGX_EHIP, "memset(running)");
+          try_hip(hipStreamSynchronize(st), KGX_EHIP, "sync");
+          for (uint64_t g = 0; g < n; ++g)
+            if (flags[g]) {
+              handed_over.push_back(static_cast<uint32_t>(g));
+              if (env_int("KGX_K7_TRACE", 0)) std::fprintf(stderr, "kgx: Loglikelihood: genome %llu handed to the passes (reason %u)\n", (unsigned long long)(g0 + g), flags[g]);
+            }
+          if (rc == KGX_OK) dev.last_path = KGX_PATH_LOGLIK_MOMENTS_AND_PASSES;
+        }
+      } else if (objective_method == 1 && rc == KGX_OK) {
+        rc = fail(KGX_ESTATE, "kgx_inbreed_objective: a frequency without a bin, or no room for the hits' words: the passes would run");
+      }
+      if (objective_method != 0) {
+        // the diagnostic: the objective at the caller's points, by the moments (above) or by ONE table pass
+        if (objective_method == 2 && rc == KGX_OK) {
+          try_hip(hipMemcpyAsync(d_f, d_start, n * sizeof(double), hipMemcpyDeviceToDevice, st), KGX_EHIP, "copy(points)");
+          tabulate(2);
+          sweep(2);
+          hipLaunchKernelGGL(k_reduce_parts, dim3(reduce_grid(n)), dim3(kBlock), 0, st, d_part, pass_n_seg, n, nullptr, d_eval);
+          try_hip(hipGetLastError(), KGX_EHIP, "objective pass launch");
+        }
+        try_hip(hipMemcpyAsync(objective_out, objective_method == 2 ? d_eval : d_f, n * sizeof(double), hipMemcpyDeviceToHost, st), KGX_EHIP, "D2H(objective)");
+        try_hip(hipStreamSynchronize(st), KGX_EHIP, "sync");
+        return rc;
+      }
+      if (by_moments && handed_over.empty()) {
+        // done: d_f holds every genome's coefficient
+      } else if (!env_int("KGX_K7_GOLDEN", 0)) {
+        if (!by_moments && rc == KGX_OK) dev.last_path = KGX_PATH_LOGLIK_PASSES;
+        tabulate(2);
         // Start: [-1, 1] from its golden point.  KGX_K7_ESTIMATE_START=1 starts in a window around the Simple estimate
         // instead (brent_start): 11 instead of 15 evaluations on a population with F in [0, 0.1], but where the clamped
         // objective has several local maxima (F < 0) it may settle on another one than a search from the middle does --
         // the reference itself lands on one or another from its random starts -- so it is not the default.
         ll_pair = planes == 2;
         hipLaunchKernelGGL(k_brent_init, dim3(lin_grid), dim3(kBlock), 0, st, d_counts, d_sums, n, env_int("KGX_K7_ESTIMATE_START", 0), pass_search, d_start, d_brent, d_f);
+        // (after the moments: only the genomes handed over search here; the others' states say "done" with their result)
+        if (by_moments)
+          hipLaunchKernelGGL(k_loglik_keep, dim3(lin_grid), dim3(kBlock), 0, st, d_needs_passes, d_keep, n, static_cast<int>(planes), d_brent, d_f);
         // Brent: golden section alone would need 38, and its safeguard keeps that bound; Nelder-Mead: the reference's own cap
         const int kMaxEvaluations = search == kSearchNelderMead ? 500 : 60;
         // The genomes still searching.  When at most half of them are left -- and the call is big enough for it to pay --
@@ -539,28 +703,19 @@ int inbreed_shard(kgx_gt8_shard& sh, uint64_t g0, uint64_t g1, const uint32_t* l
         const bool may_compact = eval_lut && !env_int("KGX_K7_NO_COMPACT", 0);
         bool may_compact_now = may_compact;
         int compaction_level = 0;
-        for (int it = 0; it < kMaxEvaluations && rc == KGX_OK; ++it) {
-          evaluate();
-          const uint32_t act_grid = stream_grid(dev, n_act, kBlock);
-          hipLaunchKernelGGL(k_reduce_parts, dim3(reduce_grid(planes * n_act)), dim3(kBlock), 0, st, d_part, pass_n_seg, planes * n_act, nullptr, d_eval);
-          try_hip(hipMemsetAsync(d_running, 0, sizeof(unsigned int), st), KGX_EHIP, "memset(running)");
-          hipLaunchKernelGGL(k_brent_step, dim3(act_grid), dim3(kBlock), 0, st, act_brent, d_eval, n_act, it == 0 ? 0 : 1, pass_search, act_f, d_running,
-                             act_global, d_f);
-          unsigned int running = 0;
-          try_hip(hipMemcpyAsync(&running, d_running, sizeof(unsigned int), hipMemcpyDeviceToHost, st), KGX_EHIP, "D2H(running)");
-          try_hip(hipStreamSynchronize(st), KGX_EHIP, "sync");
-          dev.last_evaluations = it + 1;
-          if (env_int("KGX_K7_TRACE", 0)) std::fprintf(stderr, "kgx: Loglikelihood evaluation %d: %u of %llu genomes still searching\n", it + 1, running, (unsigned long long)n_act);
-          if (running == 0) break;
+        // `running` of the n_act genomes are still searching: gather their columns and states if that pays
+        // (whatever the size: the genomes handed over by the moments, a few of many)
+        auto compact = [&](unsigned int running, bool whatever_the_size) {
           const uint64_t new_pitch = (static_cast<uint64_t>(running) + 127) / 128 * 128;
           // worth it from ~64 M cells left (a gather costs about one pass); the two knobs are for the tests
           const uint64_t min_genomes = static_cast<uint64_t>(env_int("KGX_K7_COMPACT_MIN_GENOMES", 2048));
           const uint64_t min_cells = static_cast<uint64_t>(env_int("KGX_K7_COMPACT_MIN_CELLS", 1 << 26));
-          if (!may_compact_now || static_cast<uint64_t>(running) * 2 > n_act || n_act < min_genomes || n_sel * static_cast<uint64_t>(running) < min_cells) continue;
+          if (!may_compact_now || running == 0 || static_cast<uint64_t>(running) * 2 > n_act) return;
+          if (!whatever_the_size && (n_act < min_genomes || n_sel * static_cast<uint64_t>(running) < min_cells)) return;
           host_states.resize(n_act);
           try_hip(hipMemcpyAsync(host_states.data(), act_brent, n_act * sizeof(BrentState), hipMemcpyDeviceToHost, st), KGX_EHIP, "D2H(states)");
           try_hip(hipStreamSynchronize(st), KGX_EHIP, "sync");
-          if (rc != KGX_OK) break;
+          if (rc != KGX_OK) return;
           std::vector<uint32_t> columns, new_global;
           for (uint64_t g = 0; g < n_act; ++g)
             if (!host_states[g].done) { columns.push_back(static_cast<uint32_t>(g)); new_global.push_back(global_of[g]); }
@@ -581,7 +736,7 @@ int inbreed_shard(kgx_gt8_shard& sh, uint64_t g0, uint64_t g1, const uint32_t* l
               (void)hipGetLastError();
               dev.compact[slot] = nullptr;
               may_compact_now = false;                                     // no room: carry on as is
-              continue;
+              return;
             }
             dev.compact_bytes[slot] = level.total;
           }
@@ -609,11 +764,30 @@ int inbreed_shard(kgx_gt8_shard& sh, uint64_t g0, uint64_t g1, const uint32_t* l
           act_global = d_new_global;
           n_act = n_new;
           global_of.swap(new_global);
+        };
+        if (by_moments) compact(static_cast<unsigned int>(handed_over.size()), true);
+        const int evaluations_by_moments = by_moments ? dev.last_evaluations.load() : 0;
+        for (int it = 0; it < kMaxEvaluations && rc == KGX_OK; ++it) {
+          evaluate();
+          const uint32_t act_grid = stream_grid(dev, n_act, kBlock);
+          hipLaunchKernelGGL(k_reduce_parts, dim3(reduce_grid(planes * n_act)), dim3(kBlock), 0, st, d_part, pass_n_seg, planes * n_act, nullptr, d_eval);
+          try_hip(hipMemsetAsync(d_running, 0, sizeof(unsigned int), st), KGX_EHIP, "memset(running)");
+          hipLaunchKernelGGL(k_brent_step, dim3(act_grid), dim3(kBlock), 0, st, act_brent, d_eval, n_act, it == 0 ? 0 : 1, pass_search, act_f, d_running,
+                             act_global, d_f);
+          unsigned int running = 0;
+          try_hip(hipMemcpyAsync(&running, d_running, sizeof(unsigned int), hipMemcpyDeviceToHost, st), KGX_EHIP, "D2H(running)");
+          try_hip(hipStreamSynchronize(st), KGX_EHIP, "sync");
+          dev.last_evaluations = std::max(it + 1, evaluations_by_moments);
+          if (env_int("KGX_K7_TRACE", 0)) std::fprintf(stderr, "kgx: Loglikelihood evaluation %d: %u of %llu genomes still searching\n", it + 1, running, (unsigned long long)n_act);
+          if (running == 0) break;
+          compact(running, false);
         }
         hipLaunchKernelGGL(k_brent_step, dim3(stream_grid(dev, n_act, kBlock)), dim3(kBlock), 0, st, act_brent, d_eval, n_act, 2, pass_search, act_f, d_running, act_global, d_f);
         ll_pair = false;
         try_hip(hipStreamSynchronize(st), KGX_EHIP, "sync");
       } else {
+      if (rc == KGX_OK) dev.last_path = KGX_PATH_LOGLIK_PASSES;
+      tabulate(2);
       const double inv_phi = 0.6180339887498949;
       constexpr int kGoldenSteps = 38;     // bracket 2 * 0.618^36 = 6e-8 after the two start-up evaluations
       GoldenState init;
@@ -937,6 +1111,43 @@ int kgx_inbreed_reference_starts(int algorithm, uint64_t seed, uint64_t first_st
     }
     return KGX_OK;
   });
+}
+
+int kgx_inbreed_objective(kgx_gt8* h, uint64_t g0, uint64_t g1, const uint32_t* locus_index, uint64_t n_sel, const double* minor_af,
+                          uint32_t amax, int phased, const double* at, int by_passes, double* value) {
+  return guarded([&]() -> int {
+    if (int bound = require_bound()) return bound;
+    if (!h || !at || !value || (n_sel && !minor_af)) return fail(KGX_EINVAL, "null argument");
+    if (g0 > g1 || g1 > h->n_genomes || (g0 & 3u)) return fail(KGX_EINVAL, "genome range must lie in the matrix and start on a multiple of 4");
+    if (amax == 0 || amax > 14) return fail(KGX_EINVAL, "amax %u outside [1,14] (4-bit allele indices)", amax);
+    if (n_sel == 0) return fail(KGX_EINVAL, "no loci selected");
+    for (uint64_t g = 0; g < g1 - g0; ++g)
+      if (!(at[g] >= -1.0 && at[g] <= 1.0)) return fail(KGX_EINVAL, "at[%llu] = %g outside [-1, 1]", (unsigned long long)g, at[g]);
+    if (!locus_index && n_sel > h->n_loci) return fail(KGX_EINVAL, "n_sel exceeds the locus count");
+    if (locus_index)
+      for (uint64_t i = 0; i < n_sel; ++i)
+        if (locus_index[i] >= h->n_loci) return fail(KGX_EINVAL, "locus_index[%llu] out of range", (unsigned long long)i);
+    if (g0 == g1) return KGX_OK;
+    std::vector<kgx_locus_results> unused(1);
+    const int rc = for_each_parallel(h->shards.size(), [&](size_t s) -> int {
+      kgx_gt8_shard& sh = h->shards[s];
+      const uint64_t lo = g0 > sh.genome_base ? g0 : sh.genome_base;
+      const uint64_t hi = g1 < sh.genome_base + sh.n_genomes ? g1 : sh.genome_base + sh.n_genomes;
+      if (lo >= hi) return KGX_OK;
+      return inbreed_shard(sh, lo - sh.genome_base, hi - sh.genome_base, locus_index, n_sel, minor_af, amax, phased, KGX_ALGO_LOGLIKELIHOOD,
+                           at + (lo - g0), unused.data(), by_passes ? 2 : 1, value + (lo - g0));
+    });
+    (void)use_device(*h->shards[0].dev);
+    return rc;
+  });
+}
+
+int kgx_inbreed_last_path(void) {
+  const auto rt = current_runtime();
+  int path = KGX_PATH_NONE;
+  if (rt)
+    for (const auto& dev : rt->devs) { const int p = dev->last_path.load(); path = p > path ? p : path; }
+  return path;
 }
 
 double kgx_inbreed_last_sweep_ms(void) {

@@ -41,10 +41,13 @@ struct Device {
   std::atomic<double> last_by_genome_ms{0.0};
   std::atomic<double> last_sweep_ms{0.0}, last_kernel_ms{0.0};
   std::atomic<int> last_evaluations{0};                    // objective evaluations of the last Loglikelihood call here
+  std::atomic<int> last_path{0};                           // KGX_PATH_*: what the last kgx_inbreed call here ran on
   char* scratch = nullptr;                                 // grow-only arena for kgx_inbreed's per-call buffers
   size_t scratch_bytes = 0;
   char* compact[2] = {nullptr, nullptr};                   // ping-pong buffers of the Loglikelihood search's compaction levels
   size_t compact_bytes[2] = {0, 0};
+  char* words = nullptr;                                   // Loglikelihood by moments: the class passes' hit bits, [block][genome] (grow-only, like the arena)
+  size_t words_bytes = 0;
   void* exchange_stage = nullptr;                          // "peer" exchange: staging for another shard's counts
   size_t exchange_stage_bytes = 0;
   std::mutex mutex;                                        // serialises the per-device state above between handles

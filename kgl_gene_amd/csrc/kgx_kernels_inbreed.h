@@ -299,6 +299,15 @@ constexpr uint32_t kOddMinus = 1u << 24;          // unclassified carrier at a l
 constexpr uint32_t kOddPlus = 1u << 25;           // classified at a locus without defaults: they are added
 constexpr uint32_t kOddNoRitland = 1u << 26;      // a homozygote of an allele with f <= 0.001: classified, no Ritland term
 constexpr uint32_t kOddOutside = 1u << 27;        // a byte past the table: off wherever the locus has defaults
+constexpr uint32_t kOddBigHet = 1u << 28;         // entries of mode 5 only: a heterozygous cell with 2*f1*f2 > 1/2 (see k_eval_entries)
+// Entries of mode 5 (walked by k_inbreed_eval_lut<3>: its fp64 term is whatever the entry says): what the log-likelihood by
+// moments (kgx_kernels_loglik.h) needs of the HETEROZYGOUS cells.  Their probability is u*w, u = 1 - F, w = 2*f1*f2, clamped
+// to [1e-10, 1]: with kLoglikTinyHet <= w <= 1/2 the clamp can only bind from below and only for u < 1e-10 / w, so the sum of
+// their logs is  sum(log w) + H * log u  and the term is log w.  A cell with w < kLoglikTinyHet is under the floor for every
+// u <= 2 (term 0, marked like a cell without Ritland term: it comes off the genome's sixth counter); one with w > 1/2 (two
+// copies of an allele more frequent than 1/2 counted as heterozygous: a repeated record, an unphased homozygote) can meet the
+// UPPER bound: term 0, and 2^32 onto the sixth counter -- such a genome takes the passes.
+constexpr double kLoglikTinyHet = 5e-11;
 // Slot of one byte value (the walk computes four at once: slots_of in the kernel).
 template <bool FOLD>
 __host__ __device__ constexpr uint32_t eval_slot(uint32_t byte) {
@@ -315,30 +324,42 @@ __host__ __device__ constexpr uint32_t eval_bits(uint32_t amax) { return amax <=
 template <int MODE>
 __global__ void __launch_bounds__(kBlock)
 k_eval_entries(const double* __restrict__ table, const uint8_t* __restrict__ valid, uint64_t n_sel, uint32_t amax, int phased,
-               void* __restrict__ entries_out) {
+               void* __restrict__ entries_out, unsigned long long* __restrict__ smallest_het = nullptr) {
   const uint32_t stride = sweep_stride(amax);
   const uint32_t bits = eval_bits(amax), mask = (1u << bits) - 1u;
   const uint64_t total = n_sel << (2u * bits);
+  double smallest = 1.0;                                       // MODE 5: this thread's smallest 2*f1*f2 with a term
   for (uint64_t idx = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x; idx < total;
        idx += static_cast<uint64_t>(gridDim.x) * blockDim.x) {
     const uint64_t s = idx >> (2u * bits);
     const uint32_t a1 = static_cast<uint32_t>(idx) & mask, a2 = (static_cast<uint32_t>(idx) >> bits) & mask;
-    double y = (MODE == 3 || MODE == 4) ? 0.0 : 1.0, d = 0.0;
+    constexpr bool kPacked = MODE == 3 || MODE == 4 || MODE == 5;      // the frequency sweeps' entries: packed class counters
+    double y = kPacked ? 0.0 : 1.0, d = 0.0;
     const uint8_t flag = valid[s];
     if (a1 > amax || a2 > amax) {
-      // MODE 3, 4: a byte past the table is counted as nothing but is odd wherever the locus has defaults
-      if constexpr (MODE == 3 || MODE == 4) d = __builtin_bit_cast(double, (static_cast<uint64_t>(kOddCell) << 32) | kOddOutside);
+      // MODE 3, 4, 5: a byte past the table is counted as nothing but is odd wherever the locus has defaults
+      if constexpr (kPacked) d = __builtin_bit_cast(double, (static_cast<uint64_t>(kOddCell) << 32) | kOddOutside);
     } else if (flag & kLocusValid) {
       double f1 = 0.0, f2 = 0.0;
       const int cls = classify_cell(a1 | (a2 << 4), table + s * stride, amax, phased != 0, f1, f2);
-      if constexpr (MODE == 3 || MODE == 4) {
+      if constexpr (kPacked) {
         uint32_t lo = 0, hi = 0;
         if (cls == kMajorHom) lo = 1u; else if (cls == kMajorHet) lo = 1u << 12;
         else if (cls == kMinorHom) hi = 1u; else if (cls == kMinorHet) hi = 1u << 12;
         // odd: the cell's share of the class-frequency sums is not the segment default's
         if (flag & kLocusDefault) { if (cls == kClassNone && (a1 | a2) != 0u) lo |= kOddMinus; }
         else if (cls != kClassNone) lo |= kOddPlus;
-        if (cls == kMajorHom || cls == kMinorHom) {
+        if constexpr (MODE == 5) {
+          if (cls == kMajorHet || cls == kMinorHet) {                  // (see kLoglikTinyHet)
+            const double w = 2.0 * f1 * f2;
+            if (w < kLoglikTinyHet) lo |= kOddNoRitland;
+            else if (w > 0.5) lo |= kOddBigHet;
+            else {
+              y = log(w);
+              smallest = w < smallest ? w : smallest;
+            }
+          }
+        } else if (cls == kMajorHom || cls == kMinorHom) {
           if (f1 > 0.001) { y = 1.0 / f1; y -= 1.0; }                  // minimum_frequency (_calc.cpp:380,396)
           else lo |= kOddNoRitland;
         } else if (cls != kClassNone) {
@@ -362,6 +383,12 @@ k_eval_entries(const double* __restrict__ table, const uint8_t* __restrict__ val
       entries[idx].y = y;
       entries[idx].d = d;
     }
+  }
+  if constexpr (MODE == 5) {
+    // one atomic per wave (all threads of the launch on one word took 14 ms at 5 M loci); positive doubles order as their bits
+    for (int off = 32; off > 0; off >>= 1) { const double other = __shfl_xor(smallest, off); smallest = other < smallest ? other : smallest; }
+    if (smallest_het && (threadIdx.x & (kWave - 1)) == 0 && smallest < 1.0)
+      atomicMin(smallest_het, static_cast<unsigned long long>(__double_as_longlong(smallest)));
   }
 }
 
@@ -669,6 +696,7 @@ k_inbreed_eval_lut(const uint32_t* __restrict__ gt, uint64_t dwords_per_row, uin
                   for (uint32_t k = 0; k < 4u; ++k) unsafeAtomicAdd(p + k, sign * row[amax + 1u + k]);
                 }
                 if (odd & (kOddNoRitland >> 24)) atomicAdd(&counts[g * 6 + 5], ~0ull);       // counted with the classes, not by Ritland
+                if (odd & (kOddBigHet >> 24)) atomicAdd(&counts[g * 6 + 5], 1ull << 32);      // (mode 5 entries)
               }
             }
           }

@@ -157,6 +157,7 @@ Device::~Device() {
   if (scratch) (void)hipFree(scratch);
   for (int k = 0; k < 2; ++k)
     if (compact[k]) (void)hipFree(compact[k]);
+  if (words) (void)hipFree(words);
   if (exchange_stage) (void)hipFree(exchange_stage);
   if (sweep_begin) (void)hipEventDestroy(sweep_begin);
   if (sweep_end) (void)hipEventDestroy(sweep_end);
@@ -400,6 +401,9 @@ int kgx_release_scratch(void) {
         dev->compact[k] = nullptr;
         dev->compact_bytes[k] = 0;
       }
+      if (dev->words) (void)hipFree(dev->words);
+      dev->words = nullptr;
+      dev->words_bytes = 0;
     }
     return use_device(*rt->devs[0]);
   });
