@@ -337,25 +337,58 @@ def aux_inbreeding(args, capi, torch, dev, cpu):
     # HallME over the same population (kgx_kernels_hall.h: per-genome moments, one pass over the bytes per class of
     # homozygous cell instead of processHallME's 50): calls from seeded reference start points.
     hall_seed = 4242
-    hall_start = capi.reference_starts("HallME", hall_seed, G)
-    hall_walls = []
-    hall = None
-    for i in range(4):
-        t = time.perf_counter()
-        hall = m.inbreed_resident(table_dev.data_ptr(), n_sel, amax, "HallME", phased=True, start=hall_start)
-        if i >= 1:
-            hall_walls.append((time.perf_counter() - t) * 1e3)
-    hall_ms = float(np.median(hall_walls))
     classes = 1 + amax
+
+    def iterative_leg(algorithm, calls):
+        """One iterative estimator over the whole population from seeded reference starts: wall ms per call (median), and the
+        device time of its parts from the library's own HIP events (frequency sweep, class passes, search) of the last call."""
+        start = capi.reference_starts(algorithm, hall_seed, G)
+        walls, parts, res = [], {}, None
+        for i in range(calls + 1):
+            t = time.perf_counter()
+            res = m.inbreed_resident(table_dev.data_ptr(), n_sel, amax, algorithm, phased=True, start=start)
+            if i >= 1:
+                walls.append((time.perf_counter() - t) * 1e3)
+        parts = {"frequency_sweep_ms": capi.inbreed_last_sweep_ms(), "class_passes_ms": capi.inbreed_last_moments_ms(),
+                 "search_ms": capi.inbreed_last_search_ms(), "path": capi.inbreed_last_path()}
+        return float(np.median(walls)), len(walls), res, parts
+
+    def moments_roofline(ms, parts, kernel):
+        # The unique bytes of the call are ONE read of the matrix (sweep_bytes); the call's passes re-read it (the frequency sweep,
+        # then one pass per class of homozygous cell over the loci that have the class): `achieved` prices the whole call at
+        # its unique bytes, `class_passes_GBps` the class passes at the bytes they do read (a full matrix each for the major
+        # class and alt 1; alt 2 and 3 at the share of loci that have them, from the table).
+        has_alt = np.isfinite(table).mean(axis=0)
+        class_bytes = float(G) * L * (1.0 + float(has_alt.sum()))
+        return {"bound": "hbm", "kernel": kernel, "achieved": sweep_bytes / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": sweep_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None, "algorithmic_bytes_per_launch": sweep_bytes,
+                "what": "the whole call priced at ONE read of the matrix (its unique bytes)",
+                "matrix_reads_per_call": 1.0 + class_bytes / (float(G) * L),
+                "class_passes_GBps": class_bytes / (parts["class_passes_ms"] * 1e-3) / 1e9 if parts["class_passes_ms"] > 0 else None,
+                "class_passes_frac": class_bytes / (parts["class_passes_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS if parts["class_passes_ms"] > 0 else None,
+                "device_ms": parts}
+
+    hall_ms, hall_calls, hall, hall_parts = iterative_leg("HallME", 3)
     record["hallme"] = {
         "metric": "genomes·loci/sec (inbreeding sweep + HallME)", "value": G * L / (hall_ms * 1e-3), "unit": "genomes·loci/s",
-        "ms_per_call": hall_ms, "calls": len(hall_walls),
+        "ms_per_call": hall_ms, "calls": hall_calls,
         "config": {"workload": label, "algorithm": "HallME", "start_points": f"kgx_inbreed_reference_starts(seed {hall_seed})",
                    "passes_over_the_bytes": f"1 frequency sweep + {classes} moment passes (classes of homozygous cell) instead of 1 + 50",
                    "mean_F": float(hall["inbred_allele_sum"].mean())},
-        "roofline": {"bound": "hbm", "kernel": "k_hall_sweep<8> (one class's moment pass)", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": None, "traffic": None, "algorithmic_bytes_per_launch": sweep_bytes,
-                     "note": "not timed alone in this run: profiles/r03_hall_kernel_stats.csv holds its rocprofv3 average"},
+        "roofline": moments_roofline(hall_ms, hall_parts, "k_hall_sweep<8, false> (the class passes), k_hall_iterate"),
+        "cpu_baseline": None,
+    }
+    # Loglikelihood, the reference's DEFAULT estimator (kga_analysis_inbreed_args.h:138), over the same population: the same
+    # moments plus the exact walk of the cells next to the 1e-10 floor, the reference optimiser's search run per genome in one
+    # workgroup (kgx_kernels_loglik.h) -- instead of 38 passes over the bytes.
+    ll_ms, ll_calls, ll, ll_parts = iterative_leg("Loglikelihood", 3)
+    record["loglikelihood"] = {
+        "metric": "genomes·loci/sec (inbreeding sweep + Loglikelihood)", "value": G * L / (ll_ms * 1e-3), "unit": "genomes·loci/s",
+        "ms_per_call": ll_ms, "calls": ll_calls, "evaluations": capi.inbreed_last_evaluations(),
+        "config": {"workload": label, "algorithm": "Loglikelihood", "start_points": f"kgx_inbreed_reference_starts(seed {hall_seed})",
+                   "passes_over_the_bytes": f"1 frequency sweep + {classes} moment passes instead of 1 + ~38 (two evaluations each)",
+                   "mean_F": float(ll["inbred_allele_sum"].mean())},
+        "roofline": moments_roofline(ll_ms, ll_parts, "k_hall_sweep<8, true> (the class passes, leaving the hits' bits), k_loglik_search"),
         "cpu_baseline": None,
     }
     if cpu:
@@ -372,6 +405,23 @@ def aux_inbreeding(args, capi, torch, dev, cpu):
             "value": Gs * Ls / seconds, "unit": "genomes·loci/s", "cores": threads, "kind": "port",
             "sample": f"the Simple leg's slice ({Gs * Ls:.3g} cells, {seconds:.1f} s): oracle processResults with processHallME (5 restarts of 50 "
                       f"steps, the fifth decides; {threads} pool threads), same seeded entropy; parity vs GPU on the slice: |dF| max {f_err:.1e} (bound 1e-9)",
+            "parity_ok": ok}
+        counts, freqs, present, seconds = oa.inbreed_window(ref.filter_snp_pass(), dip, np.full(Gs, oa.ALL, dtype=np.int32), "Loglikelihood", 0,
+                                                            int(d["offsets"][-1]) + 1, 1, 10**9, 0.0, 1.0, seed=hall_seed)
+        slice_start[order] = capi.reference_starts("Loglikelihood", hall_seed, Gs)
+        got = m.inbreed(np.ascontiguousarray(table[:Ls]), "Loglikelihood", phased=True, locus_index=np.arange(Ls, dtype=np.uint32), g0=0, g1=Gs,
+                        start=slice_start)[order]
+        slice_path = capi.inbreed_last_path()
+        f_abs = np.abs(got["inbred_allele_sum"] - freqs[:, 4])
+        f_err, on_path = float(f_abs.max()), int((f_abs <= 2e-6).sum())
+        # (one optimiser, one start, each side stopped at a simplex of 1e-6: 2e-6; a genome whose two paths parted at a comparison
+        # of values closer than their rounding may sit on a neighbouring maximum -- at most 1 % of them, tests/test_inbreed_gpu.py)
+        ok = bool(present.all()) and np.array_equal(got["total_allele_count"], counts[:, 4]) and on_path >= 0.99 * Gs
+        record["loglikelihood"]["cpu_baseline"] = {
+            "value": Gs * Ls / seconds, "unit": "genomes·loci/s", "cores": threads, "kind": "port",
+            "sample": f"the Simple leg's slice ({Gs * Ls:.3g} cells, {seconds:.1f} s): oracle processResults with processLogLikelihood (5 restarts of the "
+                      f"1-D Nelder-Mead, the fifth decides; {threads} pool threads), same seeded entropy; parity vs GPU on the slice (path '{slice_path}'): "
+                      f"|dF| <= 2e-6 on {on_path} of {Gs} genomes, largest {f_err:.1e}",
             "parity_ok": ok}
     m.close()
     capi.release_scratch()

@@ -326,6 +326,11 @@ double kgx_inbreed_last_sweep_ms(void);
 /* ... and of the one kernel inside it that reads the genotype bytes (k_inbreed_eval_lut<3|4>, or the SWAR / generic
  * sweep): the sweep without the per-locus helper kernels (tables, entries, segment defaults). */
 double kgx_inbreed_last_kernel_ms(void);
+/* Where the most recent successful kgx_inbreed call ran on per-genome moments (HallME, Loglikelihood over more than 8192
+ * loci): device time of its class passes over the genotype bytes (one per class of homozygous cell, with the merges of
+ * their items) and of the kernel that then iterates / searches on the moments; 0 otherwise. */
+double kgx_inbreed_last_moments_ms(void);
+double kgx_inbreed_last_search_ms(void);
 /* Objective evaluations the most recent KGX_ALGO_LOGLIKELIHOOD call needed (the most any genome made; where the call
  * made passes over the genotype bytes, the passes). */
 int kgx_inbreed_last_evaluations(void);

@@ -88,6 +88,8 @@ _SIGNATURES = {
     "kgx_inbreed_last_kernel_ms": (C.c_double, []),
     "kgx_inbreed_last_evaluations": (C.c_int, []),
     "kgx_inbreed_last_path": (C.c_int, []),
+    "kgx_inbreed_last_moments_ms": (C.c_double, []),
+    "kgx_inbreed_last_search_ms": (C.c_double, []),
     "kgx_inbreed_objective": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint32, C.c_int,
                                         C.c_void_p, C.c_int, C.c_void_p]),
     "kgx_gt8_synth_multiallelic": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64, C.c_void_p]),
@@ -617,6 +619,16 @@ PATHS = {0: "none", 1: "frequency sweep", 2: "one launch", 3: "hall moments", 4:
 def inbreed_last_path() -> str:
     """What the most recent inbreed call ran on (kgx.h: KGX_PATH_*)."""
     return PATHS[int(lib().kgx_inbreed_last_path())]
+
+
+def inbreed_last_moments_ms() -> float:
+    """Device time of the class passes (sweeps + merges) of the last inbreed call that ran on moments; 0 otherwise."""
+    return float(lib().kgx_inbreed_last_moments_ms())
+
+
+def inbreed_last_search_ms() -> float:
+    """Device time of the kernel that iterated / searched on the moments in the last such inbreed call; 0 otherwise."""
+    return float(lib().kgx_inbreed_last_search_ms())
 
 
 def inbreed_last_evaluations() -> int:

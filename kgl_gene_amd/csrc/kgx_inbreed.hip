@@ -428,6 +428,7 @@ int inbreed_shard(kgx_gt8_shard& sh, uint64_t g0, uint64_t g1, const uint32_t* l
     double* const h_bins = reinterpret_cast<double*>(arena + o_hall_bins);
     std::vector<uint32_t> class_items(plan_classes, 0u), class_blocks(plan_classes, 0u);
     LoglikClasses loglik_classes{};
+    bool moments_timed = false, search_timed = false;             // (events recorded: read after the call's last synchronisation)
     auto class_words = [&](uint32_t k) { return h_words + k * kHallClassWords; };
     auto gather_moments = [&](bool emit) -> bool {
       uint32_t* h_keys = reinterpret_cast<uint32_t*>(arena + o_hall_keys);
@@ -493,6 +494,7 @@ int inbreed_shard(kgx_gt8_shard& sh, uint64_t g0, uint64_t g1, const uint32_t* l
         words = reinterpret_cast<unsigned long long*>(dev.words);
       }
       uint64_t block_base = 0;
+      try_hip(hipEventRecord(dev.moments_begin, st), KGX_EHIP, "hipEventRecord");
       for (uint32_t k = 0; k < hall_classes && rc == KGX_OK; ++k) {
         uint32_t* item_base = class_words(k) + 2 * (kHallBins + 1);
         unsigned long long* class_out = emit ? words + block_base * words_per_block : nullptr;
@@ -514,6 +516,8 @@ int inbreed_shard(kgx_gt8_shard& sh, uint64_t g0, uint64_t g1, const uint32_t* l
       }
       loglik_classes.n = emit ? hall_classes : 0u;
       loglik_classes.block_bins = block_bins;
+      try_hip(hipEventRecord(dev.moments_end, st), KGX_EHIP, "hipEventRecord");
+      moments_timed = true;
       hipLaunchKernelGGL(k_hall_used_bins, dim3(1), dim3(kBlock), 0, st, h_bin_used, h_used, h_totals);
       try_hip(hipGetLastError(), KGX_EHIP, "hall bins launch");
       return rc == KGX_OK;
@@ -563,8 +567,11 @@ int inbreed_shard(kgx_gt8_shard& sh, uint64_t g0, uint64_t g1, const uint32_t* l
       if (hall_moments && rc == KGX_OK && gather_moments(false)) {
         // HallME on per-genome moments (kgx_kernels_hall.h): one pass over the bytes per class of homozygous cell, then
         // the 50 steps on ~10^3 numbers a genome.
+        try_hip(hipEventRecord(dev.search_begin, st), KGX_EHIP, "hipEventRecord");
         hipLaunchKernelGGL(k_hall_iterate, dim3(static_cast<uint32_t>(n)), dim3(kBlock), 0, st, h_bins, h_used, h_totals, d_counts, n, d_start, d_f);
         try_hip(hipGetLastError(), KGX_EHIP, "hall iterate launch");
+        try_hip(hipEventRecord(dev.search_end, st), KGX_EHIP, "hipEventRecord");
+        search_timed = true;
         by_moments = rc == KGX_OK;
         if (by_moments) dev.last_path = KGX_PATH_HALL_MOMENTS;
       }
@@ -619,9 +626,12 @@ int inbreed_shard(kgx_gt8_shard& sh, uint64_t g0, uint64_t g1, const uint32_t* l
         uint32_t n_used = 0;                                        // (the search keeps the genome's bins in LDS: as much of it as they need)
         try_hip(hipMemcpyAsync(&n_used, h_totals, sizeof(uint32_t), hipMemcpyDeviceToHost, st), KGX_EHIP, "D2H(used bins)");
         try_hip(hipStreamSynchronize(st), KGX_EHIP, "sync");
+        try_hip(hipEventRecord(dev.search_begin, st), KGX_EHIP, "hipEventRecord");
         hipLaunchKernelGGL(k_loglik_search, dim3(static_cast<uint32_t>(n)), dim3(kBlock), loglik_search_lds(n_used), st, h_bins, h_used, h_totals, d_counts, d_sums,
                            d_smallest_het, n, words_per_block, loglik_classes, d_start, objective_method == 1 ? 1 : 0, d_f, d_needs_passes, h_totals + 2, d_running);
         try_hip(hipGetLastError(), KGX_EHIP, "loglik search launch");
+        try_hip(hipEventRecord(dev.search_end, st), KGX_EHIP, "hipEventRecord");
+        search_timed = true;
         uint32_t handed = 0;
         unsigned int evaluations = 0;
         try_hip(hipMemcpyAsync(&handed, h_totals + 2, sizeof(uint32_t), hipMemcpyDeviceToHost, st), KGX_EHIP, "D2H(handed over)");
@@ -829,6 +839,11 @@ int inbreed_shard(kgx_gt8_shard& sh, uint64_t g0, uint64_t g1, const uint32_t* l
       if (hipEventElapsedTime(&ms, dev.kernel_begin, dev.kernel_end) == hipSuccess) dev.last_kernel_ms = ms;
     } else if (rc == KGX_OK) {
       dev.last_sweep_ms = dev.last_kernel_ms = 0.0;
+    }
+    if (rc == KGX_OK) {
+      float ms = 0.f;
+      dev.last_moments_ms = moments_timed && hipEventElapsedTime(&ms, dev.moments_begin, dev.moments_end) == hipSuccess ? ms : 0.0;
+      dev.last_search_ms = search_timed && hipEventElapsedTime(&ms, dev.search_begin, dev.search_end) == hipSuccess ? ms : 0.0;
     }
   }
   return rc;
@@ -1163,6 +1178,22 @@ double kgx_inbreed_last_kernel_ms(void) {
   double worst = 0.0;
   if (rt)
     for (const auto& dev : rt->devs) { const double ms = dev->last_kernel_ms.load(); worst = ms > worst ? ms : worst; }
+  return worst;
+}
+
+double kgx_inbreed_last_moments_ms(void) {
+  const auto rt = current_runtime();
+  double worst = 0.0;
+  if (rt)
+    for (const auto& dev : rt->devs) { const double ms = dev->last_moments_ms.load(); worst = ms > worst ? ms : worst; }
+  return worst;
+}
+
+double kgx_inbreed_last_search_ms(void) {
+  const auto rt = current_runtime();
+  double worst = 0.0;
+  if (rt)
+    for (const auto& dev : rt->devs) { const double ms = dev->last_search_ms.load(); worst = ms > worst ? ms : worst; }
   return worst;
 }
 

@@ -35,11 +35,13 @@ struct Device {
   char arch[64] = {0};
   hipEvent_t sweep_begin = nullptr, sweep_end = nullptr;   // bracket the frequency sweep of the last kgx_inbreed call here
   hipEvent_t kernel_begin = nullptr, kernel_end = nullptr; // ... and the one kernel of it that walks the genotype bytes
+  hipEvent_t moments_begin = nullptr, moments_end = nullptr;   // ... the class passes of a call that ran on moments (sweeps + merges)
+  hipEvent_t search_begin = nullptr, search_end = nullptr;     // ... and the kernel that iterates / searches on them
   hipEvent_t ready = nullptr;                              // cross-stream ordering (kgx_allele_count_by_locus_dev)
   hipEvent_t by_genome_begin = nullptr, by_genome_end = nullptr;   // bracket the K3 kernel of the last by-genome sweep here
   // what the kgx_*_last_* getters report: written by the call that owns `mutex`, read by any thread without it
   std::atomic<double> last_by_genome_ms{0.0};
-  std::atomic<double> last_sweep_ms{0.0}, last_kernel_ms{0.0};
+  std::atomic<double> last_sweep_ms{0.0}, last_kernel_ms{0.0}, last_moments_ms{0.0}, last_search_ms{0.0};
   std::atomic<int> last_evaluations{0};                    // objective evaluations of the last Loglikelihood call here
   std::atomic<int> last_path{0};                           // KGX_PATH_*: what the last kgx_inbreed call here ran on
   char* scratch = nullptr;                                 // grow-only arena for kgx_inbreed's per-call buffers

@@ -163,6 +163,8 @@ Device::~Device() {
   if (sweep_end) (void)hipEventDestroy(sweep_end);
   if (kernel_begin) (void)hipEventDestroy(kernel_begin);
   if (kernel_end) (void)hipEventDestroy(kernel_end);
+  for (hipEvent_t e : {moments_begin, moments_end, search_begin, search_end})
+    if (e) (void)hipEventDestroy(e);
   if (ready) (void)hipEventDestroy(ready);
   if (by_genome_begin) (void)hipEventDestroy(by_genome_begin);
   if (by_genome_end) (void)hipEventDestroy(by_genome_end);
@@ -304,6 +306,10 @@ int kgx_init(int device_count, const int* device_ids) {
       KGX_HIP(hipEventCreate(&dev->sweep_end));
       KGX_HIP(hipEventCreate(&dev->kernel_begin));
       KGX_HIP(hipEventCreate(&dev->kernel_end));
+      KGX_HIP(hipEventCreate(&dev->moments_begin));
+      KGX_HIP(hipEventCreate(&dev->moments_end));
+      KGX_HIP(hipEventCreate(&dev->search_begin));
+      KGX_HIP(hipEventCreate(&dev->search_end));
       KGX_HIP(hipEventCreateWithFlags(&dev->ready, hipEventDisableTiming));
       KGX_HIP(hipEventCreate(&dev->by_genome_begin));
       KGX_HIP(hipEventCreate(&dev->by_genome_end));
