@@ -305,6 +305,24 @@ int kgx_locus_class_frequencies(const double* minor_af, uint64_t n_loci, uint32_
  * inside contraction) of every genome still searching.  Ignored by Simple and RitlandLocus. */
 int kgx_inbreed(kgx_gt8* gt, uint64_t g0, uint64_t g1, const uint32_t* locus_index, uint64_t n_selected,
                 const double* minor_af, uint32_t amax, int phased, int algorithm, const double* start, kgx_locus_results* out);
+/* MANY such calls in one: the INBREED package makes one per (window of ~1000 sampled loci, super population), thousands per
+ * contig, and windows are independent once sampled (kga_analysis_inbreed_diploid.cpp:53-75; a window's super populations
+ * differ only in their frequency rows and genome range) -- so the package samples several windows ahead and hands them over
+ * together.  task i is what kgx_inbreed would be given (host pointers only); amax, phased and algorithm are the batch's.
+ * Where every task selects 1..8192 loci the batch is ONE copy in, TWO launches (the tasks' class-frequency tables, then one
+ * kernel in which a wave or a workgroup per (task, genome) classifies the genome's cells, sums its counts and class
+ * frequencies and runs the estimator's whole iteration) and ONE copy out per device; otherwise it is made of kgx_inbreed
+ * calls.  Results: those of the n_tasks kgx_inbreed calls -- the integers bit for bit, the fp64 sums up to the order of
+ * their additions (<= 1e-12 relative), the iterative estimators as between any two of the library's paths. */
+typedef struct {
+  uint64_t g0, g1;                 /* genomes [g0, g1), g0 a multiple of 4                       */
+  const uint32_t* locus_index;     /* [n_selected] rows of the matrix, ascending; NULL = 0..     */
+  uint64_t n_selected;
+  const double* minor_af;          /* [n_selected][amax]                                         */
+  const double* start;             /* [g1 - g0] or NULL (kgx_inbreed)                            */
+  kgx_locus_results* out;          /* [g1 - g0]                                                  */
+} kgx_inbreed_task;
+int kgx_inbreed_batch(kgx_gt8* gt, const kgx_inbreed_task* tasks, uint32_t n_tasks, uint32_t amax, int phased, int algorithm);
 /* The start points the reference's processHallME / processLogLikelihood end up using, for n genomes.  seed > 0: genome i
  * owns the stream std::mt19937_64(seed + first_stream + i) and draws std::uniform_real_distribution<>(0.5, 0) (HallME,
  * _calc.cpp:237) or (0.5, -0.5) (Loglikelihood, :166) once per restart; out[i] = the fifth draw.  seed 0: fresh entropy

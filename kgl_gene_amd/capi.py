@@ -80,6 +80,7 @@ _SIGNATURES = {
     "kgx_locus_class_frequencies": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint32, C.c_double, C.c_void_p, C.c_void_p]),
     "kgx_inbreed": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint32, C.c_int,
                               C.c_int, C.c_void_p, C.c_void_p]),
+    "kgx_inbreed_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_int, C.c_int]),
     "kgx_inbreed_reference_starts": (C.c_int, [C.c_int, C.c_uint64, C.c_uint64, C.c_uint64, C.c_void_p]),
     "kgx_release_scratch": (C.c_int, []),
     "kgx_count_by_genome_af_bins": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]),
@@ -561,6 +562,31 @@ class GenotypeMatrix:
                                 ALGORITHMS[algorithm], None if st is None else ptr(st), ptr(out)))
         return out
 
+    def inbreed_batch(self, tasks, algorithm: str, phased: bool) -> list:
+        """Many inbreed() calls in one (kgx_inbreed_batch): tasks = dicts with minor_af [n_selected][amax] and optionally
+        locus_index, g0, g1, start -- all with the same amax.  Returns the tasks' result arrays in order."""
+        keep, outs = [], []
+        array = (InbreedTask * len(tasks))()
+        amax = None
+        for i, t in enumerate(tasks):
+            g0 = int(t.get("g0", 0))
+            g1 = int(self.n_genomes if t.get("g1") is None else t["g1"])
+            a = np.ascontiguousarray(t["minor_af"], dtype=np.float64)
+            if a.ndim != 2 or (amax is not None and a.shape[1] != amax):
+                raise ValueError("every task's minor_af must be [n_selected][amax] with one amax")
+            amax = a.shape[1]
+            idx = None if t.get("locus_index") is None else np.ascontiguousarray(t["locus_index"], dtype=np.uint32)
+            st = None if t.get("start") is None else np.ascontiguousarray(t["start"], dtype=np.float64)
+            if st is not None and st.shape != (g1 - g0,):
+                raise ValueError("start must hold one value per genome of the range")
+            out = np.zeros(g1 - g0, dtype=LOCUS_RESULTS_DTYPE)
+            keep += [a, idx, st]
+            outs.append(out)
+            array[i] = InbreedTask(g0, g1, None if idx is None else idx.ctypes.data, a.shape[0], a.ctypes.data, None if st is None else st.ctypes.data,
+                                   out.ctypes.data)
+        check(lib().kgx_inbreed_batch(self._h, C.cast(array, C.c_void_p), len(tasks), int(amax or 1), int(bool(phased)), ALGORITHMS[algorithm]))
+        return outs
+
     def inbreed_objective(self, minor_af: np.ndarray, at, phased: bool, locus_index=None, g0: int = 0, g1: int | None = None,
                           by_passes: bool = False) -> np.ndarray:
         """The log-likelihood of each genome of the range at its point at[g] (kgx_inbreed_objective: a diagnostic) -- from the
@@ -610,6 +636,12 @@ def inbreed_last_kernel_ms() -> float:
 def inbreed_last_sweep_ms() -> float:
     """Device time of the frequency sweep of the most recent GenotypeMatrix.inbreed call (HIP events)."""
     return float(lib().kgx_inbreed_last_sweep_ms())
+
+
+class InbreedTask(C.Structure):
+    """kgx_inbreed_task (kgx.h)"""
+    _fields_ = [("g0", C.c_uint64), ("g1", C.c_uint64), ("locus_index", C.c_void_p), ("n_selected", C.c_uint64), ("minor_af", C.c_void_p),
+                ("start", C.c_void_p), ("out", C.c_void_p)]
 
 
 PATHS = {0: "none", 1: "frequency sweep", 2: "one launch", 3: "hall moments", 4: "hall passes", 5: "loglik moments",

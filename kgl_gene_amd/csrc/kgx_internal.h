@@ -48,6 +48,8 @@ struct Device {
   size_t scratch_bytes = 0;
   char* compact[2] = {nullptr, nullptr};                   // ping-pong buffers of the Loglikelihood search's compaction levels
   size_t compact_bytes[2] = {0, 0};
+  char* pinned[2] = {nullptr, nullptr};                    // kgx_inbreed_batch: page-locked host images of a batch's inputs / results (grow-only)
+  size_t pinned_bytes[2] = {0, 0};
   char* words = nullptr;                                   // Loglikelihood by moments: the class passes' hit bits, [block][genome] (grow-only, like the arena)
   size_t words_bytes = 0;
   void* exchange_stage = nullptr;                          // "peer" exchange: staging for another shard's counts
@@ -88,6 +90,8 @@ struct ScratchPlan {
   }
 };
 int scratch_reserve(Device& dev, size_t bytes, char** out);
+// ... and a page-locked host buffer of the device (which: 0 inputs, 1 results), grown when needed; the caller holds the mutex.
+int pinned_reserve(Device& dev, int which, size_t bytes, char** out);
 
 // Makes `dev` the calling thread's current HIP device.
 int use_device(const Device& dev);

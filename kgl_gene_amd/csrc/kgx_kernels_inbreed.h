@@ -2,6 +2,8 @@
 // per cell: HBM- or VALU-bound, no MFMA.  Included only by kgx_inbreed.hip.
 #ifndef KGX_KERNELS_INBREED_H
 #define KGX_KERNELS_INBREED_H
+// (Two translation units include this header -- kgx_inbreed.hip, kgx_window.hip: the kernels that are not templates are
+// `static`, each unit keeping its own copy of those it launches.)
 
 #include "kgx_kernels_common.h"
 #include "kgx_synth.h"
@@ -769,7 +771,7 @@ k_inbreed_eval_lut(const uint32_t* __restrict__ gt, uint64_t dwords_per_row, uin
 // counts[g][0..5] += the class counters the frequency table pass (k_inbreed_eval_lut<3|4>) left per (segment, genome):
 // majorHom | majorHet << 12 in the low word, minorHom | minorHet << 12 in the high word; total and Ritland count = their sum.
 // blockIdx.y strides the segments.
-__global__ void __launch_bounds__(kBlock)
+static __global__ void __launch_bounds__(kBlock)
 k_reduce_class_counts(const unsigned long long* __restrict__ seg_counts, uint64_t n_seg, uint64_t n_genomes,
                       unsigned long long* __restrict__ counts) {
   const uint64_t g = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
@@ -794,7 +796,7 @@ k_reduce_class_counts(const unsigned long long* __restrict__ seg_counts, uint64_
 // def[seg] = { sum majorHom cf, sum majorHet cf, sum minorHom cf, sum minorHet cf, Ritland sum, #default loci,
 // #Ritland-default loci, 0 }.  One wave per segment; lanes stride the loci, then a wave reduction.
 constexpr int kSegDefaults = 8;
-__global__ void __launch_bounds__(kWave)
+static __global__ void __launch_bounds__(kWave)
 k_segment_defaults(const double* __restrict__ table, const uint8_t* __restrict__ flags, uint64_t n_sel, uint64_t loci_per_seg,
                    uint32_t amax, int class_sums_elsewhere, double* __restrict__ seg_def) {
   const uint64_t seg = blockIdx.x;
@@ -830,7 +832,7 @@ k_segment_defaults(const double* __restrict__ table, const uint8_t* __restrict__
 // classification disagrees with the locus default touch fp64 class sums.  amax <= 4 (wider loci take the generic kernel).
 
 // Sets *found when some byte of the matrix holds an allele index 8..14 (bit 3 of a nibble set, the nibble not 15).
-__global__ void __launch_bounds__(kBlock)
+static __global__ void __launch_bounds__(kBlock)
 k_scan_wide_nibbles(const kgx_v4u* __restrict__ gt, uint64_t n_chunks, unsigned int* __restrict__ found) {
   uint32_t any = 0;
   for (uint64_t i = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n_chunks; i += static_cast<uint64_t>(gridDim.x) * blockDim.x) {
@@ -846,7 +848,7 @@ k_scan_wide_nibbles(const kgx_v4u* __restrict__ gt, uint64_t n_chunks, unsigned 
 }
 
 // meta[s] (for amax <= 7): flag bits (kLocus*) | in_list bits 0..7 << 8 | rit_ok bits << 16 — one scalar dword per locus.
-__global__ void __launch_bounds__(kBlock)
+static __global__ void __launch_bounds__(kBlock)
 k_locus_bits(const double* __restrict__ table, const uint8_t* __restrict__ flags, uint64_t n_sel, uint32_t amax,
              uint32_t* __restrict__ meta) {
   const uint32_t stride = sweep_stride(amax);
@@ -1193,7 +1195,7 @@ k_inbreed_sweep_swar16(const kgx_v4u* __restrict__ gt, uint64_t chunks_per_row, 
 }
 
 // part[(seg, g)][0..4] = segment defaults (class-frequency sums of a genome that is reference-homozygous throughout).
-__global__ void __launch_bounds__(kBlock)
+static __global__ void __launch_bounds__(kBlock)
 k_fill_defaults(const double* __restrict__ seg_def, uint64_t n_seg, uint64_t n_genomes, double* __restrict__ part) {
   const uint64_t total = n_seg * n_genomes;
   for (uint64_t i = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < total;
@@ -1210,7 +1212,7 @@ k_fill_defaults(const double* __restrict__ seg_def, uint64_t n_seg, uint64_t n_g
 // base (may be null): kParts0 values added to every genome's kParts0 sums -- the class-frequency sums of the defaults
 // when they are kept apart from the genomes' corrections (k_seq_chain).
 constexpr uint32_t kReduceItems = 16, kReduceSlices = kBlock / kReduceItems;
-__global__ void __launch_bounds__(kBlock)
+static __global__ void __launch_bounds__(kBlock)
 k_reduce_parts(const double* __restrict__ part, uint64_t n_seg, uint64_t n_items, const double* __restrict__ base, double* __restrict__ out) {
   __shared__ double slice_sum[kReduceSlices][kReduceItems + 1];
   const uint32_t item = threadIdx.x % kReduceItems, slice = threadIdx.x / kReduceItems;
@@ -1251,7 +1253,7 @@ k_reduce_parts(const double* __restrict__ part, uint64_t n_seg, uint64_t n_items
 constexpr int kSeqBlock = 1024;
 constexpr int kSeqWalk = -(1 << 30);          // e_pred: sum this block locus by locus
 
-__global__ void __launch_bounds__(kBlock)
+static __global__ void __launch_bounds__(kBlock)
 k_seq_block_sums(const double* __restrict__ table, const uint8_t* __restrict__ flags, uint64_t n_sel, uint32_t amax,
                  double* __restrict__ block_sum /* [n_blocks][4] */) {
   __shared__ double sh[4][kBlock / kWave];
@@ -1281,7 +1283,7 @@ k_seq_block_sums(const double* __restrict__ table, const uint8_t* __restrict__ f
 // One workgroup: the exclusive prefix of the block sums, and from it the binade (exponent of the running sum) block b
 // of class sum k is added in -- if the prefix and the prefix plus the block lie in one binade with a margin (1e-9
 // relative: the sequential sum is within ~1e-11 of these plainly added prefixes), else kSeqWalk.
-__global__ void __launch_bounds__(kBlock)
+static __global__ void __launch_bounds__(kBlock)
 k_seq_block_predict(const double* __restrict__ block_sum, uint64_t n_blocks, int* __restrict__ e_pred /* [n_blocks][4] */) {
   __shared__ double scan[4][kBlock];
   double carry[4] = {0.0, 0.0, 0.0, 0.0};
@@ -1322,7 +1324,7 @@ k_seq_block_predict(const double* __restrict__ block_sum, uint64_t n_blocks, int
 }
 
 // N[b][k] = sum over the block's default loci of rint(x * 2^(52 - e)): the block's sum in units of the binade's ulp.
-__global__ void __launch_bounds__(kBlock)
+static __global__ void __launch_bounds__(kBlock)
 k_seq_block_quantize(const double* __restrict__ table, const uint8_t* __restrict__ flags, uint64_t n_sel, uint32_t amax,
                      const int* __restrict__ e_pred, long long* __restrict__ block_n /* [n_blocks][4] */) {
   __shared__ long long sh[4][kBlock / kWave];
@@ -1360,7 +1362,7 @@ k_seq_block_quantize(const double* __restrict__ table, const uint8_t* __restrict
 // binade their integer sums are added up across the lanes and taken in one step (every partial sum lies between the two
 // ends, so it stays in the binade as well); otherwise block by block; a block that has to be walked has its 1024 values
 // fetched first (16 loads in flight) and then added one by one, as the reference adds them.
-__global__ void __launch_bounds__(kBlock)
+static __global__ void __launch_bounds__(kBlock)
 k_seq_chain(const double* __restrict__ table, const uint8_t* __restrict__ flags, uint64_t n_sel, uint32_t amax,
             const int* __restrict__ e_pred, const long long* __restrict__ block_n, uint64_t n_blocks, double* __restrict__ out /* [kParts0] */) {
   const int k = threadIdx.x / kWave;
@@ -1406,7 +1408,7 @@ k_seq_chain(const double* __restrict__ table, const uint8_t* __restrict__ flags,
 
 // processHallME's update: F <- expectation_sum / N (N = all classified loci, _calc.cpp:283).  walked > 0: the sums
 // come from k_inbreed_eval_lut<1> (sum over homozygous cells of 1/den, plus 1 for every other locus slot walked).
-__global__ void __launch_bounds__(kBlock)
+static __global__ void __launch_bounds__(kBlock)
 k_hall_update(const double* __restrict__ expectation_sum, const unsigned long long* __restrict__ counts, uint64_t n,
               unsigned long long walked, double* __restrict__ f) {
   for (uint64_t g = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x; g < n;
@@ -1425,7 +1427,7 @@ k_hall_update(const double* __restrict__ expectation_sum, const unsigned long lo
 // phase 2: f_eval is the value at the newly placed point.
 struct GoldenState { double a, b, c, d, fc, fd; int last_was_c; int pad; };
 
-__global__ void __launch_bounds__(kBlock)
+static __global__ void __launch_bounds__(kBlock)
 k_golden_step(GoldenState* __restrict__ st, const double* __restrict__ f_eval, uint64_t n, int phase, double* __restrict__ f_next) {
   const double inv_phi = 0.6180339887498949;
   for (uint64_t g = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x; g < n;
@@ -1668,7 +1670,7 @@ __device__ __forceinline__ void nm2_advance(BrentState& s, double f0, double f1)
   s.widened = kNm2Reflect;
 }
 
-__global__ void __launch_bounds__(kBlock)
+static __global__ void __launch_bounds__(kBlock)
 k_brent_init(const unsigned long long* __restrict__ counts, const double* __restrict__ sums, uint64_t n, int use_estimate, int search,
              const double* __restrict__ start, BrentState* __restrict__ st, double* __restrict__ f_next) {
   for (uint64_t g = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x; g < n;
@@ -1683,7 +1685,7 @@ k_brent_init(const unsigned long long* __restrict__ counts, const double* __rest
 
 // global_of / result (both or neither): the states are a compacted subset of the call's genomes (see kgx_inbreed);
 // a genome's coefficient goes to result[global_of[g]] when its search ends.
-__global__ void __launch_bounds__(kBlock)
+static __global__ void __launch_bounds__(kBlock)
 k_brent_step(BrentState* __restrict__ st, const double* __restrict__ f_eval, uint64_t n, int mode, int search, double* __restrict__ f_next,
              unsigned int* __restrict__ still_running, const uint32_t* __restrict__ global_of, double* __restrict__ result) {
   for (uint64_t g = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x; g < n;
@@ -1709,7 +1711,7 @@ k_brent_step(BrentState* __restrict__ st, const double* __restrict__ f_eval, uin
 
 // Compaction of the genomes still searching (kgx_inbreed, Loglikelihood): their genotype columns, dense in the selected
 // loci, and their search states.
-__global__ void __launch_bounds__(kBlock)
+static __global__ void __launch_bounds__(kBlock)
 k_gather_columns(const uint8_t* __restrict__ src, uint64_t src_pitch, uint64_t src_g0, const uint32_t* __restrict__ locus_index,
                  uint64_t n_sel, const uint32_t* __restrict__ columns, uint64_t n_columns, uint8_t* __restrict__ dst, uint64_t dst_pitch) {
   // a thread owns four consecutive output columns: four byte reads out of one (cached) source row, one dword store
@@ -1729,7 +1731,7 @@ k_gather_columns(const uint8_t* __restrict__ src, uint64_t src_pitch, uint64_t s
   }
 }
 
-__global__ void __launch_bounds__(kBlock)
+static __global__ void __launch_bounds__(kBlock)
 k_gather_states(const BrentState* __restrict__ st, const double* __restrict__ f, uint64_t n_source, int planes, const uint32_t* __restrict__ columns,
                 uint64_t n_columns, BrentState* __restrict__ st_out, double* __restrict__ f_out) {
   for (uint64_t j = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x; j < n_columns;
@@ -1884,7 +1886,7 @@ struct LocusResultsDev {
   unsigned long long total_allele_count; double inbred_allele_sum;
 };
 
-__global__ void __launch_bounds__(kBlock)
+static __global__ void __launch_bounds__(kBlock)
 k_finish_inbreed(const unsigned long long* __restrict__ counts, const double* __restrict__ sums, uint64_t n, int algorithm,
                  const double* __restrict__ f, LocusResultsDev* __restrict__ out) {
   for (uint64_t g = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x; g < n;
@@ -1914,7 +1916,7 @@ k_finish_inbreed(const unsigned long long* __restrict__ counts, const double* __
 
 // Synthetic multi-allelic genotype bytes straight into HBM (one thread per dword = 4 genomes of one locus),
 // plus the per-locus SNP allele-frequency table [n_loci][3] (NaN padded) the inbreeding sweep needs.
-__global__ void __launch_bounds__(kBlock)
+static __global__ void __launch_bounds__(kBlock)
 k_synth_gt8(uint32_t* __restrict__ gt, uint64_t dwords_per_row, uint64_t n_loci, uint64_t n_genomes, uint64_t seed,
             uint64_t genome_base, uint64_t locus_base, double* __restrict__ af_table) {
   const uint64_t quads = (n_genomes + 3) / 4;
@@ -1948,7 +1950,7 @@ k_synth_gt8(uint32_t* __restrict__ gt, uint64_t dwords_per_row, uint64_t n_loci,
 // (kga_analysis_inbreed_freq.cpp:221-420).  The reference draws from std::random_device; here Philox4x32-10 keyed by
 // `seed`, counter (locus, genome_base + genome, KGX_STREAM_SELFCHECK).  One thread per (locus, genome) byte of a shard
 // whose first genome is genome_base.
-__global__ void __launch_bounds__(kBlock)
+static __global__ void __launch_bounds__(kBlock)
 k_synth_inbred(uint8_t* __restrict__ gt, uint64_t pitch, uint64_t n_loci, uint64_t n_genomes, const double* __restrict__ af_table,
                uint32_t amax, const double* __restrict__ inbreeding, uint64_t seed, uint64_t genome_base) {
   const uint64_t total = n_loci * n_genomes;
@@ -2032,7 +2034,7 @@ k_synth_inbred(uint8_t* __restrict__ gt, uint64_t pitch, uint64_t n_loci, uint64
 }
 
 // Pack caller genome-major bytes [n][n_loci] into locus-major gt8 rows (one thread per output dword).
-__global__ void __launch_bounds__(kBlock)
+static __global__ void __launch_bounds__(kBlock)
 k_gt8_transpose(const uint8_t* __restrict__ src, uint64_t n_src, uint64_t n_loci, uint64_t g0, uint8_t* __restrict__ gt, uint64_t pitch) {
   const uint64_t total = n_src * n_loci;
   for (uint64_t i = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < total;

@@ -11,6 +11,7 @@
 
 #include <cstdint>
 
+#include "../../include/kgx.h"
 #include "kgx_kernels_inbreed.h"
 
 namespace kgx {

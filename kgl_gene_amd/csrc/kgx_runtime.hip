@@ -133,6 +133,24 @@ int scratch_reserve(Device& dev, size_t bytes, char** out) {
   return KGX_OK;
 }
 
+int pinned_reserve(Device& dev, int which, size_t bytes, char** out) {
+  if (bytes > dev.pinned_bytes[which]) {
+    if (dev.pinned[which]) (void)hipHostFree(dev.pinned[which]);
+    dev.pinned[which] = nullptr;
+    dev.pinned_bytes[which] = 0;
+    const size_t want = bytes + bytes / 4;
+    void* p = nullptr;
+    if (hipHostMalloc(&p, want, hipHostMallocDefault) != hipSuccess) {
+      (void)hipGetLastError();
+      return fail(KGX_ENOMEM, "hipHostMalloc of %llu bytes failed", static_cast<unsigned long long>(want));
+    }
+    dev.pinned[which] = static_cast<char*>(p);
+    dev.pinned_bytes[which] = want;
+  }
+  *out = dev.pinned[which];
+  return KGX_OK;
+}
+
 int use_device(const Device& dev) {
   KGX_HIP(hipSetDevice(dev.id));
   return KGX_OK;
@@ -158,6 +176,8 @@ Device::~Device() {
   for (int k = 0; k < 2; ++k)
     if (compact[k]) (void)hipFree(compact[k]);
   if (words) (void)hipFree(words);
+  for (int k = 0; k < 2; ++k)
+    if (pinned[k]) (void)hipHostFree(pinned[k]);
   if (exchange_stage) (void)hipFree(exchange_stage);
   if (sweep_begin) (void)hipEventDestroy(sweep_begin);
   if (sweep_end) (void)hipEventDestroy(sweep_end);
@@ -410,6 +430,11 @@ int kgx_release_scratch(void) {
       if (dev->words) (void)hipFree(dev->words);
       dev->words = nullptr;
       dev->words_bytes = 0;
+      for (int k = 0; k < 2; ++k) {
+        if (dev->pinned[k]) (void)hipHostFree(dev->pinned[k]);
+        dev->pinned[k] = nullptr;
+        dev->pinned_bytes[k] = 0;
+      }
     }
     return use_device(*rt->devs[0]);
   });

@@ -847,3 +847,66 @@ def test_loglikelihood_by_moments_hands_over_what_it_cannot_serve(kgx, monkeypat
     m.inbreed(table, "Loglikelihood", phased=False, start=start)
     assert kgx.inbreed_last_path() == "loglik passes", kgx.inbreed_last_path()
     m.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("algorithm", ["Simple", "RitlandLocus", "HallME", "Loglikelihood"])
+def test_batched_windows_are_the_single_calls(kgx, algorithm, monkeypatch):
+    """kgx_inbreed_batch -- many (window, super population) tasks in one launch (kgx_kernels_window.h) -- against the same
+    tasks as kgx_inbreed calls: the counts bit for bit, the class-frequency sums to 1e-12 (another order of the same
+    additions), Simple / RitlandLocus to 1e-10, HallME to 1e-9, Loglikelihood to 2e-6 on genomes with F >= 0 (as between
+    any two paths of the library).  Task shapes: genome ranges of every size and offset (a super population's), locus lists
+    from 1 to 8192 of a 9000-locus matrix, with and without start points, a dense one (no index); a batch holding a task
+    past 8192 loci is made of single calls."""
+    G, L = 1310, 9000
+    m = kgx.GenotypeMatrix(G, L)
+    table = m.synth_multiallelic(1111, 0, 0)
+    f_true = ((np.arange(G) % 101) - 50) / 100.0
+    rng = np.random.default_rng(17)
+    ranges = [(0, 347), (348, 1009), (1012, G), (0, G), (4, 5), (640, 1144)]
+    tasks = []
+    for k, n_sel in enumerate((1000, 997, 1, 255, 1024, 1025, 2048, 3000, 8192, 1000, 640, 100)):
+        g0, g1 = ranges[k % len(ranges)]
+        index = np.sort(rng.choice(L, n_sel, replace=False)).astype(np.uint32)
+        start = kgx.reference_starts(algorithm, START_SEED + k, g1 - g0) if algorithm in ("HallME", "Loglikelihood") and k % 3 != 2 else None
+        tasks.append({"g0": g0, "g1": g1, "locus_index": index, "minor_af": np.ascontiguousarray(table[index]), "start": start})
+    tasks.append({"g0": 0, "g1": 600, "locus_index": None, "minor_af": np.ascontiguousarray(table[:1500]), "start": None})
+    tolerance = {"Simple": 1e-10, "RitlandLocus": 1e-10, "HallME": 1e-9, "Loglikelihood": 2e-6}[algorithm]
+
+    def compare(batch, label, tasks):
+        for k, (t, got) in enumerate(zip(tasks, batch)):
+            want = m.inbreed(t["minor_af"], algorithm, phased=True, locus_index=t["locus_index"], g0=t["g0"], g1=t["g1"], start=t["start"])
+            ctx = (label, algorithm, k, len(t["minor_af"]), t["g0"], t["g1"])
+            for name in ("major_hetero_count", "minor_hetero_count", "minor_homo_count", "major_homo_count", "total_allele_count"):
+                assert np.array_equal(got[name], want[name]), ctx + (name,)
+            for name in ("major_hetero_freq", "minor_hetero_freq", "minor_homo_freq", "major_homo_freq"):
+                assert np.allclose(got[name], want[name], rtol=REL, atol=REL), ctx + (name,)
+            a, b = got["inbred_allele_sum"], want["inbred_allele_sum"]
+            assert np.array_equal(np.isfinite(a), np.isfinite(b)), ctx
+            both = np.isfinite(b)
+            if algorithm == "Loglikelihood":
+                both &= f_true[t["g0"]:t["g1"]] >= 0.0
+                if len(t["minor_af"]) < 255:
+                    continue                                  # (a handful of loci: a flat objective, several maxima)
+            assert np.all(np.abs(a[both] - b[both]) <= tolerance * np.maximum(1.0, np.abs(b[both]))), ctx + (float(np.abs(a[both] - b[both]).max()),)
+
+    small = [t for t in tasks if len(t["minor_af"]) <= 1024]   # (a wave per genome holds at most 1024 loci: KGX_K7_WAVE_LOCI)
+    medium = [t for t in tasks if len(t["minor_af"]) <= 2048]
+    for subset, wave_loci in ((tasks, None), (small, None), (medium, "2048")):
+        for wave_from in (None, "1", "1000000"):              # the library's choice / a wave per genome / a block per genome
+            if wave_from:
+                monkeypatch.setenv("KGX_K7_WAVE_GENOMES", wave_from)
+            if wave_loci:
+                monkeypatch.setenv("KGX_K7_WAVE_LOCI", wave_loci)
+            batch = m.inbreed_batch(subset, algorithm, phased=True)
+            assert kgx.inbreed_last_path() == "one launch"
+            monkeypatch.delenv("KGX_K7_WAVE_GENOMES", raising=False)
+            monkeypatch.delenv("KGX_K7_WAVE_LOCI", raising=False)
+            compare(batch, (len(subset), wave_from, wave_loci), subset)
+    # a task the one-launch kernel does not hold: the batch is made of single calls, with their results
+    tasks.append({"g0": 0, "g1": 400, "locus_index": None, "minor_af": np.ascontiguousarray(table[:8500]), "start": None})
+    batch = m.inbreed_batch(tasks, algorithm, phased=True)
+    for t, got in zip(tasks[-2:], batch[-2:]):
+        want = m.inbreed(t["minor_af"], algorithm, phased=True, locus_index=t["locus_index"], g0=t["g0"], g1=t["g1"], start=t["start"])
+        assert np.array_equal(got["inbred_allele_sum"], want["inbred_allele_sum"], equal_nan=True)
+    m.close()
