@@ -538,6 +538,7 @@ def aux_window_calls(args, capi):
             start = np.empty(G)
             start[order] = capi.reference_starts(algorithm, seed, G)
         got = m.inbreed(sub, algorithm, phased=True, locus_index=index, start=start)
+        got_first = got.copy()
         reps = 200
         t0 = time.perf_counter()
         for _ in range(reps):
@@ -555,6 +556,21 @@ def aux_window_calls(args, capi):
                              "parity_ok": ok}}
         if algorithm == "Loglikelihood":
             out["algorithms"][algorithm]["evaluations"] = capi.inbreed_last_evaluations()
+        # ... and as the package issues them since round 4: K windows sampled ahead, ONE kgx_inbreed_batch for all of them
+        # (one copy in, two launches, one copy out; kgx_kernels_window.h) -- here 16 windows of the same size, shifted by a locus each
+        K = 16
+        tasks = [{"locus_index": index + k, "minor_af": np.ascontiguousarray(table[index + k]), "start": start} for k in range(K)]
+        batch = m.inbreed_batch(tasks, algorithm, phased=True)
+        same = all(np.array_equal(batch[0][name], got_first[name]) for name in names) and \
+            float(np.nanmax(np.abs(batch[0]["inbred_allele_sum"] - got_first["inbred_allele_sum"]))) <= tolerance[algorithm]
+        reps = 20
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            m.inbreed_batch(tasks, algorithm, phased=True)
+        per_window = (time.perf_counter() - t0) / (reps * K)
+        out["algorithms"][algorithm]["batched"] = {"windows_per_batch": K, "ms_per_window": per_window * 1e3, "windows_per_s": 1.0 / per_window,
+                                                   "speedup_over_single_calls": per_call / per_window,
+                                                   "first_window_equals_the_single_call": bool(same)}
     out["value"] = out["algorithms"]["Simple"]["value"]
     m.close()
     capi.release_scratch()

@@ -1,6 +1,7 @@
 #include "kga_analysis_gpu_inbreed.h"
 
 #include <algorithm>
+#include <future>
 #include <atomic>
 #include <thread>
 #include <cmath>
@@ -193,6 +194,7 @@ bool kga::GpuInbreedAnalysis::initializeAnalysis(const std::string& work_directo
     {
       if (auto v = parameter_map.getSize("SyntheticSeed")) synthetic_seed_ = v.value().front();
       if (auto v = parameter_map.getSize("StartSeed")) start_seed_ = v.value().front();
+      if (auto v = parameter_map.getSize("WindowBatch")) window_batch_ = std::max<size_t>(1, v.value().front());
       if (auto v = parameter_map.getString("StartPoints")) start_midpoints_ = v.value().front() == "Midpoint";
     }
   for (const auto& parameter : extractParameters(named_parameters)) {
@@ -518,56 +520,108 @@ bool kga::GpuInbreedAnalysis::populationInbreeding(GpuParamOutput& param_output)
     }
   }
 
-  // The window loop of InbreedingAnalysis::populationInbreeding (_diploid.cpp:43-75).
+  // The window loop of InbreedingAnalysis::populationInbreeding (_diploid.cpp:43-75).  Windows are independent once sampled --
+  // a window's bounds follow from the reference contig alone, its super populations differ in their frequency rows and
+  // genome range -- so WindowBatch windows (default 16) are sampled ahead on the host and go to the device together
+  // (kgx_inbreed_batch: one copy in, two launches, one copy out for all their (window, super population) tasks), and the
+  // next batch is sampled while the device works on this one.
   const int all_slot = static_cast<int>(std::find(super_pops.begin(), super_pops.end(), std::string(FrequencyDatabaseRead::SUPER_POP_ALL_)) - super_pops.begin());
   GpuLociiArguments local = params.locii;
   std::vector<uint32_t> locii_vector = reference.sampleLocii(all_slot, local, true);
   if (locii_vector.empty()) return true;
   local.upper_offset = reference.loci[locii_vector.back()].offset;
-  std::vector<double> af_table;
-  std::vector<kgx_locus_results> device_results;
+  struct PendingTask { size_t sp; std::vector<uint32_t> selected; std::vector<double> af, start; std::vector<kgx_locus_results> results; };
+  struct PendingWindow { std::string column_ident; std::vector<PendingTask> tasks; };
   std::vector<uint64_t> streams;
-  while (local.upper_offset < params.locii.upper_offset && locii_vector.size() >= 100) {
-    GpuResultColumn column;
+  bool start_failed = false;
+  // the window at `local`, then `local` moved on to the next; false once the reference's loop would have ended
+  auto nextWindow = [&](PendingWindow& window) -> bool {
+    if (!(local.upper_offset < params.locii.upper_offset && locii_vector.size() >= 100)) return false;
     {
       std::stringstream ss;
       ss << reference.contig_id << "_" << local.lower_offset << "_" << local.upper_offset;
-      column.column_ident = ss.str();
+      window.column_ident = ss.str();
     }
     for (size_t sp = 0; sp < super_pops.size(); ++sp) {
       const uint64_t n = range_end[sp] - range_begin[sp];
       if (n == 0) continue;
-      const std::vector<uint32_t> selected = reference.sampleLocii(static_cast<int>(sp), local, false);   // getLocusList (_locus.cpp:263-326)
-      af_table.assign(selected.size() * amax, kNaN);
-      for (size_t s = 0; s < selected.size(); ++s) reference.alleleFreqRow(selected[s], static_cast<int>(sp), &af_table[s * amax], amax);
-      device_results.assign(n, kgx_locus_results{});
+      PendingTask task;
+      task.sp = sp;
+      task.selected = reference.sampleLocii(static_cast<int>(sp), local, false);   // getLocusList (_locus.cpp:263-326)
+      task.af.assign(task.selected.size() * amax, kNaN);
+      for (size_t s = 0; s < task.selected.size(); ++s) reference.alleleFreqRow(task.selected[s], static_cast<int>(sp), &task.af[s * amax], amax);
+      task.results.assign(n, kgx_locus_results{});
       streams.resize(n);
       for (uint64_t k = 0; k < n; ++k) streams[k] = by_super_pop[sp][k].stream;
-      const std::vector<double> start = startPoints(algorithm, streams);
-      if (kgx_inbreed(dev.handle, range_begin[sp], range_end[sp], selected.data(), selected.size(), af_table.data(), amax, phased ? 1 : 0,
-                      algorithm, start.empty() ? nullptr : start.data(), device_results.data()) != KGX_OK) {
-        ExecEnv::log().error("GpuInbreedAnalysis; inbreeding sweep failed: {}", kgx_last_error());
-        return false;
-      }
-      for (uint64_t k = 0; k < n; ++k) {
-        const kgx_locus_results& d = device_results[k];
-        GpuLocusResults r;
-        r.genome = by_super_pop[sp][k].id;
-        r.major_hetero_count = d.major_hetero_count;  r.major_hetero_freq = d.major_hetero_freq;
-        r.minor_hetero_count = d.minor_hetero_count;  r.minor_hetero_freq = d.minor_hetero_freq;
-        r.minor_homo_count = d.minor_homo_count;      r.minor_homo_freq = d.minor_homo_freq;
-        r.major_homo_count = d.major_homo_count;      r.major_homo_freq = d.major_homo_freq;
-        r.total_allele_count = d.total_allele_count;  r.inbred_allele_sum = d.inbred_allele_sum;
-        column.results[r.genome] = r;
-      }
+      task.start = startPoints(algorithm, streams);
+      const bool wants_start = !start_midpoints_ && (algorithm == KGX_ALGO_HALL_ME || algorithm == KGX_ALGO_LOGLIKELIHOOD);
+      if (wants_start && task.start.empty()) start_failed = true;
+      window.tasks.push_back(std::move(task));
     }
-    param_output.columns.push_back(std::move(column));
     local.lower_offset = local.upper_offset;
     locii_vector = reference.sampleLocii(all_slot, local, true);
-    if (locii_vector.empty()) break;
-    local.upper_offset = reference.loci[locii_vector.back()].offset;
+    if (locii_vector.empty()) local.upper_offset = params.locii.upper_offset;      // (the loop's `break`)
+    else local.upper_offset = reference.loci[locii_vector.back()].offset;
+    return true;
+  };
+  auto sampleBatch = [&](std::vector<PendingWindow>& batch) {
+    batch.clear();
+    while (batch.size() < window_batch_) {
+      PendingWindow window;
+      if (!nextWindow(window)) break;
+      batch.push_back(std::move(window));
+    }
+  };
+  auto runBatch = [&](std::vector<PendingWindow>& batch) -> std::string {      // on the device; "" = fine
+    std::vector<kgx_inbreed_task> tasks;
+    for (PendingWindow& window : batch)
+      for (PendingTask& task : window.tasks) {
+        kgx_inbreed_task t;
+        t.g0 = range_begin[task.sp];
+        t.g1 = range_end[task.sp];
+        t.locus_index = task.selected.data();
+        t.n_selected = task.selected.size();
+        t.minor_af = task.af.data();
+        t.start = task.start.empty() ? nullptr : task.start.data();
+        t.out = task.results.data();
+        tasks.push_back(t);
+      }
+    if (tasks.empty()) return std::string();
+    if (kgx_inbreed_batch(dev.handle, tasks.data(), static_cast<uint32_t>(tasks.size()), amax, phased ? 1 : 0, algorithm) != KGX_OK) return kgx_last_error();
+    return std::string();
+  };
+  std::vector<PendingWindow> current, ahead;
+  sampleBatch(current);
+  while (!current.empty()) {
+    if (start_failed) return false;
+    // (kgx_last_error is the calling thread's: the worker hands its message back)
+    std::future<std::string> on_device = std::async(std::launch::async, [&]() { return runBatch(current); });
+    sampleBatch(ahead);
+    const std::string failure = on_device.get();
+    if (!failure.empty()) {
+      ExecEnv::log().error("GpuInbreedAnalysis; inbreeding sweep failed: {}", failure);
+      return false;
+    }
+    for (PendingWindow& window : current) {
+      GpuResultColumn column;
+      column.column_ident = window.column_ident;
+      for (const PendingTask& task : window.tasks)
+        for (uint64_t k = 0; k < task.results.size(); ++k) {
+          const kgx_locus_results& d = task.results[k];
+          GpuLocusResults r;
+          r.genome = by_super_pop[task.sp][k].id;
+          r.major_hetero_count = d.major_hetero_count;  r.major_hetero_freq = d.major_hetero_freq;
+          r.minor_hetero_count = d.minor_hetero_count;  r.minor_hetero_freq = d.minor_hetero_freq;
+          r.minor_homo_count = d.minor_homo_count;      r.minor_homo_freq = d.minor_homo_freq;
+          r.major_homo_count = d.major_homo_count;      r.major_homo_freq = d.major_homo_freq;
+          r.total_allele_count = d.total_allele_count;  r.inbred_allele_sum = d.inbred_allele_sum;
+          column.results[r.genome] = r;
+        }
+      param_output.columns.push_back(std::move(column));
+    }
+    current.swap(ahead);
   }
-  return true;
+  return !start_failed;
 }
 
 std::vector<double> kga::GpuInbreedAnalysis::startPoints(int algorithm, const std::vector<uint64_t>& streams) const {

@@ -140,6 +140,7 @@ class GpuInbreedAnalysis : public VirtualAnalysis {
   // reference's start intervals (0.25 / 0.0) -- a deterministic mode the reference does not have.
   uint64_t start_seed_{0};
   bool start_midpoints_{false};
+  size_t window_batch_{16};                       // parameter WindowBatch: windows sampled ahead and handed to the device together (kgx_inbreed_batch)
   mutable std::array<std::vector<double>, 2> seeded_starts_;    // [HallME, Loglikelihood][stream]: drawn once under a StartSeed
   // The start points of n tasks, the first of which is the first_stream-th enqueued; empty = midpoints (or not iterative).
   [[nodiscard]] std::vector<double> startPoints(int algorithm, const std::vector<uint64_t>& streams) const;

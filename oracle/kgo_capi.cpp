@@ -720,6 +720,29 @@ int kgo_inbreed_window(kgo_pop* reference, kgo_pop* diploid, const int32_t* supe
   return 0;
 }
 
+// The 1-D Nelder-Mead the oracle restates nlopt's LN_NELDERMEAD with (neldermead1D), run on a closed-form objective over the
+// reference's box [-1, 1] with its stopping rule (xtol_abs 1e-6, 500 evaluations): the points it evaluates, in order, so
+// that tests/test_oracle_pins.py can pin every assumption about nlopt's behaviour that DESIGN.md lists.
+// objective 0: -(x - a)^2;  1: -|x - a|;  2: a * x (monotone: the optimum on a bound);  3: a two-level step, 1 for x >= a else 0.
+int kgo_neldermead_path(int objective, double a, double x0, double* path, int max_path, int* n_path, double* result) {
+  if (!path || !n_path || !result || max_path <= 0) return -1;
+  int n = 0;
+  auto f = [&](double x) {
+    if (n < max_path) path[n] = x;
+    ++n;
+    switch (objective) {
+      case 0: return -(x - a) * (x - a);
+      case 1: return -std::fabs(x - a);
+      case 2: return a * x;
+      default: return x >= a ? 1.0 : 0.0;
+    }
+  };
+  int evaluations = 0;
+  *result = neldermead1D(f, x0, -1.0, 1.0, 1e-06, 500, &evaluations);
+  *n_path = n;
+  return evaluations == n ? 0 : -2;
+}
+
 // logLikelihood (_calc.cpp:94-129) of every genome at a caller-chosen coefficient: the objective processLogLikelihood
 // maximises, over the same window and locus lists as kgo_inbreed_window.  f[G] / out[G] in genome-id order.
 int kgo_loglikelihood_at(kgo_pop* reference, kgo_pop* diploid, const int32_t* super_pop_of_genome, uint64_t lower, uint64_t upper,

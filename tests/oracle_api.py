@@ -79,6 +79,7 @@ def lib() -> C.CDLL:
         "kgo_sample_locii": (i64, [vp, C.c_int, C.c_int, u64, u64, u64, u64, dbl, dbl, vp, u64]),
         "kgo_inbreed_window": (C.c_int, [vp, vp, vp, C.c_char_p, u64, u64, u64, u64, dbl, dbl, u64, vp, vp, vp, vp]),
         "kgo_restart_draws": (C.c_int, [C.c_char_p, u64, u64, u64, vp]),
+        "kgo_neldermead_path": (C.c_int, [C.c_int, dbl, dbl, vp, C.c_int, vp, vp]),
         "kgo_loglikelihood_at": (C.c_int, [vp, vp, vp, u64, u64, u64, dbl, dbl, vp, vp]),
         "kgo_inbreed_dense": (C.c_int, [vp, vp, C.c_int, u64, u64, u64, dbl, dbl, vp, u64, vp, u64, C.c_int, vp, vp, vp]),
         "kgo_population_inbreeding": (vp, [vp, vp, vp, C.c_char_p, u64, u64, u64, u64, dbl, dbl, u64]),
@@ -435,6 +436,16 @@ def restart_draws(algorithm, seed, n, restarts=5):
     out = np.zeros((n, restarts), dtype=np.float64)
     assert lib().kgo_restart_draws(algorithm.encode(), int(seed), int(n), int(restarts), _p(out)) == 0
     return out
+
+
+def neldermead_path(objective: int, a: float, x0: float):
+    """The oracle's 1-D Nelder-Mead (its restatement of nlopt's LN_NELDERMEAD) on a closed-form objective over [-1, 1]:
+    (points evaluated in order, result).  objective 0: -(x-a)^2, 1: -|x-a|, 2: a*x, 3: step at a."""
+    path = np.zeros(600, dtype=np.float64)
+    n = C.c_int(0)
+    result = C.c_double(0.0)
+    assert lib().kgo_neldermead_path(objective, a, x0, _p(path), len(path), C.byref(n), C.byref(result)) == 0
+    return path[:n.value].copy(), result.value
 
 
 def loglikelihood_at(reference: Population, diploid: Population, super_pop_of_genome, lower, upper, spacing, min_af, max_af, f):

@@ -418,3 +418,85 @@ def test_dense_inbreeding_tier_is_generate_frequencies_bit_for_bit():
                 assert np.array_equal(f[:, 4], freqs[:, column]), algorithm
             assert counts[:, 4].min() > 10 and counts[:, 1].sum() > 0
             assert (counts[:, 2].sum() > 0) == phased          # unphased 1/1 is not homozygous(): a minor heterozygote
+
+
+# ---- the optimiser behind Loglikelihood: what the restatement of nlopt's LN_NELDERMEAD assumes ----
+# nlopt itself is not in /root/reference (CMakeLists.txt:665 names the library only): these pin the RESTATEMENT's behaviour,
+# assumption by assumption, so that a maintainer with nlopt at hand can check each against the real thing.
+
+def test_neldermead_first_simplex_is_a_quarter_of_the_box_turned_inward_at_a_bound():
+    # nlopt's default initial step for a bounded variable: (ub - lb) / 4 = 0.5, taken towards the upper bound unless that
+    # leaves the box, then towards the lower one
+    for x0, second in ((0.0, 0.5), (-0.5, 0.0), (0.5, 1.0), (0.5000001, 0.0000001), (0.9, 0.4), (-1.0, -0.5), (1.0, 0.5)):
+        path, _ = oa.neldermead_path(0, 0.123, x0)
+        assert path[0] == x0 and abs(path[1] - second) < 1e-15, (x0, path[:2])
+
+
+def test_neldermead_steps_reflection_expansion_contractions():
+    # maximise -(x - 0.3)^2 from 0: simplex {0, 0.5}, values -0.09, -0.04 -> best 0.5, worst 0
+    path, result = oa.neldermead_path(0, 0.3, 0.0)
+    assert path[:2].tolist() == [0.0, 0.5]
+    assert path[2] == 1.0                      # reflection of the worst through the best: 0.5 + (0.5 - 0) = 1.0 (on the bound)
+    assert path[3] == 0.25                     # f(1.0) = -0.49 is worse than the worst: inside contraction, halfway best -> worst
+    # 0.25 (-0.0025) beats 0.5: the simplex is {0.25 best, 0.5 worst}; reflection 0.0 (-0.09) is worst again: contraction to 0.375
+    assert path[4] == 0.0 and path[5] == 0.375
+    assert abs(result - 0.3) <= 1e-6
+    # expansion: maximise -(x + 0.6)^2 from 0.5: simplex {0.5, 1.0} -> best 0.5; reflection 0.0 is better than the best:
+    # the expansion point 0.5 + 2 * (0.5 - 1.0) = -0.5 is tried and, better still, taken; then {-0.5 best, 0.5 worst}: the
+    # reflection -1.5 is clamped to -1.0 (between the two): outside contraction halfway from the best to the CLAMPED reflection
+    path, result = oa.neldermead_path(0, -0.6, 0.5)
+    assert path[:6].tolist() == [0.5, 1.0, 0.0, -0.5, -1.0, -0.75]
+    assert abs(result + 0.6) <= 1e-6
+    # an expansion that is no better than the reflection is dropped for the reflection: -(x + 0.2)^2 from 0.5
+    path, result = oa.neldermead_path(0, -0.2, 0.5)
+    assert path[:5].tolist() == [0.5, 1.0, 0.0, -0.5, -0.5]      # reflection 0.0 kept; next simplex {0.0 best, 0.5 worst} reflects to -0.5
+    assert abs(result + 0.2) <= 1e-6
+    # Pinned on a bound: -(x + 0.9)^2 from 0.5.  After the expansion to -0.5 the clamped reflection -1.0 (-0.01) beats the best
+    # (-0.16) and the clamped expansion is the same point; with the best ON the bound the next reflection is clamped onto it,
+    # the simplex collapses there, and the search returns -1.0 -- not the maximiser -0.9.  (nlopt's reflectpt() reports a
+    # reflected point equal to the centroid and the search stops with XTOL_REACHED at that moment: the same result.)
+    path, result = oa.neldermead_path(0, -0.9, 0.5)
+    assert path[:5].tolist() == [0.5, 1.0, 0.0, -0.5, -1.0] and np.all(path[4:] == -1.0) and len(path) == 8
+    assert result == -1.0
+    # outside contraction: -|x - 0.6| from 0.0: simplex {0, 0.5}: best 0.5 (-0.1), worst 0 (-0.6); reflection 1.0 (-0.4) lies
+    # between: the outside contraction 0.5 + 0.5 * (1.0 - 0.5) = 0.75 (-0.15) is tried and, not worse than the reflection, taken
+    path, _ = oa.neldermead_path(1, 0.6, 0.0)
+    assert path[:4].tolist() == [0.0, 0.5, 1.0, 0.75]
+
+
+def test_neldermead_optimum_on_a_bound_and_the_stopping_rule():
+    # a monotone objective: expansions run to the bound; with the best ON the bound the reflected point is clamped onto it, the
+    # outside contraction lands there too, and the simplex has collapsed: the search ends on the bound after two more
+    # evaluations of the same point (nlopt stops as the clamped reflection equals the centroid: the same result)
+    for slope, bound in ((1.0, 1.0), (-1.0, -1.0)):
+        for x0 in (-0.5, 0.0, 0.5):
+            path, result = oa.neldermead_path(2, slope, x0)
+            assert result == bound, (slope, x0, result)
+            assert np.all(np.abs(path) <= 1.0)                          # never outside the box
+            assert len(path) <= 12 and np.all(path[-2:] == bound), path
+    # the stopping rule: the simplex' two points closer than 1e-6 (absolute), never the objective's change
+    path, result = oa.neldermead_path(0, 0.3, 0.0)
+    assert abs(path[-1] - path[-2]) < 4e-6 and abs(result - 0.3) < 1e-6
+    # a flat step objective (all comparisons ties or strict): a tie never replaces the best point
+    path, result = oa.neldermead_path(3, 2.0, 0.25)                    # 0 everywhere: every point ties
+    assert result == 0.25 and len(path) < 60
+
+
+def test_loglikelihood_search_from_the_ends_of_the_start_interval_and_with_the_optimum_on_a_bound():
+    # processLogLikelihood's starts are drawn from (-0.5, 0.5]: from both ends the search must end on the same coefficient
+    # as from the middle on a smooth objective (F >= 0: no cell under the floor); and a genome homozygous everywhere
+    # (no heterozygous cell to pull F down) ends ON the upper bound F = 1.
+    ref, dip, *_ = reference_and_diploid()
+    ref_f = ref.filter_snp_pass()
+    sp = np.full(8, oa.ALL, dtype=np.int32)
+    results = []
+    for seed in (3, 4, 5, 6, 7, 8):
+        _, freqs, present, _ = oa.inbreed_window(ref_f, dip, sp, "Loglikelihood", 0, 10_000, 1, 1000, 0.0, 1.0, seed=seed)
+        assert present.all()
+        results.append(freqs[:, 4].copy())
+    results = np.array(results)
+    # genome 4 (test_ritland_closed_form): five classified loci, all homozygous -> the likelihood grows with F up to the bound
+    assert np.all(results[:, 4] == 1.0), results[:, 4]
+    at_one = oa.loglikelihood_at(ref_f, dip, sp, 0, 10_000, 1, 0.0, 1.0, np.full(8, 1.0))
+    below = oa.loglikelihood_at(ref_f, dip, sp, 0, 10_000, 1, 0.0, 1.0, np.full(8, 1.0 - 1e-3))
+    assert at_one[4] > below[4]
