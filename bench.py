@@ -769,18 +769,28 @@ def main():
         want_af = (counts[:, 1].to(torch.float64) + 2.0 * counts[:, 2].to(torch.float64)) / torch.full((), 2.0 * total_genomes, dtype=torch.float64, device=dev)
         checks = torch.stack([row_ok.all(), (af == want_af).all()]).to(torch.int32)
         del row_ok, want_af
+        # per rank: the mean launch of the dominant kernel inside the region, and the region's own wall time -- their spread over the
+        # ranks shows a straggler, and (step time - sweep time) what of the exchange and the epilogue is NOT hidden beside the sweeps
+        kernel_mean = float(np.mean(region_ms)) if region_ms else 0.0
+        spread = {"kernel_ms_min": kernel_mean, "kernel_ms_max": kernel_mean, "step_ms_min": elapsed / args.steps * 1e3, "step_ms_max": elapsed / args.steps * 1e3}
         if n_gpus > 1:
             dist.all_reduce(checks, op=dist.ReduceOp.MIN)                  # every rank must agree
+            lo = torch.tensor([kernel_mean, elapsed / args.steps * 1e3], dtype=torch.float64, device=dev)
+            hi = lo.clone()
+            dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+            dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+            spread = {"kernel_ms_min": float(lo[0]), "kernel_ms_max": float(hi[0]), "step_ms_min": float(lo[1]), "step_ms_max": float(hi[1])}
             t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             elapsed = float(t.item())
+        spread["exposed_exchange_and_epilogue_ms"] = spread["step_ms_max"] - spread["kernel_ms_max"]
         exchange_ok, af_ok = (bool(x) for x in checks.tolist())
 
         # ... and the same kernel alone, back to back into a scratch buffer (a cross-check of the figure above).
         scratch = torch.empty((V, 4), dtype=torch.int32, device=dev)
         ms = pop.allele_count_timed(scratch.data_ptr(), stream, 2, max(args.steps, 10))
         del scratch
-        job = dict(total_genomes=total_genomes, G=G, elapsed=elapsed, exchange_ok=exchange_ok, af_ok=af_ok, ms=region_ms, ms_alone=ms, t_synth=t_synth,
+        job = dict(total_genomes=total_genomes, G=G, elapsed=elapsed, exchange_ok=exchange_ok, af_ok=af_ok, ms=region_ms, ms_alone=ms, t_synth=t_synth, spread=spread,
                    sweep_bytes=pop.sweep_bytes)                           # V*ceil(G/4) + 16*V
         if keep_population:
             job.update(pop=pop, counts=counts, bufs=bufs, af=af)
@@ -797,12 +807,14 @@ def main():
             return "gloo rehearsal on one device"
         return "RCCL all-reduce(sum,u32) of [V][4] counts, overlapped with the next batch's sweep"
 
-    def distributed_config():
-        """What the exchange actually ran on, as torch.distributed and the library report it."""
+    def distributed_config(job):
+        """What the exchange actually ran on, as torch.distributed and the library report it; and over the ranks the spread of
+        the dominant kernel's mean launch and of the step time, with what of a step is not the sweep (exchange + epilogue exposed)."""
         return {"world_size": dist.get_world_size() if n_gpus > 1 else 1,
                 "backend": dist.get_backend() if n_gpus > 1 else "none (single process)",
                 "kgx_exchange_kind": capi.exchange_kind(),             # inside this process: one device per rank, so "none"
-                "kgx_bound_devices": capi.bound_devices()}
+                "kgx_bound_devices": capi.bound_devices(),
+                "over_ranks": job["spread"]}
 
     job = sweep_job(shards, keep_population=True)
     total_genomes, G, elapsed, ms = job["total_genomes"], job["G"], job["elapsed"], job["ms"]
@@ -840,7 +852,7 @@ def main():
                 "exchange": exchange_description(),
                 "exchange_check": f"row sums == total genomes on all {V} variants, on every rank: " + ("ok" if exchange_ok else "MISMATCH")
                                   + "; AF epilogue == (het + 2 hom) / 2G on all of them: " + ("ok" if job["af_ok"] else "MISMATCH"),
-                "distributed": distributed_config(),
+                "distributed": distributed_config(job),
                 "scaling_series": ("weak: " + str(G) + " genomes per GPU at every N; this line is its N = " + str(n_gpus) + " point"
                                    if scaling == "weak" else "strong: " + str(total_genomes) + " genomes split over the ranks"),
                 "seed": args.seed,
@@ -907,7 +919,7 @@ def main():
                            "exchange": exchange_description(),
                            "exchange_check": f"row sums == total genomes on all {V} variants, on every rank: " + ("ok" if cjob["exchange_ok"] else "MISMATCH")
                                              + "; AF epilogue: " + ("ok" if cjob["af_ok"] else "MISMATCH"),
-                           "distributed": distributed_config(), "synth_seconds": round(cjob["t_synth"], 3)},
+                           "distributed": distributed_config(cjob), "synth_seconds": round(cjob["t_synth"], 3)},
                 "roofline": {"bound": "hbm", "kernel": "k_allele_count (rank 0's shard)", "achieved": c_achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                              "frac": c_achieved / HBM_PEAK_GBS, "traffic": None, "algorithmic_bytes_per_launch": cjob["sweep_bytes"], "kernel_ms": c_ms},
             }

@@ -117,13 +117,17 @@ def test_sharded_dosage_sweeps_equal_the_unsharded_ones(kgx, rebind, slots, G):
     assert np.array_equal(want["k2_grown"][:V], want["k2"]) and np.array_equal(want["k2_grown"][V:], want["k2"][:V // 3])
 
 
-def test_two_distinct_devices_exchange_over_rccl(kgx, rebind):
-    """kgx_init(2, {0, 1}): two real devices, communicators from ncclCommInitAll over both, the K2 counts summed by a grouped
-    in-place ncclAllReduce from one thread on the two slots' streams (Exchange::Rccl with n > 1) -- what a multi-GPU node
-    runs.  K2/K3/K4/K8, the masked sweeps, the row lists and the inbreeding sweeps against the unsharded results.  Skipped
-    on a one-GPU box (the test boxes so far): the multi-rank RCCL path is then NOT verified on hardware."""
-    if kgx.device_count() < 2:
-        pytest.skip("needs two visible MI355X devices")
+@pytest.mark.parametrize("binding", [2, 4, 8, "all"])
+def test_distinct_devices_exchange_over_rccl(kgx, rebind, binding):
+    """kgx_init over n DISTINCT devices -- the first 2, 4, 8 ordinals, and kgx_init(0, NULL): every visible one --: communicators
+    from ncclCommInitAll over all of them, the K2 counts summed by a grouped in-place ncclAllReduce from one thread on the slots'
+    streams (Exchange::Rccl with n > 1) -- what a multi-GPU node runs.  K2/K3/K4/K8, the masked sweeps, the row lists, the
+    inbreeding sweeps (window-sized, batched, and on the moments) against the unsharded results.  A case is skipped where the box
+    has fewer devices (a one-GPU box skips all four: the multi-rank RCCL path is then NOT verified on hardware)."""
+    visible = kgx.device_count()
+    n = visible if binding == "all" else binding
+    if visible < 2 or n > visible:
+        pytest.skip(f"needs {max(n, 2)} visible MI355X devices, the box shows {visible}")
     rng = np.random.default_rng(11)
     G, V = 4099, 1500
     codes = rng.choice(4, size=(V, G), p=[0.6, 0.25, 0.13, 0.02]).astype(np.uint8)
@@ -131,26 +135,38 @@ def test_two_distinct_devices_exchange_over_rccl(kgx, rebind):
     first = np.arange(0, V - 3, 7, dtype=np.uint32)
     groups = (first, np.full(len(first), 3, dtype=np.uint32), (first % 3).astype(np.uint32))
     want = dosage_results(kgx, G, V, codes, bins, 11, groups)
-    one = kgx.GenotypeMatrix(700, 3000)
+    Gi, Li = 2100, 12_000                                   # (more than 8192 loci: HallME and Loglikelihood on per-genome moments)
+    one = kgx.GenotypeMatrix(Gi, Li)
     table = one.synth_multiallelic(1111, 0, 0)
+    window = np.arange(0, Li, 12, dtype=np.uint32)
+    tasks = [{"g0": 0, "g1": 900, "locus_index": window + k, "minor_af": np.ascontiguousarray(table[window + k])} for k in range(3)] + \
+            [{"g0": 896, "g1": Gi, "locus_index": window, "minor_af": np.ascontiguousarray(table[window])}]
     want_inbreed = {a: one.inbreed(table, a, phased=True) for a in ("Simple", "HallME", "Loglikelihood")}
+    want_batch = {a: one.inbreed_batch(tasks, a, phased=True) for a in ("RitlandLocus", "Loglikelihood")}
     one.close()
-    rebind([0, 1])
-    assert kgx.bound_devices() == 2 and kgx.exchange_kind() == "rccl"
+    rebind([] if binding == "all" else list(range(n)))
+    assert kgx.bound_devices() == n and kgx.exchange_kind() == "rccl"
     got = dosage_results(kgx, G, V, codes, bins, 11, groups)
-    assert len(got["shards"]) == 2 and {s["slot"] for s in got["shards"]} == {0, 1}
+    assert len(got["shards"]) == n and {s["slot"] for s in got["shards"]} == set(range(n))
     for key in want:
         if key != "shards":
             assert np.array_equal(got[key], want[key]), key
-    many = kgx.GenotypeMatrix(700, 3000)
+    many = kgx.GenotypeMatrix(Gi, Li)
     many.synth_multiallelic(1111, 0, 0)
-    for algorithm, wanted in want_inbreed.items():
-        result = many.inbreed(table, algorithm, phased=True)
+    assert len(many.shards) == n
+
+    def same(result, wanted, ctx):
         for name in wanted.dtype.names:
             if name.endswith("_count"):
-                assert np.array_equal(result[name], wanted[name]), (algorithm, name)
+                assert np.array_equal(result[name], wanted[name]), ctx + (name,)
             else:
-                assert np.allclose(result[name], wanted[name], rtol=1e-11, atol=1e-11), (algorithm, name)
+                assert np.allclose(result[name], wanted[name], rtol=1e-11, atol=1e-11), ctx + (name,)
+
+    for algorithm, wanted in want_inbreed.items():
+        same(many.inbreed(table, algorithm, phased=True), wanted, (algorithm,))
+    for algorithm, wanted in want_batch.items():
+        for k, (result, w) in enumerate(zip(many.inbreed_batch(tasks, algorithm, phased=True), wanted)):
+            same(result, w, (algorithm, "batch", k))
     many.close()
 
 
@@ -222,7 +238,7 @@ def test_rccl_all_reduce_call_path_over_one_rank(kgx, rebind):
 
 
 @pytest.mark.parametrize("algorithm", ["Simple", "RitlandLocus", "HallME", "Loglikelihood"])
-def test_sharded_inbreeding_equals_the_unsharded_one(kgx, rebind, algorithm):
+def test_sharded_inbreeding_equals_the_unsharded_one(kgx, rebind, algorithm, monkeypatch):
     G, L = 700, 3000
     one = kgx.GenotypeMatrix(G, L)
     table = one.synth_multiallelic(1111, 0, 0)
@@ -231,6 +247,14 @@ def test_sharded_inbreeding_equals_the_unsharded_one(kgx, rebind, algorithm):
     sub = np.ascontiguousarray(table[index])
     want_all = one.inbreed(table, algorithm, phased=True)
     want_part = one.inbreed(sub, algorithm, phased=True, locus_index=index, g0=100, g1=650)
+    # ... the same through the multi-kernel paths (the iterative estimators on per-genome moments), and as a batch of tasks
+    monkeypatch.setenv("KGX_K7_NO_WAVE", "1")
+    want_big = one.inbreed(table, algorithm, phased=True)
+    big_path = kgx.inbreed_last_path()
+    monkeypatch.delenv("KGX_K7_NO_WAVE")
+    tasks = [{"g0": 0, "g1": 300, "locus_index": index, "minor_af": sub}, {"g0": 296, "g1": G, "locus_index": index[::2], "minor_af": sub[::2]},
+             {"g0": 100, "g1": 650, "locus_index": None, "minor_af": np.ascontiguousarray(table[:1000])}]
+    want_batch = one.inbreed_batch(tasks, algorithm, phased=True)
     one.close()
     rebind([0, 0, 0])
     many = kgx.GenotypeMatrix(G, L)
@@ -241,7 +265,12 @@ def test_sharded_inbreeding_equals_the_unsharded_one(kgx, rebind, algorithm):
     assert np.array_equal(np.nan_to_num(table2), np.nan_to_num(table))
     got_all = many.inbreed(table, algorithm, phased=True)
     got_part = many.inbreed(sub, algorithm, phased=True, locus_index=index, g0=100, g1=650)      # a range that straddles shards
-    for got, want in ((got_all, want_all), (got_part, want_part)):
+    monkeypatch.setenv("KGX_K7_NO_WAVE", "1")
+    got_big = many.inbreed(table, algorithm, phased=True)
+    assert kgx.inbreed_last_path() == big_path and big_path == {"HallME": "hall moments", "Loglikelihood": "loglik moments"}.get(algorithm, "frequency sweep")
+    monkeypatch.delenv("KGX_K7_NO_WAVE")
+    got_batch = many.inbreed_batch(tasks, algorithm, phased=True)
+    for got, want in [(got_all, want_all), (got_part, want_part), (got_big, want_big)] + list(zip(got_batch, want_batch)):
         for name in want.dtype.names:
             if name.endswith("_count"):
                 assert np.array_equal(got[name], want[name]), name
