@@ -65,6 +65,9 @@ int kgx_device_count(void);
  * exercise the sharded paths on a one-GPU box); RCCL cannot span such a binding, so the counts are then summed by
  * device-to-device copies + an add kernel ("peer" exchange). */
 int kgx_init(int device_count, const int* device_ids);
+/* The library's KGX_* environment switches (launch shapes, the path selectors the tests and comparisons use: DESIGN.md) are read
+ * at kgx_init, once; a process that changes them afterwards calls this to have them read again.  Never fails. */
+int kgx_reload_options(void);
 /* Slots bound by the last successful kgx_init (0 before). */
 int kgx_bound_devices(void);
 /* How per-variant counts of different shards are summed: "none" (one slot), "rccl" or "peer". */
@@ -214,7 +217,10 @@ int kgx_offset_filter_counts(kgx_pop* pop, const uint8_t* single_bin /* host [n_
  * Phase is not in the 2-bit rows; it comes as a PHASE PLANE beside them -- one bit per (variant row, genome), variant-major,
  * genome g in bit g % 8 of byte g / 8 of its row: set where the genome's copies of the variant sit on BOTH phases (a|a
  * homozygote; never for unphased data, where every copy carries VariantPhase::UNPHASED).  The filter then leaves, per
- * genome and bin, (variants carried) + (plane bits set): out[g][b].  bin_of_variant: host [n_variants], 0xFF = row not
+ * genome and bin, (variants carried) + (plane bits set): out[g][b] -- exact for copies on one or two distinct phases, which is
+ * all the reference's parsers produce (A and B of a phased diploid; UNPHASED alone); a genome whose copies of ONE variant sat on
+ * three or more distinct phases would count one short per extra phase (the host flattener counts such cells and the package
+ * warns: FlatPopulation::cells_with_three_phases).  bin_of_variant: host [n_variants], 0xFF = row not
  * counted; NULL with n_bins == 1: every row.  Honours the genome mask.  The plane is optional (half the size of the rows);
  * kgx_population_resize carries it along. */
 int kgx_population_load_phase_plane(kgx_pop* pop, const uint8_t* src, uint64_t src_pitch /* >= ceil(n_genomes / 8) */, uint64_t v0, uint64_t v1);
@@ -335,6 +341,11 @@ int kgx_inbreed_reference_starts(int algorithm, uint64_t seed, uint64_t first_st
  * genotype columns of the genomes still searching (at most ~3/4 of the swept bytes together); this frees them (they are
  * re-created when needed). */
 int kgx_release_scratch(void);
+/* (A HallME / Loglikelihood call over a large selection adds its moments -- 40 B per 1024 selected loci and genome, 100 KB of
+ * frequency bins per genome -- and, Loglikelihood, a bit per cell of the bins its floor can reach to those buffers: ~6 + 15 GB
+ * at 10,000 genomes x 5 M loci.  They are kept for the next such call while together they stay under a quarter of the device's
+ * memory (KGX_KEEP_SCRATCH_GB=n: under n GiB) and freed at the end of the call otherwise; a call whose moments would not
+ * fit into half of what is free makes the passes over the bytes instead, which need none of it.) */
 /* Device time (HIP events on the library streams) of the frequency sweep -- locus helpers + the K5 kernel, i.e. the one
  * pass over the genotype bytes that every estimator makes -- of the most recent successful kgx_inbreed call (the
  * slowest shard's); 0 before the first, and 0 after a call over fewer than 2^24 cells (selected loci x genomes of a

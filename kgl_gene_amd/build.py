@@ -69,7 +69,7 @@ def build_kgx(force: bool = False, verbose: bool = False) -> Path:
     """Compile every HIP translation unit (in parallel, one hipcc per unit) and link kgl_gene_amd/lib/libkgx.so."""
     LIBDIR.mkdir(parents=True, exist_ok=True)
     OBJDIR.mkdir(parents=True, exist_ok=True)
-    extra = os.environ.get("KGX_HIPCC_FLAGS", "").split()   # experiments only (e.g. -DKGX_EXP_...); the default build has none
+    extra = os.environ.get("KGX_HIPCC_FLAGS", "").split()   # experiments only (e.g. scripts/ubench/power_cap_experiment.patch + -DKGX_EXP_NOLOAD); the default build has none
     jobs, objects = [], []
     for src in _sources():
         obj = OBJDIR / (src.stem + ".o")

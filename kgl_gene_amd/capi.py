@@ -6,6 +6,7 @@ when no gfx950 device is bound: there is no CPU fallback anywhere in this packag
 from __future__ import annotations
 
 import ctypes as C
+import os
 import re
 from pathlib import Path
 
@@ -83,6 +84,7 @@ _SIGNATURES = {
     "kgx_inbreed_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_int, C.c_int]),
     "kgx_inbreed_reference_starts": (C.c_int, [C.c_int, C.c_uint64, C.c_uint64, C.c_uint64, C.c_void_p]),
     "kgx_release_scratch": (C.c_int, []),
+    "kgx_reload_options": (C.c_int, []),
     "kgx_count_by_genome_af_bins": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]),
     "kgx_population_resize": (C.c_int, [C.c_void_p, C.c_uint64]),
     "kgx_inbreed_last_sweep_ms": (C.c_double, []),
@@ -154,10 +156,31 @@ def hip_runtimes_mapped() -> list[str]:
     return sorted(found)
 
 
+# The library reads its KGX_* switches at kgx_init and at kgx_reload_options, not per call.  A process that flips them between
+# calls (the tests, the comparison scripts) sets WATCH_ENV: every access to the library then first hands over the switches if they
+# changed.  bench.py and production leave it off: nothing is checked per call.
+WATCH_ENV = False
+_switches_seen = None
+
+
+def reload_options() -> None:
+    """Have the library read its KGX_* switches again (kgx_reload_options)."""
+    global _switches_seen
+    _switches_seen = _switches_now()
+    handle = _lib if _lib is not None else lib()
+    check(handle.kgx_reload_options())
+
+
+def _switches_now():
+    return tuple(sorted((k, v) for k, v in os.environ.items() if k.startswith("KGX_")))
+
+
 def lib() -> C.CDLL:
     """Load libkgx.so (once).  Raises if the HIP extension has not been built."""
     global _lib
     if _lib is not None:
+        if WATCH_ENV and _switches_now() != _switches_seen:
+            reload_options()
         return _lib
     if not LIB_PATH.exists():
         raise ImportError(

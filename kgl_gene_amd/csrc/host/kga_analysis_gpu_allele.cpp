@@ -172,6 +172,9 @@ bool kga::GpuAlleleAnalysis::sweepPopulation(const PopulationDB& population) {
   // genome index, one dosage row per genome) -- here the variant-major 2-bit rows, then their upload (sweepFlat)
   const auto flatten_begin = std::chrono::steady_clock::now();
   const gpu::FlatPopulation flat = gpu::flattenPopulation(population);
+  if (flat.cells_with_three_phases)
+    ExecEnv::log().warn("GpuAlleleAnalysis; {} (genome, variant) cells hold copies on three or more distinct phases: the phase plane says \"more than one\" "
+                        "there, UniquePhasedFilter counts would be one short per extra phase", flat.cells_with_three_phases);
   k1_flatten_seconds_ = std::chrono::duration<double>(std::chrono::steady_clock::now() - flatten_begin).count();
   // contigs a genome holds without any variant still get a (zero) record (heterozygous.cpp:38-41)
   for (const auto& [genome_id, genome_ptr] : population.getMap()) {

@@ -196,9 +196,11 @@ FlatPopulation flattenPopulation(const PopulationDB& population, size_t threads)
   flat.phase_row_bytes = (G + 7) / 8;
   flat.phase_plane.assign(V * flat.phase_row_bytes, 0);
   const size_t octets = (G + 7) / 8;
-  threads = std::max<size_t>(1, std::min(threads, octets));
+  // (every packing worker keeps 3 bytes per row: at most 32 of them, as the discovery walk has)
+  threads = std::max<size_t>(1, std::min<size_t>(std::min(threads, octets), 32));
   std::vector<std::vector<NonDiploidCell>> overflow(threads);
   std::vector<uint8_t> any_two_phases(threads, 0);
+  std::vector<size_t> three_phases(threads, 0);
   auto phase_bit = [](VariantPhase phase) -> uint8_t {
     switch (phase) {
       case VariantPhase::DIPLOID_PHASE_A: return 1;
@@ -238,6 +240,7 @@ FlatPopulation flattenPopulation(const PopulationDB& population, size_t threads)
           if (seen_phases & (seen_phases - 1)) {                  // more than one distinct phase among the copies
             flat.phase_plane[static_cast<size_t>(r) * flat.phase_row_bytes + o] |= static_cast<uint8_t>(1u << j);
             any_two_phases[t] = 1;
+            if (__builtin_popcount(seen_phases) > 2) ++three_phases[t];
           }
           if (d > 2 && r < flat.primary_rows) overflow[t].push_back({r, static_cast<uint32_t>(g), d});
         }
@@ -252,6 +255,7 @@ FlatPopulation flattenPopulation(const PopulationDB& population, size_t threads)
   for (auto& o : overflow) flat.non_diploid.insert(flat.non_diploid.end(), o.begin(), o.end());
   bool two_phases = false;
   for (const uint8_t flag : any_two_phases) two_phases = two_phases || flag;
+  for (const size_t n : three_phases) flat.cells_with_three_phases += n;
   if (!two_phases) { flat.phase_plane.clear(); flat.phase_plane.shrink_to_fit(); }    // unphased data: no plane
   std::sort(flat.non_diploid.begin(), flat.non_diploid.end(), [](const NonDiploidCell& a, const NonDiploidCell& b) {
     return a.row != b.row ? a.row < b.row : a.genome < b.genome;

@@ -55,6 +55,9 @@ struct FlatPopulation {
   // Empty where no cell does (unphased data).  flattenPopulation fills it; the VCF flatteners do not.
   std::vector<uint8_t> phase_plane;
   uint64_t phase_row_bytes{0};
+  // Cells whose copies carry THREE or more distinct phases (A, B and UNPHASED or HAPLOID: no parser of the reference makes
+  // such a genome): UniquePhasedFilter would keep three Variant objects there, the one bit of the plane says "two".
+  size_t cells_with_three_phases{0};
   size_t variant_objects{0};               // Variant visits (= PopulationDB::variantCount())
   std::vector<ContigId_t> contig_ids;      // contigs EVERY genome holds, carrier or not (Pf flavour: the ##contig header lines)
 

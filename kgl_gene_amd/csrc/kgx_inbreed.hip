@@ -154,8 +154,7 @@ int inbreed_shard(kgx_gt8_shard& sh, uint64_t g0, uint64_t g1, const uint32_t* l
   // passes (kgx_kernels_hall.h, kgx_kernels_loglik.h)
   // (any amax for HallME: the class passes compare bytes, no table; the generic / no-table flavours keep the passes they are there to test)
   const bool no_tables = env_int("KGX_K5_GENERIC", 0) || env_int("KGX_K5_NO_EVAL_LUT", 0);
-  const char* search_name = std::getenv("KGX_K7_SEARCH");
-  const int search = search_name && std::strcmp(search_name, "brent") == 0 ? kSearchBrent : kSearchNelderMead;
+  const int search = env_str("KGX_K7_SEARCH") == "brent" ? kSearchBrent : kSearchNelderMead;
   const bool hall_candidate = algorithm == KGX_ALGO_HALL_ME && n_sel > 0 && n_sel < (1ull << 31) && !wave_sized && !no_tables &&
                               !env_int("KGX_K7_HALL_PASSES", 0);                 // (the radix sort counts its items in an int)
   // Loglikelihood: the reference optimiser's path alone, a phased population (unphased: every alt homozygote is a heterozygous
@@ -839,6 +838,22 @@ int inbreed_shard(kgx_gt8_shard& sh, uint64_t g0, uint64_t g1, const uint32_t* l
       if (hipEventElapsedTime(&ms, dev.kernel_begin, dev.kernel_end) == hipSuccess) dev.last_kernel_ms = ms;
     } else if (rc == KGX_OK) {
       dev.last_sweep_ms = dev.last_kernel_ms = 0.0;
+    }
+    // What a call on moments leaves in the grow-only buffers (the arena: moments, bins, the classes' blocks; the hits' words) stays for
+    // the next call like it -- up to a quarter of the device's memory (KGX_KEEP_SCRATCH_GB); past that it is given back now, so that
+    // one very large call does not starve what the process allocates next (another matrix, the compaction levels, the caller's own).
+    {
+      const uint64_t keep = env_int("KGX_KEEP_SCRATCH_GB", -1) >= 0 ? static_cast<uint64_t>(env_int("KGX_KEEP_SCRATCH_GB", 0)) << 30 : dev.hbm_bytes / 4;
+      if (static_cast<uint64_t>(dev.scratch_bytes) + dev.words_bytes > keep) {
+        (void)hipStreamSynchronize(st);
+        if (dev.words) (void)hipFree(dev.words);
+        dev.words = nullptr;
+        dev.words_bytes = 0;
+        if (dev.scratch) (void)hipFree(dev.scratch);
+        dev.scratch = nullptr;
+        dev.scratch_bytes = 0;
+        arena = nullptr;                                           // (nothing below touches it)
+      }
     }
     if (rc == KGX_OK) {
       float ms = 0.f;

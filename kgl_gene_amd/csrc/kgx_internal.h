@@ -75,7 +75,10 @@ int require_bound();
 int fail(int code, const char* fmt, ...) __attribute__((format(printf, 2, 3)));
 const std::string& last_error();
 void set_last_error(const std::string& message);
+// The KGX_* switches, from the snapshot taken at kgx_init / kgx_reload_options (never from the environment itself).
 int env_int(const char* name, int dflt);
+std::string env_str(const char* name);
+void reload_options();
 uint32_t stream_grid(const Device& dev, uint64_t work_items, uint32_t items_per_block);
 
 // Per-call device buffers come out of ONE grow-only arena per device (a window loop calls kgx_inbreed thousands of times, the

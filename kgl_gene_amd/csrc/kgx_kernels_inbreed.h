@@ -552,9 +552,6 @@ k_inbreed_eval_lut(const uint32_t* __restrict__ gt, uint64_t dwords_per_row, uin
     }
   };
   auto load_row = [&](uint32_t (&wi)[DW], uint32_t row) {
-#if defined(KGX_EXP_NOLOAD)
-    if (row != 0xFFFFFFFFu) return;                             // experiment: the pass without its HBM reads
-#endif
     const uint32_t* src = gt + (row_base + row) * dwords_per_row + col_read;
     if constexpr (DW == 1) {
       wi[0] = __builtin_nontemporal_load(src);
@@ -653,13 +650,9 @@ k_inbreed_eval_lut(const uint32_t* __restrict__ gt, uint64_t dwords_per_row, uin
         });
       } else {
         walk([&](int j, const Entry& y) {
-#if defined(KGX_EXP_NOMATH)
-          run_a[j] += y;                                          // experiment: the pass without its fp64 work
-#else
           const double v = __builtin_fma(one_minus_F[MODE == 1 ? j : 0], y, F[kCounts ? 0 : j]);
           run_a[j] = __builtin_fma(run_a[j], v, run_b[j]);
           run_b[j] *= v;
-#endif
         });
       }
       if constexpr (kCounts) {

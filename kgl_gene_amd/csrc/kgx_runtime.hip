@@ -99,9 +99,44 @@ const std::string& last_error() { return g_error; }
 void set_last_error(const std::string& message) { g_error = message; }
 
 // Tuning knobs (environment, read per launch; defaults are the shipped configuration).
+// The KGX_* switches (tuning knobs, the tests' path selectors) are parsed ONCE -- at kgx_init and by kgx_reload_options -- into
+// a snapshot every call reads (a window-sized kgx_inbreed call asked the environment ~40 questions).
+using Options = std::unordered_map<std::string, std::string>;
+std::shared_ptr<const Options> g_options;
+std::mutex g_options_mutex;
+
+std::shared_ptr<const Options> parse_options() {
+  auto parsed = std::make_shared<Options>();
+  for (char** e = environ; e && *e; ++e) {
+    if (std::strncmp(*e, "KGX_", 4) != 0) continue;
+    const char* eq = std::strchr(*e, '=');
+    if (eq) (*parsed)[std::string(*e, static_cast<size_t>(eq - *e))] = std::string(eq + 1);
+  }
+  return parsed;
+}
+
+std::shared_ptr<const Options> options() {
+  std::lock_guard<std::mutex> lock(g_options_mutex);
+  if (!g_options) g_options = parse_options();
+  return g_options;
+}
+
+void reload_options() {
+  auto parsed = parse_options();
+  std::lock_guard<std::mutex> lock(g_options_mutex);
+  g_options = std::move(parsed);
+}
+
 int env_int(const char* name, int dflt) {
-  const char* v = std::getenv(name);
-  return v && *v ? std::atoi(v) : dflt;
+  const auto snapshot = options();
+  const auto it = snapshot->find(name);
+  return it != snapshot->end() && !it->second.empty() ? std::atoi(it->second.c_str()) : dflt;
+}
+
+std::string env_str(const char* name) {
+  const auto snapshot = options();
+  const auto it = snapshot->find(name);
+  return it != snapshot->end() ? it->second : std::string();
 }
 
 uint32_t stream_grid(const Device& dev, uint64_t work_items, uint32_t items_per_block) {
@@ -286,7 +321,9 @@ int kgx_init(int device_count, const int* device_ids) {
       if (ids[i] < 0 || ids[i] >= visible) return fail(KGX_EINVAL, "device %d out of range [0,%d)", ids[i], visible);
       for (size_t j = 0; j < i; ++j) distinct = distinct && ids[j] != ids[i];
     }
-    const char* forced = std::getenv("KGX_EXCHANGE");            // "peer" | "rccl": tests and bring-up; default by the binding
+    reload_options();                                            // the KGX_* switches as they stand now (and at kgx_reload_options)
+    const std::string forced_name = env_str("KGX_EXCHANGE");     // "peer" | "rccl": tests and bring-up; default by the binding
+    const char* forced = forced_name.empty() ? nullptr : forced_name.c_str();
     Exchange exchange = ids.size() == 1 ? Exchange::None : (distinct ? Exchange::Rccl : Exchange::Peer);
     if (forced && std::strcmp(forced, "peer") == 0 && ids.size() > 1) exchange = Exchange::Peer;
     if (forced && std::strcmp(forced, "rccl") == 0) {
@@ -406,6 +443,13 @@ int kgx_synchronize(void) {
       KGX_HIP(hipDeviceSynchronize());
     }
     return use_device(*rt->devs[0]);
+  });
+}
+
+int kgx_reload_options(void) {
+  return guarded([&]() -> int {
+    reload_options();
+    return KGX_OK;
   });
 }
 

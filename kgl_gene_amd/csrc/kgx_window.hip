@@ -79,8 +79,7 @@ int batch_shard(kgx_gt8_shard& sh, const kgx_inbreed_task* tasks, const std::vec
   const uint64_t wave_loci = static_cast<uint64_t>(std::min(kGenomeWaveLoci, std::max(1, env_int("KGX_K7_WAVE_LOCI", 1024))));
   const bool per_wave = most_loci <= wave_loci && n_genomes >= static_cast<uint64_t>(std::max(1, env_int("KGX_K7_WAVE_GENOMES", algorithm == KGX_ALGO_HALL_ME ? 1024 : 512)));
   const dim3 grid(static_cast<uint32_t>(per_wave ? (most_genomes + kBlock / kWave - 1) / (kBlock / kWave) : most_genomes), static_cast<uint32_t>(pieces.size()));
-  const char* search_name = std::getenv("KGX_K7_SEARCH");
-  const int search = search_name && std::strcmp(search_name, "brent") == 0 ? kSearchBrent : kSearchNelderMead;
+  const int search = env_str("KGX_K7_SEARCH") == "brent" ? kSearchBrent : kSearchNelderMead;
 #define KGX_WINDOW(ALGO, CELLS, THREADS)                                                                                                \
   hipLaunchKernelGGL((k_inbreed_window<ALGO, CELLS, THREADS>), grid, dim3(kBlock), 0, st, sh.d_gt, sh.pitch, d_tasks, d_index, d_table, d_valid, \
                      amax, phased, search, d_start, d_out, d_evaluations)

@@ -5,6 +5,8 @@ import numpy as np
 sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
 from kgl_gene_amd import capi
 
+capi.WATCH_ENV = True            # this script flips KGX_* switches between calls (the library reads them at kgx_init / kgx_reload_options)
+
 if os.environ.get("KGX_EXP_LIB"):          # another build of the library (an experiment variant)
     capi.LIB_PATH = Path(os.environ["KGX_EXP_LIB"]).resolve()
 capi.init(0)

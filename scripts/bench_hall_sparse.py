@@ -7,6 +7,8 @@ import numpy as np
 sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
 from kgl_gene_amd import capi
 
+capi.WATCH_ENV = True            # this script flips KGX_* switches between calls (the library reads them at kgx_init / kgx_reload_options)
+
 capi.init(0)
 G, L = 10_000, 400_000
 rng = np.random.default_rng(7)

@@ -10,6 +10,8 @@ import torch
 sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
 from kgl_gene_amd import capi  # noqa: E402
 
+capi.WATCH_ENV = True            # this script flips KGX_* switches between calls (the library reads them at kgx_init / kgx_reload_options)
+
 G = int(sys.argv[1]) if len(sys.argv) > 1 else 10000
 V = int(sys.argv[2]) if len(sys.argv) > 2 else 10_000_000
 capi.ensure_built()

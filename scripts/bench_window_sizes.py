@@ -11,6 +11,8 @@ import numpy as np
 
 from kgl_gene_amd import capi
 
+capi.WATCH_ENV = True            # this script flips KGX_* switches between calls
+
 capi.init(0)
 G, L = 2512, 40_000
 m = capi.GenotypeMatrix(G, L)

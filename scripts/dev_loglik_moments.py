@@ -10,6 +10,8 @@ import numpy as np
 
 from kgl_gene_amd import capi
 
+capi.WATCH_ENV = True            # this script flips KGX_* switches between calls
+
 G = int(sys.argv[1]) if len(sys.argv) > 1 else 300
 L = int(sys.argv[2]) if len(sys.argv) > 2 else 20_000
 reps = int(sys.argv[3]) if len(sys.argv) > 3 else 3

@@ -4,6 +4,8 @@ from pathlib import Path
 sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
 import numpy as np
 from kgl_gene_amd import capi
+
+capi.WATCH_ENV = True            # this script flips KGX_* switches between calls
 capi.init(0)
 G, L = 2512, 400_000
 m = capi.GenotypeMatrix(G, L)

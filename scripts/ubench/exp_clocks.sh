@@ -1,3 +1,4 @@
+# (for the -DKGX_EXP_* builds apply scripts/ubench/power_cap_experiment.patch first: the product's kernels do not carry those branches)
 # Engine clock and power while the table passes run (HallME at C5: 50 passes a call), sampled by rocm-smi beside the run.
 # usage: bash scripts/exp_clocks.sh [extra hipcc flags, e.g. -DKGX_EXP_NOLOAD]
 set -e

@@ -19,6 +19,7 @@ def kgx():
     from kgl_gene_amd import capi
 
     capi.ensure_built()
+    capi.WATCH_ENV = True        # the tests flip KGX_* switches between calls: hand them to the library when they changed (kgx_reload_options)
     # capi.lib() loads torch (plumbing of a few tests) BEFORE libkgx.so, so that the process holds one HIP runtime: with
     # libkgx.so first the torch wheel's bundled libamdhip64 is mapped beside the system's and torch finds no device
     # (capi._one_hip_runtime; tests/test_capi_cpu.py::test_one_hip_runtime_whatever_the_import_order).
