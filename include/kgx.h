@@ -265,6 +265,15 @@ uint64_t kgx_gt8_sweep_bytes(uint64_t n_genomes, uint64_t n_selected, uint32_t a
 int kgx_gt8_load(kgx_gt8* gt, const uint8_t* src, uint64_t g0, uint64_t g1);
 int kgx_gt8_load_rows(kgx_gt8* gt, const uint8_t* src, uint64_t src_pitch, uint64_t l0, uint64_t l1);
 int kgx_gt8_read_rows(const kgx_gt8* gt, uint8_t* dst, uint64_t dst_pitch, uint64_t l0, uint64_t l1);
+/* Offsets with MORE than 14 reference alts (AlleleFreqVector has no cap, kga_analysis_inbreed_freq.cpp:18-57; a multi-base SNP
+ * record can spell out dozens): their cells do not fit two 4-bit indices.  Such a row of the matrix gets a WIDE ROW beside it:
+ * cells[i][g] = a1 | a2 << 8 for row locus[i] (ascending) -- two 8-bit indices into the locus's reference alt list, 0 = none,
+ * 255 = an alt the list does not hold, 0xFFFF = three or more variants, the pairs as the bytes' (kgx_gt8_load_rows); what the
+ * byte row holds there is ignored by a call whose amax exceeds 14.  kgx_inbreed then takes minor_af with amax up to 254 columns
+ * and runs its generic per-cell kernels (no table passes, no one-launch iteration, no moments: such offsets are rare).
+ * n_wide = 0 drops the wide rows.  Replaces any set before. */
+int kgx_gt8_set_wide_rows(kgx_gt8* gt, uint64_t n_wide, const uint32_t* locus /* [n_wide] */, const uint16_t* cells /* [n_wide][cells_pitch] */,
+                          uint64_t cells_pitch /* >= n_genomes */);
 
 /* LocusResults (kga_analysis_inbreed_output.h:21-35) without the genome id, same field order. */
 typedef struct kgx_locus_results {
@@ -283,7 +292,7 @@ typedef struct kgx_locus_results {
 
 /* K6 alone: per locus { majorAlleleFrequency, majorHom, majorHet, minorHom, minorHet } =
  * AlleleFreqVector::alleleClassFrequencies(inbreeding) (kga_analysis_inbreed_freq.cpp:119-217) from the locus's
- * minor allele frequencies minor_af[l][amax] (NaN = alt absent from the AlleleFreqVector); valid[l] =
+ * minor allele frequencies minor_af[l][amax] (amax <= 254) (NaN = alt absent from the AlleleFreqVector); valid[l] =
  * checkValidAlleleVector() (:61-75).  valid may be NULL. */
 int kgx_locus_class_frequencies(const double* minor_af, uint64_t n_loci, uint32_t amax, double inbreeding,
                                 double* out /* [n_loci][5] */, uint8_t* valid /* [n_loci] */);

@@ -81,6 +81,7 @@ _SIGNATURES = {
     "kgx_locus_class_frequencies": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint32, C.c_double, C.c_void_p, C.c_void_p]),
     "kgx_inbreed": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint32, C.c_int,
                               C.c_int, C.c_void_p, C.c_void_p]),
+    "kgx_gt8_set_wide_rows": (C.c_int, [C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_uint64]),
     "kgx_inbreed_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_int, C.c_int]),
     "kgx_inbreed_reference_starts": (C.c_int, [C.c_int, C.c_uint64, C.c_uint64, C.c_uint64, C.c_void_p]),
     "kgx_release_scratch": (C.c_int, []),
@@ -584,6 +585,18 @@ class GenotypeMatrix:
         check(lib().kgx_inbreed(self._h, g0, g1, None if idx is None else ptr(idx), n_sel, ptr(a), amax, int(bool(phased)),
                                 ALGORITHMS[algorithm], None if st is None else ptr(st), ptr(out)))
         return out
+
+    def set_wide_rows(self, locus, cells) -> None:
+        """Offsets with more than 14 reference alts (kgx_gt8_set_wide_rows): locus [n_wide] rows ascending, cells uint16
+        [n_wide][n_genomes] = a1 | a2 << 8.  None / empty drops them."""
+        if locus is None or len(locus) == 0:
+            check(lib().kgx_gt8_set_wide_rows(self._h, 0, None, None, 0))
+            return
+        rows = np.ascontiguousarray(locus, dtype=np.uint32)
+        c = np.ascontiguousarray(cells, dtype=np.uint16)
+        if c.shape != (len(rows), self.n_genomes):
+            raise ValueError("cells must be [n_wide][n_genomes]")
+        check(lib().kgx_gt8_set_wide_rows(self._h, len(rows), ptr(rows), ptr(c), self.n_genomes))
 
     def inbreed_batch(self, tasks, algorithm: str, phased: bool) -> list:
         """Many inbreed() calls in one (kgx_inbreed_batch): tasks = dicts with minor_af [n_selected][amax] and optionally

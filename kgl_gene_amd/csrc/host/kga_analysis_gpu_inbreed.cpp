@@ -116,20 +116,27 @@ kga::GpuReferenceContig kga::GpuInbreedAnalysis::buildReference(const Population
   return ref;
 }
 
-size_t kga::GpuReferenceContig::limitAlts() {
+uint32_t kga::GpuReferenceContig::narrowAlts() const {
+  uint32_t most = 1;
+  for (const auto& locus : loci)
+    if (locus.alts.size() <= kMaxAlts) most = std::max<uint32_t>(most, static_cast<uint32_t>(locus.alts.size()));
+  return most;
+}
+
+size_t kga::GpuReferenceContig::limitAlts(uint32_t kMost) {
   size_t lossy = 0;
-  if (max_alts <= kMaxAlts) return lossy;
+  if (max_alts <= kMost) return lossy;
   max_alts = 0;
   for (auto& locus : loci) {
-    if (locus.alts.size() > kMaxAlts) {
+    if (locus.alts.size() > kMost) {
       auto bears_frequency = [](const GpuReferenceAlt& alt) {
         for (const double f : alt.af)
           if (!std::isnan(f)) return true;
         return false;
       };
       const auto first_without = std::stable_partition(locus.alts.begin(), locus.alts.end(), bears_frequency);
-      if (static_cast<size_t>(first_without - locus.alts.begin()) > kMaxAlts) ++lossy;
-      locus.alts.resize(kMaxAlts);
+      if (static_cast<size_t>(first_without - locus.alts.begin()) > kMost) ++lossy;
+      locus.alts.resize(kMost);
     }
     max_alts = std::max<uint32_t>(max_alts, static_cast<uint32_t>(locus.alts.size()));
   }
@@ -274,14 +281,16 @@ bool kga::GpuInbreedAnalysis::iterationAnalysis() {
   return ok;
 }
 
-bool kga::GpuInbreedAnalysis::referenceInput(GpuReferenceContig& reference) const {
+bool kga::GpuInbreedAnalysis::referenceInput(GpuReferenceContig& reference, uint32_t most) const {
   const bool ok = referenceSource(reference);
-  if (ok && reference.max_alts > GpuReferenceContig::kMaxAlts) {
+  // An offset may hold any number of SNP alts (AlleleFreqVector has no cap): up to 14 fit the matrix bytes, up to 254 a wide row
+  // (`most`: 254 for the population sweep; the synthetic self-check draws its genomes on the device from 4-bit indices: 14).
+  if (ok && reference.max_alts > most) {
     const uint32_t widest = reference.max_alts;
-    const size_t lossy = reference.limitAlts();
-    ExecEnv::log().warn("GpuInbreedAnalysis; a reference offset holds {} SNP alts, 14 fit the 4-bit allele index: offsets cut to their first 14 "
+    const size_t lossy = reference.limitAlts(most);
+    ExecEnv::log().warn("GpuInbreedAnalysis; a reference offset holds {} SNP alts, {} fit the allele index: offsets cut to their first {} "
                         "frequency-bearing alts, {} of them lost a frequency-bearing alt (its carriers count as carriers of an unknown alt)",
-                        widest, lossy);
+                        widest, most, most, lossy);
   }
   return ok;
 }
@@ -326,18 +335,29 @@ kgl::analysis::gpu::FlatDiploid kga::GpuInbreedAnalysis::diploidBytes(const Popu
   locus_of_offset.reserve(n_loci * 2);
   for (uint32_t l = 0; l < n_loci; ++l) locus_of_offset.emplace(reference.loci[l].offset, l);
   out.bytes.assign(n_loci * G, 0);
+  // offsets with more than 14 alts: 16-bit cells beside the bytes (gpu::FlatDiploid::wide_*), their byte rows 0xFF throughout
+  std::vector<int64_t> wide_row_of(n_loci, -1);
+  for (uint32_t l = 0; l < n_loci; ++l)
+    if (reference.isWide(l)) {
+      wide_row_of[l] = static_cast<int64_t>(out.wide_loci.size());
+      out.wide_loci.push_back(l);
+      std::fill(&out.bytes[static_cast<uint64_t>(l) * G], &out.bytes[static_cast<uint64_t>(l) * G] + G, 0xFF);
+    }
+  out.wide_cells.assign(out.wide_loci.size() * G, 0);
   for (uint64_t g = 0; g < G; ++g) {
     for (const auto& [offset, offset_ptr] : contigs[g]->getMap()) {
       auto lit = locus_of_offset.find(offset);
       if (lit == locus_of_offset.end()) continue;
       const auto& alts = reference.loci[lit->second].alts;
+      const bool wide = wide_row_of[lit->second] >= 0;
+      const uint32_t unknown = wide ? 255u : 15u;                     // an alt the reference list does not hold
       uint32_t n = 0, code[2] = {0, 0};
       VariantPhase phase[2] = {VariantPhase::UNPHASED, VariantPhase::UNPHASED};
       for (const auto& variant_ptr : offset_ptr->getVariantArray()) {
         if (!variant_ptr->isSNP()) continue;                         // contig_ptr->viewFilter(SNPFilter()) (_freq.cpp:436)
         if (n < 2) {
           const std::string hgvs = variant_ptr->HGVS();
-          uint32_t c = 15;
+          uint32_t c = unknown;
           for (size_t j = 0; j < alts.size(); ++j)
             if (alts[j].hgvs == hgvs) { c = static_cast<uint32_t>(j + 1); break; }
           code[n] = c;
@@ -346,14 +366,16 @@ kgl::analysis::gpu::FlatDiploid kga::GpuInbreedAnalysis::diploidBytes(const Popu
         ++n;
       }
       if (n == 0) continue;
-      uint8_t b;
-      if (n >= 3) b = 0xFF;
+      const uint32_t bits = wide ? 8u : 4u;
+      uint32_t cell;
+      if (n >= 3) cell = wide ? 0xFFFFu : 0xFFu;
       else {
-        // two copies of one variant on ONE phase (a repeated record): analogous, not homozygous -> the (0, a) byte
-        if (n == 2 && code[0] == code[1] && code[0] != 15 && phased && phase[0] == phase[1]) b = static_cast<uint8_t>(code[0] << 4);
-        else b = static_cast<uint8_t>(code[0] | (code[1] << 4));
+        // two copies of one variant on ONE phase (a repeated record): analogous, not homozygous -> the (0, a) cell
+        if (n == 2 && code[0] == code[1] && code[0] != unknown && phased && phase[0] == phase[1]) cell = code[0] << bits;
+        else cell = code[0] | (code[1] << bits);
       }
-      out.bytes[static_cast<uint64_t>(lit->second) * G + g] = b;
+      if (wide) out.wide_cells[static_cast<uint64_t>(wide_row_of[lit->second]) * G + g] = static_cast<uint16_t>(cell);
+      else out.bytes[static_cast<uint64_t>(lit->second) * G + g] = static_cast<uint8_t>(cell);
     }
   }
   return out;
@@ -389,8 +411,10 @@ bool kga::GpuInbreedAnalysis::populationInbreeding(GpuParamOutput& param_output)
     return true;   // the reference logs and returns an empty results map (_diploid.cpp:107-112)
   }
   GpuReferenceContig reference;
-  if (!referenceInput(reference)) return false;
-  const uint32_t amax = std::max<uint32_t>(1, reference.max_alts);
+  if (!referenceInput(reference, GpuReferenceContig::kMaxWideAlts)) return false;
+  // the frequency table's columns: the most alts of an offset that fits a matrix byte -- a window that samples a WIDE offset (more
+  // than 14 alts, rare) gets a table as wide as that offset and is swept on its own, by the generic kernels
+  const uint32_t amax = reference.narrowAlts();
   const uint64_t n_loci = reference.loci.size();
   const auto& super_pops = FrequencyDatabaseRead::superPopulations();
   gpu::FlatDiploid diploid;
@@ -519,6 +543,20 @@ bool kga::GpuInbreedAnalysis::populationInbreeding(GpuParamOutput& param_output)
       return false;
     }
   }
+  // the offsets with more than 14 alts: their 16-bit rows, in the device's column order (every flattener leaves them in `diploid`)
+  if (!diploid.wide_loci.empty()) {
+    const uint64_t input_genomes = diploid.genome_ids.size(), n_wide = diploid.wide_loci.size();
+    std::vector<uint16_t> cells(n_wide * device_genomes, 0);
+    for (uint64_t w = 0; w < n_wide; ++w)
+      for (uint64_t g = 0; g < device_genomes; ++g)
+        if (column_of[g] >= 0) cells[w * device_genomes + g] = diploid.wide_cells[w * input_genomes + static_cast<uint64_t>(column_of[g])];
+    if (kgx_gt8_set_wide_rows(dev.handle, n_wide, diploid.wide_loci.data(), cells.data(), device_genomes) != KGX_OK) {
+      ExecEnv::log().error("GpuInbreedAnalysis; upload of the wide rows failed: {}", kgx_last_error());
+      return false;
+    }
+    ExecEnv::log().warn("GpuInbreedAnalysis; {} reference offsets hold more than 14 SNP alts (the widest {}): their cells are kept as 16-bit rows and the "
+                        "windows that sample them are swept on their own", n_wide, reference.max_alts);
+  }
 
   // The window loop of InbreedingAnalysis::populationInbreeding (_diploid.cpp:43-75).  Windows are independent once sampled --
   // a window's bounds follow from the reference contig alone, its super populations differ in their frequency rows and
@@ -530,7 +568,7 @@ bool kga::GpuInbreedAnalysis::populationInbreeding(GpuParamOutput& param_output)
   std::vector<uint32_t> locii_vector = reference.sampleLocii(all_slot, local, true);
   if (locii_vector.empty()) return true;
   local.upper_offset = reference.loci[locii_vector.back()].offset;
-  struct PendingTask { size_t sp; std::vector<uint32_t> selected; std::vector<double> af, start; std::vector<kgx_locus_results> results; };
+  struct PendingTask { size_t sp; uint32_t amax; std::vector<uint32_t> selected; std::vector<double> af, start; std::vector<kgx_locus_results> results; };
   struct PendingWindow { std::string column_ident; std::vector<PendingTask> tasks; };
   std::vector<uint64_t> streams;
   bool start_failed = false;
@@ -548,8 +586,11 @@ bool kga::GpuInbreedAnalysis::populationInbreeding(GpuParamOutput& param_output)
       PendingTask task;
       task.sp = sp;
       task.selected = reference.sampleLocii(static_cast<int>(sp), local, false);   // getLocusList (_locus.cpp:263-326)
-      task.af.assign(task.selected.size() * amax, kNaN);
-      for (size_t s = 0; s < task.selected.size(); ++s) reference.alleleFreqRow(task.selected[s], static_cast<int>(sp), &task.af[s * amax], amax);
+      task.amax = amax;
+      for (const uint32_t l : task.selected)
+        if (reference.isWide(l)) task.amax = std::max<uint32_t>(task.amax, static_cast<uint32_t>(reference.loci[l].alts.size()));
+      task.af.assign(task.selected.size() * task.amax, kNaN);
+      for (size_t s = 0; s < task.selected.size(); ++s) reference.alleleFreqRow(task.selected[s], static_cast<int>(sp), &task.af[s * task.amax], task.amax);
       task.results.assign(n, kgx_locus_results{});
       streams.resize(n);
       for (uint64_t k = 0; k < n; ++k) streams[k] = by_super_pop[sp][k].stream;
@@ -576,6 +617,12 @@ bool kga::GpuInbreedAnalysis::populationInbreeding(GpuParamOutput& param_output)
     std::vector<kgx_inbreed_task> tasks;
     for (PendingWindow& window : batch)
       for (PendingTask& task : window.tasks) {
+        if (task.amax != amax) {                                    // a window over a wide offset: on its own
+          if (kgx_inbreed(dev.handle, range_begin[task.sp], range_end[task.sp], task.selected.data(), task.selected.size(), task.af.data(), task.amax,
+                          phased ? 1 : 0, algorithm, task.start.empty() ? nullptr : task.start.data(), task.results.data()) != KGX_OK)
+            return kgx_last_error();
+          continue;
+        }
         kgx_inbreed_task t;
         t.g0 = range_begin[task.sp];
         t.g1 = range_end[task.sp];
@@ -693,7 +740,7 @@ bool kga::GpuInbreedAnalysis::syntheticInbreeding(GpuParamOutput& param_output) 
     return true;
   }
   GpuReferenceContig reference;
-  if (!referenceInput(reference)) return false;
+  if (!referenceInput(reference, GpuReferenceContig::kMaxAlts)) return false;
   const uint32_t amax = std::max<uint32_t>(1, reference.max_alts);
   const auto& super_pops = FrequencyDatabaseRead::superPopulations();
   const int all_slot = static_cast<int>(std::find(super_pops.begin(), super_pops.end(), std::string(FrequencyDatabaseRead::SUPER_POP_ALL_)) - super_pops.begin());

@@ -85,8 +85,11 @@ class GpuReferenceContig {
   // for some super population first (the others can be in no AlleleFreqVector and index as "unknown alt", the same to
   // every estimator) and is cut to 14; returns the number of offsets that lost a frequency-bearing alt that way (their
   // carriers of such an alt then count as carriers of an unknown one).
-  static constexpr uint32_t kMaxAlts = 14;
-  size_t limitAlts();
+  static constexpr uint32_t kMaxAlts = 14;          // two 4-bit indices of a matrix byte; offsets with more take a WIDE ROW (kgx_gt8_set_wide_rows) ...
+  static constexpr uint32_t kMaxWideAlts = 254;     // ... of two 8-bit indices
+  [[nodiscard]] bool isWide(size_t l) const { return loci[l].alts.size() > kMaxAlts; }
+  [[nodiscard]] uint32_t narrowAlts() const;        // the most alts of any offset that fits a byte (the frequency table's columns where no wide offset is selected)
+  size_t limitAlts(uint32_t most = kMaxWideAlts);
 };
 
 class GpuInbreedAnalysis : public VirtualAnalysis {
@@ -116,7 +119,7 @@ class GpuInbreedAnalysis : public VirtualAnalysis {
   bool populationInbreeding(GpuParamOutput& param_output);
   // Either source of the two inputs: the PopulationDB objects a parser delivered, or "FileNameOnly" VCF files the
   // package flattens itself (no Variant objects).
-  bool referenceInput(GpuReferenceContig& reference) const;       // referenceSource + GpuReferenceContig::limitAlts
+  bool referenceInput(GpuReferenceContig& reference, uint32_t most_alts) const;       // referenceSource + GpuReferenceContig::limitAlts(most_alts)
   bool referenceSource(GpuReferenceContig& reference) const;
   bool diploidInput(const GpuReferenceContig& reference, gpu::FlatDiploid& diploid, bool& phased) const;
   [[nodiscard]] bool haveReference() const { return unphased_population_ != nullptr || !reference_vcf_.empty(); }

@@ -162,8 +162,13 @@ struct FlatDiploid {
   std::vector<GenomeId_t> genome_ids;
   uint64_t n_loci{0};
   std::vector<uint8_t> bytes;              // [n_loci][genome_ids.size()]
+  // Reference loci with MORE than 14 alts do not fit two 4-bit indices: their cells are 16-bit here -- a1 | a2 << 8, indices up
+  // to 254, 255 = not in the list, 0xFFFF = three or more (kgx_gt8_set_wide_rows) -- and their byte rows are 0xFF throughout.
+  std::vector<uint32_t> wide_loci;         // ascending
+  std::vector<uint16_t> wide_cells;        // [wide_loci.size()][genome_ids.size()]
   std::string error;                       // reserved: every population the parser accepts is representable
 };
+constexpr size_t kGt8NarrowAlts = 14, kGt8WideAlts = 254;
 [[nodiscard]] FlatDiploid flattenVcf1000Gt8(std::string_view text, const FlatReference& reference, size_t threads = 0);
 // The same from a file read a bounded piece at a time (see flattenVcf1000File): between pieces only the calls of the
 // records that land on a reference locus are kept, a byte per cell of the result.
@@ -173,7 +178,8 @@ struct FlatDiploid {
 // Streaming: the rows of the loci a piece completes leave for the sink while the next piece is read; what stays on the
 // host between pieces is the records of the one locus that may go on.  Genomes are every sample, in id order, as soon as
 // the header is read (open); rows are [genome_ids.size()] bytes each and arrive as dense runs of consecutive loci in
-// ascending order (a locus no record lands on is never written: zero).  Returns false with two_phase set (error = why) for
+// ascending order (a locus no record lands on is never written: zero); the wide rows (loci of more than 14 alts) stay in
+// `diploid` and are complete at close.  Returns false with two_phase set (error = why) for
 // a file that has to take flattenVcf1000Gt8File instead: a sample named twice, a sample that carries nothing on the contig
 // (it is then no genome of it), records not in ascending position order.
 class Gt8StreamSink {

@@ -330,6 +330,15 @@ uint64_t kgxh_inbreed_loci(void* h) { return h ? static_cast<InbreedInputs*>(h)-
 uint64_t kgxh_inbreed_genomes(void* h) { return h ? static_cast<InbreedInputs*>(h)->diploid.genome_ids.size() : 0; }
 uint64_t kgxh_inbreed_max_alts(void* h) { return h ? static_cast<InbreedInputs*>(h)->reference.max_alts : 0; }
 uint64_t kgxh_inbreed_contigs(void* h) { return h ? static_cast<InbreedInputs*>(h)->reference.contigs : 0; }
+// the loci with more than 14 alts and their 16-bit cells (FlatDiploid::wide_*): count; then loci[n_wide], cells[n_wide][genomes]
+uint64_t kgxh_inbreed_wide_loci(void* h) { return h ? static_cast<InbreedInputs*>(h)->diploid.wide_loci.size() : 0; }
+int kgxh_inbreed_copy_wide(void* h, uint32_t* loci, uint16_t* cells) {
+  if (!h) return -1;
+  const auto& d = static_cast<InbreedInputs*>(h)->diploid;
+  if (loci && !d.wide_loci.empty()) std::memcpy(loci, d.wide_loci.data(), d.wide_loci.size() * sizeof(uint32_t));
+  if (cells && !d.wide_cells.empty()) std::memcpy(cells, d.wide_cells.data(), d.wide_cells.size() * sizeof(uint16_t));
+  return 0;
+}
 int kgxh_inbreed_error(void* h, char* buf, size_t n) {
   if (!h) return -1;
   copyOut(static_cast<InbreedInputs*>(h)->diploid.error, buf, n);

@@ -1044,19 +1044,23 @@ struct Gt8RecordCalls {
   std::vector<uint8_t> calls;           // [S]: phase A alt | phase B alt << 4  (alt numbers up to 15 fit; larger ones are clipped below)
   std::vector<std::pair<uint32_t, std::pair<uint32_t, uint32_t>>> wide;   // samples whose alt numbers need more than 4 bits
 };
-void assembleGt8Locus(const Gt8RecordCalls* const* records, size_t n_records, const std::vector<int64_t>& genome_of_sample, uint8_t* row,
+// Cell = uint8_t: two 4-bit codes (15 = not in the list); uint16_t: a wide locus, two 8-bit codes (255 = not in the list).
+template <typename Cell>
+void assembleGt8Locus(const Gt8RecordCalls* const* records, size_t n_records, const std::vector<int64_t>& genome_of_sample, Cell* row,
                       std::vector<uint8_t>& count, std::vector<uint8_t>& first_phase) {
+  constexpr unsigned kBits = sizeof(Cell) * 4;
+  constexpr unsigned kUnknown = (1u << kBits) - 1u;
   std::fill(count.begin(), count.end(), 0);
   auto add = [&](uint64_t g, uint8_t code, uint8_t phase) {
     const uint8_t n = count[g];
     if (n == 0) { row[g] = code; first_phase[g] = phase; }
     else if (n == 1) {
-      const uint8_t c0 = row[g] & 0xF;
-      // two copies of one variant on ONE phase (a repeated record): analogous, not homozygous -> the (0, a) byte
-      if (c0 == code && code != 15 && first_phase[g] == phase) row[g] = static_cast<uint8_t>(code << 4);
-      else row[g] = static_cast<uint8_t>(c0 | (code << 4));
+      const unsigned c0 = row[g] & kUnknown;
+      // two copies of one variant on ONE phase (a repeated record): analogous, not homozygous -> the (0, a) cell
+      if (c0 == code && code != kUnknown && first_phase[g] == phase) row[g] = static_cast<Cell>(static_cast<unsigned>(code) << kBits);
+      else row[g] = static_cast<Cell>(c0 | (static_cast<unsigned>(code) << kBits));
     } else {
-      row[g] = 0xFF;
+      row[g] = static_cast<Cell>(~0u);
     }
     if (n < 3) count[g] = static_cast<uint8_t>(n + 1);
   };
@@ -1103,6 +1107,8 @@ FlatDiploid flattenVcf1000Gt8Chunks(NextChunk&& next_piece, const FlatReference&
   std::unordered_map<ContigOffset_t, uint32_t> locus_of_offset;
   locus_of_offset.reserve(reference.loci.size() * 2);
   for (uint32_t l = 0; l < reference.loci.size(); ++l) locus_of_offset.emplace(reference.loci[l].offset, l);
+  std::vector<uint8_t> is_wide(reference.loci.size(), 0);          // more alts than two 4-bit indices address: 16-bit cells (FlatDiploid::wide_*)
+  for (uint32_t l = 0; l < reference.loci.size(); ++l) is_wide[l] = reference.loci[l].alts.size() > kGt8NarrowAlts ? 1 : 0;
 
   // Per record that lands on a reference locus: per alt its code in that locus's list (0 = not a SNP: filtered out
   // before the sweep, _freq.cpp:436), and per sample the two alt numbers.  A record off the loci only says who holds
@@ -1130,11 +1136,25 @@ FlatDiploid flattenVcf1000Gt8Chunks(NextChunk&& next_piece, const FlatReference&
     for (size_t k = 0; k < records.size(); ++k)
       if (k == 0 || records[k]->locus != records[k - 1]->locus) group_begin.push_back(k);
     group_begin.push_back(records.size());
+    // (the wide loci of this block: their 16-bit rows stay in `out`, appended in ascending order before the threads start)
+    std::vector<size_t> wide_at(group_begin.size() - 1, ~size_t{0});
+    for (size_t grp = 0; grp + 1 < group_begin.size(); ++grp)
+      if (is_wide[static_cast<size_t>(records[group_begin[grp]]->locus)]) {
+        wide_at[grp] = out.wide_loci.size();
+        out.wide_loci.push_back(static_cast<uint32_t>(records[group_begin[grp]]->locus));
+      }
+    out.wide_cells.resize(out.wide_loci.size() * G, 0);
     parallelChunks(group_begin.size() - 1, 64, threads, [&](size_t begin, size_t end) {
       std::vector<uint8_t> count(G), first_phase(G);
       for (size_t grp = begin; grp < end; ++grp) {
         const size_t k = group_begin[grp];
-        assembleGt8Locus(&records[k], group_begin[grp + 1] - k, stream_genome_of_sample, &block[static_cast<size_t>(records[k]->locus - first) * G], count, first_phase);
+        uint8_t* row = &block[static_cast<size_t>(records[k]->locus - first) * G];
+        if (wide_at[grp] != ~size_t{0}) {
+          assembleGt8Locus(&records[k], group_begin[grp + 1] - k, stream_genome_of_sample, &out.wide_cells[wide_at[grp] * G], count, first_phase);
+          std::fill(row, row + G, 0xFF);
+        } else {
+          assembleGt8Locus(&records[k], group_begin[grp + 1] - k, stream_genome_of_sample, row, count, first_phase);
+        }
       }
     });
     if (!stream->write(static_cast<uint64_t>(first), static_cast<uint64_t>(last - first + 1), block.data())) { streamFailed("the row sink failed while taking a piece's rows"); return false; }
@@ -1173,11 +1193,12 @@ FlatDiploid flattenVcf1000Gt8Chunks(NextChunk&& next_piece, const FlatReference&
           rc.locus = found->second;
           rc.code.assign(A, 0);
           const auto& list = reference.loci[found->second].alts;
+          const bool wide_locus = is_wide[found->second];
           for (size_t a = 0; a < A; ++a) {
             if (!isSnp(ref, alts[a])) continue;
             const std::string hgvs = std::string(f[0]) + ":g." + std::to_string(pos - 1) + std::string(ref) + ">" + std::string(alts[a]);
-            uint8_t c = 15;
-            for (size_t j = 0; j < list.size() && j < 14; ++j)
+            uint8_t c = wide_locus ? 255 : 15;                                   // not in the list
+            for (size_t j = 0; j < list.size() && j < (wide_locus ? kGt8WideAlts : kGt8NarrowAlts); ++j)
               if (list[j].hgvs == hgvs) { c = static_cast<uint8_t>(j + 1); break; }
             rc.code[a] = c;
           }
@@ -1273,6 +1294,12 @@ FlatDiploid flattenVcf1000Gt8Chunks(NextChunk&& next_piece, const FlatReference&
   const size_t G = out.genome_ids.size();
   out.bytes.assign(out.n_loci * G, 0);
   if (G == 0 || out.n_loci == 0) return out;          // nobody holds the contig, or no reference locus: nothing to assemble
+  for (uint32_t l = 0; l < reference.loci.size(); ++l)
+    if (is_wide[l]) {                                  // (every wide locus gets its row, carried or not)
+      out.wide_loci.push_back(l);
+      std::fill(&out.bytes[static_cast<uint64_t>(l) * G], &out.bytes[static_cast<uint64_t>(l) * G] + G, 0xFF);
+    }
+  out.wide_cells.assign(out.wide_loci.size() * G, 0);
 
   lap("genome order");
   // Assemble locus by locus (rows are independent; the records of one locus are taken in file order).  Per genome of the
@@ -1299,7 +1326,13 @@ FlatDiploid flattenVcf1000Gt8Chunks(NextChunk&& next_piece, const FlatReference&
         uint8_t* row = &out.bytes[static_cast<uint64_t>(locus) * G];
         std::vector<const RecordCalls*> records;
         for (; k < by_locus.size() && parsed[by_locus[k]].locus == locus; ++k) records.push_back(&parsed[by_locus[k]]);
-        assembleGt8Locus(records.data(), records.size(), genome_of_sample, row, count, first_phase);
+        if (is_wide[static_cast<size_t>(locus)]) {
+          const size_t at = static_cast<size_t>(std::lower_bound(out.wide_loci.begin(), out.wide_loci.end(), static_cast<uint32_t>(locus)) - out.wide_loci.begin());
+          assembleGt8Locus(records.data(), records.size(), genome_of_sample, &out.wide_cells[at * G], count, first_phase);
+          std::fill(row, row + G, 0xFF);
+        } else {
+          assembleGt8Locus(records.data(), records.size(), genome_of_sample, row, count, first_phase);
+        }
       }
     }
   };

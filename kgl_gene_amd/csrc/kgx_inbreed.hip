@@ -39,7 +39,12 @@ int sync_shards(const kgx_gt8* h) {
 
 void destroy_shards(kgx_gt8* h) {
   for (auto& sh : h->shards)
-    if (sh.d_gt && use_device(*sh.dev) == KGX_OK) (void)hipFree(sh.d_gt);
+    if ((sh.d_gt || sh.d_wide || sh.d_wide_of_row) && use_device(*sh.dev) == KGX_OK) {
+      if (sh.d_gt) (void)hipFree(sh.d_gt);
+      if (sh.d_wide) (void)hipFree(sh.d_wide);
+      if (sh.d_wide_of_row) (void)hipFree(sh.d_wide_of_row);
+      sh.d_gt = nullptr; sh.d_wide = nullptr; sh.d_wide_of_row = nullptr;
+    }
   if (!h->shards.empty()) (void)use_device(*h->shards[0].dev);
 }
 
@@ -146,7 +151,9 @@ int inbreed_shard(kgx_gt8_shard& sh, uint64_t g0, uint64_t g1, const uint32_t* l
   const size_t o_seq_sum = plan.add(n_seq_blocks * 4 * sizeof(double)), o_seq_e = plan.add(n_seq_blocks * 4 * sizeof(int));
   const size_t o_seq_n = plan.add(n_seq_blocks * 4 * sizeof(long long)), o_seq_out = plan.add(kParts0 * sizeof(double));
   // The table passes' entries (k_eval_entries): 64 / 256 / 1024 bytes per selected locus, only where such a pass will run.
-  const bool wave_sized = n_sel > 0 && n_sel <= static_cast<uint64_t>(kGenomeLoci) && !env_int("KGX_K7_NO_WAVE", 0) && objective_method == 0;
+  // (amax > 14: a selection with offsets of more than 14 reference alts -- their cells are in the matrix's wide rows, which the
+  // generic per-cell kernels alone read: no one-launch iteration, no moments; the table passes and SWAR sweeps stop at amax 7 / 4 anyway)
+  const bool wave_sized = n_sel > 0 && n_sel <= static_cast<uint64_t>(kGenomeLoci) && !env_int("KGX_K7_NO_WAVE", 0) && objective_method == 0 && amax <= 14;
   const bool table_passes = n_sel > 0 && (table_sweep || (eval_lut && (algorithm == 2 || algorithm == 3) && !wave_sized));
   const size_t o_entries = plan.add(table_passes ? (n_sel << (2u * eval_bits(amax))) * sizeof(EvalEntry) : 0);
   const size_t o_segcnt = plan.add(table_sweep ? max_seg * n * sizeof(unsigned long long) : sizeof(unsigned long long));
@@ -155,7 +162,7 @@ int inbreed_shard(kgx_gt8_shard& sh, uint64_t g0, uint64_t g1, const uint32_t* l
   // (any amax for HallME: the class passes compare bytes, no table; the generic / no-table flavours keep the passes they are there to test)
   const bool no_tables = env_int("KGX_K5_GENERIC", 0) || env_int("KGX_K5_NO_EVAL_LUT", 0);
   const int search = env_str("KGX_K7_SEARCH") == "brent" ? kSearchBrent : kSearchNelderMead;
-  const bool hall_candidate = algorithm == KGX_ALGO_HALL_ME && n_sel > 0 && n_sel < (1ull << 31) && !wave_sized && !no_tables &&
+  const bool hall_candidate = algorithm == KGX_ALGO_HALL_ME && n_sel > 0 && n_sel < (1ull << 31) && !wave_sized && !no_tables && amax <= 14 &&
                               !env_int("KGX_K7_HALL_PASSES", 0);                 // (the radix sort counts its items in an int)
   // Loglikelihood: the reference optimiser's path alone, a phased population (unphased: every alt homozygote is a heterozygous
   // cell that can meet the upper bound -- every genome would be handed to the passes), the frequency sweep as a table pass
@@ -327,7 +334,7 @@ int inbreed_shard(kgx_gt8_shard& sh, uint64_t g0, uint64_t g1, const uint32_t* l
 #undef KGX_SWAR16
       } else if (env_int("KGX_K5_GENERIC", 0) || amax > 4 || algorithm == KGX_ALGO_RITLAND_LOCUS) {
         hipLaunchKernelGGL((k_inbreed_sweep<0>), grid, dim3(kBlock), 0, st, gt32, dwords_per_row, g0, n, d_index, n_sel, per_seg, d_table,
-                           d_valid, amax, phased, d_f, d_counts, d_part);
+                           d_valid, amax, phased, d_f, d_counts, d_part, sh.d_wide_of_row, sh.d_wide, sh.wide_pitch);
       } else {
         hipLaunchKernelGGL(k_locus_bits, dim3(stream_grid(dev, n_sel, kBlock)), dim3(kBlock), 0, st, d_table, d_valid, n_sel, amax, d_meta);
         hipLaunchKernelGGL(k_segment_defaults, dim3(static_cast<uint32_t>(n_seg)), dim3(kWave), 0, st, d_table, d_valid, n_sel, per_seg, amax, sequential_defaults ? 1 : 0, d_segdef);
@@ -370,10 +377,10 @@ int inbreed_shard(kgx_gt8_shard& sh, uint64_t g0, uint64_t g1, const uint32_t* l
 #undef KGX_EVAL
     } else if (mode == 1)
       hipLaunchKernelGGL((k_inbreed_sweep<1>), grid, dim3(kBlock), 0, st, gt32, dwords_per_row, g0, n, d_index, n_sel, per_seg, d_table,
-                         d_valid, amax, phased, d_f, d_counts, d_part);
+                         d_valid, amax, phased, d_f, d_counts, d_part, sh.d_wide_of_row, sh.d_wide, sh.wide_pitch);
     else
       hipLaunchKernelGGL((k_inbreed_sweep<2>), grid, dim3(kBlock), 0, st, gt32, dwords_per_row, g0, n, d_index, n_sel, per_seg, d_table,
-                         d_valid, amax, phased, d_f, d_counts, d_part);
+                         d_valid, amax, phased, d_f, d_counts, d_part, sh.d_wide_of_row, sh.d_wide, sh.wide_pitch);
   };
   const uint32_t lin_grid = stream_grid(dev, n, kBlock);
   auto reduce_grid = [&](uint64_t items) { return stream_grid(dev, (items + kReduceItems - 1) / kReduceItems * kBlock, kBlock); };
@@ -1011,6 +1018,38 @@ int kgx_gt8_load_rows(kgx_gt8* h, const uint8_t* src, uint64_t src_pitch, uint64
   });
 }
 
+int kgx_gt8_set_wide_rows(kgx_gt8* h, uint64_t n_wide, const uint32_t* locus, const uint16_t* cells, uint64_t cells_pitch) {
+  return guarded([&]() -> int {
+    if (int bound = require_bound()) return bound;
+    if (!h || (n_wide && (!locus || !cells))) return fail(KGX_EINVAL, "null argument");
+    if (n_wide && cells_pitch < h->n_genomes) return fail(KGX_EINVAL, "cells_pitch below the genome count");
+    for (uint64_t i = 0; i < n_wide; ++i)
+      if (locus[i] >= h->n_loci || (i && locus[i] <= locus[i - 1])) return fail(KGX_EINVAL, "wide rows must name rows of the matrix, ascending");
+    std::vector<uint32_t> wide_of_row;
+    if (n_wide) {
+      wide_of_row.assign(h->n_loci, 0xFFFFFFFFu);
+      for (uint64_t i = 0; i < n_wide; ++i) wide_of_row[locus[i]] = static_cast<uint32_t>(i);
+    }
+    for (auto& sh : h->shards) {
+      if (int rc = use_device(*sh.dev)) return rc;
+      KGX_HIP(hipStreamSynchronize(sh.dev->stream));
+      if (sh.d_wide) (void)hipFree(sh.d_wide);
+      if (sh.d_wide_of_row) (void)hipFree(sh.d_wide_of_row);
+      sh.d_wide = nullptr; sh.d_wide_of_row = nullptr; sh.n_wide = 0; sh.wide_pitch = 0;
+      if (n_wide == 0 || sh.n_genomes == 0) continue;
+      sh.wide_pitch = (sh.n_genomes + 7) / 8 * 8;
+      KGX_HIP_MEM(hipMalloc(&sh.d_wide_of_row, h->n_loci * sizeof(uint32_t)));
+      KGX_HIP_MEM(hipMalloc(&sh.d_wide, n_wide * sh.wide_pitch * sizeof(uint16_t)));
+      KGX_HIP(hipMemsetAsync(sh.d_wide, 0, n_wide * sh.wide_pitch * sizeof(uint16_t), sh.dev->stream));
+      KGX_HIP(hipMemcpyAsync(sh.d_wide_of_row, wide_of_row.data(), h->n_loci * sizeof(uint32_t), hipMemcpyHostToDevice, sh.dev->stream));
+      KGX_HIP(hipMemcpy2DAsync(sh.d_wide, sh.wide_pitch * sizeof(uint16_t), cells + sh.genome_base, cells_pitch * sizeof(uint16_t),
+                               sh.n_genomes * sizeof(uint16_t), n_wide, hipMemcpyHostToDevice, sh.dev->stream));
+      sh.n_wide = n_wide;
+    }
+    return sync_shards(h);
+  });
+}
+
 int kgx_gt8_read_rows(const kgx_gt8* h, uint8_t* dst, uint64_t dst_pitch, uint64_t l0, uint64_t l1) {
   return guarded([&]() -> int {
     if (int bound = require_bound()) return bound;
@@ -1031,7 +1070,7 @@ int kgx_locus_class_frequencies(const double* minor_af, uint64_t n_loci, uint32_
   return guarded([&]() -> int {
     std::shared_ptr<Runtime> rt;
     if (int rc = require_runtime(rt)) return rc;
-    if (!minor_af || !out || amax == 0 || amax > 14) return fail(KGX_EINVAL, "bad arguments (amax must be 1..14)");
+    if (!minor_af || !out || amax == 0 || amax > 254) return fail(KGX_EINVAL, "bad arguments (amax must be 1..254)");
     if (n_loci == 0) return KGX_OK;
     Device& dev = *rt->devs[0];
     if (int rc = use_device(dev)) return rc;
@@ -1076,7 +1115,7 @@ int kgx_inbreed(kgx_gt8* h, uint64_t g0, uint64_t g1, const uint32_t* locus_inde
     if (int bound = require_bound()) return bound;
     if (!h || !out || (n_sel && !minor_af)) return fail(KGX_EINVAL, "null argument");
     if (g0 > g1 || g1 > h->n_genomes || (g0 & 3u)) return fail(KGX_EINVAL, "genome range must lie in the matrix and start on a multiple of 4");
-    if (amax == 0 || amax > 14) return fail(KGX_EINVAL, "amax %u outside [1,14] (4-bit allele indices)", amax);
+    if (amax == 0 || amax > 254) return fail(KGX_EINVAL, "amax %u outside [1,254] (8-bit allele indices of the wide rows; 14 for the matrix bytes)", amax);
     if (algorithm < 0 || algorithm > 3) return fail(KGX_EINVAL, "unknown algorithm %d", algorithm);
     if (start && (algorithm == KGX_ALGO_HALL_ME || algorithm == KGX_ALGO_LOGLIKELIHOOD))
       for (uint64_t g = 0; g < g1 - g0; ++g) {

@@ -186,6 +186,10 @@ struct kgx_gt8_shard {
   // bytes last changed, 1 = none, 2 = some.  Without them the SWAR sweeps need no guard against indexes past their
   // 8-entry tables (k_scan_wide_nibbles; every flattener output at <= 7 reference alts is such a matrix).
   int wide_nibbles = 0;
+  // Offsets with more than 14 reference alts (kgx_gt8_set_wide_rows): their cells as 16-bit pairs of 8-bit indices.
+  uint32_t* d_wide_of_row = nullptr;   // [n_loci]: the row's wide row, 0xFFFFFFFF = none; null = the matrix has none
+  uint16_t* d_wide = nullptr;          // [n_wide][wide_pitch]
+  uint64_t wide_pitch = 0, n_wide = 0;
 };
 
 struct kgx_gt8 {

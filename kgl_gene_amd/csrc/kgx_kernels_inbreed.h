@@ -119,16 +119,17 @@ k_locus_tables(const double* __restrict__ af_in, uint64_t n_loci, uint32_t amax,
 
 enum : int { kClassNone = 0, kMajorHom = 1, kMajorHet = 2, kMinorHom = 3, kMinorHet = 4 };
 
-// generateFrequencies' per-locus decision (_freq.cpp:452-543) for one genotype byte.
-__device__ __forceinline__ int classify_cell(uint32_t b, const double* __restrict__ row, uint32_t amax, bool phased,
+// generateFrequencies' per-locus decision (_freq.cpp:452-543) for one cell: the genome's (up to) two SNP variants at the offset
+// as 1 + their place in the locus's reference alt list (0 none; an index past amax: an alt the list does not hold -- the
+// matrix bytes' 15, a wide row's 255 -- or the "three or more variants" marker).
+__device__ __forceinline__ int classify_pair(uint32_t a1, uint32_t a2, const double* __restrict__ row, uint32_t amax, bool phased,
                                              double& f1, double& f2) {
   const double p_major = row[amax];
-  if (b == 0) {
+  if ((a1 | a2) == 0u) {
     if (p_major > 0.01) { f1 = p_major; f2 = p_major; return kMajorHom; }   // minimum_major_frequency (:531-539)
     return kClassNone;
   }
-  const uint32_t a1 = b & 15u, a2 = b >> 4;
-  if (a1 == 15u || a2 == 15u || a1 > amax || a2 > amax) return kClassNone;    // unknown alt, >= 3 variants (0xFF), past the table
+  if (a1 > amax || a2 > amax) return kClassNone;                              // unknown alt, >= 3 variants, past the table
   if (a1 == 0u) {
     // (0, a): two copies of alt a on ONE phase (a repeated VCF record).  They are analogous but not homozygous()
     // (kgl_variant_db.h:135-143), so the offset takes the two-variant branch with the same allele found twice
@@ -147,18 +148,31 @@ __device__ __forceinline__ int classify_cell(uint32_t b, const double* __restric
   return kMinorHet;
 }
 
+// ... for one genotype byte of the matrix: two 4-bit indices (15: an alt the list does not hold; 0xFF: three or more variants).
+// (amax <= 14 for every call that reads bytes alone, so 15 is past the table; a call with wider loci -- amax up to 254 --
+// reads those loci's cells from the matrix's WIDE ROWS, 8-bit indices, and a byte's 15 must not index its table.)
+__device__ __forceinline__ int classify_cell(uint32_t b, const double* __restrict__ row, uint32_t amax, bool phased,
+                                             double& f1, double& f2) {
+  const uint32_t a1 = b & 15u, a2 = b >> 4;
+  if (a1 == 15u || a2 == 15u) return kClassNone;
+  return classify_pair(a1, a2, row, amax, phased, f1, f2);
+}
+
 // MODE 0: class counts + class-frequency sums at F=0 + Ritland terms   (generateFrequencies, processRitlandLocus)
 // MODE 1: one Hall expectation step:  sum over hom loci of F/(F+(1-F)p)  (processHallME :255-285)
 // MODE 2: log-likelihood at F                                            (logLikelihood :94-129)
 // Grid: x = genome quads of 256 threads (1024 genomes), y = locus segment.  Per (segment, genome) partials
 // go to part[(seg*n_genomes + g)*kParts + k]; integer class counts are added atomically to counts[g][6].
 constexpr int kParts0 = 5;   // majorHom, majorHet, minorHom, minorHet frequency sums, Ritland sum
+// wide_of_row (may be null): for every row of the matrix the index of its WIDE ROW, 0xFFFFFFFF for none -- an offset with more than
+// 14 reference alts: its cells are 16-bit, two 8-bit indices, in wide_cells[wide row][wide_pitch] (kgx_gt8_set_wide_rows).
 template <int MODE>
 __global__ void __launch_bounds__(kBlock)
 k_inbreed_sweep(const uint32_t* __restrict__ gt, uint64_t dwords_per_row, uint64_t g0, uint64_t n_genomes,
                 const uint32_t* __restrict__ locus_index, uint64_t n_sel, uint64_t loci_per_seg,
                 const double* __restrict__ table, const uint8_t* __restrict__ valid, uint32_t amax, int phased,
-                const double* __restrict__ f_in, unsigned long long* __restrict__ counts, double* __restrict__ part) {
+                const double* __restrict__ f_in, unsigned long long* __restrict__ counts, double* __restrict__ part,
+                const uint32_t* __restrict__ wide_of_row = nullptr, const uint16_t* __restrict__ wide_cells = nullptr, uint64_t wide_pitch = 0) {
   const uint64_t quad = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x;   // 4 genomes g0 + 4*quad ..
   if (quad * 4 >= n_genomes) return;
   const uint64_t seg = blockIdx.y;
@@ -185,10 +199,18 @@ k_inbreed_sweep(const uint32_t* __restrict__ gt, uint64_t dwords_per_row, uint64
     const uint64_t l = locus_index ? static_cast<uint64_t>(locus_index[s]) : s;
     const uint32_t w = gt[l * dwords_per_row + col];
     const double* row = table + s * stride;
+    const uint32_t wide = wide_of_row ? wide_of_row[l] : 0xFFFFFFFFu;              // (the same for the whole workgroup)
+    const uint16_t* wide_row = wide != 0xFFFFFFFFu ? wide_cells + static_cast<uint64_t>(wide) * wide_pitch + g0 + quad * 4 : nullptr;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       double f1 = 0.0, f2 = 0.0;
-      const int cls = classify_cell((w >> (8 * j)) & 0xFFu, row, amax, phased != 0, f1, f2);
+      int cls;
+      if (wide_row) {
+        const uint32_t pair = quad * 4 + j < n_genomes ? wide_row[j] : 0u;
+        cls = classify_pair(pair & 0xFFu, pair >> 8, row, amax, phased != 0, f1, f2);
+      } else {
+        cls = classify_cell((w >> (8 * j)) & 0xFFu, row, amax, phased != 0, f1, f2);
+      }
       if (cls == kClassNone) continue;
       if constexpr (MODE == 0) {
         ++cnt[j][cls - 1];

@@ -133,9 +133,9 @@ extern "C" int kgx_inbreed_batch(kgx_gt8* h, const kgx_inbreed_task* tasks, uint
   return guarded([&]() -> int {
     if (int bound = require_bound()) return bound;
     if (!h || (n_tasks && !tasks)) return fail(KGX_EINVAL, "null argument");
-    if (amax == 0 || amax > 14) return fail(KGX_EINVAL, "amax %u outside [1,14] (4-bit allele indices)", amax);
+    if (amax == 0 || amax > 254) return fail(KGX_EINVAL, "amax %u outside [1,254]", amax);
     if (algorithm < 0 || algorithm > 3) return fail(KGX_EINVAL, "unknown algorithm %d", algorithm);
-    bool one_launch = !env_int("KGX_K7_NO_WAVE", 0) && !env_int("KGX_BATCH_BY_CALLS", 0);
+    bool one_launch = !env_int("KGX_K7_NO_WAVE", 0) && !env_int("KGX_BATCH_BY_CALLS", 0) && amax <= 14;   // (wider loci: the generic kernels, call by call)
     for (uint32_t i = 0; i < n_tasks; ++i) {
       const kgx_inbreed_task& t = tasks[i];
       if (!t.out || (t.n_selected && !t.minor_af)) return fail(KGX_EINVAL, "task %u: null argument", i);

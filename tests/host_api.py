@@ -215,6 +215,14 @@ class InbreedInputs:
             self.bytes = np.zeros((self.L, self.G), dtype=np.uint8)
             p = lambda a: C.c_void_p(a.ctypes.data)
             lib().kgxh_inbreed_copy(h, p(self.offsets), p(self.n_alts), p(self.af), max(self.amax, 1), p(self.bytes) if self.G and not self.error else None)
+            lib().kgxh_inbreed_wide_loci.restype = C.c_uint64
+            lib().kgxh_inbreed_wide_loci.argtypes = [C.c_void_p]
+            lib().kgxh_inbreed_copy_wide.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+            n_wide = int(lib().kgxh_inbreed_wide_loci(h))
+            self.wide_loci = np.zeros(n_wide, dtype=np.uint32)          # loci with more than 14 alts: their cells are 16-bit
+            self.wide_cells = np.zeros((n_wide, self.G), dtype=np.uint16)
+            if n_wide and self.G and not self.error:
+                lib().kgxh_inbreed_copy_wide(h, p(self.wide_loci), p(self.wide_cells))
             self.genome_ids = []
             for i in range(self.G):
                 lib().kgxh_inbreed_genome_id(h, i, buf, 1024)

@@ -81,6 +81,27 @@ class ReferenceLoci:
 
 def encode_gt8(rec, gt, loci: ReferenceLoci, phased_order=True):
     """[n_loci][G] bytes: the genome's SNP variants at each reference offset in OffsetDB order."""
+    a1, a2 = encode_pairs(rec, gt, loci, phased_order, unknown=15, many=15)
+    assert a1.max(initial=0) <= 15 and a2.max(initial=0) <= 15, "an offset with more than 14 alts: encode_wide"
+    return (a1 | (a2 << 4)).astype(np.uint8)
+
+
+def encode_wide(rec, gt, loci: ReferenceLoci, phased_order=True):
+    """The same where offsets may hold more than 14 reference alts: (bytes [n_loci][G], wide locus indices, wide cells uint16
+    [n_wide][G] = a1 | a2 << 8).  The byte row of a wide locus is 0xFF throughout (a call that reads bytes alone sees nothing there)."""
+    a1, a2 = encode_pairs(rec, gt, loci, phased_order, unknown=255, many=255)
+    wide = np.array([l for l, alts in enumerate(loci.alts) if len(alts) > 14], dtype=np.uint32)
+    narrow1, narrow2 = np.where(a1 == 255, 15, a1), np.where(a2 == 255, 15, a2)
+    assert np.delete(narrow1, wide, axis=0).max(initial=0) <= 15 and np.delete(narrow2, wide, axis=0).max(initial=0) <= 15
+    out = (narrow1 | (narrow2 << 4)).astype(np.uint8)
+    out[wide] = 0xFF
+    cells = (a1[wide].astype(np.uint16) | (a2[wide].astype(np.uint16) << 8)).astype(np.uint16)
+    return out, wide, cells
+
+
+def encode_pairs(rec, gt, loci: ReferenceLoci, phased_order, unknown, many):
+    """(a1, a2) [n_loci][G]: 1 + the place of the genome's first / second SNP variant in the offset's alt list, `unknown` for
+    an alt the list does not hold, (many, many) for three or more variants."""
     R, G, _ = gt.shape
     index_of = {int(o): i for i, o in enumerate(loci.offsets)}
     carried = [[[] for _ in range(G)] for _ in range(len(loci.offsets))]
@@ -101,9 +122,10 @@ def encode_gt8(rec, gt, loci: ReferenceLoci, phased_order=True):
                 alt = rec.alts[r][a - 1]
                 if not is_snp(rec.refs[r], alt):
                     continue
-                code = keys.get((rec.refs[r], alt), 15)
+                code = keys.get((rec.refs[r], alt), unknown)
                 carried[l][g].append((phase if phased_order else 0, r, phase, code))
-    out = np.zeros((len(loci.offsets), G), dtype=np.uint8)
+    out1 = np.zeros((len(loci.offsets), G), dtype=np.uint32)
+    out2 = np.zeros((len(loci.offsets), G), dtype=np.uint32)
     for l in range(len(loci.offsets)):
         for g in range(G):
             c = carried[l][g]
@@ -115,12 +137,12 @@ def encode_gt8(rec, gt, loci: ReferenceLoci, phased_order=True):
             else:
                 c.sort(key=lambda t: (t[1], t[2]))
             if len(c) >= 3:
-                out[l, g] = 0xFF
+                out1[l, g] = out2[l, g] = many
             else:
                 a1 = c[0][3]
                 a2 = c[1][3] if len(c) == 2 else 0
-                if phased_order and len(c) == 2 and a1 == a2 and a1 != 15 and c[0][2] == c[1][2]:
-                    out[l, g] = a1 << 4          # two copies on ONE phase (a repeated record): the (0, a) byte
+                if phased_order and len(c) == 2 and a1 == a2 and a1 != unknown and c[0][2] == c[1][2]:
+                    out1[l, g], out2[l, g] = 0, a1       # two copies on ONE phase (a repeated record): the (0, a) pair
                 else:
-                    out[l, g] = a1 | (a2 << 4)
-    return out
+                    out1[l, g], out2[l, g] = a1, a2
+    return out1, out2

@@ -910,3 +910,68 @@ def test_batched_windows_are_the_single_calls(kgx, algorithm, monkeypatch):
         want = m.inbreed(t["minor_af"], algorithm, phased=True, locus_index=t["locus_index"], g0=t["g0"], g1=t["g1"], start=t["start"])
         assert np.array_equal(got["inbred_allele_sum"], want["inbred_allele_sum"], equal_nan=True)
     m.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("algorithm", ["Simple", "RitlandLocus", "HallME", "Loglikelihood"])
+def test_offsets_with_more_than_fourteen_alts_vs_oracle(kgx, algorithm):
+    """AlleleFreqVector has no cap on the alts of an offset (kga_analysis_inbreed_freq.cpp:18-57), and isSNP() admits multi-base
+    records that differ in one nucleotide (kgl_variant_db.cpp:121-158): three offsets here spell out 20, 17 and 15 SNP alts
+    of an eight-base reference.  Their cells go to the matrix's wide rows (8-bit indices, kgx_gt8_set_wide_rows), the
+    frequency table gets 20 columns, and every estimator must give what the oracle's generateFrequencies + process* give:
+    counts bit for bit, sums to 1e-12, the coefficients as for any other window."""
+    G, L = 60, 400
+    rec, gt = sv.multiallelic_block(G, L, rng_seed=21, missing_af_frac=0.0, dup_records=0)
+    rng = np.random.default_rng(4)
+    bases = "ACGT"
+    offsets, refs, alts, afs = list(rec.offsets), list(rec.refs), [list(a) for a in rec.alts], [np.asarray(a, dtype=np.float32).reshape(-1, 6) for a in rec.af]
+    wide_records = []
+    for n_alt, at in ((20, 37), (17, 191), (15, 333)):
+        ref = "ACGTTGCA"
+        spelled = [ref[:p] + b + ref[p + 1:] for p in range(8) for b in bases if b != ref[p]][:n_alt]
+        p = rng.uniform(0.005, 0.04, n_alt)
+        refs[at], alts[at], afs[at] = ref, spelled, np.tile(p.astype(np.float32).reshape(-1, 1), (1, 6))
+        wide_records.append(at)
+    rec = oa.Records(rec.contig, np.array(offsets, dtype=np.uint64), refs, alts, af=afs)
+    gt = gt.copy()
+    for at in wide_records:                                   # genotypes over all of the offset's alts, both phases
+        n_alt = len(alts[at])
+        gt[at, :, 0] = np.where(rng.random(G) < 0.5, rng.integers(1, n_alt + 1, G), 0)
+        gt[at, :, 1] = np.where(rng.random(G) < 0.5, rng.integers(1, n_alt + 1, G), 0)
+        gt[at, :8, 0] = gt[at, :8, 1] = np.arange(13, 21)[:8].clip(max=n_alt)     # homozygotes of alts past the 14th
+    ids = sv.genome_ids(G)
+    ref = oa.Population("gnomad")
+    ref.add_genomes(["Reference"])
+    ref.add_records(rec, None, oa.Population.REFERENCE)
+    dip = sv.oracle_population(rec, gt, ids, oa.Population.PHASED)
+    loci = ii.ReferenceLoci(rec)
+    amax = max(len(a) for a in loci.alts)
+    assert amax == 20
+    table = loci.af_table(oa.ALL, amax)
+    sel = loci.sample(table, 0, 10**9, 1, 0.0, 1.0)
+    bytes_, wide, cells = ii.encode_wide(rec, gt, loci, phased_order=True)
+    assert len(wide) == 3 and set(wide.tolist()) <= set(sel.tolist())
+    m = kgx.GenotypeMatrix(G, len(loci.offsets))
+    m.load_rows(bytes_)
+    m.set_wide_rows(wide, cells)
+    order = dip.genome_order()
+    counts, freqs, present, _ = oa.inbreed_window(ref.filter_snp_pass(), dip, np.full(G, oa.ALL, dtype=np.int32), algorithm, 0, 10**9, 1, 10**6, 0.0, 1.0,
+                                                  seed=START_SEED)
+    assert present.all()
+    got = m.inbreed(table[sel], algorithm, phased=True, locus_index=sel, start=seeded_starts(kgx, algorithm, START_SEED, order))[order]
+    for k, name in enumerate(["major_hetero_count", "minor_hetero_count", "minor_homo_count", "major_homo_count", "total_allele_count"]):
+        assert np.array_equal(got[name], counts[:, k]), name
+    for k, name in enumerate(["major_hetero_freq", "minor_hetero_freq", "minor_homo_freq", "major_homo_freq"]):
+        assert np.allclose(got[name], freqs[:, k], rtol=REL, atol=REL), name
+    tolerance = {"Simple": 1e-10, "RitlandLocus": 1e-10, "HallME": 1e-9, "Loglikelihood": 2e-6}[algorithm]
+    assert np.abs(got["inbred_allele_sum"] - freqs[:, 4]).max() <= tolerance
+    # the wide offsets did count: without their rows (bytes 0xFF there: nothing) the totals fall short
+    m.set_wide_rows(None, None)
+    without = m.inbreed(table[sel], algorithm, phased=True, locus_index=sel, start=seeded_starts(kgx, algorithm, START_SEED, order))[order]
+    assert (without["total_allele_count"] < got["total_allele_count"]).any()
+    # ... and as a batch of one task (made of single calls: the one-launch kernel reads bytes alone)
+    m.set_wide_rows(wide, cells)
+    batch = m.inbreed_batch([{"locus_index": sel, "minor_af": table[sel], "start": None if algorithm in ("Simple", "RitlandLocus") else seeded_starts(kgx, algorithm, START_SEED, order)}],
+                            algorithm, phased=True)[0][order]
+    assert np.array_equal(batch["total_allele_count"], got["total_allele_count"])
+    m.close()

@@ -505,3 +505,51 @@ def test_flatteners_survive_mangled_text():
             assert flat.V >= 0 and flat.G >= 0
         got = ha.InbreedInputs(texts[2] if trial % 2 else text, DATA_SOURCE["Gnomad2_1"], text)
         assert got.L >= 0
+
+
+def test_inbreed_inputs_with_offsets_of_more_than_fourteen_alts():
+    """A reference offset with more than 14 SNP alts (multi-base records that differ in one nucleotide) does not fit two 4-bit
+    indices: every gt8 flattener -- whole text, a file in pieces, streamed -- leaves its cells as 16-bit wide rows (and its byte
+    row 0xFF throughout), equal to the scaffold encoder's."""
+    import tempfile
+    from pathlib import Path
+
+    from . import inbreed_inputs as ii
+    from .records_io import DATA_SOURCE
+
+    G, L = 23, 300
+    rec, gt = sv.multiallelic_block(G, L, rng_seed=9, indel_frac=0.0, missing_af_frac=0.0, dup_records=0)
+    rng = np.random.default_rng(2)
+    offsets, refs, alts, afs = list(rec.offsets), list(rec.refs), [list(a) for a in rec.alts], [np.array(a) for a in rec.af]
+    for at, n_alt in ((40, 19), (150, 15), (299, 21)):
+        ref = "ACGTACG"
+        al = [ref[:i] + b + ref[i + 1:] for i in range(7) for b in "ACGT" if b != ref[i]][:n_alt]
+        refs[at], alts[at] = ref, al
+        afs[at] = np.tile(rng.uniform(0.004, 0.03, n_alt).astype(np.float32).reshape(-1, 1), (1, 6))
+        gt[at, :, 0] = np.where(rng.random(G) < 0.6, rng.integers(1, n_alt + 1, G), 0)
+        gt[at, :, 1] = np.where(rng.random(G) < 0.6, rng.integers(1, n_alt + 1, G), 0)
+    # a repeated record of a wide offset right behind it: same-phase pairs and three-variant cells in 16 bits
+    offsets.insert(151, offsets[150]); refs.insert(151, refs[150]); alts.insert(151, list(alts[150])); afs.insert(151, afs[150].copy())
+    gt = np.insert(gt, 151, gt[150], axis=0)
+    gt[151, ::3, :] = 0
+    rec = oa.Records(rec.contig, np.array(offsets, dtype=np.uint64), refs, alts, af=afs)
+    for a in rec.af:
+        a[:, 4] = a[:, 5]
+    ids = [f"NA{i:05d}" for i in range(G)]
+    ref_text = vt.write_vcf_mono(rec, "Gnomad2_1")
+    dip_text = vt.write_vcf_1000(rec, gt, ids, rng_seed=1, quirks=False)
+    loci = ii.ReferenceLoci(rec)
+    want_bytes, want_wide, want_cells = ii.encode_wide(rec, gt, loci)
+    assert len(want_wide) == 3 and (want_cells == 0xFFFF).any() and ((want_cells & 0xFF) == 0)[want_cells != 0].any()
+    got = ha.InbreedInputs(ref_text, DATA_SOURCE["Gnomad2_1"], dip_text, 2)
+    assert got.error == "" and got.genome_ids == ids and got.amax == 30            # (the repeated record's alts join the offset's list)
+    with tempfile.TemporaryDirectory() as tmp:
+        path = Path(tmp) / "kg.vcf"
+        path.write_text(dip_text)
+        variants = [("text", got)]
+        for chunk_bytes in (1, 4000, 0):
+            variants.append((f"file {chunk_bytes}", ha.InbreedInputs(ref_text, DATA_SOURCE["Gnomad2_1"], None, 2, diploid_path=path, chunk_bytes=chunk_bytes)))
+            variants.append((f"streamed {chunk_bytes}", ha.InbreedInputs(ref_text, DATA_SOURCE["Gnomad2_1"], None, 2, diploid_path=path, chunk_bytes=chunk_bytes, streaming=True)))
+        for name, flat in variants:
+            assert np.array_equal(flat.bytes, want_bytes), name
+            assert np.array_equal(flat.wide_loci, want_wide) and np.array_equal(flat.wide_cells, want_cells), name
