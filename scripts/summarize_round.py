@@ -8,7 +8,7 @@ import collections, csv, glob, json, re, sys
 from pathlib import Path
 
 ROOT = Path(__file__).resolve().parent.parent
-tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r04"
 src, dst = ROOT / "gpurun_out" / f"prof_{tag}", ROOT / "profiles"
 dst.mkdir(exist_ok=True)
 
@@ -153,5 +153,54 @@ if hall_files:
         if "k_hall" in r["Name"] or "rocprim" in r["Name"] or "eval_lut<1" in r["Name"]:
             lines.append(f"| `{short(r['Name'])[:90]}` | {r['Calls']} | {float(r['AverageNs']) / 1e6:.3f} |")
     lines += ["", "```"] + [l for l in (src / "hall.txt").read_text().strip().splitlines() if "amdgpu.ids" not in l] + ["```", ""]
+# ---- Loglikelihood over a large call: the moments + the exact walk against the passes; traffic and SQ counters of its kernels
+ll_files = glob.glob(str(src / "loglik_trace/*/*kernel_stats.csv"))
+if ll_files:
+    ll_stats = Path(max(ll_files, key=lambda f: Path(f).stat().st_mtime))
+    (dst / f"{tag}_loglik_kernel_stats.csv").write_text(ll_stats.read_text())
+    lines += ["## Loglikelihood at C5 on per-genome moments (`scripts/bench_loglik.py`: 4 calls by moments, then 4 by the passes)", "",
+              "`rocprofv3 --kernel-trace --stats -- python3 scripts/bench_loglik.py`; `k_hall_sweep<8, true>` runs once per class of homozygous cell and leaves "
+              "the hits' bits for the bins a band can reach; `k_loglik_search` is the whole search of every genome.", "",
+              "| kernel | calls | avg ms |", "|---|---|---|"]
+    for r in csv.DictReader(ll_stats.open()):
+        if any(k in r["Name"] for k in ("k_hall", "k_loglik", "rocprim", "eval_lut<2", "eval_lut<3", "k_eval_entries<5", "k_gather_columns")):
+            lines.append(f"| `{short(r['Name'])[:90]}` | {r['Calls']} | {float(r['AverageNs']) / 1e6:.3f} |")
+    lines += ["", "```"] + [l for l in (src / "loglik.txt").read_text().strip().splitlines() if "amdgpu.ids" not in l] + ["```", ""]
+    try:
+        ll_fetch, ll_write = counter("loglik_fetch/*/*counter_collection.csv", "FETCH_SIZE"), counter("loglik_write/*/*counter_collection.csv", "WRITE_SIZE")
+        ll_sq = collections.defaultdict(lambda: collections.defaultdict(list))
+        for r in csv.DictReader(one("loglik_sq/*/*counter_collection.csv").open()):
+            ll_sq[short(r["Kernel_Name"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
+        lines += ["Counters of the same calls (`--moments-only`; per launch, means; the class passes: the two that cover every locus alone):", "",
+                  "| kernel | HBM read = 2 x FETCH_SIZE x 1024 | HBM write = WRITE_SIZE x 1024 | VALU wave-instr | VALU per cell (x64 / 5e10) | LDS instr | wait-inst / wave cycles |",
+                  "|---|---|---|---|---|---|---|"]
+        rows_pmc = []
+        for needle, full in (("k_hall_sweep<8, true>", True), ("k_loglik_search", False), ("k_inbreed_eval_lut<3", False)):
+            name = next((k for k in ll_sq if needle in k), None)
+            if not name:
+                continue
+            pick = (lambda v: [x for x in v if x >= 0.9 * max(v)]) if full else (lambda v: v)
+            f = pick([v for k, vs in ll_fetch.items() if needle in k for v in vs])
+            w = pick([v for k, vs in ll_write.items() if needle in k for v in vs])
+            c = {k: (lambda v: sum(v) / len(v))(pick(v)) for k, v in ll_sq[name].items() if v}
+            valu = c.get("SQ_INSTS_VALU", float("nan"))
+            lines.append(f"| `{name}` | {2.0 * sum(f) / len(f) * 1024.0:,.0f} | {sum(w) / len(w) * 1024.0:,.0f} | {valu:.4g} | {valu * 64 / cells:.2f} | "
+                         f"{c.get('SQ_INSTS_LDS', float('nan')):.4g} | {c.get('SQ_WAIT_INST_ANY', float('nan')) / c.get('SQ_WAVE_CYCLES', float('nan')):.2f} |")
+            rows_pmc += [f"{name},FETCH_SIZE,{len(f)},{sum(f) / len(f)}", f"{name},WRITE_SIZE,{len(w)},{sum(w) / len(w)}"]
+        with (dst / f"{tag}_pmc.csv").open("a") as fh:
+            fh.write("\n".join(rows_pmc) + "\n")
+        lines += [""]
+    except SystemExit:
+        lines += ["(counter passes of the Loglikelihood calls: not collected in this run)", ""]
+# ---- the batched window regime
+batch_files = glob.glob(str(src / "batch_trace/*/*kernel_stats.csv"))
+if batch_files:
+    batch_stats = Path(max(batch_files, key=lambda f: Path(f).stat().st_mtime))
+    (dst / f"{tag}_batch_kernel_stats.csv").write_text(batch_stats.read_text())
+    lines += ["## Batched windows: 16 windows x 5 super populations per `kgx_inbreed_batch` (`scripts/bench_inbreed_batch.py`)", "",
+              "| kernel | calls | avg us | share of the traced GPU time |", "|---|---|---|---|"]
+    for r in sorted(csv.DictReader(batch_stats.open()), key=lambda r: -float(r["TotalDurationNs"]))[:8]:
+        lines.append(f"| `{short(r['Name'])[:90]}` | {r['Calls']} | {float(r['AverageNs']) / 1e3:.1f} | {float(r['Percentage']):.1f} % |")
+    lines += ["", "```"] + [l for l in (src / "batch.txt").read_text().strip().splitlines() if "amdgpu.ids" not in l] + ["```", ""]
 (dst / f"{tag}_summary.md").write_text("\n".join(lines))
 print("\n".join(lines))
