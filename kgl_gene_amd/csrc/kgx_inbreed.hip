@@ -211,7 +211,7 @@ int inbreed_shard(kgx_gt8_shard& sh, uint64_t g0, uint64_t g1, const uint32_t* l
   const size_t o_hall_moments = plan.add(plan_items * kHallMoments * n * sizeof(double));
   const size_t o_hall_bins = plan.add(by_moments_planned ? static_cast<size_t>(kHallBins) * kHallMoments * n * sizeof(double) : 0);
   const size_t o_needs_passes = plan.add(loglik_moments ? n * sizeof(uint32_t) : 0);
-  const size_t o_smallest_het = plan.add(sizeof(unsigned long long));
+  const size_t o_smallest_het = plan.add(sizeof(unsigned long long)), o_search_stats = plan.add(8 * sizeof(unsigned long long));
   char* arena = nullptr;
   if (int arc = scratch_reserve(dev, plan.total, &arena)) return arc;
   d_af = reinterpret_cast<double*>(arena + o_af);
@@ -632,9 +632,12 @@ int inbreed_shard(kgx_gt8_shard& sh, uint64_t g0, uint64_t g1, const uint32_t* l
         uint32_t n_used = 0;                                        // (the search keeps the genome's bins in LDS: as much of it as they need)
         try_hip(hipMemcpyAsync(&n_used, h_totals, sizeof(uint32_t), hipMemcpyDeviceToHost, st), KGX_EHIP, "D2H(used bins)");
         try_hip(hipStreamSynchronize(st), KGX_EHIP, "sync");
+        unsigned long long* d_search_stats = env_int("KGX_K7_TRACE", 0) ? reinterpret_cast<unsigned long long*>(arena + o_search_stats) : nullptr;
+        if (d_search_stats) try_hip(hipMemsetAsync(d_search_stats, 0, 8 * sizeof(unsigned long long), st), KGX_EHIP, "memset(search stats)");
         try_hip(hipEventRecord(dev.search_begin, st), KGX_EHIP, "hipEventRecord");
         hipLaunchKernelGGL(k_loglik_search, dim3(static_cast<uint32_t>(n)), dim3(kBlock), loglik_search_lds(n_used), st, h_bins, h_used, h_totals, d_counts, d_sums,
-                           d_smallest_het, n, words_per_block, loglik_classes, d_start, objective_method == 1 ? 1 : 0, d_f, d_needs_passes, h_totals + 2, d_running);
+                           d_smallest_het, n, words_per_block, loglik_classes, d_start, objective_method == 1 ? 1 : 0, d_f, d_needs_passes, h_totals + 2, d_running,
+                           d_search_stats);
         try_hip(hipGetLastError(), KGX_EHIP, "loglik search launch");
         try_hip(hipEventRecord(dev.search_end, st), KGX_EHIP, "hipEventRecord");
         search_timed = true;
@@ -644,6 +647,13 @@ int inbreed_shard(kgx_gt8_shard& sh, uint64_t g0, uint64_t g1, const uint32_t* l
         try_hip(hipMemcpyAsync(&evaluations, d_running, sizeof(unsigned int), hipMemcpyDeviceToHost, st), KGX_EHIP, "D2H(evaluations)");
         try_hip(hipStreamSynchronize(st), KGX_EHIP, "sync");
         by_moments = rc == KGX_OK;
+        if (by_moments && d_search_stats) {
+          unsigned long long stats[8] = {0};
+          try_hip(hipMemcpy(stats, d_search_stats, sizeof(stats), hipMemcpyDeviceToHost), KGX_EHIP, "D2H(search stats)");
+          std::fprintf(stderr, "kgx: Loglikelihood search over %llu genomes (%u bins used): %llu evaluations, %llu with cells in their band -- %llu served by kept cells, "
+                               "%llu gathers kept, %llu gathers not kept, %llu dense walks; %llu cells listed, %llu blocks looked at\n",
+                       (unsigned long long)n, n_used, stats[0], stats[1], stats[2], stats[3], stats[4], stats[5], stats[6], stats[7]);
+        }
         if (by_moments) {
           dev.last_evaluations = static_cast<int>(evaluations);
           dev.last_path = KGX_PATH_LOGLIK_MOMENTS;

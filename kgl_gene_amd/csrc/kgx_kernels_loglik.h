@@ -37,7 +37,8 @@ constexpr double kLoglikTmax = 1.0 / (1 << kLoglikTmaxLog2);
 constexpr double kLoglikBand = 1.0 / (1.0 - (1.0 / 256.0) / kLoglikTmax);   // y* to the band's upper edge: 1 / (1 - 2^-8 / kTmax) = 16/15
 constexpr double kLoglikReach = 0.5 * kLoglikBand * (1.0 + 1.0 / 64.0);   // no band reaches past this y (y* <= 1/2, and a bin of margin)
 constexpr int kLoglikMaxClasses = 15;                        // byte 0x00 and a | a << 4, a = 1..14
-constexpr uint32_t kLoglikListCells = 4096;                  // a genome's cells of one stretch of a sparse band, gathered in LDS (16 KB)
+constexpr uint32_t kLoglikListCells = 2560;                  // a genome's cells of a band (or of a stretch of it), gathered in LDS: their frequencies (20 KB:
+                                                             // with ~50 KB of moments two workgroups still share a CU's 160 KB)
 constexpr int kLoglikWordsPerThread = 4;                     // blocks a thread looks at per round of the sparse walk: 1024 blocks a round
 constexpr double kLoglikDense = 1.0 / 32.0;                  // from this share of a band's slots set, the band is walked slot by slot
 constexpr double kLogSmallProb = -23.025850929940457;        // log(1e-10)
@@ -56,18 +57,28 @@ inline size_t loglik_search_lds(uint32_t n_used) {
 }
 
 // mode 0: the search, f_out[g] = the maximiser; mode 1 (a diagnostic: kgx_inbreed_objective): the objective at start[g].
-// needs_passes[g] = 1: this genome's objective cannot be had from the statistics (see above); its f_out is NaN.
+// needs_passes[g] != 0: this genome's objective cannot be had from the statistics (see above; the value says why); its f_out is NaN.
 // Dynamic LDS: loglik_search_lds(*n_used_ptr) bytes -- the genome's moments, bin-major.
+//
+// The band's cells.  A genome's cells in the bins [key_lo, key_hi) are the set bits of its words there.  Sparse (the usual
+// case: a few per cent of a band's slots): the bits of up to 1024 blocks a round are listed -- positions from a scan over the
+// threads, so the list's order, and with it every rounding, is the slots' own -- and their frequencies gathered into LDS; dense:
+// slot by slot, a lane a slot.  Successive evaluations of a search look at overlapping bands (the simplex shrinks), so when
+// the cells of a WIDER stretch of bins -- what the whole simplex can reach -- fit the list, that stretch is
+// gathered once and kept: an evaluation whose band lies inside it walks the kept frequencies (each knows its bin) and touches no
+// memory but LDS.
 __global__ void __launch_bounds__(kBlock)
 k_loglik_search(const double* __restrict__ bins, const uint32_t* __restrict__ used, const uint32_t* __restrict__ n_used_ptr,
                 const unsigned long long* __restrict__ counts, const double* __restrict__ sums,
                 const unsigned long long* __restrict__ smallest_het, uint64_t n_genomes, uint64_t words_per_block, LoglikClasses classes,
                 const double* __restrict__ start, int mode, double* __restrict__ f_out, uint32_t* __restrict__ needs_passes,
-                uint32_t* __restrict__ handed_over, unsigned int* __restrict__ max_evaluations) {
+                uint32_t* __restrict__ handed_over, unsigned int* __restrict__ max_evaluations, unsigned long long* __restrict__ stats = nullptr) {
+  // stats (KGX_K7_TRACE; may be null): evaluations, those with cells in their band, served by the kept cells, gathers kept,
+  // gathers not kept, dense walks, cells listed, blocks looked at
   extern __shared__ double bin_values[];                     // [kLoglikBinValues][n_used], then the bins' keys
-  __shared__ double row_part[2][2][16];
-  __shared__ uint32_t cell_list[kLoglikListCells];
-  __shared__ uint32_t cell_count[2];
+  __shared__ double row_part[2][3][16];
+  __shared__ double cell_y[kLoglikListCells];                // the listed cells' frequencies
+  __shared__ uint32_t wave_total[2][kBlock / kWave];
   const uint64_t g = blockIdx.x;
   if (g >= n_genomes) return;
   const uint32_t n_used = *n_used_ptr;
@@ -85,53 +96,90 @@ k_loglik_search(const double* __restrict__ bins, const uint32_t* __restrict__ us
     for (int j = 0; j < kLoglikBinValues; ++j) bin_values[static_cast<size_t>(j) * n_used + i] = v[j];
     bin_keys[i] = bin;
   }
-  if (threadIdx.x < 2) cell_count[threadIdx.x] = 0u;
   __syncthreads();
-  // the sums over the workgroup of two values a thread, the same bits in every thread; `pass` alternates the LDS slots
-  auto block_sum2 = [&](double& a, double& b, int pass) {
+  const uint32_t wave = threadIdx.x / kWave, lane = threadIdx.x % kWave;
+  const uint64_t lanes = words_per_block / 8;
+  int pass = 0, scans = 0;
+  // the sums over the workgroup of three values a thread, the same bits in every thread; `pass` alternates the LDS slots
+  auto block_sum3 = [&](double& a, double& b, double& c) {
     a = row_sum16(a);
     b = row_sum16(b);
-    if ((threadIdx.x & 15) == 0) { row_part[pass & 1][0][threadIdx.x >> 4] = a; row_part[pass & 1][1][threadIdx.x >> 4] = b; }
+    c = row_sum16(c);
+    double (*slot)[16] = row_part[pass & 1];
+    if ((threadIdx.x & 15) == 0) { slot[0][threadIdx.x >> 4] = a; slot[1][threadIdx.x >> 4] = b; slot[2][threadIdx.x >> 4] = c; }
     __syncthreads();
-    double out[2];
+    double out[3];
 #pragma unroll
-    for (int which = 0; which < 2; ++which) {
-      const double* p = row_part[pass & 1][which];
+    for (int which = 0; which < 3; ++which) {
+      const double* p = slot[which];
       double pair[8];
 #pragma unroll
       for (int i = 0; i < 8; ++i) pair[i] = p[2 * i] + p[2 * i + 1];
       out[which] = ((pair[0] + pair[1]) + (pair[2] + pair[3])) + ((pair[4] + pair[5]) + (pair[6] + pair[7]));
     }
-    a = out[0];
-    b = out[1];
+    a = out[0]; b = out[1]; c = out[2];
+    ++pass;
   };
-  const unsigned long long sixth = counts[g * 6 + 5], total = counts[g * 6 + 4];
+  // exclusive prefix of `mine` over the workgroup's threads (thread order), and the total: positions that do not depend on timing
+  auto block_scan = [&](uint32_t mine, uint32_t& total) {
+    uint32_t inclusive = mine;
+#pragma unroll
+    for (int off = 1; off < kWave; off <<= 1) {
+      const uint32_t up = __shfl_up(inclusive, off);
+      if (lane >= static_cast<uint32_t>(off)) inclusive += up;
+    }
+    uint32_t* totals = wave_total[scans & 1];
+    if (lane == kWave - 1) totals[wave] = inclusive;
+    __syncthreads();
+    uint32_t before = 0;
+    total = 0;
+#pragma unroll
+    for (uint32_t w = 0; w < kBlock / kWave; ++w) {
+      if (w < wave) before += totals[w];
+      total += totals[w];
+    }
+    ++scans;
+    return before + inclusive - mine;
+  };
+  const unsigned long long sixth = counts[g * 6 + 5], total_cells = counts[g * 6 + 4];
   const double het_big = static_cast<double>(sixth >> 32);
-  const double het_tiny = static_cast<double>(total - (sixth & 0xFFFFFFFFull));
+  const double het_tiny = static_cast<double>(total_cells - (sixth & 0xFFFFFFFFull));
   const double het_cells = static_cast<double>(counts[g * 6 + 1] + counts[g * 6 + 3]) - het_tiny;        // those with a term
   const double het_term = sums[g * kParts0 + 4];
   const double w_smallest = __longlong_as_double(static_cast<long long>(*smallest_het));                    // (1.0 where the call has none)
-  uint32_t hand_over = het_big != 0.0 ? 1u : 0u;                 // why the genome goes to the passes: 1 a cell that can meet the upper bound, 2 a band past the kept blocks, 3 the floor among the heterozygous cells
-  const uint32_t wave = threadIdx.x / kWave, lane = threadIdx.x % kWave;
-  const uint64_t lanes = words_per_block / 8;
+  // why the genome goes to the passes: 1 a cell that can meet the upper bound, 2 a band past the kept blocks, 3 the floor among the
+  // heterozygous cells, 4 the hits' bits and the moments disagree (cannot happen)
+  uint32_t hand_over = het_big != 0.0 ? 1u : 0u;
 
-  int pass = 0, round = 0;
-  auto objective = [&](double F) -> double {
+  // bins: [0, key_lo) wholly under the floor; [key_lo, key_hi) the band, walked exactly; from key_hi by their moments
+  auto band_of = [&](double F, uint32_t& key_lo, uint32_t& key_hi) {
     const double u = 1.0 - F;
     // y_floor: the cells with F*y + u*y*y < 1e-10 are those with y below the positive root (F >= 0: next to 0; F < 0: next to y*)
     const double disc = sqrt(__builtin_fma(F, F, 4.0 * u * 1e-10));
     const double y_floor = u > 0.0 ? (F <= 0.0 ? (disc - F) / (2.0 * u) : 2e-10 / (F + disc)) : 1e-10;
     const double y_under = y_floor * (1.0 - 1e-9), y_over = y_floor * (1.0 + 1e-9);      // (the root's own rounding stays inside)
-    // bins: [0, key_lo) wholly under the floor; [key_lo, key_hi) the band, walked exactly; from key_hi by their moments
-    const uint32_t key_lo = y_under < 9.5367431640625e-07 ? 1u : hall_key(y_under);      // (2^-20: the first bin's lower edge)
-    uint32_t key_hi = y_over < 9.5367431640625e-07 ? 1u : hall_key(y_over) + 1u;
+    key_lo = y_under < 9.5367431640625e-07 ? 1u : hall_key(y_under);                     // (2^-20: the first bin's lower edge)
+    key_hi = y_over < 9.5367431640625e-07 ? 1u : hall_key(y_over) + 1u;
     const double edge = F < 0.0 ? -F / u * kLoglikBand : 0.0;                              // y* to the band's edge (<= 8/15)
     if (edge >= 9.5367431640625e-07) {                                                     // (below the first bin: nothing to keep from the moments)
       const uint32_t k_edge = hall_key(edge);
       const uint32_t from = hall_centre(k_edge) < edge ? k_edge + 1u : k_edge;
       key_hi = from > key_hi ? from : key_hi;
     }
-    double sum = 0.0, band_cells = 0.0;
+  };
+  // what is kept in cell_y: every cell of the genome in the bins [kept_lo, kept_hi), kept_n of them (kept_hi == 0: nothing)
+  uint32_t kept_lo = 0, kept_hi = 0, kept_n = 0;
+
+  // F: the point; [reach_lo, reach_hi]: the stretch of F the search may ask about next (the simplex and its reflection)
+  auto objective = [&](double F, double reach_lo, double reach_hi) -> double {
+    const double u = 1.0 - F;
+    uint32_t key_lo, key_hi, wide_lo, wide_hi, unused;
+    band_of(F, key_lo, key_hi);
+    band_of(reach_hi, wide_lo, unused);                                                    // (the floor falls as F grows ...
+    band_of(reach_lo, unused, wide_hi);                                                    //  ... and y* with it)
+    wide_lo = wide_lo < key_lo ? wide_lo : key_lo;
+    wide_hi = wide_hi > key_hi ? wide_hi : key_hi;
+    double sum = 0.0, band_cells = 0.0, wide_cells = 0.0;
     for (uint32_t i = threadIdx.x; i < n_used; i += kBlock) {
       const uint32_t key = bin_keys[i];
       const double m0 = bin_values[i];
@@ -145,14 +193,15 @@ k_loglik_search(const double* __restrict__ bins, const uint32_t* __restrict__ us
       } else {
         band_cells += m0;
       }
+      if (key >= wide_lo && key < wide_hi) wide_cells += m0;
     }
-    block_sum2(sum, band_cells, pass++);
+    block_sum3(sum, band_cells, wide_cells);
     double value = sum;
-    // The band: the genome's cells there are the set bits of its words.  Each is clamp(fma(F, y - y*y, y*y)), the table pass's
-    // own arithmetic (k_eval_entries<2>, k_inbreed_eval_lut<2>), multiplied into a running product whose exponent is peeled
-    // off as it goes: one log per thread.
+    if (stats && threadIdx.x == 0) { atomicAdd(stats + 0, 1ull); if (band_cells > 0.0) atomicAdd(stats + 1, 1ull); }
+    // Each cell of the band is clamp(fma(F, y - y*y, y*y)), the table pass's own arithmetic (k_eval_entries<2>,
+    // k_inbreed_eval_lut<2>), multiplied into a running product whose exponent is peeled off as it goes: one log per thread.
     if (band_cells > 0.0) {
-      if (key_hi > classes.block_bins) hand_over = 2u;                                     // (cannot happen: kLoglikReach)
+      if (key_hi > classes.block_bins || wide_hi > classes.block_bins) hand_over = 2u;      // (cannot happen: kLoglikReach)
       double prod = 1.0;
       int expo = 0;
       auto exact_cell = [&](double y) {
@@ -164,13 +213,39 @@ k_loglik_search(const double* __restrict__ bins, const uint32_t* __restrict__ us
         expo += __builtin_amdgcn_frexp_exp(prod);
         prod = __builtin_amdgcn_frexp_mant(prod);
       };
+      // the kept cells, where they cover the band: LDS alone
+      const bool kept_covers = kept_hi != 0u && kept_lo <= key_lo && key_hi <= kept_hi;
+      // else gather: the wider stretch if its cells fit the list (then it is kept), otherwise the band itself, a listful at a time
+      const bool keep = !kept_covers && wide_cells <= static_cast<double>(kLoglikListCells);
+      const uint32_t from = keep ? wide_lo : key_lo, to = keep ? wide_hi : key_hi;
       uint32_t band_blocks = 0;
-      for (uint32_t k = 0; k < classes.n; ++k) band_blocks += classes.of[k].bin_block[key_hi] - classes.of[k].bin_block[key_lo];
-      const bool dense = band_cells >= kLoglikDense * static_cast<double>(band_blocks) * kHallBlockLoci;
-      for (uint32_t k = 0; k < classes.n && !hand_over; ++k) {
-        const LoglikClass& cl = classes.of[k];
-        const uint32_t b0 = cl.bin_block[key_lo], b1 = cl.bin_block[key_hi];
-        if (dense) {
+      if (!kept_covers)
+        for (uint32_t k = 0; k < classes.n; ++k) band_blocks += classes.of[k].bin_block[to] - classes.of[k].bin_block[from];
+      const bool dense = !kept_covers && !keep && band_cells >= kLoglikDense * static_cast<double>(band_blocks) * kHallBlockLoci;
+      auto walk_listed = [&](uint32_t n_listed) {                                          // the list's cells that lie in the band
+        for (uint32_t i0 = 0; i0 < n_listed; i0 += 8 * kBlock) {
+#pragma unroll
+          for (int q = 0; q < 8; ++q) {
+            const uint32_t i = i0 + static_cast<uint32_t>(q) * kBlock + threadIdx.x;
+            if (i < n_listed) {
+              const double y = cell_y[i];
+              const uint32_t key = hall_key(y);
+              if (key >= key_lo && key < key_hi) exact_cell(y);
+            }
+          }
+          peel();
+        }
+      };
+      if (stats && threadIdx.x == 0) {
+        atomicAdd(stats + (kept_covers ? 2 : dense ? 5 : keep ? 3 : 4), 1ull);
+        if (!kept_covers) atomicAdd(stats + 7, static_cast<unsigned long long>(band_blocks));
+      }
+      if (kept_covers) {
+        walk_listed(kept_n);
+      } else if (dense) {
+        for (uint32_t k = 0; k < classes.n && !hand_over; ++k) {
+          const LoglikClass& cl = classes.of[k];
+          const uint32_t b0 = cl.bin_block[key_lo], b1 = cl.bin_block[key_hi];
           // slot by slot: a wave takes every fourth stretch of four blocks, a lane a slot of each
           for (uint32_t b = b0 + 4u * wave; b < b1; b += 16u) {
             unsigned long long word[4];
@@ -186,9 +261,15 @@ k_loglik_search(const double* __restrict__ bins, const uint32_t* __restrict__ us
               if ((word[q] >> (63u - lane)) & 1ull) exact_cell(y[q]);
             peel();
           }
-        } else {
-          for (uint32_t base = b0; base < b1; base += kBlock * kLoglikWordsPerThread, ++round) {
-            uint32_t* const counter = &cell_count[round & 1];
+        }
+      } else {
+        // sparse: rounds of 1024 blocks; a round's set bits are dealt list positions by a scan, their frequencies gathered there
+        uint32_t listed = 0;
+        kept_hi = 0u;                                                                      // (the list is being rewritten)
+        for (uint32_t k = 0; k < classes.n && !hand_over; ++k) {
+          const LoglikClass& cl = classes.of[k];
+          const uint32_t b0 = cl.bin_block[from], b1 = cl.bin_block[to];
+          for (uint32_t base = b0; base < b1; base += kBlock * kLoglikWordsPerThread) {
             unsigned long long word[kLoglikWordsPerThread];
             uint32_t mine = 0;
 #pragma unroll
@@ -198,11 +279,19 @@ k_loglik_search(const double* __restrict__ bins, const uint32_t* __restrict__ us
             }
 #pragma unroll
             for (int w = 0; w < kLoglikWordsPerThread; ++w) mine += static_cast<uint32_t>(__popcll(word[w]));
-            uint32_t at = mine ? atomicAdd(counter, mine) : 0u;
-            const bool listed_here = at + mine <= kLoglikListCells;
-            // (no room in the list after all: this thread walks its blocks' cells itself, and what it was dealt of the list holds nothing)
-            if (!listed_here)
-              for (; at < kLoglikListCells; ++at) cell_list[at] = 0xFFFFFFFFu;
+            uint32_t round_total = 0;
+            uint32_t at = listed + block_scan(mine, round_total);
+            bool to_list = true;
+            if (listed + round_total > kLoglikListCells) {
+              // the list is full (a band gathered a listful at a time, nothing kept): walk what it holds, start it again
+              if (keep) { hand_over = 4u; break; }                                          // (a kept stretch fits by the moments' own count)
+              __syncthreads();
+              walk_listed(listed);
+              __syncthreads();
+              at -= listed;
+              listed = 0;
+              to_list = round_total <= kLoglikListCells;       // a round denser than the list holds: every thread walks its own blocks' cells
+            }
 #pragma unroll
             for (int w = 0; w < kLoglikWordsPerThread; ++w) {
               const uint32_t first = (base + static_cast<uint32_t>(w) * kBlock + threadIdx.x) * kHallBlockLoci;
@@ -211,35 +300,26 @@ k_loglik_search(const double* __restrict__ bins, const uint32_t* __restrict__ us
               while (bits != 0ull) {
                 const int p = __clzll(static_cast<long long>(bits));
                 bits &= ~(0x8000000000000000ull >> p);
-                if (listed_here) cell_list[at++] = first + static_cast<uint32_t>(p);
-                else { exact_cell(cl.ys[first + static_cast<uint32_t>(p)]); if ((++walked & 7) == 0) peel(); }
+                const double y = cl.ys[first + static_cast<uint32_t>(p)];
+                if (to_list) cell_y[at++] = y;
+                else { exact_cell(y); if ((++walked & 7) == 0) peel(); }
               }
-              peel();
+              if (!to_list) peel();
             }
-            if (threadIdx.x == 0) cell_count[(round & 1) ^ 1] = 0u;             // the next round's counter (last read two barriers ago)
-            __syncthreads();
-            const uint32_t listed = *counter < kLoglikListCells ? *counter : kLoglikListCells;
-            for (uint32_t i0 = 0; i0 < listed; i0 += 8 * kBlock) {
-              uint32_t slot[8];
-              double y[8];
-#pragma unroll
-              for (int q = 0; q < 8; ++q) {
-                const uint32_t i = i0 + static_cast<uint32_t>(q) * kBlock + threadIdx.x;
-                slot[q] = i < listed ? cell_list[i] : 0xFFFFFFFFu;
-              }
-#pragma unroll
-              for (int q = 0; q < 8; ++q) y[q] = cl.ys[slot[q] != 0xFFFFFFFFu ? slot[q] : static_cast<uint64_t>(b0) * kHallBlockLoci];
-#pragma unroll
-              for (int q = 0; q < 8; ++q)
-                if (slot[q] != 0xFFFFFFFFu) exact_cell(y[q]);
-              peel();
-            }
-            __syncthreads();                                                       // the list is free again
+            if (to_list) listed += round_total;
           }
         }
+        __syncthreads();                                                                   // the list is complete
+        if (stats && threadIdx.x == 0) atomicAdd(stats + 6, static_cast<unsigned long long>(listed));
+        if (keep && !hand_over) {
+          if (static_cast<double>(listed) != wide_cells) hand_over = 4u;                   // the bits and the moments count the same cells
+          kept_lo = from; kept_hi = to; kept_n = listed;
+        }
+        walk_listed(listed);
+        if (!keep) __syncthreads();                                                        // (a list not kept may be rewritten by the next evaluation at once)
       }
-      double exact = log(prod) + static_cast<double>(expo) * 0.6931471805599453, nothing = 0.0;
-      block_sum2(exact, nothing, pass++);
+      double exact = log(prod) + static_cast<double>(expo) * 0.6931471805599453, nothing = 0.0, none = 0.0;
+      block_sum3(exact, nothing, none);
       value += exact;
     }
     // heterozygous cells
@@ -253,7 +333,7 @@ k_loglik_search(const double* __restrict__ bins, const uint32_t* __restrict__ us
   };
 
   if (mode == 1) {
-    const double v = objective(start[g]);
+    const double v = objective(start[g], start[g], start[g]);
     if (threadIdx.x == 0) {
       f_out[g] = hand_over ? __builtin_nan("") : v;
       needs_passes[g] = hand_over;
@@ -265,7 +345,10 @@ k_loglik_search(const double* __restrict__ bins, const uint32_t* __restrict__ us
   unsigned int evaluations = 0;
   for (int it = 0; it < 500 && !hand_over; ++it) {
     const double F = it == 0 ? s.x : s.u;
-    const double value = objective(F);
+    // what the search will mostly ask about next: the simplex (best a, worst b) -- 97 % of its steps end in a contraction into it
+    // (a reflection past it finds the kept cells too narrow and gathers again)
+    const double lo = s.a < s.b ? s.a : s.b, hi = s.a < s.b ? s.b : s.a;
+    const double value = objective(F, lo < F ? lo : F, hi > F ? hi : F);
     ++evaluations;
     if (hand_over) break;
     nm_advance(s, value);
