@@ -152,8 +152,12 @@ k_inbreed_window(const uint8_t* __restrict__ gt, uint64_t pitch, const WindowTas
 #pragma unroll
       for (int c = 0; c < CELLS; ++c) {
         const double denominator = F + ((1.0 - F) * y[c]);
-        const double quotient = F / denominator;
-        sum += (d[c] != 0.0 && denominator != 0) ? quotient : 0.0;
+        // F / denominator by a reciprocal and two Newton steps (half the instructions of the IEEE division, within an ulp of it:
+        // a batch of windows spends its time here -- 50 steps x 16 cells a lane)
+        double r = __builtin_amdgcn_rcp(denominator);
+        r = __builtin_fma(r, __builtin_fma(-denominator, r, 1.0), r);
+        r = __builtin_fma(r, __builtin_fma(-denominator, r, 1.0), r);
+        sum += (d[c] != 0.0 && denominator != 0) ? F * r : 0.0;
       }
       F = block_sum(sum, it) / n_cells;
     }
