@@ -9,7 +9,7 @@ from kgl_gene_amd import capi
 
 capi.init(0)
 K = int(sys.argv[1]) if len(sys.argv) > 1 else 16
-G, L, n_sel = 2512, 200_000, 1000
+G, L, n_sel = 2560, 200_000, 1000
 # five super populations of the 1000-Genomes sizes (661 AFR, 347 AMR, 504 EAS, 503 EUR, 489 SAS), each starting on a multiple of 16
 sizes, ranges, at = (661, 347, 504, 503, 489), [], 0
 for n in sizes:
