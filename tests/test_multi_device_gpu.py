@@ -386,7 +386,11 @@ def test_bench_two_ranks_rehearsal_on_one_device(tmp_path, workload):
         assert record["config"]["total_genomes"] == 2 * record["config"]["genomes_per_gpu"] == 6000
         assert record["config"]["exchange"].startswith("gloo rehearsal") and "MISMATCH" not in record["config"]["exchange_check"]
         assert "all 300000 variants" in record["config"]["exchange_check"]
-        assert record["config"]["distributed"] == {"world_size": 2, "backend": "gloo", "kgx_exchange_kind": "none", "kgx_bound_devices": 1}
+        distributed = dict(record["config"]["distributed"])
+        spread = distributed.pop("over_ranks")         # every rank's own clocks: the kernel, the step, what the exchange leaves exposed
+        assert distributed == {"world_size": 2, "backend": "gloo", "kgx_exchange_kind": "none", "kgx_bound_devices": 1}
+        assert 0 < spread["kernel_ms_min"] <= spread["kernel_ms_max"] <= spread["step_ms_max"] and spread["step_ms_min"] <= spread["step_ms_max"]
+        assert abs(spread["exposed_exchange_and_epilogue_ms"] - (spread["step_ms_max"] - spread["kernel_ms_max"])) <= 1e-6 * spread["step_ms_max"] + 1e-9
         # ... and north_star's strong-scaled job beside it: one population split over the ranks, the same step
         strong = record["aux"]["c4_strong"]
         assert strong["scaling"] == "strong" and strong["n_gpus"] == 2 and strong["config"]["total_genomes"] == 5001
