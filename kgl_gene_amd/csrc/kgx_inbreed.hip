@@ -180,11 +180,12 @@ int inbreed_shard(kgx_gt8_shard& sh, uint64_t g0, uint64_t g1, const uint32_t* l
     // cell of the bins its floor can reach) must leave the device room to breathe: past half of what is free (counting what
     // this call may regrow) the passes, which need none of it, are made
     const uint64_t extra = hall_items * kHallMoments * n * sizeof(double) + static_cast<uint64_t>(kHallBins) * kHallMoments * n * sizeof(double) +
-                           hall_classes * (hall_blocks + 1) * kHallBlockLoci * sizeof(HallRecord) + n_sel * (sizeof(HallRecord) + 4 * sizeof(uint32_t)) +
-                           (loglik_candidate ? hall_classes * hall_blocks * words_per_block * sizeof(unsigned long long) : 0);
+                           hall_classes * (hall_blocks + 1) * kHallBlockLoci * (sizeof(HallRecord) + 36) + n_sel * (sizeof(HallRecord) + 4 * sizeof(uint32_t)) +
+                           (loglik_candidate ? hall_classes * hall_blocks * words_per_block * sizeof(unsigned long long) : 0) +
+                           hall_classes * hall_blocks * kHallBlockLoci * hall_bit_row_bytes(n);     // (the hits' bit rows, at most)
     size_t free_bytes = 0, total_bytes = 0;
     if (hipMemGetInfo(&free_bytes, &total_bytes) != hipSuccess) { (void)hipGetLastError(); free_bytes = 0; }
-    if (extra + plan.total > (static_cast<uint64_t>(free_bytes) + dev.scratch_bytes + dev.words_bytes) / 2) hall_moments = loglik_moments = false;
+    if (extra + plan.total > (static_cast<uint64_t>(free_bytes) + dev.scratch_bytes + dev.words_bytes + dev.bits_bytes) / 2) hall_moments = loglik_moments = false;
   }
   const bool by_moments_planned = hall_moments || loglik_moments;
   size_t hall_sort_bytes = 0;
@@ -207,6 +208,16 @@ int inbreed_shard(kgx_gt8_shard& sh, uint64_t g0, uint64_t g1, const uint32_t* l
   const size_t o_hall_items = plan.add(plan_classes * plan_items * sizeof(HallItem));
   const size_t o_hall_item_blocks = plan.add(plan_classes * (plan_items + 1) * sizeof(uint32_t));
   const size_t o_hall_ys = plan.add(loglik_moments ? plan_classes * (hall_blocks + 1) * kHallBlockLoci * sizeof(double) : 0);   // per class: every slot's frequency
+  // the matrix-core class pass (k_hall_mfma): per slot 32 digit bytes and its row
+  const bool hall_mfma = by_moments_planned && eval_gpl == 8 && !env_int("KGX_K7_CLASS_SWEEPS", 0);
+  const size_t o_hall_digits = plan.add(hall_mfma ? plan_classes * (hall_blocks + 1) * kHallBlockLoci * 32 : 0);
+  const size_t o_hall_rows = plan.add(hall_mfma ? plan_classes * (hall_blocks + 1) * kHallBlockLoci * sizeof(uint32_t) : 0);
+  // ... fed by ONE pass over the bytes that leaves every class's hits as bits (k_class_bits): where each selected locus sits in
+  // each class's blocks, and the bit rows themselves (a grow-only buffer of their own: an eighth of the bytes the classes cover)
+  const bool hall_bits_planned = hall_mfma && !env_int("KGX_K7_CLASS_BYTES", 0);
+  const uint64_t sel_pitch = (n_sel + 7) / 8 * 8;
+  const size_t o_slot_of_locus = plan.add(hall_bits_planned ? plan_classes * sel_pitch * sizeof(uint32_t) : 0);
+  const uint64_t bit_row_bytes = hall_bit_row_bytes(n);                        // whole spans of 2048 genomes
   const size_t o_hall_sort = plan.add(hall_sort_bytes);
   const size_t o_hall_moments = plan.add(plan_items * kHallMoments * n * sizeof(double));
   const size_t o_hall_bins = plan.add(by_moments_planned ? static_cast<size_t>(kHallBins) * kHallMoments * n * sizeof(double) : 0);
@@ -451,10 +462,14 @@ int inbreed_shard(kgx_gt8_shard& sh, uint64_t g0, uint64_t g1, const uint32_t* l
       auto ys_of = [&](uint32_t k) { return emit ? reinterpret_cast<double*>(arena + o_hall_ys) + static_cast<uint64_t>(k) * padded_records : nullptr; };
       auto items_of = [&](uint32_t k) { return reinterpret_cast<HallItem*>(arena + o_hall_items) + static_cast<uint64_t>(k) * hall_items; };
       auto item_blocks_of = [&](uint32_t k) { return reinterpret_cast<uint32_t*>(arena + o_hall_item_blocks) + static_cast<uint64_t>(k) * (hall_items + 1); };
+      auto digits_of = [&](uint32_t k) { return reinterpret_cast<int8_t*>(arena + o_hall_digits) + static_cast<uint64_t>(k) * padded_records * 32; };
+      auto rows_of = [&](uint32_t k) { return reinterpret_cast<uint32_t*>(arena + o_hall_rows) + static_cast<uint64_t>(k) * padded_records; };
       try_hip(hipMemsetAsync(h_words, 0, hall_word_count * sizeof(uint32_t), st), KGX_EHIP, "memset(hall words)");
       // (a pass reads up to two batches past an item's slots -- the next item's, or, behind the last one, this: row 0, matching nothing)
       try_hip(hipMemsetAsync(arena + o_hall_padded, 0, hall_classes * padded_records * sizeof(HallRecord), st), KGX_EHIP, "memset(hall blocks)");
       try_hip(hipMemsetAsync(h_bins, 0, static_cast<size_t>(kHallBins) * kHallMoments * n * sizeof(double), st), KGX_EHIP, "memset(hall bins)");
+      uint32_t* const slot_of_locus = hall_bits_planned ? reinterpret_cast<uint32_t*>(arena + o_slot_of_locus) : nullptr;
+      if (slot_of_locus) try_hip(hipMemsetAsync(slot_of_locus, 0xFF, static_cast<size_t>(hall_classes) * sel_pitch * sizeof(uint32_t), st), KGX_EHIP, "memset(slot of locus)");
       for (uint32_t k = 0; k < hall_classes && rc == KGX_OK; ++k) {
         uint32_t *bin_begin = class_words(k), *bin_end = bin_begin + (kHallBins + 1), *item_base = bin_begin + 2 * (kHallBins + 1);
         hipLaunchKernelGGL(k_hall_keys, dim3(stream_grid(dev, n_sel, kBlock)), dim3(kBlock), 0, st, d_table, d_valid, n_sel, amax, phased, k, h_keys,
@@ -467,7 +482,9 @@ int inbreed_shard(kgx_gt8_shard& sh, uint64_t g0, uint64_t g1, const uint32_t* l
         hipLaunchKernelGGL(k_hall_items, dim3(1), dim3(kBlock), 0, st, bin_begin, bin_end, item_base, items_of(k), h_counters + 4 * k, block_bins,
                            item_blocks_of(k), h_counters + 4 * k + 1);
         hipLaunchKernelGGL(k_hall_pad, dim3(static_cast<uint32_t>(std::min<uint64_t>(hall_items, 65535))), dim3(kBlock), 0, st, h_records, items_of(k),
-                           h_counters + 4 * k, item_blocks_of(k), padded_of(k), ys_of(k));
+                           h_counters + 4 * k, item_blocks_of(k), padded_of(k), ys_of(k), h_sorted_slots, slot_of_locus ? slot_of_locus + k * sel_pitch : nullptr);
+        if (hall_mfma) hipLaunchKernelGGL(k_hall_digits, dim3(static_cast<uint32_t>(std::min<uint64_t>(hall_items, 65535))), dim3(kBlock), 0, st, padded_of(k),
+                                          items_of(k), h_counters + 4 * k, item_blocks_of(k), digits_of(k), rows_of(k));
         if (emit) hipLaunchKernelGGL(k_hall_bin_blocks, dim3((kHallBins + kBlock) / kBlock), dim3(kBlock), 0, st, item_base, item_blocks_of(k), item_base + (kHallBins + 1));
         try_hip(hipGetLastError(), KGX_EHIP, "hall order launch");
       }
@@ -499,8 +516,41 @@ int inbreed_shard(kgx_gt8_shard& sh, uint64_t g0, uint64_t g1, const uint32_t* l
         }
         words = reinterpret_cast<unsigned long long*>(dev.words);
       }
+      // the classes' bit rows: all blocks of all classes (a slot a row)
+      bool by_bits = hall_bits_planned;
+      HallClassRows class_rows{};
+      if (by_bits) {
+        uint64_t rows = 0;
+        for (uint32_t k = 0; k < hall_classes; ++k) { class_rows.base[k] = rows; rows += static_cast<uint64_t>(counters[4 * k + 1]) * kHallBlockLoci; }
+        const size_t want = static_cast<size_t>(rows ? rows : 1) * bit_row_bytes + 64;
+        if (dev.bits_bytes < want) {
+          if (dev.bits) (void)hipFree(dev.bits);
+          dev.bits = nullptr;
+          dev.bits_bytes = 0;
+          size_t free_bytes = 0, total_bytes = 0;
+          if (hipMemGetInfo(&free_bytes, &total_bytes) != hipSuccess || free_bytes < want + (4ull << 30) || hipMalloc(&dev.bits, want) != hipSuccess) {
+            (void)hipGetLastError();
+            dev.bits = nullptr;
+            by_bits = false;                                                    // no room: a pass over the bytes per class
+          } else {
+            dev.bits_bytes = want;
+          }
+        }
+      }
       uint64_t block_base = 0;
       try_hip(hipEventRecord(dev.moments_begin, st), KGX_EHIP, "hipEventRecord");
+      if (by_bits && rc == KGX_OK) {
+        const uint32_t bit_chunks = static_cast<uint32_t>((n + kBitsSpanGenomes - 1) / kBitsSpanGenomes);   // a wave a span
+        uint64_t segments = std::max<uint64_t>(1, static_cast<uint64_t>(dev.compute_units) * 32 / bit_chunks);   // (waves: four to a workgroup's worth)
+        uint64_t loci_per_seg = std::max<uint64_t>(64, (n_sel + segments - 1) / segments);
+        loci_per_seg = (loci_per_seg + 7) / 8 * 8;
+        segments = std::min<uint64_t>(65535, (n_sel + loci_per_seg - 1) / loci_per_seg);
+        loci_per_seg = ((n_sel + segments - 1) / segments + 7) / 8 * 8;
+        segments = (n_sel + loci_per_seg - 1) / loci_per_seg;
+        hipLaunchKernelGGL(k_class_bits, dim3(bit_chunks, static_cast<uint32_t>(segments)), dim3(kWave), 0, st, gt32, dwords_per_row, g0, (g0 + n - 1) >> 2, d_index, n_sel,
+                           loci_per_seg, slot_of_locus, sel_pitch, hall_classes, class_rows, bit_row_bytes, reinterpret_cast<uint8_t*>(dev.bits));
+        try_hip(hipGetLastError(), KGX_EHIP, "class bits launch");
+      }
       for (uint32_t k = 0; k < hall_classes && rc == KGX_OK; ++k) {
         uint32_t* item_base = class_words(k) + 2 * (kHallBins + 1);
         unsigned long long* class_out = emit ? words + block_base * words_per_block : nullptr;
@@ -514,7 +564,19 @@ int inbreed_shard(kgx_gt8_shard& sh, uint64_t g0, uint64_t g1, const uint32_t* l
 #define KGX_HALL_SWEEP(GPL, EMIT)                                                                                                      \
   hipLaunchKernelGGL((k_hall_sweep<GPL, EMIT>), sweep_grid, dim3(kBlock), 0, st, gt32, dwords_per_row, g0, n, padded_of(k), items_of(k), \
                      h_counters + 4 * k, hall_chunks, code, h_moments, item_blocks_of(k), block_bins, words_per_block, class_out)
-        if (eval_gpl == 8) { if (emit) KGX_HALL_SWEEP(8, true); else KGX_HALL_SWEEP(8, false); }
+        if (hall_mfma) {
+          // the class pass on the matrix cores: a workgroup = an item x 512 genomes
+          const uint32_t mfma_chunks = static_cast<uint32_t>(by_bits ? bit_row_bytes / 128 : (n + 511) / 512);   // (bit rows: 8 tiles of 16 bytes a workgroup)
+          const dim3 mfma_grid(class_items[k] * mfma_chunks);
+          const uint8_t* bit_rows = by_bits ? reinterpret_cast<const uint8_t*>(dev.bits) + class_rows.base[k] * bit_row_bytes : nullptr;
+#define KGX_HALL_MFMA(EMIT, BITS)                                                                                                      \
+  hipLaunchKernelGGL((k_hall_mfma<EMIT, BITS>), mfma_grid, dim3(kBlock), 0, st, gt32, dwords_per_row, g0, n, rows_of(k), bit_rows, bit_row_bytes, \
+                     digits_of(k), items_of(k), h_counters + 4 * k, item_blocks_of(k), mfma_chunks, code, h_moments, block_bins,        \
+                     words_per_block, class_out)
+          if (by_bits) { if (emit) KGX_HALL_MFMA(true, true); else KGX_HALL_MFMA(false, true); }
+          else { if (emit) KGX_HALL_MFMA(true, false); else KGX_HALL_MFMA(false, false); }
+#undef KGX_HALL_MFMA
+        } else if (eval_gpl == 8) { if (emit) KGX_HALL_SWEEP(8, true); else KGX_HALL_SWEEP(8, false); }
         else KGX_HALL_SWEEP(4, false);                                          // (the hits' words are a lane of eight genomes': loglik_candidate)
 #undef KGX_HALL_SWEEP
         hipLaunchKernelGGL(k_hall_merge, dim3(hall_merge_blocks, kHallBins), dim3(kBlock), 0, st, h_moments, item_base, n, h_bins, h_bin_used);
@@ -522,6 +584,7 @@ int inbreed_shard(kgx_gt8_shard& sh, uint64_t g0, uint64_t g1, const uint32_t* l
       }
       loglik_classes.n = emit ? hall_classes : 0u;
       loglik_classes.block_bins = block_bins;
+      loglik_classes.plain_words = (by_bits && hall_mfma) ? 1u : 0u;
       try_hip(hipEventRecord(dev.moments_end, st), KGX_EHIP, "hipEventRecord");
       moments_timed = true;
       hipLaunchKernelGGL(k_hall_used_bins, dim3(1), dim3(kBlock), 0, st, h_bin_used, h_used, h_totals);
@@ -861,8 +924,11 @@ int inbreed_shard(kgx_gt8_shard& sh, uint64_t g0, uint64_t g1, const uint32_t* l
     // one very large call does not starve what the process allocates next (another matrix, the compaction levels, the caller's own).
     {
       const uint64_t keep = env_int("KGX_KEEP_SCRATCH_GB", -1) >= 0 ? static_cast<uint64_t>(env_int("KGX_KEEP_SCRATCH_GB", 0)) << 30 : dev.hbm_bytes / 4;
-      if (static_cast<uint64_t>(dev.scratch_bytes) + dev.words_bytes > keep) {
+      if (static_cast<uint64_t>(dev.scratch_bytes) + dev.words_bytes + dev.bits_bytes > keep) {
         (void)hipStreamSynchronize(st);
+        if (dev.bits) (void)hipFree(dev.bits);
+        dev.bits = nullptr;
+        dev.bits_bytes = 0;
         if (dev.words) (void)hipFree(dev.words);
         dev.words = nullptr;
         dev.words_bytes = 0;

@@ -52,6 +52,8 @@ struct Device {
   size_t pinned_bytes[2] = {0, 0};
   char* words = nullptr;                                   // Loglikelihood by moments: the class passes' hit bits, [block][genome] (grow-only, like the arena)
   size_t words_bytes = 0;
+  char* bits = nullptr;                                    // both estimators by moments: every class's hits as bit rows, [slot][genome / 8] (k_class_bits; grow-only)
+  size_t bits_bytes = 0;
   void* exchange_stage = nullptr;                          // "peer" exchange: staging for another shard's counts
   size_t exchange_stage_bytes = 0;
   std::mutex mutex;                                        // serialises the per-device state above between handles

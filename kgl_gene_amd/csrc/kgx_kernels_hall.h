@@ -194,9 +194,13 @@ k_hall_items(const uint32_t* __restrict__ bin_begin, const uint32_t* __restrict_
 // The items' records in blocks: item i's from slot 64 * item_block_base[i] on, the rest of its last block repeating its last
 // record (the pass gives such a slot a byte no cell has).  One workgroup per item (at most 1024 loci: four per thread).
 // ys (may be null): every slot's frequency y = centre(bin) + delta (the Loglikelihood walk reads these alone).
+// slot_of_locus (may be null; with sorted_slots, the sort's own output: the selected locus of every position of the bin
+// order): slot_of_locus[s] = the slot of selected locus s in this class's blocks (left as it is -- 0xFFFFFFFF -- where the
+// locus has no cell of the class): what the one pass that leaves every class's hits as bits walks (k_class_bits).
 __global__ void __launch_bounds__(kBlock)
 k_hall_pad(const HallRecord* __restrict__ records, const HallItem* __restrict__ items, const uint32_t* __restrict__ n_items,
-           const uint32_t* __restrict__ item_block_base, HallRecord* __restrict__ padded, double* __restrict__ ys) {
+           const uint32_t* __restrict__ item_block_base, HallRecord* __restrict__ padded, double* __restrict__ ys,
+           const uint32_t* __restrict__ sorted_slots, uint32_t* __restrict__ slot_of_locus) {
   const uint32_t n = *n_items;
   for (uint32_t item = blockIdx.x; item < n; item += gridDim.x) {
     const HallItem it = items[item];
@@ -207,6 +211,7 @@ k_hall_pad(const HallRecord* __restrict__ records, const HallItem* __restrict__ 
       const HallRecord r = records[it.begin + (t < len ? t : len - 1u)];
       padded[first + t] = r;
       if (ys) ys[first + t] = centre + r.delta;
+      if (slot_of_locus && t < len) slot_of_locus[sorted_slots[it.begin + t]] = static_cast<uint32_t>(first + t);
     }
   }
 }
@@ -355,6 +360,372 @@ k_hall_sweep(const uint32_t* __restrict__ gt, uint64_t dwords_per_row, uint64_t 
     out[2 * n_genomes + g] = m2[j];
     out[3 * n_genomes + g] = m3[j];
     out[4 * n_genomes + g] = m4[j];
+  }
+}
+
+// ---- every class's hits as bits, in ONE pass over the bytes -------------------------------------------------------------------
+// A class pass reads the rows of the loci that have a cell of its class: 2.2 reads of the matrix over the classes of C5.  The
+// hits themselves are a bit a cell: ONE pass over the selected rows leaves them, for every class the locus has a cell of, as a
+// row of bits in the class's own slot order -- bits[(class_row_base[k] + slot) * row_bytes + genome / 8], bit genome % 8 -- and
+// the matrix-core pass below then reads an eighth of the bytes (k_hall_mfma<.., true>).  A lane: eight genomes (two dwords), a
+// zero-byte test on each dword xor the class's byte, the four flags of a dword gathered by one multiplication.
+struct HallClassRows { uint64_t base[16]; };                               // where each class's rows begin (in rows)
+// A bit row is cut into SPANS of kBitsSpanGenomes genomes = 256 bytes: a wave of k_class_bits takes a span, lane l its dwords
+// l, l + 64, .. l + 448 (eight coalesced loads a locus) -- genomes 4 (l + 64 d) + b for dword d, byte b -- and keeps the flag
+// of (d, b) in bit 8 b + d of ONE dword: no gathering of flags inside a dword, just the eight hit masks shifted onto each
+// other.  So byte o = 4 l + b of a span holds, in bit q, genome o + 256 q of the span (hall_bits_genome).
+constexpr uint64_t kBitsSpanGenomes = 2048;
+constexpr uint64_t kBitsSpanBytes = kBitsSpanGenomes / 8;
+__host__ __device__ inline uint64_t hall_bit_row_bytes(uint64_t n_genomes) { return (n_genomes + kBitsSpanGenomes - 1) / kBitsSpanGenomes * kBitsSpanBytes; }
+// the genome (of the call) in bit q of byte `at` of a bit row
+__device__ __forceinline__ uint64_t hall_bits_genome(uint64_t at, uint32_t q) { return (at / kBitsSpanBytes) * kBitsSpanGenomes + at % kBitsSpanBytes + 256u * q; }
+
+// A wave per workgroup.  grid: x = spans, y = segments of the selected loci (whole batches of eight).
+// slot_of_locus[k * sel_pitch + s]: k_hall_pad's, class by class; a batch's eight slots of a class are one scalar load, the
+// next class's under way while this one's bits are gathered.  last_dword: the last dword of a row that may be read.
+__global__ void __launch_bounds__(kWave)
+k_class_bits(const uint32_t* __restrict__ gt, uint64_t dwords_per_row, uint64_t g0, uint64_t last_dword, const uint32_t* __restrict__ locus_index,
+             uint64_t n_sel, uint64_t loci_per_seg, const uint32_t* __restrict__ slot_of_locus, uint64_t sel_pitch, uint32_t n_classes,
+             HallClassRows class_rows, uint64_t row_bytes, uint8_t* __restrict__ bits) {
+  typedef uint32_t v8u __attribute__((ext_vector_type(8)));
+  constexpr int kBatch = 8;
+  const uint64_t span = blockIdx.x, lane = threadIdx.x;
+  uint64_t col[8];
+#pragma unroll
+  for (int d = 0; d < 8; ++d) {
+    const uint64_t at = (g0 >> 2) + span * (kBitsSpanGenomes / 4) + lane + 64u * d;
+    col[d] = at <= last_dword ? at : last_dword;                                                    // (past the row's genomes: bits nobody reads)
+  }
+  const uint64_t s_begin = static_cast<uint64_t>(blockIdx.y) * loci_per_seg;
+  const uint64_t s_end = s_begin + loci_per_seg < n_sel ? s_begin + loci_per_seg : n_sel;
+  if (s_begin >= s_end) return;
+  struct Batch { uint32_t w[kBatch][8]; };
+  auto load_batch = [&](Batch& batch, uint64_t first) {
+#pragma unroll
+    for (int i = 0; i < kBatch; ++i) {
+      const uint64_t at = first + i < s_end ? first + i : s_end - 1;                                // (past the segment: its last locus again, not used)
+      const uint64_t row = locus_index ? static_cast<uint64_t>(locus_index[at]) : at;
+      const uint32_t* p = gt + row * dwords_per_row;
+#pragma unroll
+      for (int d = 0; d < 8; ++d) batch.w[i][d] = __builtin_nontemporal_load(p + col[d]);
+    }
+  };
+  auto gather = [&](const Batch& batch, uint64_t first) {
+    __builtin_amdgcn_sched_barrier(0);                                                              // the loads issued above stay above
+    v8u of_class = *reinterpret_cast<const v8u*>(slot_of_locus + first);                            // (the same for the whole wave: scalar loads)
+    for (uint32_t k = 0; k < n_classes; ++k) {
+      const v8u mine = of_class;
+      if (k + 1 < n_classes) of_class = *reinterpret_cast<const v8u*>(slot_of_locus + (k + 1) * sel_pitch + first);
+      const uint32_t code4 = (k | (k << 4)) * 0x01010101u;
+      uint8_t* rows = bits + class_rows.base[k] * row_bytes + span * kBitsSpanBytes + lane * 4;
+#pragma unroll
+      for (int i = 0; i < kBatch; ++i) {
+        const uint32_t slot = mine[i];
+        if (slot == 0xFFFFFFFFu || first + i >= s_end) continue;
+        uint32_t word = 0;
+#pragma unroll
+        for (int d = 0; d < 8; ++d) {
+          const uint32_t x = batch.w[i][d] ^ code4;                                                 // a zero byte = a hit
+          const uint32_t nonzero = ((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x;                           // bit 7 of each byte: the byte is not zero
+          word |= (~nonzero & 0x80808080u) >> (7 - d);                                              // byte b's flag to bit 8 b + d
+        }
+        *reinterpret_cast<uint32_t*>(rows + static_cast<uint64_t>(slot) * row_bytes) = word;
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  Batch even, odd;
+  load_batch(even, s_begin);
+  for (uint64_t s = s_begin; s < s_end; s += 2 * kBatch) {
+    load_batch(odd, s + kBatch);
+    gather(even, s);
+    load_batch(even, s + 2 * kBatch);
+    if (s + kBatch < s_end) gather(odd, s + kBatch);
+  }
+}
+
+// ---- the class pass on the matrix cores ----------------------------------------------------------------------------------------
+// k_hall_sweep above is bound by its vector instructions: a compare and five adds per cell that issue for the whole wave whenever
+// any lane hits (5.95 wave-instructions per cell measured, 54 % of the HBM peak).  But an item's moments are a product of two
+// matrices,
+//     M[g][j] = sum over the item's slots s of  hit[g][s] * d_s^j ,      hit = 0 / 1,
+// and with d_s^j written in FIXED POINT -- t = d / 2^(e - 7) in [-1/2, 1/2) for a bin of exponent e, V_j = round(t^j * 2^54),
+// V_j in seven balanced base-256 digits (int8) -- it is an EXACT one in integers: v_mfma_i32_16x16x64_i8 sums 64 slots x 16
+// genomes x 16 digit columns per instruction (an item holds at most 1024 slots: |sum| <= 1024 * 128 * 128 = 2^24, no overflow),
+// and the digit sums go back to doubles once per item.  Quantisation: a term (d / c)^j / j of the series is off by at most
+// 2^-(54 + 7 j) -- far below the double rounding of the adds it replaces; M0 is a count and exact.  What is left for the
+// vector unit is the zero-byte test on a dword (four cells in four instructions) and the 4 x 4 byte transposes that turn "four
+// genomes of one locus" into "four loci of one genome" (eight v_perm_b32 per 16 cells): ~2 instructions per cell instead of 6.
+//
+// Operands (lane l of a wave: c = l & 15, u = l >> 4; both take 16 k per lane and the same k map on either side, so the slot of
+// position (u, j) only has to be the SAME in A and B: slot 64 * block + 16 * u + j):
+//   A_a[row c][k]   a = 0, 1: the digit columns, from LDS (the item's whole digit image, k_hall_digits)
+//   B[k][col c]     the hits of genome 8 * c + q of the wave's 128 (q = 0..7: two products each per block, A_0 and A_1)
+//   C_a[row][col]   lane l holds column c (its genomes), rows 4 * u + reg: the digit columns are dealt so that lane group u
+//                   holds moment u + 1 whole: register R = 4 * a + reg = digit R (R < 7); R = 7 of group 3 is M0's column of ones.
+constexpr int kHallDigits = 7;
+constexpr int kHallDigitBits = 54;                                         // |V_j| <= 2^(54 - j): the top digit stays small
+
+// The digit image and the rows of every slot of a class: digits[(block * 2 + a) * 64 + l] 16 bytes each (2 KB a block: what the
+// lanes of a wave load as A_0, A_1, in lane order), slot_rows[slot].  A slot past its item's loci: zeros (no column counts
+// it) and its item's last row.  One workgroup per item.
+__global__ void __launch_bounds__(kBlock)
+k_hall_digits(const HallRecord* __restrict__ padded, const HallItem* __restrict__ items, const uint32_t* __restrict__ n_items,
+              const uint32_t* __restrict__ item_block_base, int8_t* __restrict__ digits, uint32_t* __restrict__ slot_rows) {
+  const uint32_t n = *n_items;
+  for (uint32_t item = blockIdx.x; item < n; item += gridDim.x) {
+    const HallItem it = items[item];
+    const uint32_t len = it.end - it.begin, first_block = item_block_base[item], slots = (item_block_base[item + 1] - first_block) * kHallBlockLoci;
+    const uint64_t first = static_cast<uint64_t>(first_block) * kHallBlockLoci;
+    const int exponent = it.bin == 0u ? 0 : static_cast<int>((it.bin - 1u) >> kHallKeyMantissa) + kHallMinExponent;
+    const double to_t = __longlong_as_double(static_cast<long long>(static_cast<uint64_t>(1023 + 7 - exponent) << 52));   // 2^(7 - e)
+    const double to_fixed = __longlong_as_double(static_cast<long long>(static_cast<uint64_t>(1023 + kHallDigitBits) << 52));
+    for (uint32_t t = threadIdx.x; t < slots; t += blockDim.x) slot_rows[first + t] = padded[first + t].row;
+    for (uint32_t t = threadIdx.x; t < slots * 2; t += blockDim.x) {          // 16 bytes each: (block, a, lane)
+      const uint32_t block = t >> 7, a = (t >> 6) & 1u, l = t & 63u, u = l >> 4, row = l & 15u;
+      const uint32_t group = row >> 2, digit = 4u * a + (row & 3u);           // the column's moment (group + 1) and digit
+      const bool ones = digit == 7u && group == 3u;
+      uint32_t out[4] = {0u, 0u, 0u, 0u};
+      if (digit < 7u || ones) {
+        for (uint32_t p = 0; p < 16; ++p) {
+          const uint32_t slot = block * kHallBlockLoci + 16u * u + p;
+          if (slot >= len) break;
+          long long v = 1;
+          if (!ones) {
+            const double x = padded[first + slot].delta * to_t;               // exact: a power of two
+            const double x2 = x * x;
+            const double power = group == 0u ? x : group == 1u ? x2 : group == 2u ? x2 * x : x2 * x2;
+            v = __double2ll_rn(power * to_fixed);
+            long long low = 0;
+            for (uint32_t q = 0; q <= digit; ++q) {                           // balanced digits: -128 .. 127
+              low = ((v + 128) & 255) - 128;
+              v = (v - low) >> 8;
+            }
+            v = low;
+          }
+          out[p >> 2] |= static_cast<uint32_t>(v & 255) << (8u * (p & 3u));
+        }
+      }
+      typedef uint32_t v4u __attribute__((ext_vector_type(4)));
+      reinterpret_cast<v4u*>(digits)[first * 2 + t] = v4u{out[0], out[1], out[2], out[3]};
+    }
+  }
+}
+
+// grid: x = item * n_chunks + chunk of 512 genomes, BITS: 1024 (a wave: 128 at a time, a lane: eight at 16 of the block's 64 slots).
+// moments as k_hall_sweep's.  EMIT as there: the items of the bins below block_bins leave the hits as bits.
+// BITS: the hits come from k_class_bits' rows (bit_rows: the class's first row) instead of the bytes: a lane loads 16 bytes
+// (128 genomes) of ONE slot, the wave's 64 slots go through LDS, and lane (c, u) takes back byte c of its 16 slots -- bit q
+// of byte j is the lane's genome q (hall_bits_genome) at slot 16 u + j: a shift and a mask per product and dword.
+template <bool EMIT, bool BITS>
+__global__ void __launch_bounds__(kBlock)
+k_hall_mfma(const uint32_t* __restrict__ gt, uint64_t dwords_per_row, uint64_t g0, uint64_t n_genomes, const uint32_t* __restrict__ slot_rows,
+            const uint8_t* __restrict__ bit_rows, uint64_t row_bytes, const int8_t* __restrict__ digits, const HallItem* __restrict__ items,
+            const uint32_t* __restrict__ n_items, const uint32_t* __restrict__ item_block_base, uint32_t n_chunks, uint32_t code,
+            double* __restrict__ moments, uint32_t block_bins, uint64_t words_per_block, unsigned long long* __restrict__ words) {
+  typedef int v4i __attribute__((ext_vector_type(4)));
+  typedef uint32_t v2u __attribute__((ext_vector_type(2)));
+  typedef uint32_t v4u __attribute__((ext_vector_type(4)));
+  constexpr uint32_t kItemBlocks = kHallItemLoci / kHallBlockLoci;
+  constexpr uint32_t kWaves = kBlock / kWave;
+  __shared__ v4i lds_digits[kItemBlocks * 128];                              // 32 KB: the item's A operands, in lane order
+  __shared__ uint32_t lds_rows[BITS ? 1 : kHallItemLoci];
+  __shared__ v4u lds_bits[BITS ? kWaves * 2 * kWave : 1];                    // BITS: per wave two blocks' rows of 16 bytes
+  const uint32_t item = blockIdx.x / n_chunks;
+  if (item >= *n_items) return;
+  const HallItem it = items[item];
+  const uint32_t len = it.end - it.begin, first_block = item_block_base[item], n_blocks = item_block_base[item + 1] - first_block;
+  {
+    const v4i* src = reinterpret_cast<const v4i*>(digits) + static_cast<uint64_t>(first_block) * 128;
+    for (uint32_t t = threadIdx.x; t < n_blocks * 128; t += blockDim.x) lds_digits[t] = src[t];
+    if constexpr (!BITS) {
+      const uint32_t* rows = slot_rows + static_cast<uint64_t>(first_block) * kHallBlockLoci;
+      for (uint32_t t = threadIdx.x; t < n_blocks * kHallBlockLoci; t += blockDim.x) lds_rows[t] = rows[t];
+    }
+  }
+  __syncthreads();
+  const uint32_t wave = threadIdx.x / kWave, lane = threadIdx.x % kWave, c = lane & 15u, u = lane >> 4;
+  // BITS: a wave takes two tiles of 128 genomes, one after the other -- the workgroup's eight tiles are 128 bytes of every
+  // row it reads, whole lines (the rows are padded to them), read while they are still in the cache
+  constexpr uint32_t kTiles = BITS ? 2 : 1;
+  for (uint32_t tile = 0; tile < kTiles; ++tile) {
+  // the wave's 128 genomes: 8 c + q of a run of 128, or (BITS) the genomes of 16 bytes of the bit rows (hall_bits_genome)
+  const uint64_t wave_tile = (static_cast<uint64_t>(blockIdx.x % n_chunks) * kWaves + wave) * kTiles + tile;
+  const uint64_t wave_first = BITS ? hall_bits_genome(wave_tile * 16, 0u) : wave_tile * 128;    // the first of them, of the call's genomes
+  if (wave_first >= n_genomes) return;                                        // (whole waves, after the one barrier; later tiles begin later)
+  const uint64_t lane_first = BITS ? wave_first + c : wave_first + 8 * c;
+  constexpr uint64_t kGenomeStride = BITS ? 256 : 1;                          // between the lane's genomes q, q + 1
+  const bool active = lane_first < n_genomes;
+  const uint64_t col = (g0 >> 2) + ((active ? lane_first : wave_first) >> 2);   // (not BITS) idle lanes re-read the wave's first column
+  const uint32_t code4 = code * 0x01010101u;
+  v4i acc[8][2];
+#pragma unroll
+  for (int q = 0; q < 8; ++q) acc[q][0] = acc[q][1] = v4i{0, 0, 0, 0};
+  constexpr int kHeld = BITS ? 2 : 16;                                        // registers of a block in flight (v2u)
+  auto load_block = [&](uint32_t block, v2u (&w)[kHeld]) {
+    if constexpr (BITS) {
+      // this lane's slot of the block: the 16 bytes of the wave's 128 genomes (a slot past the item: its row was never written)
+      const uint32_t slot = block * kHallBlockLoci + lane;
+      const v4u raw = *reinterpret_cast<const v4u*>(bit_rows + (static_cast<uint64_t>(first_block) * kHallBlockLoci + slot) * row_bytes + wave_tile * 16);
+      const bool in = slot < len;
+      w[0] = v2u{in ? raw.x : 0u, in ? raw.y : 0u};
+      w[1] = v2u{in ? raw.z : 0u, in ? raw.w : 0u};
+    } else {
+      const v4u* rows = reinterpret_cast<const v4u*>(lds_rows + block * kHallBlockLoci + 16u * u);
+#pragma unroll
+      for (int m = 0; m < 4; ++m) {
+        const v4u four = rows[m];
+        w[4 * m + 0] = __builtin_nontemporal_load(reinterpret_cast<const v2u*>(gt + static_cast<uint64_t>(four.x) * dwords_per_row + col));
+        w[4 * m + 1] = __builtin_nontemporal_load(reinterpret_cast<const v2u*>(gt + static_cast<uint64_t>(four.y) * dwords_per_row + col));
+        w[4 * m + 2] = __builtin_nontemporal_load(reinterpret_cast<const v2u*>(gt + static_cast<uint64_t>(four.z) * dwords_per_row + col));
+        w[4 * m + 3] = __builtin_nontemporal_load(reinterpret_cast<const v2u*>(gt + static_cast<uint64_t>(four.w) * dwords_per_row + col));
+      }
+    }
+  };
+  bool emit = false;
+  if constexpr (EMIT) emit = it.bin < block_bins;                             // (the same for the whole workgroup)
+  uint32_t piece[8];                                                          // EMIT: per genome, this lane's 16 slots of the block as bits (slot j at bit 15 - j)
+#pragma unroll
+  for (int q = 0; q < 8; ++q) piece[q] = 0u;
+  auto multiply_block = [&](uint32_t block, const v2u (&w)[kHeld]) {
+    __builtin_amdgcn_sched_barrier(0);                                        // the loads issued above stay above
+    const v4i a0 = lds_digits[block * 128 + lane], a1 = lds_digits[block * 128 + 64 + lane];
+    // EMIT: the lane's slots that are the item's (a slot past it repeats the last row: no column counts it, and no bit may)
+    const uint32_t first_slot = block * kHallBlockLoci + 16u * u;
+    const uint32_t inside = first_slot + 16u <= len ? 0xFFFFu : first_slot >= len ? 0u : (0xFFFFu << (16u - (len - first_slot))) & 0xFFFFu;
+    uint32_t octet[4];                                                        // BITS: byte b of dword m = the eight genomes' bits at slot 16 u + 4 m + b
+    if constexpr (BITS) {
+      v4u* mine = lds_bits + (wave * 2 + (block & 1u)) * kWave;               // (two regions in turn: the next block's write does not wait for this one's reads)
+      mine[lane] = v4u{w[0].x, w[0].y, w[1].x, w[1].y};
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      const uint8_t* bytes = reinterpret_cast<const uint8_t*>(mine) + 16u * 16u * u + c;
+#pragma unroll
+      for (int m = 0; m < 4; ++m)
+        octet[m] = static_cast<uint32_t>(bytes[16 * (4 * m)]) | (static_cast<uint32_t>(bytes[16 * (4 * m + 1)]) << 8) |
+                   (static_cast<uint32_t>(bytes[16 * (4 * m + 2)]) << 16) | (static_cast<uint32_t>(bytes[16 * (4 * m + 3)]) << 24);
+    }
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {                                             // the lane's genomes 0..3, then 4..7
+      uint32_t t4[4][4];                                                      // [group of four loci][genome]: byte b = locus 4 m + b, 0x80 = a hit (-128: undone with the digit sums)
+      if constexpr (BITS) {
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+          for (int qq = 0; qq < 4; ++qq) t4[m][qq] = (octet[m] << (7 - (4 * k + qq))) & 0x80808080u;
+      } else {
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+          uint32_t hit[4];
+#pragma unroll
+          for (int b = 0; b < 4; ++b) {
+            const uint32_t x = (k ? w[4 * m + b].y : w[4 * m + b].x) ^ code4;   // a zero byte = a hit
+            const uint32_t nonzero = ((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x;     // bit 7 of each byte: the byte is not zero
+            hit[b] = ~nonzero & 0x80808080u;
+          }
+          // 4 x 4 bytes transposed: (locus, genome) -> (genome, locus).  __builtin_amdgcn_perm(hi, lo, sel): selector 0..3 = lo's bytes, 4..7 = hi's
+          const uint32_t p01_lo = __builtin_amdgcn_perm(hit[1], hit[0], 0x05010400u), p01_hi = __builtin_amdgcn_perm(hit[1], hit[0], 0x07030602u);
+          const uint32_t p23_lo = __builtin_amdgcn_perm(hit[3], hit[2], 0x05010400u), p23_hi = __builtin_amdgcn_perm(hit[3], hit[2], 0x07030602u);
+          t4[m][0] = __builtin_amdgcn_perm(p23_lo, p01_lo, 0x05040100u);
+          t4[m][1] = __builtin_amdgcn_perm(p23_lo, p01_lo, 0x07060302u);
+          t4[m][2] = __builtin_amdgcn_perm(p23_hi, p01_hi, 0x05040100u);
+          t4[m][3] = __builtin_amdgcn_perm(p23_hi, p01_hi, 0x07060302u);
+        }
+      }
+#pragma unroll
+      for (int qq = 0; qq < 4; ++qq) {
+        const v4i b = {static_cast<int>(t4[0][qq]), static_cast<int>(t4[1][qq]), static_cast<int>(t4[2][qq]), static_cast<int>(t4[3][qq])};
+        acc[4 * k + qq][0] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a0, b, acc[4 * k + qq][0], 0, 0, 0);
+        acc[4 * k + qq][1] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a1, b, acc[4 * k + qq][1], 0, 0, 0);
+        if constexpr (EMIT) {
+          if (emit) {                                                         // bit 7 of byte b of dword m = slot 4 m + b: to bit 15 - (4 m + b)
+            uint32_t bits = 0;
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+              const uint32_t four = ((t4[m][qq] >> 7) * 0x08040201u) >> 24;   // byte b's flag to bit 3 - b (the other products fall below bit 24 or past bit 31)
+              bits = (bits << 4) | (four & 0xFu);
+            }
+            piece[4 * k + qq] = bits & inside;
+          }
+        }
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  v2u even[kHeld], odd[kHeld];
+  load_block(0u, even);
+  if (!emit) {
+    for (uint32_t b = 0; b < n_blocks; b += 2) {
+      load_block(b + 1u < n_blocks ? b + 1u : b, odd);                         // (past the item: its last block again, not used)
+      multiply_block(b, even);
+      load_block(b + 2u < n_blocks ? b + 2u : b, even);
+      if (b + 1u < n_blocks) multiply_block(b + 1u, odd);
+    }
+  } else if constexpr (EMIT) {
+    // a genome's word of a block: slot p at bit 63 - p = the 16-bit pieces of the four lane groups u = 0..3, first to last.
+    // The groups swap pieces (lane l <-> l ^ 16, then l ^ 32).  Not BITS: group u then stores pair u of hall_word_index's layout
+    // (genomes 2 u, 2 u + 1: 16 bytes); BITS: the words lie [block][genome] and group u stores its lanes' genomes q = 2 u, 2 u + 1
+    // (the sixteen lanes' side by side: 128 bytes).
+    const uint64_t lanes = words_per_block / 8;
+    v4u* out = reinterpret_cast<v4u*>(words) + static_cast<uint64_t>(first_block) * 4 * lanes + (lane_first >> 3);   // pair 0 of the item's first block
+    unsigned long long* plain = words + static_cast<uint64_t>(first_block) * words_per_block + lane_first;
+    auto store_words = [&]() {
+      uint32_t upper[8], lower[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const uint32_t beside = static_cast<uint32_t>(__shfl_xor(static_cast<int>(piece[q]), 16));
+        const uint32_t half_word = (u & 1u) ? (beside << 16) | piece[q] : (piece[q] << 16) | beside;   // slots 0..31 (u < 2) or 32..63
+        const uint32_t other = static_cast<uint32_t>(__shfl_xor(static_cast<int>(half_word), 32));
+        upper[q] = u < 2u ? half_word : other;
+        lower[q] = u < 2u ? other : half_word;
+      }
+#pragma unroll
+      for (uint32_t pair = 0; pair < 4; ++pair) {                             // (a store per group: u is the lane's, an indexed register is a trip through scratch)
+        if constexpr (BITS) {
+          if (u == pair) {
+            if (lane_first + (2 * pair) * kGenomeStride < n_genomes)
+              plain[(2 * pair) * kGenomeStride] = (static_cast<unsigned long long>(upper[2 * pair]) << 32) | lower[2 * pair];
+            if (lane_first + (2 * pair + 1) * kGenomeStride < n_genomes)
+              plain[(2 * pair + 1) * kGenomeStride] = (static_cast<unsigned long long>(upper[2 * pair + 1]) << 32) | lower[2 * pair + 1];
+          }
+        } else {
+          if (active && u == pair) out[static_cast<uint64_t>(pair) * lanes] = v4u{lower[2 * pair], upper[2 * pair], lower[2 * pair + 1], upper[2 * pair + 1]};
+        }
+      }
+      out += 4 * lanes;
+      plain += words_per_block;
+    };
+    for (uint32_t b = 0; b < n_blocks; b += 2) {
+      load_block(b + 1u < n_blocks ? b + 1u : b, odd);
+      multiply_block(b, even);
+      store_words();
+      load_block(b + 2u < n_blocks ? b + 2u : b, even);
+      if (b + 1u < n_blocks) {
+        multiply_block(b + 1u, odd);
+        store_words();
+      }
+    }
+  }
+  if (!active) continue;
+  // the digit sums back to doubles: sum_d acc_d * 256^d, times -1/128 (the hits were -128), 2^-54 and 2^(j (e - 7)), j = u + 1
+  const int exponent = it.bin == 0u ? 0 : static_cast<int>((it.bin - 1u) >> kHallKeyMantissa) + kHallMinExponent;
+  const int scale = -7 - kHallDigitBits + static_cast<int>(u + 1u) * (exponent - 7);
+  double* out = moments + static_cast<uint64_t>(item) * kHallMoments * n_genomes;
+#pragma unroll
+  for (int q = 0; q < 8; ++q) {
+    const uint64_t g = lane_first + q * kGenomeStride;
+    if (g >= n_genomes) break;
+    double sum = static_cast<double>(acc[q][1][2]);
+    sum = sum * 256.0 + static_cast<double>(acc[q][1][1]);
+    sum = sum * 256.0 + static_cast<double>(acc[q][1][0]);
+    sum = sum * 256.0 + static_cast<double>(acc[q][0][3]);
+    sum = sum * 256.0 + static_cast<double>(acc[q][0][2]);
+    sum = sum * 256.0 + static_cast<double>(acc[q][0][1]);
+    sum = sum * 256.0 + static_cast<double>(acc[q][0][0]);
+    out[static_cast<uint64_t>(u + 1u) * n_genomes + g] = -ldexp(sum, scale);
+    if (u == 3u) out[g] = static_cast<double>(-acc[q][1][3]) * 0.0078125;
+  }
   }
 }
 

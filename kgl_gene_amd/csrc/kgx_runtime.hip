@@ -211,6 +211,7 @@ Device::~Device() {
   for (int k = 0; k < 2; ++k)
     if (compact[k]) (void)hipFree(compact[k]);
   if (words) (void)hipFree(words);
+  if (bits) (void)hipFree(bits);
   for (int k = 0; k < 2; ++k)
     if (pinned[k]) (void)hipHostFree(pinned[k]);
   if (exchange_stage) (void)hipFree(exchange_stage);
@@ -474,6 +475,9 @@ int kgx_release_scratch(void) {
       if (dev->words) (void)hipFree(dev->words);
       dev->words = nullptr;
       dev->words_bytes = 0;
+      if (dev->bits) (void)hipFree(dev->bits);
+      dev->bits = nullptr;
+      dev->bits_bytes = 0;
       for (int k = 0; k < 2; ++k) {
         if (dev->pinned[k]) (void)hipHostFree(dev->pinned[k]);
         dev->pinned[k] = nullptr;
