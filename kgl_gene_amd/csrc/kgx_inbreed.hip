@@ -393,6 +393,67 @@ int inbreed_shard(kgx_gt8_shard& sh, uint64_t g0, uint64_t g1, const uint32_t* l
       hipLaunchKernelGGL((k_inbreed_sweep<2>), grid, dim3(kBlock), 0, st, gt32, dwords_per_row, g0, n, d_index, n_sel, per_seg, d_table,
                          d_valid, amax, phased, d_f, d_counts, d_part, sh.d_wide_of_row, sh.d_wide, sh.wide_pitch);
   };
+  // (the moments' buffers and the ordering of the classes)
+  uint32_t* const h_words = reinterpret_cast<uint32_t*>(arena + o_hall_words);
+  uint32_t* const h_bin_used = h_words + plan_classes * kHallClassWords;
+  uint32_t* const h_used = h_bin_used + (kHallBins + 1);
+  uint32_t* const h_counters = h_used + (kHallBins + 1);                       // [class][4]: n_items, n_blocks; then n_used, unsupported, handed over
+  uint32_t* const h_totals = h_counters + plan_classes * 4;
+  double* const h_bins = reinterpret_cast<double*>(arena + o_hall_bins);
+  std::vector<uint32_t> class_items(plan_classes, 0u), class_blocks(plan_classes, 0u);
+  LoglikClasses loglik_classes{};
+  bool moments_timed = false, search_timed = false;             // (events recorded: read after the call's last synchronisation)
+  auto class_words = [&](uint32_t k) { return h_words + k * kHallClassWords; };
+  const bool moments_emit = loglik_moments;                       // (Loglikelihood: the hits of the reachable bins leave as bits too)
+  uint32_t* h_keys = reinterpret_cast<uint32_t*>(arena + o_hall_keys);
+  uint32_t *h_slots = h_keys + n_sel, *h_sorted_keys = h_keys + 2 * n_sel, *h_sorted_slots = h_keys + 3 * n_sel;
+  double* h_moments = reinterpret_cast<double*>(arena + o_hall_moments);
+  const uint32_t hall_chunks = static_cast<uint32_t>(((n + eval_gpl - 1) / eval_gpl + kBlock - 1) / kBlock);
+  // (a bin's workgroups: enough of them for the few bins that hold most loci -- the major allele's -- to fill the chip)
+  const uint32_t hall_merge_blocks = static_cast<uint32_t>(std::min<uint64_t>(64, (kHallMoments * n + kBlock - 1) / kBlock));
+  // the bins an exact walk can reach (kgx_kernels_loglik.h): those starting below kLoglikReach
+  const uint32_t block_bins = moments_emit ? hall_key_host(kLoglikReach) + 1u : 0u;
+  HallRecord* const h_records = reinterpret_cast<HallRecord*>(arena + o_hall_records);
+  const size_t padded_records = static_cast<size_t>(hall_blocks + 1) * kHallBlockLoci;
+  auto padded_of = [&](uint32_t k) { return reinterpret_cast<HallRecord*>(arena + o_hall_padded) + static_cast<uint64_t>(k) * padded_records; };
+  auto ys_of = [&](uint32_t k) { return moments_emit ? reinterpret_cast<double*>(arena + o_hall_ys) + static_cast<uint64_t>(k) * padded_records : nullptr; };
+  auto items_of = [&](uint32_t k) { return reinterpret_cast<HallItem*>(arena + o_hall_items) + static_cast<uint64_t>(k) * hall_items; };
+  auto item_blocks_of = [&](uint32_t k) { return reinterpret_cast<uint32_t*>(arena + o_hall_item_blocks) + static_cast<uint64_t>(k) * (hall_items + 1); };
+  auto digits_of = [&](uint32_t k) { return reinterpret_cast<int8_t*>(arena + o_hall_digits) + static_cast<uint64_t>(k) * padded_records * 32; };
+  auto rows_of = [&](uint32_t k) { return reinterpret_cast<uint32_t*>(arena + o_hall_rows) + static_cast<uint64_t>(k) * padded_records; };
+  uint32_t* const slot_of_locus = hall_bits_planned ? reinterpret_cast<uint32_t*>(arena + o_slot_of_locus) : nullptr;
+  std::vector<uint32_t> counters;
+  char* counters_pinned = nullptr;                                 // (page-locked)
+  // The classes in bin order, on stream `os`; the counters the host needs come back behind it (into counters_pinned).
+  auto order_classes = [&](hipStream_t os) {
+    const bool emit = moments_emit;
+    try_hip(hipMemsetAsync(h_words, 0, hall_word_count * sizeof(uint32_t), os), KGX_EHIP, "memset(hall words)");
+    // (k_hall_sweep reads up to two batches past an item's slots -- the next item's, or, behind the last one, this: row 0, matching
+    // nothing; the matrix-core pass reads its items' blocks alone.  The bins need no clearing: k_hall_merge)
+    if (!hall_mfma) try_hip(hipMemsetAsync(arena + o_hall_padded, 0, hall_classes * padded_records * sizeof(HallRecord), os), KGX_EHIP, "memset(hall blocks)");
+    if (slot_of_locus) try_hip(hipMemsetAsync(slot_of_locus, 0xFF, static_cast<size_t>(hall_classes) * sel_pitch * sizeof(uint32_t), os), KGX_EHIP, "memset(slot of locus)");
+    for (uint32_t k = 0; k < hall_classes && rc == KGX_OK; ++k) {
+      uint32_t *bin_begin = class_words(k), *bin_end = bin_begin + (kHallBins + 1), *item_base = bin_begin + 2 * (kHallBins + 1);
+      hipLaunchKernelGGL(k_hall_keys, dim3(stream_grid(dev, n_sel, kBlock)), dim3(kBlock), 0, os, d_table, d_valid, n_sel, amax, phased, k, h_keys,
+                         h_slots, h_totals + 1);
+      size_t sort_bytes = hall_sort_bytes;
+      try_hip(hipcub::DeviceRadixSort::SortPairs(arena + o_hall_sort, sort_bytes, h_keys, h_sorted_keys, h_slots, h_sorted_slots,
+                                                 static_cast<int>(n_sel), 0, 12, os), KGX_EHIP, "radix sort");
+      hipLaunchKernelGGL(k_hall_records, dim3(stream_grid(dev, n_sel, kBlock)), dim3(kBlock), 0, os, h_sorted_keys, h_sorted_slots, n_sel, d_table,
+                         amax, k, d_index, h_records, bin_begin, bin_end);
+      hipLaunchKernelGGL(k_hall_items, dim3(1), dim3(kBlock), 0, os, bin_begin, bin_end, item_base, items_of(k), h_counters + 4 * k, block_bins,
+                         item_blocks_of(k), h_counters + 4 * k + 1);
+      hipLaunchKernelGGL(k_hall_pad, dim3(static_cast<uint32_t>(std::min<uint64_t>(hall_items, 65535))), dim3(kBlock), 0, os, h_records, items_of(k),
+                         h_counters + 4 * k, item_blocks_of(k), padded_of(k), ys_of(k), h_sorted_slots, slot_of_locus ? slot_of_locus + k * sel_pitch : nullptr);
+      if (hall_mfma) hipLaunchKernelGGL(k_hall_digits, dim3(static_cast<uint32_t>(std::min<uint64_t>(hall_items, 65535))), dim3(kBlock), 0, os, padded_of(k),
+                                        items_of(k), h_counters + 4 * k, item_blocks_of(k), digits_of(k), rows_of(k));
+      if (emit) hipLaunchKernelGGL(k_hall_bin_blocks, dim3((kHallBins + kBlock) / kBlock), dim3(kBlock), 0, os, item_base, item_blocks_of(k), item_base + (kHallBins + 1));
+      try_hip(hipGetLastError(), KGX_EHIP, "hall order launch");
+    }
+    if (rc == KGX_OK && pinned_reserve(dev, 1, (hall_classes + 1) * 4 * sizeof(uint32_t), &counters_pinned) != KGX_OK) rc = KGX_ENOMEM;
+    if (rc == KGX_OK)
+      try_hip(hipMemcpyAsync(counters_pinned, h_counters, (hall_classes + 1) * 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, os), KGX_EHIP, "D2H(hall counters)");
+  };
   const uint32_t lin_grid = stream_grid(dev, n, kBlock);
   auto reduce_grid = [&](uint64_t items) { return stream_grid(dev, (items + kReduceItems - 1) / kReduceItems * kBlock, kBlock); };
   if (rc == KGX_OK) {
@@ -437,60 +498,12 @@ int inbreed_shard(kgx_gt8_shard& sh, uint64_t g0, uint64_t g1, const uint32_t* l
     // passes instead and has lost a millisecond, not the class passes), the items of each class (the passes' grids) and, with
     // `emit` (Loglikelihood), the blocks whose hits the passes leave as bits -- then one pass over the bytes per class and the
     // merge of its items into the bins.
-    uint32_t* const h_words = reinterpret_cast<uint32_t*>(arena + o_hall_words);
-    uint32_t* const h_bin_used = h_words + plan_classes * kHallClassWords;
-    uint32_t* const h_used = h_bin_used + (kHallBins + 1);
-    uint32_t* const h_counters = h_used + (kHallBins + 1);                       // [class][4]: n_items, n_blocks; then n_used, unsupported, handed over
-    uint32_t* const h_totals = h_counters + plan_classes * 4;
-    double* const h_bins = reinterpret_cast<double*>(arena + o_hall_bins);
-    std::vector<uint32_t> class_items(plan_classes, 0u), class_blocks(plan_classes, 0u);
-    LoglikClasses loglik_classes{};
-    bool moments_timed = false, search_timed = false;             // (events recorded: read after the call's last synchronisation)
-    auto class_words = [&](uint32_t k) { return h_words + k * kHallClassWords; };
     auto gather_moments = [&](bool emit) -> bool {
-      uint32_t* h_keys = reinterpret_cast<uint32_t*>(arena + o_hall_keys);
-      uint32_t *h_slots = h_keys + n_sel, *h_sorted_keys = h_keys + 2 * n_sel, *h_sorted_slots = h_keys + 3 * n_sel;
-      double* h_moments = reinterpret_cast<double*>(arena + o_hall_moments);
-      const uint32_t hall_chunks = static_cast<uint32_t>(((n + eval_gpl - 1) / eval_gpl + kBlock - 1) / kBlock);
-      // (a bin's workgroups: enough of them for the few bins that hold most loci -- the major allele's -- to fill the chip)
-      const uint32_t hall_merge_blocks = static_cast<uint32_t>(std::min<uint64_t>(64, (kHallMoments * n + kBlock - 1) / kBlock));
-      // the bins an exact walk can reach (kgx_kernels_loglik.h): those starting below kLoglikReach
-      const uint32_t block_bins = emit ? hall_key_host(kLoglikReach) + 1u : 0u;
-      HallRecord* const h_records = reinterpret_cast<HallRecord*>(arena + o_hall_records);
-      const size_t padded_records = static_cast<size_t>(hall_blocks + 1) * kHallBlockLoci;
-      auto padded_of = [&](uint32_t k) { return reinterpret_cast<HallRecord*>(arena + o_hall_padded) + static_cast<uint64_t>(k) * padded_records; };
-      auto ys_of = [&](uint32_t k) { return emit ? reinterpret_cast<double*>(arena + o_hall_ys) + static_cast<uint64_t>(k) * padded_records : nullptr; };
-      auto items_of = [&](uint32_t k) { return reinterpret_cast<HallItem*>(arena + o_hall_items) + static_cast<uint64_t>(k) * hall_items; };
-      auto item_blocks_of = [&](uint32_t k) { return reinterpret_cast<uint32_t*>(arena + o_hall_item_blocks) + static_cast<uint64_t>(k) * (hall_items + 1); };
-      auto digits_of = [&](uint32_t k) { return reinterpret_cast<int8_t*>(arena + o_hall_digits) + static_cast<uint64_t>(k) * padded_records * 32; };
-      auto rows_of = [&](uint32_t k) { return reinterpret_cast<uint32_t*>(arena + o_hall_rows) + static_cast<uint64_t>(k) * padded_records; };
-      try_hip(hipMemsetAsync(h_words, 0, hall_word_count * sizeof(uint32_t), st), KGX_EHIP, "memset(hall words)");
-      // (a pass reads up to two batches past an item's slots -- the next item's, or, behind the last one, this: row 0, matching nothing)
-      try_hip(hipMemsetAsync(arena + o_hall_padded, 0, hall_classes * padded_records * sizeof(HallRecord), st), KGX_EHIP, "memset(hall blocks)");
-      try_hip(hipMemsetAsync(h_bins, 0, static_cast<size_t>(kHallBins) * kHallMoments * n * sizeof(double), st), KGX_EHIP, "memset(hall bins)");
-      uint32_t* const slot_of_locus = hall_bits_planned ? reinterpret_cast<uint32_t*>(arena + o_slot_of_locus) : nullptr;
-      if (slot_of_locus) try_hip(hipMemsetAsync(slot_of_locus, 0xFF, static_cast<size_t>(hall_classes) * sel_pitch * sizeof(uint32_t), st), KGX_EHIP, "memset(slot of locus)");
-      for (uint32_t k = 0; k < hall_classes && rc == KGX_OK; ++k) {
-        uint32_t *bin_begin = class_words(k), *bin_end = bin_begin + (kHallBins + 1), *item_base = bin_begin + 2 * (kHallBins + 1);
-        hipLaunchKernelGGL(k_hall_keys, dim3(stream_grid(dev, n_sel, kBlock)), dim3(kBlock), 0, st, d_table, d_valid, n_sel, amax, phased, k, h_keys,
-                           h_slots, h_totals + 1);
-        size_t sort_bytes = hall_sort_bytes;
-        try_hip(hipcub::DeviceRadixSort::SortPairs(arena + o_hall_sort, sort_bytes, h_keys, h_sorted_keys, h_slots, h_sorted_slots,
-                                                   static_cast<int>(n_sel), 0, 12, st), KGX_EHIP, "radix sort");
-        hipLaunchKernelGGL(k_hall_records, dim3(stream_grid(dev, n_sel, kBlock)), dim3(kBlock), 0, st, h_sorted_keys, h_sorted_slots, n_sel, d_table,
-                           amax, k, d_index, h_records, bin_begin, bin_end);
-        hipLaunchKernelGGL(k_hall_items, dim3(1), dim3(kBlock), 0, st, bin_begin, bin_end, item_base, items_of(k), h_counters + 4 * k, block_bins,
-                           item_blocks_of(k), h_counters + 4 * k + 1);
-        hipLaunchKernelGGL(k_hall_pad, dim3(static_cast<uint32_t>(std::min<uint64_t>(hall_items, 65535))), dim3(kBlock), 0, st, h_records, items_of(k),
-                           h_counters + 4 * k, item_blocks_of(k), padded_of(k), ys_of(k), h_sorted_slots, slot_of_locus ? slot_of_locus + k * sel_pitch : nullptr);
-        if (hall_mfma) hipLaunchKernelGGL(k_hall_digits, dim3(static_cast<uint32_t>(std::min<uint64_t>(hall_items, 65535))), dim3(kBlock), 0, st, padded_of(k),
-                                          items_of(k), h_counters + 4 * k, item_blocks_of(k), digits_of(k), rows_of(k));
-        if (emit) hipLaunchKernelGGL(k_hall_bin_blocks, dim3((kHallBins + kBlock) / kBlock), dim3(kBlock), 0, st, item_base, item_blocks_of(k), item_base + (kHallBins + 1));
-        try_hip(hipGetLastError(), KGX_EHIP, "hall order launch");
-      }
-      std::vector<uint32_t> counters((hall_classes + 1) * 4, 0u);
-      try_hip(hipMemcpyAsync(counters.data(), h_counters, counters.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, st), KGX_EHIP, "D2H(hall counters)");
+      // (measured: on the side stream beside the frequency sweep, even at the highest priority, the ordering's ~50 small kernels
+      // wait for the sweep's workgroups to leave -- one radix-sort kernel 5 ms -- and the call is no shorter)
+      order_classes(st);
       try_hip(hipStreamSynchronize(st), KGX_EHIP, "sync");
+      if (rc == KGX_OK) counters.assign(reinterpret_cast<const uint32_t*>(counters_pinned), reinterpret_cast<const uint32_t*>(counters_pinned) + (hall_classes + 1) * 4);
       if (rc != KGX_OK || counters[hall_classes * 4 + 1] != 0u) return false;
       uint64_t all_blocks = 0;
       for (uint32_t k = 0; k < hall_classes; ++k) {
@@ -579,7 +592,7 @@ int inbreed_shard(kgx_gt8_shard& sh, uint64_t g0, uint64_t g1, const uint32_t* l
         } else if (eval_gpl == 8) { if (emit) KGX_HALL_SWEEP(8, true); else KGX_HALL_SWEEP(8, false); }
         else KGX_HALL_SWEEP(4, false);                                          // (the hits' words are a lane of eight genomes': loglik_candidate)
 #undef KGX_HALL_SWEEP
-        hipLaunchKernelGGL(k_hall_merge, dim3(hall_merge_blocks, kHallBins), dim3(kBlock), 0, st, h_moments, item_base, n, h_bins, h_bin_used);
+        hipLaunchKernelGGL(k_hall_merge, dim3(hall_merge_blocks, kHallBins), dim3(kBlock), 0, st, h_moments, item_base, n, h_bins, h_bin_used, k + 1u);
         try_hip(hipGetLastError(), KGX_EHIP, "hall moments launch");
       }
       loglik_classes.n = emit ? hall_classes : 0u;

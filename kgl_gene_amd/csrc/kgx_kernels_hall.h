@@ -548,6 +548,7 @@ k_hall_mfma(const uint32_t* __restrict__ gt, uint64_t dwords_per_row, uint64_t g
   // BITS: a wave takes two tiles of 128 genomes, one after the other -- the workgroup's eight tiles are 128 bytes of every
   // row it reads, whole lines (the rows are padded to them), read while they are still in the cache
   constexpr uint32_t kTiles = BITS ? 2 : 1;
+#pragma nounroll
   for (uint32_t tile = 0; tile < kTiles; ++tile) {
   // the wave's 128 genomes: 8 c + q of a run of 128, or (BITS) the genomes of 16 bytes of the bit rows (hall_bits_genome)
   const uint64_t wave_tile = (static_cast<uint64_t>(blockIdx.x % n_chunks) * kWaves + wave) * kTiles + tile;
@@ -564,12 +565,11 @@ k_hall_mfma(const uint32_t* __restrict__ gt, uint64_t dwords_per_row, uint64_t g
   constexpr int kHeld = BITS ? 2 : 16;                                        // registers of a block in flight (v2u)
   auto load_block = [&](uint32_t block, v2u (&w)[kHeld]) {
     if constexpr (BITS) {
-      // this lane's slot of the block: the 16 bytes of the wave's 128 genomes (a slot past the item: its row was never written)
+      // this lane's slot of the block: the 16 bytes of the wave's 128 genomes
       const uint32_t slot = block * kHallBlockLoci + lane;
       const v4u raw = *reinterpret_cast<const v4u*>(bit_rows + (static_cast<uint64_t>(first_block) * kHallBlockLoci + slot) * row_bytes + wave_tile * 16);
-      const bool in = slot < len;
-      w[0] = v2u{in ? raw.x : 0u, in ? raw.y : 0u};
-      w[1] = v2u{in ? raw.z : 0u, in ? raw.w : 0u};
+      w[0] = v2u{raw.x, raw.y};                                                // (masked where it is used: a select here would wait for the load)
+      w[1] = v2u{raw.z, raw.w};
     } else {
       const v4u* rows = reinterpret_cast<const v4u*>(lds_rows + block * kHallBlockLoci + 16u * u);
 #pragma unroll
@@ -596,7 +596,8 @@ k_hall_mfma(const uint32_t* __restrict__ gt, uint64_t dwords_per_row, uint64_t g
     uint32_t octet[4];                                                        // BITS: byte b of dword m = the eight genomes' bits at slot 16 u + 4 m + b
     if constexpr (BITS) {
       v4u* mine = lds_bits + (wave * 2 + (block & 1u)) * kWave;               // (two regions in turn: the next block's write does not wait for this one's reads)
-      mine[lane] = v4u{w[0].x, w[0].y, w[1].x, w[1].y};
+      const bool in = block * kHallBlockLoci + lane < len;                     // (a slot past the item: its row was never written)
+      mine[lane] = in ? v4u{w[0].x, w[0].y, w[1].x, w[1].y} : v4u{0u, 0u, 0u, 0u};
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -613,7 +614,7 @@ k_hall_mfma(const uint32_t* __restrict__ gt, uint64_t dwords_per_row, uint64_t g
 #pragma unroll
         for (int m = 0; m < 4; ++m)
 #pragma unroll
-          for (int qq = 0; qq < 4; ++qq) t4[m][qq] = (octet[m] << (7 - (4 * k + qq))) & 0x80808080u;
+          for (int qq = 0; qq < 4; ++qq) t4[m][qq] = octet[m] & (0x01010101u << (4 * k + qq));   // a hit of genome q: 2^q (q = 7: -128), undone with the digit sums
       } else {
 #pragma unroll
         for (int m = 0; m < 4; ++m) {
@@ -643,7 +644,7 @@ k_hall_mfma(const uint32_t* __restrict__ gt, uint64_t dwords_per_row, uint64_t g
             uint32_t bits = 0;
 #pragma unroll
             for (int m = 0; m < 4; ++m) {
-              const uint32_t four = ((t4[m][qq] >> 7) * 0x08040201u) >> 24;   // byte b's flag to bit 3 - b (the other products fall below bit 24 or past bit 31)
+              const uint32_t four = ((t4[m][qq] >> (BITS ? 4 * k + qq : 7)) * 0x08040201u) >> 24;   // byte b's flag to bit 3 - b (the other products fall below bit 24 or past bit 31)
               bits = (bits << 4) | (four & 0xFu);
             }
             piece[4 * k + qq] = bits & inside;
@@ -655,7 +656,15 @@ k_hall_mfma(const uint32_t* __restrict__ gt, uint64_t dwords_per_row, uint64_t g
   };
   v2u even[kHeld], odd[kHeld];
   load_block(0u, even);
-  if (!emit) {
+  if constexpr (BITS && !EMIT) {
+    // (a block in flight is four registers: one loop body, the next block's load above this block's products)
+    for (uint32_t b = 0; b < n_blocks; ++b) {
+      load_block(b + 1u < n_blocks ? b + 1u : b, odd);                         // (past the item: its last block again, not used)
+      multiply_block(b, even);
+      even[0] = odd[0];
+      even[1] = odd[1];
+    }
+  } else if (!emit) {
     for (uint32_t b = 0; b < n_blocks; b += 2) {
       load_block(b + 1u < n_blocks ? b + 1u : b, odd);                         // (past the item: its last block again, not used)
       multiply_block(b, even);
@@ -723,23 +732,31 @@ k_hall_mfma(const uint32_t* __restrict__ gt, uint64_t dwords_per_row, uint64_t g
     sum = sum * 256.0 + static_cast<double>(acc[q][0][2]);
     sum = sum * 256.0 + static_cast<double>(acc[q][0][1]);
     sum = sum * 256.0 + static_cast<double>(acc[q][0][0]);
-    out[static_cast<uint64_t>(u + 1u) * n_genomes + g] = -ldexp(sum, scale);
-    if (u == 3u) out[g] = static_cast<double>(-acc[q][1][3]) * 0.0078125;
+    // (what a hit weighed: -128 from the bytes; 2^q from the bit rows, -128 for q = 7)
+    const int weight = BITS ? q : 7;
+    const double signed_one = weight == 7 ? -1.0 : 1.0;
+    out[static_cast<uint64_t>(u + 1u) * n_genomes + g] = signed_one * ldexp(sum, scale + 7 - weight);
+    if (u == 3u) out[g] = signed_one * ldexp(static_cast<double>(acc[q][1][3]), -weight);
   }
   }
 }
 
 // bins[(bin * kHallMoments + j) * n_genomes + g] += the bin's items, in slot order (classes follow one another on the stream).
+// bin_used[bin]: 0 = nobody has written the bin yet -- this class's launch (`generation` = class + 1, which it leaves there) starts
+// its sums from 0 instead of reading them, so the bins need no clearing (1 GB at 10 000 genomes); any other value: an earlier
+// class's sums are there.  (Every workgroup of a bin sees 0 or this launch's own generation: the same answer.)
 __global__ void __launch_bounds__(kBlock)
 k_hall_merge(const double* __restrict__ moments, const uint32_t* __restrict__ item_base, uint64_t n_genomes, double* __restrict__ bins,
-             uint32_t* __restrict__ bin_used) {
+             uint32_t* __restrict__ bin_used, uint32_t generation) {
   const uint32_t bin = blockIdx.y;
   const uint32_t first = item_base[bin], last = item_base[bin + 1];
   if (first == last) return;
-  if (blockIdx.x == 0 && threadIdx.x == 0) bin_used[bin] = 1u;
+  const uint32_t before = __hip_atomic_load(bin_used + bin, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  const bool fresh = before == 0u || before == generation;
+  if (blockIdx.x == 0 && threadIdx.x == 0 && before == 0u) __hip_atomic_store(bin_used + bin, generation, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   const uint64_t per_bin = static_cast<uint64_t>(kHallMoments) * n_genomes;
   for (uint64_t e = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x; e < per_bin; e += static_cast<uint64_t>(gridDim.x) * blockDim.x) {
-    double sum = bins[bin * per_bin + e];
+    double sum = fresh ? 0.0 : bins[bin * per_bin + e];
     for (uint32_t t = first; t < last; ++t) sum += moments[t * per_bin + e];
     bins[bin * per_bin + e] = sum;
   }
