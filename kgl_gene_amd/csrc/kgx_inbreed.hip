@@ -512,9 +512,10 @@ int inbreed_shard(kgx_gt8_shard& sh, uint64_t g0, uint64_t g1, const uint32_t* l
         all_blocks += class_blocks[k];
       }
       unsigned long long* words = nullptr;
+      const uint64_t word_blocks = (all_blocks + 16) / 16 * 16;                 // (a genome's run of words: whole lines)
       if (emit) {
         // the hits' words: [block][genome], the classes' blocks one after the other; kept between calls like the arena
-        const size_t want = (all_blocks ? all_blocks : 1) * words_per_block * sizeof(unsigned long long);
+        const size_t want = word_blocks * words_per_block * sizeof(unsigned long long);
         if (dev.words_bytes < want) {
           if (dev.words) (void)hipFree(dev.words);
           dev.words = nullptr;
@@ -566,7 +567,9 @@ int inbreed_shard(kgx_gt8_shard& sh, uint64_t g0, uint64_t g1, const uint32_t* l
       }
       for (uint32_t k = 0; k < hall_classes && rc == KGX_OK; ++k) {
         uint32_t* item_base = class_words(k) + 2 * (kHallBins + 1);
-        unsigned long long* class_out = emit ? words + block_base * words_per_block : nullptr;
+        // (the words of a class: behind those of the classes before it -- block-major, or, from the bit rows, within every genome's run)
+        unsigned long long* class_out = emit ? words + block_base * (by_bits && hall_mfma ? 1 : words_per_block) : nullptr;
+        const uint64_t block_base_of_class = block_base;
         if (emit) {
           loglik_classes.of[k] = LoglikClass{ys_of(k), item_base + (kHallBins + 1), class_out};
           block_base += class_blocks[k];
@@ -585,7 +588,7 @@ int inbreed_shard(kgx_gt8_shard& sh, uint64_t g0, uint64_t g1, const uint32_t* l
 #define KGX_HALL_MFMA(EMIT, BITS)                                                                                                      \
   hipLaunchKernelGGL((k_hall_mfma<EMIT, BITS>), mfma_grid, dim3(kBlock), 0, st, gt32, dwords_per_row, g0, n, rows_of(k), bit_rows, bit_row_bytes, \
                      digits_of(k), items_of(k), h_counters + 4 * k, item_blocks_of(k), mfma_chunks, code, h_moments, block_bins,        \
-                     words_per_block, class_out)
+                     words_per_block, class_out, word_blocks, static_cast<uint32_t>(block_base_of_class & 3u))
           if (by_bits) { if (emit) KGX_HALL_MFMA(true, true); else KGX_HALL_MFMA(false, true); }
           else { if (emit) KGX_HALL_MFMA(true, false); else KGX_HALL_MFMA(false, false); }
 #undef KGX_HALL_MFMA
@@ -598,6 +601,7 @@ int inbreed_shard(kgx_gt8_shard& sh, uint64_t g0, uint64_t g1, const uint32_t* l
       loglik_classes.n = emit ? hall_classes : 0u;
       loglik_classes.block_bins = block_bins;
       loglik_classes.plain_words = (by_bits && hall_mfma) ? 1u : 0u;
+      loglik_classes.word_blocks = word_blocks;
       try_hip(hipEventRecord(dev.moments_end, st), KGX_EHIP, "hipEventRecord");
       moments_timed = true;
       hipLaunchKernelGGL(k_hall_used_bins, dim3(1), dim3(kBlock), 0, st, h_bin_used, h_used, h_totals);

@@ -522,7 +522,7 @@ __global__ void __launch_bounds__(kBlock)
 k_hall_mfma(const uint32_t* __restrict__ gt, uint64_t dwords_per_row, uint64_t g0, uint64_t n_genomes, const uint32_t* __restrict__ slot_rows,
             const uint8_t* __restrict__ bit_rows, uint64_t row_bytes, const int8_t* __restrict__ digits, const HallItem* __restrict__ items,
             const uint32_t* __restrict__ n_items, const uint32_t* __restrict__ item_block_base, uint32_t n_chunks, uint32_t code,
-            double* __restrict__ moments, uint32_t block_bins, uint64_t words_per_block, unsigned long long* __restrict__ words) {
+            double* __restrict__ moments, uint32_t block_bins, uint64_t words_per_block, unsigned long long* __restrict__ words, uint64_t word_blocks, uint32_t word_phase) {
   typedef int v4i __attribute__((ext_vector_type(4)));
   typedef uint32_t v2u __attribute__((ext_vector_type(2)));
   typedef uint32_t v4u __attribute__((ext_vector_type(4)));
@@ -673,14 +673,9 @@ k_hall_mfma(const uint32_t* __restrict__ gt, uint64_t dwords_per_row, uint64_t g
     }
   } else if constexpr (EMIT) {
     // a genome's word of a block: slot p at bit 63 - p = the 16-bit pieces of the four lane groups u = 0..3, first to last.
-    // The groups swap pieces (lane l <-> l ^ 16, then l ^ 32).  Not BITS: group u then stores pair u of hall_word_index's layout
-    // (genomes 2 u, 2 u + 1: 16 bytes); BITS: the words lie [block][genome] and group u stores its lanes' genomes q = 2 u, 2 u + 1
-    // (the sixteen lanes' side by side: 128 bytes).
-    const uint64_t lanes = words_per_block / 8;
-    v4u* out = reinterpret_cast<v4u*>(words) + static_cast<uint64_t>(first_block) * 4 * lanes + (lane_first >> 3);   // pair 0 of the item's first block
-    unsigned long long* plain = words + static_cast<uint64_t>(first_block) * words_per_block + lane_first;
-    auto store_words = [&]() {
-      uint32_t upper[8], lower[8];
+    // The groups swap pieces (lane l <-> l ^ 16, then l ^ 32): every lane of a column then holds all eight genomes' words.
+    uint32_t upper[8], lower[8];
+    auto join = [&]() {
 #pragma unroll
       for (int q = 0; q < 8; ++q) {
         const uint32_t beside = static_cast<uint32_t>(__shfl_xor(static_cast<int>(piece[q]), 16));
@@ -689,30 +684,78 @@ k_hall_mfma(const uint32_t* __restrict__ gt, uint64_t dwords_per_row, uint64_t g
         upper[q] = u < 2u ? half_word : other;
         lower[q] = u < 2u ? other : half_word;
       }
+    };
+    if constexpr (BITS) {
+      // The words lie [genome][block] -- all word_blocks kept blocks of all classes, a genome's side by side: what the search walks
+      // is a genome's words of a stretch of blocks (a word per cache line cost it the line).  Group u keeps the words of its
+      // lanes' genomes q = 2 u, 2 u + 1 over FOUR consecutive blocks -- a 32-byte sector of each genome's run (word_blocks is a
+      // multiple of four; word_phase: where the class's first block sits in its sector) -- and stores the sector whole; an item's
+      // first and last blocks that share a sector with another item's go word by word.  (Eight-byte stores alone: this pass 4 x
+      // as long -- every store a read-modify-write of its sector.)
+      const uint64_t g_a = lane_first + (2u * u) * kGenomeStride, g_b = g_a + kGenomeStride;
+      unsigned long long* const row_a = words + g_a * word_blocks + first_block;
+      unsigned long long* const row_b = words + g_b * word_blocks + first_block;
+      const bool has_a = g_a < n_genomes, has_b = g_b < n_genomes;
+      auto mine = [&](const uint32_t (&x)[8], int odd_one) {                  // x[2 u + odd_one]: u is the lane's, select
+        const uint32_t x01 = (u & 1u) ? x[2 + odd_one] : x[odd_one], x23 = (u & 1u) ? x[6 + odd_one] : x[4 + odd_one];
+        return u < 2u ? x01 : x23;
+      };
+      uint32_t b = 0;
+      while (b < n_blocks) {
+        const uint32_t slot0 = (word_phase + first_block + b) & 3u, begun = b;   // (the same for the whole workgroup)
+        uint32_t a_lo[4], a_hi[4], b_lo[4], b_hi[4];
 #pragma unroll
-      for (uint32_t pair = 0; pair < 4; ++pair) {                             // (a store per group: u is the lane's, an indexed register is a trip through scratch)
-        if constexpr (BITS) {
-          if (u == pair) {
-            if (lane_first + (2 * pair) * kGenomeStride < n_genomes)
-              plain[(2 * pair) * kGenomeStride] = (static_cast<unsigned long long>(upper[2 * pair]) << 32) | lower[2 * pair];
-            if (lane_first + (2 * pair + 1) * kGenomeStride < n_genomes)
-              plain[(2 * pair + 1) * kGenomeStride] = (static_cast<unsigned long long>(upper[2 * pair + 1]) << 32) | lower[2 * pair + 1];
+        for (uint32_t i = 0; i < 4; ++i) {
+          a_lo[i] = a_hi[i] = b_lo[i] = b_hi[i] = 0u;
+          if (i >= slot0 && b < n_blocks) {
+            load_block(b + 1u < n_blocks ? b + 1u : b, odd);
+            multiply_block(b, even);
+            join();
+            a_lo[i] = mine(lower, 0); a_hi[i] = mine(upper, 0); b_lo[i] = mine(lower, 1); b_hi[i] = mine(upper, 1);
+            even[0] = odd[0];
+            even[1] = odd[1];
+            ++b;
+          }
+        }
+        if (slot0 == 0u && b - begun == 4u) {
+          if (has_a) {
+            reinterpret_cast<v4u*>(row_a + begun)[0] = v4u{a_lo[0], a_hi[0], a_lo[1], a_hi[1]};
+            reinterpret_cast<v4u*>(row_a + begun)[1] = v4u{a_lo[2], a_hi[2], a_lo[3], a_hi[3]};
+          }
+          if (has_b) {
+            reinterpret_cast<v4u*>(row_b + begun)[0] = v4u{b_lo[0], b_hi[0], b_lo[1], b_hi[1]};
+            reinterpret_cast<v4u*>(row_b + begun)[1] = v4u{b_lo[2], b_hi[2], b_lo[3], b_hi[3]};
           }
         } else {
-          if (active && u == pair) out[static_cast<uint64_t>(pair) * lanes] = v4u{lower[2 * pair], upper[2 * pair], lower[2 * pair + 1], upper[2 * pair + 1]};
+#pragma unroll
+          for (uint32_t i = 0; i < 4; ++i) {
+            if (i >= slot0 && i - slot0 < b - begun) {
+              if (has_a) row_a[begun + i - slot0] = (static_cast<unsigned long long>(a_hi[i]) << 32) | a_lo[i];
+              if (has_b) row_b[begun + i - slot0] = (static_cast<unsigned long long>(b_hi[i]) << 32) | b_lo[i];
+            }
+          }
         }
       }
-      out += 4 * lanes;
-      plain += words_per_block;
-    };
-    for (uint32_t b = 0; b < n_blocks; b += 2) {
-      load_block(b + 1u < n_blocks ? b + 1u : b, odd);
-      multiply_block(b, even);
-      store_words();
-      load_block(b + 2u < n_blocks ? b + 2u : b, even);
-      if (b + 1u < n_blocks) {
-        multiply_block(b + 1u, odd);
+    } else {
+      // group u stores pair u of hall_word_index's layout (genomes 2 u, 2 u + 1: 16 bytes)
+      const uint64_t lanes = words_per_block / 8;
+      v4u* out = reinterpret_cast<v4u*>(words) + static_cast<uint64_t>(first_block) * 4 * lanes + (lane_first >> 3);   // pair 0 of the item's first block
+      auto store_words = [&]() {
+        join();
+#pragma unroll
+        for (uint32_t pair = 0; pair < 4; ++pair)                             // (a store per group: u is the lane's, an indexed register is a trip through scratch)
+          if (active && u == pair) out[static_cast<uint64_t>(pair) * lanes] = v4u{lower[2 * pair], upper[2 * pair], lower[2 * pair + 1], upper[2 * pair + 1]};
+        out += 4 * lanes;
+      };
+      for (uint32_t b = 0; b < n_blocks; b += 2) {
+        load_block(b + 1u < n_blocks ? b + 1u : b, odd);
+        multiply_block(b, even);
         store_words();
+        load_block(b + 2u < n_blocks ? b + 2u : b, even);
+        if (b + 1u < n_blocks) {
+          multiply_block(b + 1u, odd);
+          store_words();
+        }
       }
     }
   }

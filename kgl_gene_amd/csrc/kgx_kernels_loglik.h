@@ -49,7 +49,7 @@ struct LoglikClass {
   const uint32_t* bin_block;            // [kHallBins + 1]: the first block of each bin
   const unsigned long long* words;      // hall_word_index(block, genome): bit 63 - p = "homozygous at slot 64 * block + p"
 };
-struct LoglikClasses { LoglikClass of[kLoglikMaxClasses]; uint32_t n; uint32_t block_bins; uint32_t plain_words; };   // plain_words: [block][genome] (k_hall_mfma from bit rows)
+struct LoglikClasses { LoglikClass of[kLoglikMaxClasses]; uint32_t n; uint32_t block_bins; uint32_t plain_words; uint64_t word_blocks; };   // plain_words: [genome][block of all classes, word_blocks of them] (k_hall_mfma from bit rows)
 
 // dynamic LDS of k_loglik_search for n_used bins
 inline size_t loglik_search_lds(uint32_t n_used) {
@@ -253,7 +253,7 @@ k_loglik_search(const double* __restrict__ bins, const uint32_t* __restrict__ us
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
               const bool in = b + q < b1;
-              word[q] = in ? cl.words[classes.plain_words ? static_cast<uint64_t>(b + q) * words_per_block + g : hall_word_index(b + q, g, lanes)] : 0ull;
+              word[q] = in ? cl.words[classes.plain_words ? g * classes.word_blocks + (b + q) : hall_word_index(b + q, g, lanes)] : 0ull;
               y[q] = cl.ys[static_cast<uint64_t>(in ? b + q : b0) * kHallBlockLoci + lane];
             }
 #pragma unroll
@@ -275,7 +275,7 @@ k_loglik_search(const double* __restrict__ bins, const uint32_t* __restrict__ us
 #pragma unroll
             for (int w = 0; w < kLoglikWordsPerThread; ++w) {
               const uint32_t b = base + static_cast<uint32_t>(w) * kBlock + threadIdx.x;
-              word[w] = b < b1 ? cl.words[classes.plain_words ? static_cast<uint64_t>(b) * words_per_block + g : hall_word_index(b, g, lanes)] : 0ull;
+              word[w] = b < b1 ? cl.words[classes.plain_words ? g * classes.word_blocks + b : hall_word_index(b, g, lanes)] : 0ull;
             }
 #pragma unroll
             for (int w = 0; w < kLoglikWordsPerThread; ++w) mine += static_cast<uint32_t>(__popcll(word[w]));
