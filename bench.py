@@ -354,16 +354,20 @@ def aux_inbreeding(args, capi, torch, dev, cpu):
         return float(np.median(walls)), len(walls), res, parts
 
     def moments_roofline(ms, parts, kernel):
-        # The unique bytes of the call are ONE read of the matrix (sweep_bytes); the call's passes re-read it (the frequency sweep,
-        # then one pass per class of homozygous cell over the loci that have the class): `achieved` prices the whole call at
-        # its unique bytes, `class_passes_GBps` the class passes at the bytes they do read (a full matrix each for the major
-        # class and alt 1; alt 2 and 3 at the share of loci that have them, from the table).
+        # The unique bytes of the call are ONE read of the matrix (sweep_bytes).  The call reads it twice: the frequency sweep, then
+        # the one pass that leaves every class's hits as bit rows (k_class_bits: a bit per cell of the loci that have the class --
+        # all of them for the major class and alt 1, alt 2 and 3 at the share of loci that have them, from the table), which the
+        # matrix-core pass reads back.  `achieved` prices the whole call at its unique bytes; `class_passes_GBps` the class passes
+        # (bits pass + moment passes + merges) at the bytes they must move: the matrix once, the bit rows out and in.
         has_alt = np.isfinite(table).mean(axis=0)
-        class_bytes = float(G) * L * (1.0 + float(has_alt.sum()))
+        cover = 1.0 + float(has_alt.sum())                                   # class rows per locus, on average
+        bit_bytes = float(G) * L * cover / 8.0
+        class_bytes = float(G) * L + 2.0 * bit_bytes
         return {"bound": "hbm", "kernel": kernel, "achieved": sweep_bytes / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": sweep_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None, "algorithmic_bytes_per_launch": sweep_bytes,
                 "what": "the whole call priced at ONE read of the matrix (its unique bytes)",
-                "matrix_reads_per_call": 1.0 + class_bytes / (float(G) * L),
+                "matrix_reads_per_call": 2.0, "bit_rows_bytes": bit_bytes, "class_rows_per_locus": cover,
+                "class_passes_bytes": class_bytes,
                 "class_passes_GBps": class_bytes / (parts["class_passes_ms"] * 1e-3) / 1e9 if parts["class_passes_ms"] > 0 else None,
                 "class_passes_frac": class_bytes / (parts["class_passes_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS if parts["class_passes_ms"] > 0 else None,
                 "device_ms": parts}
@@ -373,9 +377,9 @@ def aux_inbreeding(args, capi, torch, dev, cpu):
         "metric": "genomes·loci/sec (inbreeding sweep + HallME)", "value": G * L / (hall_ms * 1e-3), "unit": "genomes·loci/s",
         "ms_per_call": hall_ms, "calls": hall_calls,
         "config": {"workload": label, "algorithm": "HallME", "start_points": f"kgx_inbreed_reference_starts(seed {hall_seed})",
-                   "passes_over_the_bytes": f"1 frequency sweep + {classes} moment passes (classes of homozygous cell) instead of 1 + 50",
+                   "passes_over_the_bytes": f"1 frequency sweep + 1 pass that leaves the {classes} classes' hits as bit rows (moments from those by int8 MFMA) instead of 1 + 50",
                    "mean_F": float(hall["inbred_allele_sum"].mean())},
-        "roofline": moments_roofline(hall_ms, hall_parts, "k_hall_sweep<8, false> (the class passes), k_hall_iterate"),
+        "roofline": moments_roofline(hall_ms, hall_parts, "k_class_bits (the classes' hits as bit rows), k_hall_mfma<false, true> (moments on the matrix cores), k_hall_iterate"),
         "cpu_baseline": None,
     }
     # Loglikelihood, the reference's DEFAULT estimator (kga_analysis_inbreed_args.h:138), over the same population: the same
@@ -386,9 +390,9 @@ def aux_inbreeding(args, capi, torch, dev, cpu):
         "metric": "genomes·loci/sec (inbreeding sweep + Loglikelihood)", "value": G * L / (ll_ms * 1e-3), "unit": "genomes·loci/s",
         "ms_per_call": ll_ms, "calls": ll_calls, "evaluations": capi.inbreed_last_evaluations(),
         "config": {"workload": label, "algorithm": "Loglikelihood", "start_points": f"kgx_inbreed_reference_starts(seed {hall_seed})",
-                   "passes_over_the_bytes": f"1 frequency sweep + {classes} moment passes instead of 1 + ~38 (two evaluations each)",
+                   "passes_over_the_bytes": f"1 frequency sweep + 1 pass that leaves the {classes} classes' hits as bit rows instead of 1 + ~38 (two evaluations each)",
                    "mean_F": float(ll["inbred_allele_sum"].mean())},
-        "roofline": moments_roofline(ll_ms, ll_parts, "k_hall_sweep<8, true> (the class passes, leaving the hits' bits), k_loglik_search"),
+        "roofline": moments_roofline(ll_ms, ll_parts, "k_class_bits, k_hall_mfma<true, true> (moments, and the hits' words of the reachable bins), k_loglik_search"),
         "cpu_baseline": None,
     }
     if cpu:

@@ -588,7 +588,7 @@ int inbreed_shard(kgx_gt8_shard& sh, uint64_t g0, uint64_t g1, const uint32_t* l
 #define KGX_HALL_MFMA(EMIT, BITS)                                                                                                      \
   hipLaunchKernelGGL((k_hall_mfma<EMIT, BITS>), mfma_grid, dim3(kBlock), 0, st, gt32, dwords_per_row, g0, n, rows_of(k), bit_rows, bit_row_bytes, \
                      digits_of(k), items_of(k), h_counters + 4 * k, item_blocks_of(k), mfma_chunks, code, h_moments, block_bins,        \
-                     words_per_block, class_out, word_blocks, static_cast<uint32_t>(block_base_of_class & 3u))
+                     words_per_block, class_out, word_blocks, static_cast<uint32_t>(block_base_of_class & 7u))
           if (by_bits) { if (emit) KGX_HALL_MFMA(true, true); else KGX_HALL_MFMA(false, true); }
           else { if (emit) KGX_HALL_MFMA(true, false); else KGX_HALL_MFMA(false, false); }
 #undef KGX_HALL_MFMA

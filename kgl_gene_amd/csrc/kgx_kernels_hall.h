@@ -607,6 +607,25 @@ k_hall_mfma(const uint32_t* __restrict__ gt, uint64_t dwords_per_row, uint64_t g
         octet[m] = static_cast<uint32_t>(bytes[16 * (4 * m)]) | (static_cast<uint32_t>(bytes[16 * (4 * m + 1)]) << 8) |
                    (static_cast<uint32_t>(bytes[16 * (4 * m + 2)]) << 16) | (static_cast<uint32_t>(bytes[16 * (4 * m + 3)]) << 24);
     }
+    if constexpr (EMIT && BITS) {
+      if (emit) {
+        // the pieces straight from the bits: 8 slots x 8 genomes are an 8 x 8 bit matrix (a byte a slot), transposed in three
+        // swaps (a byte a genome); the slots go in last first, so slot j lands at bit 7 - j of its genome's byte
+        auto transposed = [](uint32_t first_four, uint32_t next_four) {
+          unsigned long long x = (static_cast<unsigned long long>(__builtin_amdgcn_perm(0u, first_four, 0x00010203u)) << 32) |
+                                 __builtin_amdgcn_perm(0u, next_four, 0x00010203u);      // byte i = slot 7 - i
+          unsigned long long t;
+          t = (x ^ (x >> 7)) & 0x00AA00AA00AA00AAull; x = x ^ t ^ (t << 7);
+          t = (x ^ (x >> 14)) & 0x0000CCCC0000CCCCull; x = x ^ t ^ (t << 14);
+          t = (x ^ (x >> 28)) & 0x00000000F0F0F0F0ull; x = x ^ t ^ (t << 28);
+          return x;                                                           // byte q = genome q: bit 7 - j = slot j
+        };
+        const unsigned long long high = transposed(octet[0], octet[1]), low = transposed(octet[2], octet[3]);   // slots 0..7, 8..15
+#pragma unroll
+        for (int q = 0; q < 8; ++q)
+          piece[q] = ((static_cast<uint32_t>(high >> (8 * q)) & 0xFFu) << 8 | (static_cast<uint32_t>(low >> (8 * q)) & 0xFFu)) & inside;
+      }
+    }
 #pragma unroll
     for (int k = 0; k < 2; ++k) {                                             // the lane's genomes 0..3, then 4..7
       uint32_t t4[4][4];                                                      // [group of four loci][genome]: byte b = locus 4 m + b, 0x80 = a hit (-128: undone with the digit sums)
@@ -639,12 +658,12 @@ k_hall_mfma(const uint32_t* __restrict__ gt, uint64_t dwords_per_row, uint64_t g
         const v4i b = {static_cast<int>(t4[0][qq]), static_cast<int>(t4[1][qq]), static_cast<int>(t4[2][qq]), static_cast<int>(t4[3][qq])};
         acc[4 * k + qq][0] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a0, b, acc[4 * k + qq][0], 0, 0, 0);
         acc[4 * k + qq][1] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a1, b, acc[4 * k + qq][1], 0, 0, 0);
-        if constexpr (EMIT) {
+        if constexpr (EMIT && !BITS) {
           if (emit) {                                                         // bit 7 of byte b of dword m = slot 4 m + b: to bit 15 - (4 m + b)
             uint32_t bits = 0;
 #pragma unroll
             for (int m = 0; m < 4; ++m) {
-              const uint32_t four = ((t4[m][qq] >> (BITS ? 4 * k + qq : 7)) * 0x08040201u) >> 24;   // byte b's flag to bit 3 - b (the other products fall below bit 24 or past bit 31)
+              const uint32_t four = ((t4[m][qq] >> 7) * 0x08040201u) >> 24;   // byte b's flag to bit 3 - b (the other products fall below bit 24 or past bit 31)
               bits = (bits << 4) | (four & 0xFu);
             }
             piece[4 * k + qq] = bits & inside;
@@ -688,10 +707,10 @@ k_hall_mfma(const uint32_t* __restrict__ gt, uint64_t dwords_per_row, uint64_t g
     if constexpr (BITS) {
       // The words lie [genome][block] -- all word_blocks kept blocks of all classes, a genome's side by side: what the search walks
       // is a genome's words of a stretch of blocks (a word per cache line cost it the line).  Group u keeps the words of its
-      // lanes' genomes q = 2 u, 2 u + 1 over FOUR consecutive blocks -- a 32-byte sector of each genome's run (word_blocks is a
-      // multiple of four; word_phase: where the class's first block sits in its sector) -- and stores the sector whole; an item's
-      // first and last blocks that share a sector with another item's go word by word.  (Eight-byte stores alone: this pass 4 x
-      // as long -- every store a read-modify-write of its sector.)
+      // lanes' genomes q = 2 u, 2 u + 1 over EIGHT consecutive blocks -- 64 bytes of each genome's run (word_blocks is a multiple of
+      // sixteen; word_phase: where the class's first block sits in its 64 bytes) -- and stores them whole; an item's first and last
+      // blocks that share 64 bytes with another item's go word by word.  (Eight-byte stores alone: this pass 4 x as long -- every
+      // store a read-modify-write of its sector.)
       const uint64_t g_a = lane_first + (2u * u) * kGenomeStride, g_b = g_a + kGenomeStride;
       unsigned long long* const row_a = words + g_a * word_blocks + first_block;
       unsigned long long* const row_b = words + g_b * word_blocks + first_block;
@@ -700,12 +719,13 @@ k_hall_mfma(const uint32_t* __restrict__ gt, uint64_t dwords_per_row, uint64_t g
         const uint32_t x01 = (u & 1u) ? x[2 + odd_one] : x[odd_one], x23 = (u & 1u) ? x[6 + odd_one] : x[4 + odd_one];
         return u < 2u ? x01 : x23;
       };
+      constexpr uint32_t kRun = 8;                                              // blocks a lane keeps before it stores: 64 bytes of a genome's run
       uint32_t b = 0;
       while (b < n_blocks) {
-        const uint32_t slot0 = (word_phase + first_block + b) & 3u, begun = b;   // (the same for the whole workgroup)
-        uint32_t a_lo[4], a_hi[4], b_lo[4], b_hi[4];
+        const uint32_t slot0 = (word_phase + first_block + b) & (kRun - 1u), begun = b;   // (the same for the whole workgroup)
+        uint32_t a_lo[kRun], a_hi[kRun], b_lo[kRun], b_hi[kRun];
 #pragma unroll
-        for (uint32_t i = 0; i < 4; ++i) {
+        for (uint32_t i = 0; i < kRun; ++i) {
           a_lo[i] = a_hi[i] = b_lo[i] = b_hi[i] = 0u;
           if (i >= slot0 && b < n_blocks) {
             load_block(b + 1u < n_blocks ? b + 1u : b, odd);
@@ -717,18 +737,15 @@ k_hall_mfma(const uint32_t* __restrict__ gt, uint64_t dwords_per_row, uint64_t g
             ++b;
           }
         }
-        if (slot0 == 0u && b - begun == 4u) {
-          if (has_a) {
-            reinterpret_cast<v4u*>(row_a + begun)[0] = v4u{a_lo[0], a_hi[0], a_lo[1], a_hi[1]};
-            reinterpret_cast<v4u*>(row_a + begun)[1] = v4u{a_lo[2], a_hi[2], a_lo[3], a_hi[3]};
-          }
-          if (has_b) {
-            reinterpret_cast<v4u*>(row_b + begun)[0] = v4u{b_lo[0], b_hi[0], b_lo[1], b_hi[1]};
-            reinterpret_cast<v4u*>(row_b + begun)[1] = v4u{b_lo[2], b_hi[2], b_lo[3], b_hi[3]};
+        if (slot0 == 0u && b - begun == kRun) {
+#pragma unroll
+          for (uint32_t i = 0; i < kRun; i += 2) {
+            if (has_a) reinterpret_cast<v4u*>(row_a + begun)[i / 2] = v4u{a_lo[i], a_hi[i], a_lo[i + 1], a_hi[i + 1]};
+            if (has_b) reinterpret_cast<v4u*>(row_b + begun)[i / 2] = v4u{b_lo[i], b_hi[i], b_lo[i + 1], b_hi[i + 1]};
           }
         } else {
 #pragma unroll
-          for (uint32_t i = 0; i < 4; ++i) {
+          for (uint32_t i = 0; i < kRun; ++i) {
             if (i >= slot0 && i - slot0 < b - begun) {
               if (has_a) row_a[begun + i - slot0] = (static_cast<unsigned long long>(a_hi[i]) << 32) | a_lo[i];
               if (has_b) row_b[begun + i - slot0] = (static_cast<unsigned long long>(b_hi[i]) << 32) | b_lo[i];
