@@ -804,6 +804,42 @@ def test_loglikelihood_by_moments_is_the_passes(kgx, monkeypatch):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("flavour", ["KGX_K7_CLASS_BYTES", "KGX_K7_CLASS_SWEEPS"])
+def test_class_pass_flavours_agree(kgx, monkeypatch, flavour):
+    """The moments' three ways to the same numbers: the shipped one -- ONE pass over the bytes that leaves every class's hits
+    as bit rows (k_class_bits), the moments from those on the matrix cores in exact fixed point (k_hall_mfma<., true>) -- against
+    a pass over the bytes per class on the matrix cores (KGX_K7_CLASS_BYTES=1) and against the vector sweeps with their fp64 adds
+    (KGX_K7_CLASS_SWEEPS=1, round 3's): HallME within 1e-10, Loglikelihood to the bit for almost every genome (the hits' words
+    are the same bits, the moments differ in their last places), counts bit for bit.  Genome ranges that end inside a span of
+    2048 and inside a lane of eight, that begin off 0, a locus index."""
+    G, L = 2600, 30_000
+    m = kgx.GenotypeMatrix(G, L)
+    table = m.synth_multiallelic(1111, 0, 0)
+    rng = np.random.default_rng(17)
+    index = np.sort(rng.choice(L, 19_003, replace=False)).astype(np.uint32)
+    for algorithm, path in (("HallME", "hall moments"), ("Loglikelihood", "loglik moments")):
+        for sel, g0, g1 in ((None, 0, G), (index, 8, 2555), (index, 2048, 2600)):
+            sub = table if sel is None else np.ascontiguousarray(table[sel])
+            start = kgx.reference_starts(algorithm, START_SEED, g1 - g0)
+            shipped = {k: v.copy() for k, v in _fields(m.inbreed(sub, algorithm, phased=True, locus_index=sel, g0=g0, g1=g1, start=start)).items()}
+            assert kgx.inbreed_last_path() == path, kgx.inbreed_last_path()
+            monkeypatch.setenv(flavour, "1")
+            other = _fields(m.inbreed(sub, algorithm, phased=True, locus_index=sel, g0=g0, g1=g1, start=start))
+            assert kgx.inbreed_last_path() == path, kgx.inbreed_last_path()
+            monkeypatch.delenv(flavour)
+            ctx = (algorithm, None if sel is None else len(sel), g0, g1)
+            for name in shipped:
+                if name != "inbred_allele_sum":
+                    assert np.array_equal(shipped[name], other[name]), ctx + (name,)
+            d = np.abs(shipped["inbred_allele_sum"] - other["inbred_allele_sum"])
+            if algorithm == "HallME":
+                assert d.max() <= 1e-10, ctx + (float(d.max()),)
+            else:
+                assert d.max() <= 2e-6 and (d == 0).sum() >= 0.995 * (g1 - g0), ctx + (float(d.max()), int((d == 0).sum()))
+    m.close()
+
+
+@pytest.mark.gpu
 def test_loglikelihood_by_moments_hands_over_what_it_cannot_serve(kgx, monkeypatch):
     """What the statistics cannot give goes to the passes, and comes back with the passes' result: (a) a genome with a
     heterozygous cell whose 2*f1*f2 exceeds 1/2 -- two copies of an allele more frequent than 1/2 on one phase, byte
