@@ -586,7 +586,7 @@ int inbreed_shard(kgx_gt8_shard& sh, uint64_t g0, uint64_t g1, const uint32_t* l
           const dim3 mfma_grid(class_items[k] * mfma_chunks);
           const uint8_t* bit_rows = by_bits ? reinterpret_cast<const uint8_t*>(dev.bits) + class_rows.base[k] * bit_row_bytes : nullptr;
 #define KGX_HALL_MFMA(EMIT, BITS)                                                                                                      \
-  hipLaunchKernelGGL((k_hall_mfma<EMIT, BITS>), mfma_grid, dim3(kBlock), 0, st, gt32, dwords_per_row, g0, n, rows_of(k), bit_rows, bit_row_bytes, \
+  hipLaunchKernelGGL((k_hall_mfma<EMIT, BITS>), mfma_grid, dim3(BITS ? 2 * kBlock : kBlock), 0, st, gt32, dwords_per_row, g0, n, rows_of(k), bit_rows, bit_row_bytes, \
                      digits_of(k), items_of(k), h_counters + 4 * k, item_blocks_of(k), mfma_chunks, code, h_moments, block_bins,        \
                      words_per_block, class_out, word_blocks, static_cast<uint32_t>(block_base_of_class & 7u))
           if (by_bits) { if (emit) KGX_HALL_MFMA(true, true); else KGX_HALL_MFMA(false, true); }
@@ -602,6 +602,7 @@ int inbreed_shard(kgx_gt8_shard& sh, uint64_t g0, uint64_t g1, const uint32_t* l
       loglik_classes.block_bins = block_bins;
       loglik_classes.plain_words = (by_bits && hall_mfma) ? 1u : 0u;
       loglik_classes.word_blocks = word_blocks;
+      loglik_classes.dense = env_int("KGX_K7_LL_DENSE_PER_1024", 0) > 0 ? env_int("KGX_K7_LL_DENSE_PER_1024", 0) / 1024.0 : kLoglikDense;
       try_hip(hipEventRecord(dev.moments_end, st), KGX_EHIP, "hipEventRecord");
       moments_timed = true;
       hipLaunchKernelGGL(k_hall_used_bins, dim3(1), dim3(kBlock), 0, st, h_bin_used, h_used, h_totals);

@@ -512,13 +512,13 @@ k_hall_digits(const HallRecord* __restrict__ padded, const HallItem* __restrict_
   }
 }
 
-// grid: x = item * n_chunks + chunk of 512 genomes, BITS: 1024 (a wave: 128 at a time, a lane: eight at 16 of the block's 64 slots).
+// grid: x = item * n_chunks + chunk of 512 genomes, BITS: 1024 and 512 threads (a wave: 128, a lane: eight at 16 of the block's 64 slots).
 // moments as k_hall_sweep's.  EMIT as there: the items of the bins below block_bins leave the hits as bits.
 // BITS: the hits come from k_class_bits' rows (bit_rows: the class's first row) instead of the bytes: a lane loads 16 bytes
 // (128 genomes) of ONE slot, the wave's 64 slots go through LDS, and lane (c, u) takes back byte c of its 16 slots -- bit q
 // of byte j is the lane's genome q (hall_bits_genome) at slot 16 u + j: a shift and a mask per product and dword.
 template <bool EMIT, bool BITS>
-__global__ void __launch_bounds__(kBlock)
+__global__ void __launch_bounds__(BITS ? 2 * kBlock : kBlock)
 k_hall_mfma(const uint32_t* __restrict__ gt, uint64_t dwords_per_row, uint64_t g0, uint64_t n_genomes, const uint32_t* __restrict__ slot_rows,
             const uint8_t* __restrict__ bit_rows, uint64_t row_bytes, const int8_t* __restrict__ digits, const HallItem* __restrict__ items,
             const uint32_t* __restrict__ n_items, const uint32_t* __restrict__ item_block_base, uint32_t n_chunks, uint32_t code,
@@ -527,7 +527,7 @@ k_hall_mfma(const uint32_t* __restrict__ gt, uint64_t dwords_per_row, uint64_t g
   typedef uint32_t v2u __attribute__((ext_vector_type(2)));
   typedef uint32_t v4u __attribute__((ext_vector_type(4)));
   constexpr uint32_t kItemBlocks = kHallItemLoci / kHallBlockLoci;
-  constexpr uint32_t kWaves = kBlock / kWave;
+  constexpr uint32_t kWaves = (BITS ? 2 * kBlock : kBlock) / kWave;           // BITS: eight waves, a tile each -- 128 bytes of every row the workgroup reads: whole lines, read once
   __shared__ v4i lds_digits[kItemBlocks * 128];                              // 32 KB: the item's A operands, in lane order
   __shared__ uint32_t lds_rows[BITS ? 1 : kHallItemLoci];
   __shared__ v4u lds_bits[BITS ? kWaves * 2 * kWave : 1];                    // BITS: per wave two blocks' rows of 16 bytes
@@ -545,9 +545,9 @@ k_hall_mfma(const uint32_t* __restrict__ gt, uint64_t dwords_per_row, uint64_t g
   }
   __syncthreads();
   const uint32_t wave = threadIdx.x / kWave, lane = threadIdx.x % kWave, c = lane & 15u, u = lane >> 4;
-  // BITS: a wave takes two tiles of 128 genomes, one after the other -- the workgroup's eight tiles are 128 bytes of every
-  // row it reads, whole lines (the rows are padded to them), read while they are still in the cache
-  constexpr uint32_t kTiles = BITS ? 2 : 1;
+  // (two tiles a wave, one after the other, read every line twice: the second visit came after the item's other rows had passed
+  // through the L2 -- 13.2 GB fetched for 6.4 GB of rows)
+  constexpr uint32_t kTiles = 1;
 #pragma nounroll
   for (uint32_t tile = 0; tile < kTiles; ++tile) {
   // the wave's 128 genomes: 8 c + q of a run of 128, or (BITS) the genomes of 16 bytes of the bit rows (hall_bits_genome)

@@ -40,7 +40,10 @@ constexpr int kLoglikMaxClasses = 15;                        // byte 0x00 and a 
 constexpr uint32_t kLoglikListCells = 2560;                  // a genome's cells of a band (or of a stretch of it), gathered in LDS: their frequencies (20 KB:
                                                              // with ~50 KB of moments two workgroups still share a CU's 160 KB)
 constexpr int kLoglikWordsPerThread = 4;                     // blocks a thread looks at per round of the sparse walk: 1024 blocks a round
-constexpr double kLoglikDense = 1.0 / 32.0;                  // from this share of a band's slots set, the band is walked slot by slot
+// from this share of a band's slots set, the band is walked slot by slot (every slot's frequency: 520 bytes a block and genome) instead of
+// listing its set bits (a word a block, a frequency a cell).  Measured at C5, search kernel: 1/32 18.4 ms (58.6 GB fetched), 1/16 15.5,
+// 1/8 13.4, 1/4 12.4, 1/2 12.4 (KGX_K7_LL_DENSE_PER_1024 sets it per 1024)
+constexpr double kLoglikDense = 1.0 / 4.0;
 constexpr double kLogSmallProb = -23.025850929940457;        // log(1e-10)
 constexpr int kLoglikBinValues = 6;                          // per bin in LDS: M0, M1, M2/2, M3/3, M4/4, the series of sum(log y / c)
 
@@ -49,7 +52,7 @@ struct LoglikClass {
   const uint32_t* bin_block;            // [kHallBins + 1]: the first block of each bin
   const unsigned long long* words;      // hall_word_index(block, genome): bit 63 - p = "homozygous at slot 64 * block + p"
 };
-struct LoglikClasses { LoglikClass of[kLoglikMaxClasses]; uint32_t n; uint32_t block_bins; uint32_t plain_words; uint64_t word_blocks; };   // plain_words: [genome][block of all classes, word_blocks of them] (k_hall_mfma from bit rows)
+struct LoglikClasses { LoglikClass of[kLoglikMaxClasses]; uint32_t n; uint32_t block_bins; uint32_t plain_words; uint64_t word_blocks; double dense; };   // plain_words: [genome][block of all classes, word_blocks of them] (k_hall_mfma from bit rows)
 
 // dynamic LDS of k_loglik_search for n_used bins
 inline size_t loglik_search_lds(uint32_t n_used) {
@@ -221,7 +224,7 @@ k_loglik_search(const double* __restrict__ bins, const uint32_t* __restrict__ us
       uint32_t band_blocks = 0;
       if (!kept_covers)
         for (uint32_t k = 0; k < classes.n; ++k) band_blocks += classes.of[k].bin_block[to] - classes.of[k].bin_block[from];
-      const bool dense = !kept_covers && !keep && band_cells >= kLoglikDense * static_cast<double>(band_blocks) * kHallBlockLoci;
+      const bool dense = !kept_covers && !keep && band_cells >= classes.dense * static_cast<double>(band_blocks) * kHallBlockLoci;
       auto walk_listed = [&](uint32_t n_listed) {                                          // the list's cells that lie in the band
         for (uint32_t i0 = 0; i0 < n_listed; i0 += 8 * kBlock) {
 #pragma unroll

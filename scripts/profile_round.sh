@@ -29,13 +29,13 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/hall_trace -- pytho
 echo "hall trace done" >> $OUT/progress.txt
 cat $OUT/hall.txt
 # Loglikelihood over a large call on the same moments (kgx_kernels_loglik.h) against the passes, C5; then the moments alone under the
-# traffic and SQ counters (the class passes that leave the hits' bits, the search)
+# traffic and SQ counters (the pass that leaves the classes' hits as bit rows, the matrix-core moment passes, the search)
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/loglik_trace -- python3 $REPO/scripts/bench_loglik.py > $OUT/loglik.txt 2> $OUT/loglik.err
 echo "loglik trace done" >> $OUT/progress.txt
 cat $OUT/loglik.txt
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/loglik_fetch -- python3 $REPO/scripts/bench_loglik.py --moments-only > $OUT/loglik_fetch.txt 2> $OUT/loglik_fetch.err
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/loglik_write -- python3 $REPO/scripts/bench_loglik.py --moments-only > $OUT/loglik_write.txt 2> $OUT/loglik_write.err
-rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT --kernel-trace --output-format csv -d $OUT/loglik_sq -- python3 $REPO/scripts/bench_loglik.py --moments-only > $OUT/loglik_sq.txt 2> $OUT/loglik_sq.err
+rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_LDS SQ_INSTS_MFMA --kernel-trace --output-format csv -d $OUT/loglik_sq -- python3 $REPO/scripts/bench_loglik.py --moments-only > $OUT/loglik_sq.txt 2> $OUT/loglik_sq.err
 echo "loglik counters done" >> $OUT/progress.txt
 # the batched window regime: one kgx_inbreed_batch of 16 windows x 2504 genomes per launch pair
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/batch_trace -- python3 $REPO/scripts/bench_inbreed_batch.py > $OUT/batch.txt 2> $OUT/batch.err

@@ -73,22 +73,24 @@ for label, needle, roof, workload in kernels:
     traffic_db[f"{label}:{workload}"] = {"kernel": name, "hbm_bytes_per_launch": traffic, "read_bytes": read_b, "write_bytes": write_b,
                                          "algorithmic_bytes_per_launch": alg, "profile": f"profiles/{tag}_pmc.csv",
                                          "correction": "read = 2 x FETCH_SIZE x 1024 (gfx950 wide-stream correction), write = WRITE_SIZE x 1024"}
-# the moment passes of HallME in the same run (aux.c5_simple.hallme): the full classes (every locus) alone
-hall_f = [v for k, vs in fetch.items() if "k_hall_sweep" in k for v in vs]
-hall_w = [v for k, vs in write.items() if "k_hall_sweep" in k for v in vs]
+# the moments' pass over the bytes in the same run (aux.c5_simple.hallme / .loglikelihood): k_class_bits reads the matrix once and
+# leaves every class's hits as bit rows; (round 3's k_hall_sweep, if a run still holds it: its full classes alone)
 hall_note = []
-if hall_f and hall_w:
+for needle, what in (("k_class_bits", "the one pass that leaves every class's hits as bit rows"), ("k_hall_sweep", "HallME's moment pass, the two classes that cover every locus")):
+    hall_f = [v for k, vs in fetch.items() if needle in k for v in vs]
+    hall_w = [v for k, vs in write.items() if needle in k for v in vs]
+    if not (hall_f and hall_w):
+        continue
     hall_f = [v for v in hall_f if v > 0.9 * max(hall_f)]
     hall_w = [v for v in hall_w if v > 0.9 * max(hall_w)]
-    hall_name = max((k for k in stats if "k_hall_sweep" in k), key=lambda k: float(stats[k]["TotalDurationNs"]), default="k_hall_sweep")
-    pmc_rows += [f"{hall_name} (full classes),FETCH_SIZE,{len(hall_f)},{sum(hall_f) / len(hall_f)}",
-                 f"{hall_name} (full classes),WRITE_SIZE,{len(hall_w)},{sum(hall_w) / len(hall_w)}"]
+    hall_name = max((k for k in stats if needle in k), key=lambda k: float(stats[k]["TotalDurationNs"]), default=needle)
+    pmc_rows += [f"{hall_name},FETCH_SIZE,{len(hall_f)},{sum(hall_f) / len(hall_f)}", f"{hall_name},WRITE_SIZE,{len(hall_w)},{sum(hall_w) / len(hall_w)}"]
     c5 = aux.get("c5_simple", {}).get("roofline", {}).get("algorithmic_bytes_per_launch")
     if c5:
-        hall_note = ["", f"`{hall_name}` (HallME's moment pass, the two classes that cover every locus): HBM read 2 x FETCH_SIZE x 1024 = "
-                         f"{2.0 * sum(hall_f) / len(hall_f) * 1024.0:,.0f} B, write {sum(hall_w) / len(hall_w) * 1024.0:,.0f} B (the items' moments) "
-                         f"against {c5:,} algorithmic bytes of genotype rows: "
-                         f"{(2.0 * sum(hall_f) / len(hall_f) + sum(hall_w) / len(hall_w)) * 1024.0 / c5:.3f} x."]
+        hall_note += ["", f"`{hall_name}` ({what}): HBM read 2 x FETCH_SIZE x 1024 = {2.0 * sum(hall_f) / len(hall_f) * 1024.0:,.0f} B, "
+                          f"write {sum(hall_w) / len(hall_w) * 1024.0:,.0f} B against {c5:,} algorithmic bytes of genotype rows: "
+                          f"{(2.0 * sum(hall_f) / len(hall_f) + sum(hall_w) / len(hall_w)) * 1024.0 / c5:.3f} x; "
+                          f"{float(stats[hall_name]['AverageNs']) / 1e6:.3f} ms a launch."]
 (dst / f"{tag}_pmc.csv").write_text("\n".join(pmc_rows) + "\n")
 traffic_db_path.write_text(json.dumps(traffic_db, indent=1) + "\n")
 lines += hall_note
@@ -109,11 +111,12 @@ lines += ["## The table passes at C5 (10 k genomes x 5 M loci, 50.12 GB algorith
           "| kernel | calls | avg ms | TB/s at 50.12 GB | VALU wave-instr / launch | VALU per cell (x64 lanes / 5e10 cells) | SALU / launch | LDS instr / launch | LDS bank-conflict cycles | wait-inst / wave cycles |",
           "|---|---|---|---|---|---|---|---|---|---|"]
 for name in sorted(k7, key=lambda k: -float(k7[k]["TotalDurationNs"])):
-    if "k_inbreed_eval_lut" not in name and "swar" not in name and "k_hall_sweep" not in name:
+    moment_pass = any(k in name for k in ("k_hall_sweep", "k_class_bits", "k_hall_mfma"))
+    if "k_inbreed_eval_lut" not in name and "swar" not in name and not moment_pass:
         continue
     avg_ms = float(k7[name]["AverageNs"]) / 1e6
     c = {k: sum(v) / len(v) for k, v in sq.get(name, {}).items()}
-    if "k_hall_sweep" in name:
+    if moment_pass:
         # HallME's moment passes: the classes that cover every locus alone (the largest launches), not the average over all four
         full = {k: [x for x in v if x >= 0.9 * max(v)] for k, v in sq.get(name, {}).items() if v}
         c = {k: sum(v) / len(v) for k, v in full.items()}
@@ -146,11 +149,12 @@ if hall_files:
     hall_stats = Path(max(hall_files, key=lambda f: Path(f).stat().st_mtime))
     (dst / f"{tag}_hall_kernel_stats.csv").write_text(hall_stats.read_text())
     lines += ["## HallME at C5 on per-genome moments (`scripts/bench_hall.py`: 4 calls by moments, then 4 by the 50 passes)", "",
-              "`rocprofv3 --kernel-trace --stats -- python3 scripts/bench_hall.py`; `k_hall_sweep` runs once per class of homozygous cell "
-              "(4 at C5: two over every locus, two over the loci that have a second / third alt), so its average is over unequal passes.", "",
+              "`rocprofv3 --kernel-trace --stats -- python3 scripts/bench_hall.py`; `k_class_bits` runs once a call (every class's hits as bit rows), "
+              "`k_hall_mfma` once per class of homozygous cell (4 at C5: two over every locus, two over the loci that have a second / third alt), "
+              "so its average is over unequal passes.", "",
               "| kernel | calls | avg ms |", "|---|---|---|"]
     for r in csv.DictReader(hall_stats.open()):
-        if "k_hall" in r["Name"] or "rocprim" in r["Name"] or "eval_lut<1" in r["Name"]:
+        if "k_hall" in r["Name"] or "k_class_bits" in r["Name"] or "rocprim" in r["Name"] or "eval_lut<1" in r["Name"]:
             lines.append(f"| `{short(r['Name'])[:90]}` | {r['Calls']} | {float(r['AverageNs']) / 1e6:.3f} |")
     lines += ["", "```"] + [l for l in (src / "hall.txt").read_text().strip().splitlines() if "amdgpu.ids" not in l] + ["```", ""]
 # ---- Loglikelihood over a large call: the moments + the exact walk against the passes; traffic and SQ counters of its kernels
@@ -159,11 +163,11 @@ if ll_files:
     ll_stats = Path(max(ll_files, key=lambda f: Path(f).stat().st_mtime))
     (dst / f"{tag}_loglik_kernel_stats.csv").write_text(ll_stats.read_text())
     lines += ["## Loglikelihood at C5 on per-genome moments (`scripts/bench_loglik.py`: 4 calls by moments, then 4 by the passes)", "",
-              "`rocprofv3 --kernel-trace --stats -- python3 scripts/bench_loglik.py`; `k_hall_sweep<8, true>` runs once per class of homozygous cell and leaves "
-              "the hits' bits for the bins a band can reach; `k_loglik_search` is the whole search of every genome.", "",
+              "`rocprofv3 --kernel-trace --stats -- python3 scripts/bench_loglik.py`; `k_class_bits` once a call, `k_hall_mfma<true, true>` once per class of "
+              "homozygous cell -- the moments, and the hits' words of the bins a band can reach; `k_loglik_search` is the whole search of every genome.", "",
               "| kernel | calls | avg ms |", "|---|---|---|"]
     for r in csv.DictReader(ll_stats.open()):
-        if any(k in r["Name"] for k in ("k_hall", "k_loglik", "rocprim", "eval_lut<2", "eval_lut<3", "k_eval_entries<5", "k_gather_columns")):
+        if any(k in r["Name"] for k in ("k_hall", "k_class_bits", "k_loglik", "rocprim", "eval_lut<2", "eval_lut<3", "k_eval_entries<5", "k_gather_columns")):
             lines.append(f"| `{short(r['Name'])[:90]}` | {r['Calls']} | {float(r['AverageNs']) / 1e6:.3f} |")
     lines += ["", "```"] + [l for l in (src / "loglik.txt").read_text().strip().splitlines() if "amdgpu.ids" not in l] + ["```", ""]
     try:
@@ -172,10 +176,10 @@ if ll_files:
         for r in csv.DictReader(one("loglik_sq/*/*counter_collection.csv").open()):
             ll_sq[short(r["Kernel_Name"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
         lines += ["Counters of the same calls (`--moments-only`; per launch, means; the class passes: the two that cover every locus alone):", "",
-                  "| kernel | HBM read = 2 x FETCH_SIZE x 1024 | HBM write = WRITE_SIZE x 1024 | VALU wave-instr | VALU per cell (x64 / 5e10) | LDS instr | wait-inst / wave cycles |",
-                  "|---|---|---|---|---|---|---|"]
+                  "| kernel | HBM read = 2 x FETCH_SIZE x 1024 | HBM write = WRITE_SIZE x 1024 | VALU wave-instr | VALU per cell (x64 / 5e10) | MFMA instr | LDS instr | wait-inst / wave cycles |",
+                  "|---|---|---|---|---|---|---|---|"]
         rows_pmc = []
-        for needle, full in (("k_hall_sweep<8, true>", True), ("k_loglik_search", False), ("k_inbreed_eval_lut<3", False)):
+        for needle, full in (("k_class_bits", False), ("k_hall_mfma<true, true>", True), ("k_hall_sweep<8, true>", True), ("k_loglik_search", False), ("k_inbreed_eval_lut<3", False)):
             name = next((k for k in ll_sq if needle in k), None)
             if not name:
                 continue
@@ -185,7 +189,7 @@ if ll_files:
             c = {k: (lambda v: sum(v) / len(v))(pick(v)) for k, v in ll_sq[name].items() if v}
             valu = c.get("SQ_INSTS_VALU", float("nan"))
             lines.append(f"| `{name}` | {2.0 * sum(f) / len(f) * 1024.0:,.0f} | {sum(w) / len(w) * 1024.0:,.0f} | {valu:.4g} | {valu * 64 / cells:.2f} | "
-                         f"{c.get('SQ_INSTS_LDS', float('nan')):.4g} | {c.get('SQ_WAIT_INST_ANY', float('nan')) / c.get('SQ_WAVE_CYCLES', float('nan')):.2f} |")
+                         f"{c.get('SQ_INSTS_MFMA', float('nan')):.4g} | {c.get('SQ_INSTS_LDS', float('nan')):.4g} | {c.get('SQ_WAIT_INST_ANY', float('nan')) / c.get('SQ_WAVE_CYCLES', float('nan')):.2f} |")
             rows_pmc += [f"{name},FETCH_SIZE,{len(f)},{sum(f) / len(f)}", f"{name},WRITE_SIZE,{len(w)},{sum(w) / len(w)}"]
         with (dst / f"{tag}_pmc.csv").open("a") as fh:
             fh.write("\n".join(rows_pmc) + "\n")
