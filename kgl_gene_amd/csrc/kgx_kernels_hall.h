@@ -6,10 +6,13 @@
 //     1 / (F + u*(c + d)) = q * sum_j (-u*q*d)^j,   u = 1 - F,  q = 1 / (F + u*c),   |u*q*d| <= |d| / c .
 // So the y axis is cut into bins of relative half-width 2^-8 (the double's exponent and its top kHallKeyMantissa mantissa
 // bits; y = 0 has a bin of its own, d = 0), and per (genome, bin) the moments  M_j = sum over its cells of d^j,  j = 0..4,
-// are all a step needs: the truncation after j = 4 is below (2^-8)^5 = 9e-13 of a term, every term and every F.  The moments
-// cost ONE pass over the bytes per class of homozygous cell (byte 0x00: the major allele, y = p_major; byte a | a << 4 of a
-// phased population: alt a, y = its frequency), over the loci in bin order so that a workgroup's accumulators stay in
-// registers: 1 + amax passes instead of 50, and the 50 steps then run on ~10^3 numbers per genome (k_hall_iterate).
+// are all a step needs: the truncation after j = 4 is below (2^-8)^5 = 9e-13 of a term, every term and every F.  A cell
+// belongs to a CLASS of homozygous cell (byte 0x00: the major allele, y = p_major; byte a | a << 4 of a phased population:
+// alt a, y = its frequency); per class the loci are put in bin order, and the moments cost ONE more pass over the bytes --
+// every class's hits left as rows of bits (k_class_bits) -- and a pass over those rows per class on the matrix cores
+// (k_hall_mfma: the moments are an exact integer product of the hits and the powers' fixed-point digits); the 50 steps then
+// run on ~10^3 numbers per genome (k_hall_iterate).  Kept beside it as checkers: a pass over the bytes per class on the matrix
+// cores (KGX_K7_CLASS_BYTES=1) and the vector sweeps of round 3 (k_hall_sweep, KGX_K7_CLASS_SWEEPS=1).
 //
 // Deterministic by construction: the loci of a class are radix-sorted by bin (stable), a bin's stretch is cut into
 // items of at most kHallItemLoci loci, an item's moments go to its own slot, a bin's slots are added in slot order
@@ -366,9 +369,8 @@ k_hall_sweep(const uint32_t* __restrict__ gt, uint64_t dwords_per_row, uint64_t 
 // ---- every class's hits as bits, in ONE pass over the bytes -------------------------------------------------------------------
 // A class pass reads the rows of the loci that have a cell of its class: 2.2 reads of the matrix over the classes of C5.  The
 // hits themselves are a bit a cell: ONE pass over the selected rows leaves them, for every class the locus has a cell of, as a
-// row of bits in the class's own slot order -- bits[(class_row_base[k] + slot) * row_bytes + genome / 8], bit genome % 8 -- and
-// the matrix-core pass below then reads an eighth of the bytes (k_hall_mfma<.., true>).  A lane: eight genomes (two dwords), a
-// zero-byte test on each dword xor the class's byte, the four flags of a dword gathered by one multiplication.
+// row of bits in the class's own slot order -- bits[(class_row_base[k] + slot) * row_bytes + ...], a bit a genome (spans, below) -- and
+// the matrix-core pass below then reads an eighth of the bytes (k_hall_mfma<.., true>).
 struct HallClassRows { uint64_t base[16]; };                               // where each class's rows begin (in rows)
 // A bit row is cut into SPANS of kBitsSpanGenomes genomes = 256 bytes: a wave of k_class_bits takes a span, lane l its dwords
 // l, l + 64, .. l + 448 (eight coalesced loads a locus) -- genomes 4 (l + 64 d) + b for dword d, byte b -- and keeps the flag
@@ -817,7 +819,15 @@ k_hall_merge(const double* __restrict__ moments, const uint32_t* __restrict__ it
   const uint64_t per_bin = static_cast<uint64_t>(kHallMoments) * n_genomes;
   for (uint64_t e = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x; e < per_bin; e += static_cast<uint64_t>(gridDim.x) * blockDim.x) {
     double sum = fresh ? 0.0 : bins[bin * per_bin + e];
-    for (uint32_t t = first; t < last; ++t) sum += moments[t * per_bin + e];
+    uint32_t t = first;
+    for (; t + 8 <= last; t += 8) {                                           // eight loads under way, added in slot order
+      double v[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) v[i] = moments[(t + i) * per_bin + e];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) sum += v[i];
+    }
+    for (; t < last; ++t) sum += moments[t * per_bin + e];
     bins[bin * per_bin + e] = sum;
   }
 }
