@@ -139,10 +139,18 @@ k_hall_items(const uint32_t* __restrict__ bin_begin, const uint32_t* __restrict_
   __shared__ uint32_t thread_base[kBlock + 1];
   __shared__ uint32_t thread_blocks[kBlock + 1];
   __shared__ uint32_t thread_low_blocks[kBlock];
+  __shared__ uint32_t bin_item[kHallBins + 1], bin_block[kHallBins + 1];     // every bin's first item and first block
+  // item q of a bin of `loci` loci cut into n items takes [q * loci / n, (q + 1) * loci / n): its size is loci / n or one more, the
+  // first q items hold q * loci / n loci -- so the blocks of the first q items have a closed form (no walk over the items)
+  auto share_begin = [](uint32_t q, uint32_t n, uint32_t loci_of_bin) { return static_cast<uint32_t>(static_cast<uint64_t>(q) * loci_of_bin / n); };
+  auto blocks_before = [&](uint32_t q, uint32_t n, uint32_t loci_of_bin) {
+    if (n == 0u) return 0u;
+    const uint32_t small = loci_of_bin / n, bigger = share_begin(q, n, loci_of_bin) - q * small;   // of the first q items: those one locus longer
+    return (q - bigger) * ((small + kHallBlockLoci - 1) / kHallBlockLoci) + bigger * ((small + kHallBlockLoci) / kHallBlockLoci);
+  };
   const uint32_t first_bin = threadIdx.x * kHallBinsPerThread;
   uint32_t begin[kHallBinsPerThread], loci[kHallBinsPerThread], count[kHallBinsPerThread];
   uint32_t mine = 0, my_blocks = 0, my_low_blocks = 0;
-  auto share_begin = [](uint32_t q, uint32_t n, uint32_t loci_of_bin) { return static_cast<uint32_t>(static_cast<uint64_t>(q) * loci_of_bin / n); };
 #pragma unroll
   for (int i = 0; i < kHallBinsPerThread; ++i) {
     const uint32_t b = first_bin + i;
@@ -150,9 +158,7 @@ k_hall_items(const uint32_t* __restrict__ bin_begin, const uint32_t* __restrict_
     loci[i] = b < kHallBins ? bin_end[b] - begin[i] : 0u;
     count[i] = (loci[i] + kHallItemLoci - 1) / kHallItemLoci;
     mine += count[i];
-    uint32_t blocks = 0;
-    for (uint32_t q = 0; q < count[i]; ++q)
-      blocks += (share_begin(q + 1, count[i], loci[i]) - share_begin(q, count[i], loci[i]) + kHallBlockLoci - 1) / kHallBlockLoci;
+    const uint32_t blocks = blocks_before(count[i], count[i], loci[i]);
     my_blocks += blocks;
     if (b < block_bins) my_low_blocks += blocks;
   }
@@ -167,6 +173,7 @@ k_hall_items(const uint32_t* __restrict__ bin_begin, const uint32_t* __restrict_
     for (uint32_t t = 1; t <= kBlock; ++t) { thread_base[t] += thread_base[t - 1]; thread_blocks[t] += thread_blocks[t - 1]; low += thread_low_blocks[t - 1]; }
     *n_items = thread_base[kBlock];
     item_base[kHallBins] = thread_base[kBlock];
+    bin_item[kHallBins] = thread_base[kBlock];
     item_block_base[thread_base[kBlock]] = thread_blocks[kBlock];
     n_blocks[0] = thread_blocks[kBlock];
     n_blocks[1] = low;
@@ -178,19 +185,29 @@ k_hall_items(const uint32_t* __restrict__ bin_begin, const uint32_t* __restrict_
     const uint32_t b = first_bin + i;
     if (b >= kHallBins) break;
     item_base[b] = first;
-    const uint32_t n = count[i];
-    for (uint32_t q = 0; q < n; ++q) {
-      HallItem it;
-      // equal shares of the stretch (whole loci): item q takes [q * loci / n, (q + 1) * loci / n)
-      it.begin = begin[i] + share_begin(q, n, loci[i]);
-      it.end = begin[i] + share_begin(q + 1, n, loci[i]);
-      it.bin = b;
-      it.pad = 0u;
-      items[first + q] = it;
-      item_block_base[first + q] = block;
-      block += (it.end - it.begin + kHallBlockLoci - 1) / kHallBlockLoci;
+    bin_item[b] = first;
+    bin_block[b] = block;
+    first += count[i];
+    block += blocks_before(count[i], count[i], loci[i]);
+  }
+  __syncthreads();
+  // the items themselves, a thread an item: its bin by bisection over the bins' first items
+  const uint32_t total = bin_item[kHallBins];
+  for (uint32_t e = threadIdx.x; e < total; e += kBlock) {
+    uint32_t lo = 0, hi = kHallBins;                                          // bin_item[lo] <= e < bin_item[hi]: ends at the bin that holds item e
+    while (hi - lo > 1u) {
+      const uint32_t mid = (lo + hi) / 2;
+      if (bin_item[mid] <= e) lo = mid; else hi = mid;
     }
-    first += n;
+    const uint32_t b = lo, q = e - bin_item[b];
+    const uint32_t bin_first = bin_begin[b], bin_loci = bin_end[b] - bin_first, n = (bin_loci + kHallItemLoci - 1) / kHallItemLoci;
+    HallItem it;
+    it.begin = bin_first + share_begin(q, n, bin_loci);
+    it.end = bin_first + share_begin(q + 1, n, bin_loci);
+    it.bin = b;
+    it.pad = 0u;
+    items[e] = it;
+    item_block_base[e] = bin_block[b] + blocks_before(q, n, bin_loci);
   }
 }
 
@@ -474,42 +491,44 @@ constexpr int kHallDigitBits = 54;                                         // |V
 __global__ void __launch_bounds__(kBlock)
 k_hall_digits(const HallRecord* __restrict__ padded, const HallItem* __restrict__ items, const uint32_t* __restrict__ n_items,
               const uint32_t* __restrict__ item_block_base, int8_t* __restrict__ digits, uint32_t* __restrict__ slot_rows) {
+  typedef uint32_t v4u __attribute__((ext_vector_type(4)));
+  __shared__ v4u image[128];                                                 // a block's 2 KB, as it lies in memory
   const uint32_t n = *n_items;
+  const uint32_t slot_in_block = threadIdx.x & 63u, group = threadIdx.x >> 6;  // thread: a slot's power group + 1 (its seven digits; group 3: the ones too)
   for (uint32_t item = blockIdx.x; item < n; item += gridDim.x) {
     const HallItem it = items[item];
-    const uint32_t len = it.end - it.begin, first_block = item_block_base[item], slots = (item_block_base[item + 1] - first_block) * kHallBlockLoci;
+    const uint32_t len = it.end - it.begin, first_block = item_block_base[item], n_blocks = item_block_base[item + 1] - first_block;
     const uint64_t first = static_cast<uint64_t>(first_block) * kHallBlockLoci;
     const int exponent = it.bin == 0u ? 0 : static_cast<int>((it.bin - 1u) >> kHallKeyMantissa) + kHallMinExponent;
     const double to_t = __longlong_as_double(static_cast<long long>(static_cast<uint64_t>(1023 + 7 - exponent) << 52));   // 2^(7 - e)
     const double to_fixed = __longlong_as_double(static_cast<long long>(static_cast<uint64_t>(1023 + kHallDigitBits) << 52));
-    for (uint32_t t = threadIdx.x; t < slots; t += blockDim.x) slot_rows[first + t] = padded[first + t].row;
-    for (uint32_t t = threadIdx.x; t < slots * 2; t += blockDim.x) {          // 16 bytes each: (block, a, lane)
-      const uint32_t block = t >> 7, a = (t >> 6) & 1u, l = t & 63u, u = l >> 4, row = l & 15u;
-      const uint32_t group = row >> 2, digit = 4u * a + (row & 3u);           // the column's moment (group + 1) and digit
-      const bool ones = digit == 7u && group == 3u;
-      uint32_t out[4] = {0u, 0u, 0u, 0u};
-      if (digit < 7u || ones) {
-        for (uint32_t p = 0; p < 16; ++p) {
-          const uint32_t slot = block * kHallBlockLoci + 16u * u + p;
-          if (slot >= len) break;
-          long long v = 1;
-          if (!ones) {
-            const double x = padded[first + slot].delta * to_t;               // exact: a power of two
-            const double x2 = x * x;
-            const double power = group == 0u ? x : group == 1u ? x2 : group == 2u ? x2 * x : x2 * x2;
-            v = __double2ll_rn(power * to_fixed);
-            long long low = 0;
-            for (uint32_t q = 0; q <= digit; ++q) {                           // balanced digits: -128 .. 127
-              low = ((v + 128) & 255) - 128;
-              v = (v - low) >> 8;
-            }
-            v = low;
-          }
-          out[p >> 2] |= static_cast<uint32_t>(v & 255) << (8u * (p & 3u));
-        }
+    for (uint32_t t = threadIdx.x; t < n_blocks * kHallBlockLoci; t += blockDim.x) slot_rows[first + t] = padded[first + t].row;
+    for (uint32_t block = 0; block < n_blocks; ++block) {
+      const uint32_t slot = block * kHallBlockLoci + slot_in_block;
+      long long v = 0;
+      if (slot < len) {
+        const double x = padded[first + slot].delta * to_t;                   // exact: a power of two
+        const double x2 = x * x;
+        const double power = group == 0u ? x : group == 1u ? x2 : group == 2u ? x2 * x : x2 * x2;
+        v = __double2ll_rn(power * to_fixed);
       }
-      typedef uint32_t v4u __attribute__((ext_vector_type(4)));
-      reinterpret_cast<v4u*>(digits)[first * 2 + t] = v4u{out[0], out[1], out[2], out[3]};
+      // digit d of group g: operand a = d / 4, row 4 g + d % 4, lane = row + 16 (slot / 16), byte slot % 16
+      int8_t* bytes = reinterpret_cast<int8_t*>(image);
+      const uint32_t u = slot_in_block >> 4, j = slot_in_block & 15u;
+#pragma unroll
+      for (uint32_t d = 0; d < 8; ++d) {
+        long long low = 0;
+        if (d < 7u) {                                                         // balanced digits: -128 .. 127
+          low = ((v + 128) & 255) - 128;
+          v = (v - low) >> 8;
+        } else {
+          low = (group == 3u && slot < len) ? 1 : 0;                          // M0's column of ones
+        }
+        bytes[(((d >> 2) * 64u + (4u * group + (d & 3u)) + 16u * u) * 16u) + j] = static_cast<int8_t>(low);
+      }
+      __syncthreads();
+      if (threadIdx.x < 128u) reinterpret_cast<v4u*>(digits)[(first_block + block) * 128ull + threadIdx.x] = image[threadIdx.x];
+      __syncthreads();
     }
   }
 }
