@@ -295,6 +295,10 @@ k_loglik_search(const double* __restrict__ bins, const uint32_t* __restrict__ us
               listed = 0;
               to_list = round_total <= kLoglikListCells;       // a round denser than the list holds: every thread walks its own blocks' cells
             }
+            // listed: first every set bit's SLOT (in the low half of its list entry), then -- all threads at once, an entry each --
+            // the slots' frequencies in their place: a thread that fetched the frequencies of its own words' bits one after the
+            // other waited out a load per cell (the search 12.4 ms at C5, 11.3 with this)
+            uint32_t* const cell_slot = reinterpret_cast<uint32_t*>(cell_y);
 #pragma unroll
             for (int w = 0; w < kLoglikWordsPerThread; ++w) {
               const uint32_t first = (base + static_cast<uint32_t>(w) * kBlock + threadIdx.x) * kHallBlockLoci;
@@ -303,13 +307,16 @@ k_loglik_search(const double* __restrict__ bins, const uint32_t* __restrict__ us
               while (bits != 0ull) {
                 const int p = __clzll(static_cast<long long>(bits));
                 bits &= ~(0x8000000000000000ull >> p);
-                const double y = cl.ys[first + static_cast<uint32_t>(p)];
-                if (to_list) cell_y[at++] = y;
-                else { exact_cell(y); if ((++walked & 7) == 0) peel(); }
+                if (to_list) cell_slot[2u * at++] = first + static_cast<uint32_t>(p);
+                else { exact_cell(cl.ys[first + static_cast<uint32_t>(p)]); if ((++walked & 7) == 0) peel(); }
               }
               if (!to_list) peel();
             }
-            if (to_list) listed += round_total;
+            if (to_list) {
+              __syncthreads();
+              for (uint32_t i = listed + threadIdx.x; i < listed + round_total; i += kBlock) cell_y[i] = cl.ys[cell_slot[2u * i]];
+              listed += round_total;
+            }
           }
         }
         __syncthreads();                                                                   // the list is complete
