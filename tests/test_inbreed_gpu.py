@@ -840,6 +840,51 @@ def test_class_pass_flavours_agree(kgx, monkeypatch, flavour):
 
 
 @pytest.mark.gpu
+def test_moments_with_seven_classes_of_homozygous_cell(kgx, monkeypatch):
+    """The moments' pipeline with more classes than the synthetic population has (six alts: the major allele and six alt
+    homozygotes, seven bit rows a locus in k_class_bits, seven matrix-core passes): genotypes drawn allele by allele from a
+    Dirichlet-like frequency table with every number of alts from one to six, a tenth of the cells with an allele the table has no
+    frequency for (index 7) or unknown (15).  HallME within 1e-10 and Loglikelihood within 2e-6 of the passes over the bytes, the
+    counts bit for bit; the paths asserted."""
+    G, L, amax = 1300, 11_000, 6
+    rng = np.random.default_rng(23)
+    n_alts = rng.integers(1, amax + 1, L)
+    weights = rng.gamma(0.35, 1.0, (L, amax)) * (np.arange(amax)[None, :] < n_alts[:, None])
+    major = rng.uniform(0.45, 0.97, L)
+    table = weights / weights.sum(axis=1, keepdims=True) * (1.0 - major)[:, None]
+    table = np.where(np.arange(amax)[None, :] < n_alts[:, None], np.maximum(table, 2.0e-5), np.nan)      # (inside the bins: >= 2^-20)
+    cumulative = np.concatenate([major[:, None], major[:, None] + np.cumsum(np.nan_to_num(table), axis=1)], axis=1)
+    cumulative /= cumulative[:, -1:]
+    rows = np.zeros((L, G), dtype=np.uint8)
+    for phase in range(2):
+        draw = rng.random((L, G))
+        allele = (draw[:, :, None] >= cumulative[:, None, :]).sum(axis=2).astype(np.uint8)             # 0 = the major allele
+        odd = rng.random((L, G))
+        allele = np.where(odd < 0.03, 7, np.where(odd < 0.05, 15, allele)).astype(np.uint8)
+        rows |= allele << (4 * phase)
+    m = kgx.GenotypeMatrix(G, L)
+    m.load_rows(rows)
+    for algorithm, moments_path, passes_env, passes_path in (("HallME", "hall moments", "KGX_K7_HALL_PASSES", "hall passes"),
+                                                              ("Loglikelihood", "loglik moments", "KGX_K7_LL_PASSES", "loglik passes")):
+        start = kgx.reference_starts(algorithm, START_SEED, G)
+        got = {k: v.copy() for k, v in _fields(m.inbreed(table, algorithm, phased=True, start=start)).items()}
+        # (Loglikelihood: heterozygous cells of two alts at 2e-5 each have 2 f1 f2 = 8e-10 -- a search that comes within 1/8 of F = 1
+        # meets the floor among them and its genome is handed to the passes)
+        assert kgx.inbreed_last_path() in (moments_path, moments_path + " + passes"), kgx.inbreed_last_path()
+        monkeypatch.setenv(passes_env, "1")
+        want = _fields(m.inbreed(table, algorithm, phased=True, start=start))
+        assert kgx.inbreed_last_path() == passes_path, kgx.inbreed_last_path()
+        monkeypatch.delenv(passes_env)
+        for name in want:
+            if name != "inbred_allele_sum":
+                assert np.array_equal(got[name], want[name]), (algorithm, name)
+        assert int(want["minor_homo_count"].min()) > 0
+        d = np.abs(got["inbred_allele_sum"] - want["inbred_allele_sum"])
+        assert d.max() <= (1e-10 if algorithm == "HallME" else 2e-6), (algorithm, float(d.max()))
+    m.close()
+
+
+@pytest.mark.gpu
 def test_loglikelihood_by_moments_hands_over_what_it_cannot_serve(kgx, monkeypatch):
     """What the statistics cannot give goes to the passes, and comes back with the passes' result: (a) a genome with a
     heterozygous cell whose 2*f1*f2 exceeds 1/2 -- two copies of an allele more frequent than 1/2 on one phase, byte
