@@ -311,10 +311,13 @@ int kgx_locus_class_frequencies(const double* minor_af, uint64_t n_loci, uint32_
  * the FIFTH alone decides the result: kgx_inbreed_reference_starts() makes exactly those draws, so passing its output is
  * the reference's algorithm at no extra pass.  NULL: the midpoints of its start intervals (0.25 / 0.0), a deterministic
  * mode the reference does not have.  HallME runs the reference's 50 expectation steps from the start -- over a selection
- * of more than 8192 loci (up to there the whole iteration is one kernel launch) on per-genome moments of the homozygous cells' allele frequencies (one pass over the genotype
- * bytes per class of homozygous cell, then the 50 steps on those numbers: the step's sum is expanded about the centre of
- * each frequency bin and cut below 1e-12 of a term, measured 6e-16 of F from the 50 passes; KGX_K7_HALL_PASSES=1 or a
- * frequency outside [2^-20, 1] u {0} makes the 50 passes over the bytes instead); Loglikelihood
+ * of more than 8192 loci (up to there the whole iteration is one kernel launch) on per-genome moments of the homozygous
+ * cells' allele frequencies (ONE more pass over the genotype bytes, which leaves the hits of every class of homozygous cell
+ * as rows of bits; the moments from those rows as an exact integer product on the matrix cores; then the 50 steps on those
+ * numbers: the step's sum is expanded about the centre of each frequency bin and cut below 1e-12 of a term, measured 6e-16
+ * of F from the 50 passes; KGX_K7_HALL_PASSES=1 or a frequency outside [2^-20, 1] u {0} makes the 50 passes over the bytes
+ * instead; KGX_K7_CLASS_BYTES=1 / KGX_K7_CLASS_SWEEPS=1: the moments by a pass over the bytes per class, on the matrix cores /
+ * by vector adds -- the checkers of the bit rows); Loglikelihood
  * walks nlopt's 1-D Nelder-Mead from it with the reference's stopping rule (absolute simplex width 1e-6, at most 500
  * evaluations; _calc.cpp:131-144); a pass over the genotype bytes serves two evaluations (a simplex' reflection and
  * inside contraction) of every genome still searching.  Ignored by Simple and RitlandLocus. */
