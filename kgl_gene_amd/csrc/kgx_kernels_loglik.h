@@ -269,17 +269,35 @@ k_loglik_search(const double* __restrict__ bins, const uint32_t* __restrict__ us
         // sparse: rounds of 1024 blocks; a round's set bits are dealt list positions by a scan, their frequencies gathered there
         uint32_t listed = 0;
         kept_hi = 0u;                                                                      // (the list is being rewritten)
+        // A class's rounds list SLOTS (in the low half of the list's entries); the slots' frequencies take their place -- all threads at
+        // once, an entry each -- when the class is through or the list is full: one wait for the frequencies a class, not one a round
+        // (and none per cell: a thread that fetched the frequencies of its own words' bits one after the other waited out a load each).
+        // The next round's words are under way while this round's bits are counted and listed.
+        uint32_t* const cell_slot = reinterpret_cast<uint32_t*>(cell_y);
         for (uint32_t k = 0; k < classes.n && !hand_over; ++k) {
-          const LoglikClass& cl = classes.of[k];
-          const uint32_t b0 = cl.bin_block[from], b1 = cl.bin_block[to];
+          const double* const class_ys = classes.of[k].ys;                                   // (the class's members once, as scalars)
+          const unsigned long long* const class_words = classes.of[k].words;
+          const uint32_t b0 = classes.of[k].bin_block[from], b1 = classes.of[k].bin_block[to];
+          uint32_t converted = listed;                                                     // entries below hold frequencies, [converted, listed) slots
+          auto fetch_frequencies = [&]() {                                                  // (after a barrier: the slots are all written)
+            for (uint32_t i = converted + threadIdx.x; i < listed; i += kBlock) cell_y[i] = class_ys[cell_slot[2u * i]];
+            converted = listed;
+          };
+          auto load_words = [&](uint32_t base, unsigned long long (&word)[kLoglikWordsPerThread]) {
+#pragma unroll
+            for (int w = 0; w < kLoglikWordsPerThread; ++w) {
+              const uint32_t b = base + static_cast<uint32_t>(w) * kBlock + threadIdx.x;
+              word[w] = b < b1 ? class_words[classes.plain_words ? g * classes.word_blocks + b : hall_word_index(b, g, lanes)] : 0ull;
+            }
+          };
+          unsigned long long next_word[kLoglikWordsPerThread];
+          if (b0 < b1) load_words(b0, next_word);
           for (uint32_t base = b0; base < b1; base += kBlock * kLoglikWordsPerThread) {
             unsigned long long word[kLoglikWordsPerThread];
             uint32_t mine = 0;
 #pragma unroll
-            for (int w = 0; w < kLoglikWordsPerThread; ++w) {
-              const uint32_t b = base + static_cast<uint32_t>(w) * kBlock + threadIdx.x;
-              word[w] = b < b1 ? cl.words[classes.plain_words ? g * classes.word_blocks + b : hall_word_index(b, g, lanes)] : 0ull;
-            }
+            for (int w = 0; w < kLoglikWordsPerThread; ++w) word[w] = next_word[w];
+            if (base + kBlock * kLoglikWordsPerThread < b1) load_words(base + kBlock * kLoglikWordsPerThread, next_word);
 #pragma unroll
             for (int w = 0; w < kLoglikWordsPerThread; ++w) mine += static_cast<uint32_t>(__popcll(word[w]));
             uint32_t round_total = 0;
@@ -289,16 +307,15 @@ k_loglik_search(const double* __restrict__ bins, const uint32_t* __restrict__ us
               // the list is full (a band gathered a listful at a time, nothing kept): walk what it holds, start it again
               if (keep) { hand_over = 4u; break; }                                          // (a kept stretch fits by the moments' own count)
               __syncthreads();
+              fetch_frequencies();
+              __syncthreads();
               walk_listed(listed);
               __syncthreads();
               at -= listed;
               listed = 0;
+              converted = 0;
               to_list = round_total <= kLoglikListCells;       // a round denser than the list holds: every thread walks its own blocks' cells
             }
-            // listed: first every set bit's SLOT (in the low half of its list entry), then -- all threads at once, an entry each --
-            // the slots' frequencies in their place: a thread that fetched the frequencies of its own words' bits one after the
-            // other waited out a load per cell (the search 12.4 ms at C5, 11.3 with this)
-            uint32_t* const cell_slot = reinterpret_cast<uint32_t*>(cell_y);
 #pragma unroll
             for (int w = 0; w < kLoglikWordsPerThread; ++w) {
               const uint32_t first = (base + static_cast<uint32_t>(w) * kBlock + threadIdx.x) * kHallBlockLoci;
@@ -308,16 +325,14 @@ k_loglik_search(const double* __restrict__ bins, const uint32_t* __restrict__ us
                 const int p = __clzll(static_cast<long long>(bits));
                 bits &= ~(0x8000000000000000ull >> p);
                 if (to_list) cell_slot[2u * at++] = first + static_cast<uint32_t>(p);
-                else { exact_cell(cl.ys[first + static_cast<uint32_t>(p)]); if ((++walked & 7) == 0) peel(); }
+                else { exact_cell(class_ys[first + static_cast<uint32_t>(p)]); if ((++walked & 7) == 0) peel(); }
               }
               if (!to_list) peel();
             }
-            if (to_list) {
-              __syncthreads();
-              for (uint32_t i = listed + threadIdx.x; i < listed + round_total; i += kBlock) cell_y[i] = cl.ys[cell_slot[2u * i]];
-              listed += round_total;
-            }
+            if (to_list) listed += round_total;
           }
+          __syncthreads();                                                                 // the class's slots are listed
+          fetch_frequencies();
         }
         __syncthreads();                                                                   // the list is complete
         if (stats && threadIdx.x == 0) atomicAdd(stats + 6, static_cast<unsigned long long>(listed));
