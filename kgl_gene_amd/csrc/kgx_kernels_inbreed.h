@@ -331,6 +331,9 @@ constexpr uint32_t kOddBigHet = 1u << 28;         // entries of mode 5 only: a h
 // u <= 2 (term 0, marked like a cell without Ritland term: it comes off the genome's sixth counter); one with w > 1/2 (two
 // copies of an allele more frequent than 1/2 counted as heterozygous: a repeated record, an unphased homozygote) can meet the
 // UPPER bound: term 0, and 2^32 onto the sixth counter -- such a genome takes the passes.
+// Mode 6: the same marks without the terms, as 8-byte entries for the cheaper <4> pass: sum(log w) does not depend on F, so a SEARCH
+// for the maximum does without it (the objective it climbs is the reference's minus that constant); kgx_inbreed_objective, which
+// reports the value, takes mode 5.
 constexpr double kLoglikTinyHet = 5e-11;
 // Slot of one byte value (the walk computes four at once: slots_of in the kernel).
 template <bool FOLD>
@@ -357,7 +360,8 @@ k_eval_entries(const double* __restrict__ table, const uint8_t* __restrict__ val
        idx += static_cast<uint64_t>(gridDim.x) * blockDim.x) {
     const uint64_t s = idx >> (2u * bits);
     const uint32_t a1 = static_cast<uint32_t>(idx) & mask, a2 = (static_cast<uint32_t>(idx) >> bits) & mask;
-    constexpr bool kPacked = MODE == 3 || MODE == 4 || MODE == 5;      // the frequency sweeps' entries: packed class counters
+    constexpr bool kPacked = MODE == 3 || MODE == 4 || MODE == 5 || MODE == 6;      // the frequency sweeps' entries: packed class counters
+    constexpr bool kHetMarks = MODE == 5 || MODE == 6;         // MODE 6: mode 5's packed words alone (8-byte entries for the <4> pass), no term
     double y = kPacked ? 0.0 : 1.0, d = 0.0;
     const uint8_t flag = valid[s];
     if (a1 > amax || a2 > amax) {
@@ -373,13 +377,13 @@ k_eval_entries(const double* __restrict__ table, const uint8_t* __restrict__ val
         // odd: the cell's share of the class-frequency sums is not the segment default's
         if (flag & kLocusDefault) { if (cls == kClassNone && (a1 | a2) != 0u) lo |= kOddMinus; }
         else if (cls != kClassNone) lo |= kOddPlus;
-        if constexpr (MODE == 5) {
+        if constexpr (kHetMarks) {
           if (cls == kMajorHet || cls == kMinorHet) {                  // (see kLoglikTinyHet)
             const double w = 2.0 * f1 * f2;
             if (w < kLoglikTinyHet) lo |= kOddNoRitland;
             else if (w > 0.5) lo |= kOddBigHet;
             else {
-              y = log(w);
+              if constexpr (MODE == 5) y = log(w);
               smallest = w < smallest ? w : smallest;
             }
           }
@@ -398,7 +402,7 @@ k_eval_entries(const double* __restrict__ table, const uint8_t* __restrict__ val
         if constexpr (MODE == 2) { y = 2.0 * f1 * f2; d = -y; }
       }
     }
-    if constexpr (MODE == 4) {
+    if constexpr (MODE == 4 || MODE == 6) {
       static_cast<uint64_t*>(entries_out)[idx] = __builtin_bit_cast(uint64_t, d);      // the packed words alone
     } else if constexpr (MODE == 1) {
       static_cast<double*>(entries_out)[idx] = y;                                     // d = 1 - y for every entry: y alone
@@ -408,7 +412,7 @@ k_eval_entries(const double* __restrict__ table, const uint8_t* __restrict__ val
       entries[idx].d = d;
     }
   }
-  if constexpr (MODE == 5) {
+  if constexpr (MODE == 5 || MODE == 6) {
     // one atomic per wave (all threads of the launch on one word took 14 ms at 5 M loci); positive doubles order as their bits
     for (int off = 32; off > 0; off >>= 1) { const double other = __shfl_xor(smallest, off); smallest = other < smallest ? other : smallest; }
     if (smallest_het && (threadIdx.x & (kWave - 1)) == 0 && smallest < 1.0)
