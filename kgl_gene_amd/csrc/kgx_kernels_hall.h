@@ -879,16 +879,12 @@ k_hall_used_bins(const uint32_t* __restrict__ bin_used, uint32_t* __restrict__ u
 // processHallME's 50 steps (_calc.cpp:255-285) on the moments: a workgroup per genome, thread t holds the bins used[t],
 // used[t + 256], ... in registers; a step is one division and a Horner chain per bin and a block sum whose bits are the
 // same in every thread (row_sum16 + a fixed tree out of LDS).  F <= 0 stays 0 as in k_hall_update.
-__global__ void __launch_bounds__(kBlock)
-k_hall_iterate(const double* __restrict__ bins, const uint32_t* __restrict__ used, const uint32_t* __restrict__ n_used_ptr,
-               const unsigned long long* __restrict__ counts, uint64_t n_genomes, const double* __restrict__ start, double* __restrict__ f_out) {
-  __shared__ double row_part[2][16];
-  const uint64_t g = blockIdx.x;
-  if (g >= n_genomes) return;
-  const uint32_t n_used = *n_used_ptr;
-  double centre[kHallBinsPerThread], m[kHallBinsPerThread][kHallMoments];
+template <int BINS>                                       // a thread's bins: the call's used bins over the workgroup's threads, rounded up
+__device__ __forceinline__ double hall_iterate_genome(const double* __restrict__ bins, const uint32_t* __restrict__ used, uint32_t n_used,
+                                                      uint64_t n_genomes, uint64_t g, double total, double F, double (&row_part)[2][16]) {
+  double centre[BINS], m[BINS][kHallMoments];
 #pragma unroll
-  for (int i = 0; i < kHallBinsPerThread; ++i) {
+  for (int i = 0; i < BINS; ++i) {
     const uint32_t at = threadIdx.x + static_cast<uint32_t>(i) * kBlock;
     centre[i] = 1.0;
 #pragma unroll
@@ -910,15 +906,13 @@ k_hall_iterate(const double* __restrict__ bins, const uint32_t* __restrict__ use
     for (int i = 0; i < 8; ++i) pair[i] = p[2 * i] + p[2 * i + 1];
     return ((pair[0] + pair[1]) + (pair[2] + pair[3])) + ((pair[4] + pair[5]) + (pair[6] + pair[7]));
   };
-  const double total = static_cast<double>(counts[g * 6 + 4]);
-  double F = start[g];
   for (int it = 0; it < 50; ++it) {
     const bool positive = F > 0.0;
     const double Fs = positive ? F : 1.0;                                   // (F <= 0: every term F / den is 0; walked with F = 1, then zeroed)
     const double u = 1.0 - Fs;
     double sum = 0.0;
 #pragma unroll
-    for (int i = 0; i < kHallBinsPerThread; ++i) {
+    for (int i = 0; i < BINS; ++i) {
       const double q = 1.0 / __builtin_fma(u, centre[i], Fs);
       const double t = -u * q;
       double h = m[i][4];
@@ -931,6 +925,24 @@ k_hall_iterate(const double* __restrict__ bins, const uint32_t* __restrict__ use
     const double S = block_sum(sum, it);
     F = positive ? (F * S) / total : 0.0 / total;
   }
+  return F;
+}
+
+__global__ void __launch_bounds__(kBlock)
+k_hall_iterate(const double* __restrict__ bins, const uint32_t* __restrict__ used, const uint32_t* __restrict__ n_used_ptr,
+               const unsigned long long* __restrict__ counts, uint64_t n_genomes, const double* __restrict__ start, double* __restrict__ f_out) {
+  __shared__ double row_part[2][16];
+  const uint64_t g = blockIdx.x;
+  if (g >= n_genomes) return;
+  const uint32_t n_used = *n_used_ptr;
+  const double total = static_cast<double>(counts[g * 6 + 4]);
+  // (as many bins a thread as the call uses: 943 bins at C5 are four a thread, not the eleven all 2562 would be -- a bin without
+  // cells adds an exact 0 to the thread's sum, so the sums are the same numbers either way as long as the bins keep their threads:
+  // bin `at` goes to thread at % 256 in every variant)
+  double F;
+  if (n_used <= 4u * kBlock) F = hall_iterate_genome<4>(bins, used, n_used, n_genomes, g, total, start[g], row_part);
+  else if (n_used <= 8u * kBlock) F = hall_iterate_genome<8>(bins, used, n_used, n_genomes, g, total, start[g], row_part);
+  else F = hall_iterate_genome<kHallBinsPerThread>(bins, used, n_used, n_genomes, g, total, start[g], row_part);
   if (threadIdx.x == 0) f_out[g] = F;
 }
 
