@@ -30,7 +30,7 @@ constexpr int kHallKeyMantissa = 7;
 constexpr int kHallMinExponent = -20;                    // bins reach down to y = 2^-20; below (and above 1) the call takes the 50 passes
 constexpr uint32_t kHallBins = 1u + static_cast<uint32_t>(-kHallMinExponent) * (1u << kHallKeyMantissa) + 1u;   // {0}, [2^-20, 1), {1 ..}
 constexpr uint32_t kHallNoKey = 0xFFFu;                  // sorts behind every bin (12-bit keys)
-constexpr uint32_t kHallItemLoci = 1024;
+constexpr uint32_t kHallItemLoci = 2048;                 // (an item's digit image: 64 KB of the matrix-core pass's LDS; 1024: more items to merge, 4096: one workgroup a CU)
 constexpr int kHallBinsPerThread = (kHallBins + kBlock - 1) / kBlock;
 static_assert(kHallBins < kHallNoKey, "12-bit sort keys");
 
@@ -212,7 +212,7 @@ k_hall_items(const uint32_t* __restrict__ bin_begin, const uint32_t* __restrict_
 }
 
 // The items' records in blocks: item i's from slot 64 * item_block_base[i] on, the rest of its last block repeating its last
-// record (the pass gives such a slot a byte no cell has).  One workgroup per item (at most 1024 loci: four per thread).
+// record (the pass gives such a slot a byte no cell has).  One workgroup per item (at most kHallItemLoci loci).
 // ys (may be null): every slot's frequency y = centre(bin) + delta (the Loglikelihood walk reads these alone).
 // slot_of_locus (may be null; with sorted_slots, the sort's own output: the selected locus of every position of the bin
 // order): slot_of_locus[s] = the slot of selected locus s in this class's blocks (left as it is -- 0xFFFFFFFF -- where the
@@ -470,7 +470,7 @@ k_class_bits(const uint32_t* __restrict__ gt, uint64_t dwords_per_row, uint64_t 
 //     M[g][j] = sum over the item's slots s of  hit[g][s] * d_s^j ,      hit = 0 / 1,
 // and with d_s^j written in FIXED POINT -- t = d / 2^(e - 7) in [-1/2, 1/2) for a bin of exponent e, V_j = round(t^j * 2^54),
 // V_j in seven balanced base-256 digits (int8) -- it is an EXACT one in integers: v_mfma_i32_16x16x64_i8 sums 64 slots x 16
-// genomes x 16 digit columns per instruction (an item holds at most 1024 slots: |sum| <= 1024 * 128 * 128 = 2^24, no overflow),
+// genomes x 16 digit columns per instruction (an item holds at most 2048 slots: |sum| <= 2048 * 128 * 128 = 2^25, no overflow),
 // and the digit sums go back to doubles once per item.  Quantisation: a term (d / c)^j / j of the series is off by at most
 // 2^-(54 + 7 j) -- far below the double rounding of the adds it replaces; M0 is a count and exact.  What is left for the
 // vector unit is the zero-byte test on a dword (four cells in four instructions) and the 4 x 4 byte transposes that turn "four
