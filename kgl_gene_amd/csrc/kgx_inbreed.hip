@@ -302,15 +302,16 @@ int inbreed_shard(kgx_gt8_shard& sh, uint64_t g0, uint64_t g1, const uint32_t* l
     const uint64_t chunks = ((genomes + per_lane - 1) / per_lane + kBlock - 1) / kBlock;
     return static_cast<uint32_t>(chunks * ((segments + eval_xcds - 1) / eval_xcds) * eval_xcds);
   };
-  auto tabulate = [&](int mode) {
+  auto tabulate = [&](int mode, hipStream_t ts = nullptr) {
+    if (!ts) ts = dev.stream;
     if (!table_passes) return;
     const uint32_t tab_grid = stream_grid(dev, n_sel << (2u * eval_bits(amax)), kBlock);
-    if (mode == 1) hipLaunchKernelGGL((k_eval_entries<1>), dim3(tab_grid), dim3(kBlock), 0, dev.stream, d_table, d_valid, n_sel, amax, phased, d_entries, nullptr);
-    else if (mode == 2) hipLaunchKernelGGL((k_eval_entries<2>), dim3(tab_grid), dim3(kBlock), 0, dev.stream, d_table, d_valid, n_sel, amax, phased, d_entries, nullptr);
-    else if (mode == 3) hipLaunchKernelGGL((k_eval_entries<3>), dim3(tab_grid), dim3(kBlock), 0, dev.stream, d_table, d_valid, n_sel, amax, phased, d_entries, nullptr);
-    else if (mode == 5) hipLaunchKernelGGL((k_eval_entries<5>), dim3(tab_grid), dim3(kBlock), 0, dev.stream, d_table, d_valid, n_sel, amax, phased, d_entries, d_smallest_het);
-    else if (mode == 6) hipLaunchKernelGGL((k_eval_entries<6>), dim3(tab_grid), dim3(kBlock), 0, dev.stream, d_table, d_valid, n_sel, amax, phased, d_entries, d_smallest_het);
-    else hipLaunchKernelGGL((k_eval_entries<4>), dim3(tab_grid), dim3(kBlock), 0, dev.stream, d_table, d_valid, n_sel, amax, phased, d_entries, nullptr);
+    if (mode == 1) hipLaunchKernelGGL((k_eval_entries<1>), dim3(tab_grid), dim3(kBlock), 0, ts, d_table, d_valid, n_sel, amax, phased, d_entries, nullptr);
+    else if (mode == 2) hipLaunchKernelGGL((k_eval_entries<2>), dim3(tab_grid), dim3(kBlock), 0, ts, d_table, d_valid, n_sel, amax, phased, d_entries, nullptr);
+    else if (mode == 3) hipLaunchKernelGGL((k_eval_entries<3>), dim3(tab_grid), dim3(kBlock), 0, ts, d_table, d_valid, n_sel, amax, phased, d_entries, nullptr);
+    else if (mode == 5) hipLaunchKernelGGL((k_eval_entries<5>), dim3(tab_grid), dim3(kBlock), 0, ts, d_table, d_valid, n_sel, amax, phased, d_entries, d_smallest_het);
+    else if (mode == 6) hipLaunchKernelGGL((k_eval_entries<6>), dim3(tab_grid), dim3(kBlock), 0, ts, d_table, d_valid, n_sel, amax, phased, d_entries, d_smallest_het);
+    else hipLaunchKernelGGL((k_eval_entries<4>), dim3(tab_grid), dim3(kBlock), 0, ts, d_table, d_valid, n_sel, amax, phased, d_entries, nullptr);
   };
   bool ll_pair = false;                                       // Loglikelihood passes with two values of F per genome (set by its driver below)
   auto sweep = [&](int mode) {
@@ -463,17 +464,28 @@ int inbreed_shard(kgx_gt8_shard& sh, uint64_t g0, uint64_t g1, const uint32_t* l
     const bool timed = n_sel * n >= (1ull << 24) || env_int("KGX_TIME_SMALL_CALLS", 0);
     if (timed && rc == KGX_OK) try_hip(hipEventRecord(dev.sweep_begin, st), KGX_EHIP, "hipEventRecord");
     if (timed && !table_sweep && rc == KGX_OK) try_hip(hipEventRecord(dev.kernel_begin, st), KGX_EHIP, "hipEventRecord");
+    // (Loglikelihood by moments: the same pass as RitlandLocus', its fp64 term the heterozygous cells' log 2*f1*f2 -- k_eval_entries<5> --
+    // where the VALUE of the objective is asked for: kgx_inbreed_objective.  A search climbs the objective without that sum, a constant
+    // of the genome: the heterozygous cells' marks alone, through the cheaper <4> pass -- 8.4 instead of 11.7 ms at C5)
+    const bool het_terms = loglik_moments && (objective_method == 1 || env_int("KGX_K7_LL_HET_TERMS", 0));
+    const int entries_mode = ritland ? 3 : het_terms ? 5 : loglik_moments ? 6 : 4;
+    // A large call tabulates the pass's entries on the side stream, beside the segment defaults (both need the tables alone: 0.55 and
+    // 0.36 ms at C5, one after the other before)
+    const bool entries_beside = table_sweep && n_sel >= 65536 && rc == KGX_OK;
+    if (table_sweep && loglik_moments) {
+      static const double one = 1.0;                           // the smallest such product of the call, from 1 down
+      try_hip(hipMemcpyAsync(d_smallest_het, &one, sizeof(one), hipMemcpyHostToDevice, st), KGX_EHIP, "H2D(smallest het)");
+    }
+    if (entries_beside) {
+      try_hip(hipEventRecord(dev.side_begin, st), KGX_EHIP, "hipEventRecord");
+      try_hip(hipStreamWaitEvent(dev.side_stream, dev.side_begin, 0), KGX_EHIP, "hipStreamWaitEvent");
+      tabulate(entries_mode, dev.side_stream);
+      try_hip(hipEventRecord(dev.entries_end, dev.side_stream), KGX_EHIP, "hipEventRecord");
+    }
     sweep(0);
     if (table_sweep) {
-      // (Loglikelihood by moments: the same pass as RitlandLocus', its fp64 term the heterozygous cells' log 2*f1*f2 -- k_eval_entries<5>)
-      if (loglik_moments) {
-        static const double one = 1.0;                         // the smallest such product of the call, from 1 down
-        try_hip(hipMemcpyAsync(d_smallest_het, &one, sizeof(one), hipMemcpyHostToDevice, st), KGX_EHIP, "H2D(smallest het)");
-      }
-      // (... where the VALUE of the objective is asked for: kgx_inbreed_objective.  A search climbs the objective without that sum, a
-      // constant of the genome: the heterozygous cells' marks alone, through the cheaper <4> pass -- 8.4 instead of 11.7 ms at C5)
-      const bool het_terms = loglik_moments && (objective_method == 1 || env_int("KGX_K7_LL_HET_TERMS", 0));
-      tabulate(ritland ? 3 : het_terms ? 5 : loglik_moments ? 6 : 4);
+      if (entries_beside) try_hip(hipStreamWaitEvent(st, dev.entries_end, 0), KGX_EHIP, "hipStreamWaitEvent");
+      else tabulate(entries_mode);
       if (timed && rc == KGX_OK) try_hip(hipEventRecord(dev.kernel_begin, st), KGX_EHIP, "hipEventRecord");
       sweep(ritland || het_terms ? 3 : 4);
       if (timed && rc == KGX_OK) try_hip(hipEventRecord(dev.kernel_end, st), KGX_EHIP, "hipEventRecord");

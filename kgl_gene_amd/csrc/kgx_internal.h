@@ -31,6 +31,7 @@ struct Device {
   hipStream_t stream = nullptr;  // the library's stream on this device (non-blocking)
   hipStream_t side_stream = nullptr;   // small per-locus work that runs beside a sweep (the sequential-sum chain)
   hipEvent_t side_begin = nullptr, side_end = nullptr;
+  hipEvent_t entries_end = nullptr;    // a large call's table entries, tabulated on the side stream beside the segment defaults
   char name[128] = {0};
   char arch[64] = {0};
   hipEvent_t sweep_begin = nullptr, sweep_end = nullptr;   // bracket the frequency sweep of the last kgx_inbreed call here

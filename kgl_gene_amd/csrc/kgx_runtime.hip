@@ -226,6 +226,7 @@ Device::~Device() {
   if (by_genome_end) (void)hipEventDestroy(by_genome_end);
   if (side_begin) (void)hipEventDestroy(side_begin);
   if (side_end) (void)hipEventDestroy(side_end);
+  if (entries_end) (void)hipEventDestroy(entries_end);
   if (side_stream) (void)hipStreamDestroy(side_stream);
   if (stream) (void)hipStreamDestroy(stream);
 }
@@ -360,6 +361,7 @@ int kgx_init(int device_count, const int* device_ids) {
       KGX_HIP(hipStreamCreateWithFlags(&dev->side_stream, hipStreamNonBlocking));
       KGX_HIP(hipEventCreateWithFlags(&dev->side_begin, hipEventDisableTiming));
       KGX_HIP(hipEventCreateWithFlags(&dev->side_end, hipEventDisableTiming));
+      KGX_HIP(hipEventCreateWithFlags(&dev->entries_end, hipEventDisableTiming));
       KGX_HIP(hipEventCreate(&dev->sweep_begin));
       KGX_HIP(hipEventCreate(&dev->sweep_end));
       KGX_HIP(hipEventCreate(&dev->kernel_begin));
