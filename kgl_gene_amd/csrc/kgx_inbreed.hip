@@ -197,8 +197,10 @@ int inbreed_shard(kgx_gt8_shard& sh, uint64_t g0, uint64_t g1, const uint32_t* l
       return fail(KGX_EHIP, "kgx_inbreed: radix sort size query failed");
   }
   const uint64_t plan_classes = by_moments_planned ? hall_classes : 0, plan_items = by_moments_planned ? hall_items : 0;
-  const size_t o_hall_keys = plan.add(by_moments_planned ? 4 * n_sel * sizeof(uint32_t) : 0);            // keys, slots, sorted keys, sorted slots
-  const size_t o_hall_records = plan.add(by_moments_planned ? n_sel * sizeof(HallRecord) : 0);            // a class's loci in bin order, as sorted
+  // (two of each: the classes are put in order two at a time, on the call's stream and on the side stream)
+  const size_t hall_keys_bytes = (4 * n_sel * sizeof(uint32_t) + 255) / 256 * 256, hall_records_bytes = (n_sel * sizeof(HallRecord) + 255) / 256 * 256;
+  const size_t o_hall_keys = plan.add(by_moments_planned ? 2 * hall_keys_bytes : 0);                      // keys, slots, sorted keys, sorted slots
+  const size_t o_hall_records = plan.add(by_moments_planned ? 2 * hall_records_bytes : 0);                // a class's loci in bin order, as sorted
   const size_t o_hall_padded = plan.add(plan_classes * (hall_blocks + 1) * kHallBlockLoci * sizeof(HallRecord));   // per class: the same in blocks (+ a block of slack)
   // per class: bin_begin | bin_end | item_base | bin_block (kHallBins + 1 words each); then, for all: bin_used | used; then the counters:
   // per class n_items, n_blocks, n_blocks of the bins a band can reach, 0; for all n_used, unsupported, handed over, 0
@@ -218,7 +220,8 @@ int inbreed_shard(kgx_gt8_shard& sh, uint64_t g0, uint64_t g1, const uint32_t* l
   const uint64_t sel_pitch = (n_sel + 7) / 8 * 8;
   const size_t o_slot_of_locus = plan.add(hall_bits_planned ? plan_classes * sel_pitch * sizeof(uint32_t) : 0);
   const uint64_t bit_row_bytes = hall_bit_row_bytes(n);                        // whole spans of 2048 genomes
-  const size_t o_hall_sort = plan.add(hall_sort_bytes);
+  const size_t hall_sort_stride = (hall_sort_bytes + 255) / 256 * 256;
+  const size_t o_hall_sort = plan.add(2 * hall_sort_stride);
   const size_t o_hall_moments = plan.add(plan_items * kHallMoments * n * sizeof(double));
   const size_t o_hall_bins = plan.add(by_moments_planned ? static_cast<size_t>(kHallBins) * kHallMoments * n * sizeof(double) : 0);
   const size_t o_needs_passes = plan.add(loglik_moments ? n * sizeof(uint32_t) : 0);
@@ -407,15 +410,12 @@ int inbreed_shard(kgx_gt8_shard& sh, uint64_t g0, uint64_t g1, const uint32_t* l
   bool moments_timed = false, search_timed = false;             // (events recorded: read after the call's last synchronisation)
   auto class_words = [&](uint32_t k) { return h_words + k * kHallClassWords; };
   const bool moments_emit = loglik_moments;                       // (Loglikelihood: the hits of the reachable bins leave as bits too)
-  uint32_t* h_keys = reinterpret_cast<uint32_t*>(arena + o_hall_keys);
-  uint32_t *h_slots = h_keys + n_sel, *h_sorted_keys = h_keys + 2 * n_sel, *h_sorted_slots = h_keys + 3 * n_sel;
   double* h_moments = reinterpret_cast<double*>(arena + o_hall_moments);
   const uint32_t hall_chunks = static_cast<uint32_t>(((n + eval_gpl - 1) / eval_gpl + kBlock - 1) / kBlock);
   // (a bin's workgroups: enough of them for the few bins that hold most loci -- the major allele's -- to fill the chip)
   const uint32_t hall_merge_blocks = static_cast<uint32_t>(std::min<uint64_t>(64, (kHallMoments * n + kBlock - 1) / kBlock));
   // the bins an exact walk can reach (kgx_kernels_loglik.h): those starting below kLoglikReach
   const uint32_t block_bins = moments_emit ? hall_key_host(kLoglikReach) + 1u : 0u;
-  HallRecord* const h_records = reinterpret_cast<HallRecord*>(arena + o_hall_records);
   const size_t padded_records = static_cast<size_t>(hall_blocks + 1) * kHallBlockLoci;
   auto padded_of = [&](uint32_t k) { return reinterpret_cast<HallRecord*>(arena + o_hall_padded) + static_cast<uint64_t>(k) * padded_records; };
   auto ys_of = [&](uint32_t k) { return moments_emit ? reinterpret_cast<double*>(arena + o_hall_ys) + static_cast<uint64_t>(k) * padded_records : nullptr; };
@@ -426,7 +426,9 @@ int inbreed_shard(kgx_gt8_shard& sh, uint64_t g0, uint64_t g1, const uint32_t* l
   uint32_t* const slot_of_locus = hall_bits_planned ? reinterpret_cast<uint32_t*>(arena + o_slot_of_locus) : nullptr;
   std::vector<uint32_t> counters;
   char* counters_pinned = nullptr;                                 // (page-locked)
-  // The classes in bin order, on stream `os`; the counters the host needs come back behind it (into counters_pinned).
+  // The classes in bin order; the counters the host needs come back behind them (into counters_pinned).  Two classes at a time: the
+  // even ones on stream `os`, the odd ones on the side stream with scratch of their own -- ~12 small kernels a class that fill a
+  // fraction of the device each (1.9 -> 1.45 ms at C5).
   auto order_classes = [&](hipStream_t os) {
     const bool emit = moments_emit;
     try_hip(hipMemsetAsync(h_words, 0, hall_word_count * sizeof(uint32_t), os), KGX_EHIP, "memset(hall words)");
@@ -434,23 +436,37 @@ int inbreed_shard(kgx_gt8_shard& sh, uint64_t g0, uint64_t g1, const uint32_t* l
     // nothing; the matrix-core pass reads its items' blocks alone.  The bins need no clearing: k_hall_merge)
     if (!hall_mfma) try_hip(hipMemsetAsync(arena + o_hall_padded, 0, hall_classes * padded_records * sizeof(HallRecord), os), KGX_EHIP, "memset(hall blocks)");
     if (slot_of_locus) try_hip(hipMemsetAsync(slot_of_locus, 0xFF, static_cast<size_t>(hall_classes) * sel_pitch * sizeof(uint32_t), os), KGX_EHIP, "memset(slot of locus)");
+    const bool two_lanes = hall_classes > 1 && os != dev.side_stream && !env_int("KGX_K7_ORDER_ONE_LANE", 0);
+    if (two_lanes) {
+      try_hip(hipEventRecord(dev.side_begin, os), KGX_EHIP, "hipEventRecord");              // (the tables, the clearing above)
+      try_hip(hipStreamWaitEvent(dev.side_stream, dev.side_begin, 0), KGX_EHIP, "hipStreamWaitEvent");
+    }
     for (uint32_t k = 0; k < hall_classes && rc == KGX_OK; ++k) {
+      const uint32_t lane_of_class = two_lanes ? (k & 1u) : 0u;
+      hipStream_t ks = lane_of_class ? dev.side_stream : os;
+      uint32_t* h_keys = reinterpret_cast<uint32_t*>(arena + o_hall_keys + lane_of_class * hall_keys_bytes);
+      uint32_t *h_slots = h_keys + n_sel, *h_sorted_keys = h_keys + 2 * n_sel, *h_sorted_slots = h_keys + 3 * n_sel;
+      HallRecord* const h_records = reinterpret_cast<HallRecord*>(arena + o_hall_records + lane_of_class * hall_records_bytes);
       uint32_t *bin_begin = class_words(k), *bin_end = bin_begin + (kHallBins + 1), *item_base = bin_begin + 2 * (kHallBins + 1);
-      hipLaunchKernelGGL(k_hall_keys, dim3(stream_grid(dev, n_sel, kBlock)), dim3(kBlock), 0, os, d_table, d_valid, n_sel, amax, phased, k, h_keys,
+      hipLaunchKernelGGL(k_hall_keys, dim3(stream_grid(dev, n_sel, kBlock)), dim3(kBlock), 0, ks, d_table, d_valid, n_sel, amax, phased, k, h_keys,
                          h_slots, h_totals + 1);
       size_t sort_bytes = hall_sort_bytes;
-      try_hip(hipcub::DeviceRadixSort::SortPairs(arena + o_hall_sort, sort_bytes, h_keys, h_sorted_keys, h_slots, h_sorted_slots,
-                                                 static_cast<int>(n_sel), 0, 12, os), KGX_EHIP, "radix sort");
-      hipLaunchKernelGGL(k_hall_records, dim3(stream_grid(dev, n_sel, kBlock)), dim3(kBlock), 0, os, h_sorted_keys, h_sorted_slots, n_sel, d_table,
+      try_hip(hipcub::DeviceRadixSort::SortPairs(arena + o_hall_sort + lane_of_class * hall_sort_stride, sort_bytes, h_keys, h_sorted_keys, h_slots, h_sorted_slots,
+                                                 static_cast<int>(n_sel), 0, 12, ks), KGX_EHIP, "radix sort");
+      hipLaunchKernelGGL(k_hall_records, dim3(stream_grid(dev, n_sel, kBlock)), dim3(kBlock), 0, ks, h_sorted_keys, h_sorted_slots, n_sel, d_table,
                          amax, k, d_index, h_records, bin_begin, bin_end);
-      hipLaunchKernelGGL(k_hall_items, dim3(1), dim3(kBlock), 0, os, bin_begin, bin_end, item_base, items_of(k), h_counters + 4 * k, block_bins,
+      hipLaunchKernelGGL(k_hall_items, dim3(1), dim3(kBlock), 0, ks, bin_begin, bin_end, item_base, items_of(k), h_counters + 4 * k, block_bins,
                          item_blocks_of(k), h_counters + 4 * k + 1);
-      hipLaunchKernelGGL(k_hall_pad, dim3(static_cast<uint32_t>(std::min<uint64_t>(hall_items, 65535))), dim3(kBlock), 0, os, h_records, items_of(k),
+      hipLaunchKernelGGL(k_hall_pad, dim3(static_cast<uint32_t>(std::min<uint64_t>(hall_items, 65535))), dim3(kBlock), 0, ks, h_records, items_of(k),
                          h_counters + 4 * k, item_blocks_of(k), padded_of(k), ys_of(k), h_sorted_slots, slot_of_locus ? slot_of_locus + k * sel_pitch : nullptr);
-      if (hall_mfma) hipLaunchKernelGGL(k_hall_digits, dim3(static_cast<uint32_t>(std::min<uint64_t>(hall_items, 65535))), dim3(kBlock), 0, os, padded_of(k),
+      if (hall_mfma) hipLaunchKernelGGL(k_hall_digits, dim3(static_cast<uint32_t>(std::min<uint64_t>(hall_items, 65535))), dim3(kBlock), 0, ks, padded_of(k),
                                         items_of(k), h_counters + 4 * k, item_blocks_of(k), digits_of(k), rows_of(k));
-      if (emit) hipLaunchKernelGGL(k_hall_bin_blocks, dim3((kHallBins + kBlock) / kBlock), dim3(kBlock), 0, os, item_base, item_blocks_of(k), item_base + (kHallBins + 1));
+      if (emit) hipLaunchKernelGGL(k_hall_bin_blocks, dim3((kHallBins + kBlock) / kBlock), dim3(kBlock), 0, ks, item_base, item_blocks_of(k), item_base + (kHallBins + 1));
       try_hip(hipGetLastError(), KGX_EHIP, "hall order launch");
+    }
+    if (two_lanes) {
+      try_hip(hipEventRecord(dev.side_end, dev.side_stream), KGX_EHIP, "hipEventRecord");
+      try_hip(hipStreamWaitEvent(os, dev.side_end, 0), KGX_EHIP, "hipStreamWaitEvent");
     }
     if (rc == KGX_OK && pinned_reserve(dev, 1, (hall_classes + 1) * 4 * sizeof(uint32_t), &counters_pinned) != KGX_OK) rc = KGX_ENOMEM;
     if (rc == KGX_OK)
