@@ -627,7 +627,7 @@ int inbreed_shard(kgx_gt8_shard& sh, uint64_t g0, uint64_t g1, const uint32_t* l
         } else if (eval_gpl == 8) { if (emit) KGX_HALL_SWEEP(8, true); else KGX_HALL_SWEEP(8, false); }
         else KGX_HALL_SWEEP(4, false);                                          // (the hits' words are a lane of eight genomes': loglik_candidate)
 #undef KGX_HALL_SWEEP
-        hipLaunchKernelGGL(k_hall_merge, dim3(hall_merge_blocks, kHallBins), dim3(kBlock), 0, st, h_moments, item_base, n, h_bins, h_bin_used, k + 1u);
+        hipLaunchKernelGGL(k_hall_merge, dim3(hall_merge_blocks, 256), dim3(kBlock), 0, st, h_moments, item_base, n, h_bins, h_bin_used, k + 1u);
         try_hip(hipGetLastError(), KGX_EHIP, "hall moments launch");
       }
       loglik_classes.n = emit ? hall_classes : 0u;
